@@ -1,0 +1,117 @@
+"""ctypes binding of libhipensemble.so (include/hipensemble.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible when a context is created, the product path raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._build import LIB_PATH
+
+HENS_OK = 0
+ERR_INVALID, ERR_HIP, ERR_STATE, ERR_TOO_FEW_WALKERS, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+LIKE_GAUSS_DENSE, LIKE_GAUSS_DIAG, LIKE_ROSENBROCK = 0, 1, 2
+
+
+class HensConfig(C.Structure):
+    _fields_ = [
+        ("ntemps", C.c_int32), ("nwalkers", C.c_int32), ("ndim", C.c_int32),
+        ("rung_begin", C.c_int32), ("rung_end", C.c_int32), ("device_id", C.c_int32),
+        ("likelihood_kind", C.c_int32), ("tempered", C.c_int32), ("live_dangerously", C.c_int32),
+        ("adaptive", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("stop_adaptation", C.c_int64), ("a", C.c_double), ("fill_value", C.c_double),
+        ("adaptation_lag", C.c_double), ("adaptation_time", C.c_double), ("seed", C.c_uint64),
+    ]
+
+
+class HensTiming(C.Structure):
+    _fields_ = [
+        ("total_ms", C.c_double), ("stretch_ms", C.c_double), ("pt_ms", C.c_double), ("plan_ms", C.c_double),
+        ("n_stretch", C.c_int64), ("n_pt", C.c_int64), ("n_plan", C.c_int64), ("n_iters", C.c_int64),
+    ]
+
+
+class HensDeviceBuffers(C.Structure):
+    _fields_ = [
+        ("logl", C.c_void_p), ("logp", C.c_void_p), ("gather_logl", C.c_void_p), ("gather_logp", C.c_void_p),
+        ("send_rows", C.c_void_p), ("recv_rows", C.c_void_p), ("row_capacity", C.c_int64), ("stream", C.c_void_p),
+    ]
+
+
+_P = C.c_void_p
+# every symbol include/hipensemble.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "hens_create": (C.c_int, [C.POINTER(HensConfig), C.POINTER(_P)]),
+    "hens_destroy": (None, [_P]),
+    "hens_last_error": (C.c_char_p, [_P]),
+    "hens_synchronize": (C.c_int, [_P]),
+    "hens_set_prior_box": (C.c_int, [_P, _P, _P, C.c_double]),
+    "hens_set_gaussian": (C.c_int, [_P, _P, _P]),
+    "hens_set_rosenbrock": (C.c_int, [_P, C.c_double, C.c_double]),
+    "hens_upload_state": (C.c_int, [_P, _P, _P, _P, _P]),
+    "hens_download_state": (C.c_int, [_P, _P, _P, _P, _P]),
+    "hens_eval_state": (C.c_int, [_P]),
+    "hens_stretch_split": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "hens_pt_sweep": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
+    "hens_step": (C.c_int, [_P, C.c_int64]),
+    "hens_get_counters": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "hens_reset_counters": (C.c_int, [_P]),
+    "hens_set_adapt_time": (C.c_int, [_P, C.c_int64]),
+    "hens_set_profiling": (C.c_int, [_P, C.c_int32]),
+    "hens_get_timing": (C.c_int, [_P, C.POINTER(HensTiming)]),
+    "hens_get_device_buffers": (C.c_int, [_P, C.POINTER(HensDeviceBuffers)]),
+    "hens_set_stream": (C.c_int, [_P, _P]),
+    "hens_pt_plan_sharded": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
+    "hens_pt_finish_sharded": (C.c_int, [_P]),
+    "hens_version": (C.c_char_p, []),
+    "hens_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+class HipExtensionMissing(ImportError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed to load and resolve symbols)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python -m eryn_amd._build` "
+            "(hipcc --offload-arch=gfx950); eryn_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+_EXC = {ERR_INVALID: ValueError, ERR_HIP: RuntimeError, ERR_STATE: RuntimeError,
+        ERR_TOO_FEW_WALKERS: RuntimeError, ERR_NONFINITE: ValueError, ERR_UNSUPPORTED: NotImplementedError}
+
+
+def check(code, ctx=None):
+    """Map a C status to the exception type the reference raises for the same condition."""
+    if code == HENS_OK:
+        return
+    msg = load().hens_last_error(ctx)
+    raise _EXC.get(code, RuntimeError)(msg.decode() if msg else f"hens error {code}")

@@ -1,0 +1,792 @@
+// hens.hip - host side of libhipensemble.so: context, memory, launches, C ABI.
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include "../../include/hipensemble.h"
+#include "hens_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hens;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct hens_ctx_impl {
+    hens_config cfg{};
+    int T = 0, W = 0, D = 0, Tl = 0, N0 = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // state
+    double* pool = nullptr;          // [2*Tl*W][D]
+    int32_t* loc[2] = {nullptr, nullptr};
+    double* L[2] = {nullptr, nullptr};
+    double* P[2] = {nullptr, nullptr};
+    int cur = 0;                     // which of the double-buffered L/P/loc is current
+    int parity = 0;                  // home half the NEXT iteration writes into
+    double* betas = nullptr;         // [T]
+    uint32_t* accepted = nullptr;    // [Tl*W]
+    int64_t num_proposals = 0;
+    unsigned* flags = nullptr;
+    uint64_t* clock = nullptr;
+    int64_t* adapt_time = nullptr;
+    uint32_t* swap_cnt = nullptr;
+    double* swaps_last = nullptr;
+    double* swaps_total = nullptr;
+    unsigned* ticket = nullptr;
+
+    // model
+    double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr;
+    double logp_in = 0.0, rosen_a = 1.0, rosen_b = 100.0;
+    bool have_prior = false, have_like = false, have_state = false, have_logs = false;
+
+    // parity staging
+    int32_t* order = nullptr;        // [NB][Tl][W] (slot 0 used by parity mode)
+    int64_t* d_rint = nullptr; double* d_uzz = nullptr; double* d_uacc = nullptr; uint8_t* d_keep = nullptr;
+    int64_t* d_iperm = nullptr; int64_t* d_i1perm = nullptr; double* d_uswap = nullptr;
+    int32_t* d_inv = nullptr; int32_t* colslot = nullptr; int32_t* colk = nullptr; double* colu = nullptr;
+    uint8_t* selcol = nullptr; uint8_t* selk = nullptr;
+    double* xtmp = nullptr;          // [Tl*W][D] download staging
+    int expect_split = 0;
+    std::vector<uint8_t> labels_host;
+
+    // philox plan batches
+    int NB = 0;
+    int NP2 = 1, idx_bits = 0;
+
+    // sharded exchange
+    double* gather_L = nullptr; double* gather_P = nullptr;
+    double* send_rows = nullptr; double* recv_rows = nullptr;
+    int32_t* srcglob = nullptr; int32_t* send_slots = nullptr; int32_t* recv_slots = nullptr;
+    int64_t* d_counts = nullptr;     // [2*MAXR]
+    int64_t row_capacity = 0;
+    int64_t n_send = 0, n_recv = 0;
+    bool pt_pending = false;
+
+    // timing
+    bool per_kernel_events = false;
+    hens_timing timing{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evpool;
+};
+
+#define CTX(c) reinterpret_cast<hens_ctx_impl*>(c)
+
+int fail(hens_ctx_impl* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(c, HENS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+template <typename Tp>
+int dalloc(hens_ctx_impl* c, Tp** p, size_t n) {
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(Tp)));
+    return HENS_OK;
+}
+
+int grid_for(int64_t n, int block = 256) {
+    int64_t g = (n + block - 1) / block;
+    return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 2048);
+}
+
+// ---- kernel dispatch ---------------------------------------------------------------------------
+size_t stretch_lds_bytes(int D, int NW, int* RS_out) {
+    const int RS = (D % 2 == 0) ? D + 2 : D;
+    *RS_out = RS;
+    return (size_t)TILE * RS * 8 + (size_t)TILE * 8 + (size_t)NW * TILE * 8 + 4 * (size_t)TILE * 4;
+}
+
+template <int LIKE, int MODE>
+int launch_stretch_like(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
+    const dim3 grid(ntiles, c->Tl);
+    int RS;
+    hipError_t e;
+#define LAUNCH(DT, NW)                                                                             \
+    do {                                                                                           \
+        size_t lds = stretch_lds_bytes(c->D, NW, &RS);                                             \
+        StretchArgs b = a;                                                                         \
+        b.RS = RS;                                                                                 \
+        hipLaunchKernelGGL((k_stretch<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), lds, c->stream, b); \
+    } while (0)
+    if (LIKE == LIKE_ROSEN) {
+        LAUNCH(0, 4);
+    } else if (c->D == 32) {
+        LAUNCH(32, 4);
+    } else if (c->D == 64) {
+        LAUNCH(64, 8);
+    } else if (c->D == 16) {
+        LAUNCH(16, 4);
+    } else if (c->D == 8) {
+        LAUNCH(8, 4);
+    } else {
+        LAUNCH(0, 4);
+    }
+#undef LAUNCH
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
+    return HENS_OK;
+}
+
+template <int MODE>
+int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
+    switch (c->cfg.likelihood_kind) {
+        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, MODE>(c, a, ntiles);
+        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, MODE>(c, a, ntiles);
+        case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, MODE>(c, a, ntiles);
+    }
+    return fail(c, HENS_ERR_INVALID, "unknown likelihood kind %d", c->cfg.likelihood_kind);
+}
+
+StretchArgs base_args(hens_ctx_impl* c) {
+    StretchArgs a{};
+    a.pool = c->pool;
+    a.loc = c->loc[c->cur];
+    a.L = c->L[c->cur];
+    a.P = c->P[c->cur];
+    a.betas = c->cfg.tempered ? c->betas : nullptr;
+    a.order = c->order;
+    a.accepted = c->accepted;
+    a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec;
+    a.clock = c->clock;
+    a.flags = c->flags;
+    a.a = c->cfg.a;
+    a.logp_in = c->logp_in;
+    a.fill = c->cfg.fill_value;
+    a.rosen_a = c->rosen_a; a.rosen_b = c->rosen_b;
+    a.seed = c->cfg.seed;
+    a.Tl = c->Tl; a.W = c->W; a.D = c->D;
+    a.N0 = c->N0;
+    a.rung_begin = c->cfg.rung_begin;
+    a.tempered = c->cfg.tempered;
+    return a;
+}
+
+int check_flags(hens_ctx_impl* c, bool nan_logl_is_error) {
+    unsigned f = 0;
+    HIPCHK(c, hipMemcpyAsync(&f, c->flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (f) {
+        HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(unsigned), c->stream));
+        if (f & FLAG_NONFINITE_X)
+            return fail(c, HENS_ERR_NONFINITE, "At least one parameter value was infinite or NaN");
+        if ((f & FLAG_NAN_LOGL) && nan_logl_is_error)
+            return fail(c, HENS_ERR_NONFINITE, "The likelihood function is returning Nan.");
+    }
+    return HENS_OK;
+}
+
+int ready(hens_ctx_impl* c, bool need_logs) {
+    if (!c) return fail(nullptr, HENS_ERR_INVALID, "null context");
+    if (!c->have_prior) return fail(c, HENS_ERR_STATE, "prior box not set (hens_set_prior_box)");
+    if (!c->have_like) return fail(c, HENS_ERR_STATE, "likelihood constants not set");
+    if (!c->have_state) return fail(c, HENS_ERR_STATE, "no state uploaded (hens_upload_state)");
+    if (need_logs && !c->have_logs)
+        return fail(c, HENS_ERR_STATE, "log_like/log_prior not available (upload them or call hens_eval_state)");
+    return HENS_OK;
+}
+
+int ensure_pt_buffers(hens_ctx_impl* c) {
+    const size_t TW = (size_t)c->T * c->W, PW = (size_t)std::max(c->T - 1, 1) * c->W;
+    if (c->d_iperm) return HENS_OK;
+    int r;
+    if ((r = dalloc(c, &c->d_iperm, PW))) return r;
+    if ((r = dalloc(c, &c->d_i1perm, PW))) return r;
+    if ((r = dalloc(c, &c->d_uswap, PW))) return r;
+    if ((r = dalloc(c, &c->d_inv, PW))) return r;
+    if ((r = dalloc(c, &c->colk, PW))) return r;
+    if ((r = dalloc(c, &c->colu, PW))) return r;
+    if ((r = dalloc(c, &c->selcol, PW))) return r;
+    if ((r = dalloc(c, &c->selk, PW))) return r;
+    (void)TW;
+    return HENS_OK;
+}
+
+size_t pt_lds_bytes(int T) { return (size_t)T * PT_COLS * (8 + 8 + 2 + 1); }
+
+PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
+    PtArgs p{};
+    p.Lfull = sharded ? c->gather_L : c->L[c->cur];
+    p.L = c->L[c->cur]; p.P = c->P[c->cur]; p.loc = c->loc[c->cur];
+    p.Lnew = c->L[c->cur ^ 1]; p.Pnew = c->P[c->cur ^ 1]; p.locnew = c->loc[c->cur ^ 1];
+    p.betas = c->betas;
+    p.colslot = colslot;
+    p.swap_cnt = c->swap_cnt; p.swaps_last = c->swaps_last; p.swaps_total = c->swaps_total;
+    p.ticket = c->ticket; p.clock = c->clock; p.adapt_time = c->adapt_time;
+    p.seed = c->cfg.seed;
+    p.lag = c->cfg.adaptation_lag; p.nu = c->cfg.adaptation_time;
+    p.stop_adaptation = c->cfg.stop_adaptation;
+    p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin;
+    p.sharded = sharded ? 1 : 0;
+    p.srcglob = sharded ? c->srcglob : nullptr;
+    return p;
+}
+
+hipEvent_t new_event(hens_ctx_impl* c) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->evpool.push_back(e);
+    return e;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* hens_version(void) { return "hipensemble 0.1 (gfx950)"; }
+
+int hens_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* hens_last_error(const hens_ctx* ctx) {
+    const hens_ctx_impl* c = reinterpret_cast<const hens_ctx_impl*>(ctx);
+    return c ? c->err.c_str() : g_last_error.c_str();
+}
+
+int hens_create(const hens_config* cfg, hens_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, HENS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->ntemps < 1 || cfg->nwalkers < 2 || cfg->ndim < 1)
+        return fail(nullptr, HENS_ERR_INVALID, "invalid shape ntemps=%d nwalkers=%d ndim=%d", cfg->ntemps,
+                    cfg->nwalkers, cfg->ndim);
+    if (cfg->rung_begin < 0 || cfg->rung_end > cfg->ntemps || cfg->rung_begin >= cfg->rung_end)
+        return fail(nullptr, HENS_ERR_INVALID, "invalid ladder shard [%d, %d) of %d", cfg->rung_begin,
+                    cfg->rung_end, cfg->ntemps);
+    if (cfg->likelihood_kind < 0 || cfg->likelihood_kind > HENS_LIKE_ROSENBROCK)
+        return fail(nullptr, HENS_ERR_INVALID, "unknown likelihood kind %d", cfg->likelihood_kind);
+    if (!(cfg->a > 1.0)) return fail(nullptr, HENS_ERR_INVALID, "stretch scale a must be > 1");
+    if (cfg->ntemps > 1 && !cfg->tempered)
+        return fail(nullptr, HENS_ERR_INVALID, "ntemps > 1 requires tempered = 1");
+    if (cfg->ntemps > 4096) return fail(nullptr, HENS_ERR_UNSUPPORTED, "ntemps > 4096 not supported");
+    if (!cfg->live_dangerously && cfg->nwalkers < 2 * cfg->ndim)   // red_blue.py:108-114
+        return fail(nullptr, HENS_ERR_TOO_FEW_WALKERS,
+                    "It is unadvisable to use a red-blue move with fewer walkers than twice the number of "
+                    "dimensions. If you would like to do this, please set live_dangerously to True.");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, HENS_ERR_HIP, "no HIP device available (libhipensemble needs an MI355X)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(nullptr, HENS_ERR_INVALID, "device_id %d out of range (%d devices)", cfg->device_id, ndev);
+
+    hens_ctx_impl* c = new hens_ctx_impl();
+    c->cfg = *cfg;
+    c->T = cfg->ntemps; c->W = cfg->nwalkers; c->D = cfg->ndim;
+    c->Tl = cfg->rung_end - cfg->rung_begin;
+    c->N0 = (c->W + 1) / 2;
+    hens_ctx* h = reinterpret_cast<hens_ctx*>(c);
+#define TRY(x) do { int r_ = (x); if (r_) { g_last_error = c->err; hens_destroy(h); return r_; } } while (0)
+#define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(c, HENS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); g_last_error = c->err; hens_destroy(h); return HENS_ERR_HIP; } } while (0)
+    TRYHIP(hipSetDevice(cfg->device_id));
+    TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    const size_t TW = (size_t)c->Tl * c->W;
+    TRY(dalloc(c, &c->pool, 2 * TW * c->D));
+    for (int b = 0; b < 2; ++b) {
+        TRY(dalloc(c, &c->loc[b], TW));
+        TRY(dalloc(c, &c->L[b], TW));
+        TRY(dalloc(c, &c->P[b], TW));
+    }
+    TRY(dalloc(c, &c->betas, (size_t)c->T));
+    TRY(dalloc(c, &c->accepted, TW));
+    TRY(dalloc(c, &c->flags, 1));
+    TRY(dalloc(c, &c->clock, 1));
+    TRY(dalloc(c, &c->adapt_time, 1));
+    TRY(dalloc(c, &c->swap_cnt, (size_t)c->T));
+    TRY(dalloc(c, &c->swaps_last, (size_t)c->T));
+    TRY(dalloc(c, &c->swaps_total, (size_t)c->T));
+    TRY(dalloc(c, &c->ticket, 1));
+    TRY(dalloc(c, &c->lo, (size_t)c->D));
+    TRY(dalloc(c, &c->hi, (size_t)c->D));
+    TRY(dalloc(c, &c->mu, (size_t)c->D));
+    TRY(dalloc(c, &c->prec, (size_t)c->D * c->D));
+    TRY(dalloc(c, &c->d_rint, (size_t)c->Tl * c->N0));
+    TRY(dalloc(c, &c->d_uzz, (size_t)c->Tl * c->N0));
+    TRY(dalloc(c, &c->d_uacc, (size_t)c->Tl * c->N0));
+    TRY(dalloc(c, &c->d_keep, (size_t)c->Tl * c->N0));
+    TRY(dalloc(c, &c->xtmp, TW * c->D));
+    // plan batches: keep the per-batch plan under ~64 MiB
+    c->NP2 = 1; c->idx_bits = 0;
+    while (c->NP2 < c->W) { c->NP2 <<= 1; c->idx_bits++; }
+    {
+        const size_t per_iter = (TW + (size_t)c->T * c->W) * 4;
+        size_t nb = (64u << 20) / std::max<size_t>(per_iter, 1);
+        nb = std::max<size_t>(2, std::min<size_t>(nb, 64));
+        nb &= ~(size_t)1;
+        c->NB = (int)nb;
+    }
+    TRY(dalloc(c, &c->order, (size_t)c->NB * TW));
+    TRY(dalloc(c, &c->colslot, (size_t)c->NB * c->T * c->W));
+    TRYHIP(hipMemsetAsync(c->accepted, 0, TW * 4, c->stream));
+    TRYHIP(hipMemsetAsync(c->flags, 0, 4, c->stream));
+    TRYHIP(hipMemsetAsync(c->clock, 0, 8, c->stream));
+    TRYHIP(hipMemsetAsync(c->adapt_time, 0, 8, c->stream));
+    TRYHIP(hipMemsetAsync(c->swap_cnt, 0, (size_t)c->T * 4, c->stream));
+    TRYHIP(hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
+    TRYHIP(hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
+    TRYHIP(hipMemsetAsync(c->ticket, 0, 4, c->stream));
+    TRYHIP(hipEventCreate(&c->ev0));
+    TRYHIP(hipEventCreate(&c->ev1));
+    // kernels that need > 64 KiB of dynamic LDS
+    {
+        const size_t plan_lds = (size_t)c->NP2 * 8;
+        if (plan_lds > 160 * 1024) {
+            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS permutation sort (max 16384... 20480)", c->W);
+            g_last_error = c->err; hens_destroy(h); return HENS_ERR_UNSUPPORTED;
+        }
+        TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds));
+        const size_t ptl = pt_lds_bytes(c->T);
+        if (ptl > 160 * 1024) {
+            fail(c, HENS_ERR_UNSUPPORTED, "ntemps %d exceeds the in-LDS cascade column tile", c->T);
+            g_last_error = c->err; hens_destroy(h); return HENS_ERR_UNSUPPORTED;
+        }
+        TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pt_cascade<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ptl));
+        TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pt_cascade<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ptl));
+    }
+    TRYHIP(hipStreamSynchronize(c->stream));
+#undef TRY
+#undef TRYHIP
+    *out = h;
+    return HENS_OK;
+}
+
+void hens_destroy(hens_ctx* ctx) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device_id);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->pool, c->loc[0], c->loc[1], c->L[0], c->L[1], c->P[0], c->P[1], c->betas, c->accepted,
+                    c->flags, c->clock, c->adapt_time, c->swap_cnt, c->swaps_last, c->swaps_total, c->ticket,
+                    c->lo, c->hi, c->mu, c->prec, c->order, c->d_rint, c->d_uzz, c->d_uacc, c->d_keep,
+                    c->d_iperm, c->d_i1perm, c->d_uswap, c->d_inv, c->colslot, c->colk, c->colu, c->selcol,
+                    c->selk, c->xtmp, c->gather_L, c->gather_P, c->send_rows, c->recv_rows, c->srcglob,
+                    c->send_slots, c->recv_slots, c->d_counts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int hens_synchronize(hens_ctx* ctx) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(nullptr, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
+}
+
+int hens_set_stream(hens_ctx* ctx, void* s) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(nullptr, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    c->own_stream = false;
+    return HENS_OK;
+}
+
+int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double logp_inside) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !lo || !hi) return fail(c, HENS_ERR_INVALID, "null argument");
+    for (int d = 0; d < c->D; ++d)
+        if (!(lo[d] < hi[d])) return fail(c, HENS_ERR_INVALID, "prior box needs lo < hi in every dimension (dim %d)", d);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemcpyAsync(c->lo, lo, c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->hi, hi, c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->logp_in = logp_inside;
+    c->have_prior = true;
+    return HENS_OK;
+}
+
+int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !mu || !prec) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.likelihood_kind != HENS_LIKE_GAUSS_DENSE && c->cfg.likelihood_kind != HENS_LIKE_GAUSS_DIAG)
+        return fail(c, HENS_ERR_STATE, "context was not created with a Gaussian likelihood kind");
+    const size_t n = c->cfg.likelihood_kind == HENS_LIKE_GAUSS_DENSE ? (size_t)c->D * c->D : (size_t)c->D;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemcpyAsync(c->mu, mu, c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->prec, prec, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_like = true;
+    return HENS_OK;
+}
+
+int hens_set_rosenbrock(hens_ctx* ctx, double a, double b) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (c->cfg.likelihood_kind != HENS_LIKE_ROSENBROCK)
+        return fail(c, HENS_ERR_STATE, "context was not created with HENS_LIKE_ROSENBROCK");
+    c->rosen_a = a; c->rosen_b = b;
+    c->have_like = true;
+    return HENS_OK;
+}
+
+int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const double* logp, const double* betas) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !x) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.tempered && !betas) return fail(c, HENS_ERR_INVALID, "betas required for a tempered context");
+    if ((logl == nullptr) != (logp == nullptr)) return fail(c, HENS_ERR_INVALID, "give both logl and logp or neither");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    c->cur = 0;
+    c->parity = 1;            // rows live in home 0, the next iteration writes home 1
+    c->expect_split = 0;
+    c->pt_pending = false;
+    HIPCHK(c, hipMemcpyAsync(c->pool, x, TW * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(TW)), dim3(256), 0, c->stream, c->loc[0], (int64_t)TW);
+    if (logl) {
+        HIPCHK(c, hipMemcpyAsync(c->L[0], logl, TW * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->P[0], logp, TW * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (betas) HIPCHK(c, hipMemcpyAsync(c->betas, betas, (size_t)c->T * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_state = true;
+    c->have_logs = logl != nullptr;
+    return HENS_OK;
+}
+
+int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, double* betas) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (!c->have_state) return fail(c, HENS_ERR_STATE, "no state uploaded");
+    if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight (call hens_pt_finish_sharded)");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    if (x) {
+        hipLaunchKernelGGL(k_gather_rows, dim3(grid_for((int64_t)TW * c->D)), dim3(256), 0, c->stream, c->pool,
+                           c->loc[c->cur], c->xtmp, (int64_t)TW, c->D);
+        HIPCHK(c, hipMemcpyAsync(x, c->xtmp, TW * c->D * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (logl) HIPCHK(c, hipMemcpyAsync(logl, c->L[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
+    if (logp) HIPCHK(c, hipMemcpyAsync(logp, c->P[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
+    if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas, (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
+}
+
+int hens_eval_state(hens_ctx* ctx) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, false);
+    if (r) return r;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    StretchArgs a = base_args(c);
+    a.split = 0;
+    a.home_off = 0;
+    r = launch_stretch<MODE_EVAL>(c, a, (c->W + TILE - 1) / TILE);
+    if (r) return r;
+    r = check_flags(c, true);
+    if (r) return r;
+    c->have_logs = true;
+    return HENS_OK;
+}
+
+int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
+                       const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (!labels || !rint || !u_zz || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (split != 0 && split != 1) return fail(c, HENS_ERR_INVALID, "split must be 0 or 1 (nsplits = 2)");
+    if (split != c->expect_split)
+        return fail(c, HENS_ERR_STATE, "hens_stretch_split calls must alternate split 0, 1 (expected %d)", c->expect_split);
+    if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int Tl = c->Tl, W = c->W;
+    if (split == 0) {
+        // ascending index lists per label (red_blue.py:150-154): order = [label 0 ... | label 1 ...]
+        std::vector<int32_t> order((size_t)Tl * W);
+        int n0_first = -1;
+        for (int t = 0; t < Tl; ++t) {
+            int n0 = 0;
+            for (int w = 0; w < W; ++w) {
+                const uint8_t l = labels[(size_t)t * W + w];
+                if (l > 1) return fail(c, HENS_ERR_INVALID, "labels must be 0 or 1");
+                n0 += (l == 0);
+            }
+            if (n0_first < 0) n0_first = n0;
+            if (n0 != n0_first) return fail(c, HENS_ERR_INVALID, "every rung must have the same number of label-0 walkers");
+            int a0 = 0, a1 = n0;
+            for (int w = 0; w < W; ++w) {
+                if (labels[(size_t)t * W + w] == 0) order[(size_t)t * W + a0++] = w;
+                else order[(size_t)t * W + a1++] = w;
+            }
+        }
+        if (n0_first != (W + 1) / 2)   // arange(W) % 2 shuffled always has ceil(W/2) zeros (red_blue.py:120-124)
+            return fail(c, HENS_ERR_INVALID, "labels must hold ceil(W/2) zeros per rung (got %d)", n0_first);
+        c->N0 = n0_first;
+        c->labels_host.assign(labels, labels + (size_t)Tl * W);
+        HIPCHK(c, hipMemcpyAsync(c->order, order.data(), order.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        if (c->labels_host.size() != (size_t)Tl * W || memcmp(c->labels_host.data(), labels, (size_t)Tl * W) != 0)
+            return fail(c, HENS_ERR_INVALID, "labels differ between split 0 and split 1 of the same iteration");
+    }
+    const int Ns = split == 0 ? c->N0 : W - c->N0;
+    const int Nc = W - Ns;
+    for (size_t i = 0; i < (size_t)Tl * Ns; ++i)
+        if (rint[i] < 0 || rint[i] >= Nc) return fail(c, HENS_ERR_INVALID, "rint out of range [0, %d)", Nc);
+    const size_t n = (size_t)Tl * Ns;
+    HIPCHK(c, hipMemcpyAsync(c->d_rint, rint, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_uzz, u_zz, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
+    StretchArgs a = base_args(c);
+    a.split = split;
+    a.home_off = c->parity * Tl * W;
+    a.rint = c->d_rint; a.u_zz = c->d_uzz; a.u_acc = c->d_uacc;
+    a.keep_out = c->d_keep;
+    r = launch_stretch<MODE_PARITY>(c, a, (Ns + TILE - 1) / TILE);
+    if (r) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->d_keep, n, hipMemcpyDeviceToHost, c->stream));
+    r = check_flags(c, false);
+    if (r) return r;
+    if (split == 1) {
+        c->parity ^= 1;
+        c->num_proposals += 1;
+    }
+    c->expect_split = split ^ 1;
+    return HENS_OK;
+}
+
+int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, const double* u_swap, int32_t adapt,
+                  uint8_t* sel_out, double* swaps_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (!c->cfg.tempered) return fail(c, HENS_ERR_STATE, "context is not tempered");
+    if (c->Tl != c->T) return fail(c, HENS_ERR_STATE, "hens_pt_sweep needs the whole ladder resident; use hens_pt_plan_sharded");
+    if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "PT sweep between split 0 and split 1");
+    if (!iperm || !i1perm || !u_swap) return fail(c, HENS_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int T = c->T, W = c->W;
+    if (T < 2) {
+        return HENS_OK;
+    }
+    r = ensure_pt_buffers(c);
+    if (r) return r;
+    const size_t PW = (size_t)(T - 1) * W;
+    {   // validate permutations on the host (cheap, parity mode only)
+        std::vector<uint8_t> seen(W);
+        for (int j = 0; j < T - 1; ++j)
+            for (const int64_t* p : {iperm + (size_t)j * W, i1perm + (size_t)j * W}) {
+                std::fill(seen.begin(), seen.end(), 0);
+                for (int k = 0; k < W; ++k) {
+                    if (p[k] < 0 || p[k] >= W || seen[p[k]]) return fail(c, HENS_ERR_INVALID, "iperm/i1perm rows must be permutations of range(W)");
+                    seen[p[k]] = 1;
+                }
+            }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_pt_invert, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->d_iperm, c->d_inv, T - 1, W);
+    hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm, c->d_inv,
+                       c->d_uswap, c->colslot, c->colk, c->colu, T, W);
+    PtArgs p = pt_args(c, c->colslot, false);
+    p.colu = c->colu;
+    p.selcol = c->selcol;
+    p.adapt = (adapt && c->cfg.adaptive) ? 1 : 0;
+    p.tick = 0;
+    hipLaunchKernelGGL(k_pt_cascade<false>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS), pt_lds_bytes(T),
+                       c->stream, p);
+    hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk, c->selk,
+                       T - 1, W);
+    HIPCHK(c, hipGetLastError());
+    c->cur ^= 1;
+    if (sel_out) HIPCHK(c, hipMemcpyAsync(sel_out, c->selk, PW, hipMemcpyDeviceToHost, c->stream));
+    if (swaps_out) HIPCHK(c, hipMemcpyAsync(swaps_out, c->swaps_last, (size_t)(T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
+}
+
+int hens_step(hens_ctx* ctx, int64_t n_iters) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (n_iters < 0) return fail(c, HENS_ERR_INVALID, "n_iters < 0");
+    if (c->Tl != c->T) return fail(c, HENS_ERR_STATE, "hens_step needs the whole ladder resident (sharded stepping is driven by eryn_amd.ladder)");
+    if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int T = c->T, Tl = c->Tl, W = c->W;
+    c->N0 = (W + 1) / 2;
+    const bool pt = c->cfg.tempered && T > 1;
+    const int jobs = Tl + (pt ? T : 0);
+    const bool prof = c->per_kernel_events;
+    std::vector<hipEvent_t> evs;
+    auto mark = [&]() {
+        if (!prof) return;
+        hipEvent_t e = new_event(c);
+        (void)hipEventRecord(e, c->stream);
+        evs.push_back(e);
+    };
+    for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
+    c->evpool.clear();
+    c->timing = hens_timing{};
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int64_t done = 0; done < n_iters;) {
+        const int nb = (int)std::min<int64_t>(c->NB, n_iters - done);
+        PlanArgs pa{};
+        pa.order = c->order; pa.colslot = c->colslot; pa.clock = c->clock; pa.seed = c->cfg.seed;
+        pa.Tl = Tl; pa.T = T; pa.W = W; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
+        pa.n_split = Tl; pa.jobs_per_iter = jobs; pa.idx_bits = c->idx_bits;
+        mark();
+        hipLaunchKernelGGL(k_plan, dim3(nb * jobs), dim3(std::min(1024, std::max(64, c->NP2 / 2))), (size_t)c->NP2 * 8,
+                           c->stream, pa);
+        mark();
+        for (int ib = 0; ib < nb; ++ib) {
+            for (int split = 0; split < 2; ++split) {
+                StretchArgs a = base_args(c);
+                a.order = c->order + (size_t)ib * Tl * W;
+                a.split = split;
+                a.home_off = c->parity * Tl * W;
+                const int Ns = split == 0 ? c->N0 : W - c->N0;
+                mark();
+                r = launch_stretch<MODE_PHILOX>(c, a, (Ns + TILE - 1) / TILE);
+                if (r) return r;
+                mark();
+            }
+            c->parity ^= 1;
+            c->num_proposals += 1;
+            if (pt) {
+                PtArgs p = pt_args(c, c->colslot + (size_t)ib * T * W, false);
+                p.adapt = c->cfg.adaptive ? 1 : 0;
+                p.tick = 1;
+                mark();
+                hipLaunchKernelGGL(k_pt_cascade<true>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS),
+                                   pt_lds_bytes(T), c->stream, p);
+                mark();
+                c->cur ^= 1;
+            } else {
+                hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, c->stream, c->clock);
+            }
+        }
+        done += nb;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timing.n_iters = n_iters;
+    if (prof) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // events come in (start, stop) pairs in launch order: per batch [plan] then per iter [s0][s1][pt]
+        size_t e = 0;
+        for (int64_t done = 0; done < n_iters;) {
+            const int nb = (int)std::min<int64_t>(c->NB, n_iters - done);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
+            c->timing.plan_ms += ms; c->timing.n_plan += 1;
+            for (int ib = 0; ib < nb; ++ib) {
+                for (int s = 0; s < 2; ++s) {
+                    (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
+                    c->timing.stretch_ms += ms; c->timing.n_stretch += 1;
+                }
+                if (pt) {
+                    (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
+                    c->timing.pt_ms += ms; c->timing.n_pt += 1;
+                }
+            }
+            done += nb;
+        }
+    }
+    return HENS_OK;
+}
+
+int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals, double* swaps_last, double* swaps_total,
+                      int64_t* adapt_time) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    std::vector<uint32_t> acc;
+    if (accepted) {
+        acc.resize(TW);
+        HIPCHK(c, hipMemcpyAsync(acc.data(), c->accepted, TW * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (swaps_last && c->T > 1) HIPCHK(c, hipMemcpyAsync(swaps_last, c->swaps_last, (size_t)(c->T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (swaps_total && c->T > 1) HIPCHK(c, hipMemcpyAsync(swaps_total, c->swaps_total, (size_t)(c->T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (adapt_time) HIPCHK(c, hipMemcpyAsync(adapt_time, c->adapt_time, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (accepted) for (size_t i = 0; i < TW; ++i) accepted[i] = (double)acc[i];
+    if (num_proposals) *num_proposals = c->num_proposals;
+    return HENS_OK;
+}
+
+int hens_reset_counters(hens_ctx* ctx) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemsetAsync(c->accepted, 0, (size_t)c->Tl * c->W * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->num_proposals = 0;
+    return HENS_OK;
+}
+
+int hens_set_adapt_time(hens_ctx* ctx, int64_t t) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemcpyAsync(c->adapt_time, &t, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
+}
+
+int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    c->per_kernel_events = per_kernel_events != 0;
+    return HENS_OK;
+}
+
+int hens_get_timing(hens_ctx* ctx, hens_timing* out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    if (c->timing.n_iters > 0) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->timing.total_ms = ms;
+    *out = c->timing;
+    return HENS_OK;
+}
+
+int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
+    return fail(c, HENS_ERR_UNSUPPORTED, "sharded ladder buffers not built yet");
+}
+
+int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t*, const int64_t*, const double*, int32_t, const int32_t*, int32_t,
+                         int64_t*, int64_t*, uint8_t*, double*) {
+    return fail(CTX(ctx), HENS_ERR_UNSUPPORTED, "sharded PT not built yet");
+}
+
+int hens_pt_finish_sharded(hens_ctx* ctx) { return fail(CTX(ctx), HENS_ERR_UNSUPPORTED, "sharded PT not built yet"); }
+
+}  // extern "C"

@@ -1,0 +1,717 @@
+// hens_kernels.h - gfx950 (CDNA4, wave64) device code of libhipensemble.
+//
+// Compiled with -ffp-contract=off: every a*b+c below rounds twice like NumPy
+// unless it is written as an explicit fma().  That is what makes the proposal
+// q = c - (c - s) * zz (stretch.py:143-145) and the accept arithmetic
+// (red_blue.py:292) bit-identical to the reference.
+//
+// Data layout in HBM (one context = the ladder shard [rung_begin, rung_end)):
+//   pool   f64 [2 * Tl * W][D]   walker rows, AoS (a row is one contiguous 8*D-byte burst).
+//                                Every walker (tl, w) owns two "home" rows, tl*W+w and
+//                                Tl*W + tl*W+w; iteration parity p writes proposals' results
+//                                into home_p and reads through `loc`, so a stretch step is
+//                                read-own + read-complement + write-own with no in-place hazard
+//                                and the PT cascade never moves a row: it permutes `loc`.
+//   loc    i32 [Tl * W]          pool row currently holding walker (tl, w)
+//   L, P   f64 [Tl * W]          log-likelihood / log-prior (double buffered for the cascade)
+//   betas  f64 [T]               full ladder
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hens {
+
+constexpr int TILE = 64;                 // walkers per workgroup = one wavefront of walker-lanes
+constexpr unsigned FLAG_NONFINITE_X = 1u;   // inf/NaN coordinate seen (ensemble.py:1258-1262)
+constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-281)
+
+enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2 };
+enum { MODE_PARITY = 0, MODE_PHILOX = 1, MODE_EVAL = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: draws are a pure function of
+// (seed, iteration, purpose, walker), so any kernel / any rank regenerates them identically.
+// ---------------------------------------------------------------------------------------------
+struct u4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = u4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // 53-bit uniform in [0, 1)
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
+enum : uint32_t { PURPOSE_STRETCH0 = 0, PURPOSE_STRETCH1 = 1, PURPOSE_STRETCH_ACC = 2,
+                  PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9, PURPOSE_PTU = 10 };
+
+// ---------------------------------------------------------------------------------------------
+// Stretch half-step: propose + box prior + likelihood + tempered MH test + update, fused.
+// ---------------------------------------------------------------------------------------------
+struct StretchArgs {
+    double* pool;
+    int32_t* loc;
+    double* L;
+    double* P;
+    const double* betas;       // [T] or nullptr when not tempered
+    const int32_t* order;      // [Tl][W]: first N0 entries = walkers of split 0, rest = split 1
+    uint32_t* accepted;        // [Tl][W] cumulative accept counts
+    uint8_t* keep_out;         // [Tl][Ns] or nullptr
+    const int64_t* rint;       // parity draws [Tl][Ns]
+    const double* u_zz;
+    const double* u_acc;
+    const double* lo;
+    const double* hi;
+    const double* mu;
+    const double* prec;
+    const uint64_t* clock;     // device iteration counter
+    unsigned* flags;
+    double a, logp_in, fill, rosen_a, rosen_b;
+    uint64_t seed;
+    int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
+};
+
+template <int DT> struct DimOf { static __device__ __forceinline__ int get(int d) { return DT; } };
+template <> struct DimOf<0> { static __device__ __forceinline__ int get(int d) { return d; } };
+
+// One workgroup = TILE (64) walkers of one rung, NW wavefronts.
+//   phase A  lane-per-walker : indices, draws, stretch factor            (wave 0)
+//   phase B  lanes-over-d    : coalesced row gathers, q = c-(c-s)zz, box test by ballot -> LDS
+//   phase C  lane-per-walker : quadratic form, rows of the precision matrix split over the NW
+//                              waves and fed from SGPRs (scalar loads), q held in VGPRs
+//   phase D  lane-per-walker : tempered MH test, L/P/loc/accept counters
+//   phase E  lanes-over-d    : coalesced write of the new row (q if kept, old row otherwise)
+template <int DT, int LIKE, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int D = DimOf<DT>::get(A.D);
+    const int RS = (DT > 0) ? ((DT % 2 == 0) ? DT + 2 : DT) : A.RS;   // LDS row stride (doubles)
+    constexpr int NT = NW * 64;
+    double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
+    double* s_zz = qtile + TILE * RS;                                    // [TILE]
+    double* s_part = s_zz + TILE;                                        // [NW][TILE]
+    int32_t* s_rs = reinterpret_cast<int32_t*>(s_part + NW * TILE);      // [TILE] own row
+    int32_t* s_rc = s_rs + TILE;                                         // [TILE] complement row
+    int32_t* s_dst = s_rc + TILE;                                        // [TILE] destination row
+    int32_t* s_flag = s_dst + TILE;                                      // [TILE] bit0 inbox, bit1 keep, bit2 valid
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = blockIdx.y;
+    const int W = A.W;
+    const int Ns = (MODE == MODE_EVAL) ? W : (A.split == 0 ? A.N0 : W - A.N0);
+    const int Nc = W - Ns;
+    const int s_off = (MODE == MODE_EVAL) ? 0 : (A.split == 0 ? 0 : A.N0);
+    const int c_off = (A.split == 0 ? A.N0 : 0);
+    const int k0 = blockIdx.x * TILE;
+
+    // ---- phase A ---------------------------------------------------------------------------
+    double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0;
+    int own = 0;
+    bool valid = false;
+    if (wv == 0) {
+        const int k = k0 + lane;
+        valid = k < Ns;
+        double zz = 1.0;
+        int rs = 0, rc = 0;
+        if (valid) {
+            if (MODE == MODE_EVAL) {
+                own = k;
+                rs = A.loc[tl * W + own];
+                rc = rs;
+            } else {
+                own = A.order[tl * W + s_off + k];
+                double uz, ua;
+                int r;
+                if (MODE == MODE_PARITY) {
+                    r = (int)A.rint[(size_t)tl * Ns + k];
+                    uz = A.u_zz[(size_t)tl * Ns + k];
+                    ua = A.u_acc[(size_t)tl * Ns + k];
+                } else {
+                    const uint64_t it = A.clock[0];
+                    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32),
+                                 (uint32_t)((A.rung_begin + tl) * W + own), PURPOSE_STRETCH0};
+                    const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                    r = (int)__umulhi(d.x, (uint32_t)Nc);
+                    uz = u01(d.y, d.z);
+                    u4 ctr2 = ctr;
+                    ctr2.w = PURPOSE_STRETCH_ACC;
+                    const u4 e = philox4x32_10(ctr2, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                    ua = u01(e.x, e.y);
+                }
+                const int cw = A.order[tl * W + c_off + r];
+                rs = A.loc[tl * W + own];
+                rc = A.loc[tl * W + cw];
+                zz = (A.a - 1.0) * uz + 1.0;          // stretch.py:129-132
+                zz = zz * zz / A.a;
+                factors = ((double)D - 1.0) * log(zz);   // stretch.py:223
+                lu = log(ua);                            // red_blue.py:294
+                Lold = A.L[tl * W + own];
+                Pold = A.P[tl * W + own];
+            }
+        }
+        s_zz[lane] = zz;
+        s_rs[lane] = rs;
+        s_rc[lane] = rc;
+        s_dst[lane] = A.home_off + tl * W + own;
+        s_flag[lane] = valid ? 4 : 0;
+    }
+    __syncthreads();
+
+    // ---- phase B: lanes over d -------------------------------------------------------------
+    // VEC doubles per lane; LPR lanes per row (power of two <= 64); RPP rows per pass.
+    const int VEC = (D % 2 == 0) ? 2 : 1;
+    const int chunks = D / VEC;
+    int LPR = 1;
+    while (LPR < chunks && LPR < 64) LPR <<= 1;
+    const int RPP = NT / LPR;
+    const int jl = tid & (LPR - 1);
+    const int rsub = tid / LPR;
+    const double* __restrict__ pool_r = A.pool;
+    for (int r0 = 0; r0 < TILE; r0 += RPP) {
+        const int r = r0 + rsub;
+        const bool rvalid = (r < TILE) && (s_flag[r] & 4) != 0;   // RPP may exceed TILE for tiny D
+        bool ok = true, finite = true;
+        if (rvalid) {
+            const double zz = s_zz[r];
+            const double* ps = pool_r + (size_t)s_rs[r] * D;
+            const double* pc = pool_r + (size_t)s_rc[r] * D;
+            for (int ch = jl; ch < chunks; ch += LPR) {
+                const int e = ch * VEC;
+                if (VEC == 2) {
+                    const double2 sv = *reinterpret_cast<const double2*>(ps + e);
+                    double2 qv;
+                    if (MODE == MODE_EVAL) {
+                        qv = sv;
+                    } else {
+                        const double2 cv = *reinterpret_cast<const double2*>(pc + e);
+                        qv.x = cv.x - (cv.x - sv.x) * zz;     // stretch.py:143,145
+                        qv.y = cv.y - (cv.y - sv.y) * zz;
+                    }
+                    const double2 lov = *reinterpret_cast<const double2*>(A.lo + e);
+                    const double2 hiv = *reinterpret_cast<const double2*>(A.hi + e);
+                    ok = ok && (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
+                    finite = finite && (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
+                    *reinterpret_cast<double2*>(qtile + r * RS + e) = qv;
+                } else {
+                    const double sv = ps[e];
+                    double qv;
+                    if (MODE == MODE_EVAL) {
+                        qv = sv;
+                    } else {
+                        const double cv = pc[e];
+                        qv = cv - (cv - sv) * zz;
+                    }
+                    ok = ok && (qv >= A.lo[e]) && (qv <= A.hi[e]);
+                    finite = finite && (fabs(qv) < INFINITY);
+                    qtile[r * RS + e] = qv;
+                }
+            }
+        }
+        // row-wide AND over the LPR lanes of a row via wavefront ballot (prior.py:80-88)
+        const unsigned long long bad = __ballot(!ok);
+        const unsigned long long nonfin = __ballot(!finite);
+        const int gshift = lane & ~(LPR - 1);
+        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << LPR) - 1ull) << gshift);
+        if (jl == 0 && rvalid) {
+            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);
+            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: likelihood, lane per walker, precision rows split over waves ---------------
+    {
+        const bool inbox = (s_flag[lane] & 1) != 0;
+        double part = 0.0;
+        // model constants are read-only for the whole launch: address them through the constant
+        // address space so wave-uniform indices become SGPR scalar loads (s_load_dwordx*)
+        typedef const __attribute__((address_space(4))) double* cptr_t;
+        const cptr_t mu = (cptr_t)(uintptr_t)A.mu;
+        const cptr_t prec = (cptr_t)(uintptr_t)A.prec;
+        const double* qrow = qtile + lane * RS;
+        if (LIKE == LIKE_ROSEN) {
+            if (wv == 0 && inbox) {
+                double acc = 0.0;
+                for (int i = 0; i + 1 < D; ++i) {
+                    const double x0 = qrow[i], x1 = qrow[i + 1];
+                    const double t1 = x1 - x0 * x0, t2 = A.rosen_a - x0;
+                    acc += A.rosen_b * (t1 * t1) + t2 * t2;
+                }
+                part = 2.0 * acc;      // phase D multiplies by -0.5
+            }
+        } else if (DT > 0) {
+            constexpr int DC = (DT > 0) ? DT : 1;
+            constexpr int RB = (DC + NW - 1) / NW;
+            if (inbox) {
+                double qreg[DC];
+#pragma unroll
+                for (int k = 0; k < DC; ++k) qreg[k] = qrow[k] - mu[k];
+                const int i0 = wv * RB;
+                if (LIKE == LIKE_DENSE) {
+#pragma unroll 2
+                    for (int ii = 0; ii < RB; ++ii) {
+                        const int i = i0 + ii;
+                        if (i < DC) {
+                            const cptr_t prow = prec + (size_t)i * DC;
+                            double y0 = 0.0, y1 = 0.0;
+#pragma unroll
+                            for (int k = 0; k + 1 < DC; k += 2) {
+                                y0 = fma(prow[k], qreg[k], y0);
+                                y1 = fma(prow[k + 1], qreg[k + 1], y1);
+                            }
+                            if (DC & 1) y0 = fma(prow[DC - 1], qreg[DC - 1], y0);
+                            part = fma(qrow[i] - mu[i], y0 + y1, part);
+                        }
+                    }
+                } else {
+                    for (int ii = 0; ii < RB; ++ii) {
+                        const int i = i0 + ii;
+                        if (i < DC) {
+                            const double di = qrow[i] - mu[i];
+                            part = fma(di * prec[i], di, part);
+                        }
+                    }
+                }
+            }
+        } else {
+            const int RB = (D + NW - 1) / NW;
+            if (inbox) {
+                const int i0 = wv * RB;
+                for (int ii = 0; ii < RB; ++ii) {
+                    const int i = i0 + ii;
+                    if (i < D) {
+                        const double di = qrow[i] - mu[i];
+                        if (LIKE == LIKE_DENSE) {
+                            double y = 0.0;
+                            for (int k = 0; k < D; ++k) y = fma(prec[(size_t)i * D + k], qrow[k] - mu[k], y);
+                            part = fma(di, y, part);
+                        } else {
+                            part = fma(di * prec[i], di, part);
+                        }
+                    }
+                }
+            }
+        }
+        s_part[wv * TILE + lane] = part;
+    }
+    __syncthreads();
+
+    // ---- phase D: accept / update, lane per walker -------------------------------------------
+    if (wv == 0 && valid) {
+        const bool inbox = (s_flag[lane] & 1) != 0;
+        double acc = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + lane];
+        double logl = inbox ? -0.5 * acc : A.fill;             // ensemble.py:1486-1513
+        if (logl != logl) {                                    // red_blue.py:279-281
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+        const double logp = inbox ? A.logp_in : -INFINITY;     // prior.py:80-88
+        const size_t gi = (size_t)tl * W + own;
+        if (MODE == MODE_EVAL) {
+            A.L[gi] = logl;
+            A.P[gi] = logp;
+        } else {
+            double logP, prevP;
+            if (A.tempered) {                                  // tempering.py:304-306,343-349
+                const double beta = A.betas[A.rung_begin + tl];
+                double lt = logl * beta;
+                if (lt != lt) lt = -INFINITY;
+                logP = lt + logp;
+                double lo_ = Lold * beta;
+                if (lo_ != lo_) lo_ = -INFINITY;
+                prevP = lo_ + Pold;
+            } else {                                           // move.py:443-457
+                logP = logl + logp;
+                prevP = Lold + Pold;
+            }
+            const double lnpdiff = factors + logP - prevP;     // red_blue.py:292
+            const bool keep = lnpdiff > lu;                    // red_blue.py:294
+            if (keep) {                                        // move.py:513-532
+                A.L[gi] = logl;
+                A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
+                A.accepted[gi] += 1u;
+                atomicOr(&s_flag[lane], 2);
+            }
+            A.loc[gi] = s_dst[lane];
+            if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
+        }
+    }
+    if (MODE == MODE_EVAL) return;
+    __syncthreads();
+
+    // ---- phase E: write rows, lanes over d ----------------------------------------------------
+    double* __restrict__ pool_w = A.pool;
+    for (int r0 = 0; r0 < TILE; r0 += RPP) {
+        const int r = r0 + rsub;
+        if (r >= TILE) continue;
+        const int fl = s_flag[r];
+        if (!(fl & 4)) continue;
+        const bool keep = (fl & 2) != 0;
+        double* pd = pool_w + (size_t)s_dst[r] * D;
+        const double* ps = pool_r + (size_t)s_rs[r] * D;
+        for (int ch = jl; ch < chunks; ch += LPR) {
+            const int e = ch * VEC;
+            if (VEC == 2) {
+                const double2 v = keep ? *reinterpret_cast<const double2*>(qtile + r * RS + e)
+                                       : *reinterpret_cast<const double2*>(ps + e);
+                *reinterpret_cast<double2*>(pd + e) = v;
+            } else {
+                pd[e] = keep ? qtile[r * RS + e] : ps[e];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row gather for downloads: dst[tl][w][:] = pool[loc[tl][w]][:]
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
+                              double* __restrict__ dst, int64_t nrows, int D) {
+    const int64_t total = nrows * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int d = (int)(i - r * D);
+        dst[i] = pool[(size_t)loc[r] * D + d];
+    }
+}
+
+__global__ void k_iota(int32_t* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = (int32_t)i;
+}
+
+__global__ void k_tick(uint64_t* clock) { clock[0] += 1; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox plan: random permutations by a bitonic sort of (random key | index) in LDS.
+//   job j < n_split : split order of local rung j   -> order[j][W]
+//   job j >= n_split: PT column permutation of rung (j - n_split) (global, 0..T-2) -> colslot[t][W]
+//   the top rung's column map is the identity (written by job n_split + T - 1 without sorting).
+// Draws depend only on (seed, iteration, purpose, global rung), so every rank of a sharded ladder
+// builds the same PT plan.
+// ---------------------------------------------------------------------------------------------
+struct PlanArgs {
+    int32_t* order;       // [NB][Tl][W]
+    int32_t* colslot;     // [NB][T][W]
+    const uint64_t* clock;
+    uint64_t seed;
+    int32_t Tl, T, W, NP2, rung_begin, n_split, jobs_per_iter, idx_bits;
+};
+
+__global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint64_t* key = reinterpret_cast<uint64_t*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int ib = blockIdx.x / A.jobs_per_iter;          // iteration within the batch
+    const int job = blockIdx.x - ib * A.jobs_per_iter;
+    const uint64_t it = A.clock[0] + (uint64_t)ib;
+    const int W = A.W, NP2 = A.NP2;
+    int32_t* out;
+    uint32_t purpose, rung;
+    if (job < A.n_split) {
+        out = A.order + ((size_t)ib * A.Tl + job) * W;
+        purpose = PURPOSE_SPLIT;
+        rung = (uint32_t)(A.rung_begin + job);
+    } else {
+        const int t = job - A.n_split;
+        out = A.colslot + ((size_t)ib * A.T + t) * W;
+        purpose = PURPOSE_PTPERM;
+        rung = (uint32_t)t;
+        if (t == A.T - 1) {                                // identity for the hottest rung
+            for (int i = tid; i < W; i += blockDim.x) out[i] = i;
+            return;
+        }
+    }
+    const uint64_t mask = (1ull << A.idx_bits) - 1ull;
+    for (int i = tid; i < NP2; i += blockDim.x) {
+        uint64_t kv;
+        if (i < W) {
+            const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * (uint32_t)NP2 + (uint32_t)i, purpose};
+            const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+            kv = ((((uint64_t)d.x << 32) | d.y) & ~mask) | (uint64_t)i;
+            kv &= ~(1ull << 63);                           // keep below the padding keys
+        } else {
+            kv = (1ull << 63) | (uint64_t)i;
+        }
+        key[i] = kv;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = tid; idx < (NP2 >> 1); idx += blockDim.x) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int l = i | j;
+                const bool asc = (i & k) == 0;
+                const uint64_t a = key[i], b = key[l];
+                if ((a > b) == asc) {
+                    key[i] = b;
+                    key[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < W; i += blockDim.x) out[i] = (int32_t)(key[i] & mask);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PT cascade in column form.
+//
+// The reference walks the pairs (i, i-1), i = T-1 .. 1, matching slot iperm_i[k] of rung i with
+// slot i1perm_i[k] of rung i-1 (tempering.py:515-541).  Because every pair uses permutations, the
+// element (i, k) depends on exactly one element of pair i+1 (the one whose cold slot is its hot
+// slot).  The cascade is therefore W independent "columns", each visiting one slot per rung:
+// the walker carried down the column is compared with the resident of the next rung; on a swap
+// the resident moves up one rung and the carried walker keeps falling.  Columns are independent,
+// so the whole T-1 step sequential cascade is one parallel kernel.
+//
+// k_pt_chain builds the column form from the reference's draws (parity mode); in Philox mode the
+// plan kernel draws colslot directly (same distribution: independent uniform matchings).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pt_invert(const int64_t* __restrict__ iperm, int32_t* __restrict__ inv, int npairs, int W) {
+    const int64_t n = (int64_t)npairs * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i / W);
+        inv[(size_t)j * W + iperm[i]] = (int32_t)(i - (int64_t)j * W);
+    }
+}
+
+// thread c follows column c: rows j = 0..T-2 of iperm/i1perm are the pairs i = T-1-j.
+__global__ void k_pt_chain(const int64_t* __restrict__ iperm, const int64_t* __restrict__ i1perm,
+                           const int32_t* __restrict__ inv, const double* __restrict__ u_swap,
+                           int32_t* __restrict__ colslot, int32_t* __restrict__ colk,
+                           double* __restrict__ colu, int T, int W) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    int k = c;
+    for (int j = 0; j < T - 1; ++j) {
+        const int i = T - 1 - j;
+        if (j == 0) colslot[(size_t)i * W + c] = (int32_t)iperm[k];
+        const int b = (int)i1perm[(size_t)j * W + k];
+        colslot[(size_t)(i - 1) * W + c] = b;
+        colk[(size_t)j * W + c] = k;
+        colu[(size_t)j * W + c] = u_swap[(size_t)j * W + k];
+        if (j + 1 < T - 1) k = inv[(size_t)(j + 1) * W + b];
+    }
+}
+
+struct PtArgs {
+    const double* Lfull;        // [T][W] log-likelihood of the full ladder (== L when unsharded)
+    const double* L;            // local current buffers [Tl][W]
+    const double* P;
+    const int32_t* loc;
+    double* Lnew;               // local next buffers
+    double* Pnew;
+    int32_t* locnew;
+    double* betas;              // [T], updated in place by the last block
+    const int32_t* colslot;     // [T][W]
+    const double* colu;         // [T-1][W] uniforms in column order (parity) or nullptr (Philox)
+    uint8_t* selcol;            // [T-1][W] swap decisions in column order, row j <-> pair T-1-j (or nullptr)
+    int32_t* srcglob;           // [Tl][W] global slot id (t*W + w) of the walker arriving at each local slot (sharded) or nullptr
+    uint32_t* swap_cnt;         // [T-1] scratch counters (zero on entry, zeroed again on exit)
+    double* swaps_last;         // [T-1]
+    double* swaps_total;        // [T-1]
+    unsigned* ticket;
+    uint64_t* clock;            // iteration counter, advanced by the last block when tick != 0
+    int64_t* adapt_time;
+    uint64_t seed;
+    double lag, nu;
+    int64_t stop_adaptation;
+    int32_t T, W, Tl, rung_begin, adapt, tick, sharded;
+};
+
+constexpr int PT_COLS = 64;
+constexpr int PT_THREADS = 256;
+
+// LDS: Lc[T][PT_COLS] f64 column log-likelihoods, lu[T-1][PT_COLS] f64 log-uniforms,
+//      src[T][PT_COLS] u8/i16 rung each final slot takes its walker from.
+template <bool PHILOX>
+__global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int T = A.T, W = A.W;
+    double* Lc = reinterpret_cast<double*>(smem_raw);            // [T][PT_COLS]
+    double* lu = Lc + (size_t)T * PT_COLS;                       // [T][PT_COLS] (row j = pair T-1-j)
+    int16_t* src = reinterpret_cast<int16_t*>(lu + (size_t)T * PT_COLS);   // [T][PT_COLS]
+    uint8_t* sel = reinterpret_cast<uint8_t*>(src + (size_t)T * PT_COLS);  // [T][PT_COLS]
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * PT_COLS;
+    const uint64_t it = PHILOX ? A.clock[0] : 0;
+
+    // phase 1: gather the column's log-likelihoods and log-uniforms (all independent loads)
+    for (int e = tid; e < T * PT_COLS; e += PT_THREADS) {
+        const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
+        if (c < W) {
+            const int slot = A.colslot[(size_t)t * W + c];
+            Lc[e] = A.Lfull[(size_t)t * W + slot];
+            if (t < T - 1) {
+                double u;
+                if (PHILOX) {
+                    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(t * W + c), PURPOSE_PTU};
+                    const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                    u = u01(d.x, d.y);
+                } else {
+                    u = A.colu[(size_t)t * W + c];
+                }
+                lu[e] = log(u);                                  // tempering.py:535
+            }
+        }
+    }
+    __syncthreads();
+
+    // phase 2: one lane per column walks hot -> cold
+    if (tid < PT_COLS && c0 + tid < W) {
+        const int cc = tid;
+        double cL = Lc[(size_t)(T - 1) * PT_COLS + cc];
+        int cr = T - 1;                                          // rung the carried walker came from
+        for (int i = T - 1; i >= 1; --i) {
+            const int j = T - 1 - i;
+            const double Lb = Lc[(size_t)(i - 1) * PT_COLS + cc];
+            const double dbeta = A.betas[i - 1] - A.betas[i];    // tempering.py:518-522
+            const double pacc = dbeta * (cL - Lb);               // tempering.py:538
+            const bool s = pacc > lu[(size_t)j * PT_COLS + cc];  // tempering.py:541
+            sel[(size_t)j * PT_COLS + cc] = s ? 1 : 0;
+            if (s) {
+                src[(size_t)i * PT_COLS + cc] = (int16_t)(i - 1);   // resident moves up, carried keeps falling
+            } else {
+                src[(size_t)i * PT_COLS + cc] = (int16_t)cr;        // carried walker settles on rung i
+                cr = i - 1;
+                cL = Lb;
+            }
+        }
+        src[cc] = (int16_t)cr;
+    }
+    __syncthreads();
+
+    // phase 3: scatter the permuted L / P / loc of the resident rungs; count swaps
+    for (int e = tid; e < T * PT_COLS; e += PT_THREADS) {
+        const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
+        if (c >= W) continue;
+        if (t < T - 1 && A.selcol) A.selcol[(size_t)t * W + c] = sel[e];
+        const int tl = t - A.rung_begin;
+        if (tl < 0 || tl >= A.Tl) continue;
+        const int st = src[e];
+        const int dslot = A.colslot[(size_t)t * W + c];
+        const int sslot = A.colslot[(size_t)st * W + c];
+        const size_t di = (size_t)tl * W + dslot;
+        A.Lnew[di] = Lc[(size_t)st * PT_COLS + cc];
+        const int stl = st - A.rung_begin;
+        if (stl >= 0 && stl < A.Tl) {
+            const size_t si = (size_t)stl * W + sslot;
+            A.Pnew[di] = A.P[si];
+            A.locnew[di] = A.loc[si];
+            if (A.srcglob) A.srcglob[di] = -1;
+        } else {
+            // walker arrives from another rank: row, logp filled in by hens_pt_finish_sharded
+            A.locnew[di] = -1;
+            A.srcglob[di] = st * W + sslot;
+        }
+    }
+    if (tid < T - 1) {
+        unsigned n = 0;
+        for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += sel[(size_t)tid * PT_COLS + cc];
+        if (n) atomicAdd(&A.swap_cnt[T - 2 - tid], n);           // pair i = T-1-j -> index i-1
+    }
+    // for T-1 > PT_THREADS pairs
+    for (int j = tid + PT_THREADS; j < T - 1; j += PT_THREADS) {
+        unsigned n = 0;
+        for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += sel[(size_t)j * PT_COLS + cc];
+        if (n) atomicAdd(&A.swap_cnt[T - 2 - j], n);
+    }
+
+    // last block: swap ratios -> ladder adaptation (tempering.py:563-596)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(A.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        double* r = Lc;                       // reuse LDS: ratios[T-1]
+        double* bn = Lc + T;                  // new betas [T]
+        for (int j = 0; j < T - 1; ++j) {
+            const unsigned n = __hip_atomic_load(&A.swap_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.swaps_last[j] = (double)n;
+            A.swaps_total[j] += (double)n;
+            r[j] = (double)n / (double)W;                         // :587
+            A.swap_cnt[j] = 0;
+        }
+        if (A.adapt && T > 1) {
+            const int64_t time = A.adapt_time[0];
+            if (A.stop_adaptation < 0 || time < A.stop_adaptation) {
+                const double decay = A.lag / ((double)time + A.lag);      // :571
+                const double kappa = decay / A.nu;                        // :572
+                double csum = 0.0;
+                const double inv0 = 1.0 / A.betas[0];
+                for (int k = 0; k < T; ++k) bn[k] = A.betas[k];
+                for (int j = 0; j + 2 < T; ++j) {
+                    const double dS = kappa * (r[j] - r[j + 1]);          // :575
+                    double dT = 1.0 / A.betas[j + 1] - 1.0 / A.betas[j];  // :578
+                    dT *= exp(dS);
+                    csum = (j == 0) ? dT : csum + dT;
+                    bn[j + 1] = 1.0 / (csum + inv0);                      // :580
+                }
+                for (int k = 1; k + 1 < T; ++k) A.betas[k] = A.betas[k] + (bn[k] - A.betas[k]);   // :583,:593
+            }
+            A.adapt_time[0] = time + 1;                                   // :596
+        }
+        if (A.tick) A.clock[0] += 1;
+        *A.ticket = 0;
+    }
+}
+
+// column-order decisions -> the reference's k order (row j, element colk[j][c])
+__global__ void k_pt_sel_to_korder(const uint8_t* __restrict__ selcol, const int32_t* __restrict__ colk,
+                                   uint8_t* __restrict__ selk, int npairs, int W) {
+    const int64_t n = (int64_t)npairs * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i / W);
+        selk[(size_t)j * W + colk[i]] = selcol[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sharded ladder: rows that change rank.
+//   send list entry e: local slot (tl, w) whose walker leaves -> packed as [x row | logl | logp]
+//   recv list entry e: local slot that receives it; the row lands in that slot's free home row.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
+                            const double* __restrict__ L, const double* __restrict__ P,
+                            const int32_t* __restrict__ send_slots, double* __restrict__ out,
+                            int64_t nsend, int D) {
+    const int64_t total = nsend * (D + 2);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / (D + 2);
+        const int d = (int)(i - e * (D + 2));
+        const int slot = send_slots[e];
+        out[i] = (d < D) ? pool[(size_t)loc[slot] * D + d] : (d == D ? L[slot] : P[slot]);
+    }
+}
+
+__global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ locnew,
+                              double* __restrict__ Pnew, const int32_t* __restrict__ recv_slots,
+                              const double* __restrict__ in, int64_t nrecv, int D, int32_t free_off) {
+    const int64_t total = nrecv * (D + 2);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / (D + 2);
+        const int d = (int)(i - e * (D + 2));
+        const int slot = recv_slots[e];
+        if (d < D) pool[(size_t)(free_off + slot) * D + d] = in[i];
+        else if (d == D + 1) Pnew[slot] = in[i];
+        else locnew[slot] = free_off + slot;
+    }
+}
+
+}  // namespace hens

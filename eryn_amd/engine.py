@@ -1,0 +1,138 @@
+"""HipEnsemble: thin object wrapper over the C ABI (one context = one GPU = one ladder shard)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import HensConfig, HensTiming, check, f64, ptr
+
+
+def box_logp_inside(lo, hi):
+    """sum_d log(1/(hi_d - lo_d)) accumulated in the reference's order
+    (prior.py:28-41 ``logpdf_val``; prior.py:364-383 sequential ``prior_vals += temp``)."""
+    acc = np.zeros(1)
+    for d in range(len(lo)):
+        acc += np.log(1 / (hi[d] - lo[d]))
+    return float(acc[0])
+
+
+class HipEnsemble:
+    def __init__(self, ntemps, nwalkers, ndim, likelihood, lo, hi, a=2.0, tempered=None,
+                 adaptive=True, adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1,
+                 live_dangerously=False, fill_value=-1e300, seed=0, rung_range=None, device_id=0):
+        self.lib = _lib.load()
+        self.T, self.W, self.D = int(ntemps), int(nwalkers), int(ndim)
+        if tempered is None:
+            tempered = self.T > 1
+        r0, r1 = (0, self.T) if rung_range is None else (int(rung_range[0]), int(rung_range[1]))
+        self.rung_begin, self.rung_end, self.Tl = r0, r1, r1 - r0
+        if likelihood.ndim != self.D:
+            raise ValueError("likelihood dimension does not match ndim")
+        cfg = HensConfig(ntemps=self.T, nwalkers=self.W, ndim=self.D, rung_begin=r0, rung_end=r1,
+                         device_id=int(device_id), likelihood_kind=int(likelihood.kind),
+                         tempered=int(bool(tempered)), live_dangerously=int(bool(live_dangerously)),
+                         adaptive=int(bool(adaptive)), stop_adaptation=int(stop_adaptation), a=float(a),
+                         fill_value=float(fill_value), adaptation_lag=float(adaptation_lag),
+                         adaptation_time=float(adaptation_time), seed=int(seed) & (2**64 - 1))
+        self.tempered = bool(tempered)
+        self.ctx = C.c_void_p()
+        code = self.lib.hens_create(C.byref(cfg), C.byref(self.ctx))
+        if code != _lib.HENS_OK:
+            self.ctx = None
+            check(code, None)
+        self.lo = f64(np.broadcast_to(lo, (self.D,)))
+        self.hi = f64(np.broadcast_to(hi, (self.D,)))
+        self.logp_inside = box_logp_inside(self.lo, self.hi)
+        check(self.lib.hens_set_prior_box(self.ctx, ptr(self.lo), ptr(self.hi), self.logp_inside), self.ctx)
+        likelihood._install(self.lib, self.ctx)
+        self.likelihood = likelihood
+        self.N0 = (self.W + 1) // 2
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.hens_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state ---------------------------------------------------------------------------------
+    def upload(self, x, logl=None, logp=None, betas=None):
+        x = f64(x, (self.Tl, self.W, self.D))
+        logl = None if logl is None else f64(logl, (self.Tl, self.W))
+        logp = None if logp is None else f64(logp, (self.Tl, self.W))
+        betas = None if betas is None else f64(betas, (self.T,))
+        check(self.lib.hens_upload_state(self.ctx, ptr(x), ptr(logl), ptr(logp), ptr(betas)), self.ctx)
+
+    def download(self, want_x=True):
+        x = np.empty((self.Tl, self.W, self.D)) if want_x else None
+        logl = np.empty((self.Tl, self.W))
+        logp = np.empty((self.Tl, self.W))
+        betas = np.empty(self.T) if self.tempered else None
+        check(self.lib.hens_download_state(self.ctx, ptr(x), ptr(logl), ptr(logp), ptr(betas)), self.ctx)
+        return x, logl, logp, betas
+
+    def eval_state(self):
+        check(self.lib.hens_eval_state(self.ctx), self.ctx)
+
+    # -- parity-mode steps -----------------------------------------------------------------------
+    def stretch_split(self, split, labels, rint, u_zz, u_acc):
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        if labels.shape != (self.Tl, self.W):
+            raise ValueError("labels must have shape (ntemps, nwalkers)")
+        Ns = self.N0 if split == 0 else self.W - self.N0
+        rint = np.ascontiguousarray(rint, dtype=np.int64)
+        u_zz, u_acc = f64(u_zz, (self.Tl, Ns)), f64(u_acc, (self.Tl, Ns))
+        if rint.shape != (self.Tl, Ns):
+            raise ValueError(f"rint must have shape {(self.Tl, Ns)}")
+        keep = np.empty((self.Tl, Ns), dtype=np.uint8)
+        check(self.lib.hens_stretch_split(self.ctx, int(split), ptr(labels), ptr(rint), ptr(u_zz), ptr(u_acc),
+                                          ptr(keep)), self.ctx)
+        return keep.astype(bool)
+
+    def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
+        shp = (self.T - 1, self.W)
+        iperm = np.ascontiguousarray(iperm, dtype=np.int64)
+        i1perm = np.ascontiguousarray(i1perm, dtype=np.int64)
+        u_swap = f64(u_swap, shp)
+        if iperm.shape != shp or i1perm.shape != shp:
+            raise ValueError(f"iperm/i1perm must have shape {shp}")
+        sel = np.zeros(shp, dtype=np.uint8)
+        swaps = np.zeros(max(self.T - 1, 0))
+        check(self.lib.hens_pt_sweep(self.ctx, ptr(iperm), ptr(i1perm), ptr(u_swap), int(bool(adapt)), ptr(sel),
+                                     ptr(swaps)), self.ctx)
+        return sel.astype(bool), swaps
+
+    # -- production ------------------------------------------------------------------------------
+    def step(self, n_iters):
+        check(self.lib.hens_step(self.ctx, int(n_iters)), self.ctx)
+
+    def synchronize(self):
+        check(self.lib.hens_synchronize(self.ctx), self.ctx)
+
+    def counters(self):
+        acc = np.empty((self.Tl, self.W))
+        nprop, atime = C.c_int64(0), C.c_int64(0)
+        last = np.zeros(max(self.T - 1, 0))
+        total = np.zeros(max(self.T - 1, 0))
+        check(self.lib.hens_get_counters(self.ctx, ptr(acc), C.byref(nprop), ptr(last), ptr(total),
+                                         C.byref(atime)), self.ctx)
+        return dict(accepted=acc, num_proposals=nprop.value, swaps_last=last, swaps_total=total,
+                    adapt_time=atime.value)
+
+    def reset_counters(self):
+        check(self.lib.hens_reset_counters(self.ctx), self.ctx)
+
+    def set_adapt_time(self, t):
+        check(self.lib.hens_set_adapt_time(self.ctx, int(t)), self.ctx)
+
+    def set_profiling(self, on):
+        check(self.lib.hens_set_profiling(self.ctx, int(bool(on))), self.ctx)
+
+    def timing(self):
+        t = HensTiming()
+        check(self.lib.hens_get_timing(self.ctx, C.byref(t)), self.ctx)
+        return {k: getattr(t, k) for k, _ in HensTiming._fields_}

@@ -1,0 +1,212 @@
+/*
+ * hipensemble.h - C ABI of libhipensemble.so, an MI355X (gfx950) native stepping
+ * engine for Eryn's walker-parallel stretch move + parallel-tempering path.
+ *
+ * The reference (mikekatz04/Eryn v1.2.6) is pure Python and has no FFI for this
+ * path; its plugin boundary is the Python `Move.propose(model, state)` protocol.
+ * Each entry point below therefore cites the reference *Python* interface it
+ * replaces (paths relative to /root/reference/src/eryn).  The Python side of the
+ * boundary (eryn_amd/moves/stretch.py, eryn_amd/moves/tempering.py) binds these
+ * with ctypes; INTEGRATION.md shows the stub an Eryn maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an hens_status (0 = ok, < 0 = error);
+ *     hens_last_error(ctx) gives the message (ctx may be NULL after a failed
+ *     hens_create).
+ *   - host buffers are caller-owned, C-contiguous, little-endian; the library
+ *     copies and never retains host pointers.
+ *   - layouts are the reference's, with nleaves_max == 1 squeezed away:
+ *       x[ntemps][nwalkers][ndim] f64, logl/logp[ntemps][nwalkers] f64,
+ *       betas[ntemps] f64.  A context that owns the ladder shard
+ *       [rung_begin, rung_end) exchanges only those rungs (Tl = rung_end -
+ *       rung_begin rows) through x/logl/logp; betas is always the full ladder.
+ *   - one host thread per context; no callbacks into the caller.
+ */
+#ifndef HIPENSEMBLE_H
+#define HIPENSEMBLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hens_ctx hens_ctx;
+
+typedef enum hens_status {
+    HENS_OK = 0,
+    HENS_ERR_INVALID = -1,          /* bad argument / shape            -> ValueError   */
+    HENS_ERR_HIP = -2,              /* HIP runtime failure             -> RuntimeError */
+    HENS_ERR_STATE = -3,            /* call order / missing setup      -> RuntimeError */
+    HENS_ERR_TOO_FEW_WALKERS = -4,  /* red_blue.py:108-114             -> RuntimeError */
+    HENS_ERR_NONFINITE = -5,        /* ensemble.py:1258-1262,1541-1542 -> ValueError   */
+    HENS_ERR_UNSUPPORTED = -6       /* feature outside the hot path    -> NotImplementedError */
+} hens_status;
+
+typedef enum hens_likelihood {
+    HENS_LIKE_GAUSS_DENSE = 0,      /* -0.5 (x-mu)^T P (x-mu), tests/test_eryn.py:33-35 */
+    HENS_LIKE_GAUSS_DIAG = 1,       /* same with diagonal precision (test_base's identity covariance) */
+    HENS_LIKE_ROSENBROCK = 2        /* -(sum b (x[i+1]-x[i]^2)^2 + (a-x[i])^2), BASELINE config 5 */
+} hens_likelihood;
+
+/* Construction parameters.  Mirrors the keyword arguments that reach the path:
+ * EnsembleSampler(nwalkers, ndims, ...)           ensemble.py:211-247
+ * StretchMove(a=2.0, live_dangerously=False)      moves/stretch.py:37, moves/red_blue.py:41-47
+ * TemperatureControl(adaptive, adaptation_lag,    moves/tempering.py:242-255
+ *                    adaptation_time, stop_adaptation)
+ * fill_zero_leaves_val = -1e300                   ensemble.py:242,1486-1513          */
+typedef struct hens_config {
+    int32_t ntemps;            /* full ladder length T                                   */
+    int32_t nwalkers;          /* W                                                      */
+    int32_t ndim;              /* D                                                      */
+    int32_t rung_begin;        /* ladder shard owned by this context: [rung_begin,       */
+    int32_t rung_end;          /*   rung_end); 0, ntemps for a single GPU                */
+    int32_t device_id;         /* HIP device ordinal                                     */
+    int32_t likelihood_kind;   /* hens_likelihood                                        */
+    int32_t tempered;          /* 0: logP = logl + logp (move.py:443-457); 1: betas      */
+    int32_t live_dangerously;  /* skip the W >= 2 D guard (red_blue.py:108-114)          */
+    int32_t adaptive;          /* ladder adaptation on (tempering.py:632-633)            */
+    int32_t reserved0;
+    int32_t reserved1;
+    int64_t stop_adaptation;   /* < 0: never stop (tempering.py:591)                     */
+    double a;                  /* stretch scale                                          */
+    double fill_value;         /* likelihood of walkers outside the prior support        */
+    double adaptation_lag;     /* 10000                                                  */
+    double adaptation_time;    /* 100                                                    */
+    uint64_t seed;             /* Philox key for hens_step                               */
+} hens_config;
+
+/* Lifetime.  Replaces: State / Branch buffer allocation (state.py:330-562). */
+int hens_create(const hens_config* cfg, hens_ctx** out);
+void hens_destroy(hens_ctx* ctx);
+const char* hens_last_error(const hens_ctx* ctx);
+int hens_synchronize(hens_ctx* ctx);
+
+/* Model constants.
+ * hens_set_prior_box: ProbDistContainer({i: uniform_dist(lo_i, hi_i)}) (prior.py:12-91,
+ *   337-392).  logp_inside is sum_d log(1/(hi_d-lo_d)) accumulated by the caller in the
+ *   reference's order, so an in-support prior value is bit-identical.
+ * hens_set_gaussian: the (mu, invcov) `args` of the reference tests' log_like_fn
+ *   (tests/test_eryn.py:33-35,100-104).  prec has D*D entries (dense) or D (diag).
+ * hens_set_rosenbrock: constants of the config-5 stress likelihood. */
+int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double logp_inside);
+int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec);
+int hens_set_rosenbrock(hens_ctx* ctx, double a, double b);
+
+/* State transfer.  Replaces State(coords, log_like=, log_prior=, betas=) construction and
+ * the State snapshot handed to Backend.save_step (state.py:437-517, backends/backend.py:1014-1091).
+ * Any output pointer may be NULL.  logl/logp NULL on upload = "not evaluated yet". */
+int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const double* logp,
+                      const double* betas);
+int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, double* betas);
+
+/* Initial log-prior / log-likelihood of the resident coordinates.
+ * Replaces EnsembleSampler.compute_log_prior + compute_log_like as called from
+ * sample() (ensemble.py:898-912; 1127-1217; 1219-1545 incl. the -inf-prior skip and
+ * the fill value).  Returns HENS_ERR_NONFINITE if a coordinate is inf/NaN. */
+int hens_eval_state(hens_ctx* ctx);
+
+/* One red/blue half-step on all resident rungs, driven by caller-supplied draws
+ * ("parity mode").  Replaces one trip of the `for split in range(nsplits)` body of
+ * RedBlueMove.propose (red_blue.py:148-323): StretchMove.get_proposal (stretch.py:160-231),
+ * compute_log_prior, compute_log_like, the MH test (red_blue.py:292-294) and Move.update
+ * (move.py:472-703).
+ *   labels[Tl][W]   u8   split label of every walker after the reference's shuffle (red_blue.py:121-124)
+ *   rint[Tl][Ns]    i64  R.randint(Nc, size=(T, Ns))                  (stretch.py:93-99)
+ *   u_zz[Tl][Ns]    f64  R.rand(T, Ns) for the stretch factor         (stretch.py:129-132)
+ *   u_acc[Tl][Ns]   f64  R.rand(T, Ns) for the accept test            (red_blue.py:294)
+ *   keep_out[Tl][Ns] u8  accept mask in the order of the ascending moving set S
+ * Calls must alternate split = 0, 1.  Synchronous. */
+int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint,
+                       const double* u_zz, const double* u_acc, uint8_t* keep_out);
+
+/* Hot->cold swap cascade + ladder adaptation, driven by caller-supplied draws.
+ * Replaces TemperatureControl.temper_comps (tempering.py:598-649): temperature_swaps
+ * (:484-561), do_swaps_indexing (:351-482), adapt_temps (:585-596).
+ *   iperm, i1perm [T-1][W] i64; u_swap [T-1][W] f64: row j holds the draws of the pair
+ *   (i, i-1), i = T-1-j, i.e. the order np.random.permutation / uniform are called.
+ *   adapt: 0 = swaps only (rj.py:381-382 calls temper_comps(adapt=False)).
+ *   sel_out [T-1][W] u8 (same row order), swaps_accepted_out [T-1] indexed by i-1.
+ * Requires the whole ladder resident (rung_begin = 0, rung_end = ntemps).  Synchronous. */
+int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, const double* u_swap,
+                  int32_t adapt, uint8_t* sel_out, double* swaps_accepted_out);
+
+/* Production stepping: n_iters iterations of (split 0, split 1, PT cascade, adaptation)
+ * with device-side Philox4x32-10 draws, no host round trip.  Replaces the body of the
+ * hot loop of EnsembleSampler.sample for one in-model StretchMove (ensemble.py:965-981).
+ * Asynchronous on the context's stream; hens_synchronize / any download waits. */
+int hens_step(hens_ctx* ctx, int64_t n_iters);
+
+/* Counters.  Replaces Move.accepted / num_proposals (move.py:404-421, red_blue.py:326-327),
+ * TemperatureControl.swaps_accepted / time (tempering.py:542,596).  Any pointer may be NULL.
+ *   accepted[Tl][W] f64 cumulative, swaps_last[T-1], swaps_total[T-1] f64. */
+int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals,
+                      double* swaps_last, double* swaps_total, int64_t* adapt_time);
+int hens_reset_counters(hens_ctx* ctx);
+int hens_set_adapt_time(hens_ctx* ctx, int64_t t);
+
+/* Timing of the most recent hens_step call, from hipEvents on the context's stream.
+ *   total_ms      wall time of the whole call on the device
+ *   stretch_ms    summed duration of the stretch kernels, n_stretch = their count
+ *   pt_ms         summed duration of the PT cascade kernels, n_pt = their count
+ * Per-kernel figures are only filled when per-kernel events were enabled with
+ * hens_set_profiling(ctx, 1) (they serialise the stream slightly). */
+typedef struct hens_timing {
+    double total_ms;
+    double stretch_ms;
+    double pt_ms;
+    double plan_ms;
+    int64_t n_stretch;
+    int64_t n_pt;
+    int64_t n_plan;
+    int64_t n_iters;
+} hens_timing;
+int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events);
+int hens_get_timing(hens_ctx* ctx, hens_timing* out);
+
+/* Ladder sharding (one context per GPU, rungs [rung_begin, rung_end)).  The stretch
+ * step needs no communication (complement walkers are drawn within a rung,
+ * red_blue.py:183-193).  For the PT cascade every rank needs all log-likelihoods:
+ *   hens_device_buffers     device pointers of the resident logl/logp rows and of
+ *                           staging buffers, so the caller can all-gather them with
+ *                           RCCL (torch.distributed) without a host copy.
+ *   hens_pt_plan_sharded    replay the full T-1 pair cascade from the gathered
+ *                           logl[T][W] (device pointer), decide every swap, update
+ *                           betas, and report which walker rows must travel.
+ *   hens_pt_pack / _unpack  gather outgoing rows (+ their logl, logp) into a send
+ *                           buffer / scatter received rows into free pool slots.
+ * See eryn_amd/ladder.py for the protocol and DESIGN.md section 6. */
+typedef struct hens_device_buffers {
+    void* logl;          /* f64 [Tl][W] resident rows (current buffer)            */
+    void* logp;          /* f64 [Tl][W]                                           */
+    void* gather_logl;   /* f64 [T][W] staging for the all-gathered ladder        */
+    void* gather_logp;   /* f64 [T][W]                                            */
+    void* send_rows;     /* f64 [send_capacity][D + 2] outgoing rows              */
+    void* recv_rows;     /* f64 [recv_capacity][D + 2] incoming rows              */
+    int64_t row_capacity;
+    void* stream;        /* hipStream_t the library launches on                   */
+} hens_device_buffers;
+int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out);
+int hens_set_stream(hens_ctx* ctx, void* hip_stream);
+
+/* Sharded PT, step 1: decisions from the gathered ladder.  Draws come either from the
+ * caller (parity: iperm/i1perm/u_swap as in hens_pt_sweep, may be NULL for Philox mode).
+ * Outputs (host): send_counts[nranks], recv_counts[nranks] rows per peer given the
+ * rung ownership table rank_of_rung[T]; sel_out/swaps_accepted_out as in hens_pt_sweep
+ * (may be NULL).  After this call the send buffer is packed. */
+int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm,
+                         const double* u_swap, int32_t adapt, const int32_t* rank_of_rung,
+                         int32_t nranks, int64_t* send_counts, int64_t* recv_counts,
+                         uint8_t* sel_out, double* swaps_accepted_out);
+/* Sharded PT, step 2: after the caller exchanged send_rows -> recv_rows (all-to-all in
+ * rank order), scatter the received rows and finish the permutation of logl/logp/loc. */
+int hens_pt_finish_sharded(hens_ctx* ctx);
+
+/* Static description of the build. */
+const char* hens_version(void);
+int hens_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPENSEMBLE_H */
