@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark: walker-steps/s of the stretch-move + parallel-tempering path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one sampler iteration = StretchMove.propose (both red/blue halves) + the hot->cold
+PT swap cascade + ladder adaptation (ensemble.py:965-1041), over every walker of the ladder.
+N = 1: BASELINE config 2 (ntemps=16, nwalkers=4096, ndim=32 dense Gaussian).  N > 1: the ladder
+is sharded, 8 rungs of config 3 (nwalkers=16384, ndim=64) per GPU, weak scaling.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def gaussian_problem(D):
+    """SURVEY 8d synthetic inputs: mu = 0.1 randn(D), Sigma = A A^T / D + I, RandomState(0)."""
+    rs = np.random.RandomState(0)
+    A = rs.randn(D, D)
+    mu = 0.1 * rs.randn(D)
+    cov = A @ A.T / D + np.eye(D)
+    return mu, np.linalg.inv(cov)
+
+
+def b_stretch(D):
+    """Algorithmic bytes per walker-step of the stretch kernels: own row + complement
+    row + written row + log-like/log-prior read and write."""
+    return 24 * D + 32
+
+
+def b_pt(T, D, f_sw):
+    return (2.0 * (T - 1) / T) * (8 + f_sw * (16 * D + 32)) if T > 1 else 0.0
+
+
+def cpu_baseline(T, W, D, seconds=12.0):
+    """Eryn-faithful NumPy restatement (oracle/, pinned bit-exact to the reference) timed on the
+    host cores on a bounded sample of the same workload."""
+    from oracle import eryn_oracle as orc
+    mu, invcov = gaussian_problem(D)
+    R, G = np.random.RandomState(123), np.random.RandomState(456)
+    x0 = np.random.RandomState(1).randn(T, W, D)
+    o = orc.OracleSampler(x0, lambda x: orc.gaussian_log_like(x, mu, invcov), np.full(D, -50.0), np.full(D, 50.0),
+                          R, G, betas=orc.make_ladder(D, ntemps=T) if T > 1 else None)
+    o.iteration()                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        o.iteration()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 200:
+            break
+    threads = 1
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        pass
+    return {"value": T * W * n / dt, "unit": "walker-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} iterations of the same (ntemps={T}, nwalkers={W}, ndim={D}) workload, "
+                      f"NumPy oracle (BLAS threads={threads}, os.cpu_count()={os.cpu_count()}), {dt:.1f} s"}
+
+
+def load_traffic():
+    """HBM bytes per stretch launch from the committed rocprofv3 --pmc passes, if present."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("stretch_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def run_single(args):
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves.tempering import make_ladder
+    T, W, D = args.ntemps, args.nwalkers, args.ndim
+    mu, invcov = gaussian_problem(D)
+    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, device_id=0)
+    x0 = np.random.RandomState(1).randn(T, W, D)
+    eng.upload(x0, betas=make_ladder(D, ntemps=T) if T > 1 else None)      # inputs resident in HBM
+    eng.eval_state()
+    eng.step(args.warmup)
+    eng.synchronize()
+    eng.reset_counters()
+
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.step(args.steps)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = eng.counters()
+    f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps, 1))) if T > 1 else 0.0
+    acc = float(c["accepted"].mean() / max(c["num_proposals"], 1))
+
+    # dominant kernel (k_stretch): per-launch duration from HIP events on the engine's own stream,
+    # over a second pass of the same K steps with an event pair around every launch
+    eng.set_profiling(True)
+    eng.step(args.steps)
+    eng.synchronize()
+    tm = eng.timing()
+    eng.set_profiling(False)
+    stretch_us = tm["stretch_ms"] / max(tm["n_stretch"], 1) * 1e3
+    walkers_per_launch = T * W / 2.0
+    alg_bytes = b_stretch(D) * walkers_per_launch
+    achieved = alg_bytes / (stretch_us * 1e-6) / 1e9
+    eng.close()
+    value = T * W * args.steps / dt
+    out = {
+        "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Gaussian logL",
+        "value": value, "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"config 2: ntemps={T}, nwalkers={W}, ndim={D} dense-covariance Gaussian, box prior +-50, "
+                               f"StretchMove(a=2)+adaptive PT, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
+                   "parallelism": "single GPU", "stretch_acceptance": acc, "swap_fraction": f_sw},
+        "roofline": {"bound": "hbm", "kernel": "k_stretch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": stretch_us,
+                     "pt_kernel_avg_us": tm["pt_ms"] / max(tm["n_pt"], 1) * 1e3,
+                     "whole_path_GBps": (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9,
+                     "whole_path_frac": (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9 / HBM_PEAK_GBS},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(T, W, D, seconds=args.cpu_seconds)
+        out["vs_cpu"] = value / out["cpu_baseline"]["value"]
+    return out
+
+
+def run_sharded(args):
+    from eryn_amd.ladder import bench_sharded
+    return bench_sharded(args, gaussian_problem, b_stretch, b_pt, HBM_PEAK_GBS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--ntemps", type=int, default=None)
+    ap.add_argument("--nwalkers", type=int, default=None)
+    ap.add_argument("--ndim", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        args.ntemps = args.ntemps or 8 * max(args.gpus, world)
+        args.nwalkers = args.nwalkers or 16384
+        args.ndim = args.ndim or 64
+        out = run_sharded(args)
+    else:
+        args.ntemps = args.ntemps or 16
+        args.nwalkers = args.nwalkers or 4096
+        args.ndim = args.ndim or 32
+        out = run_single(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libhipensemble.so")
+LIB_PATH = os.environ.get("HENS_LIB") or os.path.join(LIB_DIR, "libhipensemble.so")
 SOURCES = [os.path.join(SRC_DIR, "hens.hip")]
 DEPS = SOURCES + [os.path.join(SRC_DIR, "hens_kernels.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -37,7 +38,7 @@ struct hens_ctx_impl {
     unsigned* flags = nullptr;
     uint64_t* clock = nullptr;
     int64_t* adapt_time = nullptr;
-    uint32_t* swap_cnt = nullptr;
+    unsigned long long* swap_cnt = nullptr;
     double* swaps_last = nullptr;
     double* swaps_total = nullptr;
     unsigned* ticket = nullptr;
@@ -69,6 +70,10 @@ struct hens_ctx_impl {
     int64_t row_capacity = 0;
     int64_t n_send = 0, n_recv = 0;
     bool pt_pending = false;
+
+    unsigned long long* d_trace = nullptr;
+    int64_t trace_words = 0;
+    bool tracing = false;
 
     // timing
     bool per_kernel_events = false;
@@ -128,19 +133,38 @@ int launch_stretch_like(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
         b.RS = RS;                                                                                 \
         hipLaunchKernelGGL((k_stretch<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), lds, c->stream, b); \
     } while (0)
-    if (LIKE == LIKE_ROSEN) {
-        LAUNCH(0, 4);
-    } else if (c->D == 32) {
-        LAUNCH(32, 4);
+#define LAUNCH_FAST(DT, NW)                                                                        \
+    do {                                                                                           \
+        size_t lds = stretch_lds_bytes(c->D, NW, &RS) + (plds_knob ? (size_t)DT * DT * 8 : 0);     \
+        if (lds > 60000) {                                                                         \
+            static bool attr_done = false;                                                         \
+            if (!attr_done) {                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                attr_done = true;                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+        if (plds_knob)                                                                             \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, true>), grid, dim3(NW * 64), lds, c->stream, a);  \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, false>), grid, dim3(NW * 64), lds, c->stream, a); \
+    } while (0)
+    static const int nw_knob = getenv("HENS_NW") ? atoi(getenv("HENS_NW")) : 0;
+    static const int plds_knob = getenv("HENS_PLDS") ? atoi(getenv("HENS_PLDS")) : 0;
+    if (c->D == 32) {
+        if (nw_knob == 4) LAUNCH_FAST(32, 4);
+        else if (nw_knob == 16) LAUNCH_FAST(32, 16);
+        else LAUNCH_FAST(32, 8);
     } else if (c->D == 64) {
-        LAUNCH(64, 8);
+        LAUNCH_FAST(64, 8);
     } else if (c->D == 16) {
-        LAUNCH(16, 4);
+        LAUNCH_FAST(16, 4);
     } else if (c->D == 8) {
-        LAUNCH(8, 4);
+        LAUNCH_FAST(8, 4);
     } else {
         LAUNCH(0, 4);
     }
+#undef LAUNCH_FAST
 #undef LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
@@ -169,6 +193,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec;
     a.clock = c->clock;
     a.flags = c->flags;
+    a.trace = c->tracing ? c->d_trace : nullptr;
     a.a = c->cfg.a;
     a.logp_in = c->logp_in;
     a.fill = c->cfg.fill_value;
@@ -221,7 +246,7 @@ int ensure_pt_buffers(hens_ctx_impl* c) {
     return HENS_OK;
 }
 
-size_t pt_lds_bytes(int T) { return (size_t)T * PT_COLS * (8 + 8 + 2 + 1); }
+size_t pt_lds_bytes(int T) { return pt_lds_layout(T); }
 
 PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     PtArgs p{};
@@ -230,14 +255,14 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     p.Lnew = c->L[c->cur ^ 1]; p.Pnew = c->P[c->cur ^ 1]; p.locnew = c->loc[c->cur ^ 1];
     p.betas = c->betas;
     p.colslot = colslot;
-    p.swap_cnt = c->swap_cnt; p.swaps_last = c->swaps_last; p.swaps_total = c->swaps_total;
+    p.swap_part = c->swap_cnt; p.swaps_last = c->swaps_last; p.swaps_total = c->swaps_total;
     p.ticket = c->ticket; p.clock = c->clock; p.adapt_time = c->adapt_time;
     p.seed = c->cfg.seed;
     p.lag = c->cfg.adaptation_lag; p.nu = c->cfg.adaptation_time;
     p.stop_adaptation = c->cfg.stop_adaptation;
     p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin;
     p.sharded = sharded ? 1 : 0;
-    p.srcglob = sharded ? c->srcglob : nullptr;
+    p.srcfull = sharded ? c->srcglob : nullptr;
     return p;
 }
 
@@ -314,7 +339,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRY(dalloc(c, &c->flags, 1));
     TRY(dalloc(c, &c->clock, 1));
     TRY(dalloc(c, &c->adapt_time, 1));
-    TRY(dalloc(c, &c->swap_cnt, (size_t)c->T));
+    TRY(dalloc(c, &c->swap_cnt, (size_t)c->T * ((c->W + PT_COLS - 1) / PT_COLS)));
     TRY(dalloc(c, &c->swaps_last, (size_t)c->T));
     TRY(dalloc(c, &c->swaps_total, (size_t)c->T));
     TRY(dalloc(c, &c->ticket, 1));
@@ -343,7 +368,6 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRYHIP(hipMemsetAsync(c->flags, 0, 4, c->stream));
     TRYHIP(hipMemsetAsync(c->clock, 0, 8, c->stream));
     TRYHIP(hipMemsetAsync(c->adapt_time, 0, 8, c->stream));
-    TRYHIP(hipMemsetAsync(c->swap_cnt, 0, (size_t)c->T * 4, c->stream));
     TRYHIP(hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
     TRYHIP(hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
     TRYHIP(hipMemsetAsync(c->ticket, 0, 4, c->stream));
@@ -382,7 +406,7 @@ void hens_destroy(hens_ctx* ctx) {
                     c->lo, c->hi, c->mu, c->prec, c->order, c->d_rint, c->d_uzz, c->d_uacc, c->d_keep,
                     c->d_iperm, c->d_i1perm, c->d_uswap, c->d_inv, c->colslot, c->colk, c->colu, c->selcol,
                     c->selk, c->xtmp, c->gather_L, c->gather_P, c->send_rows, c->recv_rows, c->srcglob,
-                    c->send_slots, c->recv_slots, c->d_counts};
+                    c->send_slots, c->recv_slots, c->d_counts, c->d_trace};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -773,6 +797,30 @@ int hens_get_timing(hens_ctx* ctx, hens_timing* out) {
     if (c->timing.n_iters > 0) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->timing.total_ms = ms;
     *out = c->timing;
+    return HENS_OK;
+}
+
+int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capacity, int64_t* n_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int64_t words = (int64_t)c->Tl * ((c->W + TILE - 1) / TILE) * 8;
+    if (enable) {
+        if (!c->d_trace) {
+            int r = dalloc(c, &c->d_trace, (size_t)words);
+            if (r) return r;
+            c->trace_words = words;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_trace, 0, (size_t)words * 8, c->stream));
+        c->tracing = true;
+        return HENS_OK;
+    }
+    c->tracing = false;
+    if (!c->d_trace || !out) return fail(c, HENS_ERR_STATE, "tracing was not enabled");
+    const int64_t n = std::min<int64_t>(capacity, c->trace_words);
+    HIPCHK(c, hipMemcpyAsync(out, c->d_trace, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_out) *n_out = n;
     return HENS_OK;
 }
 

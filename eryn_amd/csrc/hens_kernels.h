@@ -17,6 +17,9 @@
 //   betas  f64 [T]               full ladder
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef HENS_ABLATE
+#define HENS_ABLATE 0   // timing experiments only (tools/ablate.sh): bit0 no quad form, bit1 no logs, bit2 no row write, bit3 no philox
+#endif
 #include <stdint.h>
 
 namespace hens {
@@ -73,6 +76,7 @@ struct StretchArgs {
     const double* prec;
     const uint64_t* clock;     // device iteration counter
     unsigned* flags;
+    unsigned long long* trace;  // debug: per-workgroup phase timestamps (s_memtime), or nullptr
     double a, logp_in, fill, rosen_a, rosen_b;
     uint64_t seed;
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
             if (keep) {                                        // move.py:513-532
                 A.L[gi] = logl;
                 A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
-                A.accepted[gi] += 1u;
+                atomicAdd(&A.accepted[gi], 1u);
                 atomicOr(&s_flag[lane], 2);
             }
             A.loc[gi] = s_dst[lane];
@@ -371,6 +375,293 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
+//   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
+//     flight) instead of one pass at a time -> the kernel is latency-bound at config-2 size, so
+//     memory-level parallelism is what buys time;
+//   * the old row stays in registers for the write-back (no re-read on reject);
+//   * the two log() calls of the accept test are issued while those loads are in flight.
+// ---------------------------------------------------------------------------------------------
+template <int DT, int LIKE, int MODE, int NW, bool PLDS>
+__global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
+    static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int D = DT;
+    constexpr int RS = DT + 2;                 // LDS row stride (doubles): conflict-free b128 reads
+    constexpr int NT = NW * 64;
+    constexpr int LPR = DT / 2;                // lanes per row, 16 B each
+    static_assert(LPR <= 64, "row wider than a wavefront");
+    constexpr int RPP = NT / LPR;              // rows per pass
+    constexpr int NPASS = (TILE + RPP - 1) / RPP;
+    double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
+    double* s_zz = qtile + TILE * RS;                                    // [TILE]
+    double* s_part = s_zz + TILE;                                        // [NW][TILE]
+    int32_t* s_rs = reinterpret_cast<int32_t*>(s_part + NW * TILE);      // [TILE]
+    int32_t* s_rc = s_rs + TILE;
+    int32_t* s_dst = s_rc + TILE;
+    int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
+    double* s_prec = reinterpret_cast<double*>(s_flag + TILE);           // [DT][DT] when PLDS
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tl = blockIdx.y;
+    const int W = A.W;
+    const int Ns = (MODE == MODE_EVAL) ? W : (A.split == 0 ? A.N0 : W - A.N0);
+    const int Nc = W - Ns;
+    const int s_off = (MODE == MODE_EVAL) ? 0 : (A.split == 0 ? 0 : A.N0);
+    const int c_off = (A.split == 0 ? A.N0 : 0);
+    const int k0 = blockIdx.x * TILE;
+#define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    HENS_TRACE(0);
+
+    if (PLDS && LIKE == LIKE_DENSE) {
+        // stage the precision matrix in LDS while phase A/B wait on their gathers: phase C then has
+        // no global latency at all (a cold scalar cache costs ~1 us per pair of rows otherwise)
+        for (int i = tid * 2; i < DT * DT; i += NT * 2)
+            *reinterpret_cast<double2*>(s_prec + i) = *reinterpret_cast<const double2*>(A.prec + i);
+    }
+    // ---- phase A (wave 0): indices and draws; the logs wait until the row loads are in flight ---
+    double zz_own = 1.0, ua = 1.0, Lold = 0.0, Pold = 0.0;
+    int own = 0;
+    bool valid = false;
+    if (wv == 0) {
+        const int k = k0 + lane;
+        valid = k < Ns;
+        int rs = 0, rc = 0;
+        if (valid) {
+            if (MODE == MODE_EVAL) {
+                own = k;
+                rs = A.loc[tl * W + own];
+                rc = rs;
+            } else {
+                own = A.order[tl * W + s_off + k];
+                double uz;
+                int r;
+                if (MODE == MODE_PARITY) {
+                    r = (int)A.rint[(size_t)tl * Ns + k];
+                    uz = A.u_zz[(size_t)tl * Ns + k];
+                    ua = A.u_acc[(size_t)tl * Ns + k];
+                } else {
+                    const uint64_t it = A.clock[0];
+                    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32),
+                                 (uint32_t)((A.rung_begin + tl) * W + own), PURPOSE_STRETCH0};
+                    u4 d, e;
+                    if (HENS_ABLATE & 8) {
+                        d = u4{ctr.z * 2654435761u + ctr.x, ctr.z * 40503u, ctr.x * 7919u + ctr.z, 0u};
+                        e = u4{d.y, d.x, 0u, 0u};
+                    } else {
+                        d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                        u4 ctr2 = ctr;
+                        ctr2.w = PURPOSE_STRETCH_ACC;
+                        e = philox4x32_10(ctr2, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                    }
+                    r = (int)__umulhi(d.x, (uint32_t)Nc);
+                    uz = u01(d.y, d.z);
+                    ua = u01(e.x, e.y);
+                }
+                const int cw = A.order[tl * W + c_off + r];
+                rs = A.loc[tl * W + own];
+                rc = A.loc[tl * W + cw];
+                Lold = A.L[tl * W + own];
+                Pold = A.P[tl * W + own];
+                zz_own = (A.a - 1.0) * uz + 1.0;      // stretch.py:129-132
+                zz_own = zz_own * zz_own / A.a;
+            }
+        }
+        s_zz[lane] = zz_own;
+        s_rs[lane] = rs;
+        s_rc[lane] = rc;
+        s_dst[lane] = A.home_off + tl * W + own;
+        s_flag[lane] = valid ? 4 : 0;
+    }
+    HENS_TRACE(1);
+    __syncthreads();
+    HENS_TRACE(2);
+
+    // ---- phase B: lanes over d, all loads first -------------------------------------------------
+    const int jl = tid & (LPR - 1);
+    const int rsub = tid / LPR;
+    const double* __restrict__ pool_r = A.pool;
+    double2 sreg[NPASS], creg[NPASS];
+    bool rv[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
+        sreg[p] = double2{0.0, 0.0};
+        creg[p] = double2{0.0, 0.0};
+        if (rv[p]) {
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rs[r] * D + jl * 2);
+            if (MODE != MODE_EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rc[r] * D + jl * 2);
+        }
+    }
+    const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
+    const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
+    double factors = 0.0, lu = 0.0;
+    if (MODE != MODE_EVAL && wv == 0 && !(HENS_ABLATE & 2)) {
+        factors = ((double)D - 1.0) * log(zz_own);       // stretch.py:223
+        lu = log(ua);                                    // red_blue.py:294
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        bool ok = true, finite = true;
+        if (rv[p]) {
+            double2 qv;
+            if (MODE == MODE_EVAL) {
+                qv = sreg[p];
+            } else {
+                const double zz = s_zz[r];
+                qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz;     // stretch.py:143,145
+                qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
+            }
+            ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
+            finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
+            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
+        }
+        const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
+        const unsigned long long nonfin = __ballot(!finite);
+        const int gshift = lane & ~(LPR - 1);
+        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << (LPR & 63)) - 1ull) << gshift);
+        if (jl == 0 && rv[p]) {
+            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);
+            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
+        }
+    }
+    HENS_TRACE(3);
+    __syncthreads();
+    HENS_TRACE(4);
+
+    // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
+    {
+        const bool inbox = (s_flag[lane] & 1) != 0;
+        double part = 0.0;
+        typedef const __attribute__((address_space(4))) double* cptr_t;
+        const cptr_t mu = (cptr_t)(uintptr_t)A.mu;
+        const cptr_t prec = (cptr_t)(uintptr_t)A.prec;
+        const double* qrow = qtile + lane * RS;
+        if (LIKE == LIKE_ROSEN) {
+            if (wv == 0 && inbox) {
+                double acc = 0.0;
+                for (int i = 0; i + 1 < D; ++i) {
+                    const double x0 = qrow[i], x1 = qrow[i + 1];
+                    const double t1 = x1 - x0 * x0, t2 = A.rosen_a - x0;
+                    acc += A.rosen_b * (t1 * t1) + t2 * t2;
+                }
+                part = 2.0 * acc;
+            }
+        } else if (inbox && !(HENS_ABLATE & 1)) {
+            constexpr int RB = (DT + NW - 1) / NW;
+            const int i0 = wv * RB;
+            if (LIKE == LIKE_DENSE) {
+                double qreg[DT];
+#pragma unroll
+                for (int k = 0; k < DT; k += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(qrow + k);
+                    qreg[k] = v.x - mu[k];
+                    qreg[k + 1] = v.y - mu[k + 1];
+                }
+#pragma unroll 2
+                for (int ii = 0; ii < RB; ++ii) {
+                    const int i = i0 + ii;
+                    if (i < DT) {
+                        double y0 = 0.0, y1 = 0.0;
+                        if (PLDS) {
+                            const double* prow = s_prec + i * DT;       // wave-uniform address: LDS broadcast
+#pragma unroll
+                            for (int k = 0; k < DT; k += 2) {
+                                const double2 pv = *reinterpret_cast<const double2*>(prow + k);
+                                y0 = fma(pv.x, qreg[k], y0);
+                                y1 = fma(pv.y, qreg[k + 1], y1);
+                            }
+                        } else {
+                            const cptr_t prow = prec + (size_t)i * DT;  // SGPR operands via s_load
+#pragma unroll
+                            for (int k = 0; k < DT; k += 2) {
+                                y0 = fma(prow[k], qreg[k], y0);
+                                y1 = fma(prow[k + 1], qreg[k + 1], y1);
+                            }
+                        }
+                        part = fma(qrow[i] - mu[i], y0 + y1, part);
+                    }
+                }
+            } else {
+                for (int ii = 0; ii < RB; ++ii) {
+                    const int i = i0 + ii;
+                    if (i < DT) {
+                        const double di = qrow[i] - mu[i];
+                        part = fma(di * prec[i], di, part);
+                    }
+                }
+            }
+        }
+        s_part[wv * TILE + lane] = part;
+    }
+    HENS_TRACE(5);
+    __syncthreads();
+
+    // ---- phase D: accept / update (wave 0) -------------------------------------------------------
+    if (wv == 0 && valid) {
+        const bool inbox = (s_flag[lane] & 1) != 0;
+        double acc = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + lane];
+        double logl = inbox ? -0.5 * acc : A.fill;             // ensemble.py:1486-1513
+        if (logl != logl) {                                    // red_blue.py:279-281
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+        const double logp = inbox ? A.logp_in : -INFINITY;     // prior.py:80-88
+        const size_t gi = (size_t)tl * W + own;
+        if (MODE == MODE_EVAL) {
+            A.L[gi] = logl;
+            A.P[gi] = logp;
+        } else {
+            double logP, prevP;
+            if (A.tempered) {                                  // tempering.py:304-306,343-349
+                const double beta = A.betas[A.rung_begin + tl];
+                double lt = logl * beta;
+                if (lt != lt) lt = -INFINITY;
+                logP = lt + logp;
+                double lo_ = Lold * beta;
+                if (lo_ != lo_) lo_ = -INFINITY;
+                prevP = lo_ + Pold;
+            } else {                                           // move.py:443-457
+                logP = logl + logp;
+                prevP = Lold + Pold;
+            }
+            const double lnpdiff = factors + logP - prevP;     // red_blue.py:292
+            const bool keep = lnpdiff > lu;                    // red_blue.py:294
+            if (keep) {                                        // move.py:513-532
+                A.L[gi] = logl;
+                A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
+                atomicAdd(&A.accepted[gi], 1u);
+                atomicOr(&s_flag[lane], 2);
+            }
+            A.loc[gi] = s_dst[lane];
+            if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
+        }
+    }
+    if (MODE == MODE_EVAL) return;
+    HENS_TRACE(6);
+    __syncthreads();
+
+    // ---- phase E: write rows (q if kept, the register copy of the old row otherwise) ---------------
+    double* __restrict__ pool_w = A.pool;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        if (!rv[p] || (HENS_ABLATE & 4)) continue;
+        const bool keep = (s_flag[r] & 2) != 0;
+        const double2 v = keep ? *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2) : sreg[p];
+        *reinterpret_cast<double2*>(pool_w + (size_t)s_dst[r] * D + jl * 2) = v;
+    }
+    HENS_TRACE(7);
+#undef HENS_TRACE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -519,8 +810,8 @@ struct PtArgs {
     const int32_t* colslot;     // [T][W]
     const double* colu;         // [T-1][W] uniforms in column order (parity) or nullptr (Philox)
     uint8_t* selcol;            // [T-1][W] swap decisions in column order, row j <-> pair T-1-j (or nullptr)
-    int32_t* srcglob;           // [Tl][W] global slot id (t*W + w) of the walker arriving at each local slot (sharded) or nullptr
-    uint32_t* swap_cnt;         // [T-1] scratch counters (zero on entry, zeroed again on exit)
+    int32_t* srcfull;           // [T][W] global source slot id (t'*W + w') of the walker arriving at every slot of the full ladder (sharded) or nullptr
+    unsigned long long* swap_part;   // [nblocks][T-1] per-workgroup swap counts, 8-byte granules
     double* swaps_last;         // [T-1]
     double* swaps_total;        // [T-1]
     unsigned* ticket;
@@ -532,25 +823,29 @@ struct PtArgs {
     int32_t T, W, Tl, rung_begin, adapt, tick, sharded;
 };
 
-constexpr int PT_COLS = 64;
+constexpr int PT_COLS = 16;      // columns per workgroup: W/16 workgroups keep every CU busy at W = 4096
 constexpr int PT_THREADS = 256;
 
-// LDS: Lc[T][PT_COLS] f64 column log-likelihoods, lu[T-1][PT_COLS] f64 log-uniforms,
-//      src[T][PT_COLS] u8/i16 rung each final slot takes its walker from.
+// LDS: Lc[T][PT_COLS] f64 column log-likelihoods, lu[T][PT_COLS] f64 log-uniforms, sbeta[T] f64,
+//      src[T][PT_COLS] i16 rung each final slot takes its walker from, sel[T][PT_COLS] u8.
+__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 2 + 1) + (size_t)T * 8; }
+
 template <bool PHILOX>
 __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int T = A.T, W = A.W;
     double* Lc = reinterpret_cast<double*>(smem_raw);            // [T][PT_COLS]
     double* lu = Lc + (size_t)T * PT_COLS;                       // [T][PT_COLS] (row j = pair T-1-j)
-    int16_t* src = reinterpret_cast<int16_t*>(lu + (size_t)T * PT_COLS);   // [T][PT_COLS]
+    double* sbeta = lu + (size_t)T * PT_COLS;                    // [T]
+    int16_t* src = reinterpret_cast<int16_t*>(sbeta + T);        // [T][PT_COLS]
     uint8_t* sel = reinterpret_cast<uint8_t*>(src + (size_t)T * PT_COLS);  // [T][PT_COLS]
     __shared__ int s_last;
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
     const uint64_t it = PHILOX ? A.clock[0] : 0;
 
-    // phase 1: gather the column's log-likelihoods and log-uniforms (all independent loads)
+    // phase 1: gather the column's log-likelihoods, log-uniforms and the ladder (independent loads)
+    for (int t = tid; t < T; t += PT_THREADS) sbeta[t] = A.betas[t];
     for (int e = tid; e < T * PT_COLS; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
@@ -579,7 +874,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         for (int i = T - 1; i >= 1; --i) {
             const int j = T - 1 - i;
             const double Lb = Lc[(size_t)(i - 1) * PT_COLS + cc];
-            const double dbeta = A.betas[i - 1] - A.betas[i];    // tempering.py:518-522
+            const double dbeta = sbeta[i - 1] - sbeta[i];        // tempering.py:518-522
             const double pacc = dbeta * (cL - Lb);               // tempering.py:538
             const bool s = pacc > lu[(size_t)j * PT_COLS + cc];  // tempering.py:541
             sel[(size_t)j * PT_COLS + cc] = s ? 1 : 0;
@@ -600,11 +895,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
         if (t < T - 1 && A.selcol) A.selcol[(size_t)t * W + c] = sel[e];
-        const int tl = t - A.rung_begin;
-        if (tl < 0 || tl >= A.Tl) continue;
         const int st = src[e];
         const int dslot = A.colslot[(size_t)t * W + c];
         const int sslot = A.colslot[(size_t)st * W + c];
+        if (A.srcfull) A.srcfull[(size_t)t * W + dslot] = st * W + sslot;
+        const int tl = t - A.rung_begin;
+        if (tl < 0 || tl >= A.Tl) continue;
         const size_t di = (size_t)tl * W + dslot;
         A.Lnew[di] = Lc[(size_t)st * PT_COLS + cc];
         const int stl = st - A.rung_begin;
@@ -612,63 +908,90 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
             const size_t si = (size_t)stl * W + sslot;
             A.Pnew[di] = A.P[si];
             A.locnew[di] = A.loc[si];
-            if (A.srcglob) A.srcglob[di] = -1;
         } else {
-            // walker arrives from another rank: row, logp filled in by hens_pt_finish_sharded
-            A.locnew[di] = -1;
-            A.srcglob[di] = st * W + sslot;
+            A.locnew[di] = -1;       // row + log-prior arrive from another rank (hens_pt_finish_sharded)
         }
     }
-    if (tid < T - 1) {
-        unsigned n = 0;
-        for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += sel[(size_t)tid * PT_COLS + cc];
-        if (n) atomicAdd(&A.swap_cnt[T - 2 - tid], n);           // pair i = T-1-j -> index i-1
-    }
-    // for T-1 > PT_THREADS pairs
-    for (int j = tid + PT_THREADS; j < T - 1; j += PT_THREADS) {
+    // Per-workgroup swap counts go to a private row with write-through (sc1) stores; the last
+    // workgroup to take a ticket reduces them.  No release fence: a buffer_wbl2 per workgroup
+    // writes back the whole XCD L2 and made this kernel 10x slower; device atomics on T-1
+    // counters sharing one cache line were no better (MI355X_MICROARCH: publish forms R1/R2).
+    for (int j = tid; j < T - 1; j += PT_THREADS) {
         unsigned n = 0;
         for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += sel[(size_t)j * PT_COLS + cc];
-        if (n) atomicAdd(&A.swap_cnt[T - 2 - j], n);
+        __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (T - 1) + (T - 2 - j)], (unsigned long long)n,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // pair i = T-1-j -> index i-1
     }
-
-    // last block: swap ratios -> ladder adaptation (tempering.py:563-596)
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(A.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    if (tid == 0) {
-        double* r = Lc;                       // reuse LDS: ratios[T-1]
-        double* bn = Lc + T;                  // new betas [T]
-        for (int j = 0; j < T - 1; ++j) {
-            const unsigned n = __hip_atomic_load(&A.swap_cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            A.swaps_last[j] = (double)n;
-            A.swaps_total[j] += (double)n;
-            r[j] = (double)n / (double)W;                         // :587
-            A.swap_cnt[j] = 0;
-        }
-        if (A.adapt && T > 1) {
-            const int64_t time = A.adapt_time[0];
-            if (A.stop_adaptation < 0 || time < A.stop_adaptation) {
-                const double decay = A.lag / ((double)time + A.lag);      // :571
-                const double kappa = decay / A.nu;                        // :572
-                double csum = 0.0;
-                const double inv0 = 1.0 / A.betas[0];
-                for (int k = 0; k < T; ++k) bn[k] = A.betas[k];
-                for (int j = 0; j + 2 < T; ++j) {
-                    const double dS = kappa * (r[j] - r[j + 1]);          // :575
-                    double dT = 1.0 / A.betas[j + 1] - 1.0 / A.betas[j];  // :578
-                    dT *= exp(dS);
-                    csum = (j == 0) ? dT : csum + dT;
-                    bn[j + 1] = 1.0 / (csum + inv0);                      // :580
-                }
-                for (int k = 1; k + 1 < T; ++k) A.betas[k] = A.betas[k] + (bn[k] - A.betas[k]);   // :583,:593
+    // every thread of the last block sums a slice of the per-workgroup rows into LDS counters
+    unsigned* cnt = reinterpret_cast<unsigned*>(lu);              // [T-1], lu is dead by now
+    for (int j = tid; j < T - 1; j += PT_THREADS) cnt[j] = 0;
+    __syncthreads();
+    {
+        // 8 independent agent-scope loads in flight per thread, then the LDS adds
+        const unsigned total = gridDim.x * (unsigned)(T - 1);
+        for (unsigned e0 = tid; e0 < total; e0 += 8 * PT_THREADS) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned e = e0 + q * PT_THREADS;
+                v[q] = (e < total) ? __hip_atomic_load(&A.swap_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
             }
-            A.adapt_time[0] = time + 1;                                   // :596
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned e = e0 + q * PT_THREADS;
+                if (v[q]) atomicAdd(&cnt[e % (unsigned)(T - 1)], (unsigned)v[q]);
+            }
         }
+    }
+    __syncthreads();
+    // Ladder adaptation, lane-parallel where the reference's arithmetic allows it (a single lane
+    // running T divisions + exps serially cost ~18 us): ratios, dS, deltaT per lane; the cumsum stays
+    // a sequential left-to-right sum like np.cumsum; the reciprocal and the update per lane again.
+    double* r = Lc;                           // ratios [T-1]
+    double* dT = Lc + T;                      // deltaTs, then their running sum [T-2]
+    const bool do_adapt = A.adapt && T > 1;
+    int64_t time = 0;
+    bool moving = false;
+    if (do_adapt) {
+        time = A.adapt_time[0];
+        moving = A.stop_adaptation < 0 || time < A.stop_adaptation;
+    }
+    for (int j = tid; j < T - 1; j += PT_THREADS) {
+        const double n = (double)cnt[j];
+        A.swaps_last[j] = n;
+        A.swaps_total[j] += n;
+        r[j] = n / (double)W;                                         // :587
+    }
+    __syncthreads();
+    if (moving) {
+        const double decay = A.lag / ((double)time + A.lag);          // :571
+        const double kappa = decay / A.nu;                            // :572
+        for (int j = tid; j + 2 < T; j += PT_THREADS) {
+            const double dS = kappa * (r[j] - r[j + 1]);              // :575
+            double d = 1.0 / sbeta[j + 1] - 1.0 / sbeta[j];           // :578
+            d *= exp(dS);
+            dT[j] = d;
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int j = 1; j + 2 < T; ++j) dT[j] = dT[j - 1] + dT[j];    // np.cumsum order
+        __syncthreads();
+        const double inv0 = 1.0 / sbeta[0];
+        for (int j = tid; j + 2 < T; j += PT_THREADS) {
+            const double bn = 1.0 / (dT[j] + inv0);                   // :580
+            A.betas[j + 1] = sbeta[j + 1] + (bn - sbeta[j + 1]);      // :583,:593
+        }
+    }
+    if (tid == 0) {
+        if (do_adapt) A.adapt_time[0] = time + 1;                     // :596
         if (A.tick) A.clock[0] += 1;
-        *A.ticket = 0;
+        __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

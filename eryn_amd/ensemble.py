@@ -1,0 +1,271 @@
+"""``EnsembleSampler`` with the reference's constructor / ``sample`` / ``run_mcmc`` contract
+(eryn/ensemble.py:211-681, 808-1125) for the stretch + parallel-tempering path, driving the
+MI355X engine.
+
+Two RNG modes:
+  rng="numpy"   the reference's streams (sampler-owned RandomState cloned from the global
+                ``np.random`` at construction + the global stream itself) drive the device
+                kernels -> same chain as Eryn for the same seeds (drop-in / parity mode).
+  rng="philox"  device-side counter-based Philox, ``thin_by`` iterations per host call with no
+                host round trip (production mode; statistically equivalent sampler).
+"""
+import numpy as np
+
+from .backend import Backend
+from .engine import HipEnsemble
+from .model import Model
+from .moves import StretchMove, TemperatureControl
+from .prior import ProbDistContainer
+from .state import State
+
+
+class EnsembleSampler:
+    def __init__(self, nwalkers, ndims, log_like_fn, priors, tempering_kwargs={}, branch_names=None,
+                 nleaves_max=1, moves=None, args=None, kwargs=None, backend=None, vectorize=True,
+                 fill_zero_leaves_val=-1e300, rng="numpy", seed=None, device_id=0, info={}, **unused):
+        # -- shapes: a single branch with one leaf (ensemble.py:265-317 normalises to dicts)
+        if isinstance(ndims, dict):
+            if len(ndims) != 1:
+                raise NotImplementedError("the device path handles a single branch")
+            branch_names = list(ndims.keys())
+            ndims = list(ndims.values())[0]
+        if isinstance(ndims, (list, tuple, np.ndarray)):
+            if len(ndims) != 1:
+                raise NotImplementedError("the device path handles a single branch")
+            ndims = int(ndims[0])
+        if isinstance(nleaves_max, dict):
+            nleaves_max = list(nleaves_max.values())[0]
+        if isinstance(nleaves_max, (list, tuple, np.ndarray)):
+            nleaves_max = int(nleaves_max[0])
+        if nleaves_max != 1:
+            raise NotImplementedError("the device path handles nleaves_max == 1 (RJ is a later row, SURVEY 8f-4)")
+        if not hasattr(log_like_fn, "_install"):
+            raise NotImplementedError(
+                "log_like_fn must be an eryn_amd.likelihood object (GaussianLikelihood, RosenbrockLikelihood): "
+                "the likelihood is evaluated inside the HIP kernel; arbitrary Python callables are not supported")
+        self.nwalkers, self.ndim = int(nwalkers), int(ndims)
+        self.branch_names = ["model_0"] if branch_names is None else list(branch_names)
+        self.ndims = {self.branch_names[0]: self.ndim}
+        self.nleaves_max = {self.branch_names[0]: 1}
+        self.log_like_fn = log_like_fn
+        self.fill_zero_leaves_val = fill_zero_leaves_val
+        self.rng = rng
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+
+        # -- priors (ensemble.py:334-348): dict of dists, a container, or {branch: container}
+        if isinstance(priors, dict) and self.branch_names[0] in priors:
+            priors = priors[self.branch_names[0]]
+        if isinstance(priors, dict):
+            priors = ProbDistContainer(priors)
+        if not hasattr(priors, "box_bounds"):
+            raise NotImplementedError("priors must be uniform box priors (eryn_amd.prior.ProbDistContainer)")
+        self.priors = {self.branch_names[0]: priors}
+        lo, hi = priors.box_bounds()
+
+        # -- tempering (ensemble.py:321-332): enabled iff tempering_kwargs != {}
+        if tempering_kwargs == {}:
+            self.temperature_control, self.ntemps = None, 1
+        else:
+            self.temperature_control = TemperatureControl(self.ndim, self.nwalkers, **tempering_kwargs)
+            self.ntemps = self.temperature_control.ntemps
+        tc = self.temperature_control
+
+        # -- moves (ensemble.py:350-378, 517-544)
+        if moves is None:
+            moves = [StretchMove(a=2.0)]
+        elif not isinstance(moves, (list, tuple)):
+            moves = [moves]
+        self.moves, weights = [], []
+        for m in moves:
+            m, w = m if isinstance(m, (list, tuple)) else (m, 1.0)
+            self.moves.append(m)
+            weights.append(w)
+        self.weights = np.atleast_1d(weights).astype(float)
+        self.weights /= np.sum(self.weights)
+
+        kw = {}
+        if tc is not None:
+            kw = dict(adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag, adaptation_time=tc.adaptation_time,
+                      stop_adaptation=tc.stop_adaptation)
+        live = any(getattr(m, "live_dangerously", False) for m in self.moves)
+        a_vals = {getattr(m, "a", 2.0) for m in self.moves}
+        if len(a_vals) != 1:
+            raise NotImplementedError("all device stretch moves must share one scale a")
+        if seed is None:
+            seed = int(np.random.randint(0, 2**31 - 1)) if rng == "philox" else 0
+        self.engine = HipEnsemble(self.ntemps, self.nwalkers, self.ndim, log_like_fn, lo, hi, a=a_vals.pop(),
+                                  tempered=tc is not None, live_dangerously=live,
+                                  fill_value=fill_zero_leaves_val, seed=seed, device_id=device_id, **kw)
+        for m in self.moves:
+            if not isinstance(m, StretchMove):
+                raise NotImplementedError("only eryn_amd.moves.StretchMove runs on the device path")
+            if m.temperature_control is None:
+                m.temperature_control = tc
+            m.attach_engine(self.engine)
+            m.trust_resident = True
+            m.accepted = np.zeros((self.ntemps, self.nwalkers))
+
+        # -- backend + RNG (ensemble.py:593-652)
+        self.backend = Backend() if backend is None else backend
+        if not self.backend.initialized:
+            self.backend.reset(self.nwalkers, self.ndims, ntemps=self.ntemps, branch_names=self.branch_names)
+        self._random = np.random.mtrand.RandomState()
+        self._random.set_state(np.random.get_state())       # R := snapshot of the global stream
+        self._previous_state = None
+
+    # -- reference accessors ----------------------------------------------------------------------
+    @property
+    def random_state(self):
+        return self._random.get_state()
+
+    @random_state.setter
+    def random_state(self, state):
+        try:
+            self._random.set_state(state)
+        except Exception:
+            pass
+
+    @property
+    def iteration(self):
+        return self.backend.iteration
+
+    @property
+    def acceptance_fraction(self):
+        return self.backend.accepted / float(max(self.backend.iteration, 1))
+
+    def get_model(self):
+        """ensemble.py:780-806."""
+        return Model(self.log_like_fn, self.compute_log_like, self.compute_log_prior,
+                     self.temperature_control, map, self._random)
+
+    def _eval(self, coords):
+        x = coords[self.branch_names[0]] if isinstance(coords, dict) else coords
+        x = np.asarray(x)
+        if x.ndim == 4:
+            x = x[:, :, 0, :]
+        tc = self.temperature_control
+        self.engine.upload(x, betas=None if tc is None else tc.betas)
+        self.engine.eval_state()
+        _, L, P, _ = self.engine.download(want_x=False)
+        for m in self.moves:
+            m._resident = None
+        return L, P
+
+    def compute_log_prior(self, coords, inds=None, supps=None, branch_supps=None):
+        """[ntemps, nwalkers] log-prior, evaluated on the device (ensemble.py:1127-1217)."""
+        return self._eval(coords)[1]
+
+    def compute_log_like(self, coords, inds=None, logp=None, supps=None, branch_supps=None):
+        """([ntemps, nwalkers] log-like, blobs=None), evaluated on the device (ensemble.py:1219-1545):
+        walkers outside the prior support are not evaluated and get ``fill_zero_leaves_val``."""
+        return self._eval(coords)[0], None
+
+    # -- main loop (ensemble.py:808-1045) ------------------------------------------------------------
+    def sample(self, initial_state, iterations=1, tune=False, skip_initial_state_check=True, thin_by=1,
+               store=True, progress=False):
+        state = State(initial_state, copy=True)
+        name = self.branch_names[0]
+        if state.branches[name].shape != (self.ntemps, self.nwalkers, 1, self.ndim):
+            raise ValueError("incompatible input dimensions")
+        if state.log_prior is None or state.log_like is None:
+            L, P = self._eval(state.branches_coords)
+            state.log_prior = P if state.log_prior is None else state.log_prior
+            state.log_like = L if state.log_like is None else state.log_like
+        tc = self.temperature_control
+        if tc is not None:
+            if state.betas is not None:
+                if state.betas.shape[0] != self.ntemps:
+                    raise ValueError("Input state has inverse temperatures (betas), but not the correct number.")
+                tc.betas = state.betas.copy()
+            else:
+                state.betas = tc.betas.copy()
+        if np.any(np.isinf(state.log_like)):
+            raise ValueError("The initial log_like was +/- infinite")
+        if np.any(np.isinf(state.log_prior)):
+            raise ValueError("The initial log_prior was +/- infinite")
+        if np.any(np.isnan(state.log_like)) or np.any(np.isnan(state.log_prior)):
+            raise ValueError("The initial log_like / log_prior was NaN")
+        thin_by = int(thin_by)
+        if thin_by <= 0:
+            raise ValueError("Invalid thinning argument")
+        if store:
+            self.backend.grow(iterations, None)
+        model = self.get_model()
+
+        if self.rng == "philox":
+            yield from self._sample_philox(state, iterations, thin_by, store)
+            return
+
+        for _ in range(iterations):
+            for _ in range(thin_by):
+                accepted = np.zeros((self.ntemps, self.nwalkers))
+                move = self._random.choice(self.moves, p=self.weights)          # ensemble.py:971
+                state, accepted_out = move.propose(model, state)
+                accepted += accepted_out
+                swaps = tc.swaps_accepted if self.ntemps > 1 else None
+                state.random_state = self.random_state
+            if store:
+                self.backend.save_step(state, accepted, swaps_accepted=swaps)
+            self._previous_state = state
+            yield state
+
+    def _sample_philox(self, state, iterations, thin_by, store):
+        eng, tc, name = self.engine, self.temperature_control, self.branch_names[0]
+        eng.upload(state.branches[name].coords[:, :, 0, :], state.log_like, state.log_prior,
+                   None if tc is None else tc.betas)
+        if tc is not None:
+            eng.set_adapt_time(tc.time)
+        move = self.moves[0]
+        prev = eng.counters()
+        inds = state.branches[name].inds
+        for _ in range(iterations):
+            eng.step(thin_by)
+            x, L, P, betas = eng.download()
+            c = eng.counters()
+            accepted = c["accepted"] - prev["accepted"]
+            move.accepted += accepted
+            move.num_proposals += thin_by
+            swaps = None
+            if tc is not None:
+                tc.betas = betas
+                tc.time = c["adapt_time"]
+                tc.swaps_accepted = c["swaps_last"]
+                swaps = c["swaps_total"] - prev["swaps_total"]
+            prev = c
+            state = State({name: x[:, :, None, :]}, inds={name: inds}, log_like=L, log_prior=P,
+                          betas=None if tc is None else betas, random_state=None)
+            if store:
+                self.backend.save_step(state, accepted, swaps_accepted=swaps)
+            self._previous_state = state
+            yield state
+
+    def run_mcmc(self, initial_state, nsteps, burn=None, post_burn_update=False, **kwargs):
+        """ensemble.py:1047-1125."""
+        if initial_state is None:
+            if self._previous_state is None:
+                raise ValueError("Cannot have `initial_state=None` if run_mcmc has never been called.")
+            initial_state = self._previous_state
+        if burn is not None and burn != 0:
+            bk = dict(kwargs)
+            bk.update(store=False, thin_by=1)
+            for initial_state in self.sample(initial_state, iterations=burn, **bk):
+                pass
+        results = None
+        for results in self.sample(initial_state, iterations=nsteps, **kwargs):
+            pass
+        self._previous_state = results
+        return results
+
+    # -- chain accessors --------------------------------------------------------------------------
+    def get_chain(self, **kw):
+        return self.backend.get_chain(**kw)
+
+    def get_log_like(self, **kw):
+        return self.backend.get_log_like(**kw)
+
+    def get_log_prior(self, **kw):
+        return self.backend.get_log_prior(**kw)
+
+    def get_betas(self, **kw):
+        return self.backend.get_betas(**kw)

@@ -202,6 +202,12 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
  * rank order), scatter the received rows and finish the permutation of logl/logp/loc. */
 int hens_pt_finish_sharded(hens_ctx* ctx);
 
+/* Debug: per-workgroup phase timestamps of the stretch kernel (shader-clock ticks, 8 per
+ * workgroup: start, A done, barrier, B done, barrier, C done, D done, end).  enable != 0 makes
+ * the following stretch launches record; enable == 0 copies the last launch's trace to `out`
+ * (capacity in 64-bit words) and stops recording.  *n_out = words written. */
+int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capacity, int64_t* n_out);
+
 /* Static description of the build. */
 const char* hens_version(void);
 int hens_device_count(void);
