@@ -35,8 +35,8 @@ class HensTiming(C.Structure):
 
 class HensDeviceBuffers(C.Structure):
     _fields_ = [
-        ("logl", C.c_void_p), ("logp", C.c_void_p), ("gather_logl", C.c_void_p), ("gather_logp", C.c_void_p),
-        ("send_rows", C.c_void_p), ("recv_rows", C.c_void_p), ("row_capacity", C.c_int64), ("stream", C.c_void_p),
+        ("logl", C.c_void_p), ("gather_logl", C.c_void_p), ("send_rows", C.c_void_p), ("recv_rows", C.c_void_p),
+        ("row_capacity", C.c_int64), ("row_doubles", C.c_int64), ("stream", C.c_void_p),
     ]
 
 
@@ -63,8 +63,9 @@ SIGNATURES = {
     "hens_get_timing": (C.c_int, [_P, C.POINTER(HensTiming)]),
     "hens_get_device_buffers": (C.c_int, [_P, C.POINTER(HensDeviceBuffers)]),
     "hens_set_stream": (C.c_int, [_P, _P]),
-    "hens_pt_plan_sharded": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
-    "hens_pt_finish_sharded": (C.c_int, [_P]),
+    "hens_stretch_iter": (C.c_int, [_P]),
+    "hens_pt_plan_sharded": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "hens_pt_finish_sharded": (C.c_int, [_P, C.c_int64]),
     "hens_debug_trace": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     "hens_version": (C.c_char_p, []),
     "hens_device_count": (C.c_int, []),

@@ -66,7 +66,8 @@ struct hens_ctx_impl {
     double* gather_L = nullptr; double* gather_P = nullptr;
     double* send_rows = nullptr; double* recv_rows = nullptr;
     int32_t* srcglob = nullptr; int32_t* send_slots = nullptr; int32_t* recv_slots = nullptr;
-    int64_t* d_counts = nullptr;     // [2*MAXR]
+    int64_t* d_counts = nullptr;     // scratch: counts + cursors
+    int32_t* d_rank_of = nullptr;    // [T]
     int64_t row_capacity = 0;
     int64_t n_send = 0, n_recv = 0;
     bool pt_pending = false;
@@ -406,7 +407,7 @@ void hens_destroy(hens_ctx* ctx) {
                     c->lo, c->hi, c->mu, c->prec, c->order, c->d_rint, c->d_uzz, c->d_uacc, c->d_keep,
                     c->d_iperm, c->d_i1perm, c->d_uswap, c->d_inv, c->colslot, c->colk, c->colu, c->selcol,
                     c->selk, c->xtmp, c->gather_L, c->gather_P, c->send_rows, c->recv_rows, c->srcglob,
-                    c->send_slots, c->recv_slots, c->d_counts, c->d_trace};
+                    c->send_slots, c->recv_slots, c->d_counts, c->d_trace, c->d_rank_of};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -824,17 +825,167 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
     return HENS_OK;
 }
 
+static int ensure_shard_buffers(hens_ctx_impl* c) {
+    if (c->gather_L) return HENS_OK;
+    const size_t TW = (size_t)c->T * c->W, cap = (size_t)c->Tl * c->W;
+    int r;
+    if ((r = dalloc(c, &c->gather_L, TW))) return r;
+    if ((r = dalloc(c, &c->srcglob, TW))) return r;
+    if ((r = dalloc(c, &c->send_rows, cap * (c->D + 2)))) return r;
+    if ((r = dalloc(c, &c->recv_rows, cap * (c->D + 2)))) return r;
+    if ((r = dalloc(c, &c->send_slots, cap))) return r;
+    if ((r = dalloc(c, &c->recv_slots, cap))) return r;       // used as send_dest
+    if ((r = dalloc(c, &c->d_counts, 4 * MAX_RANKS))) return r;
+    c->row_capacity = (int64_t)cap;
+    return HENS_OK;
+}
+
 int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
-    return fail(c, HENS_ERR_UNSUPPORTED, "sharded ladder buffers not built yet");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int r = ensure_shard_buffers(c);
+    if (r) return r;
+    out->logl = c->L[c->cur];
+    out->gather_logl = c->gather_L;
+    out->send_rows = c->send_rows;
+    out->recv_rows = c->recv_rows;
+    out->row_capacity = c->row_capacity;
+    out->row_doubles = c->D + 2;
+    out->stream = c->stream;
+    return HENS_OK;
 }
 
-int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t*, const int64_t*, const double*, int32_t, const int32_t*, int32_t,
-                         int64_t*, int64_t*, uint8_t*, double*) {
-    return fail(CTX(ctx), HENS_ERR_UNSUPPORTED, "sharded PT not built yet");
+int hens_stretch_iter(hens_ctx* ctx) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_stretch_iter between split 0 and split 1");
+    if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int Tl = c->Tl, W = c->W;
+    c->N0 = (W + 1) / 2;
+    PlanArgs pa{};
+    pa.order = c->order; pa.colslot = c->colslot; pa.clock = c->clock; pa.seed = c->cfg.seed;
+    pa.Tl = Tl; pa.T = c->T; pa.W = W; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
+    pa.n_split = Tl; pa.jobs_per_iter = Tl; pa.idx_bits = c->idx_bits;
+    hipLaunchKernelGGL(k_plan, dim3(Tl), dim3(std::min(1024, std::max(64, c->NP2 / 2))), (size_t)c->NP2 * 8, c->stream, pa);
+    for (int split = 0; split < 2; ++split) {
+        StretchArgs a = base_args(c);
+        a.split = split;
+        a.home_off = c->parity * Tl * W;
+        const int Ns = split == 0 ? c->N0 : W - c->N0;
+        r = launch_stretch<MODE_PHILOX>(c, a, (Ns + TILE - 1) / TILE);
+        if (r) return r;
+    }
+    c->parity ^= 1;
+    c->num_proposals += 1;
+    if (!(c->cfg.tempered && c->T > 1)) hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, c->stream, c->clock);
+    HIPCHK(c, hipGetLastError());
+    return HENS_OK;
 }
 
-int hens_pt_finish_sharded(hens_ctx* ctx) { return fail(CTX(ctx), HENS_ERR_UNSUPPORTED, "sharded PT not built yet"); }
+int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, const double* u_swap,
+                         int32_t adapt, const int32_t* rank_of_rung, int32_t nranks, int32_t my_rank,
+                         int64_t* send_counts, int64_t* recv_counts, uint8_t* sel_out, double* swaps_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (!c->cfg.tempered || c->T < 2) return fail(c, HENS_ERR_STATE, "context is not tempered");
+    if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "PT sweep between split 0 and split 1");
+    if (c->pt_pending) return fail(c, HENS_ERR_STATE, "previous sharded PT exchange not finished");
+    if (!rank_of_rung || !send_counts || !recv_counts) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (nranks < 1 || nranks > MAX_RANKS || my_rank < 0 || my_rank >= nranks)
+        return fail(c, HENS_ERR_INVALID, "nranks must be in [1, %d] and my_rank inside it", MAX_RANKS);
+    const bool parity_draws = iperm != nullptr;
+    if (parity_draws && (!i1perm || !u_swap)) return fail(c, HENS_ERR_INVALID, "give iperm, i1perm and u_swap together");
+    const int T = c->T, W = c->W, Tl = c->Tl;
+    for (int t = 0; t < T; ++t) {
+        if (rank_of_rung[t] < 0 || rank_of_rung[t] >= nranks) return fail(c, HENS_ERR_INVALID, "rank_of_rung out of range");
+        const bool mine = t >= c->cfg.rung_begin && t < c->cfg.rung_end;
+        if (mine != (rank_of_rung[t] == my_rank)) return fail(c, HENS_ERR_INVALID, "rank_of_rung disagrees with this context's shard");
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    if ((r = ensure_shard_buffers(c))) return r;
+    if ((r = ensure_pt_buffers(c))) return r;
+    const size_t PW = (size_t)(T - 1) * W;
+    if (!c->d_rank_of) { if ((r = dalloc(c, &c->d_rank_of, (size_t)T))) return r; }
+    HIPCHK(c, hipMemcpyAsync(c->d_rank_of, rank_of_rung, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
+    PtArgs p = pt_args(c, c->colslot, true);
+    p.adapt = (adapt && c->cfg.adaptive) ? 1 : 0;
+    p.tick = 0;                                   // the clock advances in hens_pt_finish_sharded
+    p.selcol = c->selcol;
+    if (parity_draws) {
+        HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_pt_invert, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->d_iperm, c->d_inv, T - 1, W);
+        hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm,
+                           c->d_inv, c->d_uswap, c->colslot, c->colk, c->colu, T, W);
+        p.colu = c->colu;
+        hipLaunchKernelGGL(k_pt_cascade<false>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS), pt_lds_bytes(T),
+                           c->stream, p);
+        hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk,
+                           c->selk, T - 1, W);
+    } else {
+        PlanArgs pa{};
+        pa.order = c->order; pa.colslot = c->colslot; pa.clock = c->clock; pa.seed = c->cfg.seed;
+        pa.Tl = Tl; pa.T = T; pa.W = W; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
+        pa.n_split = 0; pa.jobs_per_iter = T; pa.idx_bits = c->idx_bits;
+        hipLaunchKernelGGL(k_plan, dim3(T), dim3(std::min(1024, std::max(64, c->NP2 / 2))), (size_t)c->NP2 * 8, c->stream, pa);
+        hipLaunchKernelGGL(k_pt_cascade<true>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS), pt_lds_bytes(T),
+                           c->stream, p);
+    }
+    // who sends what to whom
+    unsigned* counts = reinterpret_cast<unsigned*>(c->d_counts);
+    HIPCHK(c, hipMemsetAsync(counts, 0, 2 * MAX_RANKS * sizeof(unsigned), c->stream));
+    const int g = grid_for((int64_t)T * W);
+    hipLaunchKernelGGL(k_xchg_count, dim3(g), dim3(256), 0, c->stream, c->srcglob, c->d_rank_of, T, W, (int)my_rank, counts);
+    unsigned hc[2 * MAX_RANKS];
+    HIPCHK(c, hipMemcpyAsync(hc, counts, sizeof hc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned cursors[MAX_RANKS] = {0};
+    int64_t nsend = 0, nrecv = 0;
+    for (int q = 0; q < nranks; ++q) {
+        cursors[q] = (unsigned)nsend;
+        send_counts[q] = hc[q];
+        recv_counts[q] = hc[MAX_RANKS + q];
+        nsend += hc[q];
+        nrecv += hc[MAX_RANKS + q];
+    }
+    if (nsend > c->row_capacity || nrecv > c->row_capacity) return fail(c, HENS_ERR_STATE, "exchange exceeds row capacity");
+    unsigned* d_cursors = counts + 2 * MAX_RANKS;
+    HIPCHK(c, hipMemcpyAsync(d_cursors, cursors, sizeof cursors, hipMemcpyHostToDevice, c->stream));
+    if (nsend > 0) {
+        hipLaunchKernelGGL(k_xchg_fill, dim3(g), dim3(256), 0, c->stream, c->srcglob, c->d_rank_of, T, W, (int)my_rank,
+                           (int)c->cfg.rung_begin, d_cursors, c->send_slots, c->recv_slots);
+        hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(nsend * (c->D + 2))), dim3(256), 0, c->stream, c->pool,
+                           c->loc[c->cur], c->P[c->cur], c->send_slots, c->recv_slots, c->send_rows, nsend, c->D);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (sel_out && parity_draws) HIPCHK(c, hipMemcpyAsync(sel_out, c->selk, PW, hipMemcpyDeviceToHost, c->stream));
+    if (swaps_out) HIPCHK(c, hipMemcpyAsync(swaps_out, c->swaps_last, (size_t)(T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_send = nsend; c->n_recv = nrecv;
+    c->pt_pending = true;
+    return HENS_OK;
+}
+
+int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (!c->pt_pending) return fail(c, HENS_ERR_STATE, "no sharded PT exchange in flight");
+    if (n_recv != c->n_recv) return fail(c, HENS_ERR_INVALID, "expected %lld received rows, got %lld", (long long)c->n_recv, (long long)n_recv);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    if (n_recv > 0)
+        hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(n_recv * (c->D + 2))), dim3(256), 0, c->stream, c->pool,
+                           c->loc[c->cur ^ 1], c->P[c->cur ^ 1], c->recv_rows, n_recv, c->D, c->W,
+                           (int)c->cfg.rung_begin, (int32_t)(c->parity * c->Tl * c->W));
+    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, c->stream, c->clock);
+    HIPCHK(c, hipGetLastError());
+    c->cur ^= 1;
+    c->pt_pending = false;
+    return HENS_OK;
+}
 
 }  // extern "C"

@@ -1006,34 +1006,75 @@ __global__ void k_pt_sel_to_korder(const uint8_t* __restrict__ selcol, const int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sharded ladder: rows that change rank.
-//   send list entry e: local slot (tl, w) whose walker leaves -> packed as [x row | logl | logp]
-//   recv list entry e: local slot that receives it; the row lands in that slot's free home row.
+// Sharded ladder: rows that change rank.  Every rank replays the whole cascade from the
+// all-gathered log-likelihoods, so every rank knows srcfull[t][w] = global slot the walker arriving
+// at (t, w) comes from.  A row travels as D + 2 doubles: [destination global slot id (bit pattern) |
+// x[0..D) | log-prior]; its log-likelihood is already in the gathered ladder.
 // ---------------------------------------------------------------------------------------------
+constexpr int MAX_RANKS = 16;
+
+// counts[0..nranks) = rows this rank sends to each peer, counts[MAX_RANKS..) = rows it receives
+__global__ void k_xchg_count(const int32_t* __restrict__ srcfull, const int32_t* __restrict__ rank_of_rung,
+                             int T, int W, int me, unsigned* __restrict__ counts) {
+    __shared__ unsigned s_cnt[2 * MAX_RANKS];
+    if (threadIdx.x < 2 * MAX_RANKS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t n = (int64_t)T * W;
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+        const int src = srcfull[g];
+        const int dr = rank_of_rung[g / W], sr = rank_of_rung[src / W];
+        if (dr != sr) {
+            if (sr == me) atomicAdd(&s_cnt[dr], 1u);
+            if (dr == me) atomicAdd(&s_cnt[MAX_RANKS + sr], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * MAX_RANKS && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// cursors[p] starts at the offset of peer p's segment in the send buffer
+__global__ void k_xchg_fill(const int32_t* __restrict__ srcfull, const int32_t* __restrict__ rank_of_rung,
+                            int T, int W, int me, int rung_begin, unsigned* __restrict__ cursors,
+                            int32_t* __restrict__ send_slot, int32_t* __restrict__ send_dest) {
+    const int64_t n = (int64_t)T * W;
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+        const int src = srcfull[g];
+        const int dr = rank_of_rung[g / W], sr = rank_of_rung[src / W];
+        if (dr != sr && sr == me) {
+            const unsigned pos = atomicAdd(&cursors[dr], 1u);
+            send_slot[pos] = src - rung_begin * W;       // local slot of the leaving walker
+            send_dest[pos] = (int32_t)g;
+        }
+    }
+}
+
 __global__ void k_pack_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
-                            const double* __restrict__ L, const double* __restrict__ P,
-                            const int32_t* __restrict__ send_slots, double* __restrict__ out,
-                            int64_t nsend, int D) {
+                            const double* __restrict__ P, const int32_t* __restrict__ send_slot,
+                            const int32_t* __restrict__ send_dest, double* __restrict__ out, int64_t nsend, int D) {
     const int64_t total = nsend * (D + 2);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = i / (D + 2);
         const int d = (int)(i - e * (D + 2));
-        const int slot = send_slots[e];
-        out[i] = (d < D) ? pool[(size_t)loc[slot] * D + d] : (d == D ? L[slot] : P[slot]);
+        const int slot = send_slot[e];
+        double v;
+        if (d == 0) v = __longlong_as_double((long long)send_dest[e]);
+        else if (d <= D) v = pool[(size_t)loc[slot] * D + (d - 1)];
+        else v = P[slot];
+        out[i] = v;
     }
 }
 
-__global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ locnew,
-                              double* __restrict__ Pnew, const int32_t* __restrict__ recv_slots,
-                              const double* __restrict__ in, int64_t nrecv, int D, int32_t free_off) {
+__global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ locnew, double* __restrict__ Pnew,
+                              const double* __restrict__ in, int64_t nrecv, int D, int W, int rung_begin,
+                              int32_t free_off) {
     const int64_t total = nrecv * (D + 2);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = i / (D + 2);
         const int d = (int)(i - e * (D + 2));
-        const int slot = recv_slots[e];
-        if (d < D) pool[(size_t)(free_off + slot) * D + d] = in[i];
-        else if (d == D + 1) Pnew[slot] = in[i];
-        else locnew[slot] = free_off + slot;
+        const int slot = (int)__double_as_longlong(in[e * (D + 2)]) - rung_begin * W;
+        if (d == 0) locnew[slot] = free_off + slot;
+        else if (d <= D) pool[(size_t)(free_off + slot) * D + (d - 1)] = in[i];
+        else Pnew[slot] = in[i];
     }
 }
 

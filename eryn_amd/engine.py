@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import HensConfig, HensTiming, check, f64, ptr
+from ._lib import HensConfig, HensDeviceBuffers, HensTiming, check, f64, ptr
 
 
 def box_logp_inside(lo, hi):
@@ -136,3 +136,36 @@ class HipEnsemble:
         t = HensTiming()
         check(self.lib.hens_get_timing(self.ctx, C.byref(t)), self.ctx)
         return {k: getattr(t, k) for k, _ in HensTiming._fields_}
+
+    # -- ladder sharding (eryn_amd/ladder.py) ----------------------------------------------------------
+    def stretch_iter(self):
+        """One Philox iteration of both halves on the resident rungs (asynchronous, no PT)."""
+        check(self.lib.hens_stretch_iter(self.ctx), self.ctx)
+
+    def device_buffers(self):
+        b = HensDeviceBuffers()
+        check(self.lib.hens_get_device_buffers(self.ctx, C.byref(b)), self.ctx)
+        return b
+
+    def pt_plan_sharded(self, rank_of_rung, nranks, my_rank, iperm=None, i1perm=None, u_swap=None, adapt=True):
+        rank_of_rung = np.ascontiguousarray(rank_of_rung, dtype=np.int32)
+        if rank_of_rung.shape != (self.T,):
+            raise ValueError("rank_of_rung must have shape (ntemps,)")
+        shp = (self.T - 1, self.W)
+        if iperm is not None:
+            iperm = np.ascontiguousarray(iperm, dtype=np.int64)
+            i1perm = np.ascontiguousarray(i1perm, dtype=np.int64)
+            u_swap = f64(u_swap, shp)
+            if iperm.shape != shp or i1perm.shape != shp:
+                raise ValueError(f"iperm/i1perm must have shape {shp}")
+        send = np.zeros(nranks, dtype=np.int64)
+        recv = np.zeros(nranks, dtype=np.int64)
+        sel = np.zeros(shp, dtype=np.uint8)
+        swaps = np.zeros(self.T - 1)
+        check(self.lib.hens_pt_plan_sharded(self.ctx, ptr(iperm), ptr(i1perm), ptr(u_swap), int(bool(adapt)),
+                                            ptr(rank_of_rung), int(nranks), int(my_rank), ptr(send), ptr(recv),
+                                            ptr(sel), ptr(swaps)), self.ctx)
+        return send, recv, sel.astype(bool), swaps
+
+    def pt_finish_sharded(self, n_recv):
+        check(self.lib.hens_pt_finish_sharded(self.ctx, int(n_recv)), self.ctx)

@@ -1,1 +1,225 @@
-"""Ladder sharding across GPUs (one process per GPU).  Filled in below."""
+"""Temperature-ladder sharding across the GPUs of one node (one process per GPU).
+
+Rank g owns the contiguous rungs [g*Tl, (g+1)*Tl).  Per iteration:
+
+  1. stretch move on the local rungs                     no communication
+     (complement walkers are drawn inside a rung, red_blue.py:183-193)
+  2. all-gather of the log-likelihoods  [Tl, W] -> [T, W]            RCCL all_gather
+  3. EVERY rank replays the whole hot->cold swap cascade (tempering.py:484-561) from the
+     gathered ladder.  In the column form used by the HIP kernel the T-1 sequential pairs
+     collapse into one parallel kernel, so the redundant replay is cheaper than a chain of
+     T/Tl dependent neighbour hand-offs; all ranks reach identical decisions and identical
+     adapted betas without a further collective.
+  4. walker rows that change rank travel as [dest id | x | logp] records    RCCL all_to_all
+  5. received rows are scattered into free pool slots.
+
+The communication layer is ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  The compute engine is injected: the product uses
+:class:`HipShardEngine`; the CPU tests drive the same orchestration with a NumPy stand-in.
+"""
+import numpy as np
+
+
+def rung_partition(ntemps, nranks):
+    """Contiguous equal shards; returns (rank_of_rung[T], [(begin, end)] per rank)."""
+    if ntemps % nranks != 0:
+        raise ValueError("ntemps must be a multiple of the number of ranks (T < G: use replicas instead)")
+    tl = ntemps // nranks
+    bounds = [(g * tl, (g + 1) * tl) for g in range(nranks)]
+    return np.repeat(np.arange(nranks, dtype=np.int32), tl), bounds
+
+
+class _DevArray:
+    """Expose a raw device pointer through __cuda_array_interface__ so torch can wrap it."""
+
+    def __init__(self, ptr, shape, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+class HipShardEngine:
+    """The HIP engine seen through the small interface ShardedLadder needs."""
+
+    def __init__(self, engine, device):
+        import torch
+        self.torch = torch
+        self.e = engine
+        self.device = device
+        self.T, self.Tl, self.W, self.D = engine.T, engine.Tl, engine.W, engine.D
+        b = engine.device_buffers()
+        self.row_doubles = int(b.row_doubles)
+        self.cap = int(b.row_capacity)
+        self._gather = torch.as_tensor(_DevArray(b.gather_logl, (self.T, self.W)), device=device)
+        self._send = torch.as_tensor(_DevArray(b.send_rows, (self.cap, self.row_doubles)), device=device)
+        self._recv = torch.as_tensor(_DevArray(b.recv_rows, (self.cap, self.row_doubles)), device=device)
+
+    def stretch(self, draws=None):
+        if draws is None:
+            self.e.stretch_iter()
+            return None
+        keeps = []
+        for sp in (0, 1):
+            keeps.append(self.e.stretch_split(sp, draws["labels"], draws[f"rint{sp}"], draws[f"u_zz{sp}"],
+                                              draws[f"u_acc{sp}"]))
+        return keeps
+
+    def local_logl(self):
+        b = self.e.device_buffers()                     # the current buffer flips every PT step
+        self.e.synchronize()                            # library stream -> visible to the comm stream
+        return self.torch.as_tensor(_DevArray(b.logl, (self.Tl, self.W)), device=self.device)
+
+    def gather_buffer(self):
+        return self._gather
+
+    def plan(self, rank_of_rung, nranks, rank, draws=None, adapt=True):
+        kw = {} if draws is None else dict(iperm=draws["iperm"], i1perm=draws["i1perm"], u_swap=draws["u_swap"])
+        send, recv, sel, swaps = self.e.pt_plan_sharded(rank_of_rung, nranks, rank, adapt=adapt, **kw)
+        return send, recv, sel, swaps
+
+    def send_buffer(self, n):
+        return self._send[:n]
+
+    def recv_buffer(self, n):
+        return self._recv[:n]
+
+    def finish(self, n_recv):
+        self.e.pt_finish_sharded(n_recv)
+
+
+class ShardedLadder:
+    """Drives one rank's shard.  ``dist`` is torch.distributed (already initialised)."""
+
+    def __init__(self, engine, ntemps, dist=None, rank=0, nranks=1, group=None):
+        self.eng, self.T = engine, int(ntemps)
+        self.dist, self.rank, self.nranks, self.group = dist, int(rank), int(nranks), group
+        self.rank_of_rung, self.bounds = rung_partition(self.T, self.nranks)
+        self.swaps_accepted = np.zeros(self.T - 1)
+
+    def pt_step(self, draws=None, adapt=True):
+        """Steps 2-5.  Returns (sel or None, swaps_accepted)."""
+        eng, dist = self.eng, self.dist
+        local = eng.local_logl()
+        full = eng.gather_buffer()
+        if self.nranks > 1:
+            dist.all_gather_into_tensor(full.view(-1), local.reshape(-1), group=self.group)
+        else:
+            full.copy_(local)
+        self._sync_comm()
+        send, recv, sel, swaps = eng.plan(self.rank_of_rung, self.nranks, self.rank, draws=draws, adapt=adapt)
+        n_send, n_recv = int(send.sum()), int(recv.sum())
+        if self.nranks > 1:
+            out_buf, in_buf = eng.recv_buffer(n_recv), eng.send_buffer(n_send)
+            self._all_to_all(out_buf, in_buf, recv, send)
+            self._sync_comm()
+        eng.finish(n_recv)
+        self.swaps_accepted = swaps
+        return sel, swaps
+
+    def _all_to_all(self, out_buf, in_buf, recv_counts, send_counts):
+        """Variable all-to-all of rows.  all_to_all_single where the backend has it (RCCL);
+        pairwise isend/irecv otherwise (gloo on CPU)."""
+        dist = self.dist
+        backend = dist.get_backend(self.group)
+        if backend == "nccl":
+            dist.all_to_all_single(out_buf, in_buf, output_split_sizes=[int(c) for c in recv_counts],
+                                   input_split_sizes=[int(c) for c in send_counts], group=self.group)
+            return
+        reqs, so, ro = [], 0, 0
+        ops = []
+        for peer in range(self.nranks):
+            ns, nr = int(send_counts[peer]), int(recv_counts[peer])
+            if peer != self.rank:
+                if ns:
+                    ops.append(dist.P2POp(dist.isend, in_buf[so:so + ns].contiguous(), peer, group=self.group))
+                if nr:
+                    ops.append(dist.P2POp(dist.irecv, out_buf[ro:ro + nr], peer, group=self.group))
+            so += ns
+            ro += nr
+        if ops:
+            reqs = dist.batch_isend_irecv(ops)
+            for r in reqs:
+                r.wait()
+
+    def _sync_comm(self):
+        eng = self.eng
+        if hasattr(eng, "torch") and eng.torch.cuda.is_available():
+            eng.torch.cuda.current_stream().synchronize()
+
+    def step(self, n_iters=1, adapt=True):
+        """Production (Philox) iterations."""
+        for _ in range(int(n_iters)):
+            self.eng.stretch()
+            if self.T > 1:
+                self.pt_step(adapt=adapt)
+
+
+def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
+    """N-GPU leg of bench.py: weak scaling, 8 rungs of config 3 per GPU."""
+    import json
+    import os
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from .engine import HipEnsemble
+    from .likelihood import GaussianLikelihood
+    from .moves.tempering import make_ladder
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=device)
+    T, W, D = args.ntemps, args.nwalkers, args.ndim
+    _, bounds = rung_partition(T, world)
+    r0, r1 = bounds[rank]
+    mu, invcov = gaussian_problem(D)
+    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=(r0, r1),
+                      device_id=local_rank)
+    x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
+    eng.upload(x0, betas=make_ladder(D, ntemps=T))
+    eng.eval_state()
+    lad = ShardedLadder(HipShardEngine(eng, device), T, dist=dist if world > 1 else None, rank=rank, nranks=world)
+    lad.step(args.warmup)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lad.step(args.steps)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    c = eng.counters()
+    f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps + args.warmup, 1)))
+    value = T * W * args.steps / dt
+    out = None
+    if rank == 0:
+        whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
+        out = {
+            "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Gaussian logL",
+            "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config 3 shard: ntemps={T} ({T // world} rungs/GPU), nwalkers={W}, ndim={D} "
+                                   f"dense-covariance Gaussian, ladder sharded, RCCL all-gather(logL) + all-to-all(rows)",
+                       "ntemps": T, "nwalkers": W, "ndim": D, "parallelism": f"ladder-shard x{world}",
+                       "swap_fraction": f_sw},
+            "roofline": {"bound": "hbm", "kernel": "whole path (per GPU)", "achieved": whole / world, "peak": hbm_peak,
+                         "unit": "GB/s", "frac": whole / world / hbm_peak, "traffic": None},
+        }
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return out

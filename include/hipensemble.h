@@ -164,43 +164,45 @@ typedef struct hens_timing {
 int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events);
 int hens_get_timing(hens_ctx* ctx, hens_timing* out);
 
-/* Ladder sharding (one context per GPU, rungs [rung_begin, rung_end)).  The stretch
+/* Ladder sharding (one context per GPU, rungs [rung_begin, rung_end), SURVEY 8e).  The stretch
  * step needs no communication (complement walkers are drawn within a rung,
- * red_blue.py:183-193).  For the PT cascade every rank needs all log-likelihoods:
- *   hens_device_buffers     device pointers of the resident logl/logp rows and of
- *                           staging buffers, so the caller can all-gather them with
- *                           RCCL (torch.distributed) without a host copy.
- *   hens_pt_plan_sharded    replay the full T-1 pair cascade from the gathered
- *                           logl[T][W] (device pointer), decide every swap, update
- *                           betas, and report which walker rows must travel.
- *   hens_pt_pack / _unpack  gather outgoing rows (+ their logl, logp) into a send
- *                           buffer / scatter received rows into free pool slots.
- * See eryn_amd/ladder.py for the protocol and DESIGN.md section 6. */
+ * red_blue.py:183-193).  The PT cascade (tempering.py:484-561) is replayed by EVERY rank from the
+ * all-gathered log-likelihoods: in column form it is one cheap parallel kernel, and identical
+ * decisions / betas on all ranks need no further agreement.  Only walker rows that change rank
+ * travel (an all-to-all of [dest id | x | logp] records).  Protocol per iteration, see
+ * eryn_amd/ladder.py:
+ *   hens_stretch_iter (or two hens_stretch_split calls)     local, no communication
+ *   all-gather  device_buffers.logl -> device_buffers.gather_logl           (RCCL)
+ *   hens_pt_plan_sharded     decisions, betas, send buffer packed, per-peer counts returned
+ *   all-to-all  send_rows -> recv_rows with those counts                    (RCCL)
+ *   hens_pt_finish_sharded   received rows scattered into free pool slots, buffers swapped */
 typedef struct hens_device_buffers {
-    void* logl;          /* f64 [Tl][W] resident rows (current buffer)            */
-    void* logp;          /* f64 [Tl][W]                                           */
-    void* gather_logl;   /* f64 [T][W] staging for the all-gathered ladder        */
-    void* gather_logp;   /* f64 [T][W]                                            */
-    void* send_rows;     /* f64 [send_capacity][D + 2] outgoing rows              */
-    void* recv_rows;     /* f64 [recv_capacity][D + 2] incoming rows              */
+    void* logl;          /* f64 [Tl][W] resident rungs (current buffer; changes every PT step) */
+    void* gather_logl;   /* f64 [T][W] staging for the all-gathered ladder                     */
+    void* send_rows;     /* f64 [row_capacity][D + 2], segments in peer order                  */
+    void* recv_rows;     /* f64 [row_capacity][D + 2]                                          */
     int64_t row_capacity;
-    void* stream;        /* hipStream_t the library launches on                   */
+    int64_t row_doubles; /* D + 2                                                              */
+    void* stream;        /* hipStream_t the library launches on                                */
 } hens_device_buffers;
 int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out);
 int hens_set_stream(hens_ctx* ctx, void* hip_stream);
 
-/* Sharded PT, step 1: decisions from the gathered ladder.  Draws come either from the
- * caller (parity: iperm/i1perm/u_swap as in hens_pt_sweep, may be NULL for Philox mode).
- * Outputs (host): send_counts[nranks], recv_counts[nranks] rows per peer given the
- * rung ownership table rank_of_rung[T]; sel_out/swaps_accepted_out as in hens_pt_sweep
- * (may be NULL).  After this call the send buffer is packed. */
+/* One Philox iteration of both red/blue halves on the resident rungs, no PT, asynchronous.
+ * Same kernels and draws as hens_step; exists so a sharded ladder can interleave communication. */
+int hens_stretch_iter(hens_ctx* ctx);
+
+/* Sharded PT, step 1.  iperm/i1perm/u_swap as in hens_pt_sweep, or all NULL for device-side
+ * Philox draws (identical on every rank: they depend only on seed and iteration).
+ * rank_of_rung[T] gives the owner of every rung; this context is rank `my_rank`.
+ * Outputs (host): send_counts[nranks], recv_counts[nranks] in rows; sel_out / swaps_accepted_out
+ * as in hens_pt_sweep (may be NULL).  On return the send buffer is packed.  Synchronous. */
 int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm,
                          const double* u_swap, int32_t adapt, const int32_t* rank_of_rung,
-                         int32_t nranks, int64_t* send_counts, int64_t* recv_counts,
+                         int32_t nranks, int32_t my_rank, int64_t* send_counts, int64_t* recv_counts,
                          uint8_t* sel_out, double* swaps_accepted_out);
-/* Sharded PT, step 2: after the caller exchanged send_rows -> recv_rows (all-to-all in
- * rank order), scatter the received rows and finish the permutation of logl/logp/loc. */
-int hens_pt_finish_sharded(hens_ctx* ctx);
+/* Sharded PT, step 2: scatter n_recv received rows (recv_rows, any order) and swap buffers. */
+int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv);
 
 /* Debug: per-workgroup phase timestamps of the stretch kernel (shader-clock ticks, 8 per
  * workgroup: start, A done, barrier, B done, barrier, C done, D done, end).  enable != 0 makes
