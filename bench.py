@@ -16,6 +16,7 @@ import sys
 import time
 
 import numpy as np
+import torch  # noqa: F401  (before libhipensemble: both must share one HIP runtime, torch's goes first)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -96,7 +97,6 @@ def run_single(args):
     eng.synchronize()
     eng.reset_counters()
 
-    import torch
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.step(args.steps)

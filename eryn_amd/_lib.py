@@ -2,6 +2,10 @@
 
 There is no CPU fallback: if the shared library is missing, or no MI355X is
 visible when a context is created, the product path raises.
+
+Process-level note: PyTorch-ROCm bundles its own HIP runtime.  A process that uses both torch
+and this library must import torch FIRST (bench.py, eryn_amd.ladder do); initialising the system
+HIP runtime through this library and importing torch afterwards leaves torch without devices.
 """
 import ctypes as C
 import os

@@ -754,7 +754,51 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
             __syncthreads();
         }
     }
-    for (int i = tid; i < W; i += blockDim.x) out[i] = (int32_t)(key[i] & mask);
+    if (job >= A.n_split) {                                // PT column map: the permutation itself
+        for (int i = tid; i < W; i += blockDim.x) out[i] = (int32_t)(key[i] & mask);
+        return;
+    }
+    // Split order: the first N0 = ceil(W/2) entries of the permutation are the walkers of split 0
+    // (a uniformly random balanced labelling, red_blue.py:119-124).  Emit each half in ASCENDING
+    // walker order like the reference's boolean masks do: a tile of 64 moving walkers then touches
+    // ~128 consecutive ids, so the per-walker scalars (loc, L, P, accept counts) are read and
+    // written as whole cache lines instead of one line per 4..8-byte element.
+    const int N0 = (W + 1) / 2;
+    const int nt = blockDim.x;
+    const int per = (NP2 + nt - 1) / nt;                   // permutation entries per thread
+    uint32_t mine[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + q * nt;
+        mine[q] = (q < per && i < W) ? (uint32_t)(key[i] & mask) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    uint8_t* lab = reinterpret_cast<uint8_t*>(key);        // [W] labels, reusing the sort buffer
+    uint32_t* scan = reinterpret_cast<uint32_t*>(lab + ((W + 15) & ~15));   // [nt] zero counts
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int i = tid + q * nt;
+        if (q < per && i < W) lab[mine[q]] = (i >= N0) ? 1 : 0;
+    }
+    __syncthreads();
+    const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
+    const int lo = tid * chunk, hi = min(W, lo + chunk);
+    uint32_t z = 0;
+    for (int i = lo; i < hi; ++i) z += (lab[i] == 0);
+    scan[tid] = z;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {               // inclusive Hillis-Steele scan of zero counts
+        const uint32_t v = (tid >= off) ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t z0 = scan[tid] - z;                           // zeros before this thread's chunk
+    uint32_t o0 = (uint32_t)lo - z0;                       // ones before it
+    for (int i = lo; i < hi; ++i) {
+        if (lab[i] == 0) out[z0++] = i;
+        else out[N0 + o0++] = i;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -19,6 +19,11 @@ The communication layer is ``torch.distributed`` (backend "nccl" = RCCL over xGM
 """
 import numpy as np
 
+try:                                   # torch first: see the process-level note in eryn_amd/_lib.py
+    import torch  # noqa: F401
+except ImportError:                    # pragma: no cover - the orchestration itself needs torch.distributed
+    torch = None
+
 
 def rung_partition(ntemps, nranks):
     """Contiguous equal shards; returns (rank_of_rung[T], [(begin, end)] per rank)."""
