@@ -7,8 +7,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <cstring>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -18,10 +18,15 @@ namespace {
 
 thread_local std::string g_last_error;
 
+struct DrawBuf {                     // one batch of planned iterations
+    Draws d{};
+    int32_t* colslot = nullptr;      // [NB][T][W]
+};
+
 struct hens_ctx_impl {
     hens_config cfg{};
     int T = 0, W = 0, D = 0, Tl = 0, N0 = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, plan_stream = nullptr;
     bool own_stream = false;
     std::string err;
 
@@ -32,55 +37,57 @@ struct hens_ctx_impl {
     double* P[2] = {nullptr, nullptr};
     int cur = 0;                     // which of the double-buffered L/P/loc is current
     int parity = 0;                  // home half the NEXT iteration writes into
-    double* betas = nullptr;         // [T]
+    double* betas[2] = {nullptr, nullptr};   // [T]; bcur is current
+    int bcur = 0;
     uint32_t* accepted = nullptr;    // [Tl*W]
     int64_t num_proposals = 0;
     unsigned* flags = nullptr;
-    uint64_t* clock = nullptr;
-    int64_t* adapt_time = nullptr;
-    unsigned long long* swap_cnt = nullptr;
+    uint64_t iter = 0;               // iterations completed (the Philox counter)
+    int64_t adapt_time = 0;          // tempering.py:596
+    bool adapt_pending = false;      // a cascade ran and its swap counts have not been reduced yet
+    bool adapt_pending_adaptive = false;
+    uint32_t* swap_part = nullptr;   // [nblocks][T-1]
     double* swaps_last = nullptr;
     double* swaps_total = nullptr;
-    unsigned* ticket = nullptr;
 
     // model
     double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr;
     double logp_in = 0.0, rosen_a = 1.0, rosen_b = 100.0;
     bool have_prior = false, have_like = false, have_state = false, have_logs = false;
 
+    // draws: two batch buffers (plan of batch b+1 overlaps the stepping of batch b)
+    DrawBuf db[2];
+    int NB = 0, NP2 = 1, idx_bits = 0;
+    hipEvent_t ev_plan[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+
     // parity staging
-    int32_t* order = nullptr;        // [NB][Tl][W] (slot 0 used by parity mode)
+    int32_t* order = nullptr;        // [Tl][W]
     int64_t* d_rint = nullptr; double* d_uzz = nullptr; double* d_uacc = nullptr; uint8_t* d_keep = nullptr;
     int64_t* d_iperm = nullptr; int64_t* d_i1perm = nullptr; double* d_uswap = nullptr;
-    int32_t* d_inv = nullptr; int32_t* colslot = nullptr; int32_t* colk = nullptr; double* colu = nullptr;
+    int32_t* d_inv = nullptr; int32_t* colk = nullptr; double* colu = nullptr;
     uint8_t* selcol = nullptr; uint8_t* selk = nullptr;
     double* xtmp = nullptr;          // [Tl*W][D] download staging
     int expect_split = 0;
     std::vector<uint8_t> labels_host;
 
-    // philox plan batches
-    int NB = 0;
-    int NP2 = 1, idx_bits = 0;
-
     // sharded exchange
-    double* gather_L = nullptr; double* gather_P = nullptr;
+    double* gather_L = nullptr;
     double* send_rows = nullptr; double* recv_rows = nullptr;
-    int32_t* srcglob = nullptr; int32_t* send_slots = nullptr; int32_t* recv_slots = nullptr;
-    int64_t* d_counts = nullptr;     // scratch: counts + cursors
+    int32_t* srcglob = nullptr; int32_t* send_slots = nullptr; int32_t* send_dest = nullptr;
+    unsigned* d_counts = nullptr;    // counts [2*MAX_RANKS] + cursors [MAX_RANKS]
     int32_t* d_rank_of = nullptr;    // [T]
-    int64_t row_capacity = 0;
-    int64_t n_send = 0, n_recv = 0;
+    int64_t row_capacity = 0, n_send = 0, n_recv = 0;
     bool pt_pending = false;
 
+    // debug / timing
     unsigned long long* d_trace = nullptr;
     int64_t trace_words = 0;
     bool tracing = false;
-
-    // timing
     bool per_kernel_events = false;
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evpool;
+    std::vector<void*> allocs;
 };
 
 #define CTX(c) reinterpret_cast<hens_ctx_impl*>(c)
@@ -107,6 +114,7 @@ int fail(hens_ctx_impl* c, int code, const char* fmt, ...) {
 template <typename Tp>
 int dalloc(hens_ctx_impl* c, Tp** p, size_t n) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(Tp)));
+    c->allocs.push_back(*p);
     return HENS_OK;
 }
 
@@ -115,47 +123,43 @@ int grid_for(int64_t n, int block = 256) {
     return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 2048);
 }
 
-// ---- kernel dispatch ---------------------------------------------------------------------------
-size_t stretch_lds_bytes(int D, int NW, int* RS_out) {
+int pt_blocks(const hens_ctx_impl* c) { return (c->W + PT_COLS - 1) / PT_COLS; }
+bool has_pt(const hens_ctx_impl* c) { return c->cfg.tempered && c->T > 1; }
+int plan_threads(const hens_ctx_impl* c) { return std::min(1024, std::max(64, c->NP2 / 4)); }   // <= 16 elements per thread
+size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)c->NP2 * 8 + (((size_t)c->W + 15) & ~(size_t)15); }
+
+// ---- stretch dispatch ----------------------------------------------------------------------------
+constexpr int FAST_NW_32 = 8;
+int fast_nw(int D) { return D == 32 ? FAST_NW_32 : (D == 64 ? 8 : 4); }
+bool is_fast_dim(int D) { return D == 8 || D == 16 || D == 32 || D == 64; }
+
+size_t generic_lds_bytes(int D, int* RS_out) {
     const int RS = (D % 2 == 0) ? D + 2 : D;
     *RS_out = RS;
-    return (size_t)TILE * RS * 8 + (size_t)TILE * 8 + (size_t)NW * TILE * 8 + 4 * (size_t)TILE * 4;
+    return (size_t)TILE * RS * 8 + (size_t)TILE * 8 + (size_t)4 * TILE * 8 + 4 * (size_t)TILE * 4;
+}
+size_t fast_lds_bytes(int D, int NW) {
+    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 64) * 8 + 5 * (size_t)TILE * 4;
 }
 
-template <int LIKE, int MODE>
-int launch_stretch_like(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
+template <int LIKE, bool EVAL>
+int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
-    int RS;
-    hipError_t e;
-#define LAUNCH(DT, NW)                                                                             \
-    do {                                                                                           \
-        size_t lds = stretch_lds_bytes(c->D, NW, &RS);                                             \
-        StretchArgs b = a;                                                                         \
-        b.RS = RS;                                                                                 \
-        hipLaunchKernelGGL((k_stretch<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), lds, c->stream, b); \
-    } while (0)
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \
-        size_t lds = stretch_lds_bytes(c->D, NW, &RS) + (plds_knob ? (size_t)DT * DT * 8 : 0);     \
+        const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
-        if (plds_knob)                                                                             \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, true>), grid, dim3(NW * 64), lds, c->stream, a);  \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, false>), grid, dim3(NW * 64), lds, c->stream, a); \
+        hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
-    static const int nw_knob = getenv("HENS_NW") ? atoi(getenv("HENS_NW")) : 0;
-    static const int plds_knob = getenv("HENS_PLDS") ? atoi(getenv("HENS_PLDS")) : 0;
     if (c->D == 32) {
-        if (nw_knob == 4) LAUNCH_FAST(32, 4);
-        else if (nw_knob == 16) LAUNCH_FAST(32, 16);
-        else LAUNCH_FAST(32, 8);
+        LAUNCH_FAST(32, FAST_NW_32);
     } else if (c->D == 64) {
         LAUNCH_FAST(64, 8);
     } else if (c->D == 16) {
@@ -163,23 +167,36 @@ int launch_stretch_like(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
     } else if (c->D == 8) {
         LAUNCH_FAST(8, 4);
     } else {
-        LAUNCH(0, 4);
+        int RS;
+        const size_t lds = generic_lds_bytes(c->D, &RS);
+        if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
+        if (lds > 60000)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE, EVAL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        a.RS = RS;
+        a.ad_on = 0;
+        hipLaunchKernelGGL((k_stretch<LIKE, EVAL>), grid, dim3(256), lds, c->stream, a);
     }
 #undef LAUNCH_FAST
-#undef LAUNCH
-    e = hipGetLastError();
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
     return HENS_OK;
 }
 
-template <int MODE>
+template <bool EVAL>
 int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, MODE>(c, a, ntiles);
-        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, MODE>(c, a, ntiles);
-        case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, MODE>(c, a, ntiles);
+        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, EVAL>(c, a, ntiles);
+        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, EVAL>(c, a, ntiles);
+        case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, EVAL>(c, a, ntiles);
     }
     return fail(c, HENS_ERR_INVALID, "unknown likelihood kind %d", c->cfg.likelihood_kind);
+}
+
+Draws draws_at(const DrawBuf& b, size_t off) {
+    Draws d = b.d;
+    d.own += off; d.cw += off; d.zz += off; d.fac += off; d.lu += off;
+    return d;
 }
 
 StretchArgs base_args(hens_ctx_impl* c) {
@@ -188,23 +205,49 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.loc = c->loc[c->cur];
     a.L = c->L[c->cur];
     a.P = c->P[c->cur];
-    a.betas = c->cfg.tempered ? c->betas : nullptr;
-    a.order = c->order;
+    a.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
+    a.dr = c->db[0].d;
     a.accepted = c->accepted;
     a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec;
-    a.clock = c->clock;
     a.flags = c->flags;
     a.trace = c->tracing ? c->d_trace : nullptr;
-    a.a = c->cfg.a;
     a.logp_in = c->logp_in;
     a.fill = c->cfg.fill_value;
     a.rosen_a = c->rosen_a; a.rosen_b = c->rosen_b;
-    a.seed = c->cfg.seed;
     a.Tl = c->Tl; a.W = c->W; a.D = c->D;
     a.N0 = c->N0;
     a.rung_begin = c->cfg.rung_begin;
     a.tempered = c->cfg.tempered;
     return a;
+}
+
+AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* out) {
+    AdaptArgs a{};
+    a.swap_part = c->swap_part;
+    a.betas_in = in; a.betas_out = out;
+    a.swaps_last = c->swaps_last; a.swaps_total = c->swaps_total;
+    a.lag = c->cfg.adaptation_lag; a.nu = c->cfg.adaptation_time;
+    a.time = c->adapt_time;
+    a.T = c->T; a.W = c->W; a.nblocks = pt_blocks(c);
+    a.moving = (adaptive && (c->cfg.stop_adaptation < 0 || c->adapt_time < c->cfg.stop_adaptation)) ? 1 : 0;
+    return a;
+}
+
+// reduce the pending cascade's swap counts and adapt the ladder as a kernel of its own
+void flush_adapt(hens_ctx_impl* c) {
+    if (!c->adapt_pending) return;
+    const AdaptArgs a = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur]);
+    hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), (size_t)c->T * 28 + 16, c->stream, a);
+    if (c->adapt_pending_adaptive) c->adapt_time += 1;               // tempering.py:596
+    c->adapt_pending = false;
+}
+
+// can the pending adaptation ride in the next split-0 stretch launch?
+bool can_fold_adapt(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_NO_FOLD") != nullptr;
+    if (off || !c->adapt_pending || !is_fast_dim(c->D) || c->T > 64) return false;
+    const int nw = fast_nw(c->D);
+    return nw >= 2 && (int64_t)pt_blocks(c) * (c->T - 1) <= (int64_t)8 * nw * 64;
 }
 
 int check_flags(hens_ctx_impl* c, bool nan_logl_is_error) {
@@ -232,8 +275,8 @@ int ready(hens_ctx_impl* c, bool need_logs) {
 }
 
 int ensure_pt_buffers(hens_ctx_impl* c) {
-    const size_t TW = (size_t)c->T * c->W, PW = (size_t)std::max(c->T - 1, 1) * c->W;
     if (c->d_iperm) return HENS_OK;
+    const size_t PW = (size_t)std::max(c->T - 1, 1) * c->W;
     int r;
     if ((r = dalloc(c, &c->d_iperm, PW))) return r;
     if ((r = dalloc(c, &c->d_i1perm, PW))) return r;
@@ -243,7 +286,22 @@ int ensure_pt_buffers(hens_ctx_impl* c) {
     if ((r = dalloc(c, &c->colu, PW))) return r;
     if ((r = dalloc(c, &c->selcol, PW))) return r;
     if ((r = dalloc(c, &c->selk, PW))) return r;
-    (void)TW;
+    return HENS_OK;
+}
+
+int ensure_shard_buffers(hens_ctx_impl* c) {
+    if (c->gather_L) return HENS_OK;
+    const size_t TW = (size_t)c->T * c->W, cap = (size_t)c->Tl * c->W;
+    int r;
+    if ((r = dalloc(c, &c->gather_L, TW))) return r;
+    if ((r = dalloc(c, &c->srcglob, TW))) return r;
+    if ((r = dalloc(c, &c->send_rows, cap * (c->D + 2)))) return r;
+    if ((r = dalloc(c, &c->recv_rows, cap * (c->D + 2)))) return r;
+    if ((r = dalloc(c, &c->send_slots, cap))) return r;
+    if ((r = dalloc(c, &c->send_dest, cap))) return r;
+    if ((r = dalloc(c, &c->d_counts, 4 * MAX_RANKS))) return r;
+    if ((r = dalloc(c, &c->d_rank_of, (size_t)c->T))) return r;
+    c->row_capacity = (int64_t)cap;
     return HENS_OK;
 }
 
@@ -252,19 +310,33 @@ size_t pt_lds_bytes(int T) { return pt_lds_layout(T); }
 PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     PtArgs p{};
     p.Lfull = sharded ? c->gather_L : c->L[c->cur];
-    p.L = c->L[c->cur]; p.P = c->P[c->cur]; p.loc = c->loc[c->cur];
+    p.P = c->P[c->cur]; p.loc = c->loc[c->cur];
     p.Lnew = c->L[c->cur ^ 1]; p.Pnew = c->P[c->cur ^ 1]; p.locnew = c->loc[c->cur ^ 1];
-    p.betas = c->betas;
+    p.betas = c->betas[c->bcur];
     p.colslot = colslot;
-    p.swap_part = c->swap_cnt; p.swaps_last = c->swaps_last; p.swaps_total = c->swaps_total;
-    p.ticket = c->ticket; p.clock = c->clock; p.adapt_time = c->adapt_time;
+    p.swap_part = c->swap_part;
+    p.iter = c->iter;
     p.seed = c->cfg.seed;
-    p.lag = c->cfg.adaptation_lag; p.nu = c->cfg.adaptation_time;
-    p.stop_adaptation = c->cfg.stop_adaptation;
     p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin;
-    p.sharded = sharded ? 1 : 0;
     p.srcfull = sharded ? c->srcglob : nullptr;
     return p;
+}
+
+// plan nb iterations starting at iteration `iter0` into draw buffer `which`
+void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool splits, bool pt) {
+    PlanArgs pa{};
+    pa.dr = c->db[which].d;
+    pa.colslot = c->db[which].colslot;
+    pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
+    pa.Tl = c->Tl; pa.T = c->T; pa.W = c->W; pa.D = c->D; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
+    pa.n_split = splits ? c->Tl : 0;
+    pa.jobs_per_iter = pa.n_split + (pt ? c->T : 0);
+    pa.idx_bits = c->idx_bits;
+    if (pa.jobs_per_iter == 0) return;
+    static const bool replay = getenv("HENS_REPLAY_PLAN") != nullptr;   // timing experiment: reuse stale draws
+    static int n_planned = 0;
+    if (replay && n_planned++ >= 2) return;
+    hipLaunchKernelGGL(k_plan, dim3(nb * pa.jobs_per_iter), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
 }
 
 hipEvent_t new_event(hens_ctx_impl* c) {
@@ -274,12 +346,52 @@ hipEvent_t new_event(hens_ctx_impl* c) {
     return e;
 }
 
+// both halves of one Philox iteration from draw buffer `which`, batch slot `ib`
+int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
+    const int Tl = c->Tl, W = c->W;
+    auto mark = [&]() {
+        if (!evs) return;
+        hipEvent_t e = new_event(c);
+        (void)hipEventRecord(e, c->stream);
+        evs->push_back(e);
+    };
+    for (int split = 0; split < 2; ++split) {
+        StretchArgs a = base_args(c);
+        a.dr = draws_at(c->db[which], (size_t)ib * Tl * W);
+        a.split = split;
+        a.home_off = c->parity * Tl * W;
+        if (split == 0 && c->adapt_pending) {
+            if (can_fold_adapt(c)) {
+                // the previous cascade's ladder adaptation rides in this launch: every workgroup reads
+                // the old ladder, workgroup (0,0) writes the new one into the other buffer
+                a.ad_on = 1;
+                a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
+                a.betas = c->betas[c->bcur];
+                if (c->adapt_pending_adaptive) c->adapt_time += 1;
+                c->adapt_pending = false;
+                c->bcur ^= 1;
+            } else {
+                flush_adapt(c);
+                a.betas = c->betas[c->bcur];
+            }
+        }
+        const int Ns = split == 0 ? c->N0 : W - c->N0;
+        mark();
+        const int r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
+        if (r) return r;
+        mark();
+    }
+    c->parity ^= 1;
+    c->num_proposals += 1;
+    return HENS_OK;
+}
+
 }  // namespace
 
 // ================================================================================================
 extern "C" {
 
-const char* hens_version(void) { return "hipensemble 0.1 (gfx950)"; }
+const char* hens_version(void) { return "hipensemble 0.2 (gfx950)"; }
 
 int hens_device_count(void) {
     int n = 0;
@@ -326,7 +438,12 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
 #define TRY(x) do { int r_ = (x); if (r_) { g_last_error = c->err; hens_destroy(h); return r_; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(c, HENS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); g_last_error = c->err; hens_destroy(h); return HENS_ERR_HIP; } } while (0)
     TRYHIP(hipSetDevice(cfg->device_id));
-    TRYHIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {   // the stepping stream outranks the plan stream: plans run ahead in the gaps
+        int prio_lo = 0, prio_hi = 0;
+        TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        TRYHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi));
+        TRYHIP(hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, prio_lo));
+    }
     c->own_stream = true;
     const size_t TW = (size_t)c->Tl * c->W;
     TRY(dalloc(c, &c->pool, 2 * TW * c->D));
@@ -334,51 +451,55 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->loc[b], TW));
         TRY(dalloc(c, &c->L[b], TW));
         TRY(dalloc(c, &c->P[b], TW));
+        TRY(dalloc(c, &c->betas[b], (size_t)c->T));
     }
-    TRY(dalloc(c, &c->betas, (size_t)c->T));
     TRY(dalloc(c, &c->accepted, TW));
     TRY(dalloc(c, &c->flags, 1));
-    TRY(dalloc(c, &c->clock, 1));
-    TRY(dalloc(c, &c->adapt_time, 1));
-    TRY(dalloc(c, &c->swap_cnt, (size_t)c->T * ((c->W + PT_COLS - 1) / PT_COLS)));
+    TRY(dalloc(c, &c->swap_part, (size_t)c->T * pt_blocks(c)));
     TRY(dalloc(c, &c->swaps_last, (size_t)c->T));
     TRY(dalloc(c, &c->swaps_total, (size_t)c->T));
-    TRY(dalloc(c, &c->ticket, 1));
     TRY(dalloc(c, &c->lo, (size_t)c->D));
     TRY(dalloc(c, &c->hi, (size_t)c->D));
     TRY(dalloc(c, &c->mu, (size_t)c->D));
     TRY(dalloc(c, &c->prec, (size_t)c->D * c->D));
+    TRY(dalloc(c, &c->order, TW));
     TRY(dalloc(c, &c->d_rint, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->d_uzz, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->d_uacc, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->d_keep, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->xtmp, TW * c->D));
-    // plan batches: keep the per-batch plan under ~64 MiB
+    // plan batches: two buffers of NB iterations, each kept under ~48 MiB
     c->NP2 = 1; c->idx_bits = 0;
     while (c->NP2 < c->W) { c->NP2 <<= 1; c->idx_bits++; }
     {
-        const size_t per_iter = (TW + (size_t)c->T * c->W) * 4;
-        size_t nb = (64u << 20) / std::max<size_t>(per_iter, 1);
-        nb = std::max<size_t>(2, std::min<size_t>(nb, 64));
+        const size_t per_iter = TW * 32 + (size_t)c->T * c->W * 4;
+        size_t nb = (48u << 20) / std::max<size_t>(per_iter, 1);
+        nb = std::max<size_t>(2, std::min<size_t>(nb, 32));
         nb &= ~(size_t)1;
         c->NB = (int)nb;
     }
-    TRY(dalloc(c, &c->order, (size_t)c->NB * TW));
-    TRY(dalloc(c, &c->colslot, (size_t)c->NB * c->T * c->W));
+    for (int b = 0; b < 2; ++b) {
+        const size_t n = (size_t)c->NB * TW;
+        TRY(dalloc(c, &c->db[b].d.own, n));
+        TRY(dalloc(c, &c->db[b].d.cw, n));
+        TRY(dalloc(c, &c->db[b].d.zz, n));
+        TRY(dalloc(c, &c->db[b].d.fac, n));
+        TRY(dalloc(c, &c->db[b].d.lu, n));
+        TRY(dalloc(c, &c->db[b].colslot, (size_t)c->NB * c->T * c->W));
+        TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
+        TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
+    }
     TRYHIP(hipMemsetAsync(c->accepted, 0, TW * 4, c->stream));
     TRYHIP(hipMemsetAsync(c->flags, 0, 4, c->stream));
-    TRYHIP(hipMemsetAsync(c->clock, 0, 8, c->stream));
-    TRYHIP(hipMemsetAsync(c->adapt_time, 0, 8, c->stream));
+    TRYHIP(hipMemsetAsync(c->swap_part, 0, (size_t)c->T * pt_blocks(c) * 4, c->stream));
     TRYHIP(hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
     TRYHIP(hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
-    TRYHIP(hipMemsetAsync(c->ticket, 0, 4, c->stream));
     TRYHIP(hipEventCreate(&c->ev0));
     TRYHIP(hipEventCreate(&c->ev1));
-    // kernels that need > 64 KiB of dynamic LDS
-    {
-        const size_t plan_lds = (size_t)c->NP2 * 8;
+    {   // kernels that may need > 64 KiB of dynamic LDS
+        const size_t plan_lds = plan_lds_bytes(c);
         if (plan_lds > 160 * 1024) {
-            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS permutation sort (max 16384... 20480)", c->W);
+            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS permutation sort (max 16384)", c->W);
             g_last_error = c->err; hens_destroy(h); return HENS_ERR_UNSUPPORTED;
         }
         TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds));
@@ -401,18 +522,18 @@ void hens_destroy(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
+    if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->pool, c->loc[0], c->loc[1], c->L[0], c->L[1], c->P[0], c->P[1], c->betas, c->accepted,
-                    c->flags, c->clock, c->adapt_time, c->swap_cnt, c->swaps_last, c->swaps_total, c->ticket,
-                    c->lo, c->hi, c->mu, c->prec, c->order, c->d_rint, c->d_uzz, c->d_uacc, c->d_keep,
-                    c->d_iperm, c->d_i1perm, c->d_uswap, c->d_inv, c->colslot, c->colk, c->colu, c->selcol,
-                    c->selk, c->xtmp, c->gather_L, c->gather_P, c->send_rows, c->recv_rows, c->srcglob,
-                    c->send_slots, c->recv_slots, c->d_counts, c->d_trace, c->d_rank_of};
-    for (void* p : ptrs)
+    for (void* p : c->allocs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
+    for (int b = 0; b < 2; ++b) {
+        if (c->ev_plan[b]) (void)hipEventDestroy(c->ev_plan[b]);
+        if (c->ev_used[b]) (void)hipEventDestroy(c->ev_used[b]);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -479,6 +600,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     if (c->cfg.tempered && !betas) return fail(c, HENS_ERR_INVALID, "betas required for a tempered context");
     if ((logl == nullptr) != (logp == nullptr)) return fail(c, HENS_ERR_INVALID, "give both logl and logp or neither");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     c->cur = 0;
     c->parity = 1;            // rows live in home 0, the next iteration writes home 1
@@ -490,7 +612,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
         HIPCHK(c, hipMemcpyAsync(c->L[0], logl, TW * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->P[0], logp, TW * 8, hipMemcpyHostToDevice, c->stream));
     }
-    if (betas) HIPCHK(c, hipMemcpyAsync(c->betas, betas, (size_t)c->T * 8, hipMemcpyHostToDevice, c->stream));
+    if (betas) HIPCHK(c, hipMemcpyAsync(c->betas[c->bcur], betas, (size_t)c->T * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_state = true;
     c->have_logs = logl != nullptr;
@@ -503,6 +625,7 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     if (!c->have_state) return fail(c, HENS_ERR_STATE, "no state uploaded");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight (call hens_pt_finish_sharded)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     if (x) {
         hipLaunchKernelGGL(k_gather_rows, dim3(grid_for((int64_t)TW * c->D)), dim3(256), 0, c->stream, c->pool,
@@ -511,7 +634,7 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     }
     if (logl) HIPCHK(c, hipMemcpyAsync(logl, c->L[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
     if (logp) HIPCHK(c, hipMemcpyAsync(logp, c->P[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
-    if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas, (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
+    if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas[c->bcur], (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return HENS_OK;
 }
@@ -524,7 +647,7 @@ int hens_eval_state(hens_ctx* ctx) {
     StretchArgs a = base_args(c);
     a.split = 0;
     a.home_off = 0;
-    r = launch_stretch<MODE_EVAL>(c, a, (c->W + TILE - 1) / TILE);
+    r = launch_stretch<true>(c, a, (c->W + TILE - 1) / TILE);
     if (r) return r;
     r = check_flags(c, true);
     if (r) return r;
@@ -543,11 +666,11 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
         return fail(c, HENS_ERR_STATE, "hens_stretch_split calls must alternate split 0, 1 (expected %d)", c->expect_split);
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
     const int Tl = c->Tl, W = c->W;
     if (split == 0) {
         // ascending index lists per label (red_blue.py:150-154): order = [label 0 ... | label 1 ...]
         std::vector<int32_t> order((size_t)Tl * W);
-        int n0_first = -1;
         for (int t = 0; t < Tl; ++t) {
             int n0 = 0;
             for (int w = 0; w < W; ++w) {
@@ -555,17 +678,15 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
                 if (l > 1) return fail(c, HENS_ERR_INVALID, "labels must be 0 or 1");
                 n0 += (l == 0);
             }
-            if (n0_first < 0) n0_first = n0;
-            if (n0 != n0_first) return fail(c, HENS_ERR_INVALID, "every rung must have the same number of label-0 walkers");
+            if (n0 != (W + 1) / 2)   // arange(W) % 2 shuffled always has ceil(W/2) zeros (red_blue.py:120-124)
+                return fail(c, HENS_ERR_INVALID, "labels must hold ceil(W/2) zeros per rung (got %d)", n0);
             int a0 = 0, a1 = n0;
             for (int w = 0; w < W; ++w) {
                 if (labels[(size_t)t * W + w] == 0) order[(size_t)t * W + a0++] = w;
                 else order[(size_t)t * W + a1++] = w;
             }
         }
-        if (n0_first != (W + 1) / 2)   // arange(W) % 2 shuffled always has ceil(W/2) zeros (red_blue.py:120-124)
-            return fail(c, HENS_ERR_INVALID, "labels must hold ceil(W/2) zeros per rung (got %d)", n0_first);
-        c->N0 = n0_first;
+        c->N0 = (W + 1) / 2;
         c->labels_host.assign(labels, labels + (size_t)Tl * W);
         HIPCHK(c, hipMemcpyAsync(c->order, order.data(), order.size() * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -581,12 +702,13 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     HIPCHK(c, hipMemcpyAsync(c->d_rint, rint, n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uzz, u_zz, n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_prep_draws, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, c->order, c->d_rint, c->d_uzz,
+                       c->d_uacc, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, c->D);
     StretchArgs a = base_args(c);
     a.split = split;
     a.home_off = c->parity * Tl * W;
-    a.rint = c->d_rint; a.u_zz = c->d_uzz; a.u_acc = c->d_uacc;
     a.keep_out = c->d_keep;
-    r = launch_stretch<MODE_PARITY>(c, a, (Ns + TILE - 1) / TILE);
+    r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
     if (r) return r;
     if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->d_keep, n, hipMemcpyDeviceToHost, c->stream));
     r = check_flags(c, false);
@@ -594,6 +716,7 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     if (split == 1) {
         c->parity ^= 1;
         c->num_proposals += 1;
+        if (!has_pt(c)) c->iter += 1;
     }
     c->expect_split = split ^ 1;
     return HENS_OK;
@@ -610,9 +733,8 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     if (!iperm || !i1perm || !u_swap) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int T = c->T, W = c->W;
-    if (T < 2) {
-        return HENS_OK;
-    }
+    if (T < 2) return HENS_OK;
+    flush_adapt(c);
     r = ensure_pt_buffers(c);
     if (r) return r;
     const size_t PW = (size_t)(T - 1) * W;
@@ -630,20 +752,22 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
+    int32_t* colslot = c->db[0].colslot;
     hipLaunchKernelGGL(k_pt_invert, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->d_iperm, c->d_inv, T - 1, W);
     hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm, c->d_inv,
-                       c->d_uswap, c->colslot, c->colk, c->colu, T, W);
-    PtArgs p = pt_args(c, c->colslot, false);
+                       c->d_uswap, colslot, c->colk, c->colu, T, W);
+    PtArgs p = pt_args(c, colslot, false);
     p.colu = c->colu;
     p.selcol = c->selcol;
-    p.adapt = (adapt && c->cfg.adaptive) ? 1 : 0;
-    p.tick = 0;
-    hipLaunchKernelGGL(k_pt_cascade<false>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS), pt_lds_bytes(T),
-                       c->stream, p);
+    hipLaunchKernelGGL(k_pt_cascade<false>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = adapt && c->cfg.adaptive;
+    flush_adapt(c);
     hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk, c->selk,
                        T - 1, W);
     HIPCHK(c, hipGetLastError());
     c->cur ^= 1;
+    c->iter += 1;
     if (sel_out) HIPCHK(c, hipMemcpyAsync(sel_out, c->selk, PW, hipMemcpyDeviceToHost, c->stream));
     if (swaps_out) HIPCHK(c, hipMemcpyAsync(swaps_out, c->swaps_last, (size_t)(T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -658,84 +782,69 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (c->Tl != c->T) return fail(c, HENS_ERR_STATE, "hens_step needs the whole ladder resident (sharded stepping is driven by eryn_amd.ladder)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    const int T = c->T, Tl = c->Tl, W = c->W;
+    const int T = c->T, W = c->W;
     c->N0 = (W + 1) / 2;
-    const bool pt = c->cfg.tempered && T > 1;
-    const int jobs = Tl + (pt ? T : 0);
+    const bool pt = has_pt(c);
     const bool prof = c->per_kernel_events;
     std::vector<hipEvent_t> evs;
-    auto mark = [&]() {
-        if (!prof) return;
-        hipEvent_t e = new_event(c);
-        (void)hipEventRecord(e, c->stream);
-        evs.push_back(e);
-    };
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
     c->evpool.clear();
     c->timing = hens_timing{};
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int64_t done = 0; done < n_iters;) {
-        const int nb = (int)std::min<int64_t>(c->NB, n_iters - done);
-        PlanArgs pa{};
-        pa.order = c->order; pa.colslot = c->colslot; pa.clock = c->clock; pa.seed = c->cfg.seed;
-        pa.Tl = Tl; pa.T = T; pa.W = W; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
-        pa.n_split = Tl; pa.jobs_per_iter = jobs; pa.idx_bits = c->idx_bits;
-        mark();
-        hipLaunchKernelGGL(k_plan, dim3(nb * jobs), dim3(std::min(1024, std::max(64, c->NP2 / 2))), (size_t)c->NP2 * 8,
-                           c->stream, pa);
-        mark();
-        for (int ib = 0; ib < nb; ++ib) {
-            for (int split = 0; split < 2; ++split) {
-                StretchArgs a = base_args(c);
-                a.order = c->order + (size_t)ib * Tl * W;
-                a.split = split;
-                a.home_off = c->parity * Tl * W;
-                const int Ns = split == 0 ? c->N0 : W - c->N0;
-                mark();
-                r = launch_stretch<MODE_PHILOX>(c, a, (Ns + TILE - 1) / TILE);
-                if (r) return r;
-                mark();
-            }
-            c->parity ^= 1;
-            c->num_proposals += 1;
-            if (pt) {
-                PtArgs p = pt_args(c, c->colslot + (size_t)ib * T * W, false);
-                p.adapt = c->cfg.adaptive ? 1 : 0;
-                p.tick = 1;
-                mark();
-                hipLaunchKernelGGL(k_pt_cascade<true>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS),
-                                   pt_lds_bytes(T), c->stream, p);
-                mark();
-                c->cur ^= 1;
-            } else {
-                hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, c->stream, c->clock);
-            }
-        }
-        done += nb;
+    // the plan of batch b+1 runs on plan_stream while batch b steps on the main stream
+    const int64_t nbatch = (n_iters + c->NB - 1) / c->NB;
+    auto batch_size = [&](int64_t b) { return (int)std::min<int64_t>(c->NB, n_iters - b * c->NB); };
+    if (nbatch > 0) {
+        HIPCHK(c, hipEventRecord(c->ev_used[0], c->stream));      // earlier work may still read buffer 0
+        HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[0], 0));
+        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0), true, pt);
+        HIPCHK(c, hipEventRecord(c->ev_plan[0], c->plan_stream));
+        c->timing.n_plan += 1;
     }
+    for (int64_t b = 0; b < nbatch; ++b) {
+        const int which = (int)(b & 1), nb = batch_size(b);
+        if (b + 1 < nbatch) {
+            const int nxt = which ^ 1;
+            HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
+            HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));
+            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), true, pt);
+            HIPCHK(c, hipEventRecord(c->ev_plan[nxt], c->plan_stream));
+            c->timing.n_plan += 1;
+        }
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
+        for (int ib = 0; ib < nb; ++ib) {
+            r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
+            if (r) return r;
+            if (pt) {
+                PtArgs p = pt_args(c, c->db[which].colslot + (size_t)ib * T * W, false);
+                if (prof) { hipEvent_t e = new_event(c); (void)hipEventRecord(e, c->stream); evs.push_back(e); }
+                hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T),
+                                   c->stream, p);
+                if (prof) { hipEvent_t e = new_event(c); (void)hipEventRecord(e, c->stream); evs.push_back(e); }
+                c->cur ^= 1;
+                c->adapt_pending = true;
+                c->adapt_pending_adaptive = c->cfg.adaptive != 0;
+            }
+            c->iter += 1;
+        }
+    }
+    flush_adapt(c);      // the ladder and the swap counters are final when the call's work completes
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;
     if (prof) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        // events come in (start, stop) pairs in launch order: per batch [plan] then per iter [s0][s1][pt]
         size_t e = 0;
-        for (int64_t done = 0; done < n_iters;) {
-            const int nb = (int)std::min<int64_t>(c->NB, n_iters - done);
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
-            c->timing.plan_ms += ms; c->timing.n_plan += 1;
-            for (int ib = 0; ib < nb; ++ib) {
-                for (int s = 0; s < 2; ++s) {
-                    (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
-                    c->timing.stretch_ms += ms; c->timing.n_stretch += 1;
-                }
-                if (pt) {
-                    (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
-                    c->timing.pt_ms += ms; c->timing.n_pt += 1;
-                }
+        float ms = 0;
+        for (int64_t i = 0; i < n_iters; ++i) {
+            for (int s = 0; s < 2; ++s) {
+                (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
+                c->timing.stretch_ms += ms; c->timing.n_stretch += 1;
             }
-            done += nb;
+            if (pt) {
+                (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
+                c->timing.pt_ms += ms; c->timing.n_pt += 1;
+            }
         }
     }
     return HENS_OK;
@@ -746,6 +855,7 @@ int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals, d
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     std::vector<uint32_t> acc;
     if (accepted) {
@@ -754,10 +864,10 @@ int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals, d
     }
     if (swaps_last && c->T > 1) HIPCHK(c, hipMemcpyAsync(swaps_last, c->swaps_last, (size_t)(c->T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
     if (swaps_total && c->T > 1) HIPCHK(c, hipMemcpyAsync(swaps_total, c->swaps_total, (size_t)(c->T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    if (adapt_time) HIPCHK(c, hipMemcpyAsync(adapt_time, c->adapt_time, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (accepted) for (size_t i = 0; i < TW; ++i) accepted[i] = (double)acc[i];
     if (num_proposals) *num_proposals = c->num_proposals;
+    if (adapt_time) *adapt_time = c->adapt_time;
     return HENS_OK;
 }
 
@@ -765,6 +875,7 @@ int hens_reset_counters(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
     HIPCHK(c, hipMemsetAsync(c->accepted, 0, (size_t)c->Tl * c->W * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
@@ -777,8 +888,8 @@ int hens_set_adapt_time(hens_ctx* ctx, int64_t t) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    HIPCHK(c, hipMemcpyAsync(c->adapt_time, &t, 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    flush_adapt(c);
+    c->adapt_time = t;
     return HENS_OK;
 }
 
@@ -825,21 +936,7 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
     return HENS_OK;
 }
 
-static int ensure_shard_buffers(hens_ctx_impl* c) {
-    if (c->gather_L) return HENS_OK;
-    const size_t TW = (size_t)c->T * c->W, cap = (size_t)c->Tl * c->W;
-    int r;
-    if ((r = dalloc(c, &c->gather_L, TW))) return r;
-    if ((r = dalloc(c, &c->srcglob, TW))) return r;
-    if ((r = dalloc(c, &c->send_rows, cap * (c->D + 2)))) return r;
-    if ((r = dalloc(c, &c->recv_rows, cap * (c->D + 2)))) return r;
-    if ((r = dalloc(c, &c->send_slots, cap))) return r;
-    if ((r = dalloc(c, &c->recv_slots, cap))) return r;       // used as send_dest
-    if ((r = dalloc(c, &c->d_counts, 4 * MAX_RANKS))) return r;
-    c->row_capacity = (int64_t)cap;
-    return HENS_OK;
-}
-
+// ---- ladder sharding ---------------------------------------------------------------------------------
 int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -863,24 +960,12 @@ int hens_stretch_iter(hens_ctx* ctx) {
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_stretch_iter between split 0 and split 1");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    const int Tl = c->Tl, W = c->W;
-    c->N0 = (W + 1) / 2;
-    PlanArgs pa{};
-    pa.order = c->order; pa.colslot = c->colslot; pa.clock = c->clock; pa.seed = c->cfg.seed;
-    pa.Tl = Tl; pa.T = c->T; pa.W = W; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
-    pa.n_split = Tl; pa.jobs_per_iter = Tl; pa.idx_bits = c->idx_bits;
-    hipLaunchKernelGGL(k_plan, dim3(Tl), dim3(std::min(1024, std::max(64, c->NP2 / 2))), (size_t)c->NP2 * 8, c->stream, pa);
-    for (int split = 0; split < 2; ++split) {
-        StretchArgs a = base_args(c);
-        a.split = split;
-        a.home_off = c->parity * Tl * W;
-        const int Ns = split == 0 ? c->N0 : W - c->N0;
-        r = launch_stretch<MODE_PHILOX>(c, a, (Ns + TILE - 1) / TILE);
-        if (r) return r;
-    }
-    c->parity ^= 1;
-    c->num_proposals += 1;
-    if (!(c->cfg.tempered && c->T > 1)) hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, c->stream, c->clock);
+    flush_adapt(c);
+    c->N0 = (c->W + 1) / 2;
+    launch_plan(c, c->stream, 0, c->iter, 1, true, false);
+    r = stretch_pair(c, 0, 0, nullptr);
+    if (r) return r;
+    if (!has_pt(c)) c->iter += 1;
     HIPCHK(c, hipGetLastError());
     return HENS_OK;
 }
@@ -899,21 +984,20 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         return fail(c, HENS_ERR_INVALID, "nranks must be in [1, %d] and my_rank inside it", MAX_RANKS);
     const bool parity_draws = iperm != nullptr;
     if (parity_draws && (!i1perm || !u_swap)) return fail(c, HENS_ERR_INVALID, "give iperm, i1perm and u_swap together");
-    const int T = c->T, W = c->W, Tl = c->Tl;
+    const int T = c->T, W = c->W;
     for (int t = 0; t < T; ++t) {
         if (rank_of_rung[t] < 0 || rank_of_rung[t] >= nranks) return fail(c, HENS_ERR_INVALID, "rank_of_rung out of range");
         const bool mine = t >= c->cfg.rung_begin && t < c->cfg.rung_end;
         if (mine != (rank_of_rung[t] == my_rank)) return fail(c, HENS_ERR_INVALID, "rank_of_rung disagrees with this context's shard");
     }
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
     if ((r = ensure_shard_buffers(c))) return r;
     if ((r = ensure_pt_buffers(c))) return r;
     const size_t PW = (size_t)(T - 1) * W;
-    if (!c->d_rank_of) { if ((r = dalloc(c, &c->d_rank_of, (size_t)T))) return r; }
     HIPCHK(c, hipMemcpyAsync(c->d_rank_of, rank_of_rung, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
-    PtArgs p = pt_args(c, c->colslot, true);
-    p.adapt = (adapt && c->cfg.adaptive) ? 1 : 0;
-    p.tick = 0;                                   // the clock advances in hens_pt_finish_sharded
+    int32_t* colslot = c->db[0].colslot;
+    PtArgs p = pt_args(c, colslot, true);
     p.selcol = c->selcol;
     if (parity_draws) {
         HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
@@ -921,23 +1005,20 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_pt_invert, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->d_iperm, c->d_inv, T - 1, W);
         hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm,
-                           c->d_inv, c->d_uswap, c->colslot, c->colk, c->colu, T, W);
+                           c->d_inv, c->d_uswap, colslot, c->colk, c->colu, T, W);
         p.colu = c->colu;
-        hipLaunchKernelGGL(k_pt_cascade<false>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS), pt_lds_bytes(T),
-                           c->stream, p);
+        hipLaunchKernelGGL(k_pt_cascade<false>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
         hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk,
                            c->selk, T - 1, W);
     } else {
-        PlanArgs pa{};
-        pa.order = c->order; pa.colslot = c->colslot; pa.clock = c->clock; pa.seed = c->cfg.seed;
-        pa.Tl = Tl; pa.T = T; pa.W = W; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
-        pa.n_split = 0; pa.jobs_per_iter = T; pa.idx_bits = c->idx_bits;
-        hipLaunchKernelGGL(k_plan, dim3(T), dim3(std::min(1024, std::max(64, c->NP2 / 2))), (size_t)c->NP2 * 8, c->stream, pa);
-        hipLaunchKernelGGL(k_pt_cascade<true>, dim3((W + PT_COLS - 1) / PT_COLS), dim3(PT_THREADS), pt_lds_bytes(T),
-                           c->stream, p);
+        launch_plan(c, c->stream, 0, c->iter, 1, false, true);
+        hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
     }
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = adapt && c->cfg.adaptive;
+    flush_adapt(c);
     // who sends what to whom
-    unsigned* counts = reinterpret_cast<unsigned*>(c->d_counts);
+    unsigned* counts = c->d_counts;
     HIPCHK(c, hipMemsetAsync(counts, 0, 2 * MAX_RANKS * sizeof(unsigned), c->stream));
     const int g = grid_for((int64_t)T * W);
     hipLaunchKernelGGL(k_xchg_count, dim3(g), dim3(256), 0, c->stream, c->srcglob, c->d_rank_of, T, W, (int)my_rank, counts);
@@ -958,9 +1039,9 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
     HIPCHK(c, hipMemcpyAsync(d_cursors, cursors, sizeof cursors, hipMemcpyHostToDevice, c->stream));
     if (nsend > 0) {
         hipLaunchKernelGGL(k_xchg_fill, dim3(g), dim3(256), 0, c->stream, c->srcglob, c->d_rank_of, T, W, (int)my_rank,
-                           (int)c->cfg.rung_begin, d_cursors, c->send_slots, c->recv_slots);
+                           (int)c->cfg.rung_begin, d_cursors, c->send_slots, c->send_dest);
         hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(nsend * (c->D + 2))), dim3(256), 0, c->stream, c->pool,
-                           c->loc[c->cur], c->P[c->cur], c->send_slots, c->recv_slots, c->send_rows, nsend, c->D);
+                           c->loc[c->cur], c->P[c->cur], c->send_slots, c->send_dest, c->send_rows, nsend, c->D);
     }
     HIPCHK(c, hipGetLastError());
     if (sel_out && parity_draws) HIPCHK(c, hipMemcpyAsync(sel_out, c->selk, PW, hipMemcpyDeviceToHost, c->stream));
@@ -981,9 +1062,9 @@ int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
         hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(n_recv * (c->D + 2))), dim3(256), 0, c->stream, c->pool,
                            c->loc[c->cur ^ 1], c->P[c->cur ^ 1], c->recv_rows, n_recv, c->D, c->W,
                            (int)c->cfg.rung_begin, (int32_t)(c->parity * c->Tl * c->W));
-    hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, c->stream, c->clock);
     HIPCHK(c, hipGetLastError());
     c->cur ^= 1;
+    c->iter += 1;
     c->pt_pending = false;
     return HENS_OK;
 }

@@ -1,39 +1,38 @@
 // hens_kernels.h - gfx950 (CDNA4, wave64) device code of libhipensemble.
 //
-// Compiled with -ffp-contract=off: every a*b+c below rounds twice like NumPy
-// unless it is written as an explicit fma().  That is what makes the proposal
-// q = c - (c - s) * zz (stretch.py:143-145) and the accept arithmetic
-// (red_blue.py:292) bit-identical to the reference.
+// Compiled with -ffp-contract=off: every a*b+c below rounds twice like NumPy unless it is
+// written as an explicit fma().  That is what makes the proposal q = c - (c - s) * zz
+// (stretch.py:143-145) and the accept arithmetic (red_blue.py:292) bit-identical to the
+// reference.  All file:line citations are relative to /root/reference/src/eryn.
 //
 // Data layout in HBM (one context = the ladder shard [rung_begin, rung_end)):
 //   pool   f64 [2 * Tl * W][D]   walker rows, AoS (a row is one contiguous 8*D-byte burst).
 //                                Every walker (tl, w) owns two "home" rows, tl*W+w and
-//                                Tl*W + tl*W+w; iteration parity p writes proposals' results
-//                                into home_p and reads through `loc`, so a stretch step is
-//                                read-own + read-complement + write-own with no in-place hazard
-//                                and the PT cascade never moves a row: it permutes `loc`.
-//   loc    i32 [Tl * W]          pool row currently holding walker (tl, w)
-//   L, P   f64 [Tl * W]          log-likelihood / log-prior (double buffered for the cascade)
-//   betas  f64 [T]               full ladder
+//                                Tl*W + tl*W+w; iteration parity p writes into home_p and reads
+//                                through `loc`, so a stretch step is read-own + read-complement +
+//                                write-own with no in-place hazard, and the PT cascade never moves
+//                                a row: it permutes `loc`.
+//   loc    i32 [Tl * W]          pool row currently holding walker (tl, w)   (double buffered)
+//   L, P   f64 [Tl * W]          log-likelihood / log-prior                  (double buffered)
+//   betas  f64 [T]               full ladder                                  (double buffered)
+//   draws  per iteration, per rung, per split position: own i32, cw i32, zz f64, fac f64, lu f64
+//          - everything about a proposal that does not depend on the state.  Built ahead of time
+//          by the plan kernel (Philox) or from the caller's NumPy draws (parity mode).
 #pragma once
 #include <hip/hip_runtime.h>
-#ifndef HENS_ABLATE
-#define HENS_ABLATE 0   // timing experiments only (tools/ablate.sh): bit0 no quad form, bit1 no logs, bit2 no row write, bit3 no philox
-#endif
 #include <stdint.h>
 
 namespace hens {
 
-constexpr int TILE = 64;                 // walkers per workgroup = one wavefront of walker-lanes
+constexpr int TILE = 64;                    // walkers per workgroup = one wavefront of walker-lanes
 constexpr unsigned FLAG_NONFINITE_X = 1u;   // inf/NaN coordinate seen (ensemble.py:1258-1262)
 constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-281)
 
 enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2 };
-enum { MODE_PARITY = 0, MODE_PHILOX = 1, MODE_EVAL = 2 };
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: draws are a pure function of
-// (seed, iteration, purpose, walker), so any kernel / any rank regenerates them identically.
+// (seed, iteration, purpose, global rung, walker), so any kernel / any rank regenerates them.
 // ---------------------------------------------------------------------------------------------
 struct u4 { uint32_t x, y, z, w; };
 
@@ -52,8 +51,42 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // 53-bit un
     const uint64_t v = ((uint64_t)hi << 32) | lo;
     return (double)(v >> 11) * (1.0 / 9007199254740992.0);
 }
-enum : uint32_t { PURPOSE_STRETCH0 = 0, PURPOSE_STRETCH1 = 1, PURPOSE_STRETCH_ACC = 2,
-                  PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9, PURPOSE_PTU = 10 };
+enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
+                  PURPOSE_PTU = 10 };
+
+// The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
+struct Draws {
+    int32_t* own;    // [Tl][W] moving walker at each split position (positions < N0: split 0)
+    int32_t* cw;     // [Tl][W] its complement walker
+    double* zz;      // [Tl][W] stretch factor ((a-1) u + 1)^2 / a
+    double* fac;     // [Tl][W] (D - 1) log zz
+    double* lu;      // [Tl][W] log of the accept uniform
+};
+
+__device__ __forceinline__ void make_draw(const Draws& d, size_t idx, int own, int cw, double uz, double ua,
+                                          double a, int D) {
+    double zz = (a - 1.0) * uz + 1.0;              // stretch.py:129-132 (mul, add, square, divide)
+    zz = zz * zz / a;
+    d.own[idx] = own;
+    d.cw[idx] = cw;
+    d.zz[idx] = zz;
+    d.fac[idx] = ((double)D - 1.0) * log(zz);      // stretch.py:223
+    d.lu[idx] = log(ua);                           // red_blue.py:294
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ladder adaptation (tempering.py:563-596) from the per-workgroup swap counts of the cascade.
+// ---------------------------------------------------------------------------------------------
+struct AdaptArgs {
+    const uint32_t* swap_part;  // [nblocks][T-1] per-workgroup swap counts of the last cascade
+    const double* betas_in;     // [T]
+    double* betas_out;          // [T] (may alias betas_in when run as its own kernel)
+    double* swaps_last;         // [T-1]
+    double* swaps_total;        // [T-1]
+    double lag, nu;
+    int64_t time;               // adaptation steps taken so far (tempering.py:596)
+    int32_t T, W, nblocks, moving;   // moving: adaptive and not past stop_adaptation (tempering.py:591)
+};
 
 // ---------------------------------------------------------------------------------------------
 // Stretch half-step: propose + box prior + likelihood + tempered MH test + update, fused.
@@ -64,60 +97,49 @@ struct StretchArgs {
     double* L;
     double* P;
     const double* betas;       // [T] or nullptr when not tempered
-    const int32_t* order;      // [Tl][W]: first N0 entries = walkers of split 0, rest = split 1
+    Draws dr;
     uint32_t* accepted;        // [Tl][W] cumulative accept counts
     uint8_t* keep_out;         // [Tl][Ns] or nullptr
-    const int64_t* rint;       // parity draws [Tl][Ns]
-    const double* u_zz;
-    const double* u_acc;
     const double* lo;
     const double* hi;
     const double* mu;
     const double* prec;
-    const uint64_t* clock;     // device iteration counter
     unsigned* flags;
-    unsigned long long* trace;  // debug: per-workgroup phase timestamps (s_memtime), or nullptr
-    double a, logp_in, fill, rosen_a, rosen_b;
-    uint64_t seed;
+    unsigned long long* trace; // debug: per-workgroup phase timestamps (s_memtime), or nullptr
+    double logp_in, fill, rosen_a, rosen_b;
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
+    int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
+    AdaptArgs ad;
 };
 
-template <int DT> struct DimOf { static __device__ __forceinline__ int get(int d) { return DT; } };
-template <> struct DimOf<0> { static __device__ __forceinline__ int get(int d) { return d; } };
-
-// One workgroup = TILE (64) walkers of one rung, NW wavefronts.
-//   phase A  lane-per-walker : indices, draws, stretch factor            (wave 0)
+// One workgroup = TILE (64) walkers of one rung, NW wavefronts.  Generic row width (runtime D).
+//   phase A  lane-per-walker : indices, draws                              (wave 0)
 //   phase B  lanes-over-d    : coalesced row gathers, q = c-(c-s)zz, box test by ballot -> LDS
-//   phase C  lane-per-walker : quadratic form, rows of the precision matrix split over the NW
-//                              waves and fed from SGPRs (scalar loads), q held in VGPRs
+//   phase C  lane-per-walker : quadratic form, rows of the precision matrix split over the waves
 //   phase D  lane-per-walker : tempered MH test, L/P/loc/accept counters
 //   phase E  lanes-over-d    : coalesced write of the new row (q if kept, old row otherwise)
-template <int DT, int LIKE, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
+template <int LIKE, bool EVAL>
+__global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int D = DimOf<DT>::get(A.D);
-    const int RS = (DT > 0) ? ((DT % 2 == 0) ? DT + 2 : DT) : A.RS;   // LDS row stride (doubles)
-    constexpr int NT = NW * 64;
+    constexpr int NW = 4, NT = 256;
+    const int D = A.D, RS = A.RS;
     double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
     double* s_zz = qtile + TILE * RS;                                    // [TILE]
     double* s_part = s_zz + TILE;                                        // [NW][TILE]
     int32_t* s_rs = reinterpret_cast<int32_t*>(s_part + NW * TILE);      // [TILE] own row
     int32_t* s_rc = s_rs + TILE;                                         // [TILE] complement row
     int32_t* s_dst = s_rc + TILE;                                        // [TILE] destination row
-    int32_t* s_flag = s_dst + TILE;                                      // [TILE] bit0 inbox, bit1 keep, bit2 valid
+    int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tl = blockIdx.y;
     const int W = A.W;
-    const int Ns = (MODE == MODE_EVAL) ? W : (A.split == 0 ? A.N0 : W - A.N0);
-    const int Nc = W - Ns;
-    const int s_off = (MODE == MODE_EVAL) ? 0 : (A.split == 0 ? 0 : A.N0);
-    const int c_off = (A.split == 0 ? A.N0 : 0);
+    const int Ns = EVAL ? W : (A.split == 0 ? A.N0 : W - A.N0);
+    const int s_off = EVAL ? 0 : (A.split == 0 ? 0 : A.N0);
     const int k0 = blockIdx.x * TILE;
 
-    // ---- phase A ---------------------------------------------------------------------------
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0;
     int own = 0;
     bool valid = false;
@@ -127,37 +149,19 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
         double zz = 1.0;
         int rs = 0, rc = 0;
         if (valid) {
-            if (MODE == MODE_EVAL) {
+            if (EVAL) {
                 own = k;
                 rs = A.loc[tl * W + own];
                 rc = rs;
             } else {
-                own = A.order[tl * W + s_off + k];
-                double uz, ua;
-                int r;
-                if (MODE == MODE_PARITY) {
-                    r = (int)A.rint[(size_t)tl * Ns + k];
-                    uz = A.u_zz[(size_t)tl * Ns + k];
-                    ua = A.u_acc[(size_t)tl * Ns + k];
-                } else {
-                    const uint64_t it = A.clock[0];
-                    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32),
-                                 (uint32_t)((A.rung_begin + tl) * W + own), PURPOSE_STRETCH0};
-                    const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                    r = (int)__umulhi(d.x, (uint32_t)Nc);
-                    uz = u01(d.y, d.z);
-                    u4 ctr2 = ctr;
-                    ctr2.w = PURPOSE_STRETCH_ACC;
-                    const u4 e = philox4x32_10(ctr2, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                    ua = u01(e.x, e.y);
-                }
-                const int cw = A.order[tl * W + c_off + r];
+                const size_t di = (size_t)tl * W + s_off + k;
+                own = A.dr.own[di];
+                const int cw = A.dr.cw[di];
+                zz = A.dr.zz[di];
+                factors = A.dr.fac[di];
+                lu = A.dr.lu[di];
                 rs = A.loc[tl * W + own];
-                rc = A.loc[tl * W + cw];
-                zz = (A.a - 1.0) * uz + 1.0;          // stretch.py:129-132
-                zz = zz * zz / A.a;
-                factors = ((double)D - 1.0) * log(zz);   // stretch.py:223
-                lu = log(ua);                            // red_blue.py:294
+                rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
                 Lold = A.L[tl * W + own];
                 Pold = A.P[tl * W + own];
             }
@@ -170,8 +174,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
     }
     __syncthreads();
 
-    // ---- phase B: lanes over d -------------------------------------------------------------
-    // VEC doubles per lane; LPR lanes per row (power of two <= 64); RPP rows per pass.
+    // ---- phase B: VEC doubles per lane; LPR lanes per row (power of two <= 64); RPP rows per pass
     const int VEC = (D % 2 == 0) ? 2 : 1;
     const int chunks = D / VEC;
     int LPR = 1;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
     const double* __restrict__ pool_r = A.pool;
     for (int r0 = 0; r0 < TILE; r0 += RPP) {
         const int r = r0 + rsub;
-        const bool rvalid = (r < TILE) && (s_flag[r] & 4) != 0;   // RPP may exceed TILE for tiny D
+        const bool rvalid = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;   // RPP may exceed TILE for tiny D
         bool ok = true, finite = true;
         if (rvalid) {
             const double zz = s_zz[r];
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
                 if (VEC == 2) {
                     const double2 sv = *reinterpret_cast<const double2*>(ps + e);
                     double2 qv;
-                    if (MODE == MODE_EVAL) {
+                    if (EVAL) {
                         qv = sv;
                     } else {
                         const double2 cv = *reinterpret_cast<const double2*>(pc + e);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
                 } else {
                     const double sv = ps[e];
                     double qv;
-                    if (MODE == MODE_EVAL) {
+                    if (EVAL) {
                         qv = sv;
                     } else {
                         const double cv = pc[e];
@@ -232,13 +235,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
     }
     __syncthreads();
 
-    // ---- phase C: likelihood, lane per walker, precision rows split over waves ---------------
+    // ---- phase C
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
         double part = 0.0;
-        // model constants are read-only for the whole launch: address them through the constant
-        // address space so wave-uniform indices become SGPR scalar loads (s_load_dwordx*)
-        typedef const __attribute__((address_space(4))) double* cptr_t;
+        typedef const __attribute__((address_space(4))) double* cptr_t;   // read-only for the launch: scalar loads
         const cptr_t mu = (cptr_t)(uintptr_t)A.mu;
         const cptr_t prec = (cptr_t)(uintptr_t)A.prec;
         const double* qrow = qtile + lane * RS;
@@ -252,55 +253,19 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
                 }
                 part = 2.0 * acc;      // phase D multiplies by -0.5
             }
-        } else if (DT > 0) {
-            constexpr int DC = (DT > 0) ? DT : 1;
-            constexpr int RB = (DC + NW - 1) / NW;
-            if (inbox) {
-                double qreg[DC];
-#pragma unroll
-                for (int k = 0; k < DC; ++k) qreg[k] = qrow[k] - mu[k];
-                const int i0 = wv * RB;
-                if (LIKE == LIKE_DENSE) {
-#pragma unroll 2
-                    for (int ii = 0; ii < RB; ++ii) {
-                        const int i = i0 + ii;
-                        if (i < DC) {
-                            const cptr_t prow = prec + (size_t)i * DC;
-                            double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-                            for (int k = 0; k + 1 < DC; k += 2) {
-                                y0 = fma(prow[k], qreg[k], y0);
-                                y1 = fma(prow[k + 1], qreg[k + 1], y1);
-                            }
-                            if (DC & 1) y0 = fma(prow[DC - 1], qreg[DC - 1], y0);
-                            part = fma(qrow[i] - mu[i], y0 + y1, part);
-                        }
-                    }
-                } else {
-                    for (int ii = 0; ii < RB; ++ii) {
-                        const int i = i0 + ii;
-                        if (i < DC) {
-                            const double di = qrow[i] - mu[i];
-                            part = fma(di * prec[i], di, part);
-                        }
-                    }
-                }
-            }
-        } else {
+        } else if (inbox) {
             const int RB = (D + NW - 1) / NW;
-            if (inbox) {
-                const int i0 = wv * RB;
-                for (int ii = 0; ii < RB; ++ii) {
-                    const int i = i0 + ii;
-                    if (i < D) {
-                        const double di = qrow[i] - mu[i];
-                        if (LIKE == LIKE_DENSE) {
-                            double y = 0.0;
-                            for (int k = 0; k < D; ++k) y = fma(prec[(size_t)i * D + k], qrow[k] - mu[k], y);
-                            part = fma(di, y, part);
-                        } else {
-                            part = fma(di * prec[i], di, part);
-                        }
+            const int i0 = wv * RB;
+            for (int ii = 0; ii < RB; ++ii) {
+                const int i = i0 + ii;
+                if (i < D) {
+                    const double di = qrow[i] - mu[i];
+                    if (LIKE == LIKE_DENSE) {
+                        double y = 0.0;
+                        for (int k = 0; k < D; ++k) y = fma(prec[(size_t)i * D + k], qrow[k] - mu[k], y);
+                        part = fma(di, y, part);
+                    } else {
+                        part = fma(di * prec[i], di, part);
                     }
                 }
             }
@@ -309,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
     }
     __syncthreads();
 
-    // ---- phase D: accept / update, lane per walker -------------------------------------------
+    // ---- phase D
     if (wv == 0 && valid) {
         const bool inbox = (s_flag[lane] & 1) != 0;
         double acc = 0.0;
@@ -322,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
         }
         const double logp = inbox ? A.logp_in : -INFINITY;     // prior.py:80-88
         const size_t gi = (size_t)tl * W + own;
-        if (MODE == MODE_EVAL) {
+        if (EVAL) {
             A.L[gi] = logl;
             A.P[gi] = logp;
         } else {
@@ -351,10 +316,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
             if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
         }
     }
-    if (MODE == MODE_EVAL) return;
+    if (EVAL) return;
     __syncthreads();
 
-    // ---- phase E: write rows, lanes over d ----------------------------------------------------
+    // ---- phase E
     double* __restrict__ pool_w = A.pool;
     for (int r0 = 0; r0 < TILE; r0 += RPP) {
         const int r = r0 + rsub;
@@ -380,12 +345,14 @@ __global__ __launch_bounds__(NW * 64) void k_stretch(const StretchArgs A) {
 // ---------------------------------------------------------------------------------------------
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
-//     flight) instead of one pass at a time -> the kernel is latency-bound at config-2 size, so
-//     memory-level parallelism is what buys time;
+//     flight) - the kernel is latency-bound at config-2 size, memory-level parallelism buys time;
 //   * the old row stays in registers for the write-back (no re-read on reject);
-//   * the two log() calls of the accept test are issued while those loads are in flight.
+//   * optionally (ad_on) the ladder adaptation that follows the previous PT cascade is folded in:
+//     every workgroup reduces the cascade's per-workgroup swap counts while its row gathers are
+//     in flight and recomputes the ladder in one wavefront; workgroup (0,0) publishes it.  That
+//     removes a dependent single-workgroup launch (~5.5 us + boundary) from every iteration.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int LIKE, int MODE, int NW, bool PLDS>
+template <int DT, int LIKE, bool EVAL, int NW>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -399,84 +366,60 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
     double* s_zz = qtile + TILE * RS;                                    // [TILE]
     double* s_part = s_zz + TILE;                                        // [NW][TILE]
-    int32_t* s_rs = reinterpret_cast<int32_t*>(s_part + NW * TILE);      // [TILE]
+    double* s_beta = s_part + NW * TILE;                                 // [64] adapted ladder (ad_on)
+    int32_t* s_rs = reinterpret_cast<int32_t*>(s_beta + 64);             // [TILE]
     int32_t* s_rc = s_rs + TILE;
     int32_t* s_dst = s_rc + TILE;
     int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
-    double* s_prec = reinterpret_cast<double*>(s_flag + TILE);           // [DT][DT] when PLDS
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [64] swap counts (ad_on)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tl = blockIdx.y;
     const int W = A.W;
-    const int Ns = (MODE == MODE_EVAL) ? W : (A.split == 0 ? A.N0 : W - A.N0);
-    const int Nc = W - Ns;
-    const int s_off = (MODE == MODE_EVAL) ? 0 : (A.split == 0 ? 0 : A.N0);
-    const int c_off = (A.split == 0 ? A.N0 : 0);
+    const int Ns = EVAL ? W : (A.split == 0 ? A.N0 : W - A.N0);
+    const int s_off = EVAL ? 0 : (A.split == 0 ? 0 : A.N0);
     const int k0 = blockIdx.x * TILE;
+    const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     HENS_TRACE(0);
 
-    if (PLDS && LIKE == LIKE_DENSE) {
-        // stage the precision matrix in LDS while phase A/B wait on their gathers: phase C then has
-        // no global latency at all (a cold scalar cache costs ~1 us per pair of rows otherwise)
-        for (int i = tid * 2; i < DT * DT; i += NT * 2)
-            *reinterpret_cast<double2*>(s_prec + i) = *reinterpret_cast<const double2*>(A.prec + i);
-    }
-    // ---- phase A (wave 0): indices and draws; the logs wait until the row loads are in flight ---
-    double zz_own = 1.0, ua = 1.0, Lold = 0.0, Pold = 0.0;
+    // ---- phase A (wave 0): indices and draws -------------------------------------------------------
+    double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0;
     int own = 0;
     bool valid = false;
     if (wv == 0) {
         const int k = k0 + lane;
         valid = k < Ns;
+        double zz = 1.0;
         int rs = 0, rc = 0;
         if (valid) {
-            if (MODE == MODE_EVAL) {
+            if (EVAL) {
                 own = k;
                 rs = A.loc[tl * W + own];
                 rc = rs;
             } else {
-                own = A.order[tl * W + s_off + k];
-                double uz;
-                int r;
-                if (MODE == MODE_PARITY) {
-                    r = (int)A.rint[(size_t)tl * Ns + k];
-                    uz = A.u_zz[(size_t)tl * Ns + k];
-                    ua = A.u_acc[(size_t)tl * Ns + k];
-                } else {
-                    const uint64_t it = A.clock[0];
-                    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32),
-                                 (uint32_t)((A.rung_begin + tl) * W + own), PURPOSE_STRETCH0};
-                    u4 d, e;
-                    if (HENS_ABLATE & 8) {
-                        d = u4{ctr.z * 2654435761u + ctr.x, ctr.z * 40503u, ctr.x * 7919u + ctr.z, 0u};
-                        e = u4{d.y, d.x, 0u, 0u};
-                    } else {
-                        d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                        u4 ctr2 = ctr;
-                        ctr2.w = PURPOSE_STRETCH_ACC;
-                        e = philox4x32_10(ctr2, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                    }
-                    r = (int)__umulhi(d.x, (uint32_t)Nc);
-                    uz = u01(d.y, d.z);
-                    ua = u01(e.x, e.y);
-                }
-                const int cw = A.order[tl * W + c_off + r];
+                const size_t di = (size_t)tl * W + s_off + k;
+                own = A.dr.own[di];
+                const int cw = A.dr.cw[di];
+                zz = A.dr.zz[di];
+                factors = A.dr.fac[di];
+                lu = A.dr.lu[di];
                 rs = A.loc[tl * W + own];
-                rc = A.loc[tl * W + cw];
+                // split 1's complement walkers were all rewritten by split 0: their row is their home
+                rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
                 Lold = A.L[tl * W + own];
                 Pold = A.P[tl * W + own];
-                zz_own = (A.a - 1.0) * uz + 1.0;      // stretch.py:129-132
-                zz_own = zz_own * zz_own / A.a;
             }
         }
-        s_zz[lane] = zz_own;
+        s_zz[lane] = zz;
         s_rs[lane] = rs;
         s_rc[lane] = rc;
         s_dst[lane] = A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
+    } else if (ad_on && wv == 1) {
+        s_cnt[lane] = 0;
     }
     HENS_TRACE(1);
     __syncthreads();
@@ -496,15 +439,21 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rs[r] * D + jl * 2);
-            if (MODE != MODE_EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rc[r] * D + jl * 2);
+            if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rc[r] * D + jl * 2);
         }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
-    double factors = 0.0, lu = 0.0;
-    if (MODE != MODE_EVAL && wv == 0 && !(HENS_ABLATE & 2)) {
-        factors = ((double)D - 1.0) * log(zz_own);       // stretch.py:223
-        lu = log(ua);                                    // red_blue.py:294
+    unsigned adv[8];
+    double ad_b = 1.0;
+    if (ad_on) {                                   // the cascade's per-workgroup swap counts: <= 8 per thread
+        const int total = A.ad.nblocks * (A.ad.T - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * NT;
+            adv[q] = (e < total) ? A.ad.swap_part[e] : 0u;
+        }
+        if (wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
     }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
@@ -512,7 +461,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         bool ok = true, finite = true;
         if (rv[p]) {
             double2 qv;
-            if (MODE == MODE_EVAL) {
+            if (EVAL) {
                 qv = sreg[p];
             } else {
                 const double zz = s_zz[r];
@@ -532,15 +481,60 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
         }
     }
+    if (ad_on) {
+        const int Tm1 = A.ad.T - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
+    }
     HENS_TRACE(3);
     __syncthreads();
     HENS_TRACE(4);
+
+    // ---- ladder adaptation in one wavefront (tempering.py:563-596), T <= 64 ---------------------------
+    if (ad_on && wv == 1) {
+        const int T = A.ad.T;
+        const double cntl = (lane < T - 1) ? (double)s_cnt[lane] : 0.0;
+        const double r = cntl / (double)A.ad.W;                             // :587
+        double bnew = ad_b;
+        if (A.ad.moving) {
+            const double decay = A.ad.lag / ((double)A.ad.time + A.ad.lag); // :571
+            const double kappa = decay / A.ad.nu;                           // :572
+            const double r1 = __shfl_down(r, 1);
+            const double b1 = __shfl_down(ad_b, 1);
+            double dTl = 0.0;
+            if (lane + 2 < T) {
+                const double dS = kappa * (r - r1);                         // :575
+                dTl = 1.0 / b1 - 1.0 / ad_b;                                // :578
+                dTl *= exp(dS);
+            }
+            double csum = 0.0;                                              // np.cumsum: left-to-right
+            for (int i = 0; i + 2 < T; ++i) {
+                const double v = __shfl(dTl, i);
+                if (i == 0) csum = v;
+                else if (i <= lane) csum = csum + v;
+            }
+            const double inv0 = 1.0 / __shfl(ad_b, 0);
+            const double bn = 1.0 / (csum + inv0);                          // :580, belongs to rung lane+1
+            const double upd = b1 + (bn - b1);                              // :583,:593
+            const double from_below = __shfl_up(upd, 1);
+            if (lane >= 1 && lane + 1 < T) bnew = from_below;
+        }
+        if (lane < T) s_beta[lane] = bnew;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (lane < T) A.ad.betas_out[lane] = bnew;
+            if (lane < T - 1) {
+                A.ad.swaps_last[lane] = cntl;
+                A.ad.swaps_total[lane] += cntl;
+            }
+        }
+    }
 
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
         double part = 0.0;
-        typedef const __attribute__((address_space(4))) double* cptr_t;
+        typedef const __attribute__((address_space(4))) double* cptr_t;   // read-only for the launch: SGPR scalar loads
         const cptr_t mu = (cptr_t)(uintptr_t)A.mu;
         const cptr_t prec = (cptr_t)(uintptr_t)A.prec;
         const double* qrow = qtile + lane * RS;
@@ -554,7 +548,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 }
                 part = 2.0 * acc;
             }
-        } else if (inbox && !(HENS_ABLATE & 1)) {
+        } else if (inbox) {
             constexpr int RB = (DT + NW - 1) / NW;
             const int i0 = wv * RB;
             if (LIKE == LIKE_DENSE) {
@@ -569,22 +563,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 for (int ii = 0; ii < RB; ++ii) {
                     const int i = i0 + ii;
                     if (i < DT) {
+                        const cptr_t prow = prec + (size_t)i * DT;
                         double y0 = 0.0, y1 = 0.0;
-                        if (PLDS) {
-                            const double* prow = s_prec + i * DT;       // wave-uniform address: LDS broadcast
 #pragma unroll
-                            for (int k = 0; k < DT; k += 2) {
-                                const double2 pv = *reinterpret_cast<const double2*>(prow + k);
-                                y0 = fma(pv.x, qreg[k], y0);
-                                y1 = fma(pv.y, qreg[k + 1], y1);
-                            }
-                        } else {
-                            const cptr_t prow = prec + (size_t)i * DT;  // SGPR operands via s_load
-#pragma unroll
-                            for (int k = 0; k < DT; k += 2) {
-                                y0 = fma(prow[k], qreg[k], y0);
-                                y1 = fma(prow[k + 1], qreg[k + 1], y1);
-                            }
+                        for (int k = 0; k < DT; k += 2) {
+                            y0 = fma(prow[k], qreg[k], y0);
+                            y1 = fma(prow[k + 1], qreg[k + 1], y1);
                         }
                         part = fma(qrow[i] - mu[i], y0 + y1, part);
                     }
@@ -617,13 +601,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         }
         const double logp = inbox ? A.logp_in : -INFINITY;     // prior.py:80-88
         const size_t gi = (size_t)tl * W + own;
-        if (MODE == MODE_EVAL) {
+        if (EVAL) {
             A.L[gi] = logl;
             A.P[gi] = logp;
         } else {
             double logP, prevP;
             if (A.tempered) {                                  // tempering.py:304-306,343-349
-                const double beta = A.betas[A.rung_begin + tl];
+                const double beta = ad_on ? s_beta[A.rung_begin + tl] : A.betas[A.rung_begin + tl];
                 double lt = logl * beta;
                 if (lt != lt) lt = -INFINITY;
                 logP = lt + logp;
@@ -646,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
         }
     }
-    if (MODE == MODE_EVAL) return;
+    if (EVAL) return;
     HENS_TRACE(6);
     __syncthreads();
 
@@ -655,7 +639,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
-        if (!rv[p] || (HENS_ABLATE & 4)) continue;
+        if (!rv[p]) continue;
         const bool keep = (s_flag[r] & 2) != 0;
         const double2 v = keep ? *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2) : sreg[p];
         *reinterpret_cast<double2*>(pool_w + (size_t)s_dst[r] * D + jl * 2) = v;
@@ -665,7 +649,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row gather for downloads: dst[tl][w][:] = pool[loc[tl][w]][:]
+// Small utilities
 // ---------------------------------------------------------------------------------------------
 __global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
                               double* __restrict__ dst, int64_t nrows, int D) {
@@ -683,121 +667,179 @@ __global__ void k_iota(int32_t* p, int64_t n) {
         p[i] = (int32_t)i;
 }
 
-__global__ void k_tick(uint64_t* clock) { clock[0] += 1; }
+// parity mode: the caller's NumPy draws (stretch.py:93-99,129-132; red_blue.py:294) -> Draws
+__global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* __restrict__ rint,
+                             const double* __restrict__ u_zz, const double* __restrict__ u_acc, Draws d,
+                             int Tl, int W, int N0, int split, double a, int D) {
+    const int Ns = split == 0 ? N0 : W - N0;
+    const int s_off = split == 0 ? 0 : N0, c_off = split == 0 ? N0 : 0;
+    const int64_t n = (int64_t)Tl * Ns;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tl = (int)(i / Ns), k = (int)(i - (int64_t)tl * Ns);
+        const int own = order[(size_t)tl * W + s_off + k];
+        const int cw = order[(size_t)tl * W + c_off + (int)rint[i]];
+        make_draw(d, (size_t)tl * W + s_off + k, own, cw, u_zz[i], u_acc[i], a, D);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
-// Philox plan: random permutations by a bitonic sort of (random key | index) in LDS.
-//   job j < n_split : split order of local rung j   -> order[j][W]
-//   job j >= n_split: PT column permutation of rung (j - n_split) (global, 0..T-2) -> colslot[t][W]
-//   the top rung's column map is the identity (written by job n_split + T - 1 without sorting).
-// Draws depend only on (seed, iteration, purpose, global rung), so every rank of a sharded ladder
-// builds the same PT plan.
+// Philox plan: everything about an iteration that does not depend on the state.
+//   job j < n_split : split of local rung j -> Draws for every position of that rung
+//   job j >= n_split: PT column permutation of global rung (j - n_split) -> colslot[t][W]
+//     (the hottest rung's column map is the identity)
+// A uniformly random permutation = sort by a random key.  The key's top bits pick one of NP2
+// buckets (a counting sort: one LDS atomic per element + one block scan); the few elements that
+// share a bucket are ranked by the remaining random bits (ties, 2^-18 per pair at W = 16384, fall
+// back to the index).  ~15 barriers per permutation instead of the 78 stages of a bitonic sort.
+// One launch plans a batch of iterations; it depends on nothing but (seed, iteration), so it runs
+// ahead of the stepping kernels on its own low-priority stream.
 // ---------------------------------------------------------------------------------------------
 struct PlanArgs {
-    int32_t* order;       // [NB][Tl][W]
+    Draws dr;             // [NB][Tl][W] each
     int32_t* colslot;     // [NB][T][W]
-    const uint64_t* clock;
+    uint64_t iter0;       // iteration index of the first planned iteration
     uint64_t seed;
-    int32_t Tl, T, W, NP2, rung_begin, n_split, jobs_per_iter, idx_bits;
+    double a;
+    int32_t Tl, T, W, D, NP2, rung_begin, n_split, jobs_per_iter, idx_bits;
 };
+
+// exclusive scan of this thread's value across the workgroup (wave shuffles + one LDS hop)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, int tid, int nt, uint32_t* total) {
+    const int lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
+    uint32_t inc = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(inc, off);
+        if (lane >= off) inc += y;
+    }
+    __syncthreads();                                       // wtot may still be read from a previous call
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t t = (lane < nw) ? wtot[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(t, off);
+            if (lane >= off) t += y;
+        }
+        if (lane < nw) wtot[lane] = t;                     // inclusive wave totals
+    }
+    __syncthreads();
+    if (total) *total = wtot[nw - 1];
+    return inc - x + (wave > 0 ? wtot[wave - 1] : 0u);
+}
 
 __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint64_t* key = reinterpret_cast<uint64_t*>(smem_raw);
     const int tid = threadIdx.x;
+    const int nt = blockDim.x;
     const int ib = blockIdx.x / A.jobs_per_iter;          // iteration within the batch
     const int job = blockIdx.x - ib * A.jobs_per_iter;
-    const uint64_t it = A.clock[0] + (uint64_t)ib;
+    const uint64_t it = A.iter0 + (uint64_t)ib;
     const int W = A.W, NP2 = A.NP2;
-    int32_t* out;
+    const bool is_split = job < A.n_split;
     uint32_t purpose, rung;
-    if (job < A.n_split) {
-        out = A.order + ((size_t)ib * A.Tl + job) * W;
+    int32_t* pt_out = nullptr;
+    if (is_split) {
         purpose = PURPOSE_SPLIT;
         rung = (uint32_t)(A.rung_begin + job);
     } else {
         const int t = job - A.n_split;
-        out = A.colslot + ((size_t)ib * A.T + t) * W;
+        pt_out = A.colslot + ((size_t)ib * A.T + t) * W;
         purpose = PURPOSE_PTPERM;
         rung = (uint32_t)t;
         if (t == A.T - 1) {                                // identity for the hottest rung
-            for (int i = tid; i < W; i += blockDim.x) out[i] = i;
+            for (int i = tid; i < W; i += nt) pt_out[i] = i;
             return;
         }
     }
-    const uint64_t mask = (1ull << A.idx_bits) - 1ull;
-    for (int i = tid; i < NP2; i += blockDim.x) {
-        uint64_t kv;
-        if (i < W) {
-            const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * (uint32_t)NP2 + (uint32_t)i, purpose};
-            const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-            kv = ((((uint64_t)d.x << 32) | d.y) & ~mask) | (uint64_t)i;
-            kv &= ~(1ull << 63);                           // keep below the padding keys
-        } else {
-            kv = (1ull << 63) | (uint64_t)i;
-        }
-        key[i] = kv;
-    }
-    __syncthreads();
-    for (int k = 2; k <= NP2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int idx = tid; idx < (NP2 >> 1); idx += blockDim.x) {
-                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-                const int l = i | j;
-                const bool asc = (i & k) == 0;
-                const uint64_t a = key[i], b = key[l];
-                if ((a > b) == asc) {
-                    key[i] = b;
-                    key[l] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (job >= A.n_split) {                                // PT column map: the permutation itself
-        for (int i = tid; i < W; i += blockDim.x) out[i] = (int32_t)(key[i] & mask);
-        return;
-    }
-    // Split order: the first N0 = ceil(W/2) entries of the permutation are the walkers of split 0
-    // (a uniformly random balanced labelling, red_blue.py:119-124).  Emit each half in ASCENDING
-    // walker order like the reference's boolean masks do: a tile of 64 moving walkers then touches
-    // ~128 consecutive ids, so the per-walker scalars (loc, L, P, accept counts) are read and
-    // written as whole cache lines instead of one line per 4..8-byte element.
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);          // [NP2] bucket counts -> cursors
+    uint32_t* tmp = cnt + NP2;                                      // [NP2] bucketed (random | index) words
+    uint8_t* lab = reinterpret_cast<uint8_t*>(tmp + NP2);           // [W] split labels
+    __shared__ uint32_t wtot[16];
+    const uint32_t imask = (1u << A.idx_bits) - 1u;
     const int N0 = (W + 1) / 2;
-    const int nt = blockDim.x;
-    const int per = (NP2 + nt - 1) / nt;                   // permutation entries per thread
-    uint32_t mine[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int i = tid + q * nt;
-        mine[q] = (q < per && i < W) ? (uint32_t)(key[i] & mask) : 0xFFFFFFFFu;
+    // the random key of element i: bucket = top bits, word = remaining random bits | index.
+    // Recomputed in each pass instead of being held in registers across barriers.
+    auto key_of = [&](int i, uint32_t& bkt, uint32_t& word) {
+        const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * (uint32_t)NP2 + (uint32_t)i, purpose};
+        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        bkt = d.x >> (32 - A.idx_bits);
+        word = (d.y & ~imask) | (uint32_t)i;
+    };
+
+    for (int i = tid; i < NP2; i += nt) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < W; i += nt) {
+        uint32_t b, w;
+        key_of(i, b, w);
+        atomicAdd(&cnt[b], 1u);
     }
     __syncthreads();
-    uint8_t* lab = reinterpret_cast<uint8_t*>(key);        // [W] labels, reusing the sort buffer
-    uint32_t* scan = reinterpret_cast<uint32_t*>(lab + ((W + 15) & ~15));   // [nt] zero counts
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int i = tid + q * nt;
-        if (q < per && i < W) lab[mine[q]] = (i >= N0) ? 1 : 0;
+    {   // bucket counts -> exclusive bucket starts (each thread owns a contiguous run of buckets)
+        const int bper = NP2 / nt > 0 ? NP2 / nt : 1;
+        const int b0 = tid * bper;
+        uint32_t s = 0;
+        if (b0 < NP2)
+            for (int k = 0; k < bper; ++k) s += cnt[b0 + k];
+        uint32_t run = block_excl_scan(s, wtot, tid, nt, nullptr);
+        if (b0 < NP2)
+            for (int k = 0; k < bper; ++k) {
+                const uint32_t v = cnt[b0 + k];
+                cnt[b0 + k] = run;
+                run += v;
+            }
     }
     __syncthreads();
+    for (int i = tid; i < W; i += nt) {                              // scatter; cnt[b] ends at bucket b's end
+        uint32_t b, w;
+        key_of(i, b, w);
+        tmp[atomicAdd(&cnt[b], 1u)] = w;
+    }
+    __syncthreads();
+    for (int i = tid; i < W; i += nt) {                              // rank inside the bucket -> position
+        uint32_t b, w;
+        key_of(i, b, w);
+        const uint32_t s0 = b ? cnt[b - 1] : 0u, s1 = cnt[b];
+        uint32_t r = 0;
+        for (uint32_t m = s0; m < s1; ++m) r += (tmp[m] < w);
+        const uint32_t pos = s0 + r;                                 // position of element i in the permutation
+        if (is_split) lab[i] = (pos >= (uint32_t)N0) ? 1 : 0;
+        else pt_out[pos] = i;
+    }
+    if (!is_split) return;
+    // Split: the first N0 = ceil(W/2) positions of the permutation are the walkers of split 0 (a
+    // uniformly random balanced labelling, red_blue.py:119-124).  Each half is listed in ASCENDING
+    // walker order like the reference's boolean masks: a tile of 64 moving walkers then touches
+    // ~128 consecutive ids, so the per-walker scalars (loc, L, P, accept counts) move as whole
+    // cache lines instead of one line per 4..8-byte element.
+    __syncthreads();                                                 // labels complete; cnt / tmp are dead
+    int32_t* ord = reinterpret_cast<int32_t*>(smem_raw);             // [W] ordered walker ids (reuses cnt/tmp)
     const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
-    const int lo = tid * chunk, hi = min(W, lo + chunk);
+    const int lo = min(W, tid * chunk), hi = min(W, lo + chunk);
     uint32_t z = 0;
     for (int i = lo; i < hi; ++i) z += (lab[i] == 0);
-    scan[tid] = z;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {               // inclusive Hillis-Steele scan of zero counts
-        const uint32_t v = (tid >= off) ? scan[tid - off] : 0u;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
-    }
-    uint32_t z0 = scan[tid] - z;                           // zeros before this thread's chunk
-    uint32_t o0 = (uint32_t)lo - z0;                       // ones before it
+    uint32_t z0 = block_excl_scan(z, wtot, tid, nt, nullptr);        // zeros before this thread's chunk
+    uint32_t o0 = (uint32_t)lo - z0;                                 // ones before it
     for (int i = lo; i < hi; ++i) {
-        if (lab[i] == 0) out[z0++] = i;
-        else out[N0 + o0++] = i;
+        if (lab[i] == 0) ord[z0++] = i;
+        else ord[N0 + o0++] = i;
+    }
+    __syncthreads();
+    // per-position draws (stretch.py:93-99: randint(Nc); :129-132 zz; red_blue.py:294 accept uniform)
+    const size_t base = ((size_t)ib * A.Tl + job) * W;
+    for (int p = tid; p < W; p += nt) {
+        const int own = ord[p];
+        const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * (uint32_t)W + (uint32_t)own, PURPOSE_STRETCH};
+        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        u4 ctr2 = ctr;
+        ctr2.w = PURPOSE_STRETCH_ACC;
+        const u4 e = philox4x32_10(ctr2, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        const bool s0 = p < N0;
+        const int Nc = s0 ? W - N0 : N0;
+        const int r = (int)__umulhi(d.x, (uint32_t)Nc);
+        const int cw = ord[(s0 ? N0 : 0) + r];
+        make_draw(A.dr, base + p, own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
     }
 }
 
@@ -844,57 +886,65 @@ __global__ void k_pt_chain(const int64_t* __restrict__ iperm, const int64_t* __r
 
 struct PtArgs {
     const double* Lfull;        // [T][W] log-likelihood of the full ladder (== L when unsharded)
-    const double* L;            // local current buffers [Tl][W]
-    const double* P;
+    const double* P;            // local current buffers [Tl][W]
     const int32_t* loc;
     double* Lnew;               // local next buffers
     double* Pnew;
     int32_t* locnew;
-    double* betas;              // [T], updated in place by the last block
+    const double* betas;        // [T]
     const int32_t* colslot;     // [T][W]
     const double* colu;         // [T-1][W] uniforms in column order (parity) or nullptr (Philox)
     uint8_t* selcol;            // [T-1][W] swap decisions in column order, row j <-> pair T-1-j (or nullptr)
-    int32_t* srcfull;           // [T][W] global source slot id (t'*W + w') of the walker arriving at every slot of the full ladder (sharded) or nullptr
-    unsigned long long* swap_part;   // [nblocks][T-1] per-workgroup swap counts, 8-byte granules
-    double* swaps_last;         // [T-1]
-    double* swaps_total;        // [T-1]
-    unsigned* ticket;
-    uint64_t* clock;            // iteration counter, advanced by the last block when tick != 0
-    int64_t* adapt_time;
+    int32_t* srcfull;           // [T][W] global source slot id of the walker arriving at every slot (sharded) or nullptr
+    uint32_t* swap_part;        // [nblocks][T-1] per-workgroup swap counts (reduced by the adaptation)
+    uint64_t iter;
     uint64_t seed;
-    double lag, nu;
-    int64_t stop_adaptation;
-    int32_t T, W, Tl, rung_begin, adapt, tick, sharded;
+    int32_t T, W, Tl, rung_begin;
 };
 
 constexpr int PT_COLS = 16;      // columns per workgroup: W/16 workgroups keep every CU busy at W = 4096
 constexpr int PT_THREADS = 256;
 
-// LDS: Lc[T][PT_COLS] f64 column log-likelihoods, lu[T][PT_COLS] f64 log-uniforms, sbeta[T] f64,
-//      src[T][PT_COLS] i16 rung each final slot takes its walker from, sel[T][PT_COLS] u8.
-__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 2 + 1) + (size_t)T * 8; }
+// LDS per (rung, column) element: L f64, log-uniform f64, P f64, loc i32, slot i32, src i16, sel u8; + betas[T]
+__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 8 + 4 + 4 + 2 + 1) + (size_t)T * 8; }
 
+// One launch = the whole hot->cold cascade.  Two dependent global-load levels only
+// (colslot -> {L, P, loc}); everything after that runs out of LDS.  No inter-workgroup
+// communication: the swap totals needed for the ladder adaptation leave as per-workgroup rows
+// and are reduced after the kernel boundary (a last-block ticket + release fence inside this
+// kernel cost more than the cascade itself).
 template <bool PHILOX>
 __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int T = A.T, W = A.W;
+    const size_t NE = (size_t)T * PT_COLS;
     double* Lc = reinterpret_cast<double*>(smem_raw);            // [T][PT_COLS]
-    double* lu = Lc + (size_t)T * PT_COLS;                       // [T][PT_COLS] (row j = pair T-1-j)
-    double* sbeta = lu + (size_t)T * PT_COLS;                    // [T]
-    int16_t* src = reinterpret_cast<int16_t*>(sbeta + T);        // [T][PT_COLS]
-    uint8_t* sel = reinterpret_cast<uint8_t*>(src + (size_t)T * PT_COLS);  // [T][PT_COLS]
-    __shared__ int s_last;
+    double* lu = Lc + NE;                                        // [T][PT_COLS] (row j = pair T-1-j)
+    double* Pc = lu + NE;                                        // [T][PT_COLS]
+    double* sbeta = Pc + NE;                                     // [T]
+    int32_t* locc = reinterpret_cast<int32_t*>(sbeta + T);       // [T][PT_COLS]
+    int32_t* scol = locc + NE;                                   // [T][PT_COLS]
+    int16_t* src = reinterpret_cast<int16_t*>(scol + NE);        // [T][PT_COLS]
+    uint8_t* sel = reinterpret_cast<uint8_t*>(src + NE);         // [T][PT_COLS]
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
-    const uint64_t it = PHILOX ? A.clock[0] : 0;
+    const uint64_t it = A.iter;
 
-    // phase 1: gather the column's log-likelihoods, log-uniforms and the ladder (independent loads)
+    // phase 1: column slots, then everything the column needs (independent gathers)
     for (int t = tid; t < T; t += PT_THREADS) sbeta[t] = A.betas[t];
-    for (int e = tid; e < T * PT_COLS; e += PT_THREADS) {
+    for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
             const int slot = A.colslot[(size_t)t * W + c];
+            scol[e] = slot;
             Lc[e] = A.Lfull[(size_t)t * W + slot];
+            const int tl = t - A.rung_begin;
+            if (tl >= 0 && tl < A.Tl) {
+                Pc[e] = A.P[(size_t)tl * W + slot];
+                locc[e] = A.loc[(size_t)tl * W + slot];
+            } else {
+                locc[e] = -1;                                    // walker owned by another rank
+            }
             if (t < T - 1) {
                 double u;
                 if (PHILOX) {
@@ -934,91 +984,69 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     }
     __syncthreads();
 
-    // phase 3: scatter the permuted L / P / loc of the resident rungs; count swaps
-    for (int e = tid; e < T * PT_COLS; e += PT_THREADS) {
+    // phase 3: write the permuted L / P / loc of the resident rungs straight from LDS
+    for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
         if (t < T - 1 && A.selcol) A.selcol[(size_t)t * W + c] = sel[e];
         const int st = src[e];
-        const int dslot = A.colslot[(size_t)t * W + c];
-        const int sslot = A.colslot[(size_t)st * W + c];
-        if (A.srcfull) A.srcfull[(size_t)t * W + dslot] = st * W + sslot;
+        const int se = st * PT_COLS + cc;
+        const int dslot = scol[e];
+        if (A.srcfull) A.srcfull[(size_t)t * W + dslot] = st * W + scol[se];
         const int tl = t - A.rung_begin;
         if (tl < 0 || tl >= A.Tl) continue;
         const size_t di = (size_t)tl * W + dslot;
-        A.Lnew[di] = Lc[(size_t)st * PT_COLS + cc];
-        const int stl = st - A.rung_begin;
-        if (stl >= 0 && stl < A.Tl) {
-            const size_t si = (size_t)stl * W + sslot;
-            A.Pnew[di] = A.P[si];
-            A.locnew[di] = A.loc[si];
-        } else {
-            A.locnew[di] = -1;       // row + log-prior arrive from another rank (hens_pt_finish_sharded)
-        }
+        A.Lnew[di] = Lc[se];
+        A.locnew[di] = locc[se];      // -1: row + log-prior arrive from another rank (hens_pt_finish_sharded)
+        if (locc[se] >= 0) A.Pnew[di] = Pc[se];
     }
-    // Per-workgroup swap counts go to a private row with write-through (sc1) stores; the last
-    // workgroup to take a ticket reduces them.  No release fence: a buffer_wbl2 per workgroup
-    // writes back the whole XCD L2 and made this kernel 10x slower; device atomics on T-1
-    // counters sharing one cache line were no better (MI355X_MICROARCH: publish forms R1/R2).
     for (int j = tid; j < T - 1; j += PT_THREADS) {
         unsigned n = 0;
         for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += sel[(size_t)j * PT_COLS + cc];
-        __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (T - 1) + (T - 2 - j)], (unsigned long long)n,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // pair i = T-1-j -> index i-1
+        A.swap_part[(size_t)blockIdx.x * (T - 1) + (T - 2 - j)] = n;     // pair i = T-1-j -> index i-1
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains
+}
+
+// Stand-alone ladder adaptation (one workgroup): used where it cannot ride in the next stretch
+// launch (parity API, sharded ladder, generic row widths, T > 64, end of a hens_step call).
+// Lane-parallel where the reference's arithmetic allows: ratios, dS, deltaT per lane; the cumsum
+// stays a sequential left-to-right sum like np.cumsum; reciprocal and update per lane again.
+__global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NTHREADS = 256;
+    const int T = A.T, tid = threadIdx.x;
+    double* r = reinterpret_cast<double*>(smem_raw);
+    double* dT = r + T;
+    double* bnew = dT + T;
+    unsigned* cnt = reinterpret_cast<unsigned*>(bnew + T);
+    for (int j = tid; j < T; j += NTHREADS) cnt[j] = 0;
     __syncthreads();
-    if (tid == 0)
-        s_last = (__hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    // every thread of the last block sums a slice of the per-workgroup rows into LDS counters
-    unsigned* cnt = reinterpret_cast<unsigned*>(lu);              // [T-1], lu is dead by now
-    for (int j = tid; j < T - 1; j += PT_THREADS) cnt[j] = 0;
-    __syncthreads();
-    {
-        // 8 independent agent-scope loads in flight per thread, then the LDS adds
-        const unsigned total = gridDim.x * (unsigned)(T - 1);
-        for (unsigned e0 = tid; e0 < total; e0 += 8 * PT_THREADS) {
-            unsigned long long v[8];
+    const int total = A.nblocks * (T - 1);
+    for (int e0 = tid; e0 < total; e0 += 8 * NTHREADS) {
+        unsigned v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const unsigned e = e0 + q * PT_THREADS;
-                v[q] = (e < total) ? __hip_atomic_load(&A.swap_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            }
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * NTHREADS;
+            v[q] = (e < total) ? A.swap_part[e] : 0u;
+        }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const unsigned e = e0 + q * PT_THREADS;
-                if (v[q]) atomicAdd(&cnt[e % (unsigned)(T - 1)], (unsigned)v[q]);
-            }
+        for (int q = 0; q < 8; ++q) {
+            const int e = e0 + q * NTHREADS;
+            if (v[q]) atomicAdd(&cnt[e % (T - 1)], v[q]);
         }
     }
     __syncthreads();
-    // Ladder adaptation, lane-parallel where the reference's arithmetic allows it (a single lane
-    // running T divisions + exps serially cost ~18 us): ratios, dS, deltaT per lane; the cumsum stays
-    // a sequential left-to-right sum like np.cumsum; the reciprocal and the update per lane again.
-    double* r = Lc;                           // ratios [T-1]
-    double* dT = Lc + T;                      // deltaTs, then their running sum [T-2]
-    const bool do_adapt = A.adapt && T > 1;
-    int64_t time = 0;
-    bool moving = false;
-    if (do_adapt) {
-        time = A.adapt_time[0];
-        moving = A.stop_adaptation < 0 || time < A.stop_adaptation;
-    }
-    for (int j = tid; j < T - 1; j += PT_THREADS) {
-        const double n = (double)cnt[j];
-        A.swaps_last[j] = n;
-        A.swaps_total[j] += n;
-        r[j] = n / (double)W;                                         // :587
+    for (int j = tid; j < T; j += NTHREADS) {
+        bnew[j] = A.betas_in[j];
+        if (j < T - 1) r[j] = (double)cnt[j] / (double)A.W;           // :587
     }
     __syncthreads();
-    if (moving) {
-        const double decay = A.lag / ((double)time + A.lag);          // :571
+    if (A.moving) {
+        const double decay = A.lag / ((double)A.time + A.lag);        // :571
         const double kappa = decay / A.nu;                            // :572
-        for (int j = tid; j + 2 < T; j += PT_THREADS) {
+        for (int j = tid; j + 2 < T; j += NTHREADS) {
             const double dS = kappa * (r[j] - r[j + 1]);              // :575
-            double d = 1.0 / sbeta[j + 1] - 1.0 / sbeta[j];           // :578
+            double d = 1.0 / bnew[j + 1] - 1.0 / bnew[j];             // :578
             d *= exp(dS);
             dT[j] = d;
         }
@@ -1026,16 +1054,25 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         if (tid == 0)
             for (int j = 1; j + 2 < T; ++j) dT[j] = dT[j - 1] + dT[j];    // np.cumsum order
         __syncthreads();
-        const double inv0 = 1.0 / sbeta[0];
-        for (int j = tid; j + 2 < T; j += PT_THREADS) {
-            const double bn = 1.0 / (dT[j] + inv0);                   // :580
-            A.betas[j + 1] = sbeta[j + 1] + (bn - sbeta[j + 1]);      // :583,:593
+        const double inv0 = 1.0 / bnew[0];
+        for (int j0 = 0; j0 + 2 < T; j0 += NTHREADS) {
+            const int j = j0 + tid;
+            double upd = 0.0;
+            if (j + 2 < T) {
+                const double bn = 1.0 / (dT[j] + inv0);               // :580
+                upd = bnew[j + 1] + (bn - bnew[j + 1]);               // :583,:593
+            }
+            __syncthreads();
+            if (j + 2 < T) bnew[j + 1] = upd;
         }
+        __syncthreads();
     }
-    if (tid == 0) {
-        if (do_adapt) A.adapt_time[0] = time + 1;                     // :596
-        if (A.tick) A.clock[0] += 1;
-        __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = tid; j < T; j += NTHREADS) {
+        A.betas_out[j] = bnew[j];
+        if (j < T - 1) {
+            A.swaps_last[j] = (double)cnt[j];
+            A.swaps_total[j] += (double)cnt[j];
+        }
     }
 }
 
