@@ -145,18 +145,22 @@ size_t fast_lds_bytes(int D, int NW) {
 template <int LIKE, bool EVAL>
 int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
+    static const int preg_knob = getenv("HENS_PREG") ? atoi(getenv("HENS_PREG")) : 0;
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \
         const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW, true>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW, false>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
-        hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
+        if (preg_knob) hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW, true>), grid, dim3(NW * 64), lds, c->stream, a); \
+        else hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW, false>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);

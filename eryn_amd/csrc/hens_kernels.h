@@ -342,6 +342,18 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
+// every outstanding global STORE (CDNA4 counts stores in vmcnt); the stretch kernel deliberately leaves
+// row stores in flight across its phases.  Global loads are still waited for where their values are used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wave-uniform broadcast of lane `lane`'s double (v_readlane_b32 x2 -> an SGPR pair the FMA can take)
+__device__ __forceinline__ double bcast_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
 //     in flight and recomputes the ladder in one wavefront; workgroup (0,0) publishes it.  That
 //     removes a dependent single-workgroup launch (~5.5 us + boundary) from every iteration.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int LIKE, bool EVAL, int NW>
+template <int DT, int LIKE, bool EVAL, int NW, bool PREG>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(0);
 
     // ---- phase A (wave 0): indices and draws -------------------------------------------------------
-    double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0;
+    double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
     int own = 0;
     bool valid = false;
     if (wv == 0) {
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         valid = k < Ns;
         double zz = 1.0;
         int rs = 0, rc = 0;
+        if (!EVAL && A.tempered && !ad_on) beta_pre = A.betas[A.rung_begin + tl];   // off the phase-D critical path
         if (valid) {
             if (EVAL) {
                 own = k;
@@ -421,8 +434,20 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     } else if (ad_on && wv == 1) {
         s_cnt[lane] = 0;
     }
+    // this wave's rows of the precision matrix, RB*DT doubles spread over the 64 lanes (coalesced load,
+    // issued before the first barrier); phase C broadcasts them with v_readlane into SGPR operands
+    constexpr int RBC = (DT + NW - 1) / NW;
+    constexpr int NPR = (RBC * DT + 63) / 64;
+    double preg[NPR];
+    if (PREG && LIKE == LIKE_DENSE) {
+#pragma unroll
+        for (int r = 0; r < NPR; ++r) {
+            const int e = wv * RBC * DT + r * 64 + lane;
+            preg[r] = (e < DT * DT) ? A.prec[e] : 0.0;
+        }
+    }
     HENS_TRACE(1);
-    __syncthreads();
+    lds_barrier();
     HENS_TRACE(2);
 
     // ---- phase B: lanes over d, all loads first -------------------------------------------------
@@ -471,6 +496,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
+            // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
+            // overwrites only accepted rows, so the store tail after the accept test is short
+            if (!EVAL) *reinterpret_cast<double2*>(A.pool + (size_t)s_dst[r] * D + jl * 2) = sreg[p];
         }
         const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
         const unsigned long long nonfin = __ballot(!finite);
@@ -488,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
     }
     HENS_TRACE(3);
-    __syncthreads();
+    lds_barrier();
     HENS_TRACE(4);
 
     // ---- ladder adaptation in one wavefront (tempering.py:563-596), T <= 64 ---------------------------
@@ -559,16 +587,21 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     qreg[k] = v.x - mu[k];
                     qreg[k + 1] = v.y - mu[k + 1];
                 }
-#pragma unroll 2
+#pragma unroll
                 for (int ii = 0; ii < RB; ++ii) {
                     const int i = i0 + ii;
                     if (i < DT) {
-                        const cptr_t prow = prec + (size_t)i * DT;
                         double y0 = 0.0, y1 = 0.0;
 #pragma unroll
                         for (int k = 0; k < DT; k += 2) {
-                            y0 = fma(prow[k], qreg[k], y0);
-                            y1 = fma(prow[k + 1], qreg[k + 1], y1);
+                            const int e0 = ii * DT + k, e1 = e0 + 1;
+                            if (PREG) {
+                                y0 = fma(bcast_lane(preg[e0 / 64], e0 % 64), qreg[k], y0);
+                                y1 = fma(bcast_lane(preg[e1 / 64], e1 % 64), qreg[k + 1], y1);
+                            } else {
+                                y0 = fma(prec[(size_t)i * DT + k], qreg[k], y0);
+                                y1 = fma(prec[(size_t)i * DT + k + 1], qreg[k + 1], y1);
+                            }
                         }
                         part = fma(qrow[i] - mu[i], y0 + y1, part);
                     }
@@ -586,7 +619,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_part[wv * TILE + lane] = part;
     }
     HENS_TRACE(5);
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase D: accept / update (wave 0) -------------------------------------------------------
     if (wv == 0 && valid) {
@@ -607,7 +640,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         } else {
             double logP, prevP;
             if (A.tempered) {                                  // tempering.py:304-306,343-349
-                const double beta = ad_on ? s_beta[A.rung_begin + tl] : A.betas[A.rung_begin + tl];
+                const double beta = ad_on ? s_beta[A.rung_begin + tl] : beta_pre;
                 double lt = logl * beta;
                 if (lt != lt) lt = -INFINITY;
                 logP = lt + logp;
@@ -632,17 +665,17 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     if (EVAL) return;
     HENS_TRACE(6);
-    __syncthreads();
+    lds_barrier();
 
-    // ---- phase E: write rows (q if kept, the register copy of the old row otherwise) ---------------
+    // ---- phase E: accepted rows only (the old rows went out right after phase B) ------------------------
     double* __restrict__ pool_w = A.pool;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
-        const bool keep = (s_flag[r] & 2) != 0;
-        const double2 v = keep ? *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2) : sreg[p];
-        *reinterpret_cast<double2*>(pool_w + (size_t)s_dst[r] * D + jl * 2) = v;
+        if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
+        *reinterpret_cast<double2*>(pool_w + (size_t)s_dst[r] * D + jl * 2) =
+            *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
     }
     HENS_TRACE(7);
 #undef HENS_TRACE
