@@ -6,7 +6,9 @@
 One "step" = one sampler iteration = StretchMove.propose (both red/blue halves) + the hot->cold
 PT swap cascade + ladder adaptation (ensemble.py:965-1041), over every walker of the ladder.
 N = 1: BASELINE config 2 (ntemps=16, nwalkers=4096, ndim=32 dense Gaussian).  N > 1: the ladder
-is sharded, 8 rungs of config 3 (nwalkers=16384, ndim=64) per GPU, weak scaling.
+is sharded and grows with N (weak scaling): every GPU owns one config-2-sized shard (16 rungs x 4096
+walkers x 32 dims, ntemps = 16 N).  --workload cfg3 selects BASELINE config 3's shards instead
+(8 rungs x 16384 x 64 per GPU, ntemps = 8 N).
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -154,14 +156,17 @@ def main():
     ap.add_argument("--ntemps", type=int, default=None)
     ap.add_argument("--nwalkers", type=int, default=None)
     ap.add_argument("--ndim", type=int, default=None)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:
-        args.ntemps = args.ntemps or 8 * max(args.gpus, world)
-        args.nwalkers = args.nwalkers or 16384
-        args.ndim = args.ndim or 64
+        n = max(args.gpus, world)
+        if args.workload == "cfg3":
+            args.ntemps, args.nwalkers, args.ndim = args.ntemps or 8 * n, args.nwalkers or 16384, args.ndim or 64
+        else:
+            args.ntemps, args.nwalkers, args.ndim = args.ntemps or 16 * n, args.nwalkers or 4096, args.ndim or 32
         out = run_sharded(args)
     else:
         args.ntemps = args.ntemps or 16

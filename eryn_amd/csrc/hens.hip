@@ -59,6 +59,7 @@ struct hens_ctx_impl {
     DrawBuf db[2];
     int NB = 0, NP2 = 1, idx_bits = 0;
     hipEvent_t ev_plan[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    uint64_t win_from = 0; int win_count = 0;   // iterations planned in db[0] for hens_stretch_iter / sharded PT
 
     // parity staging
     int32_t* order = nullptr;        // [Tl][W]
@@ -69,6 +70,7 @@ struct hens_ctx_impl {
     double* xtmp = nullptr;          // [Tl*W][D] download staging
     int expect_split = 0;
     std::vector<uint8_t> labels_host;
+    std::vector<int32_t> rank_of_host;
 
     // sharded exchange
     double* gather_L = nullptr;
@@ -145,22 +147,18 @@ size_t fast_lds_bytes(int D, int NW) {
 template <int LIKE, bool EVAL>
 int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
-    static const int preg_knob = getenv("HENS_PREG") ? atoi(getenv("HENS_PREG")) : 0;
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \
         const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW, true>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW, false>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
-        if (preg_knob) hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW, true>), grid, dim3(NW * 64), lds, c->stream, a); \
-        else hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW, false>), grid, dim3(NW * 64), lds, c->stream, a); \
+        hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
@@ -706,6 +704,7 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     HIPCHK(c, hipMemcpyAsync(c->d_rint, rint, n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uzz, u_zz, n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
+    c->win_count = 0;
     hipLaunchKernelGGL(k_prep_draws, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, c->order, c->d_rint, c->d_uzz,
                        c->d_uacc, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, c->D);
     StretchArgs a = base_args(c);
@@ -757,6 +756,7 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
     int32_t* colslot = c->db[0].colslot;
+    c->win_count = 0;
     hipLaunchKernelGGL(k_pt_invert, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->d_iperm, c->d_inv, T - 1, W);
     hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm, c->d_inv,
                        c->d_uswap, colslot, c->colk, c->colu, T, W);
@@ -788,6 +788,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int T = c->T, W = c->W;
     c->N0 = (W + 1) / 2;
+    c->win_count = 0;
     const bool pt = has_pt(c);
     const bool prof = c->per_kernel_events;
     std::vector<hipEvent_t> evs;
@@ -966,8 +967,13 @@ int hens_stretch_iter(hens_ctx* ctx) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     flush_adapt(c);
     c->N0 = (c->W + 1) / 2;
-    launch_plan(c, c->stream, 0, c->iter, 1, true, false);
-    r = stretch_pair(c, 0, 0, nullptr);
+    if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
+        // plan a whole batch (splits of the resident rungs + every PT column map) once per NB iterations
+        launch_plan(c, c->stream, 0, c->iter, c->NB, true, has_pt(c));
+        c->win_from = c->iter;
+        c->win_count = c->NB;
+    }
+    r = stretch_pair(c, 0, (int)(c->iter - c->win_from), nullptr);
     if (r) return r;
     if (!has_pt(c)) c->iter += 1;
     HIPCHK(c, hipGetLastError());
@@ -999,11 +1005,16 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
     if ((r = ensure_shard_buffers(c))) return r;
     if ((r = ensure_pt_buffers(c))) return r;
     const size_t PW = (size_t)(T - 1) * W;
-    HIPCHK(c, hipMemcpyAsync(c->d_rank_of, rank_of_rung, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
-    int32_t* colslot = c->db[0].colslot;
+    if (c->rank_of_host.size() != (size_t)T || memcmp(c->rank_of_host.data(), rank_of_rung, (size_t)T * 4) != 0) {
+        c->rank_of_host.assign(rank_of_rung, rank_of_rung + T);
+        HIPCHK(c, hipMemcpyAsync(c->d_rank_of, c->rank_of_host.data(), (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    const bool in_window = !parity_draws && c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count;
+    int32_t* colslot = c->db[0].colslot + (in_window ? (size_t)(c->iter - c->win_from) * T * W : 0);
     PtArgs p = pt_args(c, colslot, true);
     p.selcol = c->selcol;
     if (parity_draws) {
+        c->win_count = 0;                      // the parity chain builder overwrites slot 0 of the plan buffer
         HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
@@ -1015,7 +1026,10 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk,
                            c->selk, T - 1, W);
     } else {
-        launch_plan(c, c->stream, 0, c->iter, 1, false, true);
+        if (!in_window) {
+            launch_plan(c, c->stream, 0, c->iter, 1, false, true);
+            c->win_count = 0;
+        }
         hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
     }
     c->adapt_pending = true;
@@ -1050,7 +1064,7 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
     HIPCHK(c, hipGetLastError());
     if (sel_out && parity_draws) HIPCHK(c, hipMemcpyAsync(sel_out, c->selk, PW, hipMemcpyDeviceToHost, c->stream));
     if (swaps_out) HIPCHK(c, hipMemcpyAsync(swaps_out, c->swaps_last, (size_t)(T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((sel_out && parity_draws) || swaps_out) HIPCHK(c, hipStreamSynchronize(c->stream));   // else: packing stays async
     c->n_send = nsend; c->n_recv = nrecv;
     c->pt_pending = true;
     return HENS_OK;

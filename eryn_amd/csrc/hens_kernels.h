@@ -347,24 +347,39 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
 // row stores in flight across its phases.  Global loads are still waited for where their values are used.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// wave-uniform broadcast of lane `lane`'s double (v_readlane_b32 x2 -> an SGPR pair the FMA can take)
-__device__ __forceinline__ double bcast_lane(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
+// 16-byte row store, variant selected at build time for the experiment:
+//   HENS_ROWSTORE 0 plain (write-back L2), 1 sc1 write-through (asm), 2 nontemporal
+#ifndef HENS_ROWSTORE
+#define HENS_ROWSTORE 1
+#endif
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_row16(double* p, double2 v) {
+#if HENS_ROWSTORE == 1
+    const dvec2 t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif HENS_ROWSTORE == 2
+    const dvec2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<dvec2*>(p));
+#else
+    *reinterpret_cast<double2*>(p) = v;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
 //     flight) - the kernel is latency-bound at config-2 size, memory-level parallelism buys time;
-//   * the old row stays in registers for the write-back (no re-read on reject);
+//   * the old row goes to its new home right after the gathers (most proposals are rejected), the
+//     accept test only adds the accepted rows; barriers order LDS only, so stores stay in flight;
+//   * scalar-load (SGPR) precision rows beat both an LDS copy and a v_readlane broadcast (measured);
+//   * a single fused launch for both halves (write-through rows + per-rung flags) was measured
+//     slower than two launches (polling + sc1 traffic) and is not used;
 //   * optionally (ad_on) the ladder adaptation that follows the previous PT cascade is folded in:
 //     every workgroup reduces the cascade's per-workgroup swap counts while its row gathers are
 //     in flight and recomputes the ladder in one wavefront; workgroup (0,0) publishes it.  That
 //     removes a dependent single-workgroup launch (~5.5 us + boundary) from every iteration.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int LIKE, bool EVAL, int NW, bool PREG>
+template <int DT, int LIKE, bool EVAL, int NW>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -434,18 +449,6 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     } else if (ad_on && wv == 1) {
         s_cnt[lane] = 0;
     }
-    // this wave's rows of the precision matrix, RB*DT doubles spread over the 64 lanes (coalesced load,
-    // issued before the first barrier); phase C broadcasts them with v_readlane into SGPR operands
-    constexpr int RBC = (DT + NW - 1) / NW;
-    constexpr int NPR = (RBC * DT + 63) / 64;
-    double preg[NPR];
-    if (PREG && LIKE == LIKE_DENSE) {
-#pragma unroll
-        for (int r = 0; r < NPR; ++r) {
-            const int e = wv * RBC * DT + r * 64 + lane;
-            preg[r] = (e < DT * DT) ? A.prec[e] : 0.0;
-        }
-    }
     HENS_TRACE(1);
     lds_barrier();
     HENS_TRACE(2);
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
-            if (!EVAL) *reinterpret_cast<double2*>(A.pool + (size_t)s_dst[r] * D + jl * 2) = sreg[p];
+            if (!EVAL) store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
         }
         const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
         const unsigned long long nonfin = __ballot(!finite);
@@ -594,14 +597,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                         double y0 = 0.0, y1 = 0.0;
 #pragma unroll
                         for (int k = 0; k < DT; k += 2) {
-                            const int e0 = ii * DT + k, e1 = e0 + 1;
-                            if (PREG) {
-                                y0 = fma(bcast_lane(preg[e0 / 64], e0 % 64), qreg[k], y0);
-                                y1 = fma(bcast_lane(preg[e1 / 64], e1 % 64), qreg[k + 1], y1);
-                            } else {
-                                y0 = fma(prec[(size_t)i * DT + k], qreg[k], y0);
-                                y1 = fma(prec[(size_t)i * DT + k + 1], qreg[k + 1], y1);
-                            }
+                            y0 = fma(prec[(size_t)i * DT + k], qreg[k], y0);
+                            y1 = fma(prec[(size_t)i * DT + k + 1], qreg[k + 1], y1);
                         }
                         part = fma(qrow[i] - mu[i], y0 + y1, part);
                     }
@@ -674,8 +671,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
-        *reinterpret_cast<double2*>(pool_w + (size_t)s_dst[r] * D + jl * 2) =
-            *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+        store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
     }
     HENS_TRACE(7);
 #undef HENS_TRACE

@@ -147,7 +147,8 @@ class HipEnsemble:
         check(self.lib.hens_get_device_buffers(self.ctx, C.byref(b)), self.ctx)
         return b
 
-    def pt_plan_sharded(self, rank_of_rung, nranks, my_rank, iperm=None, i1perm=None, u_swap=None, adapt=True):
+    def pt_plan_sharded(self, rank_of_rung, nranks, my_rank, iperm=None, i1perm=None, u_swap=None, adapt=True,
+                        want_swaps=True):
         rank_of_rung = np.ascontiguousarray(rank_of_rung, dtype=np.int32)
         if rank_of_rung.shape != (self.T,):
             raise ValueError("rank_of_rung must have shape (ntemps,)")
@@ -160,12 +161,17 @@ class HipEnsemble:
                 raise ValueError(f"iperm/i1perm must have shape {shp}")
         send = np.zeros(nranks, dtype=np.int64)
         recv = np.zeros(nranks, dtype=np.int64)
-        sel = np.zeros(shp, dtype=np.uint8)
-        swaps = np.zeros(self.T - 1)
+        sel = np.zeros(shp, dtype=np.uint8) if iperm is not None else None
+        swaps = np.zeros(self.T - 1) if want_swaps else None
         check(self.lib.hens_pt_plan_sharded(self.ctx, ptr(iperm), ptr(i1perm), ptr(u_swap), int(bool(adapt)),
                                             ptr(rank_of_rung), int(nranks), int(my_rank), ptr(send), ptr(recv),
                                             ptr(sel), ptr(swaps)), self.ctx)
-        return send, recv, sel.astype(bool), swaps
+        return send, recv, (None if sel is None else sel.astype(bool)), swaps
+
+    def set_stream(self, stream_handle):
+        """Launch on a caller-owned HIP stream (e.g. torch's current stream, so RCCL collectives and the
+        kernels order themselves without host synchronisation)."""
+        check(self.lib.hens_set_stream(self.ctx, C.c_void_p(int(stream_handle))), self.ctx)
 
     def pt_finish_sharded(self, n_recv):
         check(self.lib.hens_pt_finish_sharded(self.ctx, int(n_recv)), self.ctx)

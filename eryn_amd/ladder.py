@@ -45,12 +45,19 @@ class _DevArray:
 class HipShardEngine:
     """The HIP engine seen through the small interface ShardedLadder needs."""
 
-    def __init__(self, engine, device):
+    def __init__(self, engine, device, share_stream=True):
         import torch
         self.torch = torch
         self.e = engine
         self.device = device
         self.T, self.Tl, self.W, self.D = engine.T, engine.Tl, engine.W, engine.D
+        if share_stream:
+            # one non-default stream for the kernels and (through torch's stream dependencies) the RCCL
+            # collectives; the legacy null stream would serialise against every other stream
+            self.stream = torch.cuda.Stream(device)
+            torch.cuda.set_stream(self.stream)
+            engine.set_stream(self.stream.cuda_stream)
+        self.shared_stream = bool(share_stream)
         b = engine.device_buffers()
         self.row_doubles = int(b.row_doubles)
         self.cap = int(b.row_capacity)
@@ -70,7 +77,8 @@ class HipShardEngine:
 
     def local_logl(self):
         b = self.e.device_buffers()                     # the current buffer flips every PT step
-        self.e.synchronize()                            # library stream -> visible to the comm stream
+        if not self.shared_stream:
+            self.e.synchronize()                        # library stream -> visible to the comm stream
         return self.torch.as_tensor(_DevArray(b.logl, (self.Tl, self.W)), device=self.device)
 
     def gather_buffer(self):
@@ -78,7 +86,9 @@ class HipShardEngine:
 
     def plan(self, rank_of_rung, nranks, rank, draws=None, adapt=True):
         kw = {} if draws is None else dict(iperm=draws["iperm"], i1perm=draws["i1perm"], u_swap=draws["u_swap"])
-        send, recv, sel, swaps = self.e.pt_plan_sharded(rank_of_rung, nranks, rank, adapt=adapt, **kw)
+        # production steps skip the per-iteration D2H of the swap counts (hens_get_counters has the totals)
+        send, recv, sel, swaps = self.e.pt_plan_sharded(rank_of_rung, nranks, rank, adapt=adapt,
+                                                        want_swaps=draws is not None, **kw)
         return send, recv, sel, swaps
 
     def send_buffer(self, n):
@@ -99,25 +109,29 @@ class ShardedLadder:
         self.dist, self.rank, self.nranks, self.group = dist, int(rank), int(nranks), group
         self.rank_of_rung, self.bounds = rung_partition(self.T, self.nranks)
         self.swaps_accepted = np.zeros(self.T - 1)
+        # exercise the collectives even with one rank (lets a 1-GPU box validate the RCCL plumbing)
+        self.force_collectives = bool(int(__import__("os").environ.get("HENS_FORCE_COLLECTIVES", "0")))
 
     def pt_step(self, draws=None, adapt=True):
         """Steps 2-5.  Returns (sel or None, swaps_accepted)."""
         eng, dist = self.eng, self.dist
         local = eng.local_logl()
         full = eng.gather_buffer()
-        if self.nranks > 1:
+        force = self.force_collectives and dist is not None
+        if self.nranks > 1 or force:
             dist.all_gather_into_tensor(full.view(-1), local.reshape(-1), group=self.group)
         else:
             full.copy_(local)
         self._sync_comm()
         send, recv, sel, swaps = eng.plan(self.rank_of_rung, self.nranks, self.rank, draws=draws, adapt=adapt)
         n_send, n_recv = int(send.sum()), int(recv.sum())
-        if self.nranks > 1:
+        if self.nranks > 1 or force:
             out_buf, in_buf = eng.recv_buffer(n_recv), eng.send_buffer(n_send)
             self._all_to_all(out_buf, in_buf, recv, send)
             self._sync_comm()
         eng.finish(n_recv)
-        self.swaps_accepted = swaps
+        if swaps is not None:
+            self.swaps_accepted = swaps
         return sel, swaps
 
     def _all_to_all(self, out_buf, in_buf, recv_counts, send_counts):
@@ -147,6 +161,8 @@ class ShardedLadder:
 
     def _sync_comm(self):
         eng = self.eng
+        if getattr(eng, "shared_stream", False):
+            return                                      # same stream: ordered without a host sync
         if hasattr(eng, "torch") and eng.torch.cuda.is_available():
             eng.torch.cuda.current_stream().synchronize()
 
@@ -159,7 +175,7 @@ class ShardedLadder:
 
 
 def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
-    """N-GPU leg of bench.py: weak scaling, 8 rungs of config 3 per GPU."""
+    """N-GPU leg of bench.py: weak scaling, one fixed-size ladder shard per GPU."""
     import json
     import os
     import time
@@ -176,7 +192,8 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1 and not dist.is_initialized():
+    force = bool(int(os.environ.get("HENS_FORCE_COLLECTIVES", "0")))
+    if (world > 1 or force) and not dist.is_initialized():
         dist.init_process_group("nccl", device_id=device)
     T, W, D = args.ntemps, args.nwalkers, args.ndim
     _, bounds = rung_partition(T, world)
@@ -187,7 +204,7 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
     eng.upload(x0, betas=make_ladder(D, ntemps=T))
     eng.eval_state()
-    lad = ShardedLadder(HipShardEngine(eng, device), T, dist=dist if world > 1 else None, rank=rank, nranks=world)
+    lad = ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank, nranks=world)
     lad.step(args.warmup)
     eng.synchronize()
     torch.cuda.synchronize()
@@ -217,14 +234,15 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
             "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"config 3 shard: ntemps={T} ({T // world} rungs/GPU), nwalkers={W}, ndim={D} "
-                                   f"dense-covariance Gaussian, ladder sharded, RCCL all-gather(logL) + all-to-all(rows)",
+            "config": {"workload": f"ladder sharded over {world} GPU(s): ntemps={T} ({T // world} rungs/GPU), nwalkers={W}, "
+                                   f"ndim={D} dense-covariance Gaussian, StretchMove(a=2)+adaptive PT, Philox RNG, "
+                                   f"RCCL all-gather(logL) + all-to-all(rows)",
                        "ntemps": T, "nwalkers": W, "ndim": D, "parallelism": f"ladder-shard x{world}",
                        "swap_fraction": f_sw},
             "roofline": {"bound": "hbm", "kernel": "whole path (per GPU)", "achieved": whole / world, "peak": hbm_peak,
                          "unit": "GB/s", "frac": whole / world / hbm_peak, "traffic": None},
         }
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     return out

@@ -21,7 +21,7 @@ def _make_shards(o, mu, invcov, nranks):
     for r0, r1 in bounds:
         e = HipEnsemble(o.T, o.W, o.D, GaussianLikelihood(mu, invcov), o.lo, o.hi, a=o.a, rung_range=(r0, r1), seed=7)
         e.upload(o.x[r0:r1], o.L[r0:r1], o.P[r0:r1], o.betas)
-        shards.append(HipShardEngine(e, dev))
+        shards.append(HipShardEngine(e, dev, share_stream=False))
     return rank_of, bounds, shards
 
 
