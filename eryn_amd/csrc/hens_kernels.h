@@ -372,8 +372,10 @@ __device__ __forceinline__ void store_row16(double* p, double2 v) {
 //   * the old row goes to its new home right after the gathers (most proposals are rejected), the
 //     accept test only adds the accepted rows; barriers order LDS only, so stores stay in flight;
 //   * scalar-load (SGPR) precision rows beat both an LDS copy and a v_readlane broadcast (measured);
-//   * a single fused launch for both halves (write-through rows + per-rung flags) was measured
-//     slower than two launches (polling + sc1 traffic) and is not used;
+//   * measured and rejected: a single fused launch for both halves (write-through rows + per-rung
+//     flags: polling + sc1 traffic cost more than the boundary), and a row-resident variant that keeps
+//     q in the 16 lanes of its row and rotates it with v_mov_dpp row_ror against pre-rotated precision
+//     rows (no LDS tile, no barriers: correct, but 20 % slower - 16x redundant scalar loads, 1 wave/SIMD);
 //   * optionally (ad_on) the ladder adaptation that follows the previous PT cascade is folded in:
 //     every workgroup reduces the cascade's per-workgroup swap counts while its row gathers are
 //     in flight and recomputes the ladder in one wavefront; workgroup (0,0) publishes it.  That
