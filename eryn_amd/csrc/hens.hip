@@ -2,6 +2,7 @@
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 #include "../../include/hipensemble.h"
 #include "hens_kernels.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -51,7 +52,7 @@ struct hens_ctx_impl {
     double* swaps_total = nullptr;
 
     // model
-    double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr;
+    double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr; double* prec_sym = nullptr;
     double logp_in = 0.0, rosen_a = 1.0, rosen_b = 100.0;
     bool have_prior = false, have_like = false, have_state = false, have_logs = false;
 
@@ -88,6 +89,7 @@ struct hens_ctx_impl {
     bool per_kernel_events = false;
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ext_start = nullptr, ext_stop = nullptr;   // armed: the next stretch launch records its own begin/end
     std::vector<hipEvent_t> evpool;
     std::vector<void*> allocs;
 };
@@ -127,7 +129,10 @@ int grid_for(int64_t n, int block = 256) {
 
 int pt_blocks(const hens_ctx_impl* c) { return (c->W + PT_COLS - 1) / PT_COLS; }
 bool has_pt(const hens_ctx_impl* c) { return c->cfg.tempered && c->T > 1; }
-int plan_threads(const hens_ctx_impl* c) { return std::min(1024, std::max(64, c->NP2 / 4)); }   // <= 16 elements per thread
+int plan_threads(const hens_ctx_impl* c) {
+    static const int cap = getenv("HENS_PLAN_THREADS") ? atoi(getenv("HENS_PLAN_THREADS")) : 1024;
+    return std::min(cap, std::max(64, c->NP2 / 4));
+}
 size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)c->NP2 * 8 + (((size_t)c->W + 15) & ~(size_t)15); }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
@@ -158,7 +163,11 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
-        hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
+        if (c->ext_start)                                                                          \
+            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
+                                  c->ext_start, c->ext_stop, 0, a);                                \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
@@ -177,7 +186,11 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         a.RS = RS;
         a.ad_on = 0;
-        hipLaunchKernelGGL((k_stretch<LIKE, EVAL>), grid, dim3(256), lds, c->stream, a);
+        if (c->ext_start)
+            hipExtLaunchKernelGGL((k_stretch<LIKE, EVAL>), grid, dim3(256), (uint32_t)lds, c->stream, c->ext_start,
+                                  c->ext_stop, 0, a);
+        else
+            hipLaunchKernelGGL((k_stretch<LIKE, EVAL>), grid, dim3(256), lds, c->stream, a);
     }
 #undef LAUNCH_FAST
     const hipError_t e = hipGetLastError();
@@ -210,7 +223,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
     a.dr = c->db[0].d;
     a.accepted = c->accepted;
-    a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec;
+    a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec; a.prec_sym = c->prec_sym;
     a.flags = c->flags;
     a.trace = c->tracing ? c->d_trace : nullptr;
     a.logp_in = c->logp_in;
@@ -351,12 +364,6 @@ hipEvent_t new_event(hens_ctx_impl* c) {
 // both halves of one Philox iteration from draw buffer `which`, batch slot `ib`
 int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
     const int Tl = c->Tl, W = c->W;
-    auto mark = [&]() {
-        if (!evs) return;
-        hipEvent_t e = new_event(c);
-        (void)hipEventRecord(e, c->stream);
-        evs->push_back(e);
-    };
     for (int split = 0; split < 2; ++split) {
         StretchArgs a = base_args(c);
         a.dr = draws_at(c->db[which], (size_t)ib * Tl * W);
@@ -378,10 +385,15 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
             }
         }
         const int Ns = split == 0 ? c->N0 : W - c->N0;
-        mark();
+        if (evs) {           // per-kernel timing: the dispatch packet's own begin/end timestamps
+            c->ext_start = new_event(c);
+            c->ext_stop = new_event(c);
+            evs->push_back(c->ext_start);
+            evs->push_back(c->ext_stop);
+        }
         const int r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
+        c->ext_start = c->ext_stop = nullptr;
         if (r) return r;
-        mark();
     }
     c->parity ^= 1;
     c->num_proposals += 1;
@@ -464,6 +476,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRY(dalloc(c, &c->hi, (size_t)c->D));
     TRY(dalloc(c, &c->mu, (size_t)c->D));
     TRY(dalloc(c, &c->prec, (size_t)c->D * c->D));
+    TRY(dalloc(c, &c->prec_sym, (size_t)(c->D / 2 + 1) * (c->D + 2)));
     TRY(dalloc(c, &c->order, TW));
     TRY(dalloc(c, &c->d_rint, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->d_uzz, (size_t)c->Tl * c->N0));
@@ -581,6 +594,20 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipMemcpyAsync(c->mu, mu, c->D * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->prec, prec, n * 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<double> sym;
+    if (c->cfg.likelihood_kind == HENS_LIKE_GAUSS_DENSE && c->D % 2 == 0) {
+        // packed symmetric rows for sym_quad: pair p = rows (p, D-1-p), each from its diagonal rightwards,
+        // off-diagonal entries A_ik + A_ki (so a non-symmetric input gives the same quadratic form)
+        const int D = c->D, stride = D + 2;
+        sym.assign((size_t)(D / 2) * stride, 0.0);
+        for (int p = 0; p < D / 2; ++p) {
+            double* row = sym.data() + (size_t)p * stride;
+            int o = 0;
+            for (int i : {p, D - 1 - p})
+                for (int k = i; k < D; ++k) row[o++] = (k == i) ? prec[(size_t)i * D + i] : prec[(size_t)i * D + k] + prec[(size_t)k * D + i];
+        }
+        HIPCHK(c, hipMemcpyAsync(c->prec_sym, sym.data(), sym.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_like = true;
     return HENS_OK;
@@ -822,10 +849,16 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             if (r) return r;
             if (pt) {
                 PtArgs p = pt_args(c, c->db[which].colslot + (size_t)ib * T * W, false);
-                if (prof) { hipEvent_t e = new_event(c); (void)hipEventRecord(e, c->stream); evs.push_back(e); }
-                hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T),
-                                   c->stream, p);
-                if (prof) { hipEvent_t e = new_event(c); (void)hipEventRecord(e, c->stream); evs.push_back(e); }
+                if (prof) {
+                    hipEvent_t e0 = new_event(c), e1 = new_event(c);
+                    evs.push_back(e0);
+                    evs.push_back(e1);
+                    hipExtLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), (uint32_t)pt_lds_bytes(T),
+                                          c->stream, e0, e1, 0, p);
+                } else {
+                    hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T),
+                                       c->stream, p);
+                }
                 c->cur ^= 1;
                 c->adapt_pending = true;
                 c->adapt_pending_adaptive = c->cfg.adaptive != 0;

@@ -104,6 +104,7 @@ struct StretchArgs {
     const double* hi;
     const double* mu;
     const double* prec;
+    const double* prec_sym;    // packed symmetric rows for the fast kernel (see sym_quad), dense only
     unsigned* flags;
     unsigned long long* trace; // debug: per-workgroup phase timestamps (s_memtime), or nullptr
     double logp_in, fill, rosen_a, rosen_b;
@@ -365,6 +366,36 @@ __device__ __forceinline__ void store_row16(double* p, double2 v) {
 #endif
 }
 
+// Symmetric quadratic form, the share of wave WI.  psym holds, for every row pair p = 0..D/2-1,
+// D + 2 doubles: row p from its diagonal rightwards [A_pp, A_p,p+1 + A_p+1,p, ...] (D - p entries)
+// followed by row D-1-p likewise (p + 1 entries), then one pad.  Wave WI owns the pairs
+// WI*PPW .. WI*PPW + PPW - 1.
+template <int DT, int NW, int WI>
+__device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attribute__((address_space(4))) double* psym) {
+    constexpr int PPW = (DT / 2) / NW;                 // row pairs per wave
+    static_assert(PPW >= 1 && (DT / 2) % NW == 0, "row pairs must divide over the waves");
+    double part = 0.0;
+    if (WI >= NW) return part;
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        constexpr int STRIDE = DT + 2;
+        const int p = (WI < NW ? WI : 0) * PPW + pp;
+        const __attribute__((address_space(4))) double* c = psym + p * STRIDE;
+        double y = 0.0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            if (t < DT - p) y = fma(c[t], q[p + t < DT ? p + t : 0], y);
+        part = fma(q[p], y, part);
+        const int i2 = DT - 1 - p;
+        double y2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+            if (t <= p) y2 = fma(c[DT - p + t], q[i2 + t < DT ? i2 + t : 0], y2);
+        part = fma(q[i2], y2, part);
+    }
+    return part;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
@@ -592,18 +623,17 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     qreg[k] = v.x - mu[k];
                     qreg[k + 1] = v.y - mu[k + 1];
                 }
-#pragma unroll
-                for (int ii = 0; ii < RB; ++ii) {
-                    const int i = i0 + ii;
-                    if (i < DT) {
-                        double y0 = 0.0, y1 = 0.0;
-#pragma unroll
-                        for (int k = 0; k < DT; k += 2) {
-                            y0 = fma(prec[(size_t)i * DT + k], qreg[k], y0);
-                            y1 = fma(prec[(size_t)i * DT + k + 1], qreg[k + 1], y1);
-                        }
-                        part = fma(qrow[i] - mu[i], y0 + y1, part);
-                    }
+                // q'^T A q' = sum_i q'_i (A_ii q'_i + sum_{k>i} (A_ik + A_ki) q'_k): half the FP64 FMAs of
+                // the full product (phase C is FP64-rate-bound: vector fp64 = 78.6 TF/s).  Rows are dealt
+                // to the waves in pairs (p, D-1-p) of equal total length; the wave index becomes a
+                // compile-time constant through the switch so every register index is static.
+                const cptr_t psym = (cptr_t)(uintptr_t)A.prec_sym;
+                switch (wv) {
+#define HENS_SYM_CASE(WI) case WI: part = sym_quad<DT, NW, WI>(qreg, psym); break;
+                    HENS_SYM_CASE(0) HENS_SYM_CASE(1) HENS_SYM_CASE(2) HENS_SYM_CASE(3)
+                    HENS_SYM_CASE(4) HENS_SYM_CASE(5) HENS_SYM_CASE(6) HENS_SYM_CASE(7)
+#undef HENS_SYM_CASE
+                    default: break;
                 }
             } else {
                 for (int ii = 0; ii < RB; ++ii) {
