@@ -21,7 +21,6 @@ thread_local std::string g_last_error;
 
 struct DrawBuf {                     // one batch of planned iterations
     Draws d{};
-    int32_t* colslot = nullptr;      // [NB][T][W]
 };
 
 struct hens_ctx_impl {
@@ -66,7 +65,7 @@ struct hens_ctx_impl {
     int32_t* order = nullptr;        // [Tl][W]
     int64_t* d_rint = nullptr; double* d_uzz = nullptr; double* d_uacc = nullptr; uint8_t* d_keep = nullptr;
     int64_t* d_iperm = nullptr; int64_t* d_i1perm = nullptr; double* d_uswap = nullptr;
-    int32_t* d_inv = nullptr; int32_t* colk = nullptr; double* colu = nullptr;
+    int32_t* d_inv = nullptr; int32_t* colk = nullptr; double* colu = nullptr; int32_t* colslot = nullptr;   // [T][W]
     uint8_t* selcol = nullptr; uint8_t* selk = nullptr;
     double* xtmp = nullptr;          // [Tl*W][D] download staging
     int expect_split = 0;
@@ -133,7 +132,7 @@ int plan_threads(const hens_ctx_impl* c) {
     static const int cap = getenv("HENS_PLAN_THREADS") ? atoi(getenv("HENS_PLAN_THREADS")) : 1024;
     return std::min(cap, std::max(64, c->NP2 / 4));
 }
-size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)c->NP2 * 8 + (((size_t)c->W + 15) & ~(size_t)15); }
+size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)5 * c->W + 16; }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
@@ -298,6 +297,7 @@ int ensure_pt_buffers(hens_ctx_impl* c) {
     if ((r = dalloc(c, &c->d_uswap, PW))) return r;
     if ((r = dalloc(c, &c->d_inv, PW))) return r;
     if ((r = dalloc(c, &c->colk, PW))) return r;
+    if ((r = dalloc(c, &c->colslot, (size_t)c->T * c->W))) return r;
     if ((r = dalloc(c, &c->colu, PW))) return r;
     if ((r = dalloc(c, &c->selcol, PW))) return r;
     if ((r = dalloc(c, &c->selk, PW))) return r;
@@ -332,26 +332,19 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     p.swap_part = c->swap_part;
     p.iter = c->iter;
     p.seed = c->cfg.seed;
-    p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin;
+    p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin; p.idx_bits = c->idx_bits;
     p.srcfull = sharded ? c->srcglob : nullptr;
     return p;
 }
 
 // plan nb iterations starting at iteration `iter0` into draw buffer `which`
-void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool splits, bool pt) {
+void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb) {
     PlanArgs pa{};
     pa.dr = c->db[which].d;
-    pa.colslot = c->db[which].colslot;
     pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
-    pa.Tl = c->Tl; pa.T = c->T; pa.W = c->W; pa.D = c->D; pa.NP2 = c->NP2; pa.rung_begin = c->cfg.rung_begin;
-    pa.n_split = splits ? c->Tl : 0;
-    pa.jobs_per_iter = pa.n_split + (pt ? c->T : 0);
+    pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin;
     pa.idx_bits = c->idx_bits;
-    if (pa.jobs_per_iter == 0) return;
-    static const bool replay = getenv("HENS_REPLAY_PLAN") != nullptr;   // timing experiment: reuse stale draws
-    static int n_planned = 0;
-    if (replay && n_planned++ >= 2) return;
-    hipLaunchKernelGGL(k_plan, dim3(nb * pa.jobs_per_iter), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
+    hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
 }
 
 hipEvent_t new_event(hens_ctx_impl* c) {
@@ -487,7 +480,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     c->NP2 = 1; c->idx_bits = 0;
     while (c->NP2 < c->W) { c->NP2 <<= 1; c->idx_bits++; }
     {
-        const size_t per_iter = TW * 32 + (size_t)c->T * c->W * 4;
+        const size_t per_iter = TW * 32;
         size_t nb = (48u << 20) / std::max<size_t>(per_iter, 1);
         nb = std::max<size_t>(2, std::min<size_t>(nb, 32));
         nb &= ~(size_t)1;
@@ -500,7 +493,6 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->db[b].d.zz, n));
         TRY(dalloc(c, &c->db[b].d.fac, n));
         TRY(dalloc(c, &c->db[b].d.lu, n));
-        TRY(dalloc(c, &c->db[b].colslot, (size_t)c->NB * c->T * c->W));
         TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
     }
@@ -782,8 +774,7 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
-    int32_t* colslot = c->db[0].colslot;
-    c->win_count = 0;
+    int32_t* colslot = c->colslot;
     hipLaunchKernelGGL(k_pt_invert, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->d_iperm, c->d_inv, T - 1, W);
     hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm, c->d_inv,
                        c->d_uswap, colslot, c->colk, c->colu, T, W);
@@ -829,7 +820,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (nbatch > 0) {
         HIPCHK(c, hipEventRecord(c->ev_used[0], c->stream));      // earlier work may still read buffer 0
         HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[0], 0));
-        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0), true, pt);
+        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0));
         HIPCHK(c, hipEventRecord(c->ev_plan[0], c->plan_stream));
         c->timing.n_plan += 1;
     }
@@ -839,7 +830,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
             HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));
-            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), true, pt);
+            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1));
             HIPCHK(c, hipEventRecord(c->ev_plan[nxt], c->plan_stream));
             c->timing.n_plan += 1;
         }
@@ -848,7 +839,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
             if (r) return r;
             if (pt) {
-                PtArgs p = pt_args(c, c->db[which].colslot + (size_t)ib * T * W, false);
+                PtArgs p = pt_args(c, nullptr, false);
                 if (prof) {
                     hipEvent_t e0 = new_event(c), e1 = new_event(c);
                     evs.push_back(e0);
@@ -974,6 +965,18 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
     return HENS_OK;
 }
 
+int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t iter, int32_t* out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int32_t* d = reinterpret_cast<int32_t*>(c->xtmp);          // scratch: at least W * 4 bytes
+    hipLaunchKernelGGL(k_debug_prp, dim3(grid_for(c->W)), dim3(256), 0, c->stream, d, c->W, c->idx_bits, c->cfg.seed,
+                       (uint64_t)iter, which == 0 ? PURPOSE_PTPERM : PURPOSE_SPLIT, (uint32_t)rung);
+    HIPCHK(c, hipMemcpyAsync(out, d, (size_t)c->W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
+}
+
 // ---- ladder sharding ---------------------------------------------------------------------------------
 int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
     hens_ctx_impl* c = CTX(ctx);
@@ -1002,7 +1005,7 @@ int hens_stretch_iter(hens_ctx* ctx) {
     c->N0 = (c->W + 1) / 2;
     if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
         // plan a whole batch (splits of the resident rungs + every PT column map) once per NB iterations
-        launch_plan(c, c->stream, 0, c->iter, c->NB, true, has_pt(c));
+        launch_plan(c, c->stream, 0, c->iter, c->NB);
         c->win_from = c->iter;
         c->win_count = c->NB;
     }
@@ -1042,12 +1045,10 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         c->rank_of_host.assign(rank_of_rung, rank_of_rung + T);
         HIPCHK(c, hipMemcpyAsync(c->d_rank_of, c->rank_of_host.data(), (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
     }
-    const bool in_window = !parity_draws && c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count;
-    int32_t* colslot = c->db[0].colslot + (in_window ? (size_t)(c->iter - c->win_from) * T * W : 0);
+    int32_t* colslot = c->colslot;
     PtArgs p = pt_args(c, colslot, true);
     p.selcol = c->selcol;
     if (parity_draws) {
-        c->win_count = 0;                      // the parity chain builder overwrites slot 0 of the plan buffer
         HIPCHK(c, hipMemcpyAsync(c->d_iperm, iperm, PW * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_i1perm, i1perm, PW * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_uswap, u_swap, PW * 8, hipMemcpyHostToDevice, c->stream));
@@ -1059,10 +1060,6 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk,
                            c->selk, T - 1, W);
     } else {
-        if (!in_window) {
-            launch_plan(c, c->stream, 0, c->iter, 1, false, true);
-            c->win_count = 0;
-        }
         hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
     }
     c->adapt_pending = true;

@@ -51,6 +51,35 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // 53-bit un
     const uint64_t v = ((uint64_t)hi << 32) | lo;
     return (double)(v >> 11) * (1.0 / 9007199254740992.0);
 }
+// Keyed pseudo-random permutation of [0, W): an 8-round alternating Feistel network on idx_bits bits
+// (round function = murmur3 finaliser of the half-block xor a Philox-drawn round key), cycle-walked
+// into [0, W).  A bijection for every key, no memory, no sort: position c of rung t's permutation is
+// prp(c) wherever it is needed, and every rank of a sharded ladder computes the same value.
+struct PrpKey { uint32_t k[8]; };
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ PrpKey prp_key(uint64_t seed, uint64_t it, uint32_t purpose, uint32_t rung) {
+    const u4 a = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), rung, purpose}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const u4 b = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), rung, purpose ^ 0x100u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return PrpKey{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits, uint32_t W) {
+    const int lb = bits >> 1, rb = bits - lb;            // left (high) / right (low) half widths
+    const uint32_t lm = (1u << lb) - 1u, rm = (1u << rb) - 1u;
+    do {
+        uint32_t L = x >> rb, R = x & rm;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            L ^= fmix32(R ^ k[r]) & lm;
+            R ^= fmix32(L ^ k[r + 1]) & rm;
+        }
+        x = (L << rb) | R;
+    } while (x >= W);                                     // cycle walking keeps it a bijection on [0, W)
+    return x;
+}
+
 enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
                   PURPOSE_PTU = 10 };
 
@@ -744,28 +773,26 @@ __global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox plan: everything about an iteration that does not depend on the state.
-//   job j < n_split : split of local rung j -> Draws for every position of that rung
-//   job j >= n_split: PT column permutation of global rung (j - n_split) -> colslot[t][W]
-//     (the hottest rung's column map is the identity)
-// A uniformly random permutation = sort by a random key.  The key's top bits pick one of NP2
-// buckets (a counting sort: one LDS atomic per element + one block scan); the few elements that
-// share a bucket are ranked by the remaining random bits (ties, 2^-18 per pair at W = 16384, fall
-// back to the index).  ~15 barriers per permutation instead of the 78 stages of a bitonic sort.
+// Philox plan: the state-independent part of the stretch proposals, ahead of time.
+// One workgroup per (iteration, resident rung): a pseudo-random BALANCED red/blue labelling
+// (label(w) = prp(w) >= ceil(W/2): exactly ceil(W/2) walkers in split 0, like the reference's shuffle
+// of arange(W) % 2, red_blue.py:119-124), each half listed in ASCENDING walker order like the
+// reference's boolean masks - a tile of 64 moving walkers then touches ~128 consecutive ids, so the
+// per-walker scalars (loc, L, P, accept counts) move as whole cache lines - and for every position
+// the complement index and the stretch / accept terms (stretch.py:93-99,129-132,223; red_blue.py:294).
 // One launch plans a batch of iterations; it depends on nothing but (seed, iteration), so it runs
 // ahead of the stepping kernels on its own low-priority stream.
 // ---------------------------------------------------------------------------------------------
 struct PlanArgs {
     Draws dr;             // [NB][Tl][W] each
-    int32_t* colslot;     // [NB][T][W]
     uint64_t iter0;       // iteration index of the first planned iteration
     uint64_t seed;
     double a;
-    int32_t Tl, T, W, D, NP2, rung_begin, n_split, jobs_per_iter, idx_bits;
+    int32_t Tl, W, D, rung_begin, idx_bits;
 };
 
 // exclusive scan of this thread's value across the workgroup (wave shuffles + one LDS hop)
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, int tid, int nt, uint32_t* total) {
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, int tid, int nt) {
     const int lane = tid & 63, wave = tid >> 6, nw = (nt + 63) >> 6;
     uint32_t inc = x;
 #pragma unroll
@@ -773,7 +800,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, 
         const uint32_t y = __shfl_up(inc, off);
         if (lane >= off) inc += y;
     }
-    __syncthreads();                                       // wtot may still be read from a previous call
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
     if (wave == 0) {
@@ -786,108 +812,44 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, 
         if (lane < nw) wtot[lane] = t;                     // inclusive wave totals
     }
     __syncthreads();
-    if (total) *total = wtot[nw - 1];
     return inc - x + (wave > 0 ? wtot[wave - 1] : 0u);
 }
 
 __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t skey[8];
     const int tid = threadIdx.x;
     const int nt = blockDim.x;
-    const int ib = blockIdx.x / A.jobs_per_iter;          // iteration within the batch
-    const int job = blockIdx.x - ib * A.jobs_per_iter;
+    const int ib = blockIdx.x / A.Tl;                      // iteration within the batch
+    const int job = blockIdx.x - ib * A.Tl;                // resident rung
     const uint64_t it = A.iter0 + (uint64_t)ib;
-    const int W = A.W, NP2 = A.NP2;
-    const bool is_split = job < A.n_split;
-    uint32_t purpose, rung;
-    int32_t* pt_out = nullptr;
-    if (is_split) {
-        purpose = PURPOSE_SPLIT;
-        rung = (uint32_t)(A.rung_begin + job);
-    } else {
-        const int t = job - A.n_split;
-        pt_out = A.colslot + ((size_t)ib * A.T + t) * W;
-        purpose = PURPOSE_PTPERM;
-        rung = (uint32_t)t;
-        if (t == A.T - 1) {                                // identity for the hottest rung
-            for (int i = tid; i < W; i += nt) pt_out[i] = i;
-            return;
-        }
-    }
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);          // [NP2] bucket counts -> cursors
-    uint32_t* tmp = cnt + NP2;                                      // [NP2] bucketed (random | index) words
-    uint8_t* lab = reinterpret_cast<uint8_t*>(tmp + NP2);           // [W] split labels
-    __shared__ uint32_t wtot[16];
-    const uint32_t imask = (1u << A.idx_bits) - 1u;
+    const int W = A.W;
+    const uint32_t rung = (uint32_t)(A.rung_begin + job);
     const int N0 = (W + 1) / 2;
-    // the random key of element i: bucket = top bits, word = remaining random bits | index.
-    // Recomputed in each pass instead of being held in registers across barriers.
-    auto key_of = [&](int i, uint32_t& bkt, uint32_t& word) {
-        const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * (uint32_t)NP2 + (uint32_t)i, purpose};
-        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        bkt = d.x >> (32 - A.idx_bits);
-        word = (d.y & ~imask) | (uint32_t)i;
-    };
-
-    for (int i = tid; i < NP2; i += nt) cnt[i] = 0;
-    __syncthreads();
-    for (int i = tid; i < W; i += nt) {
-        uint32_t b, w;
-        key_of(i, b, w);
-        atomicAdd(&cnt[b], 1u);
+    int32_t* ord = reinterpret_cast<int32_t*>(smem_raw);             // [W] ordered walker ids
+    uint8_t* lab = reinterpret_cast<uint8_t*>(ord + W);              // [W] split labels
+    if (tid < 64) {                                                  // one wave draws the rung's round keys
+        const PrpKey K = prp_key(A.seed, it, PURPOSE_SPLIT, rung);
+        if (tid < 8) skey[tid] = K.k[tid];
     }
     __syncthreads();
-    {   // bucket counts -> exclusive bucket starts (each thread owns a contiguous run of buckets)
-        const int bper = NP2 / nt > 0 ? NP2 / nt : 1;
-        const int b0 = tid * bper;
-        uint32_t s = 0;
-        if (b0 < NP2)
-            for (int k = 0; k < bper; ++k) s += cnt[b0 + k];
-        uint32_t run = block_excl_scan(s, wtot, tid, nt, nullptr);
-        if (b0 < NP2)
-            for (int k = 0; k < bper; ++k) {
-                const uint32_t v = cnt[b0 + k];
-                cnt[b0 + k] = run;
-                run += v;
-            }
-    }
+    uint32_t key[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) key[r] = skey[r];
+    for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 1 : 0;
     __syncthreads();
-    for (int i = tid; i < W; i += nt) {                              // scatter; cnt[b] ends at bucket b's end
-        uint32_t b, w;
-        key_of(i, b, w);
-        tmp[atomicAdd(&cnt[b], 1u)] = w;
-    }
-    __syncthreads();
-    for (int i = tid; i < W; i += nt) {                              // rank inside the bucket -> position
-        uint32_t b, w;
-        key_of(i, b, w);
-        const uint32_t s0 = b ? cnt[b - 1] : 0u, s1 = cnt[b];
-        uint32_t r = 0;
-        for (uint32_t m = s0; m < s1; ++m) r += (tmp[m] < w);
-        const uint32_t pos = s0 + r;                                 // position of element i in the permutation
-        if (is_split) lab[i] = (pos >= (uint32_t)N0) ? 1 : 0;
-        else pt_out[pos] = i;
-    }
-    if (!is_split) return;
-    // Split: the first N0 = ceil(W/2) positions of the permutation are the walkers of split 0 (a
-    // uniformly random balanced labelling, red_blue.py:119-124).  Each half is listed in ASCENDING
-    // walker order like the reference's boolean masks: a tile of 64 moving walkers then touches
-    // ~128 consecutive ids, so the per-walker scalars (loc, L, P, accept counts) move as whole
-    // cache lines instead of one line per 4..8-byte element.
-    __syncthreads();                                                 // labels complete; cnt / tmp are dead
-    int32_t* ord = reinterpret_cast<int32_t*>(smem_raw);             // [W] ordered walker ids (reuses cnt/tmp)
     const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
     const int lo = min(W, tid * chunk), hi = min(W, lo + chunk);
     uint32_t z = 0;
     for (int i = lo; i < hi; ++i) z += (lab[i] == 0);
-    uint32_t z0 = block_excl_scan(z, wtot, tid, nt, nullptr);        // zeros before this thread's chunk
+    uint32_t z0 = block_excl_scan(z, wtot, tid, nt);                 // zeros before this thread's chunk
     uint32_t o0 = (uint32_t)lo - z0;                                 // ones before it
     for (int i = lo; i < hi; ++i) {
         if (lab[i] == 0) ord[z0++] = i;
         else ord[N0 + o0++] = i;
     }
     __syncthreads();
-    // per-position draws (stretch.py:93-99: randint(Nc); :129-132 zz; red_blue.py:294 accept uniform)
     const size_t base = ((size_t)ib * A.Tl + job) * W;
     for (int p = tid; p < W; p += nt) {
         const int own = ord[p];
@@ -915,8 +877,9 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
 // the resident moves up one rung and the carried walker keeps falling.  Columns are independent,
 // so the whole T-1 step sequential cascade is one parallel kernel.
 //
-// k_pt_chain builds the column form from the reference's draws (parity mode); in Philox mode the
-// plan kernel draws colslot directly (same distribution: independent uniform matchings).
+// k_pt_chain builds the column form from the reference's draws (parity mode); in Philox mode column c
+// meets slot prp_t(c) of rung t (a keyed pseudo-random matching per pair, computed inline - one
+// permutation per pair has the same distribution as the reference's two).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_pt_invert(const int64_t* __restrict__ iperm, int32_t* __restrict__ inv, int npairs, int W) {
     const int64_t n = (int64_t)npairs * W;
@@ -960,14 +923,14 @@ struct PtArgs {
     uint32_t* swap_part;        // [nblocks][T-1] per-workgroup swap counts (reduced by the adaptation)
     uint64_t iter;
     uint64_t seed;
-    int32_t T, W, Tl, rung_begin;
+    int32_t T, W, Tl, rung_begin, idx_bits;
 };
 
 constexpr int PT_COLS = 16;      // columns per workgroup: W/16 workgroups keep every CU busy at W = 4096
 constexpr int PT_THREADS = 256;
 
 // LDS per (rung, column) element: L f64, log-uniform f64, P f64, loc i32, slot i32, src i16, sel u8; + betas[T]
-__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 8 + 4 + 4 + 2 + 1) + (size_t)T * 8; }
+__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 8 + 4 + 4 + 2 + 1) + (size_t)T * (8 + 32); }
 
 // One launch = the whole hot->cold cascade.  Two dependent global-load levels only
 // (colslot -> {L, P, loc}); everything after that runs out of LDS.  No inter-workgroup
@@ -985,18 +948,30 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     double* sbeta = Pc + NE;                                     // [T]
     int32_t* locc = reinterpret_cast<int32_t*>(sbeta + T);       // [T][PT_COLS]
     int32_t* scol = locc + NE;                                   // [T][PT_COLS]
-    int16_t* src = reinterpret_cast<int16_t*>(scol + NE);        // [T][PT_COLS]
+    uint32_t* skey = reinterpret_cast<uint32_t*>(scol + NE);     // [T][8] PRP round keys (Philox mode)
+    int16_t* src = reinterpret_cast<int16_t*>(skey + (size_t)T * 8);   // [T][PT_COLS]
     uint8_t* sel = reinterpret_cast<uint8_t*>(src + NE);         // [T][PT_COLS]
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
     const uint64_t it = A.iter;
 
+    // phase 0 (Philox): one lane per rung draws that rung's permutation keys
+    for (int t = tid; t < T; t += PT_THREADS) {
+        sbeta[t] = A.betas[t];
+        if (PHILOX) {
+            const PrpKey K = prp_key(A.seed, it, PURPOSE_PTPERM, (uint32_t)t);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) skey[t * 8 + r] = K.k[r];
+        }
+    }
+    if (PHILOX) __syncthreads();
     // phase 1: column slots, then everything the column needs (independent gathers)
-    for (int t = tid; t < T; t += PT_THREADS) sbeta[t] = A.betas[t];
     for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
-            const int slot = A.colslot[(size_t)t * W + c];
+            int slot;
+            if (PHILOX) slot = (t == T - 1) ? c : (int)prp((uint32_t)c, skey + t * 8, A.idx_bits, (uint32_t)W);
+            else slot = A.colslot[(size_t)t * W + c];
             scol[e] = slot;
             Lc[e] = A.Lfull[(size_t)t * W + slot];
             const int tl = t - A.rung_begin;
@@ -1135,6 +1110,13 @@ __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
             A.swaps_total[j] += (double)cnt[j];
         }
     }
+}
+
+// debug: materialise one PRP permutation (tests/test_hip_parity.py checks bijectivity and uniformity)
+__global__ void k_debug_prp(int32_t* out, int W, int idx_bits, uint64_t seed, uint64_t it, uint32_t purpose, uint32_t rung) {
+    const PrpKey K = prp_key(seed, it, purpose, rung);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x)
+        out[c] = (int32_t)prp((uint32_t)c, K.k, idx_bits, (uint32_t)W);
 }
 
 // column-order decisions -> the reference's k order (row j, element colk[j][c])

@@ -129,6 +129,11 @@ class HipEnsemble:
     def set_adapt_time(self, t):
         check(self.lib.hens_set_adapt_time(self.ctx, int(t)), self.ctx)
 
+    def debug_permutation(self, which, rung, it):
+        out = np.empty(self.W, dtype=np.int32)
+        check(self.lib.hens_debug_permutation(self.ctx, int(which), int(rung), int(it), ptr(out)), self.ctx)
+        return out
+
     def set_profiling(self, on):
         check(self.lib.hens_set_profiling(self.ctx, int(bool(on))), self.ctx)
 

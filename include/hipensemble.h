@@ -210,6 +210,11 @@ int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv);
  * (capacity in 64-bit words) and stops recording.  *n_out = words written. */
 int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capacity, int64_t* n_out);
 
+/* Debug: the keyed pseudo-random permutation the Philox mode uses for iteration `iter`:
+ * which = 0 the PT column map of global rung `rung`, which = 1 the split labelling permutation of
+ * rung `rung`.  out[nwalkers] i32. */
+int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t iter, int32_t* out);
+
 /* Static description of the build. */
 const char* hens_version(void);
 int hens_device_count(void);

@@ -120,3 +120,32 @@ def test_error_mapping():
     with pytest.raises(ValueError):
         eng.eval_state()                                        # ensemble.py:1258-1262
     eng.close()
+
+
+@pytest.mark.parametrize("W", [2, 7, 64, 100, 4096, 5000])
+def test_philox_permutations_are_uniform_bijections(W):
+    """The production RNG pairs walkers through a keyed Feistel permutation instead of sorting random
+    keys: it must be a bijection for every key and look uniform (position frequencies, fixed points,
+    displacement) over many keys."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import GaussianLikelihood
+    eng = HipEnsemble(2, W, 1, GaussianLikelihood(np.zeros(1), np.eye(1)), -1, 1, seed=99, live_dangerously=True)
+    n = 400 if W <= 100 else 60
+    perms = np.stack([eng.debug_permutation(k % 2, k % 2, k) for k in range(n)])
+    assert np.array_equal(np.sort(perms, axis=1), np.tile(np.arange(W), (n, 1))), "not a bijection"
+    if W >= 7:
+        fixed = (perms == np.arange(W)).sum(axis=1)                 # ~Poisson(1) for uniform permutations
+        assert 0.5 < fixed.mean() < 1.6
+        # mean |perm(c) - c| of a uniform permutation is (W^2 - 1) / (3 W)
+        disp = np.abs(perms - np.arange(W)).mean()
+        assert abs(disp / ((W * W - 1) / (3.0 * W)) - 1.0) < 0.05
+        # no position is favoured: chi-square of where element 0 and element W-1 land (coarse bins)
+        for el in (0, W - 1):
+            nb = W if W <= 100 else 8                               # landing-position histogram
+            edges = np.linspace(0, W, nb + 1)
+            obs = np.histogram(perms[:, el], bins=edges)[0]
+            exp = n * np.diff(np.ceil(edges)) / W
+            assert np.all(np.abs(obs - exp) < 5.0 * np.sqrt(exp) + 1.0), (obs, exp)
+        # successive keys are unrelated
+        assert np.mean(perms[0] == perms[1]) < 0.5
+    eng.close()
