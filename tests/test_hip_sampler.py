@@ -81,3 +81,37 @@ def test_state_round_trip_and_errors():
     assert st.branches["model_0"].coords.shape == (1, W, 1, D)
     lp = s.compute_log_prior({"model_0": st.branches["model_0"].coords})
     assert np.array_equal(lp, st.log_prior)
+
+
+@pytest.mark.parametrize("T,W,D,like", [(1, 100, 3, "dense"), (3, 130, 7, "dense"), (2, 64, 16, "diag"),
+                                        (4, 256, 64, "dense"), (64, 80, 8, "dense"), (5, 333, 32, "dense")])
+def test_philox_step_shapes(T, W, D, like):
+    """hens_step on awkward shapes: generic row widths, odd walker counts, no tempering, many rungs
+    (T = 64 uses the stand-alone adaptation kernel's limit case)."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.moves.tempering import make_ladder
+    rs = np.random.RandomState(0)
+    A = rs.randn(D, D)
+    mu = 0.1 * rs.randn(D)
+    cov = A @ A.T / D + np.eye(D)
+    prec = np.linalg.inv(cov) if like == "dense" else 1.0 / np.diag(cov)
+    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, prec), -20.0, 20.0, seed=3)
+    eng.upload(np.random.RandomState(1).randn(T, W, D), betas=make_ladder(D, ntemps=T) if T > 1 else None)
+    eng.eval_state()
+    x0, L0, P0, _ = eng.download()
+    ref = -0.5 * np.einsum("twi,ij,twj->tw", x0 - mu, prec if like == "dense" else np.diag(prec), x0 - mu)
+    np.testing.assert_allclose(L0, ref, rtol=1e-11)
+    n = 60
+    eng.step(n)
+    x, L, P, betas = eng.download()
+    c = eng.counters()
+    assert np.isfinite(x).all() and np.abs(x).max() <= 20.0
+    np.testing.assert_allclose(L, -0.5 * np.einsum("twi,ij,twj->tw", x - mu, prec if like == "dense" else np.diag(prec), x - mu), rtol=1e-10)
+    assert np.all(P == P0[0, 0])
+    assert c["num_proposals"] == n and c["accepted"].shape == (T, W)
+    acc = c["accepted"].mean() / n
+    assert 0.03 < acc < 0.97, acc
+    if T > 1:
+        assert c["adapt_time"] == n and betas[0] == 1.0 and np.all(np.diff(betas) < 0)
+        assert np.all(c["swaps_total"] <= n * W) and c["swaps_total"].sum() > 0
+    eng.close()
