@@ -70,6 +70,9 @@ def cpu_baseline(T, W, D, seconds=12.0):
     except Exception:
         pass
     return {"value": T * W * n / dt, "unit": "walker-steps/s", "cores": int(threads), "kind": "port",
+            # the real reference is 1.76x slower than this port on identical inputs (BASELINE.md section 5,
+            # measured in the build container where /root/reference can be imported)
+            "reference_over_port": 1.76,
             "sample": f"{n} iterations of the same (ntemps={T}, nwalkers={W}, ndim={D}) workload, "
                       f"NumPy oracle (BLAS threads={threads}, os.cpu_count()={os.cpu_count()}), {dt:.1f} s"}
 
