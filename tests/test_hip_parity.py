@@ -149,3 +149,21 @@ def test_philox_permutations_are_uniform_bijections(W):
         # successive keys are unrelated
         assert np.mean(perms[0] == perms[1]) < 0.5
     eng.close()
+
+
+@pytest.mark.parametrize("T,W,D", [(3, 128, 8), (2, 100, 5), (2, 256, 32)])
+def test_rosenbrock_likelihood(T, W, D):
+    """The config-5 stress likelihood (not in the reference; defined in oracle.rosenbrock_log_like)
+    through the same fused kernel, teacher-forced: low acceptance, generic and fast row widths."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import RosenbrockLikelihood
+    box = 3.0
+    R, G = np.random.RandomState(5), np.random.RandomState(6)
+    x0 = np.random.RandomState(1).uniform(-1.5, 1.5, size=(T, W, D))
+    o = orc.OracleSampler(x0, lambda x: orc.rosenbrock_log_like(x, 1.0, 100.0), np.full(D, -box), np.full(D, box), R, G,
+                          betas=orc.make_ladder(D, ntemps=T), record=True)
+    eng = HipEnsemble(T, W, D, RosenbrockLikelihood(D, 1.0, 100.0), -box, box)
+    stats = {}
+    assert pu.run_parity(o, eng, 5, teacher_forced=True, stats=stats) == 0
+    assert 0.0 < o.accepted.mean() / o.num_proposals < 0.6
+    eng.close()
