@@ -16,7 +16,7 @@ from ._build import LIB_PATH
 
 HENS_OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_TOO_FEW_WALKERS, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
-LIKE_GAUSS_DENSE, LIKE_GAUSS_DIAG, LIKE_ROSENBROCK = 0, 1, 2
+LIKE_GAUSS_DENSE, LIKE_GAUSS_DIAG, LIKE_ROSENBROCK, LIKE_HOST = 0, 1, 2, 3
 
 
 class HensConfig(C.Structure):
@@ -58,6 +58,8 @@ SIGNATURES = {
     "hens_download_state": (C.c_int, [_P, _P, _P, _P, _P]),
     "hens_eval_state": (C.c_int, [_P]),
     "hens_stretch_split": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "hens_propose_split": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "hens_accept_split": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "hens_pt_sweep": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P]),
     "hens_step": (C.c_int, [_P, C.c_int64]),
     "hens_get_counters": (C.c_int, [_P, _P, _P, _P, _P, _P]),

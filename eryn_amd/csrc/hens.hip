@@ -69,6 +69,8 @@ struct hens_ctx_impl {
     uint8_t* selcol = nullptr; uint8_t* selk = nullptr;
     double* xtmp = nullptr;          // [Tl*W][D] download staging
     int expect_split = 0;
+    bool propose_pending = false;
+    int32_t* hl_rs = nullptr; uint8_t* hl_keep = nullptr;   // host-likelihood path scratch
     std::vector<uint8_t> labels_host;
     std::vector<int32_t> rank_of_host;
 
@@ -136,7 +138,10 @@ size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)5 * c->W + 16; }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
-int fast_nw(int D) { return D == 32 ? FAST_NW_32 : (D == 64 ? 8 : 4); }
+int fast_nw(int D) {
+    static const int nw64 = getenv("HENS_NW64") ? atoi(getenv("HENS_NW64")) : 8;
+    return D == 32 ? FAST_NW_32 : (D == 64 ? nw64 : 4);
+}
 bool is_fast_dim(int D) { return D == 8 || D == 16 || D == 32 || D == 64; }
 
 size_t generic_lds_bytes(int D, int* RS_out) {
@@ -171,7 +176,10 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
     } else if (c->D == 64) {
-        LAUNCH_FAST(64, 8);
+        static const int nw64 = getenv("HENS_NW64") ? atoi(getenv("HENS_NW64")) : 8;
+        if (nw64 == 4) LAUNCH_FAST(64, 4);
+        else if (nw64 == 16) LAUNCH_FAST(64, 16);
+        else LAUNCH_FAST(64, 8);
     } else if (c->D == 16) {
         LAUNCH_FAST(16, 4);
     } else if (c->D == 8) {
@@ -197,12 +205,30 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     return HENS_OK;
 }
 
+int launch_hostlike_eval(hens_ctx_impl* c, StretchArgs a, int ntiles) {
+    int RS;
+    const size_t lds = generic_lds_bytes(c->D, &RS);
+    if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
+    if (lds > 60000)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE_HOST, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    a.RS = RS;
+    a.ad_on = 0;
+    hipLaunchKernelGGL((k_stretch<LIKE_HOST, true>), dim3(ntiles, c->Tl), dim3(256), lds, c->stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
+    return HENS_OK;
+}
+
 template <bool EVAL>
 int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, EVAL>(c, a, ntiles);
         case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, EVAL>(c, a, ntiles);
         case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, EVAL>(c, a, ntiles);
+        case HENS_LIKE_HOST:
+            if (EVAL) return launch_hostlike_eval(c, a, ntiles);
+            return fail(c, HENS_ERR_STATE, "host-likelihood context: use hens_propose_split / hens_accept_split");
     }
     return fail(c, HENS_ERR_INVALID, "unknown likelihood kind %d", c->cfg.likelihood_kind);
 }
@@ -420,7 +446,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     if (cfg->rung_begin < 0 || cfg->rung_end > cfg->ntemps || cfg->rung_begin >= cfg->rung_end)
         return fail(nullptr, HENS_ERR_INVALID, "invalid ladder shard [%d, %d) of %d", cfg->rung_begin,
                     cfg->rung_end, cfg->ntemps);
-    if (cfg->likelihood_kind < 0 || cfg->likelihood_kind > HENS_LIKE_ROSENBROCK)
+    if (cfg->likelihood_kind < 0 || cfg->likelihood_kind > HENS_LIKE_HOST)
         return fail(nullptr, HENS_ERR_INVALID, "unknown likelihood kind %d", cfg->likelihood_kind);
     if (!(cfg->a > 1.0)) return fail(nullptr, HENS_ERR_INVALID, "stretch scale a must be > 1");
     if (cfg->ntemps > 1 && !cfg->tempered)
@@ -441,6 +467,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     c->T = cfg->ntemps; c->W = cfg->nwalkers; c->D = cfg->ndim;
     c->Tl = cfg->rung_end - cfg->rung_begin;
     c->N0 = (c->W + 1) / 2;
+    c->have_like = cfg->likelihood_kind == HENS_LIKE_HOST;
     hens_ctx* h = reinterpret_cast<hens_ctx*>(c);
 #define TRY(x) do { int r_ = (x); if (r_) { g_last_error = c->err; hens_destroy(h); return r_; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(c, HENS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); g_last_error = c->err; hens_destroy(h); return HENS_ERR_HIP; } } while (0)
@@ -627,6 +654,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     c->parity = 1;            // rows live in home 0, the next iteration writes home 1
     c->expect_split = 0;
     c->pt_pending = false;
+    c->propose_pending = false;
     HIPCHK(c, hipMemcpyAsync(c->pool, x, TW * c->D * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_iota, dim3(grid_for(TW)), dim3(256), 0, c->stream, c->loc[0], (int64_t)TW);
     if (logl) {
@@ -676,16 +704,15 @@ int hens_eval_state(hens_ctx* ctx) {
     return HENS_OK;
 }
 
-int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
-                       const double* u_acc, uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
-    int r = ready(c, true);
-    if (r) return r;
-    if (!labels || !rint || !u_zz || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+// shared front half of the parity-mode half-steps: labels -> ascending split lists, draws -> device
+static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels, const int64_t* rint,
+                         const double* u_zz, const double* u_acc, int* Ns_out) {
+    if (!labels || !rint || !u_zz) return fail(c, HENS_ERR_INVALID, "null argument");
     if (split != 0 && split != 1) return fail(c, HENS_ERR_INVALID, "split must be 0 or 1 (nsplits = 2)");
     if (split != c->expect_split)
-        return fail(c, HENS_ERR_STATE, "hens_stretch_split calls must alternate split 0, 1 (expected %d)", c->expect_split);
+        return fail(c, HENS_ERR_STATE, "half-step calls must alternate split 0, 1 (expected %d)", c->expect_split);
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
+    if (c->propose_pending) return fail(c, HENS_ERR_STATE, "hens_propose_split without its hens_accept_split");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     flush_adapt(c);
     const int Tl = c->Tl, W = c->W;
@@ -722,25 +749,113 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     const size_t n = (size_t)Tl * Ns;
     HIPCHK(c, hipMemcpyAsync(c->d_rint, rint, n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_uzz, u_zz, n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
+    if (u_acc) HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
     c->win_count = 0;
     hipLaunchKernelGGL(k_prep_draws, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, c->order, c->d_rint, c->d_uzz,
-                       c->d_uacc, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, c->D);
-    StretchArgs a = base_args(c);
-    a.split = split;
-    a.home_off = c->parity * Tl * W;
-    a.keep_out = c->d_keep;
-    r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
-    if (r) return r;
-    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->d_keep, n, hipMemcpyDeviceToHost, c->stream));
-    r = check_flags(c, false);
-    if (r) return r;
+                       u_acc ? c->d_uacc : c->d_uzz, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, c->D);
+    *Ns_out = Ns;
+    return HENS_OK;
+}
+
+static void finish_split(hens_ctx_impl* c, int32_t split) {
     if (split == 1) {
         c->parity ^= 1;
         c->num_proposals += 1;
         if (!has_pt(c)) c->iter += 1;
     }
     c->expect_split = split ^ 1;
+}
+
+int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
+                       const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
+        return fail(c, HENS_ERR_STATE, "host-likelihood context: use hens_propose_split / hens_accept_split");
+    if (!u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    int Ns = 0;
+    if ((r = prepare_split(c, split, labels, rint, u_zz, u_acc, &Ns))) return r;
+    const size_t n = (size_t)c->Tl * Ns;
+    StretchArgs a = base_args(c);
+    a.split = split;
+    a.home_off = c->parity * c->Tl * c->W;
+    a.keep_out = c->d_keep;
+    r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
+    if (r) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->d_keep, n, hipMemcpyDeviceToHost, c->stream));
+    r = check_flags(c, false);
+    if (r) return r;
+    finish_split(c, split);
+    return HENS_OK;
+}
+
+static HostLikeArgs hostlike_args(hens_ctx_impl* c, int32_t split) {
+    HostLikeArgs h{};
+    h.pool = c->pool; h.loc = c->loc[c->cur]; h.L = c->L[c->cur]; h.P = c->P[c->cur];
+    h.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
+    h.dr = c->db[0].d;
+    h.lo = c->lo; h.hi = c->hi;
+    h.qbuf = c->xtmp;                                   // [Tl*W][D] scratch: Ns <= W rows per rung
+    h.inbox = c->d_keep;                                // [Tl][N0] scratch (keep flags go to hl_keep)
+    h.rs_old = c->hl_rs; h.keep = c->hl_keep;
+    h.logl = c->d_uzz;                                  // staging reused after the proposal consumed u_zz
+    h.u_acc = c->d_uacc;
+    h.accepted = c->accepted; h.flags = c->flags;
+    h.logp_in = c->logp_in;
+    h.Tl = c->Tl; h.W = c->W; h.D = c->D; h.split = split; h.N0 = c->N0;
+    h.rung_begin = c->cfg.rung_begin; h.home_off = c->parity * c->Tl * c->W; h.tempered = c->cfg.tempered;
+    return h;
+}
+
+int hens_propose_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
+                       double* q_out, uint8_t* inbox_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (c->cfg.likelihood_kind != HENS_LIKE_HOST)
+        return fail(c, HENS_ERR_STATE, "hens_propose_split needs a context created with HENS_LIKE_HOST");
+    if (!q_out || !inbox_out) return fail(c, HENS_ERR_INVALID, "null argument");
+    int Ns = 0;
+    if ((r = prepare_split(c, split, labels, rint, u_zz, nullptr, &Ns))) return r;
+    if (!c->hl_rs) {
+        if ((r = dalloc(c, &c->hl_rs, (size_t)c->Tl * c->N0))) return r;
+        if ((r = dalloc(c, &c->hl_keep, (size_t)c->Tl * c->N0))) return r;
+    }
+    const size_t n = (size_t)c->Tl * Ns;
+    const HostLikeArgs h = hostlike_args(c, split);
+    HIPCHK(c, hipMemsetAsync(h.inbox, 1, n, c->stream));
+    hipLaunchKernelGGL(k_propose, dim3(grid_for((int64_t)n * c->D)), dim3(256), 0, c->stream, h);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(q_out, h.qbuf, n * c->D * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(inbox_out, h.inbox, n, hipMemcpyDeviceToHost, c->stream));
+    r = check_flags(c, false);
+    if (r) return r;
+    c->propose_pending = true;
+    return HENS_OK;
+}
+
+int hens_accept_split(hens_ctx* ctx, int32_t split, const double* logl, const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (!c->propose_pending || split != c->expect_split)
+        return fail(c, HENS_ERR_STATE, "hens_accept_split must follow hens_propose_split of the same split");
+    if (!logl || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const int Ns = split == 0 ? c->N0 : c->W - c->N0;
+    const size_t n = (size_t)c->Tl * Ns;
+    const HostLikeArgs h = hostlike_args(c, split);
+    HIPCHK(c, hipMemcpyAsync(c->d_uzz, logl, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_accept_decide, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, h);
+    hipLaunchKernelGGL(k_accept_rows, dim3(grid_for((int64_t)n * c->D)), dim3(256), 0, c->stream, h);
+    HIPCHK(c, hipGetLastError());
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->hl_keep, n, hipMemcpyDeviceToHost, c->stream));
+    r = check_flags(c, false);
+    c->propose_pending = false;
+    if (r) return r;
+    finish_split(c, split);
     return HENS_OK;
 }
 
@@ -803,6 +918,8 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (n_iters < 0) return fail(c, HENS_ERR_INVALID, "n_iters < 0");
     if (c->Tl != c->T) return fail(c, HENS_ERR_STATE, "hens_step needs the whole ladder resident (sharded stepping is driven by eryn_amd.ladder)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
+    if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
+        return fail(c, HENS_ERR_UNSUPPORTED, "hens_step needs a device likelihood (host-callable likelihoods step through hens_propose_split / hens_accept_split)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int T = c->T, W = c->W;
     c->N0 = (W + 1) / 2;
@@ -999,6 +1116,7 @@ int hens_stretch_iter(hens_ctx* ctx) {
     int r = ready(c, true);
     if (r) return r;
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_stretch_iter between split 0 and split 1");
+    if (c->cfg.likelihood_kind == HENS_LIKE_HOST) return fail(c, HENS_ERR_UNSUPPORTED, "hens_stretch_iter needs a device likelihood");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     flush_adapt(c);

@@ -28,7 +28,7 @@ constexpr int TILE = 64;                    // walkers per workgroup = one wavef
 constexpr unsigned FLAG_NONFINITE_X = 1u;   // inf/NaN coordinate seen (ensemble.py:1258-1262)
 constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-281)
 
-enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2 };
+enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2, LIKE_HOST = 3 };
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: draws are a pure function of
@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
         const cptr_t mu = (cptr_t)(uintptr_t)A.mu;
         const cptr_t prec = (cptr_t)(uintptr_t)A.prec;
         const double* qrow = qtile + lane * RS;
-        if (LIKE == LIKE_ROSEN) {
+        if (LIKE == LIKE_HOST) {
+            part = 0.0;                // the caller evaluates the likelihood (hens_propose_split / hens_accept_split)
+        } else if (LIKE == LIKE_ROSEN) {
             if (wv == 0 && inbox) {
                 double acc = 0.0;
                 for (int i = 0; i + 1 < D; ++i) {
@@ -1117,6 +1119,106 @@ __global__ void k_debug_prp(int32_t* out, int W, int idx_bits, uint64_t seed, ui
     const PrpKey K = prp_key(seed, it, purpose, rung);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x)
         out[c] = (int32_t)prp((uint32_t)c, K.k, idx_bits, (uint32_t)W);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-callable likelihood: proposal and accept/update stay on the device, the caller
+// evaluates log_like_fn on the proposed points in between (ensemble.py:1219-1545 contract).
+// Throughput here is set by the host function and two PCIe hops per half-step, not by these kernels.
+// ---------------------------------------------------------------------------------------------
+struct HostLikeArgs {
+    double* pool;
+    int32_t* loc;
+    double* L;
+    double* P;
+    const double* betas;
+    Draws dr;
+    const double* lo;
+    const double* hi;
+    double* qbuf;            // [Tl][Ns][D] proposed points
+    uint8_t* inbox;          // [Tl][Ns] 1 = inside the prior box
+    int32_t* rs_old;         // [Tl][Ns] pool row of the moving walker before the update
+    uint8_t* keep;           // [Tl][Ns]
+    const double* logl;      // [Tl][Ns] from the caller
+    const double* u_acc;     // [Tl][Ns]
+    uint32_t* accepted;
+    unsigned* flags;
+    double logp_in;
+    int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered;
+};
+
+__global__ void k_propose(const HostLikeArgs A) {
+    const int Ns = A.split == 0 ? A.N0 : A.W - A.N0, s_off = A.split == 0 ? 0 : A.N0;
+    const int64_t total = (int64_t)A.Tl * Ns * A.D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t wk = i / A.D;
+        const int d = (int)(i - wk * A.D);
+        const int tl = (int)(wk / Ns), k = (int)(wk - (int64_t)tl * Ns);
+        const size_t di = (size_t)tl * A.W + s_off + k;
+        const int own = A.dr.own[di], cw = A.dr.cw[di];
+        const double zz = A.dr.zz[di];
+        const double sv = A.pool[(size_t)A.loc[tl * A.W + own] * A.D + d];
+        const double cv = A.pool[(size_t)A.loc[tl * A.W + cw] * A.D + d];
+        const double qv = cv - (cv - sv) * zz;                       // stretch.py:143,145
+        A.qbuf[i] = qv;
+        if (!((qv >= A.lo[d]) && (qv <= A.hi[d]))) A.inbox[wk] = 0;  // prior.py:80-88 (inbox preset to 1)
+        if (!(fabs(qv) < INFINITY)) atomicOr(A.flags, FLAG_NONFINITE_X);
+    }
+}
+
+__global__ void k_accept_decide(const HostLikeArgs A) {
+    const int Ns = A.split == 0 ? A.N0 : A.W - A.N0, s_off = A.split == 0 ? 0 : A.N0;
+    const int64_t total = (int64_t)A.Tl * Ns;
+    for (int64_t wk = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; wk < total; wk += (int64_t)gridDim.x * blockDim.x) {
+        const int tl = (int)(wk / Ns), k = (int)(wk - (int64_t)tl * Ns);
+        const size_t di = (size_t)tl * A.W + s_off + k;
+        const int own = A.dr.own[di];
+        const size_t gi = (size_t)tl * A.W + own;
+        const bool inbox = A.inbox[wk] != 0;
+        double logl = A.logl[wk];
+        if (logl != logl) {                                            // red_blue.py:279-281
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+        const double logp = inbox ? A.logp_in : -INFINITY;
+        const double Lold = A.L[gi], Pold = A.P[gi];
+        double logP, prevP;
+        if (A.tempered) {                                              // tempering.py:304-306,343-349
+            const double beta = A.betas[A.rung_begin + tl];
+            double lt = logl * beta;
+            if (lt != lt) lt = -INFINITY;
+            logP = lt + logp;
+            double lo_ = Lold * beta;
+            if (lo_ != lo_) lo_ = -INFINITY;
+            prevP = lo_ + Pold;
+        } else {
+            logP = logl + logp;
+            prevP = Lold + Pold;
+        }
+        const double lnpdiff = A.dr.fac[di] + logP - prevP;           // red_blue.py:292
+        const bool keep = lnpdiff > log(A.u_acc[wk]);                  // red_blue.py:294
+        if (keep) {                                                    // move.py:513-532
+            A.L[gi] = logl;
+            A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
+            atomicAdd(&A.accepted[gi], 1u);
+        }
+        A.rs_old[wk] = A.loc[gi];
+        A.loc[gi] = A.home_off + tl * A.W + own;
+        A.keep[wk] = keep ? 1 : 0;
+    }
+}
+
+__global__ void k_accept_rows(const HostLikeArgs A) {
+    const int Ns = A.split == 0 ? A.N0 : A.W - A.N0, s_off = A.split == 0 ? 0 : A.N0;
+    const int64_t total = (int64_t)A.Tl * Ns * A.D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t wk = i / A.D;
+        const int d = (int)(i - wk * A.D);
+        const int tl = (int)(wk / Ns), k = (int)(wk - (int64_t)tl * Ns);
+        const int own = A.dr.own[(size_t)tl * A.W + s_off + k];
+        const double v = A.keep[wk] ? A.qbuf[i] : A.pool[(size_t)A.rs_old[wk] * A.D + d];
+        A.pool[(size_t)(A.home_off + tl * A.W + own) * A.D + d] = v;
+    }
 }
 
 // column-order decisions -> the reference's k order (row j, element colk[j][c])

@@ -93,6 +93,27 @@ class HipEnsemble:
                                           ptr(keep)), self.ctx)
         return keep.astype(bool)
 
+    def propose_split(self, split, labels, rint, u_zz):
+        """Host-likelihood contexts: proposed points q[Tl, Ns, D] and the in-prior mask [Tl, Ns]."""
+        labels = np.ascontiguousarray(labels, dtype=np.uint8)
+        Ns = self.N0 if split == 0 else self.W - self.N0
+        rint = np.ascontiguousarray(rint, dtype=np.int64)
+        u_zz = f64(u_zz, (self.Tl, Ns))
+        if labels.shape != (self.Tl, self.W) or rint.shape != (self.Tl, Ns):
+            raise ValueError("labels / rint have the wrong shape")
+        q = np.empty((self.Tl, Ns, self.D))
+        inbox = np.empty((self.Tl, Ns), dtype=np.uint8)
+        check(self.lib.hens_propose_split(self.ctx, int(split), ptr(labels), ptr(rint), ptr(u_zz), ptr(q),
+                                          ptr(inbox)), self.ctx)
+        return q, inbox.astype(bool)
+
+    def accept_split(self, split, logl, u_acc):
+        Ns = self.N0 if split == 0 else self.W - self.N0
+        logl, u_acc = f64(logl, (self.Tl, Ns)), f64(u_acc, (self.Tl, Ns))
+        keep = np.empty((self.Tl, Ns), dtype=np.uint8)
+        check(self.lib.hens_accept_split(self.ctx, int(split), ptr(logl), ptr(u_acc), ptr(keep)), self.ctx)
+        return keep.astype(bool)
+
     def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
         shp = (self.T - 1, self.W)
         iperm = np.ascontiguousarray(iperm, dtype=np.int64)

@@ -40,9 +40,15 @@ class EnsembleSampler:
         if nleaves_max != 1:
             raise NotImplementedError("the device path handles nleaves_max == 1 (RJ is a later row, SURVEY 8f-4)")
         if not hasattr(log_like_fn, "_install"):
-            raise NotImplementedError(
-                "log_like_fn must be an eryn_amd.likelihood object (GaussianLikelihood, RosenbrockLikelihood): "
-                "the likelihood is evaluated inside the HIP kernel; arbitrary Python callables are not supported")
+            # an arbitrary Python callable (the reference's contract): proposal / prior / accept / update /
+            # PT on the device, the likelihood here on the host, two PCIe hops per half-step
+            if not callable(log_like_fn):
+                raise ValueError("log_like_fn must be callable or an eryn_amd.likelihood object")
+            if rng != "numpy":
+                raise NotImplementedError("a host-callable likelihood needs rng='numpy' (the device cannot call Python)")
+            from .likelihood import HostLikelihood
+            log_like_fn = HostLikelihood(log_like_fn, int(ndims), args=args, kwargs=kwargs, vectorize=vectorize,
+                                         fill_value=fill_zero_leaves_val)
         self.nwalkers, self.ndim = int(nwalkers), int(ndims)
         self.branch_names = ["model_0"] if branch_names is None else list(branch_names)
         self.ndims = {self.branch_names[0]: self.ndim}
@@ -148,6 +154,8 @@ class EnsembleSampler:
         self.engine.upload(x, betas=None if tc is None else tc.betas)
         self.engine.eval_state()
         _, L, P, _ = self.engine.download(want_x=False)
+        if hasattr(self.log_like_fn, "evaluate"):            # host-callable likelihood: the device filled log_prior only
+            L = self.log_like_fn.evaluate(np.ascontiguousarray(x), ~np.isinf(P))
         for m in self.moves:
             m._resident = None
         return L, P

@@ -116,8 +116,15 @@ class StretchMove(Move):
             Nc = W - Ns
             rint = model.random.randint(Nc, size=(T, Ns))              # stretch.py:93-99
             u_zz = model.random.rand(T, Ns)                            # stretch.py:129-132
-            u_acc = model.random.rand(T, Ns)                           # red_blue.py:294
-            keep = eng.stretch_split(split, labels, rint, u_zz, u_acc)
+            if hasattr(eng.likelihood, "evaluate"):
+                # arbitrary Python likelihood: propose on the device, evaluate here, accept on the device
+                q, inbox = eng.propose_split(split, labels, rint, u_zz)
+                logl = eng.likelihood.evaluate(q, inbox)               # ensemble.py:1219-1545
+                u_acc = model.random.rand(T, Ns)                       # red_blue.py:294 (drawn after the likelihood)
+                keep = eng.accept_split(split, logl, u_acc)
+            else:
+                u_acc = model.random.rand(T, Ns)                       # red_blue.py:294
+                keep = eng.stretch_split(split, labels, rint, u_zz, u_acc)
             accepted[tt, S] = keep
         if self._accepted is not None:
             self.accepted += accepted                                  # red_blue.py:326-327

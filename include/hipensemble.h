@@ -46,7 +46,8 @@ typedef enum hens_status {
 typedef enum hens_likelihood {
     HENS_LIKE_GAUSS_DENSE = 0,      /* -0.5 (x-mu)^T P (x-mu), tests/test_eryn.py:33-35 */
     HENS_LIKE_GAUSS_DIAG = 1,       /* same with diagonal precision (test_base's identity covariance) */
-    HENS_LIKE_ROSENBROCK = 2        /* -(sum b (x[i+1]-x[i]^2)^2 + (a-x[i])^2), BASELINE config 5 */
+    HENS_LIKE_ROSENBROCK = 2,       /* -(sum b (x[i+1]-x[i]^2)^2 + (a-x[i])^2), BASELINE config 5 */
+    HENS_LIKE_HOST = 3              /* arbitrary caller-side log_like_fn: hens_propose_split / hens_accept_split */
 } hens_likelihood;
 
 /* Construction parameters.  Mirrors the keyword arguments that reach the path:
@@ -119,6 +120,18 @@ int hens_eval_state(hens_ctx* ctx);
  * Calls must alternate split = 0, 1.  Synchronous. */
 int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint,
                        const double* u_zz, const double* u_acc, uint8_t* keep_out);
+
+/* Host-callable likelihood (contexts created with HENS_LIKE_HOST).  The half-step of
+ * hens_stretch_split is cut in two around the caller's log_like_fn (ensemble.py:1219-1545,
+ * 1623-1667): hens_propose_split returns the proposed points q[Tl][Ns][D] and inbox[Tl][Ns]
+ * (1 = inside the prior box; walkers with 0 must not be evaluated and get the fill value,
+ * ensemble.py:1279-1282,1486-1513); hens_accept_split takes logl[Tl][Ns] and the accept uniforms and
+ * performs the MH test and Move.update on the device.  Same alternation rule as hens_stretch_split;
+ * hens_eval_state on such a context fills log_prior only.  hens_step is not available. */
+int hens_propose_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint,
+                       const double* u_zz, double* q_out, uint8_t* inbox_out);
+int hens_accept_split(hens_ctx* ctx, int32_t split, const double* logl, const double* u_acc,
+                      uint8_t* keep_out);
 
 /* Hot->cold swap cascade + ladder adaptation, driven by caller-supplied draws.
  * Replaces TemperatureControl.temper_comps (tempering.py:598-649): temperature_swaps

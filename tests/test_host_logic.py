@@ -134,7 +134,39 @@ def test_prior_container_box():
     assert box_logp_inside(lo, hi) == np.log(1 / 10.0) + np.log(1 / 2.0)
 
 
-def test_sampler_rejects_python_callable():
+def test_sampler_callable_needs_numpy_rng_and_a_gpu():
     from eryn_amd.ensemble import EnsembleSampler
-    with pytest.raises(NotImplementedError, match="likelihood"):
-        EnsembleSampler(16, 2, lambda x: 0.0, {0: uniform_dist(-1, 1), 1: uniform_dist(-1, 1)})
+    pri = {0: uniform_dist(-1, 1), 1: uniform_dist(-1, 1)}
+    with pytest.raises(NotImplementedError, match="host-callable"):
+        EnsembleSampler(16, 2, lambda x: 0.0, pri, rng="philox")
+    with pytest.raises(ValueError):
+        EnsembleSampler(16, 2, 3.0, pri)
+    if _lib.load().hens_device_count() == 0:
+        with pytest.raises(RuntimeError, match="no HIP device"):      # no CPU fallback for the device half
+            EnsembleSampler(16, 2, lambda x: 0.0, pri)
+
+
+def test_host_likelihood_contract():
+    """eryn_amd.likelihood.HostLikelihood.evaluate mirrors compute_log_like (ensemble.py:1219-1545)."""
+    from eryn_amd.likelihood import HostLikelihood
+    calls = []
+
+    def f(x, shift):
+        calls.append(x.shape)
+        return -0.5 * ((x - shift) ** 2).sum(axis=1)
+
+    hl = HostLikelihood(f, 3, args=[0.5])
+    q = np.arange(24, dtype=float).reshape(2, 4, 3) / 10
+    inbox = np.array([[1, 0, 1, 1], [0, 0, 1, 1]], dtype=bool)
+    ll = hl.evaluate(q, inbox)
+    assert calls == [(5, 3)]                                  # only in-prior walkers are evaluated, flattened C order
+    assert np.all(ll[~inbox] == -1e300)
+    assert np.array_equal(ll[inbox], -0.5 * ((q[inbox] - 0.5) ** 2).sum(axis=1))
+    with pytest.warns(UserWarning):
+        assert np.all(hl.evaluate(q, np.zeros((2, 4), bool)) == -1e300)
+    with pytest.raises(ValueError, match="Nan"):
+        HostLikelihood(lambda x: np.full(len(x), np.nan), 3).evaluate(q, inbox)
+    with pytest.raises(ValueError, match="infinite"):
+        hl.evaluate(np.full((1, 2, 3), np.inf), np.ones((1, 2), bool))
+    per_walker = HostLikelihood(lambda x, s: -0.5 * ((x - s) ** 2).sum(), 3, args=[0.5], vectorize=False)
+    assert np.array_equal(per_walker.evaluate(q, inbox)[inbox], ll[inbox])
