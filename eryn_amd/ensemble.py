@@ -260,8 +260,15 @@ class EnsembleSampler:
             for initial_state in self.sample(initial_state, iterations=burn, **bk):
                 pass
         results = None
-        for results in self.sample(initial_state, iterations=nsteps, **kwargs):
-            pass
+        if self.rng == "philox" and kwargs.get("store", True) is False and nsteps > 0:
+            # nothing is stored: one device-resident call for all iterations, one download at the end
+            kw = dict(kwargs)
+            thin = int(kw.pop("thin_by", 1))
+            for results in self.sample(initial_state, iterations=1, thin_by=thin * nsteps, **kw):
+                pass
+        else:
+            for results in self.sample(initial_state, iterations=nsteps, **kwargs):
+                pass
         self._previous_state = results
         return results
 
