@@ -86,7 +86,7 @@ struct hens_ctx_impl {
     // debug / timing
     unsigned long long* d_trace = nullptr;
     int64_t trace_words = 0;
-    bool tracing = false;
+    bool tracing = false, trace_pt = false;
     bool per_kernel_events = false;
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -250,7 +250,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.accepted = c->accepted;
     a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec; a.prec_sym = c->prec_sym;
     a.flags = c->flags;
-    a.trace = c->tracing ? c->d_trace : nullptr;
+    a.trace = (c->tracing && !c->trace_pt) ? c->d_trace : nullptr;
     a.logp_in = c->logp_in;
     a.fill = c->cfg.fill_value;
     a.rosen_a = c->rosen_a; a.rosen_b = c->rosen_b;
@@ -360,6 +360,7 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     p.seed = c->cfg.seed;
     p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin; p.idx_bits = c->idx_bits;
     p.srcfull = sharded ? c->srcglob : nullptr;
+    p.trace = (c->tracing && c->trace_pt) ? c->d_trace : nullptr;
     return p;
 }
 
@@ -1062,7 +1063,7 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    const int64_t words = (int64_t)c->Tl * ((c->W + TILE - 1) / TILE) * 8;
+    const int64_t words = std::max<int64_t>((int64_t)c->Tl * ((c->W + TILE - 1) / TILE), pt_blocks(c)) * 8;
     if (enable) {
         if (!c->d_trace) {
             int r = dalloc(c, &c->d_trace, (size_t)words);
@@ -1071,6 +1072,7 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
         }
         HIPCHK(c, hipMemsetAsync(c->d_trace, 0, (size_t)words * 8, c->stream));
         c->tracing = true;
+        c->trace_pt = enable == 2;           // 1: stretch kernel, 2: PT cascade
         return HENS_OK;
     }
     c->tracing = false;

@@ -925,14 +925,15 @@ struct PtArgs {
     uint32_t* swap_part;        // [nblocks][T-1] per-workgroup swap counts (reduced by the adaptation)
     uint64_t iter;
     uint64_t seed;
+    unsigned long long* trace;  // debug: per-workgroup phase timestamps, or nullptr
     int32_t T, W, Tl, rung_begin, idx_bits;
 };
 
 constexpr int PT_COLS = 16;      // columns per workgroup: W/16 workgroups keep every CU busy at W = 4096
 constexpr int PT_THREADS = 256;
 
-// LDS per (rung, column) element: L f64, log-uniform f64, P f64, loc i32, slot i32, src i16, sel u8; + betas[T]
-__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 8 + 4 + 4 + 2 + 1) + (size_t)T * (8 + 32); }
+// LDS per (rung, column) element: L f64, log-uniform f64, P f64, loc i32, slot i32; + betas[T] + swap bitmasks
+__host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 8 + 4 + 4) + (size_t)T * 8 + (size_t)PT_COLS * ((T + 31) / 32) * 4; }
 
 // One launch = the whole hot->cold cascade.  Two dependent global-load levels only
 // (colslot -> {L, P, loc}); everything after that runs out of LDS.  No inter-workgroup
@@ -950,30 +951,31 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     double* sbeta = Pc + NE;                                     // [T]
     int32_t* locc = reinterpret_cast<int32_t*>(sbeta + T);       // [T][PT_COLS]
     int32_t* scol = locc + NE;                                   // [T][PT_COLS]
-    uint32_t* skey = reinterpret_cast<uint32_t*>(scol + NE);     // [T][8] PRP round keys (Philox mode)
-    int16_t* src = reinterpret_cast<int16_t*>(skey + (size_t)T * 8);   // [T][PT_COLS]
-    uint8_t* sel = reinterpret_cast<uint8_t*>(src + NE);         // [T][PT_COLS]
+    uint32_t* smask = reinterpret_cast<uint32_t*>(scol + NE);    // [PT_COLS][MW] swap bitmask per column (bit i = pair (i, i-1))
+    const int MW = (T + 31) / 32;
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
     const uint64_t it = A.iter;
+#define PT_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    PT_TRACE(0);
 
-    // phase 0 (Philox): one lane per rung draws that rung's permutation keys
-    for (int t = tid; t < T; t += PT_THREADS) {
-        sbeta[t] = A.betas[t];
-        if (PHILOX) {
-            const PrpKey K = prp_key(A.seed, it, PURPOSE_PTPERM, (uint32_t)t);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) skey[t * 8 + r] = K.k[r];
-        }
-    }
-    if (PHILOX) __syncthreads();
-    // phase 1: column slots, then everything the column needs (independent gathers)
+    // phase 1: column slots (Philox: computed in place from the rung's keys), then everything the
+    // column needs - independent gathers, the log-uniform overlaps their latency
+    for (int t = tid; t < T; t += PT_THREADS) sbeta[t] = A.betas[t];
     for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
             int slot;
-            if (PHILOX) slot = (t == T - 1) ? c : (int)prp((uint32_t)c, skey + t * 8, A.idx_bits, (uint32_t)W);
-            else slot = A.colslot[(size_t)t * W + c];
+            if (PHILOX) {
+                if (t == T - 1) {
+                    slot = c;                                    // hottest rung: identity
+                } else {
+                    const PrpKey K = prp_key(A.seed, it, PURPOSE_PTPERM, (uint32_t)t);
+                    slot = (int)prp((uint32_t)c, K.k, A.idx_bits, (uint32_t)W);
+                }
+            } else {
+                slot = A.colslot[(size_t)t * W + c];
+            }
             scol[e] = slot;
             Lc[e] = A.Lfull[(size_t)t * W + slot];
             const int tl = t - A.rung_begin;
@@ -996,38 +998,72 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
             }
         }
     }
+    PT_TRACE(1);
+    PT_TRACE(2);
     __syncthreads();
+    PT_TRACE(3);
 
-    // phase 2: one lane per column walks hot -> cold
+    // phase 2: one lane per column walks hot -> cold.  Nothing is stored inside the loop (the swap
+    // decisions go into a register bitmask), so the LDS reads of the next steps are issued ahead and
+    // only the compare/select chain is serial.
     if (tid < PT_COLS && c0 + tid < W) {
         const int cc = tid;
         double cL = Lc[(size_t)(T - 1) * PT_COLS + cc];
-        int cr = T - 1;                                          // rung the carried walker came from
-        for (int i = T - 1; i >= 1; --i) {
-            const int j = T - 1 - i;
-            const double Lb = Lc[(size_t)(i - 1) * PT_COLS + cc];
-            const double dbeta = sbeta[i - 1] - sbeta[i];        // tempering.py:518-522
-            const double pacc = dbeta * (cL - Lb);               // tempering.py:538
-            const bool s = pacc > lu[(size_t)j * PT_COLS + cc];  // tempering.py:541
-            sel[(size_t)j * PT_COLS + cc] = s ? 1 : 0;
-            if (s) {
-                src[(size_t)i * PT_COLS + cc] = (int16_t)(i - 1);   // resident moves up, carried keeps falling
-            } else {
-                src[(size_t)i * PT_COLS + cc] = (int16_t)cr;        // carried walker settles on rung i
-                cr = i - 1;
-                cL = Lb;
+        uint32_t m = 0;
+        for (int i0 = T - 1; i0 >= 1; i0 -= 8) {                   // 8 steps per LDS round trip
+            double Lb[8], lv[8], db[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = (i0 - q >= 1) ? i0 - q : 1;
+                Lb[q] = Lc[(size_t)(i - 1) * PT_COLS + cc];
+                lv[q] = lu[(size_t)(T - 1 - i) * PT_COLS + cc];
+                db[q] = sbeta[i - 1] - sbeta[i];                                 // tempering.py:518-522
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 - q;
+                if (i >= 1) {
+                    const double pacc = db[q] * (cL - Lb[q]);                    // tempering.py:538
+                    const bool sw = pacc > lv[q];                                // tempering.py:541
+                    m |= sw ? (1u << (i & 31)) : 0u;
+                    cL = sw ? cL : Lb[q];                        // no swap: the resident becomes the carried walker
+                    if ((i & 31) == 0 || i == 1) {
+                        smask[cc * MW + (i >> 5)] = m;
+                        m = 0;
+                    }
+                }
             }
         }
-        src[cc] = (int16_t)cr;
     }
+    PT_TRACE(4);
     __syncthreads();
+    PT_TRACE(5);
 
-    // phase 3: write the permuted L / P / loc of the resident rungs straight from LDS
+    // phase 3: write the permuted L / P / loc of the resident rungs straight from LDS.  The walker
+    // arriving on rung t of a column comes from rung t-1 if pair (t, t-1) swapped; otherwise the
+    // carried walker settles there, and it started its fall at t + (number of consecutive swapped
+    // pairs directly above).
+    auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
     for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
-        if (t < T - 1 && A.selcol) A.selcol[(size_t)t * W + c] = sel[e];
-        const int st = src[e];
+        int st;
+        bool sel_out;
+        if (MW == 1) {                                            // T <= 32: the whole column mask in one register
+            const uint32_t mw = smask[cc];
+            sel_out = (mw >> ((T - 1 - t) & 31)) & 1u;
+            if ((mw >> t) & 1u) st = t - 1;                       // bit 0 is never set
+            else st = t + __builtin_ctz(~(mw >> 1 >> t));         // consecutive swapped pairs directly above
+        } else {
+            sel_out = bit(cc, T - 1 - t);
+            if (bit(cc, t)) {
+                st = t - 1;
+            } else {
+                st = t;
+                while (bit(cc, st + 1)) ++st;
+            }
+        }
+        if (t < T - 1 && A.selcol) A.selcol[(size_t)t * W + c] = sel_out ? 1 : 0;   // row j <-> pair T-1-j
         const int se = st * PT_COLS + cc;
         const int dslot = scol[e];
         if (A.srcfull) A.srcfull[(size_t)t * W + dslot] = st * W + scol[se];
@@ -1038,11 +1074,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         A.locnew[di] = locc[se];      // -1: row + log-prior arrive from another rank (hens_pt_finish_sharded)
         if (locc[se] >= 0) A.Pnew[di] = Pc[se];
     }
-    for (int j = tid; j < T - 1; j += PT_THREADS) {
+    for (int i = 1 + tid; i < T; i += PT_THREADS) {               // pair (i, i-1) -> swap_part index i-1
         unsigned n = 0;
-        for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += sel[(size_t)j * PT_COLS + cc];
-        A.swap_part[(size_t)blockIdx.x * (T - 1) + (T - 2 - j)] = n;     // pair i = T-1-j -> index i-1
+        for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += bit(cc, i) ? 1u : 0u;
+        A.swap_part[(size_t)blockIdx.x * (T - 1) + (i - 1)] = n;
     }
+    PT_TRACE(6);
+#undef PT_TRACE
 }
 
 // Stand-alone ladder adaptation (one workgroup): used where it cannot ride in the next stretch
