@@ -83,6 +83,22 @@ struct hens_ctx_impl {
     int64_t row_capacity = 0, n_send = 0, n_recv = 0;
     bool pt_pending = false;
 
+    // ladder pipeline (neighbour exchange by one-sided puts, hens_pipe_*)
+    struct Pipe {
+        bool on = false, connected = false;
+        int nranks = 0, rank = 0;
+        char* box = nullptr;               // my mailbox (uncached device memory)
+        size_t box_bytes = 0;
+        std::vector<char*> boxes;          // every rank's mailbox as mapped into this process
+        std::vector<char> opened;          // 1: mapped through hipIpcOpenMemHandle (to be closed)
+        char** d_boxes = nullptr;
+        double* Lcur = nullptr; double* Pcur = nullptr; int32_t* botsrc = nullptr;
+        uint32_t sweep = 0;
+        long long budget = 0;              // wall-clock ticks a flag wait may take
+    } pipe;
+    const uint32_t* adapt_src = nullptr;   // pending swap counts: swap_part (nullptr) or the mailbox's reduced counts
+    int adapt_nblocks = 0;
+
     // debug / timing
     unsigned long long* d_trace = nullptr;
     int64_t trace_words = 0;
@@ -239,6 +255,12 @@ Draws draws_at(const DrawBuf& b, size_t off) {
     return d;
 }
 
+int64_t guest_delta(const hens_ctx_impl* c) {
+    if (!c->pipe.on) return 0;
+    const PipeBox b = pipe_box(c->pipe.box, c->T, c->W, c->D);
+    return (int64_t)(b.guest - c->pool);              // in doubles; both 256-byte aligned
+}
+
 StretchArgs base_args(hens_ctx_impl* c) {
     StretchArgs a{};
     a.pool = c->pool;
@@ -258,17 +280,18 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.N0 = c->N0;
     a.rung_begin = c->cfg.rung_begin;
     a.tempered = c->cfg.tempered;
+    a.guest_delta = guest_delta(c);
     return a;
 }
 
 AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* out) {
     AdaptArgs a{};
-    a.swap_part = c->swap_part;
+    a.swap_part = c->adapt_src ? c->adapt_src : c->swap_part;
     a.betas_in = in; a.betas_out = out;
     a.swaps_last = c->swaps_last; a.swaps_total = c->swaps_total;
     a.lag = c->cfg.adaptation_lag; a.nu = c->cfg.adaptation_time;
     a.time = c->adapt_time;
-    a.T = c->T; a.W = c->W; a.nblocks = pt_blocks(c);
+    a.T = c->T; a.W = c->W; a.nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     a.moving = (adaptive && (c->cfg.stop_adaptation < 0 || c->adapt_time < c->cfg.stop_adaptation)) ? 1 : 0;
     return a;
 }
@@ -280,6 +303,7 @@ void flush_adapt(hens_ctx_impl* c) {
     hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), (size_t)c->T * 28 + 16, c->stream, a);
     if (c->adapt_pending_adaptive) c->adapt_time += 1;               // tempering.py:596
     c->adapt_pending = false;
+    c->adapt_src = nullptr;
 }
 
 // can the pending adaptation ride in the next split-0 stretch launch?
@@ -287,7 +311,8 @@ bool can_fold_adapt(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FOLD") != nullptr;
     if (off || !c->adapt_pending || !is_fast_dim(c->D) || c->T > 64) return false;
     const int nw = fast_nw(c->D);
-    return nw >= 2 && (int64_t)pt_blocks(c) * (c->T - 1) <= (int64_t)8 * nw * 64;
+    const int64_t nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
+    return nw >= 2 && nblocks * (c->T - 1) <= (int64_t)8 * nw * 64;
 }
 
 int check_flags(hens_ctx_impl* c, bool nan_logl_is_error) {
@@ -298,6 +323,8 @@ int check_flags(hens_ctx_impl* c, bool nan_logl_is_error) {
         HIPCHK(c, hipMemsetAsync(c->flags, 0, sizeof(unsigned), c->stream));
         if (f & FLAG_NONFINITE_X)
             return fail(c, HENS_ERR_NONFINITE, "At least one parameter value was infinite or NaN");
+        if (f & FLAG_PIPE_TIMEOUT)
+            return fail(c, HENS_ERR_STATE, "ladder pipeline: a neighbour rank did not answer (flag wait timed out)");
         if ((f & FLAG_NAN_LOGL) && nan_logl_is_error)
             return fail(c, HENS_ERR_NONFINITE, "The likelihood function is returning Nan.");
     }
@@ -364,6 +391,102 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     return p;
 }
 
+// ---- ladder pipeline ------------------------------------------------------------------------------
+bool pipe_has_top(const hens_ctx_impl* c) { return c->cfg.rung_end < c->T; }
+bool pipe_has_bot(const hens_ctx_impl* c) { return c->cfg.rung_begin > 0; }
+bool pipe_active(const hens_ctx_impl* c) { return c->pipe.on && c->pipe.connected; }
+
+PipeArgs pipe_args(hens_ctx_impl* c) {
+    PipeArgs a{};
+    a.pool = c->pool;
+    a.guest_delta = guest_delta(c);
+    a.L = c->L[c->cur]; a.P = c->P[c->cur]; a.loc = c->loc[c->cur];
+    a.Lnew = c->L[c->cur ^ 1]; a.Pnew = c->P[c->cur ^ 1]; a.locnew = c->loc[c->cur ^ 1];
+    a.betas = c->betas[c->bcur];
+    a.box = c->pipe.box;
+    a.box_hot = pipe_has_top(c) ? c->pipe.boxes[c->pipe.rank + 1] : nullptr;
+    a.box_cold = pipe_has_bot(c) ? c->pipe.boxes[c->pipe.rank - 1] : nullptr;
+    a.boxes = c->pipe.d_boxes;
+    a.Lcur = c->pipe.Lcur; a.Pcur = c->pipe.Pcur; a.botsrc = c->pipe.botsrc;
+    a.swap_part = c->swap_part;
+    a.flags = c->flags;
+    a.iter = c->iter; a.seed = c->cfg.seed;
+    a.sweep = c->pipe.sweep;
+    a.T = c->T; a.W = c->W; a.D = c->D; a.Tl = c->Tl; a.rung_begin = c->cfg.rung_begin; a.idx_bits = c->idx_bits;
+    a.par = (int)(c->pipe.sweep & 1u);
+    a.nranks = c->pipe.nranks; a.rank = c->pipe.rank;
+    return a;
+}
+
+// the stream waits until the listed flags of MY mailbox (and, optionally, every rank's counts flag) reach `target`
+void pipe_wait(hens_ctx_impl* c, std::initializer_list<int> which, bool counts, uint32_t target) {
+    const PipeBox me = pipe_box(c->pipe.box, c->T, c->W, c->D);
+    PipeWaitArgs w{};
+    for (int f : which) w.p[w.n++] = me.flags + f;
+    w.cnt_flags = counts ? me.flags + PF_CNT0 : nullptr;
+    w.nranks = c->pipe.nranks;
+    if (w.n == 0 && !counts) return;
+    w.err = c->flags;
+    w.budget = c->pipe.budget;
+    w.target = target;
+    hipLaunchKernelGGL(k_pipe_wait, dim3(1), dim3(64), 0, c->stream, w);
+}
+void pipe_flag(hens_ctx_impl* c, char* peer_box, int which, uint32_t value) {
+    const PipeBox b = pipe_box(peer_box, c->T, c->W, c->D);
+    hipLaunchKernelGGL(k_pipe_flag, dim3(1), dim3(1), 0, c->stream, b.flags + which, value);
+}
+
+// before the stretch move of sweep s > 0: the rows that arrived in sweep s-1 and (if a ladder adaptation is
+// pending) every rank's swap counts must be here
+void pipe_prewait(hens_ctx_impl* c) {
+    if (c->pipe.sweep == 0) return;
+    const bool top = pipe_has_top(c), bot = pipe_has_bot(c);
+    const bool cnt = c->adapt_pending && c->adapt_src != nullptr;
+    if (top && bot) pipe_wait(c, {PF_ROWS_TOP, PF_ROWS_BOT}, cnt, c->pipe.sweep);
+    else if (top) pipe_wait(c, {PF_ROWS_TOP}, cnt, c->pipe.sweep);
+    else if (bot) pipe_wait(c, {PF_ROWS_BOT}, cnt, c->pipe.sweep);
+    else pipe_wait(c, {}, cnt, c->pipe.sweep);
+}
+
+// one PT sweep of the sharded ladder (tempering.py:598-649 across ranks); see hens_kernels.h
+void pipe_sweep(hens_ctx_impl* c) {
+    const bool top = pipe_has_top(c), bot = pipe_has_bot(c);
+    const PipeArgs a = pipe_args(c);
+    const uint32_t done = c->pipe.sweep + 1;
+    const int W = c->W;
+    const int bgrid = (W + PIPE_COLS - 1) / PIPE_COLS;
+    const int TE = c->Tl + (top ? 1 : 0);
+    if (top) {
+        hipLaunchKernelGGL(k_pipe_pub, dim3(grid_for(2 * (int64_t)W)), dim3(256), 0, c->stream, a);
+        pipe_flag(c, a.box_hot, PF_LDN, done);
+        pipe_wait(c, {PF_LUP}, false, done);
+        hipLaunchKernelGGL(k_pipe_top, dim3(bgrid), dim3(256), 0, c->stream, a);
+        pipe_flag(c, a.box_hot, PF_ROWS_BOT, done);
+    }
+    hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);
+    if (bot) {
+        pipe_flag(c, a.box_cold, PF_LUP, done);
+        if (top) pipe_wait(c, {PF_LDN, PF_ROWS_TOP}, false, done);   // a walker may fall through all my rungs in one sweep
+        else pipe_wait(c, {PF_LDN}, false, done);
+        hipLaunchKernelGGL(k_pipe_bottom, dim3(bgrid), dim3(256), 0, c->stream, a);
+        pipe_flag(c, a.box_cold, PF_ROWS_TOP, done);
+    }
+    hipLaunchKernelGGL(k_pipe_counts, dim3(1), dim3(256), (size_t)(TE + 1) * 4, c->stream, a, pt_blocks(c));
+    const PipeBox me = pipe_box(c->pipe.box, c->T, c->W, c->D);
+    c->adapt_src = me.counts + (size_t)a.par * c->T;
+    c->adapt_nblocks = 1;
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = c->cfg.adaptive != 0;
+    c->cur ^= 1;
+    c->pipe.sweep += 1;
+}
+
+// the pending adaptation needs every rank's counts of the last sweep
+void pipe_flush_adapt(hens_ctx_impl* c) {
+    if (c->adapt_pending && c->adapt_src) pipe_wait(c, {}, true, c->pipe.sweep);
+    flush_adapt(c);
+}
+
 // plan nb iterations starting at iteration `iter0` into draw buffer `which`
 void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb) {
     PlanArgs pa{};
@@ -398,6 +521,7 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
                 a.betas = c->betas[c->bcur];
                 if (c->adapt_pending_adaptive) c->adapt_time += 1;
                 c->adapt_pending = false;
+                c->adapt_src = nullptr;
                 c->bcur ^= 1;
             } else {
                 flush_adapt(c);
@@ -559,6 +683,9 @@ void hens_destroy(hens_ctx* ctx) {
     (void)hipSetDevice(c->cfg.device_id);
     if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (size_t q = 0; q < c->pipe.boxes.size(); ++q)
+        if (c->pipe.opened[q] && c->pipe.boxes[q]) (void)hipIpcCloseMemHandle(c->pipe.boxes[q]);
+    if (c->pipe.box) (void)hipFree(c->pipe.box);
     for (void* p : c->allocs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -679,7 +806,7 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     const size_t TW = (size_t)c->Tl * c->W;
     if (x) {
         hipLaunchKernelGGL(k_gather_rows, dim3(grid_for((int64_t)TW * c->D)), dim3(256), 0, c->stream, c->pool,
-                           c->loc[c->cur], c->xtmp, (int64_t)TW, c->D);
+                           c->loc[c->cur], c->xtmp, (int64_t)TW, c->D, guest_delta(c));
         HIPCHK(c, hipMemcpyAsync(x, c->xtmp, TW * c->D * 8, hipMemcpyDeviceToHost, c->stream));
     }
     if (logl) HIPCHK(c, hipMemcpyAsync(logl, c->L[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
@@ -917,7 +1044,10 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     int r = ready(c, true);
     if (r) return r;
     if (n_iters < 0) return fail(c, HENS_ERR_INVALID, "n_iters < 0");
-    if (c->Tl != c->T) return fail(c, HENS_ERR_STATE, "hens_step needs the whole ladder resident (sharded stepping is driven by eryn_amd.ladder)");
+    const bool piped = pipe_active(c);
+    if (c->Tl != c->T && !piped)
+        return fail(c, HENS_ERR_STATE, "hens_step on a ladder shard needs the pipeline connected (hens_pipe_init / hens_pipe_connect)");
+    if (piped && !has_pt(c)) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
         return fail(c, HENS_ERR_UNSUPPORTED, "hens_step needs a device likelihood (host-callable likelihoods step through hens_propose_split / hens_accept_split)");
@@ -954,9 +1084,14 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         }
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
         for (int ib = 0; ib < nb; ++ib) {
+            if (piped) pipe_prewait(c);
             r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
             if (r) return r;
-            if (pt) {
+            if (piped) {
+                if (prof) { hipEvent_t e0 = new_event(c); evs.push_back(e0); (void)hipEventRecord(e0, c->stream); }
+                pipe_sweep(c);
+                if (prof) { hipEvent_t e1 = new_event(c); evs.push_back(e1); (void)hipEventRecord(e1, c->stream); }
+            } else if (pt) {
                 PtArgs p = pt_args(c, nullptr, false);
                 if (prof) {
                     hipEvent_t e0 = new_event(c), e1 = new_event(c);
@@ -975,7 +1110,8 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             c->iter += 1;
         }
     }
-    flush_adapt(c);      // the ladder and the swap counters are final when the call's work completes
+    if (piped) pipe_flush_adapt(c);
+    else flush_adapt(c);      // the ladder and the swap counters are final when the call's work completes
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;
@@ -1235,6 +1371,93 @@ int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
     c->iter += 1;
     c->pt_pending = false;
     return HENS_OK;
+}
+
+// ---- ladder pipeline set-up -------------------------------------------------------------------------
+int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* handle_out, int64_t* box_bytes_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (c->pipe.on) return fail(c, HENS_ERR_STATE, "pipeline already initialised");
+    if (!c->cfg.tempered || c->T < 2) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
+    if (nranks < 1 || nranks > PIPE_MAX_RANKS || my_rank < 0 || my_rank >= nranks)
+        return fail(c, HENS_ERR_INVALID, "nranks must be in [1, %d] and my_rank inside it", PIPE_MAX_RANKS);
+    if ((my_rank == 0) != (c->cfg.rung_begin == 0) || (my_rank == nranks - 1) != (c->cfg.rung_end == c->T))
+        return fail(c, HENS_ERR_INVALID, "ranks must hold contiguous rung ranges in rank order (rank 0 = coldest rungs)");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t bytes = pipe_box_bytes(c->T, c->W, c->D);
+    void* box = nullptr;
+    HIPCHK(c, hipExtMallocWithFlags(&box, bytes, hipDeviceMallocUncached));
+    HIPCHK(c, hipMemsetAsync(box, 0, bytes, c->stream));
+    c->pipe.box = static_cast<char*>(box);
+    c->pipe.box_bytes = bytes;
+    c->pipe.nranks = nranks;
+    c->pipe.rank = my_rank;
+    c->pipe.boxes.assign((size_t)nranks, nullptr);
+    c->pipe.opened.assign((size_t)nranks, 0);
+    c->pipe.boxes[my_rank] = c->pipe.box;
+    int r;
+    if ((r = dalloc(c, &c->pipe.Lcur, (size_t)c->W))) return r;
+    if ((r = dalloc(c, &c->pipe.Pcur, (size_t)c->W))) return r;
+    if ((r = dalloc(c, &c->pipe.botsrc, (size_t)c->W))) return r;
+    if ((r = dalloc(c, &c->pipe.d_boxes, (size_t)nranks))) return r;
+    int khz = 0;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device_id);
+    const double secs = getenv("HENS_PIPE_TIMEOUT_S") ? atof(getenv("HENS_PIPE_TIMEOUT_S")) : 20.0;
+    c->pipe.budget = (long long)((khz > 0 ? khz : 100000) * 1000.0 * secs);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (handle_out) {
+        hipIpcMemHandle_t h;
+        HIPCHK(c, hipIpcGetMemHandle(&h, box));
+        static_assert(sizeof(hipIpcMemHandle_t) == HENS_IPC_HANDLE_BYTES, "IPC handle size");
+        memcpy(handle_out, &h, sizeof h);
+    }
+    if (box_bytes_out) *box_bytes_out = (int64_t)bytes;
+    c->pipe.on = true;
+    return HENS_OK;
+}
+
+static int pipe_finish_connect(hens_ctx_impl* c) {
+    for (int q = 0; q < c->pipe.nranks; ++q)
+        if (!c->pipe.boxes[q]) return fail(c, HENS_ERR_STATE, "mailbox of rank %d missing", q);
+    HIPCHK(c, hipMemcpyAsync(c->pipe.d_boxes, c->pipe.boxes.data(), (size_t)c->pipe.nranks * sizeof(char*),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pipe.connected = true;
+    return HENS_OK;
+}
+
+int hens_pipe_connect(hens_ctx* ctx, const void* handles) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !handles) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
+    if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const char* hb = static_cast<const char*>(handles);
+    for (int q = 0; q < c->pipe.nranks; ++q) {
+        if (q == c->pipe.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, hb + (size_t)q * sizeof h, sizeof h);
+        void* p = nullptr;
+        HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        c->pipe.boxes[q] = static_cast<char*>(p);
+        c->pipe.opened[q] = 1;
+    }
+    return pipe_finish_connect(c);
+}
+
+int hens_pipe_connect_local(hens_ctx* ctx, hens_ctx* const* peers) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !peers) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
+    if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
+    for (int q = 0; q < c->pipe.nranks; ++q) {
+        const hens_ctx_impl* o = CTX(peers[q]);
+        if (!o || !o->pipe.on || o->pipe.rank != q || o->pipe.nranks != c->pipe.nranks || o->T != c->T || o->W != c->W ||
+            o->D != c->D)
+            return fail(c, HENS_ERR_INVALID, "peer %d is not an initialised pipeline context of the same ladder", q);
+        c->pipe.boxes[q] = o->pipe.box;
+    }
+    return pipe_finish_connect(c);
 }
 
 }  // extern "C"

@@ -84,6 +84,12 @@ enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 
                   PURPOSE_PTU = 10 };
 
 // The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
+// loc >= 0: a row of the pool.  loc < 0: guest row ~loc of this rank's mailbox (a walker that arrived
+// through the ladder pipeline during the last PT sweep); `guest_delta` = (guest - pool) in doubles.
+__device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_delta) {
+    return loc >= 0 ? (int64_t)loc * D : guest_delta + (int64_t)(~loc) * D;
+}
+
 struct Draws {
     int32_t* own;    // [Tl][W] moving walker at each split position (positions < N0: split 0)
     int32_t* cw;     // [Tl][W] its complement walker
@@ -139,6 +145,7 @@ struct StretchArgs {
     double logp_in, fill, rosen_a, rosen_b;
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
     int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
+    int64_t guest_delta;       // see row_off (0 when there is no pipeline)
     AdaptArgs ad;
 };
 
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
         bool ok = true, finite = true;
         if (rvalid) {
             const double zz = s_zz[r];
-            const double* ps = pool_r + (size_t)s_rs[r] * D;
-            const double* pc = pool_r + (size_t)s_rc[r] * D;
+            const double* ps = pool_r + row_off(s_rs[r], D, A.guest_delta);
+            const double* pc = pool_r + row_off(s_rc[r], D, A.guest_delta);
             for (int ch = jl; ch < chunks; ch += LPR) {
                 const int e = ch * VEC;
                 if (VEC == 2) {
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
         if (!(fl & 4)) continue;
         const bool keep = (fl & 2) != 0;
         double* pd = pool_w + (size_t)s_dst[r] * D;
-        const double* ps = pool_r + (size_t)s_rs[r] * D;
+        const double* ps = pool_r + row_off(s_rs[r], D, A.guest_delta);
         for (int ch = jl; ch < chunks; ch += LPR) {
             const int e = ch * VEC;
             if (VEC == 2) {
@@ -530,8 +537,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rs[r] * D + jl * 2);
-            if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (size_t)s_rc[r] * D + jl * 2);
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rs[r], D, A.guest_delta) + jl * 2);
+            if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rc[r], D, A.guest_delta) + jl * 2);
         }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
@@ -744,13 +751,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 // Small utilities
 // ---------------------------------------------------------------------------------------------
 __global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
-                              double* __restrict__ dst, int64_t nrows, int D) {
+                              double* __restrict__ dst, int64_t nrows, int D, int64_t guest_delta) {
     const int64_t total = nrows * D;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / D;
         const int d = (int)(i - r * D);
-        dst[i] = pool[(size_t)loc[r] * D + d];
+        dst[i] = pool[row_off(loc[r], D, guest_delta) + d];
     }
 }
 
@@ -1339,6 +1346,310 @@ __global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ l
         if (d == 0) locnew[slot] = free_off + slot;
         else if (d <= D) pool[(size_t)(free_off + slot) * D + (d - 1)] = in[i];
         else Pnew[slot] = in[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ladder pipeline: the sharded ladder's PT sweep as a neighbour exchange of one-sided puts.
+//
+// Rank r keeps the global rungs [b, e) (rung 0 = beta 1 is the coldest).  The cascade runs hot ->
+// cold (tempering.py:515-541), so the only true dependency between ranks is "the column state at the
+// top of my rungs", which the hot neighbour knows when ITS walk is done.  Per sweep and boundary
+// (hot rung e on rank r+1, cold rung e-1 on rank r):
+//   r   -> r+1 : (L, P) of rung e-1 after the stretch move, slot order            [k_pipe_pub]
+//   r+1 -> r   : (L, P) of the walker each column carries on leaving rung e       [k_pipe_walk]
+//   both sides evaluate the boundary pair from identical Philox draws; then
+//   r   -> r+1 : rows of the walkers that move up   (sparse, indexed by column)   [k_pipe_top]
+//   r+1 -> r   : rows of the walkers that move down (sparse, indexed by column)   [k_pipe_bottom]
+//   every rank -> all ranks: swap counts of the pairs it owns (ladder adaptation) [k_pipe_counts]
+// Every message is a kernel that stores straight into the peer's MAILBOX (uncached device memory,
+// peer-mapped through HIP IPC: xGMI stores on a multi-GPU node) followed by a flag; the consumer's
+// stream waits on the flag (k_pipe_wait).  No host round trip, no packing, no counts: a row that
+// moves lands in the guest area at its COLUMN index, and `loc` simply points there (row_off) until
+// the next stretch move rewrites every walker into its home row anyway.
+// Mailbox buffers are double-buffered by sweep parity; the flag protocol itself keeps a rank at
+// most one sweep ahead of its neighbours.
+// ---------------------------------------------------------------------------------------------
+enum { PF_LUP = 0, PF_LDN = 1, PF_ROWS_TOP = 2, PF_ROWS_BOT = 3, PF_CNT0 = 8, PIPE_FLAG_WORDS = 64 };
+constexpr int PIPE_MAX_RANKS = PIPE_FLAG_WORDS - PF_CNT0;
+constexpr unsigned FLAG_PIPE_TIMEOUT = 4u;
+
+struct PipeBox {
+    unsigned* flags;       // [PIPE_FLAG_WORDS] sweep counters raised by the peers
+    unsigned* counts;      // [2][T] accepted swaps per pair (index i-1 for pair (i, i-1)), written by the pair's owner
+    double* lp_up;         // [2][2][W] (L, P) carried by each column of the hot neighbour (column order)
+    double* lp_dn;         // [2][2][W] (L, P) of the cold neighbour's hottest rung after its stretch move (slot order)
+    double* guest;         // [2][2][W][D] arrived rows: side 0 = from the hot neighbour, side 1 = from the cold one
+};
+__host__ __device__ inline size_t pipe_round(size_t n) { return (n + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t pipe_box_bytes(int T, int W, int D) {
+    return pipe_round(PIPE_FLAG_WORDS * 4) + pipe_round((size_t)2 * T * 4) + 2 * pipe_round((size_t)4 * W * 8) +
+           pipe_round((size_t)4 * W * D * 8);
+}
+__host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
+    PipeBox b;
+    size_t off = 0;
+    b.flags = reinterpret_cast<unsigned*>(base + off); off += pipe_round(PIPE_FLAG_WORDS * 4);
+    b.counts = reinterpret_cast<unsigned*>(base + off); off += pipe_round((size_t)2 * T * 4);
+    b.lp_up = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
+    b.lp_dn = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
+    b.guest = reinterpret_cast<double*>(base + off);
+    return b;
+}
+// guest row index of column c (sweep parity par, side) and its `loc` encoding
+__host__ __device__ inline int32_t pipe_guest_loc(int par, int side, int W, int c) { return ~((par * 2 + side) * W + c); }
+
+// peer memory is written and read with system-scope accesses (sc0 sc1: nothing lingers in a cache)
+__device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+struct PipeArgs {
+    const double* pool;
+    int64_t guest_delta;
+    const double* L; const double* P; const int32_t* loc;     // current [Tl][W] (all rows at home after the stretch move)
+    double* Lnew; double* Pnew; int32_t* locnew;              // next
+    const double* betas;          // [T] whole ladder (replicated)
+    char* box;                    // my mailbox
+    char* box_hot;                // hot neighbour's (rank + 1) or nullptr
+    char* box_cold;               // cold neighbour's (rank - 1) or nullptr
+    char* const* boxes;           // [nranks] every mailbox (swap counts)
+    double* Lcur; double* Pcur; int32_t* botsrc;              // [W] what each column carries below my coldest rung
+    uint32_t* swap_part;          // [nblocks][TE-1]
+    unsigned* flags;              // context error flags
+    uint64_t iter, seed;
+    uint32_t sweep;               // pipeline sweep counter (flags carry sweep + 1)
+    int32_t T, W, D, Tl, rung_begin, idx_bits, par, nranks, rank;
+};
+
+__device__ __forceinline__ int pipe_slot(const PipeArgs& A, int g, int c) {
+    if (g == A.T - 1) return c;                                      // hottest rung of the ladder: identity
+    const PrpKey K = prp_key(A.seed, A.iter, PURPOSE_PTPERM, (uint32_t)g);
+    return (int)prp((uint32_t)c, K.k, A.idx_bits, (uint32_t)A.W);
+}
+// log-uniform of pair (i, i-1), column c - keyed exactly like k_pt_cascade (row T-1-i)
+__device__ __forceinline__ double pipe_logu(const PipeArgs& A, int i, int c) {
+    const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), (uint32_t)((A.T - 1 - i) * A.W + c), PURPOSE_PTU};
+    const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+    return log(u01(d.x, d.y));                                       // tempering.py:535
+}
+
+struct PipeWaitArgs {
+    const unsigned* p[4];
+    const unsigned* cnt_flags;    // my flags + PF_CNT0 (or nullptr): wait for every rank's counts
+    unsigned* err;
+    long long budget;             // wall_clock64 ticks
+    uint32_t target;
+    int32_t n, nranks;
+};
+__global__ void k_pipe_wait(const PipeWaitArgs A) {
+    const int i = threadIdx.x;
+    const unsigned* f = nullptr;
+    if (i < A.n) f = A.p[i];
+    else if (A.cnt_flags && i - A.n < A.nranks) f = A.cnt_flags + (i - A.n);
+    if (!f) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.target) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > A.budget) {            // a peer died: fail the run instead of hanging the GPU
+            atomicOr(A.err, FLAG_PIPE_TIMEOUT);
+            return;
+        }
+    }
+}
+__global__ void k_pipe_flag(unsigned* f, uint32_t v) {
+    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// my hottest rung after the stretch move -> hot neighbour
+__global__ void k_pipe_pub(const PipeArgs A) {
+    const PipeBox hot = pipe_box(A.box_hot, A.T, A.W, A.D);
+    const int W = A.W;
+    const size_t base = (size_t)(A.Tl - 1) * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * W; i += gridDim.x * blockDim.x) {
+        const int w = i < W ? i : i - W;
+        sys_store(hot.lp_dn + (size_t)(A.par * 2 + (i < W ? 0 : 1)) * W + w, i < W ? A.L[base + w] : A.P[base + w]);
+    }
+}
+
+constexpr int PIPE_COLS = 64;       // columns per workgroup of the boundary kernels
+constexpr int32_t PIPE_NOSEL = INT32_MIN;
+
+__device__ __forceinline__ void pipe_copy_rows(const PipeArgs& A, const int32_t* s_src, double* dst_rows, int c0) {
+    const int D = A.D;
+    for (int idx = threadIdx.x; idx < PIPE_COLS * D; idx += blockDim.x) {
+        const int col = idx / D, d = idx - col * D;
+        const int32_t src = s_src[col];
+        if (src != PIPE_NOSEL) sys_store(dst_rows + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
+    }
+}
+
+// top boundary, cold side: decide pair (e, e-1) and send the rows that move up
+__global__ __launch_bounds__(256) void k_pipe_top(const PipeArgs A) {
+    __shared__ int32_t s_src[PIPE_COLS];
+    const int W = A.W, c0 = blockIdx.x * PIPE_COLS;
+    if (threadIdx.x < PIPE_COLS) {
+        const int c = c0 + threadIdx.x;
+        int32_t src = PIPE_NOSEL;
+        if (c < W) {
+            const int tl = A.Tl - 1, g = A.rung_begin + tl;          // my hottest rung; the pair is (g+1, g)
+            const PipeBox me = pipe_box(A.box, A.T, W, A.D);
+            const int slot = pipe_slot(A, g, c);
+            const double La = sys_load(me.lp_up + (size_t)(A.par * 2) * W + c);
+            const double Lb = A.L[(size_t)tl * W + slot];
+            const double db = A.betas[g] - A.betas[g + 1];           // tempering.py:518-522
+            if (db * (La - Lb) > pipe_logu(A, g + 1, c)) src = A.loc[(size_t)tl * W + slot];   // :538,:541
+        }
+        s_src[threadIdx.x] = src;
+    }
+    __syncthreads();
+    const PipeBox hot = pipe_box(A.box_hot, A.T, W, A.D);
+    pipe_copy_rows(A, s_src, hot.guest + (size_t)(A.par * 2 + 1) * W * A.D, c0);
+}
+
+// the walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended ladder
+__global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int T = A.T, W = A.W, Tl = A.Tl;
+    const bool has_top = A.rung_begin + Tl < T, has_bot = A.rung_begin > 0;
+    const int TE = Tl + (has_top ? 1 : 0);
+    const size_t NE = (size_t)TE * PT_COLS;
+    double* Lc = reinterpret_cast<double*>(smem_raw);            // [TE][PT_COLS]
+    double* lu = Lc + NE;                                        // [TE][PT_COLS] row i = pair (i, i-1), extended indices
+    double* Pc = lu + NE;
+    double* sbeta = Pc + NE;                                     // [TE]
+    int32_t* locc = reinterpret_cast<int32_t*>(sbeta + TE);
+    int32_t* scol = locc + NE;
+    uint32_t* smask = reinterpret_cast<uint32_t*>(scol + NE);    // [PT_COLS][MW]
+    const int MW = (TE + 31) / 32;
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * PT_COLS;
+    const PipeBox me = pipe_box(A.box, T, W, A.D);
+
+    for (int t = tid; t < TE; t += PT_THREADS) sbeta[t] = A.betas[A.rung_begin + t];
+    for (int e = tid; e < (int)NE; e += PT_THREADS) {
+        const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
+        if (c >= W) continue;
+        const int g = A.rung_begin + t;
+        if (t == Tl) {                                           // what the hot neighbour's column c carries
+            scol[e] = c;
+            Lc[e] = sys_load(me.lp_up + (size_t)(A.par * 2) * W + c);
+            Pc[e] = sys_load(me.lp_up + (size_t)(A.par * 2 + 1) * W + c);
+            locc[e] = pipe_guest_loc(A.par, 0, W, c);
+        } else {
+            const int slot = pipe_slot(A, g, c);
+            scol[e] = slot;
+            Lc[e] = A.L[(size_t)t * W + slot];
+            Pc[e] = A.P[(size_t)t * W + slot];
+            locc[e] = A.loc[(size_t)t * W + slot];
+        }
+        if (t >= 1) lu[e] = pipe_logu(A, g, c);
+    }
+    __syncthreads();
+
+    if (tid < PT_COLS && c0 + tid < W) {
+        const int cc = tid;
+        double cL = Lc[(size_t)(TE - 1) * PT_COLS + cc];
+        uint32_t m = 0;
+        for (int i = TE - 1; i >= 1; --i) {
+            const double Lb = Lc[(size_t)(i - 1) * PT_COLS + cc];
+            const double db = sbeta[i - 1] - sbeta[i];                           // tempering.py:518-522
+            const bool sw = db * (cL - Lb) > lu[(size_t)i * PT_COLS + cc];       // :538,:541
+            m |= sw ? (1u << (i & 31)) : 0u;
+            cL = sw ? cL : Lb;
+            if ((i & 31) == 0 || i == 1) {
+                smask[cc * MW + (i >> 5)] = m;
+                m = 0;
+            }
+        }
+        if (TE == 1) smask[cc * MW] = 0;
+    }
+    __syncthreads();
+
+    auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < TE) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
+    PipeBox cold{};
+    if (has_bot) cold = pipe_box(A.box_cold, T, W, A.D);
+    for (int e = tid; e < Tl * PT_COLS; e += PT_THREADS) {
+        const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
+        if (c >= W) continue;
+        int st;
+        if (bit(cc, t)) {
+            st = t - 1;
+        } else {
+            st = t;
+            while (bit(cc, st + 1)) ++st;
+        }
+        const int se = st * PT_COLS + cc;
+        const size_t di = (size_t)t * W + scol[e];
+        A.Lnew[di] = Lc[se];
+        A.Pnew[di] = Pc[se];
+        A.locnew[di] = locc[se];
+        if (t == 0) {                                            // the column leaves my rungs with this walker
+            A.Lcur[c] = Lc[se];
+            A.Pcur[c] = Pc[se];
+            A.botsrc[c] = locc[se];
+            if (has_bot) {
+                sys_store(cold.lp_up + (size_t)(A.par * 2) * W + c, Lc[se]);
+                sys_store(cold.lp_up + (size_t)(A.par * 2 + 1) * W + c, Pc[se]);
+            }
+        }
+    }
+    for (int i = 1 + tid; i < TE; i += PT_THREADS) {
+        unsigned n = 0;
+        for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += bit(cc, i) ? 1u : 0u;
+        A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)] = n;
+    }
+}
+
+// bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, send the rows that move down
+__global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
+    __shared__ int32_t s_src[PIPE_COLS];
+    const int W = A.W, c0 = blockIdx.x * PIPE_COLS;
+    if (threadIdx.x < PIPE_COLS) {
+        const int c = c0 + threadIdx.x;
+        int32_t src = PIPE_NOSEL;
+        if (c < W) {
+            const int g = A.rung_begin;                              // my coldest rung; the pair is (g, g-1)
+            const PipeBox me = pipe_box(A.box, A.T, W, A.D);
+            const int slot = pipe_slot(A, g, c), slot_below = pipe_slot(A, g - 1, c);
+            const double La = A.Lcur[c];
+            const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
+            const double db = A.betas[g - 1] - A.betas[g];
+            if (db * (La - Lb) > pipe_logu(A, g, c)) {
+                src = A.botsrc[c];
+                A.Lnew[slot] = Lb;
+                A.Pnew[slot] = sys_load(me.lp_dn + (size_t)(A.par * 2 + 1) * W + slot_below);
+                A.locnew[slot] = pipe_guest_loc(A.par, 1, W, c);
+            }
+        }
+        s_src[threadIdx.x] = src;
+    }
+    __syncthreads();
+    const PipeBox cold = pipe_box(A.box_cold, A.T, W, A.D);
+    pipe_copy_rows(A, s_src, cold.guest + (size_t)(A.par * 2) * W * A.D, c0);
+}
+
+// swap counts of the pairs I own (my internal pairs + the pair across my top boundary) -> every rank
+__global__ __launch_bounds__(256) void k_pipe_counts(const PipeArgs A, int nblocks) {
+    const int T = A.T, Tl = A.Tl;
+    const bool has_top = A.rung_begin + Tl < T;
+    const int TE = Tl + (has_top ? 1 : 0);
+    extern __shared__ unsigned s_n[];                                // [TE]
+    for (int i = 1 + (int)threadIdx.x; i < TE; i += blockDim.x) {
+        unsigned n = 0;
+        for (int b = 0; b < nblocks; ++b) n += A.swap_part[(size_t)b * (TE - 1) + (i - 1)];
+        s_n[i] = n;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < A.nranks * (TE - 1); e += blockDim.x) {
+        const int q = e / (TE - 1), i = 1 + (e - q * (TE - 1));
+        const PipeBox bx = pipe_box(A.boxes[q], T, A.W, A.D);
+        __hip_atomic_store(bx.counts + (size_t)A.par * T + (A.rung_begin + i - 1), s_n[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if ((int)threadIdx.x < A.nranks) {
+        const PipeBox bx = pipe_box(A.boxes[threadIdx.x], T, A.W, A.D);
+        __hip_atomic_store(bx.flags + PF_CNT0 + A.rank, A.sweep + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -199,5 +199,24 @@ class HipEnsemble:
         kernels order themselves without host synchronisation)."""
         check(self.lib.hens_set_stream(self.ctx, C.c_void_p(int(stream_handle))), self.ctx)
 
+    # -- ladder pipeline (include/hipensemble.h: hens_pipe_*) ------------------------------------------
+    def pipe_init(self, nranks, rank):
+        """Allocate this shard's mailbox; returns its 64-byte HIP IPC handle."""
+        h = (C.c_ubyte * 64)()
+        nbytes = C.c_int64(0)
+        check(self.lib.hens_pipe_init(self.ctx, int(nranks), int(rank), C.cast(h, C.c_void_p), C.byref(nbytes)), self.ctx)
+        self.pipe_bytes = int(nbytes.value)
+        return bytes(h)
+
+    def pipe_connect(self, handles):
+        """handles: the ranks' IPC handles concatenated in rank order (other processes)."""
+        buf = (C.c_ubyte * len(handles)).from_buffer_copy(handles)
+        check(self.lib.hens_pipe_connect(self.ctx, C.cast(buf, C.c_void_p)), self.ctx)
+
+    def pipe_connect_local(self, engines):
+        """All shards live in this process (several contexts on one GPU)."""
+        arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+        check(self.lib.hens_pipe_connect_local(self.ctx, C.cast(arr, C.c_void_p)), self.ctx)
+
     def pt_finish_sharded(self, n_recv):
         check(self.lib.hens_pt_finish_sharded(self.ctx, int(n_recv)), self.ctx)

@@ -174,6 +174,42 @@ class ShardedLadder:
                 self.pt_step(adapt=adapt)
 
 
+class LadderPipeline:
+    """Sharded stepping by neighbour exchange (include/hipensemble.h, "Ladder pipeline").
+
+    Every rank holds a contiguous rung range and a mailbox its two ladder neighbours store into directly
+    (HIP IPC peer mapping: xGMI stores on a multi-GPU node).  ``torch.distributed`` is used ONCE, to
+    exchange the 64-byte IPC handles; after that ``step(n)`` is a single library call per rank and the
+    ranks synchronise through device-side flags only.  The result is bit-identical to one context
+    holding the whole ladder (tests/test_hip_pipeline.py).
+    """
+
+    def __init__(self, engine, rank, nranks, dist=None, group=None):
+        self.e = engine
+        self.rank, self.nranks = int(rank), int(nranks)
+        handle = engine.pipe_init(self.nranks, self.rank)
+        if self.nranks == 1:
+            engine.pipe_connect_local([engine])
+            return
+        if dist is None:
+            raise ValueError("nranks > 1 needs torch.distributed to exchange the mailbox handles")
+        handles = [None] * self.nranks
+        dist.all_gather_object(handles, handle, group=group)
+        engine.pipe_connect(b"".join(handles))
+        dist.barrier(group=group)          # nobody stores into a mailbox that is not mapped everywhere yet
+
+    @staticmethod
+    def connect_local(engines):
+        """Several shards in ONE process (tests): engines in rank order."""
+        for r, e in enumerate(engines):
+            e.pipe_init(len(engines), r)
+        for e in engines:
+            e.pipe_connect_local(engines)
+
+    def step(self, n_iters=1):
+        self.e.step(n_iters)
+
+
 def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     """N-GPU leg of bench.py: weak scaling, one fixed-size ladder shard per GPU."""
     import json

@@ -217,6 +217,25 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
 /* Sharded PT, step 2: scatter n_recv received rows (recv_rows, any order) and swap buffers. */
 int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv);
 
+/* ---- Ladder pipeline: sharded stepping by neighbour exchange (one process per GPU) ------------------
+ * No reference counterpart (the reference has no distributed path; it walks the whole ladder in one
+ * process, tempering.py:598-649).  Each rank keeps a contiguous rung range (rank 0 = coldest rungs)
+ * and a MAILBOX in uncached device memory that its neighbours write into directly (one-sided stores
+ * over xGMI through HIP IPC) followed by a flag; the consumer's stream waits on the flag.  After
+ *   hens_pipe_init           allocate the mailbox, export its IPC handle
+ *   (exchange the handles: torch.distributed all_gather in eryn_amd.ladder)
+ *   hens_pipe_connect        map every rank's mailbox
+ * hens_step(n) on every rank advances the WHOLE ladder by n iterations with device-side draws:
+ * the result is bit-identical to one context holding all the rungs.  A neighbour that stops
+ * answering makes the waiting rank fail with HENS_ERR_STATE after HENS_PIPE_TIMEOUT_S (default 20 s)
+ * instead of hanging the GPU. */
+#define HENS_IPC_HANDLE_BYTES 64
+int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* handle_out /* HENS_IPC_HANDLE_BYTES or NULL */,
+                   int64_t* mailbox_bytes_out);
+int hens_pipe_connect(hens_ctx* ctx, const void* handles /* nranks * HENS_IPC_HANDLE_BYTES, rank order */);
+/* Same, for contexts that live in ONE process (tests; several shards on one GPU): peers[nranks]. */
+int hens_pipe_connect_local(hens_ctx* ctx, hens_ctx* const* peers);
+
 /* Debug: per-workgroup phase timestamps of the stretch kernel (shader-clock ticks, 8 per
  * workgroup: start, A done, barrier, B done, barrier, C done, D done, end).  enable != 0 makes
  * the following stretch launches record; enable == 0 copies the last launch's trace to `out`

@@ -1,0 +1,92 @@
+"""Worker for tests/test_hip_pipeline.py (run as a subprocess so the HIP runtime sees its env).
+
+  local <nranks> <T> <W> <D> <iters> <out.npz>       N shards in this process on one GPU
+  ipc   <rank> <world> <T> <W> <D> <iters> <outdir>  one shard per PROCESS, mailboxes mapped through HIP IPC
+  single <T> <W> <D> <iters> <out.npz>               the unsharded run both are compared with
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401  (before libhipensemble, see eryn_amd/_lib.py)
+
+from eryn_amd.engine import HipEnsemble  # noqa: E402
+from eryn_amd.ladder import LadderPipeline, rung_partition  # noqa: E402
+from eryn_amd.likelihood import GaussianLikelihood  # noqa: E402
+from eryn_amd.moves.tempering import make_ladder  # noqa: E402
+
+SEED = 11
+
+
+def problem(T, W, D):
+    rng = np.random.RandomState(5)
+    mu = rng.uniform(-1, 1, size=D)
+    a = rng.randn(D, D)
+    invcov = a @ a.T / D + np.eye(D)
+    x0 = rng.uniform(-3, 3, size=(T, W, D))
+    return mu, invcov, x0, make_ladder(D, ntemps=T)
+
+
+def make(T, W, D, rng_range=None):
+    mu, invcov, x0, betas = problem(T, W, D)
+    e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -6.0, 6.0, seed=SEED, rung_range=rng_range)
+    r0, r1 = rng_range if rng_range else (0, T)
+    e.upload(x0[r0:r1], betas=betas)
+    e.eval_state()
+    return e
+
+
+def snapshot(e):
+    x, L, P, betas = e.download()
+    c = e.counters()
+    return dict(x=x, L=L, P=P, betas=betas, accepted=c["accepted"], swaps_total=c["swaps_total"],
+                swaps_last=c["swaps_last"])
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "single":
+        T, W, D, iters = map(int, sys.argv[2:6])
+        e = make(T, W, D)
+        for n in (iters // 2, iters - iters // 2):     # two calls: the batch / flush logic at a call boundary
+            e.step(n)
+        np.savez(sys.argv[6], **snapshot(e))
+    elif mode == "local":
+        nranks, T, W, D, iters = map(int, sys.argv[2:7])
+        _, bounds = rung_partition(T, nranks)
+        engs = [make(T, W, D, b) for b in bounds]
+        LadderPipeline.connect_local(engs)
+        for n in (iters // 2, iters - iters // 2):
+            for e in engs:
+                e.step(n)                               # asynchronous: the shards run concurrently on the GPU
+            for e in engs:
+                e.synchronize()
+        snaps = [snapshot(e) for e in engs]
+        out = {k: np.concatenate([s[k] for s in snaps], axis=0) for k in ("x", "L", "P", "accepted")}
+        for k in ("betas", "swaps_total", "swaps_last"):
+            for s in snaps[1:]:
+                assert np.array_equal(s[k], snaps[0][k]), f"{k} differs between ranks"
+            out[k] = snaps[0][k]
+        np.savez(sys.argv[7], **out)
+    elif mode == "ipc":
+        rank, world, T, W, D, iters = map(int, sys.argv[2:8])
+        outdir = sys.argv[8]
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # only to exchange the handles
+        _, bounds = rung_partition(T, world)
+        e = make(T, W, D, bounds[rank])
+        pipe = LadderPipeline(e, rank, world, dist=dist)
+        for n in (iters // 2, iters - iters // 2):
+            pipe.step(n)
+            e.synchronize()
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), **snapshot(e))
+        dist.barrier()
+        e.close()
+        dist.destroy_process_group()
+    print("worker done", mode, flush=True)
+
+
+if __name__ == "__main__":
+    main()

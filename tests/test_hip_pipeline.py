@@ -1,0 +1,85 @@
+"""GPU tests of the ladder pipeline (sharded stepping by one-sided neighbour puts, hens_pipe_*).
+
+The sharded run must be BIT-IDENTICAL to one context holding the whole ladder (which the parity
+tests pin to the oracle): positions, log-likelihood, log-prior, adapted betas, accept and swap counters.
+ * local: N shards as N contexts of one process on one GPU (same kernels, flags and mailboxes);
+ * ipc  : one shard per PROCESS, mailboxes mapped with hipIpcOpenMemHandle exactly as on a multi-GPU
+          node (there the mapping goes over xGMI; a 1-GPU box cannot host two RCCL ranks, but two
+          processes can share the device).
+Workers run as subprocesses with a short pipeline timeout so a protocol bug fails instead of hanging."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "pipeline_worker.py")
+KEYS = ("x", "L", "P", "betas", "accepted", "swaps_total", "swaps_last")
+
+
+def _env(port=None):
+    env = dict(os.environ)
+    env["GPU_MAX_HW_QUEUES"] = "16"          # in-process shards: every stream on its own hardware queue
+    env["HENS_PIPE_TIMEOUT_S"] = "10"
+    env["MASTER_ADDR"] = "127.0.0.1"
+    if port:
+        env["MASTER_PORT"] = str(port)
+    return env
+
+
+def _run(args, **kw):
+    return subprocess.run([sys.executable, WORKER] + [str(a) for a in args], env=_env(), capture_output=True, text=True,
+                          timeout=300, **kw)
+
+
+def _single(tmp_path, T, W, D, iters):
+    out = tmp_path / "single.npz"
+    r = _run(["single", T, W, D, iters, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out)
+
+
+def _compare(ref, got):
+    for k in KEYS:
+        assert np.array_equal(ref[k], got[k]), f"{k} differs from the unsharded run"
+
+
+@pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 128, 8, 6), (4, 8, 256, 32, 8), (2, 6, 70, 5, 7),
+                                                 (4, 4, 64, 16, 6), (1, 4, 128, 8, 5)])
+def test_pipeline_local_matches_single_context(tmp_path, nranks, T, W, D, iters):
+    ref = _single(tmp_path, T, W, D, iters)
+    out = tmp_path / "local.npz"
+    r = _run(["local", nranks, T, W, D, iters, out])
+    assert r.returncode == 0, r.stdout + r.stderr
+    _compare(ref, np.load(out))
+    assert ref["swaps_total"].sum() > 0           # the boundary pairs really exchanged walkers
+
+
+@pytest.mark.parametrize("world,T,W,D,iters", [(2, 4, 256, 32, 8), (3, 6, 128, 8, 6)])
+def test_pipeline_ipc_processes_match_single_context(tmp_path, world, T, W, D, iters):
+    ref = _single(tmp_path, T, W, D, iters)
+    port = 29500 + (os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, WORKER, "ipc", str(r), str(world), str(T), str(W), str(D), str(iters),
+                               str(tmp_path)], env=_env(port), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    snaps = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    got = {k: np.concatenate([s[k] for s in snaps], axis=0) for k in ("x", "L", "P", "accepted")}
+    for k in ("betas", "swaps_total", "swaps_last"):
+        for s in snaps[1:]:
+            assert np.array_equal(s[k], snaps[0][k])
+        got[k] = snaps[0][k]
+    _compare(ref, got)
