@@ -412,6 +412,7 @@ PipeArgs pipe_args(hens_ctx_impl* c) {
     a.flags = c->flags;
     a.iter = c->iter; a.seed = c->cfg.seed;
     a.sweep = c->pipe.sweep;
+    a.budget = c->pipe.budget;
     a.T = c->T; a.W = c->W; a.D = c->D; a.Tl = c->Tl; a.rung_begin = c->cfg.rung_begin; a.idx_bits = c->idx_bits;
     a.par = (int)(c->pipe.sweep & 1u);
     a.nranks = c->pipe.nranks; a.rank = c->pipe.rank;
@@ -431,17 +432,31 @@ void pipe_wait(hens_ctx_impl* c, std::initializer_list<int> which, bool counts, 
     w.target = target;
     hipLaunchKernelGGL(k_pipe_wait, dim3(1), dim3(64), 0, c->stream, w);
 }
-void pipe_flag(hens_ctx_impl* c, char* peer_box, int which, uint32_t value) {
-    const PipeBox b = pipe_box(peer_box, c->T, c->W, c->D);
-    hipLaunchKernelGGL(k_pipe_flag, dim3(1), dim3(1), 0, c->stream, b.flags + which, value);
+// raise up to two flags in peers' mailboxes once everything queued before has completed
+void pipe_flag(hens_ctx_impl* c, char* box0, int which0, char* box1, int which1, uint32_t value) {
+    unsigned* f0 = box0 ? pipe_box(box0, c->T, c->W, c->D).flags + which0 : nullptr;
+    unsigned* f1 = box1 ? pipe_box(box1, c->T, c->W, c->D).flags + which1 : nullptr;
+    if (!f0 && !f1) return;
+    hipLaunchKernelGGL(k_pipe_flag, dim3(1), dim3(2), 0, c->stream, f0, f1, value);
 }
 
 // before the stretch move of sweep s > 0: the rows that arrived in sweep s-1 and (if a ladder adaptation is
-// pending) every rank's swap counts must be here
+// pending) every rank's swap counts must be here.  The fast stretch kernel waits in its own prologue
+// (wmask); other row widths get a wait kernel.
+unsigned long long pipe_prewait_mask(const hens_ctx_impl* c) {
+    if (!pipe_active(c) || c->pipe.sweep == 0) return 0ull;
+    unsigned long long m = 0;
+    if (pipe_has_top(c)) m |= 1ull << PF_ROWS_TOP;
+    if (pipe_has_bot(c)) m |= 1ull << PF_ROWS_BOT;
+    if (c->adapt_pending && c->adapt_src != nullptr && c->pipe.nranks > 1)
+        for (int q = 0; q < c->pipe.nranks; ++q) m |= 1ull << (PF_CNT0 + q);
+    return m;
+}
 void pipe_prewait(hens_ctx_impl* c) {
-    if (c->pipe.sweep == 0) return;
-    const bool top = pipe_has_top(c), bot = pipe_has_bot(c);
-    const bool cnt = c->adapt_pending && c->adapt_src != nullptr;
+    const unsigned long long m = pipe_prewait_mask(c);
+    if (!m || is_fast_dim(c->D)) return;
+    const bool cnt = (m >> PF_CNT0) != 0;
+    const bool top = (m >> PF_ROWS_TOP) & 1, bot = (m >> PF_ROWS_BOT) & 1;
     if (top && bot) pipe_wait(c, {PF_ROWS_TOP, PF_ROWS_BOT}, cnt, c->pipe.sweep);
     else if (top) pipe_wait(c, {PF_ROWS_TOP}, cnt, c->pipe.sweep);
     else if (bot) pipe_wait(c, {PF_ROWS_BOT}, cnt, c->pipe.sweep);
@@ -453,25 +468,15 @@ void pipe_sweep(hens_ctx_impl* c) {
     const bool top = pipe_has_top(c), bot = pipe_has_bot(c);
     const PipeArgs a = pipe_args(c);
     const uint32_t done = c->pipe.sweep + 1;
-    const int W = c->W;
-    const int bgrid = (W + PIPE_COLS - 1) / PIPE_COLS;
     const int TE = c->Tl + (top ? 1 : 0);
-    if (top) {
-        hipLaunchKernelGGL(k_pipe_pub, dim3(grid_for(2 * (int64_t)W)), dim3(256), 0, c->stream, a);
-        pipe_flag(c, a.box_hot, PF_LDN, done);
-        pipe_wait(c, {PF_LUP}, false, done);
-        hipLaunchKernelGGL(k_pipe_top, dim3(bgrid), dim3(256), 0, c->stream, a);
-        pipe_flag(c, a.box_hot, PF_ROWS_BOT, done);
-    }
-    hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);
+    if (top) hipLaunchKernelGGL(k_pipe_pub, dim3(1), dim3(1024), 0, c->stream, a);            // raises the neighbour's PF_LDN
+    hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);   // waits for PF_LUP
+    pipe_flag(c, bot ? a.box_cold : nullptr, PF_LUP, top ? a.box_hot : nullptr, PF_ROWS_BOT, done);
+    hipLaunchKernelGGL(k_pipe_counts, dim3(1), dim3(1024), (size_t)(TE + 1) * 4, c->stream, a, pt_blocks(c));
     if (bot) {
-        pipe_flag(c, a.box_cold, PF_LUP, done);
-        if (top) pipe_wait(c, {PF_LDN, PF_ROWS_TOP}, false, done);   // a walker may fall through all my rungs in one sweep
-        else pipe_wait(c, {PF_LDN}, false, done);
-        hipLaunchKernelGGL(k_pipe_bottom, dim3(bgrid), dim3(256), 0, c->stream, a);
-        pipe_flag(c, a.box_cold, PF_ROWS_TOP, done);
+        hipLaunchKernelGGL(k_pipe_bottom, dim3((c->W + PIPE_COLS - 1) / PIPE_COLS), dim3(256), 0, c->stream, a);   // waits for PF_LDN (+ PF_ROWS_TOP)
+        pipe_flag(c, a.box_cold, PF_ROWS_TOP, nullptr, 0, done);
     }
-    hipLaunchKernelGGL(k_pipe_counts, dim3(1), dim3(256), (size_t)(TE + 1) * 4, c->stream, a, pt_blocks(c));
     const PipeBox me = pipe_box(c->pipe.box, c->T, c->W, c->D);
     c->adapt_src = me.counts + (size_t)a.par * c->T;
     c->adapt_nblocks = 1;
@@ -483,7 +488,7 @@ void pipe_sweep(hens_ctx_impl* c) {
 
 // the pending adaptation needs every rank's counts of the last sweep
 void pipe_flush_adapt(hens_ctx_impl* c) {
-    if (c->adapt_pending && c->adapt_src) pipe_wait(c, {}, true, c->pipe.sweep);
+    if (c->adapt_pending && c->adapt_src && c->pipe.nranks > 1) pipe_wait(c, {}, true, c->pipe.sweep);
     flush_adapt(c);
 }
 
@@ -512,6 +517,14 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
         a.dr = draws_at(c->db[which], (size_t)ib * Tl * W);
         a.split = split;
         a.home_off = c->parity * Tl * W;
+        if (split == 0 && is_fast_dim(c->D)) {
+            a.wmask = pipe_prewait_mask(c);
+            if (a.wmask) {
+                a.wflags = pipe_box(c->pipe.box, c->T, c->W, c->D).flags;
+                a.wtarget = c->pipe.sweep;
+                a.wbudget = c->pipe.budget;
+            }
+        }
         if (split == 0 && c->adapt_pending) {
             if (can_fold_adapt(c)) {
                 // the previous cascade's ladder adaptation rides in this launch: every workgroup reads
@@ -524,7 +537,8 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
                 c->adapt_src = nullptr;
                 c->bcur ^= 1;
             } else {
-                flush_adapt(c);
+                if (pipe_active(c)) pipe_flush_adapt(c);      // the counts of every rank first
+                else flush_adapt(c);
                 a.betas = c->betas[c->bcur];
             }
         }

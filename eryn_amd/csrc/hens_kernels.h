@@ -28,6 +28,8 @@ constexpr int TILE = 64;                    // walkers per workgroup = one wavef
 constexpr unsigned FLAG_NONFINITE_X = 1u;   // inf/NaN coordinate seen (ensemble.py:1258-1262)
 constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-281)
 
+constexpr unsigned FLAG_PIPE_TIMEOUT = 4u; // ladder pipeline: a neighbour's flag did not arrive in time
+
 enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2, LIKE_HOST = 3 };
 
 // ---------------------------------------------------------------------------------------------
@@ -84,6 +86,19 @@ enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 
                   PURPOSE_PTU = 10 };
 
 // The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
+// a workgroup's thread 0 spins until flag >= target (or the budget runs out: a peer died - fail the run
+// instead of hanging the GPU); callers follow with __syncthreads()
+__device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, long long budget, unsigned* err) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > budget) {
+            atomicOr(err, FLAG_PIPE_TIMEOUT);
+            return;
+        }
+    }
+}
+
 // loc >= 0: a row of the pool.  loc < 0: guest row ~loc of this rank's mailbox (a walker that arrived
 // through the ladder pipeline during the last PT sweep); `guest_delta` = (guest - pool) in doubles.
 __device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_delta) {
@@ -146,6 +161,11 @@ struct StretchArgs {
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
     int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
     int64_t guest_delta;       // see row_off (0 when there is no pipeline)
+    // ladder pipeline: before touching the state, wait until the mailbox flags selected by wmask reach wtarget
+    const unsigned* wflags;
+    unsigned long long wmask;
+    long long wbudget;
+    uint32_t wtarget;
     AdaptArgs ad;
 };
 
@@ -482,6 +502,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     HENS_TRACE(0);
+    if (!EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
+        if (wv == 0 && ((A.wmask >> lane) & 1ull)) pipe_spin(A.wflags + lane, A.wtarget, A.wbudget, A.flags);
+        __syncthreads();
+    }
 
     // ---- phase A (wave 0): indices and draws -------------------------------------------------------
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
@@ -1372,7 +1396,6 @@ __global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ l
 // ---------------------------------------------------------------------------------------------
 enum { PF_LUP = 0, PF_LDN = 1, PF_ROWS_TOP = 2, PF_ROWS_BOT = 3, PF_CNT0 = 8, PIPE_FLAG_WORDS = 64 };
 constexpr int PIPE_MAX_RANKS = PIPE_FLAG_WORDS - PF_CNT0;
-constexpr unsigned FLAG_PIPE_TIMEOUT = 4u;
 
 struct PipeBox {
     unsigned* flags;       // [PIPE_FLAG_WORDS] sweep counters raised by the peers
@@ -1418,6 +1441,7 @@ struct PipeArgs {
     unsigned* flags;              // context error flags
     uint64_t iter, seed;
     uint32_t sweep;               // pipeline sweep counter (flags carry sweep + 1)
+    long long budget;             // wall-clock ticks a flag wait may take
     int32_t T, W, D, Tl, rung_begin, idx_bits, par, nranks, rank;
 };
 
@@ -1433,6 +1457,15 @@ __device__ __forceinline__ double pipe_logu(const PipeArgs& A, int i, int c) {
     return log(u01(d.x, d.y));                                       // tempering.py:535
 }
 
+// Flag discipline: everything a peer reads is stored with system-scope write-through stores (sys_store),
+// so raising a flag only needs those stores COMPLETE (s_waitcnt vmcnt(0)), not an L2 write-back: the
+// compiler's system-scope release would write back the whole L2 - megabytes of dirty walker rows that
+// no peer ever reads - and costs ~5 us per flag.
+__device__ __forceinline__ void pipe_raise(unsigned* f, uint32_t v) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct PipeWaitArgs {
     const unsigned* p[4];
     const unsigned* cnt_flags;    // my flags + PF_CNT0 (or nullptr): wait for every rank's counts
@@ -1446,70 +1479,36 @@ __global__ void k_pipe_wait(const PipeWaitArgs A) {
     const unsigned* f = nullptr;
     if (i < A.n) f = A.p[i];
     else if (A.cnt_flags && i - A.n < A.nranks) f = A.cnt_flags + (i - A.n);
-    if (!f) return;
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.target) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > A.budget) {            // a peer died: fail the run instead of hanging the GPU
-            atomicOr(A.err, FLAG_PIPE_TIMEOUT);
-            return;
-        }
-    }
+    if (f) pipe_spin(f, A.target, A.budget, A.err);
 }
-__global__ void k_pipe_flag(unsigned* f, uint32_t v) {
-    __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ void k_pipe_flag(unsigned* f0, unsigned* f1, uint32_t v) {
+    unsigned* f = threadIdx.x == 0 ? f0 : f1;
+    if (f) pipe_raise(f, v);
 }
 
-// my hottest rung after the stretch move -> hot neighbour
-__global__ void k_pipe_pub(const PipeArgs A) {
+// my hottest rung after the stretch move -> hot neighbour, flag included (one workgroup)
+__global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
     const PipeBox hot = pipe_box(A.box_hot, A.T, A.W, A.D);
     const int W = A.W;
     const size_t base = (size_t)(A.Tl - 1) * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * W; i += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < 2 * W; i += blockDim.x) {
         const int w = i < W ? i : i - W;
         sys_store(hot.lp_dn + (size_t)(A.par * 2 + (i < W ? 0 : 1)) * W + w, i < W ? A.L[base + w] : A.P[base + w]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) pipe_raise(hot.flags + PF_LDN, A.sweep + 1);
 }
 
-constexpr int PIPE_COLS = 64;       // columns per workgroup of the boundary kernels
+constexpr int PIPE_COLS = 64;       // columns per workgroup of the bottom-boundary kernel
 constexpr int32_t PIPE_NOSEL = INT32_MIN;
 
-__device__ __forceinline__ void pipe_copy_rows(const PipeArgs& A, const int32_t* s_src, double* dst_rows, int c0) {
-    const int D = A.D;
-    for (int idx = threadIdx.x; idx < PIPE_COLS * D; idx += blockDim.x) {
-        const int col = idx / D, d = idx - col * D;
-        const int32_t src = s_src[col];
-        if (src != PIPE_NOSEL) sys_store(dst_rows + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
-    }
-}
-
-// top boundary, cold side: decide pair (e, e-1) and send the rows that move up
-__global__ __launch_bounds__(256) void k_pipe_top(const PipeArgs A) {
-    __shared__ int32_t s_src[PIPE_COLS];
-    const int W = A.W, c0 = blockIdx.x * PIPE_COLS;
-    if (threadIdx.x < PIPE_COLS) {
-        const int c = c0 + threadIdx.x;
-        int32_t src = PIPE_NOSEL;
-        if (c < W) {
-            const int tl = A.Tl - 1, g = A.rung_begin + tl;          // my hottest rung; the pair is (g+1, g)
-            const PipeBox me = pipe_box(A.box, A.T, W, A.D);
-            const int slot = pipe_slot(A, g, c);
-            const double La = sys_load(me.lp_up + (size_t)(A.par * 2) * W + c);
-            const double Lb = A.L[(size_t)tl * W + slot];
-            const double db = A.betas[g] - A.betas[g + 1];           // tempering.py:518-522
-            if (db * (La - Lb) > pipe_logu(A, g + 1, c)) src = A.loc[(size_t)tl * W + slot];   // :538,:541
-        }
-        s_src[threadIdx.x] = src;
-    }
-    __syncthreads();
-    const PipeBox hot = pipe_box(A.box_hot, A.T, W, A.D);
-    pipe_copy_rows(A, s_src, hot.guest + (size_t)(A.par * 2 + 1) * W * A.D, c0);
-}
-
-// the walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended ladder
+// The walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended
+// ladder.  The pair across my top boundary is the first step of every column, so the rows that move UP
+// leave from here too (waves 1.. copy them into the hot neighbour's guest area while wave 0 walks).
 __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int T = A.T, W = A.W, Tl = A.Tl;
+    const int T = A.T, W = A.W, Tl = A.Tl, D = A.D;
     const bool has_top = A.rung_begin + Tl < T, has_bot = A.rung_begin > 0;
     const int TE = Tl + (has_top ? 1 : 0);
     const size_t NE = (size_t)TE * PT_COLS;
@@ -1523,14 +1522,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     const int MW = (TE + 31) / 32;
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
-    const PipeBox me = pipe_box(A.box, T, W, A.D);
+    const PipeBox me = pipe_box(A.box, T, W, D);
 
+    if (has_top) {                                               // what the hot neighbour's columns carry must be here
+        if (tid == 0) pipe_spin(me.flags + PF_LUP, A.sweep + 1, A.budget, A.flags);
+        __syncthreads();
+    }
     for (int t = tid; t < TE; t += PT_THREADS) sbeta[t] = A.betas[A.rung_begin + t];
     for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
         const int g = A.rung_begin + t;
-        if (t == Tl) {                                           // what the hot neighbour's column c carries
+        if (t == Tl) {
             scol[e] = c;
             Lc[e] = sys_load(me.lp_up + (size_t)(A.par * 2) * W + c);
             Pc[e] = sys_load(me.lp_up + (size_t)(A.par * 2 + 1) * W + c);
@@ -1546,28 +1549,53 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     }
     __syncthreads();
 
-    if (tid < PT_COLS && c0 + tid < W) {
-        const int cc = tid;
-        double cL = Lc[(size_t)(TE - 1) * PT_COLS + cc];
-        uint32_t m = 0;
-        for (int i = TE - 1; i >= 1; --i) {
-            const double Lb = Lc[(size_t)(i - 1) * PT_COLS + cc];
-            const double db = sbeta[i - 1] - sbeta[i];                           // tempering.py:518-522
-            const bool sw = db * (cL - Lb) > lu[(size_t)i * PT_COLS + cc];       // :538,:541
-            m |= sw ? (1u << (i & 31)) : 0u;
-            cL = sw ? cL : Lb;
-            if ((i & 31) == 0 || i == 1) {
-                smask[cc * MW + (i >> 5)] = m;
-                m = 0;
+    if (tid < PT_COLS) {
+        if (c0 + tid < W) {
+            const int cc = tid;
+            double cL = Lc[(size_t)(TE - 1) * PT_COLS + cc];
+            uint32_t m = 0;
+            if (TE == 1) smask[cc * MW] = 0;
+            for (int i0 = TE - 1; i0 >= 1; i0 -= 8) {                  // 8 steps per LDS round trip
+                double Lb[8], lv[8], db[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = (i0 - q >= 1) ? i0 - q : 1;
+                    Lb[q] = Lc[(size_t)(i - 1) * PT_COLS + cc];
+                    lv[q] = lu[(size_t)i * PT_COLS + cc];
+                    db[q] = sbeta[i - 1] - sbeta[i];                   // tempering.py:518-522
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = i0 - q;
+                    if (i >= 1) {
+                        const bool sw = db[q] * (cL - Lb[q]) > lv[q];  // :538,:541
+                        m |= sw ? (1u << (i & 31)) : 0u;
+                        cL = sw ? cL : Lb[q];
+                        if ((i & 31) == 0 || i == 1) {
+                            smask[cc * MW + (i >> 5)] = m;
+                            m = 0;
+                        }
+                    }
+                }
             }
         }
-        if (TE == 1) smask[cc * MW] = 0;
+    } else if (has_top && tid >= 64) {                           // rows that move up across my top boundary
+        const double db = sbeta[Tl - 1] - sbeta[Tl];
+        const PipeBox hot = pipe_box(A.box_hot, T, W, D);
+        double* dst = hot.guest + (size_t)(A.par * 2 + 1) * W * D;
+        for (int idx = tid - 64; idx < PT_COLS * D; idx += PT_THREADS - 64) {
+            const int cc = idx / D, d = idx - cc * D;
+            if (c0 + cc >= W) continue;
+            const int eh = Tl * PT_COLS + cc, el = (Tl - 1) * PT_COLS + cc;
+            if (db * (Lc[eh] - Lc[el]) > lu[eh])                       // the column's first step, recomputed
+                sys_store(dst + (size_t)(c0 + cc) * D + d, A.pool[row_off(locc[el], D, A.guest_delta) + d]);
+        }
     }
     __syncthreads();
 
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < TE) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
     PipeBox cold{};
-    if (has_bot) cold = pipe_box(A.box_cold, T, W, A.D);
+    if (has_bot) cold = pipe_box(A.box_cold, T, W, D);
     for (int e = tid; e < Tl * PT_COLS; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
@@ -1603,13 +1631,19 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
 // bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, send the rows that move down
 __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     __shared__ int32_t s_src[PIPE_COLS];
-    const int W = A.W, c0 = blockIdx.x * PIPE_COLS;
+    const int W = A.W, D = A.D, c0 = blockIdx.x * PIPE_COLS;
+    const PipeBox me = pipe_box(A.box, A.T, W, D);
+    const bool has_top = A.rung_begin + A.Tl < A.T;
+    // the cold neighbour's rung after ITS stretch move; a walker may fall through all my rungs in one sweep,
+    // so the rows from above must have landed too
+    if (threadIdx.x == 0) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags);
+    if (threadIdx.x == 64 && has_top) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags);
+    __syncthreads();
     if (threadIdx.x < PIPE_COLS) {
         const int c = c0 + threadIdx.x;
         int32_t src = PIPE_NOSEL;
         if (c < W) {
             const int g = A.rung_begin;                              // my coldest rung; the pair is (g, g-1)
-            const PipeBox me = pipe_box(A.box, A.T, W, A.D);
             const int slot = pipe_slot(A, g, c), slot_below = pipe_slot(A, g - 1, c);
             const double La = A.Lcur[c];
             const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
@@ -1624,32 +1658,48 @@ __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
         s_src[threadIdx.x] = src;
     }
     __syncthreads();
-    const PipeBox cold = pipe_box(A.box_cold, A.T, W, A.D);
-    pipe_copy_rows(A, s_src, cold.guest + (size_t)(A.par * 2) * W * A.D, c0);
+    const PipeBox cold = pipe_box(A.box_cold, A.T, W, D);
+    double* dst = cold.guest + (size_t)(A.par * 2) * W * D;
+    for (int idx = threadIdx.x; idx < PIPE_COLS * D; idx += blockDim.x) {
+        const int col = idx / D, d = idx - col * D;
+        const int32_t src = s_src[col];
+        if (src != PIPE_NOSEL) sys_store(dst + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
+    }
 }
 
 // swap counts of the pairs I own (my internal pairs + the pair across my top boundary) -> every rank
-__global__ __launch_bounds__(256) void k_pipe_counts(const PipeArgs A, int nblocks) {
+__global__ __launch_bounds__(1024) void k_pipe_counts(const PipeArgs A, int nblocks) {
     const int T = A.T, Tl = A.Tl;
     const bool has_top = A.rung_begin + Tl < T;
-    const int TE = Tl + (has_top ? 1 : 0);
+    const int TE = Tl + (has_top ? 1 : 0), NP = TE - 1;
     extern __shared__ unsigned s_n[];                                // [TE]
-    for (int i = 1 + (int)threadIdx.x; i < TE; i += blockDim.x) {
-        unsigned n = 0;
-        for (int b = 0; b < nblocks; ++b) n += A.swap_part[(size_t)b * (TE - 1) + (i - 1)];
-        s_n[i] = n;
+    for (int i = threadIdx.x; i < TE; i += blockDim.x) s_n[i] = 0;
+    __syncthreads();
+    const int total = nblocks * NP;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * blockDim.x) {
+        unsigned v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * blockDim.x;
+            v[q] = e < total ? A.swap_part[e] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * blockDim.x;
+            if (v[q]) atomicAdd(&s_n[e % NP], v[q]);
+        }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < A.nranks * (TE - 1); e += blockDim.x) {
-        const int q = e / (TE - 1), i = 1 + (e - q * (TE - 1));
+    for (int e = threadIdx.x; e < A.nranks * NP; e += blockDim.x) {
+        const int q = e / NP, j = e - q * NP;                        // ext pair j+1 = global pair (rung_begin+j+1, rung_begin+j)
         const PipeBox bx = pipe_box(A.boxes[q], T, A.W, A.D);
-        __hip_atomic_store(bx.counts + (size_t)A.par * T + (A.rung_begin + i - 1), s_n[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(bx.counts + (size_t)A.par * T + (A.rung_begin + j), s_n[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if ((int)threadIdx.x < A.nranks) {
         const PipeBox bx = pipe_box(A.boxes[threadIdx.x], T, A.W, A.D);
-        __hip_atomic_store(bx.flags + PF_CNT0 + A.rank, A.sweep + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        pipe_raise(bx.flags + PF_CNT0 + A.rank, A.sweep + 1);
     }
 }
 

@@ -225,12 +225,18 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force = bool(int(os.environ.get("HENS_FORCE_COLLECTIVES", "0")))
+    # "nccl" = RCCL.  HENS_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): used to
+    # exercise this exact code path on a single-GPU box.
+    backend = os.environ.get("HENS_DIST_BACKEND", "nccl")
     if (world > 1 or force) and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     T, W, D = args.ntemps, args.nwalkers, args.ndim
     _, bounds = rung_partition(T, world)
     r0, r1 = bounds[rank]
@@ -240,15 +246,37 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
     eng.upload(x0, betas=make_ladder(D, ntemps=T))
     eng.eval_state()
-    lad = ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank, nranks=world)
-    lad.step(args.warmup)
+    # Stepping: the ladder pipeline (one-sided neighbour puts over xGMI) unless HENS_SHARD_MODE=collective or
+    # the mailboxes cannot be mapped on this node, in which case every rank falls back to the RCCL
+    # all-gather / all-to-all orchestration.
+    mode = os.environ.get("HENS_SHARD_MODE", "pipeline")
+    stepper = None
+    if mode == "pipeline" and not force:
+        ok = 1
+        try:
+            stepper = LadderPipeline(eng, rank, world, dist=dist if world > 1 else None)
+        except Exception as exc:                      # noqa: BLE001 - any failure means "use the collective path"
+            print(f"[rank {rank}] ladder pipeline unavailable ({exc}); falling back to RCCL collectives", flush=True)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            stepper = None
+    transport = "xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline)"
+    if stepper is None:
+        stepper = ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank,
+                                nranks=world)
+        transport = "RCCL all-gather(logL) + all-to-all(rows)"
+    stepper.step(args.warmup)
     eng.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    lad.step(args.steps)
+    stepper.step(args.steps)
     eng.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -272,7 +300,7 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"ladder sharded over {world} GPU(s): ntemps={T} ({T // world} rungs/GPU), nwalkers={W}, "
                                    f"ndim={D} dense-covariance Gaussian, StretchMove(a=2)+adaptive PT, Philox RNG, "
-                                   f"RCCL all-gather(logL) + all-to-all(rows)",
+                                   f"{transport}",
                        "ntemps": T, "nwalkers": W, "ndim": D, "parallelism": f"ladder-shard x{world}",
                        "swap_fraction": f_sw},
             "roofline": {"bound": "hbm", "kernel": "whole path (per GPU)", "achieved": whole / world, "peak": hbm_peak,
