@@ -719,6 +719,7 @@ int hens_synchronize(hens_ctx* ctx) {
     if (!c) return fail(nullptr, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (pipe_active(c)) return check_flags(c, false);     // a neighbour that never answered surfaces here
     return HENS_OK;
 }
 

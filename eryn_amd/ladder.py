@@ -241,11 +241,16 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     _, bounds = rung_partition(T, world)
     r0, r1 = bounds[rank]
     mu, invcov = gaussian_problem(D)
-    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=(r0, r1),
-                      device_id=local_rank)
     x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
-    eng.upload(x0, betas=make_ladder(D, ntemps=T))
-    eng.eval_state()
+
+    def make_engine():
+        e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=(r0, r1),
+                        device_id=local_rank)
+        e.upload(x0, betas=make_ladder(D, ntemps=T))
+        e.eval_state()
+        return e
+
+    eng = make_engine()
     # Stepping: the ladder pipeline (one-sided neighbour puts over xGMI) unless HENS_SHARD_MODE=collective or
     # the mailboxes cannot be mapped on this node, in which case every rank falls back to the RCCL
     # all-gather / all-to-all orchestration.
@@ -265,24 +270,47 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
         if not ok:
             stepper = None
     transport = "xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline)"
+    def make_collective(eng):
+        return ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank,
+                             nranks=world)
+
+    def timed_run(stp, eng):
+        stp.step(args.warmup)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stp.step(args.steps)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
     if stepper is None:
-        stepper = ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank,
-                                nranks=world)
+        stepper = make_collective(eng)
         transport = "RCCL all-gather(logL) + all-to-all(rows)"
-    stepper.step(args.warmup)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stepper.step(args.steps)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        dt = timed_run(stepper, eng)
+    else:
+        ok, dt = 1, 0.0
+        try:
+            dt = timed_run(stepper, eng)
+        except RuntimeError as exc:                   # a flag wait timed out: a neighbour never answered
+            print(f"[rank {rank}] ladder pipeline failed ({exc}); re-running on RCCL collectives", flush=True)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            eng.close()
+            eng = make_engine()                       # a fresh context: no mailbox, no pending flags
+            stepper = make_collective(eng)
+            transport = "RCCL all-gather(logL) + all-to-all(rows) (pipeline failed on this node)"
+            dt = timed_run(stepper, eng)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

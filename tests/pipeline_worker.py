@@ -3,6 +3,7 @@
   local <nranks> <T> <W> <D> <iters> <out.npz>       N shards in this process on one GPU
   ipc   <rank> <world> <T> <W> <D> <iters> <outdir>  one shard per PROCESS, mailboxes mapped through HIP IPC
   single <T> <W> <D> <iters> <out.npz>               the unsharded run both are compared with
+  timeout                                            rank 1 never steps: rank 0 must raise, not hang
 """
 import os
 import sys
@@ -85,6 +86,18 @@ def main():
         dist.barrier()
         e.close()
         dist.destroy_process_group()
+    elif mode == "timeout":
+        # a neighbour that never steps: the waiting rank must fail with an error, not hang the GPU
+        _, bounds = rung_partition(4, 2)
+        engs = [make(4, 128, 8, b) for b in bounds]
+        LadderPipeline.connect_local(engs)
+        engs[0].step(2)
+        try:
+            engs[0].synchronize()
+        except RuntimeError as exc:
+            print("raised:", exc, flush=True)
+        else:
+            raise SystemExit("no error although rank 1 never answered")
     print("worker done", mode, flush=True)
 
 

@@ -83,3 +83,11 @@ def test_pipeline_ipc_processes_match_single_context(tmp_path, world, T, W, D, i
             assert np.array_equal(s[k], snaps[0][k])
         got[k] = snaps[0][k]
     _compare(ref, got)
+
+
+def test_pipeline_dead_neighbour_raises_instead_of_hanging():
+    env = _env()
+    env["HENS_PIPE_TIMEOUT_S"] = "0.5"
+    r = subprocess.run([sys.executable, WORKER, "timeout"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "did not answer" in r.stdout
