@@ -1,20 +1,24 @@
 """Temperature-ladder sharding across the GPUs of one node (one process per GPU).
 
-Rank g owns the contiguous rungs [g*Tl, (g+1)*Tl).  Per iteration:
+Rank g owns the contiguous rungs [g*Tl, (g+1)*Tl).  The stretch move needs no communication
+(complement walkers are drawn inside a rung, red_blue.py:183-193).  Two ways to run the PT sweep
+(tempering.py:484-561, 598-649) across ranks:
 
-  1. stretch move on the local rungs                     no communication
-     (complement walkers are drawn inside a rung, red_blue.py:183-193)
-  2. all-gather of the log-likelihoods  [Tl, W] -> [T, W]            RCCL all_gather
-  3. EVERY rank replays the whole hot->cold swap cascade (tempering.py:484-561) from the
-     gathered ladder.  In the column form used by the HIP kernel the T-1 sequential pairs
-     collapse into one parallel kernel, so the redundant replay is cheaper than a chain of
-     T/Tl dependent neighbour hand-offs; all ranks reach identical decisions and identical
-     adapted betas without a further collective.
-  4. walker rows that change rank travel as [dest id | x | logp] records    RCCL all_to_all
-  5. received rows are scattered into free pool slots.
+:class:`LadderPipeline` (default) - neighbour exchange by one-sided puts.  Every rank has a mailbox in
+uncached device memory that its two ladder neighbours store into directly (HIP IPC mapping = xGMI peer
+stores), followed by a flag the consumer kernel spins on.  ``torch.distributed`` only all-gathers the
+IPC handles once; after that ``step(n)`` is one library call per rank.  Philox draws only.  DESIGN 6.1.
 
-The communication layer is ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).  The compute engine is injected: the product uses
+:class:`ShardedLadder` (fallback; also the teacher-forced path) - RCCL collectives per iteration:
+
+  1. all-gather of the log-likelihoods  [Tl, W] -> [T, W]            RCCL all_gather
+  2. EVERY rank replays the whole hot->cold cascade from the gathered ladder (one parallel kernel in
+     column form); all ranks reach identical decisions and identical adapted betas
+  3. walker rows that change rank travel as [dest id | x | logp] records    RCCL all_to_all
+  4. received rows are scattered into free pool slots.
+
+The communication layer of the fallback is ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).  Its compute engine is injected: the product uses
 :class:`HipShardEngine`; the CPU tests drive the same orchestration with a NumPy stand-in.
 """
 import numpy as np
