@@ -672,7 +672,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     {   // kernels that may need > 64 KiB of dynamic LDS
         const size_t plan_lds = plan_lds_bytes(c);
         if (plan_lds > 160 * 1024) {
-            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS permutation sort (max 16384)", c->W);
+            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS split plan (5 bytes of LDS per walker: max %d)", c->W, (160 * 1024 - 16) / 5);
             g_last_error = c->err; hens_destroy(h); return HENS_ERR_UNSUPPORTED;
         }
         TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds));
@@ -760,13 +760,29 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
     if (c->cfg.likelihood_kind == HENS_LIKE_GAUSS_DENSE && c->D % 2 == 0) {
         // packed symmetric rows for sym_quad: pair p = rows (p, D-1-p), each from its diagonal rightwards,
         // off-diagonal entries A_ik + A_ki (so a non-symmetric input gives the same quadratic form)
-        const int D = c->D, stride = D + 2;
-        sym.assign((size_t)(D / 2) * stride, 0.0);
-        for (int p = 0; p < D / 2; ++p) {
-            double* row = sym.data() + (size_t)p * stride;
-            int o = 0;
-            for (int i : {p, D - 1 - p})
-                for (int k = i; k < D; ++k) row[o++] = (k == i) ? prec[(size_t)i * D + i] : prec[(size_t)i * D + k] + prec[(size_t)k * D + i];
+        const int D = c->D;
+        auto S = [&](int i, int k) { return (k == i) ? prec[(size_t)i * D + i] : prec[(size_t)i * D + k] + prec[(size_t)k * D + i]; };
+        // one H x H diagonal block starting at row/column `base`, in sym_quad's pair layout
+        auto pack_block = [&](int base, int H, double* out) {
+            const int stride = H + 2;
+            for (int p = 0; p < H / 2; ++p) {
+                double* row = out + (size_t)p * stride;
+                int o = 0;
+                for (int i : {p, H - 1 - p})
+                    for (int k = i; k < H; ++k) row[o++] = S(base + i, base + k);
+            }
+        };
+        if (D == 64) {
+            // blocked form (see k_stretch_fast phase C, DT = 64): [lo-lo block][hi-hi block][32 x 32 cross block]
+            constexpr int H = 32, BLK = (H / 2) * (H + 2);
+            sym.assign((size_t)2 * BLK + (size_t)H * H, 0.0);
+            pack_block(0, H, sym.data());
+            pack_block(H, H, sym.data() + BLK);
+            for (int i = 0; i < H; ++i)
+                for (int k = 0; k < H; ++k) sym[(size_t)2 * BLK + (size_t)i * H + k] = S(i, H + k);
+        } else {
+            sym.assign((size_t)(D / 2) * (D + 2), 0.0);
+            pack_block(0, D, sym.data());
         }
         HIPCHK(c, hipMemcpyAsync(c->prec_sym, sym.data(), sym.size() * 8, hipMemcpyHostToDevice, c->stream));
     }

@@ -10,7 +10,7 @@ from eryn_amd.engine import HipEnsemble
 from eryn_amd.likelihood import GaussianLikelihood
 from eryn_amd import _lib
 
-T, W, D = 16, 4096, 32
+T, W, D = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (16, 4096, 32)))
 mu, invcov, cov = problem(D)
 eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024)
 eng.upload(np.random.RandomState(1).randn(T, W, D), betas=ladder(D, T))
