@@ -233,6 +233,87 @@ def stretch_split(x, L, P, betas, labels, split, rint, u_zz, u_acc, a, lo, hi,
 
 
 # --------------------------------------------------------------------------
+# Metropolis-Hastings moves             moves/mh.py, gaussian.py
+# --------------------------------------------------------------------------
+
+class GaussianProposal:
+    """``GaussianMove``'s proposal function for one branch (gaussian.py:27-66, 197-270).
+
+    ``cov`` scalar -> isotropic, 2-D -> full covariance (``rng.multivariate_normal``); a 1-D covariance
+    cannot be constructed in the reference at this numpy (gaussian.py:144 raises) and is not restated.
+    ``draw_step`` consumes R exactly like ``proposal_fn(coords[inds_here], random)`` and returns the
+    step ``q - x0`` (zero where ``mode`` leaves a coordinate untouched), so that ``q = x0 + step``
+    reproduces the reference's ``x0 + factor * scale * randn`` bit for bit.
+    """
+
+    def __init__(self, cov, mode="vector", factor=None):
+        cov = np.asarray(cov, dtype=np.float64)
+        if cov.ndim == 0:
+            self.kind, self.scale = "iso", np.sqrt(float(cov))            # gaussian.py:60
+        elif cov.ndim == 2 and cov.shape[0] == cov.shape[1]:
+            self.kind, self.scale = "full", cov                           # gaussian.py:53
+            if mode != "vector":
+                raise ValueError("full-covariance proposals only run in 'vector' mode")   # gaussian.py:260
+        else:
+            raise ValueError("Invalid proposal scale dimensions")
+        if factor is not None and factor < 1.0:
+            raise ValueError("'factor' must be >= 1.0")                   # gaussian.py:149-150
+        if mode not in ("vector", "random", "sequential"):
+            raise ValueError("unrecognized mode")
+        self.log_factor = None if factor is None else np.log(factor)
+        self.mode = mode
+        self.index = 0
+
+    def get_factor(self, R):                                              # gaussian.py:161-164
+        if self.log_factor is None:
+            return 1.0
+        return np.exp(R.uniform(-self.log_factor, self.log_factor))
+
+    def draw_step(self, R, n, D):
+        f = self.get_factor(R)
+        if self.kind == "full":                                           # gaussian.py:265-268
+            step = f * R.multivariate_normal(np.zeros(D), self.scale, size=n)
+        else:                                                             # gaussian.py:166-167
+            step = f * self.scale * R.randn(n, D)
+        if self.mode == "vector":
+            return step
+        if self.mode == "random":                                         # gaussian.py:172-173
+            m = R.randint(D, size=n)
+        else:                                                             # gaussian.py:174-176
+            m = self.index % D + np.zeros(n, dtype=int)
+            self.index = (self.index + 1) % D
+        out = np.zeros_like(step)
+        out[np.arange(n), m] = step[np.arange(n), m]
+        return out
+
+
+def mh_step(x, L, P, betas, step, u_acc, lo, hi, loglike, fill=-1e300):
+    """One full-ensemble Metropolis-Hastings proposal q = x + step; mutates x, L, P in place.
+
+    ``MHMove.propose`` (mh.py:56-193) for a single branch with every leaf active: no red/blue split,
+    factors = 0 (gaussian.py:131), same tempered accept test and ``Move.update`` as the stretch move.
+    """
+    T, W, D = x.shape
+    q = x + step.reshape(T, W, D)
+    logp = box_log_prior(q.reshape(-1, D), lo, hi).reshape(T, W)          # mh.py:120
+    if np.any(np.isnan(logp)):
+        raise ValueError("The prior function is returning Nan.")
+    logl = compute_log_like(q, logp, loglike, fill=fill)                  # mh.py:126-132
+    logP = tempered_log_posterior(logl, logp, betas)                      # mh.py:142
+    prev_logP = tempered_log_posterior(L, P, betas)                       # mh.py:146-152
+    with np.errstate(invalid="ignore"):
+        lnpdiff = np.zeros((T, W)) + logP - prev_logP                     # mh.py:155
+    with np.errstate(divide="ignore"):
+        keep = lnpdiff > np.log(u_acc)                                    # mh.py:157
+    new_logp = logp.copy()
+    new_logp[np.isinf(new_logp)] = 0.0                                    # move.py:513-532
+    L[...] = logl * keep + L * (~keep)
+    P[...] = new_logp * keep + P * (~keep)
+    x[keep] = q[keep]
+    return dict(q=q, logp=logp, logl=logl, lnpdiff=lnpdiff, keep=keep)
+
+
+# --------------------------------------------------------------------------
 # parallel tempering                                     moves/tempering.py
 # --------------------------------------------------------------------------
 
@@ -289,7 +370,12 @@ class OracleSampler:
     def __init__(self, x0, loglike, lo, hi, R, G, betas=None, a=2.0,
                  adaptive=True, permute=True, adaptation_lag=10000,
                  adaptation_time=100, stop_adaptation=-1, randomize_split=True,
-                 live_dangerously=False, fill=-1e300, record=False):
+                 live_dangerously=False, fill=-1e300, record=False, moves=None):
+        # moves: [("stretch" | GaussianProposal, weight), ...]; default the reference's single StretchMove
+        self.moves = [("stretch", 1.0)] if moves is None else list(moves)
+        w = np.atleast_1d([m[1] for m in self.moves]).astype(float)
+        self.weights = w / np.sum(w)                                  # ensemble.py:377-378
+        self.move_accepted = None
         self.x = np.array(x0, dtype=np.float64, copy=True)
         self.T, self.W, self.D = self.x.shape
         self.loglike = loglike
@@ -313,6 +399,8 @@ class OracleSampler:
         self.L = compute_log_like(self.x, self.P, loglike, fill=fill)
         self.accepted = np.zeros((T, W))
         self.num_proposals = 0
+        self.move_accepted = [np.zeros((T, W)) for _ in self.moves]
+        self.move_num_proposals = [0 for _ in self.moves]
         self.swaps_accepted = np.zeros(max(T - 1, 0))
         self.swaps_accepted_total = np.zeros(max(T - 1, 0))
 
@@ -340,7 +428,49 @@ class OracleSampler:
     def iteration(self):
         T, W, D = self.T, self.W, self.D
         rec = {}
-        self.R.choice([0], p=[1.0])                                   # ensemble.py:971
+        mi = int(self.R.choice(len(self.moves), p=self.weights))      # ensemble.py:971
+        rec["move"] = mi
+        if self.moves[mi][0] == "stretch":
+            accepted = self._stretch_move(rec)
+        else:
+            accepted = self._mh_move(self.moves[mi][0], rec)
+        self.accepted += accepted
+        self.num_proposals += 1
+        self.move_accepted[mi] += accepted
+        self.move_num_proposals[mi] += 1
+        if self.record:
+            rec["L_stretch"], rec["P_stretch"] = self.L.copy(), self.P.copy()
+        if self.tempered:
+            iperm, i1perm, u_swap = self.draw_pt()
+            sel, sw = pt_sweep(self.x, self.L, self.P, self.betas, iperm, i1perm, u_swap)
+            self.swaps_accepted = sw
+            self.swaps_accepted_total += sw
+            if self.adaptive and T > 1:                               # tempering.py:632-633
+                if self.stop_adaptation < 0 or self.time < self.stop_adaptation:
+                    self.betas = adapt_ladder(self.betas, sw, W, self.time, self.lag, self.nu)
+                self.time += 1
+            if self.record:
+                rec.update(iperm=iperm, i1perm=i1perm, u_swap=u_swap, sel=sel,
+                           swaps_accepted=sw.copy(), betas_after=self.betas.copy())
+        if self.record:
+            rec.update(x=self.x.copy(), L=self.L.copy(), P=self.P.copy(), accepted=accepted)
+            self.trace.append(rec)
+        return accepted
+
+    def _mh_move(self, prop, rec):
+        """MHMove.propose (mh.py:56-193): proposal draws, then the accept uniforms, all from R."""
+        T, W, D = self.T, self.W, self.D
+        step = prop.draw_step(self.R, T * W, D).reshape(T, W, D)
+        u_acc = self.R.rand(T, W)                                     # mh.py:157
+        out = mh_step(self.x, self.L, self.P, self.betas, step, u_acc, self.lo, self.hi, self.loglike,
+                      fill=self.fill)
+        if self.record:
+            rec.update(mh_step=step, mh_u_acc=u_acc, mh_q=out["q"], mh_logp=out["logp"], mh_logl=out["logl"],
+                       mh_lnpdiff=out["lnpdiff"], mh_keep=out["keep"])
+        return out["keep"]
+
+    def _stretch_move(self, rec):
+        T, W, D = self.T, self.W, self.D
         if W < 2 * D and not self.live_dangerously:                   # red_blue.py:108-114
             raise RuntimeError("It is unadvisable to use a red-blue move with fewer "
                                "walkers than twice the number of dimensions.")
@@ -364,25 +494,6 @@ class OracleSampler:
                 for k in ("q", "logp", "logl", "factors", "lnpdiff", "keep"):
                     rec[f"{k}{split}"] = out[k]
                 rec[f"x_after{split}"] = self.x.copy()
-        self.accepted += accepted
-        self.num_proposals += 1
-        if self.record:
-            rec["L_stretch"], rec["P_stretch"] = self.L.copy(), self.P.copy()
-        if self.tempered:
-            iperm, i1perm, u_swap = self.draw_pt()
-            sel, sw = pt_sweep(self.x, self.L, self.P, self.betas, iperm, i1perm, u_swap)
-            self.swaps_accepted = sw
-            self.swaps_accepted_total += sw
-            if self.adaptive and T > 1:                               # tempering.py:632-633
-                if self.stop_adaptation < 0 or self.time < self.stop_adaptation:
-                    self.betas = adapt_ladder(self.betas, sw, W, self.time, self.lag, self.nu)
-                self.time += 1
-            if self.record:
-                rec.update(iperm=iperm, i1perm=i1perm, u_swap=u_swap, sel=sel,
-                           swaps_accepted=sw.copy(), betas_after=self.betas.copy())
-        if self.record:
-            rec.update(x=self.x.copy(), L=self.L.copy(), P=self.P.copy(), accepted=accepted)
-            self.trace.append(rec)
         return accepted
 
     def run(self, n):

@@ -105,3 +105,64 @@ def test_fill_path_exercised(golden_dir):
     n_inf = sum(int(np.isinf(fx[f"it{i}_logp{sp}"]).sum()) for i in range(int(fx["nsteps"])) for sp in (0, 1))
     n_fill = sum(int((fx[f"it{i}_logl{sp}"] == -1e300).sum()) for i in range(int(fx["nsteps"])) for sp in (0, 1))
     assert n_inf > 50 and n_fill == n_inf
+
+
+# ---- Metropolis-Hastings moves: fixtures from tests/golden/make_golden_mh.py -----------------
+MH_FIXTURES = ["m1_gauss_iso", "m3_gauss_full", "m4_gauss_random_factor", "m5_gauss_sequential", "m6_mix",
+               "m7_gauss_untempered", "m8_mix_narrowbox"]
+
+
+def mh_moves_from_fixture(fx, make_gauss):
+    moves = []
+    for i in range(int(fx["nmoves"])):
+        if str(fx[f"move{i}_kind"]) == "stretch":
+            moves.append(("stretch", float(fx["weights"][i])))
+        else:
+            factor = float(fx[f"move{i}_factor"])
+            moves.append((make_gauss(fx[f"move{i}_cov"], str(fx[f"move{i}_mode"]), None if np.isnan(factor) else factor),
+                          float(fx["weights"][i])))
+    return moves
+
+
+def build_mh_oracle(fx, record=True):
+    D = int(fx["D"])
+    R = np.random.RandomState(int(fx["seed_construct"]))
+    G = np.random.RandomState(int(fx["seed_run"]))
+    box = float(fx["box"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    kw = {}
+    if "betas0" in fx.files:
+        kw.update(betas=fx["betas0"])
+    moves = mh_moves_from_fixture(fx, lambda cov, mode, factor: orc.GaussianProposal(cov, mode=mode, factor=factor))
+    return orc.OracleSampler(fx["x0"], lambda x: orc.gaussian_log_like(x, mu, invcov), np.full(D, -box), np.full(D, box),
+                             R, G, record=record, moves=moves, **kw)
+
+
+@pytest.mark.parametrize("name", MH_FIXTURES)
+def test_oracle_reproduces_reference_mh(name, golden_dir):
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    o = build_mh_oracle(fx)
+    picked = np.zeros(int(fx["nmoves"]), dtype=int)
+    for it in range(int(fx["nsteps"])):
+        o.iteration()
+        rec, pre = o.trace[-1], f"it{it}_"
+        assert rec["move"] == int(fx[pre + "move"]), "move choice (ensemble.py:971)"
+        picked[rec["move"]] += 1
+        if "mh_q" in rec:
+            _same(rec["mh_q"], fx[pre + "mh_q"], pre + "q")
+            _same(rec["mh_logp"], fx[pre + "mh_logp"], pre + "logp")
+            _same(rec["mh_logl"], fx[pre + "mh_logl"], pre + "logl")
+            _same(rec["mh_keep"], fx[pre + "mh_keep"], pre + "keep")
+            # the accept uniforms are the last R draw of the proposal
+            kinds = list(fx[pre + "r_kinds"])
+            assert kinds[-1] == "rand"
+            _same(rec["mh_u_acc"], fx[pre + f"r{len(kinds) - 1}"], pre + "u_acc")
+        _same(rec["x"], fx[pre + "x"], pre + "x")
+        _same(rec["L"], fx[pre + "L"], pre + "L")
+        _same(rec["P"], fx[pre + "P"], pre + "P")
+        if o.tempered:
+            _same(o.betas, fx[pre + "betas"], pre + "betas")
+            _same(o.swaps_accepted, fx[pre + "swaps_accepted"], pre + "swaps_accepted")
+    for i in range(int(fx["nmoves"])):
+        assert o.move_num_proposals[i] == int(fx[f"move{i}_num_proposals"]) == picked[i]
+        _same(o.move_accepted[i], fx[f"move{i}_accepted"], f"move{i}.accepted")
