@@ -72,6 +72,9 @@ SIGNATURES = {
     "hens_stretch_iter": (C.c_int, [_P]),
     "hens_pt_plan_sharded": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "hens_pt_finish_sharded": (C.c_int, [_P, C.c_int64]),
+    "hens_mh_step": (C.c_int, [_P, _P, _P, _P]),
+    "hens_set_mh_proposal": (C.c_int, [_P, C.c_int32, _P, C.c_double]),
+    "hens_get_mh_counters": (C.c_int, [_P, _P, _P]),
     "hens_pipe_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "hens_pipe_connect": (C.c_int, [_P, _P]),
     "hens_pipe_connect_local": (C.c_int, [_P, _P]),

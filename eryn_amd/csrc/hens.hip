@@ -96,6 +96,16 @@ struct hens_ctx_impl {
         uint32_t sweep = 0;
         long long budget = 0;              // wall-clock ticks a flag wait may take
     } pipe;
+    // Metropolis-Hastings (GaussianMove) proposals
+    double* mh_step = nullptr;             // [Tl][W][D]
+    double* mh_lu = nullptr;               // [Tl][W] log accept uniforms
+    double* mh_u = nullptr;                // [Tl][W] staging
+    uint8_t* mh_keep = nullptr;            // [Tl][W]
+    double* mh_scale = nullptr;            // [D*D] proposal scale (see MhDrawArgs)
+    uint32_t* accepted_mh = nullptr;       // [Tl][W] accept counts of the MH move
+    int mh_kind = -1;                      // -1: hens_step runs the stretch move only
+    double mh_weight = 0.0;                // probability that an iteration of hens_step is an MH proposal
+    int64_t num_proposals_mh = 0;
     const uint32_t* adapt_src = nullptr;   // pending swap counts: swap_part (nullptr) or the mailbox's reduced counts
     int adapt_nblocks = 0;
 
@@ -169,7 +179,7 @@ size_t fast_lds_bytes(int D, int NW) {
     return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 64) * 8 + 5 * (size_t)TILE * 4;
 }
 
-template <int LIKE, bool EVAL>
+template <int LIKE, int MODE>
 int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
 #define LAUNCH_FAST(DT, NW)                                                                        \
@@ -178,16 +188,16 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, EVAL, NW>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
         if (c->ext_start)                                                                          \
-            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
+            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
                                   c->ext_start, c->ext_stop, 0, a);                                \
         else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, EVAL, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
@@ -205,15 +215,15 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         const size_t lds = generic_lds_bytes(c->D, &RS);
         if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
         if (lds > 60000)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE, EVAL>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE, MODE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         a.RS = RS;
         a.ad_on = 0;
         if (c->ext_start)
-            hipExtLaunchKernelGGL((k_stretch<LIKE, EVAL>), grid, dim3(256), (uint32_t)lds, c->stream, c->ext_start,
+            hipExtLaunchKernelGGL((k_stretch<LIKE, MODE>), grid, dim3(256), (uint32_t)lds, c->stream, c->ext_start,
                                   c->ext_stop, 0, a);
         else
-            hipLaunchKernelGGL((k_stretch<LIKE, EVAL>), grid, dim3(256), lds, c->stream, a);
+            hipLaunchKernelGGL((k_stretch<LIKE, MODE>), grid, dim3(256), lds, c->stream, a);
     }
 #undef LAUNCH_FAST
     const hipError_t e = hipGetLastError();
@@ -226,24 +236,24 @@ int launch_hostlike_eval(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const size_t lds = generic_lds_bytes(c->D, &RS);
     if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
     if (lds > 60000)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE_HOST, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE_HOST, MODE_EVAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.RS = RS;
     a.ad_on = 0;
-    hipLaunchKernelGGL((k_stretch<LIKE_HOST, true>), dim3(ntiles, c->Tl), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL((k_stretch<LIKE_HOST, MODE_EVAL>), dim3(ntiles, c->Tl), dim3(256), lds, c->stream, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
     return HENS_OK;
 }
 
-template <bool EVAL>
+template <int MODE>
 int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, EVAL>(c, a, ntiles);
-        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, EVAL>(c, a, ntiles);
-        case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, EVAL>(c, a, ntiles);
+        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, MODE>(c, a, ntiles);
+        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, MODE>(c, a, ntiles);
+        case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, MODE>(c, a, ntiles);
         case HENS_LIKE_HOST:
-            if (EVAL) return launch_hostlike_eval(c, a, ntiles);
+            if (MODE == MODE_EVAL) return launch_hostlike_eval(c, a, ntiles);
             return fail(c, HENS_ERR_STATE, "host-likelihood context: use hens_propose_split / hens_accept_split");
     }
     return fail(c, HENS_ERR_INVALID, "unknown likelihood kind %d", c->cfg.likelihood_kind);
@@ -509,6 +519,35 @@ hipEvent_t new_event(hens_ctx_impl* c) {
     return e;
 }
 
+// the first launch of an iteration: wait for the pipeline's arrivals in its prologue and carry the pending
+// ladder adaptation (or run it as a kernel of its own where it cannot be folded)
+void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
+    if (is_fast_dim(c->D)) {
+        a.wmask = pipe_prewait_mask(c);
+        if (a.wmask) {
+            a.wflags = pipe_box(c->pipe.box, c->T, c->W, c->D).flags;
+            a.wtarget = c->pipe.sweep;
+            a.wbudget = c->pipe.budget;
+        }
+    }
+    if (!c->adapt_pending) return;
+    if (can_fold_adapt(c)) {
+        // the previous cascade's ladder adaptation rides in this launch: every workgroup reads
+        // the old ladder, workgroup (0,0) writes the new one into the other buffer
+        a.ad_on = 1;
+        a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
+        a.betas = c->betas[c->bcur];
+        if (c->adapt_pending_adaptive) c->adapt_time += 1;
+        c->adapt_pending = false;
+        c->adapt_src = nullptr;
+        c->bcur ^= 1;
+    } else {
+        if (pipe_active(c)) pipe_flush_adapt(c);      // the counts of every rank first
+        else flush_adapt(c);
+        a.betas = c->betas[c->bcur];
+    }
+}
+
 // both halves of one Philox iteration from draw buffer `which`, batch slot `ib`
 int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
     const int Tl = c->Tl, W = c->W;
@@ -517,31 +556,7 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
         a.dr = draws_at(c->db[which], (size_t)ib * Tl * W);
         a.split = split;
         a.home_off = c->parity * Tl * W;
-        if (split == 0 && is_fast_dim(c->D)) {
-            a.wmask = pipe_prewait_mask(c);
-            if (a.wmask) {
-                a.wflags = pipe_box(c->pipe.box, c->T, c->W, c->D).flags;
-                a.wtarget = c->pipe.sweep;
-                a.wbudget = c->pipe.budget;
-            }
-        }
-        if (split == 0 && c->adapt_pending) {
-            if (can_fold_adapt(c)) {
-                // the previous cascade's ladder adaptation rides in this launch: every workgroup reads
-                // the old ladder, workgroup (0,0) writes the new one into the other buffer
-                a.ad_on = 1;
-                a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
-                a.betas = c->betas[c->bcur];
-                if (c->adapt_pending_adaptive) c->adapt_time += 1;
-                c->adapt_pending = false;
-                c->adapt_src = nullptr;
-                c->bcur ^= 1;
-            } else {
-                if (pipe_active(c)) pipe_flush_adapt(c);      // the counts of every rank first
-                else flush_adapt(c);
-                a.betas = c->betas[c->bcur];
-            }
-        }
+        if (split == 0) attach_iteration_head(c, a);
         const int Ns = split == 0 ? c->N0 : W - c->N0;
         if (evs) {           // per-kernel timing: the dispatch packet's own begin/end timestamps
             c->ext_start = new_event(c);
@@ -549,13 +564,82 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
             evs->push_back(c->ext_start);
             evs->push_back(c->ext_stop);
         }
-        const int r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
+        const int r = launch_stretch<MODE_STRETCH>(c, a, (Ns + TILE - 1) / TILE);
         c->ext_start = c->ext_stop = nullptr;
         if (r) return r;
     }
     c->parity ^= 1;
     c->num_proposals += 1;
     return HENS_OK;
+}
+
+
+int ensure_mh_buffers(hens_ctx_impl* c) {
+    if (c->mh_step) return HENS_OK;
+    const size_t TW = (size_t)c->Tl * c->W;
+    int r;
+    if ((r = dalloc(c, &c->mh_step, TW * c->D))) return r;
+    if ((r = dalloc(c, &c->mh_lu, TW))) return r;
+    if ((r = dalloc(c, &c->mh_u, TW))) return r;
+    if ((r = dalloc(c, &c->mh_keep, TW))) return r;
+    if ((r = dalloc(c, &c->mh_scale, (size_t)c->D * c->D))) return r;
+    if ((r = dalloc(c, &c->accepted_mh, TW))) return r;
+    HIPCHK(c, hipMemsetAsync(c->accepted_mh, 0, TW * 4, c->stream));
+    return HENS_OK;
+}
+
+// one full-ensemble MH proposal from the step rows / log-uniforms already in mh_step / mh_lu (mh.py:56-193)
+int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs) {
+    StretchArgs a = base_args(c);
+    a.split = 0;
+    a.home_off = c->parity * c->Tl * c->W;
+    a.mh_step = c->mh_step;
+    a.dr.lu = c->mh_lu;
+    a.accepted = c->accepted_mh;
+    a.keep_out = want_keep ? c->mh_keep : nullptr;
+    attach_iteration_head(c, a);
+    if (evs) {
+        c->ext_start = new_event(c);
+        c->ext_stop = new_event(c);
+        evs->push_back(c->ext_start);
+        evs->push_back(c->ext_stop);
+    }
+    const int r = launch_stretch<MODE_MH>(c, a, (c->W + TILE - 1) / TILE);
+    c->ext_start = c->ext_stop = nullptr;
+    if (r) return r;
+    c->parity ^= 1;
+    c->num_proposals_mh += 1;
+    return HENS_OK;
+}
+
+// Philox mode: draw the iteration's steps and accept uniforms on the device, then propose
+int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
+    MhDrawArgs d{};
+    d.step = c->mh_step; d.lu = c->mh_lu; d.scale = c->mh_scale;
+    d.iter = c->iter; d.seed = c->cfg.seed;
+    d.Tl = c->Tl; d.W = c->W; d.D = c->D; d.rung_begin = c->cfg.rung_begin; d.kind = c->mh_kind;
+    hipLaunchKernelGGL(k_mh_draw, dim3((c->W + 63) / 64, c->Tl), dim3(256), (size_t)64 * (c->D + 1) * 8, c->stream, d);
+    return mh_launch(c, false, evs);
+}
+
+// host-side move choice of hens_step (ensemble.py:971 in Philox form): one counter-based uniform per iteration
+uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+double move_uniform(uint64_t seed, uint64_t it) {
+    uint32_t c0 = (uint32_t)it, c1 = (uint32_t)(it >> 32), c2 = 0, c3 = PURPOSE_MOVE;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t v = ((uint64_t)c0 << 32) | c1;
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+}
+bool iteration_is_mh(const hens_ctx_impl* c) {
+    if (c->mh_kind < 0 || c->mh_weight <= 0.0) return false;
+    return c->mh_weight >= 1.0 || move_uniform(c->cfg.seed, c->iter) < c->mh_weight;
 }
 
 }  // namespace
@@ -855,7 +939,7 @@ int hens_eval_state(hens_ctx* ctx) {
     StretchArgs a = base_args(c);
     a.split = 0;
     a.home_off = 0;
-    r = launch_stretch<true>(c, a, (c->W + TILE - 1) / TILE);
+    r = launch_stretch<MODE_EVAL>(c, a, (c->W + TILE - 1) / TILE);
     if (r) return r;
     r = check_flags(c, true);
     if (r) return r;
@@ -940,7 +1024,7 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     a.split = split;
     a.home_off = c->parity * c->Tl * c->W;
     a.keep_out = c->d_keep;
-    r = launch_stretch<false>(c, a, (Ns + TILE - 1) / TILE);
+    r = launch_stretch<MODE_STRETCH>(c, a, (Ns + TILE - 1) / TILE);
     if (r) return r;
     if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->d_keep, n, hipMemcpyDeviceToHost, c->stream));
     r = check_flags(c, false);
@@ -1116,7 +1200,13 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
         for (int ib = 0; ib < nb; ++ib) {
             if (piped) pipe_prewait(c);
-            r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
+            const bool mh = iteration_is_mh(c);
+            if (mh) {
+                r = mh_iteration(c, prof ? &evs : nullptr);
+                if (prof) { evs.push_back(evs[evs.size() - 2]); evs.push_back(evs[evs.size() - 2]); }   // one launch, two timing slots
+            } else {
+                r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
+            }
             if (r) return r;
             if (piped) {
                 if (prof) { hipEvent_t e0 = new_event(c); evs.push_back(e0); (void)hipEventRecord(e0, c->stream); }
@@ -1193,8 +1283,10 @@ int hens_reset_counters(hens_ctx* ctx) {
     HIPCHK(c, hipMemsetAsync(c->accepted, 0, (size_t)c->Tl * c->W * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
+    if (c->accepted_mh) HIPCHK(c, hipMemsetAsync(c->accepted_mh, 0, (size_t)c->Tl * c->W * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->num_proposals = 0;
+    c->num_proposals_mh = 0;
     return HENS_OK;
 }
 
@@ -1401,6 +1493,72 @@ int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
     c->cur ^= 1;
     c->iter += 1;
     c->pt_pending = false;
+    return HENS_OK;
+}
+
+// ---- Metropolis-Hastings proposals ----------------------------------------------------------
+int hens_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (!step || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.likelihood_kind == HENS_LIKE_HOST) return fail(c, HENS_ERR_UNSUPPORTED, "hens_mh_step needs a device likelihood");
+    if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_mh_step between split 0 and split 1");
+    if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    if ((r = ensure_mh_buffers(c))) return r;
+    flush_adapt(c);
+    const size_t TW = (size_t)c->Tl * c->W;
+    HIPCHK(c, hipMemcpyAsync(c->mh_step, step, TW * c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->mh_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_mh_prep, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, c->mh_u, c->mh_lu, (int64_t)TW);
+    c->win_count = 0;
+    if ((r = mh_launch(c, true, nullptr))) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->mh_keep, TW, hipMemcpyDeviceToHost, c->stream));
+    if ((r = check_flags(c, true))) return r;
+    if (!has_pt(c)) c->iter += 1;
+    return HENS_OK;
+}
+
+int hens_set_mh_proposal(hens_ctx* ctx, int32_t kind, const double* scale, double weight) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (kind < 0) {                                   // back to the stretch move only
+        c->mh_kind = -1;
+        c->mh_weight = 0.0;
+        return HENS_OK;
+    }
+    if (kind > MH_FULL || !scale) return fail(c, HENS_ERR_INVALID, "kind must be 0 (isotropic), 1 (diagonal) or 2 (full) with its scale");
+    if (!(weight >= 0.0 && weight <= 1.0)) return fail(c, HENS_ERR_INVALID, "weight must be a probability");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    int r = ensure_mh_buffers(c);
+    if (r) return r;
+    const size_t n = kind == MH_ISO ? 1 : (kind == MH_DIAG ? (size_t)c->D : (size_t)c->D * c->D);
+    for (size_t i = 0; i < n; ++i)
+        if (!(std::fabs(scale[i]) < INFINITY)) return fail(c, HENS_ERR_INVALID, "proposal scale must be finite");
+    HIPCHK(c, hipMemcpyAsync(c->mh_scale, scale, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->mh_kind = kind;
+    c->mh_weight = weight;
+    return HENS_OK;
+}
+
+int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    if (accepted) {
+        if (!c->accepted_mh) {
+            for (size_t i = 0; i < TW; ++i) accepted[i] = 0.0;
+        } else {
+            std::vector<uint32_t> h(TW);
+            HIPCHK(c, hipMemcpyAsync(h.data(), c->accepted_mh, TW * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < TW; ++i) accepted[i] = (double)h[i];
+        }
+    }
+    if (num_proposals) *num_proposals = c->num_proposals_mh;
     return HENS_OK;
 }
 

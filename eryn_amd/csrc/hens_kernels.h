@@ -31,6 +31,10 @@ constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-2
 constexpr unsigned FLAG_PIPE_TIMEOUT = 4u; // ladder pipeline: a neighbour's flag did not arrive in time
 
 enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2, LIKE_HOST = 3 };
+// what a stretch-kernel launch does: a red/blue stretch half-step, the evaluation of the resident state, or a
+// full-ensemble Metropolis-Hastings proposal q = x + step (mh.py:56-193; the step rows are read where the
+// stretch move reads the complement walker)
+enum { MODE_STRETCH = 0, MODE_EVAL = 1, MODE_MH = 2 };
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: draws are a pure function of
@@ -83,7 +87,7 @@ __device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits,
 }
 
 enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
-                  PURPOSE_PTU = 10 };
+                  PURPOSE_PTU = 10, PURPOSE_MH_ACC = 11, PURPOSE_MH_NORMAL = 12, PURPOSE_MOVE = 13 };
 
 // The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
 // a workgroup's thread 0 spins until flag >= target (or the budget runs out: a peer died - fail the run
@@ -161,6 +165,7 @@ struct StretchArgs {
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
     int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
     int64_t guest_delta;       // see row_off (0 when there is no pipeline)
+    const double* mh_step;     // MODE_MH: [Tl][W][D] proposal steps
     // ladder pipeline: before touching the state, wait until the mailbox flags selected by wmask reach wtarget
     const unsigned* wflags;
     unsigned long long wmask;
@@ -175,9 +180,10 @@ struct StretchArgs {
 //   phase C  lane-per-walker : quadratic form, rows of the precision matrix split over the waves
 //   phase D  lane-per-walker : tempered MH test, L/P/loc/accept counters
 //   phase E  lanes-over-d    : coalesced write of the new row (q if kept, old row otherwise)
-template <int LIKE, bool EVAL>
+template <int LIKE, int MODE>
 __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
     constexpr int NW = 4, NT = 256;
     const int D = A.D, RS = A.RS;
     double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tl = blockIdx.y;
     const int W = A.W;
-    const int Ns = EVAL ? W : (A.split == 0 ? A.N0 : W - A.N0);
-    const int s_off = EVAL ? 0 : (A.split == 0 ? 0 : A.N0);
+    const int Ns = (EVAL || MH) ? W : (A.split == 0 ? A.N0 : W - A.N0);
+    const int s_off = (EVAL || MH) ? 0 : (A.split == 0 ? 0 : A.N0);
     const int k0 = blockIdx.x * TILE;
 
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0;
@@ -210,6 +216,13 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                 own = k;
                 rs = A.loc[tl * W + own];
                 rc = rs;
+            } else if (MH) {                     // every walker proposes; no partner, no Hastings factor
+                own = k;
+                rs = A.loc[tl * W + own];
+                rc = rs;
+                lu = A.dr.lu[(size_t)tl * W + own];
+                Lold = A.L[tl * W + own];
+                Pold = A.P[tl * W + own];
             } else {
                 const size_t di = (size_t)tl * W + s_off + k;
                 own = A.dr.own[di];
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
         if (rvalid) {
             const double zz = s_zz[r];
             const double* ps = pool_r + row_off(s_rs[r], D, A.guest_delta);
-            const double* pc = pool_r + row_off(s_rc[r], D, A.guest_delta);
+            const double* pc = MH ? A.mh_step + ((size_t)tl * W + k0 + r) * D : pool_r + row_off(s_rc[r], D, A.guest_delta);
             for (int ch = jl; ch < chunks; ch += LPR) {
                 const int e = ch * VEC;
                 if (VEC == 2) {
@@ -257,8 +270,13 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                         qv = sv;
                     } else {
                         const double2 cv = *reinterpret_cast<const double2*>(pc + e);
-                        qv.x = cv.x - (cv.x - sv.x) * zz;     // stretch.py:143,145
-                        qv.y = cv.y - (cv.y - sv.y) * zz;
+                        if (MH) {
+                            qv.x = sv.x + cv.x;               // gaussian.py:166-167
+                            qv.y = sv.y + cv.y;
+                        } else {
+                            qv.x = cv.x - (cv.x - sv.x) * zz; // stretch.py:143,145
+                            qv.y = cv.y - (cv.y - sv.y) * zz;
+                        }
                     }
                     const double2 lov = *reinterpret_cast<const double2*>(A.lo + e);
                     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + e);
@@ -272,7 +290,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                         qv = sv;
                     } else {
                         const double cv = pc[e];
-                        qv = cv - (cv - sv) * zz;
+                        qv = MH ? sv + cv : cv - (cv - sv) * zz;
                     }
                     ok = ok && (qv >= A.lo[e]) && (qv <= A.hi[e]);
                     finite = finite && (fabs(qv) < INFINITY);
@@ -470,8 +488,9 @@ __device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attrib
 //     in flight and recomputes the ladder in one wavefront; workgroup (0,0) publishes it.  That
 //     removes a dependent single-workgroup launch (~5.5 us + boundary) from every iteration.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int LIKE, bool EVAL, int NW>
+template <int DT, int LIKE, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
+    constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int D = DT;
@@ -496,8 +515,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tl = blockIdx.y;
     const int W = A.W;
-    const int Ns = EVAL ? W : (A.split == 0 ? A.N0 : W - A.N0);
-    const int s_off = EVAL ? 0 : (A.split == 0 ? 0 : A.N0);
+    const int Ns = (EVAL || MH) ? W : (A.split == 0 ? A.N0 : W - A.N0);
+    const int s_off = (EVAL || MH) ? 0 : (A.split == 0 ? 0 : A.N0);
     const int k0 = blockIdx.x * TILE;
     const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -522,6 +541,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 own = k;
                 rs = A.loc[tl * W + own];
                 rc = rs;
+            } else if (MH) {                     // every walker proposes; no partner, no Hastings factor
+                own = k;
+                rs = A.loc[tl * W + own];
+                rc = rs;
+                lu = A.dr.lu[(size_t)tl * W + own];
+                Lold = A.L[tl * W + own];
+                Pold = A.P[tl * W + own];
             } else {
                 const size_t di = (size_t)tl * W + s_off + k;
                 own = A.dr.own[di];
@@ -562,7 +588,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rs[r], D, A.guest_delta) + jl * 2);
-            if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rc[r], D, A.guest_delta) + jl * 2);
+            if (MH) creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
+            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rc[r], D, A.guest_delta) + jl * 2);
         }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
@@ -588,8 +615,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 qv = sreg[p];
             } else {
                 const double zz = s_zz[r];
-                qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz;     // stretch.py:143,145
-                qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
+                if (MH) {
+                    qv.x = sreg[p].x + creg[p].x;                    // gaussian.py:166-167
+                    qv.y = sreg[p].y + creg[p].y;
+                } else {
+                    qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; // stretch.py:143,145
+                    qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
+                }
             }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
@@ -835,6 +867,68 @@ __global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* _
         const int own = order[(size_t)tl * W + s_off + k];
         const int cw = order[(size_t)tl * W + c_off + (int)rint[i]];
         make_draw(d, (size_t)tl * W + s_off + k, own, cw, u_zz[i], u_acc[i], a, D);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Metropolis-Hastings proposals: the draws of a GaussianMove (gaussian.py:68-270).
+// ---------------------------------------------------------------------------------------------
+// parity mode: the caller's accept uniforms (mh.py:157) -> log
+__global__ void k_mh_prep(const double* __restrict__ u_acc, double* __restrict__ lu, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        lu[i] = log(u_acc[i]);
+}
+
+enum { MH_ISO = 0, MH_DIAG = 1, MH_FULL = 2 };
+struct MhDrawArgs {
+    double* step;            // [Tl][W][D]
+    double* lu;              // [Tl][W]
+    const double* scale;     // MH_ISO: [1] std dev; MH_DIAG: [D] std devs; MH_FULL: [D][D] lower Cholesky factor, row-major
+    uint64_t iter, seed;
+    int32_t Tl, W, D, rung_begin, kind;
+};
+// Philox mode: step = scale * z (isotropic / diagonal) or chol * z (full covariance), z ~ N(0, 1) by
+// Box-Muller from Philox counters keyed (iteration, global rung, walker, coordinate pair); the accept
+// uniform likewise.  One workgroup = 64 walkers of one rung; z goes through LDS for the triangular product.
+__global__ __launch_bounds__(256) void k_mh_draw(const MhDrawArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* z = reinterpret_cast<double*>(smem_raw);                  // [64][D + 1]
+    const int D = A.D, W = A.W, ZS = D + 1;
+    const int tl = blockIdx.y, w0 = blockIdx.x * 64;
+    const uint32_t rung = (uint32_t)(A.rung_begin + tl);
+    const int npair = (D + 1) / 2;
+    for (int i = threadIdx.x; i < 64 * npair; i += blockDim.x) {
+        const int wl = i / npair, pr = i - wl * npair, w = w0 + wl;
+        if (w >= W) continue;
+        const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), rung * (uint32_t)W + (uint32_t)w,
+                     PURPOSE_MH_NORMAL | ((uint32_t)pr << 8)};
+        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        const double u1 = 1.0 - u01(d.x, d.y);                        // (0, 1]
+        const double u2 = u01(d.z, d.w);
+        const double r = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincospi(2.0 * u2, &sn, &cs);
+        z[wl * ZS + 2 * pr] = r * cs;
+        if (2 * pr + 1 < D) z[wl * ZS + 2 * pr + 1] = r * sn;
+    }
+    if (threadIdx.x < 64 && w0 + (int)threadIdx.x < W) {
+        const int w = w0 + threadIdx.x;
+        const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), rung * (uint32_t)W + (uint32_t)w, PURPOSE_MH_ACC};
+        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        A.lu[(size_t)tl * W + w] = log(u01(d.x, d.y));               // mh.py:157
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * D; i += blockDim.x) {
+        const int wl = i / D, d = i - wl * D, w = w0 + wl;
+        if (w >= W) continue;
+        double v;
+        if (A.kind == MH_FULL) {
+            v = 0.0;
+            for (int k = 0; k <= d; ++k) v = fma(A.scale[(size_t)d * D + k], z[wl * ZS + k], v);
+        } else {
+            v = (A.kind == MH_ISO ? A.scale[0] : A.scale[d]) * z[wl * ZS + d];
+        }
+        A.step[((size_t)tl * W + w) * D + d] = v;
     }
 }
 

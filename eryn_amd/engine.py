@@ -199,6 +199,34 @@ class HipEnsemble:
         kernels order themselves without host synchronisation)."""
         check(self.lib.hens_set_stream(self.ctx, C.c_void_p(int(stream_handle))), self.ctx)
 
+    # -- Metropolis-Hastings proposals (include/hipensemble.h: hens_mh_*) --------------------------------
+    def mh_step(self, step, u_acc):
+        """One full-ensemble proposal q = x + step with the caller's draws; returns the accept mask [Tl, W]."""
+        step = np.ascontiguousarray(step, dtype=np.float64).reshape(self.Tl, self.W, self.D)
+        u_acc = np.ascontiguousarray(u_acc, dtype=np.float64).reshape(self.Tl, self.W)
+        keep = np.empty((self.Tl, self.W), dtype=np.uint8)
+        check(self.lib.hens_mh_step(self.ctx, ptr(step), ptr(u_acc), ptr(keep)), self.ctx)
+        return keep.astype(bool)
+
+    def set_mh_proposal(self, kind, scale, weight):
+        """Mix Gaussian MH proposals into ``step()``: kind "iso" | "diag" | "full" (scale = std dev, std devs,
+        lower Cholesky factor), weight = probability per iteration; kind None switches the mix off."""
+        if kind is None:
+            check(self.lib.hens_set_mh_proposal(self.ctx, -1, None, 0.0), self.ctx)
+            return
+        k = {"iso": 0, "diag": 1, "full": 2}[kind]
+        scale = np.ascontiguousarray(np.atleast_1d(scale), dtype=np.float64)
+        need = {0: 1, 1: self.D, 2: self.D * self.D}[k]
+        if scale.size != need:
+            raise ValueError(f"{kind} proposal needs {need} scale value(s)")
+        check(self.lib.hens_set_mh_proposal(self.ctx, k, ptr(scale), float(weight)), self.ctx)
+
+    def mh_counters(self):
+        acc = np.zeros((self.Tl, self.W))
+        n = C.c_int64(0)
+        check(self.lib.hens_get_mh_counters(self.ctx, ptr(acc), C.byref(n)), self.ctx)
+        return dict(accepted=acc, num_proposals=int(n.value))
+
     # -- ladder pipeline (include/hipensemble.h: hens_pipe_*) ------------------------------------------
     def pipe_init(self, nranks, rank):
         """Allocate this shard's mailbox; returns its 64-byte HIP IPC handle."""

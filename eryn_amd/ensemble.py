@@ -14,7 +14,7 @@ import numpy as np
 from .backend import Backend
 from .engine import HipEnsemble
 from .model import Model
-from .moves import StretchMove, TemperatureControl
+from .moves import DeviceMove, GaussianMove, MHMove, StretchMove, TemperatureControl
 from .prior import ProbDistContainer
 from .state import State
 
@@ -94,8 +94,12 @@ class EnsembleSampler:
         if tc is not None:
             kw = dict(adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag, adaptation_time=tc.adaptation_time,
                       stop_adaptation=tc.stop_adaptation)
-        live = any(getattr(m, "live_dangerously", False) for m in self.moves)
-        a_vals = {getattr(m, "a", 2.0) for m in self.moves}
+        for m in self.moves:
+            if not isinstance(m, DeviceMove):
+                raise NotImplementedError("only eryn_amd.moves.StretchMove / GaussianMove run on the device path")
+        stretch_moves = [m for m in self.moves if isinstance(m, StretchMove)]
+        live = any(m.live_dangerously for m in stretch_moves)
+        a_vals = {m.a for m in stretch_moves} or {2.0}
         if len(a_vals) != 1:
             raise NotImplementedError("all device stretch moves must share one scale a")
         if seed is None:
@@ -103,14 +107,24 @@ class EnsembleSampler:
         self.engine = HipEnsemble(self.ntemps, self.nwalkers, self.ndim, log_like_fn, lo, hi, a=a_vals.pop(),
                                   tempered=tc is not None, live_dangerously=live,
                                   fill_value=fill_zero_leaves_val, seed=seed, device_id=device_id, **kw)
+        self._resident = [None]              # the State the device context mirrors, shared by the moves
         for m in self.moves:
-            if not isinstance(m, StretchMove):
-                raise NotImplementedError("only eryn_amd.moves.StretchMove runs on the device path")
             if m.temperature_control is None:
                 m.temperature_control = tc
-            m.attach_engine(self.engine)
+            m.attach_engine(self.engine, self._resident)
             m.trust_resident = True
             m.accepted = np.zeros((self.ntemps, self.nwalkers))
+        # device-side draws (rng="philox"): at most one stretch move and one Gaussian MH move, mixed by weight
+        self._philox_moves = None
+        if rng == "philox":
+            mh = [(m, w) for m, w in zip(self.moves, self.weights) if isinstance(m, MHMove)]
+            st = [(m, w) for m, w in zip(self.moves, self.weights) if isinstance(m, StretchMove)]
+            if len(mh) > 1 or len(st) > 1 or any(not isinstance(m, GaussianMove) for m, _ in mh):
+                raise NotImplementedError("rng='philox' mixes at most one StretchMove with one GaussianMove")
+            if mh:
+                kind, scale = mh[0][0].device_proposal()
+                self.engine.set_mh_proposal(kind, scale, float(mh[0][1]))
+            self._philox_moves = (st[0][0] if st else None, mh[0][0] if mh else None)
 
         # -- backend + RNG (ensemble.py:593-652)
         self.backend = Backend() if backend is None else backend
@@ -156,6 +170,7 @@ class EnsembleSampler:
         _, L, P, _ = self.engine.download(want_x=False)
         if hasattr(self.log_like_fn, "evaluate"):            # host-callable likelihood: the device filled log_prior only
             L = self.log_like_fn.evaluate(np.ascontiguousarray(x), ~np.isinf(P))
+        self._resident[0] = None
         for m in self.moves:
             m._resident = None
         return L, P
@@ -224,16 +239,25 @@ class EnsembleSampler:
                    None if tc is None else tc.betas)
         if tc is not None:
             eng.set_adapt_time(tc.time)
-        move = self.moves[0]
+        st_move, mh_move = self._philox_moves
         prev = eng.counters()
+        prev_mh = eng.mh_counters() if mh_move is not None else None
         inds = state.branches[name].inds
         for _ in range(iterations):
             eng.step(thin_by)
             x, L, P, betas = eng.download()
             c = eng.counters()
             accepted = c["accepted"] - prev["accepted"]
-            move.accepted += accepted
-            move.num_proposals += thin_by
+            if st_move is not None:
+                st_move.accepted += accepted
+                st_move.num_proposals += c["num_proposals"] - prev["num_proposals"]
+            if mh_move is not None:
+                cm = eng.mh_counters()
+                acc_mh = cm["accepted"] - prev_mh["accepted"]
+                mh_move.accepted += acc_mh
+                mh_move.num_proposals += cm["num_proposals"] - prev_mh["num_proposals"]
+                accepted = accepted + acc_mh
+                prev_mh = cm
             swaps = None
             if tc is not None:
                 tc.betas = betas

@@ -1,0 +1,132 @@
+"""Plumbing shared by the HIP-backed moves: the device context, the resident-state shortcut and the
+parallel-tempering tail every in-model move ends with (red_blue.py:330-331, mh.py:190-191)."""
+import numpy as np
+
+from ..engine import HipEnsemble
+from ..state import State
+from .move import Move
+
+__all__ = ["DeviceMove"]
+
+
+class DeviceMove(Move):
+    """A move evaluated by libhipensemble.  Moves of one sampler share ONE device context
+    (``attach_engine``) so the walkers stay resident between different moves of a weighted mix."""
+
+    def __init__(self, likelihood=None, prior_box=None, device_id=0, fill_value=-1e300, trust_resident=False,
+                 a=2.0, live_dangerously=False, **kwargs):
+        self.likelihood = likelihood
+        self.prior_box = prior_box
+        self.device_id = device_id
+        self.fill_value = fill_value
+        self.trust_resident = trust_resident
+        self.engine = None
+        self._resident = None
+        self._engine_a = a
+        self._engine_live = live_dangerously
+        Move.__init__(self, **kwargs)
+
+    # -- engine -----------------------------------------------------------------------------------
+    def _box(self):
+        pb = self.prior_box
+        if pb is None:
+            raise ValueError(f"{type(self).__name__} needs prior_box=(lo, hi) or a ProbDistContainer")
+        if hasattr(pb, "box_bounds"):
+            return pb.box_bounds()
+        return pb
+
+    def attach_engine(self, engine, shared=None):
+        """Share one device context between the sampler, its moves and the temperature control.
+        ``shared``: a one-element list holding the State the context currently mirrors (so that the
+        resident-state shortcut works across the moves of a mix)."""
+        self.engine = engine
+        self._shared = shared
+
+    def _ensure_engine(self, T, W, D):
+        e = self.engine
+        if e is not None and (e.T, e.W, e.D) == (T, W, D):
+            return e
+        if self.likelihood is None:
+            raise ValueError(f"{type(self).__name__} needs likelihood=<eryn_amd.likelihood object>")
+        lo, hi = self._box()
+        tc = self.temperature_control
+        kw = {}
+        if tc is not None:
+            kw = dict(adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag, adaptation_time=tc.adaptation_time,
+                      stop_adaptation=tc.stop_adaptation)
+        self.engine = HipEnsemble(T, W, D, self.likelihood, lo, hi, a=self._engine_a, tempered=tc is not None,
+                                  live_dangerously=self._engine_live, fill_value=self.fill_value,
+                                  device_id=self.device_id, **kw)
+        return self.engine
+
+    @staticmethod
+    def _single_branch(state):
+        names = list(state.branches.keys())
+        if len(names) != 1:
+            raise NotImplementedError("the device path handles a single branch (SURVEY 8f-4: RJ is a later row)")
+        br = state.branches[names[0]]
+        T, W, nl, D = br.shape
+        if nl != 1 or not np.all(br.inds):
+            raise NotImplementedError("the device path handles nleaves_max == 1 with all leaves active")
+        if state.blobs is not None or state.supplemental is not None:
+            raise NotImplementedError("blobs / supplementals are outside the device hot path")
+        return names[0], br, T, W, D
+
+    # -- resident state ------------------------------------------------------------------------------
+    def _get_resident(self):
+        shared = getattr(self, "_shared", None)
+        return shared[0] if shared is not None else self._resident
+
+    def _set_resident(self, state):
+        shared = getattr(self, "_shared", None)
+        if shared is not None:
+            shared[0] = state
+        self._resident = state
+
+    def _upload_if_needed(self, eng, state, br):
+        tc = self.temperature_control
+        if self.trust_resident and self._get_resident() is state:
+            return
+        if state.log_like is None or state.log_prior is None:
+            raise ValueError("state must carry log_like and log_prior")
+        eng.upload(br.coords[:, :, 0, :], state.log_like, state.log_prior, None if tc is None else tc.betas)
+        if tc is not None:
+            eng.set_adapt_time(tc.time)
+
+    # -- the tail of every in-model propose(): PT sweep, adaptation, new State -------------------------
+    def _finish(self, eng, state, name, br, T, W):
+        tc = self.temperature_control
+        if tc is not None and T > 1:                                   # red_blue.py:330-331, mh.py:190-191
+            iperm, i1perm, u = _swap_draws(tc, T, W)
+            do_adapt = bool(tc.adaptive)
+            sel, swaps = eng.pt_sweep(iperm, i1perm, u, adapt=do_adapt)
+            tc.swaps_accepted = swaps
+            x, L, P, betas = eng.download()
+            if do_adapt:
+                tc.betas = betas
+                tc.time += 1
+        else:
+            x, L, P, betas = eng.download()
+            if tc is not None:
+                tc.swaps_accepted = np.empty(0)
+        out = State({name: x[:, :, None, :]}, inds={name: br.inds}, log_like=L, log_prior=P,
+                    betas=None if tc is None else tc.betas, random_state=state.random_state)
+        self._set_resident(out)
+        return out
+
+
+def _swap_draws(tc, T, W):
+    if hasattr(tc, "draw_swap_randoms"):
+        return tc.draw_swap_randoms()
+    # duck-typed reference TemperatureControl: same draw order (tempering.py:515-535)
+    iperm = np.empty((T - 1, W), dtype=np.int64)
+    i1perm = np.empty((T - 1, W), dtype=np.int64)
+    u = np.empty((T - 1, W))
+    for j in range(T - 1):
+        if tc.permute:
+            iperm[j] = np.random.permutation(W)
+            i1perm[j] = np.random.permutation(W)
+        else:
+            iperm[j] = i1perm[j] = np.arange(W)
+        u[j] = np.random.uniform(size=W)
+    return iperm, i1perm, u

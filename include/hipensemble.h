@@ -217,6 +217,24 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
 /* Sharded PT, step 2: scatter n_recv received rows (recv_rows, any order) and swap buffers. */
 int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv);
 
+/* ---- Metropolis-Hastings proposals: GaussianMove / MHMove ---------------------------
+ * One full-ensemble proposal q = x + step for every walker of every resident rung, box prior,
+ * likelihood, tempered accept test with factors = 0, update - MHMove.propose (mh.py:56-193) with
+ * GaussianMove.get_proposal (gaussian.py:68-195).  The PT sweep that ends the reference's propose()
+ * (mh.py:190-191) is hens_pt_sweep, as for the stretch move.
+ *   step  f64 [Tl][W][D]  q - x: factor * scale * randn (gaussian.py:166-167) or the multivariate-normal
+ *                         draw (gaussian.py:265-268), zero where mode="random"/"sequential" keeps a coordinate
+ *   u_acc f64 [Tl][W]     accept uniforms (mh.py:157)
+ *   keep_out u8 [Tl][W]   accept mask, or NULL */
+int hens_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out);
+/* Device-side draws for hens_step: with probability `weight` an iteration is a Gaussian MH proposal
+ * instead of the stretch move (the reference's weighted move mix, ensemble.py:971).  kind 0: isotropic,
+ * scale[1] = standard deviation; 1: axis-aligned, scale[D] = standard deviations; 2: full covariance,
+ * scale[D*D] = lower Cholesky factor, row-major.  kind < 0 switches the mix off. */
+int hens_set_mh_proposal(hens_ctx* ctx, int32_t kind, const double* scale, double weight);
+/* accept counts [Tl][W] and number of MH proposals so far (Move.accepted / num_proposals of the MH move). */
+int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals);
+
 /* ---- Ladder pipeline: sharded stepping by neighbour exchange (one process per GPU) ------------------
  * No reference counterpart (the reference has no distributed path; it walks the whole ladder in one
  * process, tempering.py:598-649).  Each rank keeps a contiguous rung range (rank 0 = coldest rungs)
