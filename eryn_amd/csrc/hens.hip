@@ -91,8 +91,17 @@ struct hens_ctx_impl {
         size_t box_bytes = 0;
         std::vector<char*> boxes;          // every rank's mailbox as mapped into this process
         std::vector<char> opened;          // 1: mapped through hipIpcOpenMemHandle (to be closed)
+        const double* pool_cold = nullptr; // cold neighbour's walker pool as mapped here
+        bool pool_cold_opened = false;
         char** d_boxes = nullptr;
         double* Lcur = nullptr; double* Pcur = nullptr; int32_t* botsrc = nullptr;
+        unsigned* tickets = nullptr;
+        unsigned long long* stats = nullptr;   // HENS_PIPE_STATS: wait ticks / waits per site
+        uint32_t pub_count = 0;            // cumulative workgroups of the hottest rung that have published
+        // swap counts whose ladder adaptation has not been applied yet (oldest first; at most delay + 1)
+        struct Pending { const uint32_t* src; uint32_t sweep; bool adaptive; } pend[3];
+        int npend = 0;
+        uint32_t due_sweep = 0;            // sweep whose counts the current adapt_pending refers to
         uint32_t sweep = 0;
         long long budget = 0;              // wall-clock ticks a flag wait may take
     } pipe;
@@ -406,6 +415,11 @@ bool pipe_has_top(const hens_ctx_impl* c) { return c->cfg.rung_end < c->T; }
 bool pipe_has_bot(const hens_ctx_impl* c) { return c->cfg.rung_begin > 0; }
 bool pipe_active(const hens_ctx_impl* c) { return c->pipe.on && c->pipe.connected; }
 
+bool pipe_publish_fused(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_PIPE_SEPARATE_PUB") != nullptr;     // A/B knob
+    return !off && is_fast_dim(c->D);
+}
+
 PipeArgs pipe_args(hens_ctx_impl* c) {
     PipeArgs a{};
     a.pool = c->pool;
@@ -416,10 +430,14 @@ PipeArgs pipe_args(hens_ctx_impl* c) {
     a.box = c->pipe.box;
     a.box_hot = pipe_has_top(c) ? c->pipe.boxes[c->pipe.rank + 1] : nullptr;
     a.box_cold = pipe_has_bot(c) ? c->pipe.boxes[c->pipe.rank - 1] : nullptr;
+    a.pool_cold = c->pipe.pool_cold;
+    a.home_off = (c->parity ^ 1) * c->Tl * c->W;      // the stretch move of this iteration has already flipped parity
     a.boxes = c->pipe.d_boxes;
     a.Lcur = c->pipe.Lcur; a.Pcur = c->pipe.Pcur; a.botsrc = c->pipe.botsrc;
     a.swap_part = c->swap_part;
     a.flags = c->flags;
+    a.tickets = c->pipe.tickets;
+    a.stats = c->pipe.stats;
     a.iter = c->iter; a.seed = c->cfg.seed;
     a.sweep = c->pipe.sweep;
     a.budget = c->pipe.budget;
@@ -442,14 +460,6 @@ void pipe_wait(hens_ctx_impl* c, std::initializer_list<int> which, bool counts, 
     w.target = target;
     hipLaunchKernelGGL(k_pipe_wait, dim3(1), dim3(64), 0, c->stream, w);
 }
-// raise up to two flags in peers' mailboxes once everything queued before has completed
-void pipe_flag(hens_ctx_impl* c, char* box0, int which0, char* box1, int which1, uint32_t value) {
-    unsigned* f0 = box0 ? pipe_box(box0, c->T, c->W, c->D).flags + which0 : nullptr;
-    unsigned* f1 = box1 ? pipe_box(box1, c->T, c->W, c->D).flags + which1 : nullptr;
-    if (!f0 && !f1) return;
-    hipLaunchKernelGGL(k_pipe_flag, dim3(1), dim3(2), 0, c->stream, f0, f1, value);
-}
-
 // before the stretch move of sweep s > 0: the rows that arrived in sweep s-1 and (if a ladder adaptation is
 // pending) every rank's swap counts must be here.  The fast stretch kernel waits in its own prologue
 // (wmask); other row widths get a wait kernel.
@@ -457,20 +467,28 @@ unsigned long long pipe_prewait_mask(const hens_ctx_impl* c) {
     if (!pipe_active(c) || c->pipe.sweep == 0) return 0ull;
     unsigned long long m = 0;
     if (pipe_has_top(c)) m |= 1ull << PF_ROWS_TOP;
-    if (pipe_has_bot(c)) m |= 1ull << PF_ROWS_BOT;
     if (c->adapt_pending && c->adapt_src != nullptr && c->pipe.nranks > 1)
         for (int q = 0; q < c->pipe.nranks; ++q) m |= 1ull << (PF_CNT0 + q);
     return m;
 }
+// make the oldest queued adaptation the pending one if it is due (more than `delay` sweeps are queued, or `all`)
+void pipe_promote_pending(hens_ctx_impl* c, bool all) {
+    if (c->adapt_pending || c->pipe.npend == 0) return;
+    if (!all && c->pipe.npend <= c->cfg.adaptation_delay) return;
+    const auto e = c->pipe.pend[0];
+    for (int i = 1; i < c->pipe.npend; ++i) c->pipe.pend[i - 1] = c->pipe.pend[i];
+    c->pipe.npend -= 1;
+    c->adapt_src = e.src;
+    c->adapt_nblocks = 1;
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = e.adaptive;
+    c->pipe.due_sweep = e.sweep;
+}
 void pipe_prewait(hens_ctx_impl* c) {
     const unsigned long long m = pipe_prewait_mask(c);
     if (!m || is_fast_dim(c->D)) return;
-    const bool cnt = (m >> PF_CNT0) != 0;
-    const bool top = (m >> PF_ROWS_TOP) & 1, bot = (m >> PF_ROWS_BOT) & 1;
-    if (top && bot) pipe_wait(c, {PF_ROWS_TOP, PF_ROWS_BOT}, cnt, c->pipe.sweep);
-    else if (top) pipe_wait(c, {PF_ROWS_TOP}, cnt, c->pipe.sweep);
-    else if (bot) pipe_wait(c, {PF_ROWS_BOT}, cnt, c->pipe.sweep);
-    else pipe_wait(c, {}, cnt, c->pipe.sweep);
+    if ((m >> PF_ROWS_TOP) & 1) pipe_wait(c, {PF_ROWS_TOP}, false, c->pipe.sweep);
+    if ((m >> PF_CNT0) != 0) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);
 }
 
 // one PT sweep of the sharded ladder (tempering.py:598-649 across ranks); see hens_kernels.h
@@ -479,27 +497,29 @@ void pipe_sweep(hens_ctx_impl* c) {
     const PipeArgs a = pipe_args(c);
     const uint32_t done = c->pipe.sweep + 1;
     const int TE = c->Tl + (top ? 1 : 0);
-    if (top) hipLaunchKernelGGL(k_pipe_pub, dim3(1), dim3(1024), 0, c->stream, a);            // raises the neighbour's PF_LDN
-    hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);   // waits for PF_LUP
-    pipe_flag(c, bot ? a.box_cold : nullptr, PF_LUP, top ? a.box_hot : nullptr, PF_ROWS_BOT, done);
-    hipLaunchKernelGGL(k_pipe_counts, dim3(1), dim3(1024), (size_t)(TE + 1) * 4, c->stream, a, pt_blocks(c));
-    if (bot) {
-        hipLaunchKernelGGL(k_pipe_bottom, dim3((c->W + PIPE_COLS - 1) / PIPE_COLS), dim3(256), 0, c->stream, a);   // waits for PF_LDN (+ PF_ROWS_TOP)
-        pipe_flag(c, a.box_cold, PF_ROWS_TOP, nullptr, 0, done);
-    }
+    if (top && !pipe_publish_fused(c))   // (the fast stretch kernels publish from their accept phase)
+        hipLaunchKernelGGL(k_pipe_pub, dim3(1), dim3(1024), 0, c->stream, a);                 // raises the neighbour's PF_LDN
+    // waits for PF_LUP; its last workgroup raises the cold neighbour's PF_LUP and publishes my swap counts
+    hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);
+    if (bot)   // waits for PF_LDN (+ PF_ROWS_TOP); moves the rows both ways; its last workgroup raises the cold neighbour's PF_ROWS_TOP
+        hipLaunchKernelGGL(k_pipe_bottom, dim3((c->W + PIPE_COLS - 1) / PIPE_COLS), dim3(256), 0, c->stream, a);
     const PipeBox me = pipe_box(c->pipe.box, c->T, c->W, c->D);
-    c->adapt_src = me.counts + (size_t)a.par * c->T;
-    c->adapt_nblocks = 1;
-    c->adapt_pending = true;
-    c->adapt_pending_adaptive = c->cfg.adaptive != 0;
+    c->pipe.pend[c->pipe.npend++] = {me.counts + (size_t)(c->pipe.sweep & 3u) * c->T, c->pipe.sweep, c->cfg.adaptive != 0};
     c->cur ^= 1;
     c->pipe.sweep += 1;
+    pipe_promote_pending(c, false);
 }
 
-// the pending adaptation needs every rank's counts of the last sweep
+// apply the adaptations that are due (end of a hens_step call): each needs every rank's counts of its sweep.
+// With adaptation_delay = 1 the newest sweep's counts stay queued across calls, so the chain does not depend
+// on how the iterations are split into calls.
 void pipe_flush_adapt(hens_ctx_impl* c) {
-    if (c->adapt_pending && c->adapt_src && c->pipe.nranks > 1) pipe_wait(c, {}, true, c->pipe.sweep);
-    flush_adapt(c);
+    for (;;) {
+        pipe_promote_pending(c, false);
+        if (!c->adapt_pending) break;
+        if (c->adapt_src && c->pipe.nranks > 1) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);
+        flush_adapt(c);
+    }
 }
 
 // plan nb iterations starting at iteration `iter0` into draw buffer `which`
@@ -527,7 +547,9 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
         if (a.wmask) {
             a.wflags = pipe_box(c->pipe.box, c->T, c->W, c->D).flags;
             a.wtarget = c->pipe.sweep;
+            a.wtarget_cnt = c->pipe.due_sweep + 1;
             a.wbudget = c->pipe.budget;
+            a.wstats = c->pipe.stats;
         }
     }
     if (!c->adapt_pending) return;
@@ -542,9 +564,26 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
         c->adapt_src = nullptr;
         c->bcur ^= 1;
     } else {
-        if (pipe_active(c)) pipe_flush_adapt(c);      // the counts of every rank first
-        else flush_adapt(c);
+        if (pipe_active(c) && c->adapt_src && c->pipe.nranks > 1) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);   // every rank's counts first
+        flush_adapt(c);
         a.betas = c->betas[c->bcur];
+    }
+}
+
+// ladder pipeline: this launch (one of the iteration's move launches; `final` = the last one) publishes the
+// hottest resident rung's (L, P) to the hot neighbour; ntiles = workgroups per rung of this launch
+void attach_publish(hens_ctx_impl* c, StretchArgs& a, bool final, int ntiles) {
+    if (!pipe_active(c) || !pipe_has_top(c) || !pipe_publish_fused(c)) return;
+    const PipeBox hot = pipe_box(c->pipe.boxes[c->pipe.rank + 1], c->T, c->W, c->D);
+    a.pub_lp = hot.lp_dn + (size_t)(c->pipe.sweep & 1u) * 2 * c->W;
+    a.pub_flag = hot.flags + PF_LDN;
+    a.pub_meta = hot.meta + (c->pipe.sweep & 1u);
+    a.pub_ticket = c->pipe.tickets + 2;
+    a.pub_value = c->pipe.sweep + 1;
+    a.pub_final = final ? 1 : 0;
+    if (final) {
+        c->pipe.pub_count += (uint32_t)ntiles;
+        a.pub_target = c->pipe.pub_count;
     }
 }
 
@@ -558,6 +597,7 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
         a.home_off = c->parity * Tl * W;
         if (split == 0) attach_iteration_head(c, a);
         const int Ns = split == 0 ? c->N0 : W - c->N0;
+        attach_publish(c, a, split == 1, (Ns + TILE - 1) / TILE);
         if (evs) {           // per-kernel timing: the dispatch packet's own begin/end timestamps
             c->ext_start = new_event(c);
             c->ext_stop = new_event(c);
@@ -598,6 +638,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs) {
     a.accepted = c->accepted_mh;
     a.keep_out = want_keep ? c->mh_keep : nullptr;
     attach_iteration_head(c, a);
+    attach_publish(c, a, true, (c->W + TILE - 1) / TILE);
     if (evs) {
         c->ext_start = new_event(c);
         c->ext_stop = new_event(c);
@@ -663,6 +704,7 @@ const char* hens_last_error(const hens_ctx* ctx) {
 int hens_create(const hens_config* cfg, hens_ctx** out) {
     if (!cfg || !out) return fail(nullptr, HENS_ERR_INVALID, "null argument");
     *out = nullptr;
+    if (cfg->adaptation_delay != 0 && cfg->adaptation_delay != 1) return fail(nullptr, HENS_ERR_INVALID, "adaptation_delay must be 0 or 1");
     if (cfg->ntemps < 1 || cfg->nwalkers < 2 || cfg->ndim < 1)
         return fail(nullptr, HENS_ERR_INVALID, "invalid shape ntemps=%d nwalkers=%d ndim=%d", cfg->ntemps,
                     cfg->nwalkers, cfg->ndim);
@@ -783,6 +825,7 @@ void hens_destroy(hens_ctx* ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t q = 0; q < c->pipe.boxes.size(); ++q)
         if (c->pipe.opened[q] && c->pipe.boxes[q]) (void)hipIpcCloseMemHandle(c->pipe.boxes[q]);
+    if (c->pipe.pool_cold_opened) (void)hipIpcCloseMemHandle(const_cast<double*>(c->pipe.pool_cold));
     if (c->pipe.box) (void)hipFree(c->pipe.box);
     for (void* p : c->allocs)
         if (p) (void)hipFree(p);
@@ -1163,6 +1206,8 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (c->Tl != c->T && !piped)
         return fail(c, HENS_ERR_STATE, "hens_step on a ladder shard needs the pipeline connected (hens_pipe_init / hens_pipe_connect)");
     if (piped && !has_pt(c)) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
+    if (!piped && c->cfg.adaptation_delay != 0)
+        return fail(c, HENS_ERR_UNSUPPORTED, "adaptation_delay is an option of the ladder pipeline (hens_pipe_*)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
         return fail(c, HENS_ERR_UNSUPPORTED, "hens_step needs a device likelihood (host-callable likelihoods step through hens_propose_split / hens_accept_split)");
@@ -1563,7 +1608,7 @@ int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals
 }
 
 // ---- ladder pipeline set-up -------------------------------------------------------------------------
-int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* handle_out, int64_t* box_bytes_out) {
+int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_out, int64_t* box_bytes_out) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->pipe.on) return fail(c, HENS_ERR_STATE, "pipeline already initialised");
@@ -1589,16 +1634,23 @@ int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* handle_
     if ((r = dalloc(c, &c->pipe.Pcur, (size_t)c->W))) return r;
     if ((r = dalloc(c, &c->pipe.botsrc, (size_t)c->W))) return r;
     if ((r = dalloc(c, &c->pipe.d_boxes, (size_t)nranks))) return r;
+    if ((r = dalloc(c, &c->pipe.tickets, (size_t)4))) return r;
+    HIPCHK(c, hipMemsetAsync(c->pipe.tickets, 0, 16, c->stream));
+    if (getenv("HENS_PIPE_STATS")) {
+        if ((r = dalloc(c, &c->pipe.stats, (size_t)16))) return r;
+        HIPCHK(c, hipMemsetAsync(c->pipe.stats, 0, 128, c->stream));
+    }
     int khz = 0;
     (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device_id);
     const double secs = getenv("HENS_PIPE_TIMEOUT_S") ? atof(getenv("HENS_PIPE_TIMEOUT_S")) : 20.0;
     c->pipe.budget = (long long)((khz > 0 ? khz : 100000) * 1000.0 * secs);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (handle_out) {
-        hipIpcMemHandle_t h;
-        HIPCHK(c, hipIpcGetMemHandle(&h, box));
-        static_assert(sizeof(hipIpcMemHandle_t) == HENS_IPC_HANDLE_BYTES, "IPC handle size");
-        memcpy(handle_out, &h, sizeof h);
+    if (blob_out) {       // [mailbox handle | pool handle]
+        hipIpcMemHandle_t h[2];
+        HIPCHK(c, hipIpcGetMemHandle(&h[0], box));
+        HIPCHK(c, hipIpcGetMemHandle(&h[1], c->pool));
+        static_assert(sizeof(h) == HENS_PIPE_BLOB_BYTES, "IPC blob size");
+        memcpy(blob_out, h, sizeof h);
     }
     if (box_bytes_out) *box_bytes_out = (int64_t)bytes;
     c->pipe.on = true;
@@ -1615,23 +1667,40 @@ static int pipe_finish_connect(hens_ctx_impl* c) {
     return HENS_OK;
 }
 
-int hens_pipe_connect(hens_ctx* ctx, const void* handles) {
+int hens_pipe_connect(hens_ctx* ctx, const void* blobs) {
     hens_ctx_impl* c = CTX(ctx);
-    if (!c || !handles) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (!c || !blobs) return fail(c, HENS_ERR_INVALID, "null argument");
     if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
     if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    const char* hb = static_cast<const char*>(handles);
+    const char* hb = static_cast<const char*>(blobs);
     for (int q = 0; q < c->pipe.nranks; ++q) {
         if (q == c->pipe.rank) continue;
-        hipIpcMemHandle_t h;
-        memcpy(&h, hb + (size_t)q * sizeof h, sizeof h);
+        hipIpcMemHandle_t h[2];
+        memcpy(h, hb + (size_t)q * sizeof h, sizeof h);
         void* p = nullptr;
-        HIPCHK(c, hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        HIPCHK(c, hipIpcOpenMemHandle(&p, h[0], hipIpcMemLazyEnablePeerAccess));
         c->pipe.boxes[q] = static_cast<char*>(p);
         c->pipe.opened[q] = 1;
+        if (q == c->pipe.rank - 1) {          // rows that move up are pulled out of the cold neighbour's pool
+            void* pp = nullptr;
+            HIPCHK(c, hipIpcOpenMemHandle(&pp, h[1], hipIpcMemLazyEnablePeerAccess));
+            c->pipe.pool_cold = static_cast<const double*>(pp);
+            c->pipe.pool_cold_opened = true;
+        }
     }
     return pipe_finish_connect(c);
+}
+
+int hens_pipe_debug_stats(hens_ctx* ctx, uint64_t* out16, int32_t reset) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !out16) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (!c->pipe.stats) return fail(c, HENS_ERR_STATE, "set HENS_PIPE_STATS=1 before hens_pipe_init");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipMemcpyAsync(out16, c->pipe.stats, 128, hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIPCHK(c, hipMemsetAsync(c->pipe.stats, 0, 128, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
 }
 
 int hens_pipe_connect_local(hens_ctx* ctx, hens_ctx* const* peers) {
@@ -1645,6 +1714,7 @@ int hens_pipe_connect_local(hens_ctx* ctx, hens_ctx* const* peers) {
             o->D != c->D)
             return fail(c, HENS_ERR_INVALID, "peer %d is not an initialised pipeline context of the same ladder", q);
         c->pipe.boxes[q] = o->pipe.box;
+        if (q == c->pipe.rank - 1) c->pipe.pool_cold = o->pool;
     }
     return pipe_finish_connect(c);
 }

@@ -89,10 +89,55 @@ __device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits,
 enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
                   PURPOSE_PTU = 10, PURPOSE_MH_ACC = 11, PURPOSE_MH_NORMAL = 12, PURPOSE_MOVE = 13 };
 
-// The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
+// ---------------------------------------------------------------------------------------------
+// Ladder-pipeline primitives (used by the stretch kernels too; the protocol is described at k_pipe_*).
+// ---------------------------------------------------------------------------------------------
+// mailbox flag words (sweep counters raised by the peers)
+enum { PF_LUP = 0, PF_LDN = 1, PF_ROWS_TOP = 2, PF_CNT0 = 8, PIPE_FLAG_WORDS = 64 };
+
+// Ticket: a workgroup whose own stores have completed takes a number; the call returns true in the LAST
+// workgroup of the launch, which may then raise flags on behalf of the whole grid (no extra launch, no
+// L2 write-back: the data the flags cover was written with write-through stores).
+__device__ __forceinline__ bool pipe_last_block(unsigned* ticket, unsigned nblocks, uint32_t sweep) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old + 1u) == nblocks * (sweep + 1u);      // tickets are cumulative over the sweeps (mod 2^32)
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// peer memory is written and read with system-scope accesses (sc0 sc1: nothing lingers in a cache)
+__device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+
+// Flag discipline: everything a peer reads is stored with system-scope write-through stores (sys_store),
+// so raising a flag only needs those stores COMPLETE (s_waitcnt vmcnt(0)), not an L2 write-back: the
+// compiler's system-scope release would write back the whole L2 - megabytes of dirty walker rows that
+// no peer ever reads - and costs ~5 us per flag.
+__device__ __forceinline__ void pipe_raise(unsigned* f, uint32_t v) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// same with an explicit cumulative target (launches of different grid sizes share one ticket)
+__device__ __forceinline__ bool pipe_last_ticket(unsigned* ticket, uint32_t target) {
+    __shared__ int s_last_t;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last_t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == target;
+    __syncthreads();
+    return s_last_t != 0;
+}
+
 // a workgroup's thread 0 spins until flag >= target (or the budget runs out: a peer died - fail the run
 // instead of hanging the GPU); callers follow with __syncthreads()
-__device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, long long budget, unsigned* err) {
+__device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, long long budget, unsigned* err,
+                                          unsigned long long* stats = nullptr) {
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
         __builtin_amdgcn_s_sleep(2);
@@ -100,6 +145,10 @@ __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, lo
             atomicOr(err, FLAG_PIPE_TIMEOUT);
             return;
         }
+    }
+    if (stats) {                       // debug (HENS_PIPE_STATS): ticks spent waiting and number of waits at this site
+        atomicAdd(stats, (unsigned long long)(wall_clock64() - t0));
+        atomicAdd(stats + 1, 1ull);
     }
 }
 
@@ -109,6 +158,7 @@ __device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_del
     return loc >= 0 ? (int64_t)loc * D : guest_delta + (int64_t)(~loc) * D;
 }
 
+// The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
 struct Draws {
     int32_t* own;    // [Tl][W] moving walker at each split position (positions < N0: split 0)
     int32_t* cw;     // [Tl][W] its complement walker
@@ -166,11 +216,19 @@ struct StretchArgs {
     int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
     int64_t guest_delta;       // see row_off (0 when there is no pipeline)
     const double* mh_step;     // MODE_MH: [Tl][W][D] proposal steps
+    // ladder pipeline: the hottest resident rung's (L, P) after this move go straight to the hot neighbour
+    double* pub_lp;            // neighbour's lp_dn for this sweep: [2][W], or nullptr
+    unsigned* pub_flag;        // neighbour's PF_LDN, raised by the last workgroup of the iteration's last launch
+    unsigned* pub_ticket;
+    uint32_t pub_target, pub_value;
+    int32_t pub_final;
+    long long* pub_meta;       // neighbour's meta[par]: receives the pool row of (hottest rung, slot 0) after this move
     // ladder pipeline: before touching the state, wait until the mailbox flags selected by wmask reach wtarget
     const unsigned* wflags;
     unsigned long long wmask;
     long long wbudget;
-    uint32_t wtarget;
+    uint32_t wtarget, wtarget_cnt;   // rows flags / swap-count flags (PF_CNT0..)
+    unsigned long long* wstats;      // debug wait statistics or nullptr
     AdaptArgs ad;
 };
 
@@ -522,7 +580,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     HENS_TRACE(0);
     if (!EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
-        if (wv == 0 && ((A.wmask >> lane) & 1ull)) pipe_spin(A.wflags + lane, A.wtarget, A.wbudget, A.flags);
+        if (wv == 0 && ((A.wmask >> lane) & 1ull))
+            pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
+                      A.wstats ? A.wstats + (lane >= PF_CNT0 ? 2 : 0) : nullptr);
         __syncthreads();
     }
 
@@ -809,11 +869,16 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             }
             const double lnpdiff = factors + logP - prevP;     // red_blue.py:292
             const bool keep = lnpdiff > lu;                    // red_blue.py:294
+            const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;
             if (keep) {                                        // move.py:513-532
                 A.L[gi] = logl;
-                A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
+                A.P[gi] = newP;
                 atomicAdd(&A.accepted[gi], 1u);
                 atomicOr(&s_flag[lane], 2);
+            }
+            if (A.pub_lp && tl == A.Tl - 1) {                  // ladder pipeline: what the hot neighbour's bottom pair needs
+                sys_store(A.pub_lp + own, keep ? logl : Lold);
+                sys_store(A.pub_lp + W + own, keep ? newP : Pold);
             }
             A.loc[gi] = s_dst[lane];
             if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
@@ -832,6 +897,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
         store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
     }
+    if (A.pub_lp && A.pub_final && tl == A.Tl - 1)             // every walker of the rung has published: tell the neighbour
+        if (pipe_last_ticket(A.pub_ticket, A.pub_target) && tid == 0) {
+            __hip_atomic_store(A.pub_meta, (long long)A.home_off + (long long)tl * W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            pipe_raise(A.pub_flag, A.pub_value);
+        }
     HENS_TRACE(7);
 #undef HENS_TRACE
 }
@@ -1507,40 +1577,43 @@ __global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ l
 // cold (tempering.py:515-541), so the only true dependency between ranks is "the column state at the
 // top of my rungs", which the hot neighbour knows when ITS walk is done.  Per sweep and boundary
 // (hot rung e on rank r+1, cold rung e-1 on rank r):
-//   r   -> r+1 : (L, P) of rung e-1 after the stretch move, slot order            [k_pipe_pub]
+//   r   -> r+1 : (L, P) of rung e-1 after the stretch move, slot order, + where its rows are
+//                                                       [stretch kernel, phase D; k_pipe_pub for generic D]
 //   r+1 -> r   : (L, P) of the walker each column carries on leaving rung e       [k_pipe_walk]
-//   both sides evaluate the boundary pair from identical Philox draws; then
-//   r   -> r+1 : rows of the walkers that move up   (sparse, indexed by column)   [k_pipe_top]
-//   r+1 -> r   : rows of the walkers that move down (sparse, indexed by column)   [k_pipe_bottom]
-//   every rank -> all ranks: swap counts of the pairs it owns (ladder adaptation) [k_pipe_counts]
-// Every message is a kernel that stores straight into the peer's MAILBOX (uncached device memory,
-// peer-mapped through HIP IPC: xGMI stores on a multi-GPU node) followed by a flag; the consumer's
-// stream waits on the flag (k_pipe_wait).  No host round trip, no packing, no counts: a row that
-// moves lands in the guest area at its COLUMN index, and `loc` simply points there (row_off) until
-// the next stretch move rewrites every walker into its home row anyway.
-// Mailbox buffers are double-buffered by sweep parity; the flag protocol itself keeps a rank at
-// most one sweep ahead of its neighbours.
+//   both sides evaluate the boundary pair from identical Philox draws; then the HOT side moves the rows
+//   in both directions, so that its next iteration never waits for the (lagging) cold side's walk:
+//   r+1 -> r   : PUSH the rows that move down (sparse, at their column index)     [k_pipe_bottom]
+//   r+1 <- r   : PULL the rows that move up straight out of rank r's pool         [k_pipe_bottom]
+//   every rank -> all ranks: swap counts of the pairs it owns (ladder adaptation) [k_pipe_walk, last workgroup]
+// Every message is a store straight into the peer's MAILBOX (uncached device memory, peer-mapped
+// through HIP IPC: xGMI stores on a multi-GPU node) followed by a flag raised by the last workgroup of
+// the producing launch; the consuming kernel spins on the flag in its prologue.  No host round trip,
+// no packing, no counts, no extra launches: a row that moves lands in a guest area at its COLUMN index,
+// and `loc` simply points there (row_off) until the next stretch move rewrites every walker into its
+// home row anyway.  Mailbox buffers are double-buffered by sweep parity; the flag protocol itself keeps
+// a rank at most one sweep ahead of its neighbours.
 // ---------------------------------------------------------------------------------------------
-enum { PF_LUP = 0, PF_LDN = 1, PF_ROWS_TOP = 2, PF_ROWS_BOT = 3, PF_CNT0 = 8, PIPE_FLAG_WORDS = 64 };
 constexpr int PIPE_MAX_RANKS = PIPE_FLAG_WORDS - PF_CNT0;
 
 struct PipeBox {
     unsigned* flags;       // [PIPE_FLAG_WORDS] sweep counters raised by the peers
-    unsigned* counts;      // [2][T] accepted swaps per pair (index i-1 for pair (i, i-1)), written by the pair's owner
+    long long* meta;       // [32]: [par] = pool row of slot 0 of the cold neighbour's hottest rung after its stretch move
+    unsigned* counts;      // [4][T] accepted swaps per pair (index i-1 for pair (i, i-1)), written by the pair's owner; buffer = sweep & 3
     double* lp_up;         // [2][2][W] (L, P) carried by each column of the hot neighbour (column order)
     double* lp_dn;         // [2][2][W] (L, P) of the cold neighbour's hottest rung after its stretch move (slot order)
     double* guest;         // [2][2][W][D] arrived rows: side 0 = from the hot neighbour, side 1 = from the cold one
 };
 __host__ __device__ inline size_t pipe_round(size_t n) { return (n + 255) & ~(size_t)255; }
 __host__ __device__ inline size_t pipe_box_bytes(int T, int W, int D) {
-    return pipe_round(PIPE_FLAG_WORDS * 4) + pipe_round((size_t)2 * T * 4) + 2 * pipe_round((size_t)4 * W * 8) +
+    return pipe_round(PIPE_FLAG_WORDS * 4) + 256 + pipe_round((size_t)4 * T * 4) + 2 * pipe_round((size_t)4 * W * 8) +
            pipe_round((size_t)4 * W * D * 8);
 }
 __host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
     PipeBox b;
     size_t off = 0;
     b.flags = reinterpret_cast<unsigned*>(base + off); off += pipe_round(PIPE_FLAG_WORDS * 4);
-    b.counts = reinterpret_cast<unsigned*>(base + off); off += pipe_round((size_t)2 * T * 4);
+    b.meta = reinterpret_cast<long long*>(base + off); off += 256;
+    b.counts = reinterpret_cast<unsigned*>(base + off); off += pipe_round((size_t)4 * T * 4);
     b.lp_up = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
     b.lp_dn = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
     b.guest = reinterpret_cast<double*>(base + off);
@@ -1548,10 +1621,6 @@ __host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
 }
 // guest row index of column c (sweep parity par, side) and its `loc` encoding
 __host__ __device__ inline int32_t pipe_guest_loc(int par, int side, int W, int c) { return ~((par * 2 + side) * W + c); }
-
-// peer memory is written and read with system-scope accesses (sc0 sc1: nothing lingers in a cache)
-__device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 struct PipeArgs {
     const double* pool;
@@ -1562,14 +1631,18 @@ struct PipeArgs {
     char* box;                    // my mailbox
     char* box_hot;                // hot neighbour's (rank + 1) or nullptr
     char* box_cold;               // cold neighbour's (rank - 1) or nullptr
+    const double* pool_cold;      // cold neighbour's walker pool (rows that move up are read from it)
     char* const* boxes;           // [nranks] every mailbox (swap counts)
     double* Lcur; double* Pcur; int32_t* botsrc;              // [W] what each column carries below my coldest rung
     uint32_t* swap_part;          // [nblocks][TE-1]
     unsigned* flags;              // context error flags
+    unsigned* tickets;            // [4] workgroup tickets: 0 walk, 1 bottom, 2 stretch publish
+    unsigned long long* stats;    // debug wait statistics [16] (pairs: ticks, waits) or nullptr
     uint64_t iter, seed;
     uint32_t sweep;               // pipeline sweep counter (flags carry sweep + 1)
     long long budget;             // wall-clock ticks a flag wait may take
     int32_t T, W, D, Tl, rung_begin, idx_bits, par, nranks, rank;
+    int32_t home_off;             // pool row of (rung 0, slot 0) after this iteration's stretch move
 };
 
 __device__ __forceinline__ int pipe_slot(const PipeArgs& A, int g, int c) {
@@ -1582,15 +1655,6 @@ __device__ __forceinline__ double pipe_logu(const PipeArgs& A, int i, int c) {
     const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), (uint32_t)((A.T - 1 - i) * A.W + c), PURPOSE_PTU};
     const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
     return log(u01(d.x, d.y));                                       // tempering.py:535
-}
-
-// Flag discipline: everything a peer reads is stored with system-scope write-through stores (sys_store),
-// so raising a flag only needs those stores COMPLETE (s_waitcnt vmcnt(0)), not an L2 write-back: the
-// compiler's system-scope release would write back the whole L2 - megabytes of dirty walker rows that
-// no peer ever reads - and costs ~5 us per flag.
-__device__ __forceinline__ void pipe_raise(unsigned* f, uint32_t v) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct PipeWaitArgs {
@@ -1608,12 +1672,8 @@ __global__ void k_pipe_wait(const PipeWaitArgs A) {
     else if (A.cnt_flags && i - A.n < A.nranks) f = A.cnt_flags + (i - A.n);
     if (f) pipe_spin(f, A.target, A.budget, A.err);
 }
-__global__ void k_pipe_flag(unsigned* f0, unsigned* f1, uint32_t v) {
-    unsigned* f = threadIdx.x == 0 ? f0 : f1;
-    if (f) pipe_raise(f, v);
-}
-
-// my hottest rung after the stretch move -> hot neighbour, flag included (one workgroup)
+// my hottest rung after the stretch move -> hot neighbour, flag included (one workgroup).  Only for row widths
+// without a fast stretch kernel: those publish from their own accept phase (StretchArgs::pub_lp).
 __global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
     const PipeBox hot = pipe_box(A.box_hot, A.T, A.W, A.D);
     const int W = A.W;
@@ -1622,6 +1682,8 @@ __global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
         const int w = i < W ? i : i - W;
         sys_store(hot.lp_dn + (size_t)(A.par * 2 + (i < W ? 0 : 1)) * W + w, i < W ? A.L[base + w] : A.P[base + w]);
     }
+    if (threadIdx.x == 0)
+        __hip_atomic_store(hot.meta + A.par, (long long)A.home_off + (long long)(A.Tl - 1) * W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) pipe_raise(hot.flags + PF_LDN, A.sweep + 1);
@@ -1631,8 +1693,7 @@ constexpr int PIPE_COLS = 64;       // columns per workgroup of the bottom-bound
 constexpr int32_t PIPE_NOSEL = INT32_MIN;
 
 // The walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended
-// ladder.  The pair across my top boundary is the first step of every column, so the rows that move UP
-// leave from here too (waves 1.. copy them into the hot neighbour's guest area while wave 0 walks).
+// ladder; the pair across my top boundary is the first step of every column.
 __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int T = A.T, W = A.W, Tl = A.Tl, D = A.D;
@@ -1652,7 +1713,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     const PipeBox me = pipe_box(A.box, T, W, D);
 
     if (has_top) {                                               // what the hot neighbour's columns carry must be here
-        if (tid == 0) pipe_spin(me.flags + PF_LUP, A.sweep + 1, A.budget, A.flags);
+        if (tid == 0) pipe_spin(me.flags + PF_LUP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
         __syncthreads();
     }
     for (int t = tid; t < TE; t += PT_THREADS) sbeta[t] = A.betas[A.rung_begin + t];
@@ -1706,17 +1767,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
                 }
             }
         }
-    } else if (has_top && tid >= 64) {                           // rows that move up across my top boundary
-        const double db = sbeta[Tl - 1] - sbeta[Tl];
-        const PipeBox hot = pipe_box(A.box_hot, T, W, D);
-        double* dst = hot.guest + (size_t)(A.par * 2 + 1) * W * D;
-        for (int idx = tid - 64; idx < PT_COLS * D; idx += PT_THREADS - 64) {
-            const int cc = idx / D, d = idx - cc * D;
-            if (c0 + cc >= W) continue;
-            const int eh = Tl * PT_COLS + cc, el = (Tl - 1) * PT_COLS + cc;
-            if (db * (Lc[eh] - Lc[el]) > lu[eh])                       // the column's first step, recomputed
-                sys_store(dst + (size_t)(c0 + cc) * D + d, A.pool[row_off(locc[el], D, A.guest_delta) + d]);
-        }
     }
     __syncthreads();
 
@@ -1751,27 +1801,61 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     for (int i = 1 + tid; i < TE; i += PT_THREADS) {
         unsigned n = 0;
         for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += bit(cc, i) ? 1u : 0u;
-        A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)] = n;
+        __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+
+    // ---- the last workgroup speaks for the launch: neighbour flags, then the swap counts of my pairs ------
+    if (!pipe_last_block(A.tickets + 0, gridDim.x, A.sweep)) return;
+    if (tid == 0 && has_bot) pipe_raise(cold.flags + PF_LUP, A.sweep + 1);
+    const int NP = TE - 1;
+    unsigned* s_n = reinterpret_cast<unsigned*>(smem_raw);           // [NP] (the column tables are dead)
+    for (int i = tid; i < NP; i += PT_THREADS) s_n[i] = 0;
+    __syncthreads();
+    const int total = (int)gridDim.x * NP;
+    for (int e0 = tid; e0 < total; e0 += 4 * PT_THREADS) {
+        unsigned v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * PT_THREADS;
+            v[q] = e < total ? __hip_atomic_load(&A.swap_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = e0 + q * PT_THREADS;
+            if (v[q]) atomicAdd(&s_n[e % NP], v[q]);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < A.nranks * NP; e += PT_THREADS) {
+        const int q = e / NP, j = e - q * NP;                        // ext pair j+1 = global pair (rung_begin+j+1, rung_begin+j)
+        const PipeBox bx = pipe_box(A.boxes[q], T, W, D);
+        __hip_atomic_store(bx.counts + (size_t)(A.sweep & 3u) * T + (A.rung_begin + j), s_n[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < A.nranks) pipe_raise(pipe_box(A.boxes[tid], T, W, D).flags + PF_CNT0 + A.rank, A.sweep + 1);
 }
 
-// bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, send the rows that move down
+// bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, push the rows that move down into
+// the cold neighbour's guest area and pull the rows that move up out of its pool
 __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     __shared__ int32_t s_src[PIPE_COLS];
+    __shared__ int32_t s_below[PIPE_COLS];
     const int W = A.W, D = A.D, c0 = blockIdx.x * PIPE_COLS;
     const PipeBox me = pipe_box(A.box, A.T, W, D);
     const bool has_top = A.rung_begin + A.Tl < A.T;
     // the cold neighbour's rung after ITS stretch move; a walker may fall through all my rungs in one sweep,
     // so the rows from above must have landed too
-    if (threadIdx.x == 0) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags);
-    if (threadIdx.x == 64 && has_top) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags);
+    if (threadIdx.x == 0) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
+    if (threadIdx.x == 64 && has_top) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
     __syncthreads();
     if (threadIdx.x < PIPE_COLS) {
         const int c = c0 + threadIdx.x;
-        int32_t src = PIPE_NOSEL;
+        int32_t src = PIPE_NOSEL, sb = 0;
         if (c < W) {
             const int g = A.rung_begin;                              // my coldest rung; the pair is (g, g-1)
             const int slot = pipe_slot(A, g, c), slot_below = pipe_slot(A, g - 1, c);
+            sb = slot_below;
             const double La = A.Lcur[c];
             const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
             const double db = A.betas[g - 1] - A.betas[g];
@@ -1783,51 +1867,21 @@ __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
             }
         }
         s_src[threadIdx.x] = src;
+        s_below[threadIdx.x] = sb;
     }
     __syncthreads();
     const PipeBox cold = pipe_box(A.box_cold, A.T, W, D);
-    double* dst = cold.guest + (size_t)(A.par * 2) * W * D;
+    double* dst = cold.guest + (size_t)(A.par * 2) * W * D;                     // rows that move down: push
+    double* mine = me.guest + (size_t)(A.par * 2 + 1) * W * D;                  // rows that move up: pull
+    const long long cold_home = __hip_atomic_load(me.meta + A.par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int idx = threadIdx.x; idx < PIPE_COLS * D; idx += blockDim.x) {
         const int col = idx / D, d = idx - col * D;
         const int32_t src = s_src[col];
-        if (src != PIPE_NOSEL) sys_store(dst + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
+        if (src == PIPE_NOSEL) continue;
+        sys_store(dst + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
+        mine[(size_t)(c0 + col) * D + d] = sys_load(A.pool_cold + (size_t)(cold_home + s_below[col]) * D + d);
     }
-}
-
-// swap counts of the pairs I own (my internal pairs + the pair across my top boundary) -> every rank
-__global__ __launch_bounds__(1024) void k_pipe_counts(const PipeArgs A, int nblocks) {
-    const int T = A.T, Tl = A.Tl;
-    const bool has_top = A.rung_begin + Tl < T;
-    const int TE = Tl + (has_top ? 1 : 0), NP = TE - 1;
-    extern __shared__ unsigned s_n[];                                // [TE]
-    for (int i = threadIdx.x; i < TE; i += blockDim.x) s_n[i] = 0;
-    __syncthreads();
-    const int total = nblocks * NP;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 4 * blockDim.x) {
-        unsigned v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = e0 + q * blockDim.x;
-            v[q] = e < total ? A.swap_part[e] : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = e0 + q * blockDim.x;
-            if (v[q]) atomicAdd(&s_n[e % NP], v[q]);
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < A.nranks * NP; e += blockDim.x) {
-        const int q = e / NP, j = e - q * NP;                        // ext pair j+1 = global pair (rung_begin+j+1, rung_begin+j)
-        const PipeBox bx = pipe_box(A.boxes[q], T, A.W, A.D);
-        __hip_atomic_store(bx.counts + (size_t)A.par * T + (A.rung_begin + j), s_n[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if ((int)threadIdx.x < A.nranks) {
-        const PipeBox bx = pipe_box(A.boxes[threadIdx.x], T, A.W, A.D);
-        pipe_raise(bx.flags + PF_CNT0 + A.rank, A.sweep + 1);
-    }
+    if (pipe_last_block(A.tickets + 1, gridDim.x, A.sweep) && threadIdx.x == 0) pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
 }
 
 }  // namespace hens

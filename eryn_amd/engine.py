@@ -19,7 +19,8 @@ def box_logp_inside(lo, hi):
 class HipEnsemble:
     def __init__(self, ntemps, nwalkers, ndim, likelihood, lo, hi, a=2.0, tempered=None,
                  adaptive=True, adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1,
-                 live_dangerously=False, fill_value=-1e300, seed=0, rung_range=None, device_id=0):
+                 live_dangerously=False, fill_value=-1e300, seed=0, rung_range=None, device_id=0,
+                 adaptation_delay=0):
         self.lib = _lib.load()
         self.T, self.W, self.D = int(ntemps), int(nwalkers), int(ndim)
         if tempered is None:
@@ -31,7 +32,8 @@ class HipEnsemble:
         cfg = HensConfig(ntemps=self.T, nwalkers=self.W, ndim=self.D, rung_begin=r0, rung_end=r1,
                          device_id=int(device_id), likelihood_kind=int(likelihood.kind),
                          tempered=int(bool(tempered)), live_dangerously=int(bool(live_dangerously)),
-                         adaptive=int(bool(adaptive)), stop_adaptation=int(stop_adaptation), a=float(a),
+                         adaptive=int(bool(adaptive)), adaptation_delay=int(adaptation_delay),
+                         stop_adaptation=int(stop_adaptation), a=float(a),
                          fill_value=float(fill_value), adaptation_lag=float(adaptation_lag),
                          adaptation_time=float(adaptation_time), seed=int(seed) & (2**64 - 1))
         self.tempered = bool(tempered)
@@ -229,15 +231,15 @@ class HipEnsemble:
 
     # -- ladder pipeline (include/hipensemble.h: hens_pipe_*) ------------------------------------------
     def pipe_init(self, nranks, rank):
-        """Allocate this shard's mailbox; returns its 64-byte HIP IPC handle."""
-        h = (C.c_ubyte * 64)()
+        """Allocate this shard's mailbox; returns the 128-byte blob of HIP IPC handles (mailbox, walker pool)."""
+        h = (C.c_ubyte * 128)()
         nbytes = C.c_int64(0)
         check(self.lib.hens_pipe_init(self.ctx, int(nranks), int(rank), C.cast(h, C.c_void_p), C.byref(nbytes)), self.ctx)
         self.pipe_bytes = int(nbytes.value)
         return bytes(h)
 
     def pipe_connect(self, handles):
-        """handles: the ranks' IPC handles concatenated in rank order (other processes)."""
+        """handles: the ranks' IPC blobs concatenated in rank order (other processes)."""
         buf = (C.c_ubyte * len(handles)).from_buffer_copy(handles)
         check(self.lib.hens_pipe_connect(self.ctx, C.cast(buf, C.c_void_p)), self.ctx)
 
@@ -245,6 +247,13 @@ class HipEnsemble:
         """All shards live in this process (several contexts on one GPU)."""
         arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
         check(self.lib.hens_pipe_connect_local(self.ctx, C.cast(arr, C.c_void_p)), self.ctx)
+
+    def pipe_debug_stats(self, reset=True):
+        """{site: (seconds waited summed over workgroups, waits)} - needs HENS_PIPE_STATS=1 at pipe_init."""
+        raw = np.zeros(16, dtype=np.uint64)
+        check(self.lib.hens_pipe_debug_stats(self.ctx, ptr(raw), int(bool(reset))), self.ctx)
+        names = ["stretch:rows", "stretch:counts", "walk:columns", "bottom:cold rung", "bottom:rows from above"]
+        return {n: (float(raw[2 * i]) * 1e-8, int(raw[2 * i + 1])) for i, n in enumerate(names)}
 
     def pt_finish_sharded(self, n_recv):
         check(self.lib.hens_pt_finish_sharded(self.ctx, int(n_recv)), self.ctx)

@@ -247,9 +247,14 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     mu, invcov = gaussian_problem(D)
     x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
 
-    def make_engine():
+    mode = os.environ.get("HENS_SHARD_MODE", "pipeline")
+    # With the reference's schedule (delay 0) every rank needs the swap ratios of the WHOLE cascade before its next
+    # accept test, which serialises the ranks; the pipeline's delayed schedule applies them one sweep later.
+    delay = int(os.environ.get("HENS_ADAPT_DELAY", "1")) if (mode == "pipeline" and world > 1 and not force) else 0
+
+    def make_engine(delay=delay):
         e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=(r0, r1),
-                        device_id=local_rank)
+                        device_id=local_rank, adaptation_delay=delay)
         e.upload(x0, betas=make_ladder(D, ntemps=T))
         e.eval_state()
         return e
@@ -258,7 +263,6 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     # Stepping: the ladder pipeline (one-sided neighbour puts over xGMI) unless HENS_SHARD_MODE=collective or
     # the mailboxes cannot be mapped on this node, in which case every rank falls back to the RCCL
     # all-gather / all-to-all orchestration.
-    mode = os.environ.get("HENS_SHARD_MODE", "pipeline")
     stepper = None
     if mode == "pipeline" and not force:
         ok = 1
@@ -273,7 +277,8 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
             ok = int(flag.item())
         if not ok:
             stepper = None
-    transport = "xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline)"
+    transport = ("xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline), ladder adaptation "
+                 + ("on the reference's schedule" if delay == 0 else "applied one sweep late (adaptation_delay=1)"))
     def make_collective(eng):
         return ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank,
                              nranks=world)
@@ -295,6 +300,9 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
         return time.perf_counter() - t0
 
     if stepper is None:
+        if delay:
+            eng.close()
+            eng = make_engine(0)
         stepper = make_collective(eng)
         transport = "RCCL all-gather(logL) + all-to-all(rows)"
         dt = timed_run(stepper, eng)
@@ -311,7 +319,7 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
             ok = int(flag.item())
         if not ok:
             eng.close()
-            eng = make_engine()                       # a fresh context: no mailbox, no pending flags
+            eng = make_engine(0)                      # a fresh context: no mailbox, no pending flags
             stepper = make_collective(eng)
             transport = "RCCL all-gather(logL) + all-to-all(rows) (pipeline failed on this node)"
             dt = timed_run(stepper, eng)

@@ -67,7 +67,9 @@ typedef struct hens_config {
     int32_t tempered;          /* 0: logP = logl + logp (move.py:443-457); 1: betas      */
     int32_t live_dangerously;  /* skip the W >= 2 D guard (red_blue.py:108-114)          */
     int32_t adaptive;          /* ladder adaptation on (tempering.py:632-633)            */
-    int32_t reserved0;
+    int32_t adaptation_delay;  /* ladder pipeline only: 0 = the reference's schedule (the swap ratios of sweep s move the
+                                * ladder before iteration s+1 - every rank then waits for the whole cascade);
+                                * 1 = they move it before iteration s+2, which lets the ranks pipeline          */
     int32_t reserved1;
     int64_t stop_adaptation;   /* < 0: never stop (tempering.py:591)                     */
     double a;                  /* stretch scale                                          */
@@ -239,18 +241,24 @@ int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals
  * No reference counterpart (the reference has no distributed path; it walks the whole ladder in one
  * process, tempering.py:598-649).  Each rank keeps a contiguous rung range (rank 0 = coldest rungs)
  * and a MAILBOX in uncached device memory that its neighbours write into directly (one-sided stores
- * over xGMI through HIP IPC) followed by a flag; the consumer's stream waits on the flag.  After
- *   hens_pipe_init           allocate the mailbox, export its IPC handle
- *   (exchange the handles: torch.distributed all_gather in eryn_amd.ladder)
+ * over xGMI through HIP IPC) followed by a flag the consuming kernel spins on; rows that move up a
+ * boundary are read straight out of the cold neighbour's walker pool (also IPC-mapped).  After
+ *   hens_pipe_init           allocate the mailbox, export the IPC handles (mailbox + pool)
+ *   (exchange the blobs: torch.distributed all_gather in eryn_amd.ladder)
  *   hens_pipe_connect        map every rank's mailbox
  * hens_step(n) on every rank advances the WHOLE ladder by n iterations with device-side draws:
  * the result is bit-identical to one context holding all the rungs.  A neighbour that stops
  * answering makes the waiting rank fail with HENS_ERR_STATE after HENS_PIPE_TIMEOUT_S (default 20 s)
  * instead of hanging the GPU. */
-#define HENS_IPC_HANDLE_BYTES 64
-int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* handle_out /* HENS_IPC_HANDLE_BYTES or NULL */,
+#define HENS_PIPE_BLOB_BYTES 128   /* two HIP IPC handles: the rank's mailbox and its walker pool */
+int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_out /* HENS_PIPE_BLOB_BYTES or NULL */,
                    int64_t* mailbox_bytes_out);
-int hens_pipe_connect(hens_ctx* ctx, const void* handles /* nranks * HENS_IPC_HANDLE_BYTES, rank order */);
+int hens_pipe_connect(hens_ctx* ctx, const void* blobs /* nranks * HENS_PIPE_BLOB_BYTES, rank order */);
+/* Debug (env HENS_PIPE_STATS=1 at hens_pipe_init): where the pipeline waits.  out16 = 8 pairs (wall-clock
+ * ticks spent spinning, number of waits): [0] stretch prologue on arrived rows, [1] stretch prologue on swap
+ * counts, [2] walk on the hot neighbour's columns, [3] bottom on the cold neighbour's rung, [4] bottom on rows
+ * from above.  Ticks are hipDeviceAttributeWallClockRate (100 MHz on MI355X). */
+int hens_pipe_debug_stats(hens_ctx* ctx, uint64_t* out16, int32_t reset);
 /* Same, for contexts that live in ONE process (tests; several shards on one GPU): peers[nranks]. */
 int hens_pipe_connect_local(hens_ctx* ctx, hens_ctx* const* peers);
 

@@ -3,6 +3,7 @@
   local <nranks> <T> <W> <D> <iters> <out.npz>       N shards in this process on one GPU
   ipc   <rank> <world> <T> <W> <D> <iters> <outdir>  one shard per PROCESS, mailboxes mapped through HIP IPC
   single <T> <W> <D> <iters> <out.npz>               the unsharded run both are compared with
+env PIPE_TEST_DELAY=1 runs everything with adaptation_delay = 1 (then "single" is a 1-rank pipeline).
   timeout                                            rank 1 never steps: rank 0 must raise, not hang
 """
 import os
@@ -30,9 +31,13 @@ def problem(T, W, D):
     return mu, invcov, x0, make_ladder(D, ntemps=T)
 
 
-def make(T, W, D, rng_range=None):
+DELAY = int(os.environ.get("PIPE_TEST_DELAY", "0"))      # hens_config.adaptation_delay of every context
+
+
+def make(T, W, D, rng_range=None, delay=None):
     mu, invcov, x0, betas = problem(T, W, D)
-    e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -6.0, 6.0, seed=SEED, rung_range=rng_range)
+    e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -6.0, 6.0, seed=SEED, rung_range=rng_range,
+                    adaptation_delay=DELAY if delay is None else delay)
     r0, r1 = rng_range if rng_range else (0, T)
     e.upload(x0[r0:r1], betas=betas)
     e.eval_state()
@@ -51,6 +56,8 @@ def main():
     if mode == "single":
         T, W, D, iters = map(int, sys.argv[2:6])
         e = make(T, W, D)
+        if DELAY:                                      # the delayed schedule exists in the pipeline only: one rank of it
+            LadderPipeline.connect_local([e])
         for n in (iters // 2, iters - iters // 2):     # two calls: the batch / flush logic at a call boundary
             e.step(n)
         np.savez(sys.argv[6], **snapshot(e))

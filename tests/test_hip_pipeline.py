@@ -21,8 +21,9 @@ WORKER = os.path.join(HERE, "pipeline_worker.py")
 KEYS = ("x", "L", "P", "betas", "accepted", "swaps_total", "swaps_last")
 
 
-def _env(port=None):
+def _env(port=None, delay=0):
     env = dict(os.environ)
+    env["PIPE_TEST_DELAY"] = str(delay)
     env["GPU_MAX_HW_QUEUES"] = "16"          # in-process shards: every stream on its own hardware queue
     env["HENS_PIPE_TIMEOUT_S"] = "10"
     env["MASTER_ADDR"] = "127.0.0.1"
@@ -31,16 +32,17 @@ def _env(port=None):
     return env
 
 
-def _run(args, **kw):
-    return subprocess.run([sys.executable, WORKER] + [str(a) for a in args], env=_env(), capture_output=True, text=True,
-                          timeout=300, **kw)
+def _run(args, delay=0, **kw):
+    return subprocess.run([sys.executable, WORKER] + [str(a) for a in args], env=_env(delay=delay), capture_output=True,
+                          text=True, timeout=300, **kw)
 
 
-def _single(tmp_path, T, W, D, iters):
-    out = tmp_path / "single.npz"
-    r = _run(["single", T, W, D, iters, out])
+def _single(tmp_path, T, W, D, iters, delay=0):
+    out = tmp_path / f"single{delay}.npz"
+    r = _run(["single", T, W, D, iters, out], delay=delay)
     assert r.returncode == 0, r.stdout + r.stderr
-    return np.load(out)
+    with np.load(out) as f:
+        return {k: f[k] for k in f.files}
 
 
 def _compare(ref, got):
@@ -59,12 +61,27 @@ def test_pipeline_local_matches_single_context(tmp_path, nranks, T, W, D, iters)
     assert ref["swaps_total"].sum() > 0           # the boundary pairs really exchanged walkers
 
 
-@pytest.mark.parametrize("world,T,W,D,iters", [(2, 4, 256, 32, 8), (3, 6, 128, 8, 6)])
-def test_pipeline_ipc_processes_match_single_context(tmp_path, world, T, W, D, iters):
-    ref = _single(tmp_path, T, W, D, iters)
+@pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 128, 8, 7), (4, 8, 256, 32, 8)])
+def test_pipeline_delayed_adaptation_is_rank_count_invariant(tmp_path, nranks, T, W, D, iters):
+    """adaptation_delay = 1 (the swap ratios of sweep s move the ladder before iteration s+2, so the ranks need
+    not wait for the whole cascade): N ranks == one rank of the same pipeline, bit for bit; and it differs from
+    the reference schedule only through the adapted ladder."""
+    ref = _single(tmp_path, T, W, D, iters, delay=1)
+    out = tmp_path / "local.npz"
+    r = _run(["local", nranks, T, W, D, iters, out], delay=1)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _compare(ref, np.load(out))
+    exact = _single(tmp_path, T, W, D, iters, delay=0)
+    assert not np.array_equal(exact["betas"], ref["betas"])
+    np.testing.assert_allclose(exact["betas"], ref["betas"], rtol=0.05)
+
+
+@pytest.mark.parametrize("world,T,W,D,iters,delay", [(2, 4, 256, 32, 8, 0), (3, 6, 128, 8, 6, 0), (3, 6, 128, 8, 7, 1)])
+def test_pipeline_ipc_processes_match_single_context(tmp_path, world, T, W, D, iters, delay):
+    ref = _single(tmp_path, T, W, D, iters, delay=delay)
     port = 29500 + (os.getpid() % 2000)
     procs = [subprocess.Popen([sys.executable, WORKER, "ipc", str(r), str(world), str(T), str(W), str(D), str(iters),
-                               str(tmp_path)], env=_env(port), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               str(tmp_path)], env=_env(port, delay=delay), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(world)]
     outs = []
     for p in procs:

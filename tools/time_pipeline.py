@@ -28,7 +28,8 @@ def make(T, W, D, rr=None):
     a = rng.randn(D, D)
     invcov = a @ a.T / D + np.eye(D)
     r0, r1 = rr if rr else (0, T)
-    e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=3, rung_range=rr)
+    e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=3, rung_range=rr,
+                    adaptation_delay=int(os.environ.get("PIPE_DELAY", "0")) if rr is not None else 0)
     e.upload(np.random.RandomState(1).randn(T, W, D)[r0:r1], betas=make_ladder(D, ntemps=T))
     e.eval_state()
     return e
@@ -65,6 +66,10 @@ def main():
         for e in engs:
             e.step(200)
         print(f"local x{n} shards  T={T} W={W} D={D}: {timed(engs, iters):8.2f} us/iter (shards share one GPU)")
+        if os.environ.get("HENS_PIPE_STATS"):
+            for r, e in enumerate(engs):
+                st = e.pipe_debug_stats()
+                print(f"   rank {r} mean wait per workgroup [us]:", {k: round(v[0] / max(v[1], 1) * 1e6, 2) for k, v in st.items()})
     elif mode == "ipc":
         world = int(sys.argv[2])
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000))
@@ -89,6 +94,11 @@ def main():
             e.synchronize()
             best = min(best, time.perf_counter() - t0)
         print(f"ipc rank {rank}/{world}     T={T} W={W} D={D}: {best / iters * 1e6:8.2f} us/iter (processes share one GPU)", flush=True)
+        if os.environ.get("HENS_PIPE_STATS"):
+            st = e.pipe_debug_stats()
+            n_it = 200 + 5 * iters
+            print(f"   rank {rank} mean wait per workgroup [us]:", {k: round(v[0] / max(v[1], 1) * 1e6, 2) for k, v in st.items()},
+                  "waits/iter:", {k: round(v[1] / n_it, 1) for k, v in st.items()}, flush=True)
         dist.barrier()
         e.close()
         dist.destroy_process_group()
