@@ -191,22 +191,27 @@ size_t fast_lds_bytes(int D, int NW) {
 template <int LIKE, int MODE>
 int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
-#define LAUNCH_FAST(DT, NW)                                                                        \
+#define LAUNCH_FAST_P(DT, NW, PIPE)                                                                \
     do {                                                                                           \
         const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
         if (c->ext_start)                                                                          \
-            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
+            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
                                   c->ext_start, c->ext_stop, 0, a);                                \
         else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW>), grid, dim3(NW * 64), lds, c->stream, a); \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), lds, c->stream, a); \
+    } while (0)
+#define LAUNCH_FAST(DT, NW)                                                                        \
+    do {                                                                                           \
+        if (c->pipe.on) LAUNCH_FAST_P(DT, NW, true);                                               \
+        else LAUNCH_FAST_P(DT, NW, false);                                                         \
     } while (0)
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
@@ -235,6 +240,7 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
             hipLaunchKernelGGL((k_stretch<LIKE, MODE>), grid, dim3(256), lds, c->stream, a);
     }
 #undef LAUNCH_FAST
+#undef LAUNCH_FAST_P
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
     return HENS_OK;
@@ -274,6 +280,10 @@ Draws draws_at(const DrawBuf& b, size_t off) {
     return d;
 }
 
+bool pipe_has_top(const hens_ctx_impl* c) { return c->cfg.rung_end < c->T; }
+bool pipe_has_bot(const hens_ctx_impl* c) { return c->cfg.rung_begin > 0; }
+bool pipe_active(const hens_ctx_impl* c) { return c->pipe.on && c->pipe.connected; }
+
 int64_t guest_delta(const hens_ctx_impl* c) {
     if (!c->pipe.on) return 0;
     const PipeBox b = pipe_box(c->pipe.box, c->T, c->W, c->D);
@@ -300,6 +310,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.rung_begin = c->cfg.rung_begin;
     a.tempered = c->cfg.tempered;
     a.guest_delta = guest_delta(c);
+    a.sys_rung = (pipe_active(c) && pipe_has_top(c)) ? c->Tl - 1 : -1;   // the hot neighbour pulls rows out of that rung
     return a;
 }
 
@@ -411,9 +422,6 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
 }
 
 // ---- ladder pipeline ------------------------------------------------------------------------------
-bool pipe_has_top(const hens_ctx_impl* c) { return c->cfg.rung_end < c->T; }
-bool pipe_has_bot(const hens_ctx_impl* c) { return c->cfg.rung_begin > 0; }
-bool pipe_active(const hens_ctx_impl* c) { return c->pipe.on && c->pipe.connected; }
 
 bool pipe_publish_fused(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_PIPE_SEPARATE_PUB") != nullptr;     // A/B knob

@@ -222,6 +222,7 @@ struct StretchArgs {
     unsigned* pub_ticket;
     uint32_t pub_target, pub_value;
     int32_t pub_final;
+    int32_t sys_rung;          // local rung whose rows a peer will read (written through to memory, system scope), or -1
     long long* pub_meta;       // neighbour's meta[par]: receives the pool row of (hottest rung, slot 0) after this move
     // ladder pipeline: before touching the state, wait until the mailbox flags selected by wmask reach wtarget
     const unsigned* wflags;
@@ -469,9 +470,16 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
             if (VEC == 2) {
                 const double2 v = keep ? *reinterpret_cast<const double2*>(qtile + r * RS + e)
                                        : *reinterpret_cast<const double2*>(ps + e);
-                *reinterpret_cast<double2*>(pd + e) = v;
+                if (tl == A.sys_rung) {                 // the hot neighbour pulls rows out of this rung (ladder pipeline)
+                    sys_store(pd + e, v.x);
+                    sys_store(pd + e + 1, v.y);
+                } else {
+                    *reinterpret_cast<double2*>(pd + e) = v;
+                }
             } else {
-                pd[e] = keep ? qtile[r * RS + e] : ps[e];
+                const double v = keep ? qtile[r * RS + e] : ps[e];
+                if (tl == A.sys_rung) sys_store(pd + e, v);
+                else pd[e] = v;
             }
         }
     }
@@ -488,6 +496,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define HENS_ROWSTORE 1
 #endif
 typedef double dvec2 __attribute__((ext_vector_type(2)));
+// system scope (sc0 sc1): written through to memory - for rows a peer GPU reads (an agent-scope store may sit
+// dirty in this GPU's L2, which a read arriving over xGMI does not probe)
+__device__ __forceinline__ void store_row16_sys(double* p, double2 v) {
+    const double __attribute__((ext_vector_type(2))) t = {v.x, v.y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
 __device__ __forceinline__ void store_row16(double* p, double2 v) {
 #if HENS_ROWSTORE == 1
     const dvec2 t = {v.x, v.y};
@@ -546,7 +560,9 @@ __device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attrib
 //     in flight and recomputes the ladder in one wavefront; workgroup (0,0) publishes it.  That
 //     removes a dependent single-workgroup launch (~5.5 us + boundary) from every iteration.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int LIKE, int MODE, int NW>
+// PIPE: the context is a rank of the ladder pipeline (guest rows, flag waits, boundary-rung publishing);
+// compiled out of the single-GPU instantiation, where those hooks cost ~6 % at config 2.
+template <int DT, int LIKE, int MODE, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     HENS_TRACE(0);
-    if (!EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
+    if (PIPE && !EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
         if (wv == 0 && ((A.wmask >> lane) & 1ull))
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
                       A.wstats ? A.wstats + (lane >= PF_CNT0 ? 2 : 0) : nullptr);
@@ -647,9 +663,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rs[r], D, A.guest_delta) + jl * 2);
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
             if (MH) creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
-            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + row_off(s_rc[r], D, A.guest_delta) + jl * 2);
+            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
         }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
@@ -688,7 +704,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
-            if (!EVAL) store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
+            if (!EVAL) {
+                if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
+                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
+            }
         }
         const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
         const unsigned long long nonfin = __ballot(!finite);
@@ -876,7 +895,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 atomicAdd(&A.accepted[gi], 1u);
                 atomicOr(&s_flag[lane], 2);
             }
-            if (A.pub_lp && tl == A.Tl - 1) {                  // ladder pipeline: what the hot neighbour's bottom pair needs
+            if (PIPE && A.pub_lp && tl == A.Tl - 1) {                  // ladder pipeline: what the hot neighbour's bottom pair needs
                 sys_store(A.pub_lp + own, keep ? logl : Lold);
                 sys_store(A.pub_lp + W + own, keep ? newP : Pold);
             }
@@ -895,9 +914,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
-        store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
+        const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+        if (PIPE && tl == A.sys_rung) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
+        else store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
     }
-    if (A.pub_lp && A.pub_final && tl == A.Tl - 1)             // every walker of the rung has published: tell the neighbour
+    if (PIPE && A.pub_lp && A.pub_final && tl == A.Tl - 1)             // every walker of the rung has published: tell the neighbour
         if (pipe_last_ticket(A.pub_ticket, A.pub_target) && tid == 0) {
             __hip_atomic_store(A.pub_meta, (long long)A.home_off + (long long)tl * W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             pipe_raise(A.pub_flag, A.pub_value);
