@@ -19,10 +19,10 @@ def mean_of(path, pattern):
     raise SystemExit(f"{pattern} not found in {path}")
 
 
-fetch = mean_of(f"{src}/{tag}_pmc_FETCH_SIZE.txt", r"k_stretch_fast<32, 0, false")
-write = mean_of(f"{src}/{tag}_pmc_WRITE_SIZE.txt", r"k_stretch_fast<32, 0, false")
-cal_fetch = mean_of(f"{src}/{tag}_pmc_FETCH_SIZE.txt", r"k_stretch_fast<32, 0, true")
-cal_write = mean_of(f"{src}/{tag}_pmc_WRITE_SIZE.txt", r"k_stretch_fast<32, 0, true")
+fetch = mean_of(f"{src}/{tag}_pmc_FETCH_SIZE.txt", r"k_stretch_fast<32, 0, 0,")
+write = mean_of(f"{src}/{tag}_pmc_WRITE_SIZE.txt", r"k_stretch_fast<32, 0, 0,")
+cal_fetch = mean_of(f"{src}/{tag}_pmc_FETCH_SIZE.txt", r"k_stretch_fast<32, 0, 1,")
+cal_write = mean_of(f"{src}/{tag}_pmc_WRITE_SIZE.txt", r"k_stretch_fast<32, 0, 1,")
 known_read = 16 * 4096 * 32 * 8          # eval kernel: every row once
 known_write = 2 * 16 * 4096 * 8          # eval kernel: logl + logp
 out = {
