@@ -32,23 +32,35 @@ def problem(T, W, D):
 
 
 DELAY = int(os.environ.get("PIPE_TEST_DELAY", "0"))      # hens_config.adaptation_delay of every context
+MODEL = os.environ.get("PIPE_TEST_MODEL", "gauss")       # "rosen_mix": BASELINE config 4 in small - Rosenbrock + Stretch/Gaussian mix
 
 
 def make(T, W, D, rng_range=None, delay=None):
     mu, invcov, x0, betas = problem(T, W, D)
-    e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -6.0, 6.0, seed=SEED, rung_range=rng_range,
+    if MODEL == "rosen_mix":
+        from eryn_amd.likelihood import RosenbrockLikelihood
+        like = RosenbrockLikelihood(D)
+    else:
+        like = GaussianLikelihood(mu, invcov)
+    e = HipEnsemble(T, W, D, like, -6.0, 6.0, seed=SEED, rung_range=rng_range,
                     adaptation_delay=DELAY if delay is None else delay)
     r0, r1 = rng_range if rng_range else (0, T)
     e.upload(x0[r0:r1], betas=betas)
     e.eval_state()
+    if MODEL == "rosen_mix":
+        e.set_mh_proposal("iso", 0.02, 0.5)              # half of the iterations are Gaussian MH proposals
     return e
 
 
 def snapshot(e):
     x, L, P, betas = e.download()
     c = e.counters()
-    return dict(x=x, L=L, P=P, betas=betas, accepted=c["accepted"], swaps_total=c["swaps_total"],
-                swaps_last=c["swaps_last"])
+    acc = c["accepted"]
+    if MODEL == "rosen_mix":
+        m = e.mh_counters()
+        assert m["num_proposals"] > 0 and c["num_proposals"] > 0, "the mix must use both moves"
+        acc = acc + 1000.0 * m["accepted"]              # both counters in one array (accept counts stay < 1000)
+    return dict(x=x, L=L, P=P, betas=betas, accepted=acc, swaps_total=c["swaps_total"], swaps_last=c["swaps_last"])
 
 
 def main():

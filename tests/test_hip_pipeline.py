@@ -21,9 +21,10 @@ WORKER = os.path.join(HERE, "pipeline_worker.py")
 KEYS = ("x", "L", "P", "betas", "accepted", "swaps_total", "swaps_last")
 
 
-def _env(port=None, delay=0):
+def _env(port=None, delay=0, model="gauss"):
     env = dict(os.environ)
     env["PIPE_TEST_DELAY"] = str(delay)
+    env["PIPE_TEST_MODEL"] = model
     env["GPU_MAX_HW_QUEUES"] = "16"          # in-process shards: every stream on its own hardware queue
     env["HENS_PIPE_TIMEOUT_S"] = "10"
     env["MASTER_ADDR"] = "127.0.0.1"
@@ -32,14 +33,14 @@ def _env(port=None, delay=0):
     return env
 
 
-def _run(args, delay=0, **kw):
-    return subprocess.run([sys.executable, WORKER] + [str(a) for a in args], env=_env(delay=delay), capture_output=True,
-                          text=True, timeout=300, **kw)
+def _run(args, delay=0, model="gauss", **kw):
+    return subprocess.run([sys.executable, WORKER] + [str(a) for a in args], env=_env(delay=delay, model=model),
+                          capture_output=True, text=True, timeout=300, **kw)
 
 
-def _single(tmp_path, T, W, D, iters, delay=0):
+def _single(tmp_path, T, W, D, iters, delay=0, model="gauss"):
     out = tmp_path / f"single{delay}.npz"
-    r = _run(["single", T, W, D, iters, out], delay=delay)
+    r = _run(["single", T, W, D, iters, out], delay=delay, model=model)
     assert r.returncode == 0, r.stdout + r.stderr
     with np.load(out) as f:
         return {k: f[k] for k in f.files}
@@ -74,6 +75,17 @@ def test_pipeline_delayed_adaptation_is_rank_count_invariant(tmp_path, nranks, T
     exact = _single(tmp_path, T, W, D, iters, delay=0)
     assert not np.array_equal(exact["betas"], ref["betas"])
     np.testing.assert_allclose(exact["betas"], ref["betas"], rtol=0.05)
+
+
+@pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 256, 128, 10), (4, 4, 64, 16, 10)])
+def test_pipeline_rosenbrock_move_mix(tmp_path, nranks, T, W, D, iters):
+    """BASELINE config 4 in small: Rosenbrock likelihood (ndim = 128: the generic-row-width kernels, wait and
+    publish kernels instead of the fused prologues), StretchMove + GaussianMove mixed by weight, sharded."""
+    ref = _single(tmp_path, T, W, D, iters, model="rosen_mix")
+    out = tmp_path / "local.npz"
+    r = _run(["local", nranks, T, W, D, iters, out], model="rosen_mix")
+    assert r.returncode == 0, r.stdout + r.stderr
+    _compare(ref, np.load(out))
 
 
 @pytest.mark.parametrize("world,T,W,D,iters,delay", [(2, 4, 256, 32, 8, 0), (3, 6, 128, 8, 6, 0), (3, 6, 128, 8, 7, 1)])
