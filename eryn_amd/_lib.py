@@ -78,6 +78,7 @@ SIGNATURES = {
     "hens_pipe_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "hens_pipe_connect": (C.c_int, [_P, _P]),
     "hens_pipe_connect_local": (C.c_int, [_P, _P]),
+    "hens_pipe_selftest": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_double]),
     "hens_pipe_debug_stats": (C.c_int, [_P, _P, C.c_int32]),
     "hens_debug_trace": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     "hens_debug_permutation": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int64, _P]),

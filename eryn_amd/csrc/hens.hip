@@ -5,6 +5,8 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
+#include <unistd.h>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1698,6 +1700,93 @@ int hens_pipe_connect(hens_ctx* ctx, const void* blobs) {
         }
     }
     return pipe_finish_connect(c);
+}
+
+// ---- pipeline self-test --------------------------------------------------------------------------------
+// Run in a throw-away process per rank BEFORE the real connect (eryn_amd.ladder does): a node where peer
+// mappings do not work shows up here as an error code or a dead helper process, not as a GPU fault in the
+// sampler.  Ranks find each other through files in `dir`.  Checks, with the rank's ladder neighbours:
+//   put   - kernel stores into the neighbour's uncached mailbox-like buffer + flag, neighbour sees the data
+//   pull  - kernel reads the neighbour's ordinary (cached) device memory written with system-scope stores
+static bool wait_for_file(const std::string& path, double timeout_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (access(path.c_str(), R_OK) != 0) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+        usleep(2000);
+    }
+    return true;
+}
+
+int hens_pipe_selftest(int32_t device_id, int32_t rank, int32_t nranks, const char* dir, double timeout_s) {
+    if (!dir || rank < 0 || rank >= nranks) return fail(nullptr, HENS_ERR_INVALID, "bad self-test arguments");
+    hens_ctx_impl* c = nullptr;
+    HIPCHK(c, hipSetDevice(device_id));
+    constexpr int N = 4096;
+    double* ubuf = nullptr; unsigned* uflag = nullptr; double* cbuf = nullptr; unsigned* result = nullptr;
+    HIPCHK(c, hipExtMallocWithFlags((void**)&ubuf, N * 8, hipDeviceMallocUncached));
+    HIPCHK(c, hipExtMallocWithFlags((void**)&uflag, 256, hipDeviceMallocUncached));
+    HIPCHK(c, hipMalloc((void**)&cbuf, N * 8));
+    HIPCHK(c, hipMalloc((void**)&result, 4));
+    HIPCHK(c, hipMemset(ubuf, 0, N * 8));
+    HIPCHK(c, hipMemset(uflag, 0, 256));
+    HIPCHK(c, hipMemset(result, 0, 4));
+    hipLaunchKernelGGL(k_probe_fill, dim3(1), dim3(256), 0, nullptr, cbuf, N, 7000.0 + rank);   // what my hot neighbour will pull
+    HIPCHK(c, hipDeviceSynchronize());
+    hipIpcMemHandle_t h[3];
+    HIPCHK(c, hipIpcGetMemHandle(&h[0], ubuf));
+    HIPCHK(c, hipIpcGetMemHandle(&h[1], uflag));
+    HIPCHK(c, hipIpcGetMemHandle(&h[2], cbuf));
+    const std::string base(dir);
+    {
+        const std::string tmp = base + "/h" + std::to_string(rank) + ".tmp", fin = base + "/h" + std::to_string(rank) + ".bin";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f) return fail(nullptr, HENS_ERR_INVALID, "cannot write %s", tmp.c_str());
+        fwrite(h, sizeof h, 1, f);
+        fclose(f);
+        rename(tmp.c_str(), fin.c_str());
+    }
+    auto read_handles = [&](int q, hipIpcMemHandle_t* out) -> bool {
+        const std::string p = base + "/h" + std::to_string(q) + ".bin";
+        if (!wait_for_file(p, timeout_s)) return false;
+        FILE* f = fopen(p.c_str(), "rb");
+        if (!f) return false;
+        const bool ok = fread(out, sizeof(hipIpcMemHandle_t) * 3, 1, f) == 1;
+        fclose(f);
+        return ok;
+    };
+    const bool has_hot = rank + 1 < nranks, has_cold = rank > 0;
+    double* hot_ubuf = nullptr; unsigned* hot_uflag = nullptr; double* cold_cbuf = nullptr;
+    if (has_hot) {           // I put into my hot neighbour's buffer (like the LDN / ROWS messages going up)
+        hipIpcMemHandle_t g[3];
+        if (!read_handles(rank + 1, g)) return fail(nullptr, HENS_ERR_STATE, "self-test: rank %d never published its handles", rank + 1);
+        HIPCHK(c, hipIpcOpenMemHandle((void**)&hot_ubuf, g[0], hipIpcMemLazyEnablePeerAccess));
+        HIPCHK(c, hipIpcOpenMemHandle((void**)&hot_uflag, g[1], hipIpcMemLazyEnablePeerAccess));
+    }
+    if (has_cold) {          // I pull out of my cold neighbour's cached memory (like the rows that move up)
+        hipIpcMemHandle_t g[3];
+        if (!read_handles(rank - 1, g)) return fail(nullptr, HENS_ERR_STATE, "self-test: rank %d never published its handles", rank - 1);
+        HIPCHK(c, hipIpcOpenMemHandle((void**)&cold_cbuf, g[2], hipIpcMemLazyEnablePeerAccess));
+    }
+    if (has_hot) hipLaunchKernelGGL(k_probe_put, dim3(1), dim3(256), 0, nullptr, hot_ubuf, hot_uflag, N, 100.0 * (rank + 1));
+    int khz = 0;
+    (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_id);
+    const long long budget = (long long)((khz > 0 ? khz : 100000) * 1000.0 * timeout_s);
+    hipLaunchKernelGGL(k_probe_check, dim3(1), dim3(256), 0, nullptr, uflag, ubuf, cold_cbuf, N, 100.0 * rank,
+                       7000.0 + (rank - 1), has_cold ? 1 : 0, has_cold ? 1 : 0, budget, result);
+    HIPCHK(c, hipDeviceSynchronize());
+    unsigned res = 0;
+    HIPCHK(c, hipMemcpy(&res, result, 4, hipMemcpyDeviceToHost));
+    // keep my memory alive until the neighbours are done with it
+    { FILE* f = fopen((base + "/done" + std::to_string(rank)).c_str(), "w"); if (f) fclose(f); }
+    for (int q : {rank - 1, rank + 1})
+        if (q >= 0 && q < nranks) (void)wait_for_file(base + "/done" + std::to_string(q), timeout_s);
+    if (hot_ubuf) (void)hipIpcCloseMemHandle(hot_ubuf);
+    if (hot_uflag) (void)hipIpcCloseMemHandle(hot_uflag);
+    if (cold_cbuf) (void)hipIpcCloseMemHandle(cold_cbuf);
+    (void)hipFree(ubuf); (void)hipFree(uflag); (void)hipFree(cbuf); (void)hipFree(result);
+    if (res & FLAG_PIPE_TIMEOUT) return fail(nullptr, HENS_ERR_STATE, "self-test: the flag of the cold neighbour never arrived");
+    if (res >> 8) return fail(nullptr, HENS_ERR_STATE, "self-test: wrong data (put %u, pull %u)", (res >> 8) & 1u, (res >> 9) & 1u);
+    return HENS_OK;
 }
 
 int hens_pipe_debug_stats(hens_ctx* ctx, uint64_t* out16, int32_t reset) {

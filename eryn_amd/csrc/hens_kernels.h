@@ -1905,4 +1905,31 @@ __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     if (pipe_last_block(A.tickets + 1, gridDim.x, A.sweep) && threadIdx.x == 0) pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
 }
 
+// ---- hens_pipe_selftest: the three access patterns the pipeline relies on, between two processes ----------
+__global__ void k_probe_put(double* peer_buf, unsigned* peer_flag, int n, double tag) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sys_store(peer_buf + i, tag + i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) pipe_raise(peer_flag, 1u);
+}
+__global__ void k_probe_fill(double* buf, int n, double tag) {     // system-scope stores into my own cached memory
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sys_store(buf + i, tag + i);
+}
+__global__ void k_probe_check(const unsigned* my_flag, const double* my_buf, const double* peer_cached, int n,
+                              double tag_in, double tag_pull, int check_put, int check_pull, long long budget,
+                              unsigned* result) {
+    __shared__ unsigned bad;
+    if (threadIdx.x == 0) {
+        bad = 0;
+        if (check_put) pipe_spin(my_flag, 1u, budget, result);     // result bit FLAG_PIPE_TIMEOUT on timeout
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (check_put && sys_load(my_buf + i) != tag_in + i) atomicOr(&bad, 1u);
+        if (check_pull && sys_load(peer_cached + i) != tag_pull + i) atomicOr(&bad, 2u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) atomicOr(result, bad << 8);
+}
+
 }  // namespace hens

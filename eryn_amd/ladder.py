@@ -188,19 +188,50 @@ class LadderPipeline:
     holding the whole ladder (tests/test_hip_pipeline.py).
     """
 
-    def __init__(self, engine, rank, nranks, dist=None, group=None):
+    def __init__(self, engine, rank, nranks, dist=None, group=None, device_id=0, selftest=None):
+        import os
+        if selftest is None:
+            selftest = os.environ.get("HENS_PIPE_SELFTEST", "1") != "0"
         self.e = engine
         self.rank, self.nranks = int(rank), int(nranks)
+        if self.nranks > 1 and dist is None:
+            raise ValueError("nranks > 1 needs torch.distributed to exchange the mailbox handles")
+        if self.nranks > 1 and selftest:
+            self._selftest(dist, group, device_id)
         handle = engine.pipe_init(self.nranks, self.rank)
         if self.nranks == 1:
             engine.pipe_connect_local([engine])
             return
-        if dist is None:
-            raise ValueError("nranks > 1 needs torch.distributed to exchange the mailbox handles")
         handles = [None] * self.nranks
         dist.all_gather_object(handles, handle, group=group)
         engine.pipe_connect(b"".join(handles))
         dist.barrier(group=group)          # nobody stores into a mailbox that is not mapped everywhere yet
+
+    def _selftest(self, dist, group, device_id, timeout_s=30.0):
+        """hens_pipe_selftest in a throw-away process per rank: a node where peer mappings do not work must show
+        up as a failed helper, not as a GPU fault in this process.  Raises RuntimeError if ANY rank failed."""
+        import os
+        import shutil
+        import subprocess
+        import sys
+        import tempfile
+        box = [tempfile.mkdtemp(prefix="hens_probe_") if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            r = subprocess.run([sys.executable, "-m", "eryn_amd.pipe_probe", str(int(device_id)), str(self.rank),
+                                str(self.nranks), box[0], str(timeout_s)], cwd=root, capture_output=True, text=True,
+                               timeout=3 * timeout_s + 60)
+            ok, msg = r.returncode == 0, (r.stdout + r.stderr).strip()[-300:]
+        except subprocess.TimeoutExpired:
+            ok, msg = False, "helper process timed out"
+        results = [None] * self.nranks
+        dist.all_gather_object(results, (ok, msg), group=group)
+        if self.rank == 0:
+            shutil.rmtree(box[0], ignore_errors=True)
+        bad = [(q, m) for q, (o, m) in enumerate(results) if not o]
+        if bad:
+            raise RuntimeError(f"ladder pipeline self-test failed on ranks {[q for q, _ in bad]}: {bad[0][1]}")
 
     @staticmethod
     def connect_local(engines):
@@ -267,7 +298,7 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     if mode == "pipeline" and not force:
         ok = 1
         try:
-            stepper = LadderPipeline(eng, rank, world, dist=dist if world > 1 else None)
+            stepper = LadderPipeline(eng, rank, world, dist=dist if world > 1 else None, device_id=local_rank)
         except Exception as exc:                      # noqa: BLE001 - any failure means "use the collective path"
             print(f"[rank {rank}] ladder pipeline unavailable ({exc}); falling back to RCCL collectives", flush=True)
             ok = 0

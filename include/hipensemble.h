@@ -254,6 +254,11 @@ int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals
 int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_out /* HENS_PIPE_BLOB_BYTES or NULL */,
                    int64_t* mailbox_bytes_out);
 int hens_pipe_connect(hens_ctx* ctx, const void* blobs /* nranks * HENS_PIPE_BLOB_BYTES, rank order */);
+/* Self-test of the peer accesses the pipeline relies on (one-sided put + flag into uncached memory, pull out of
+ * ordinary device memory), between this process and its ladder neighbours' processes, which find each other
+ * through files in `dir`.  Needs no context.  eryn_amd.ladder runs it in a throw-away process per rank before
+ * hens_pipe_connect, so a node where peer mappings do not work fails here and not in the sampler. */
+int hens_pipe_selftest(int32_t device_id, int32_t rank, int32_t nranks, const char* dir, double timeout_s);
 /* Debug (env HENS_PIPE_STATS=1 at hens_pipe_init): where the pipeline waits.  out16 = 8 pairs (wall-clock
  * ticks spent spinning, number of waits): [0] stretch prologue on arrived rows, [1] stretch prologue on swap
  * counts, [2] walk on the hot neighbour's columns, [3] bottom on the cold neighbour's rung, [4] bottom on rows

@@ -120,3 +120,20 @@ def test_pipeline_dead_neighbour_raises_instead_of_hanging():
     r = subprocess.run([sys.executable, WORKER, "timeout"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "did not answer" in r.stdout
+
+
+def test_pipe_selftest_helper_processes(tmp_path):
+    """hens_pipe_selftest (what LadderPipeline runs in throw-away processes before connecting): three ranks put into
+    and pull from their neighbours through HIP IPC; a rank whose neighbour never shows up fails instead of hanging."""
+    root = os.path.dirname(HERE)
+    d = tmp_path / "probe"
+    d.mkdir()
+    procs = [subprocess.Popen([sys.executable, "-m", "eryn_amd.pipe_probe", "0", str(r), "3", str(d), "20"], cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    lone = tmp_path / "lone"
+    lone.mkdir()
+    r = subprocess.run([sys.executable, "-m", "eryn_amd.pipe_probe", "0", "0", "2", str(lone), "1"], cwd=root,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "never published" in r.stdout
