@@ -60,6 +60,8 @@ def test_golden_fixture_teacher_forced(name, golden_dir):
 @pytest.mark.parametrize("T,W,D,box,n", [
     (16, 4096, 32, 50.0, 3),      # BASELINE config 2, full size
     (4, 1024, 64, 50.0, 2),       # D = 64 kernel (config 3 row width)
+    (8, 16384, 64, 50.0, 1),      # BASELINE config 3, one GPU's shard at full size (8 of the 64 rungs)
+    (4, 512, 128, 50.0, 2),       # config 4's row width (generic kernel)
     (3, 130, 7, 2.0, 6),          # odd D (scalar rows), uneven tiles, narrow box
     (2, 64, 16, 50.0, 4),
     (5, 256, 8, 1.5, 4),
