@@ -247,7 +247,6 @@ class LadderPipeline:
 
 def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     """N-GPU leg of bench.py: weak scaling, one fixed-size ladder shard per GPU."""
-    import json
     import os
     import time
 
