@@ -639,11 +639,12 @@ int ensure_mh_buffers(hens_ctx_impl* c) {
 }
 
 // one full-ensemble MH proposal from the step rows / log-uniforms already in mh_step / mh_lu (mh.py:56-193)
-int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs) {
+int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bool inline_draws = false) {
     StretchArgs a = base_args(c);
     a.split = 0;
     a.home_off = c->parity * c->Tl * c->W;
-    a.mh_step = c->mh_step;
+    a.mh_step = inline_draws ? nullptr : c->mh_step;
+    a.mh_scale = c->mh_scale; a.mh_kind = c->mh_kind; a.mh_iter = c->iter; a.mh_seed = c->cfg.seed;
     a.dr.lu = c->mh_lu;
     a.accepted = c->accepted_mh;
     a.keep_out = want_keep ? c->mh_keep : nullptr;
@@ -663,14 +664,22 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs) {
     return HENS_OK;
 }
 
-// Philox mode: draw the iteration's steps and accept uniforms on the device, then propose
+// Philox mode: draw the iteration's steps and accept uniforms on the device, then propose.  Isotropic and
+// axis-aligned proposals on the fast row widths are drawn inside the MH launch itself (one Box-Muller pair per
+// lane); a full covariance (Cholesky product) and the generic row widths go through k_mh_draw + the step buffer.
 int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
-    MhDrawArgs d{};
-    d.step = c->mh_step; d.lu = c->mh_lu; d.scale = c->mh_scale;
-    d.iter = c->iter; d.seed = c->cfg.seed;
-    d.Tl = c->Tl; d.W = c->W; d.D = c->D; d.rung_begin = c->cfg.rung_begin; d.kind = c->mh_kind;
-    hipLaunchKernelGGL(k_mh_draw, dim3((c->W + 63) / 64, c->Tl), dim3(256), (size_t)64 * (c->D + 1) * 8, c->stream, d);
-    return mh_launch(c, false, evs);
+    const bool inline_draws = c->mh_kind != MH_FULL && is_fast_dim(c->D);
+    if (!inline_draws) {
+        MhDrawArgs d{};
+        d.step = c->mh_step; d.lu = c->mh_lu; d.scale = c->mh_scale;
+        d.iter = c->iter; d.seed = c->cfg.seed;
+        d.Tl = c->Tl; d.W = c->W; d.D = c->D; d.rung_begin = c->cfg.rung_begin; d.kind = c->mh_kind;
+        size_t lds = (size_t)64 * (c->D + 1) * 8;
+        d.chol_lds = (c->mh_kind == MH_FULL && lds + (size_t)c->D * (c->D + 1) * 8 <= 60000) ? 1 : 0;
+        if (d.chol_lds) lds += (size_t)c->D * (c->D + 1) * 8;
+        hipLaunchKernelGGL(k_mh_draw, dim3((c->W + 63) / 64, c->Tl), dim3(256), lds, c->stream, d);
+    }
+    return mh_launch(c, false, evs, inline_draws);
 }
 
 // host-side move choice of hens_step (ensemble.py:971 in Philox form): one counter-based uniform per iteration

@@ -88,6 +88,25 @@ __device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits,
 
 enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
                   PURPOSE_PTU = 10, PURPOSE_MH_ACC = 11, PURPOSE_MH_NORMAL = 12, PURPOSE_MOVE = 13 };
+enum { MH_ISO = 0, MH_DIAG = 1, MH_FULL = 2 };
+
+// One Box-Muller pair of standard normals for coordinates (2 pr, 2 pr + 1) of walker `wid` (= rung * W + walker)
+// in iteration `it`: the draw of the Gaussian MH move (k_mh_draw and the inline MODE_MH path share it).
+__device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t wid, uint32_t pr) {
+    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_NORMAL | (pr << 8)};
+    const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const double u1 = 1.0 - u01(d.x, d.y);                            // (0, 1]
+    const double u2 = u01(d.z, d.w);
+    const double r = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    return double2{r * cs, r * sn};
+}
+__device__ __forceinline__ double mh_log_uniform(uint64_t seed, uint64_t it, uint32_t wid) {     // mh.py:157
+    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_ACC};
+    const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return log(u01(d.x, d.y));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Ladder-pipeline primitives (used by the stretch kernels too; the protocol is described at k_pipe_*).
@@ -215,7 +234,10 @@ struct StretchArgs {
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
     int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
     int64_t guest_delta;       // see row_off (0 when there is no pipeline)
-    const double* mh_step;     // MODE_MH: [Tl][W][D] proposal steps
+    const double* mh_step;     // MODE_MH: [Tl][W][D] proposal steps, or nullptr: isotropic / axis-aligned steps drawn in place
+    const double* mh_scale;    //   (mh_kind MH_ISO: [1], MH_DIAG: [D] standard deviations; Philox keys mh_iter, mh_seed)
+    uint64_t mh_iter, mh_seed;
+    int32_t mh_kind;
     // ladder pipeline: the hottest resident rung's (L, P) after this move go straight to the hot neighbour
     double* pub_lp;            // neighbour's lp_dn for this sweep: [2][W], or nullptr
     unsigned* pub_flag;        // neighbour's PF_LDN, raised by the last workgroup of the iteration's last launch
@@ -621,7 +643,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 own = k;
                 rs = A.loc[tl * W + own];
                 rc = rs;
-                lu = A.dr.lu[(size_t)tl * W + own];
+                lu = A.mh_step ? A.dr.lu[(size_t)tl * W + own]
+                               : mh_log_uniform(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)own);
                 Lold = A.L[tl * W + own];
                 Pold = A.P[tl * W + own];
             } else {
@@ -664,7 +687,16 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
-            if (MH) creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
+            if (MH) {
+                if (A.mh_step) {
+                    creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
+                } else {                         // one Box-Muller pair per lane: exactly the two coordinates it owns
+                    const double2 z = mh_normal_pair(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(k0 + r), (uint32_t)jl);
+                    const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];
+                    const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];
+                    creg[p] = double2{s0 * z.x, s1 * z.y};
+                }
+            }
             else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
         }
     }
@@ -970,13 +1002,12 @@ __global__ void k_mh_prep(const double* __restrict__ u_acc, double* __restrict__
         lu[i] = log(u_acc[i]);
 }
 
-enum { MH_ISO = 0, MH_DIAG = 1, MH_FULL = 2 };
 struct MhDrawArgs {
     double* step;            // [Tl][W][D]
     double* lu;              // [Tl][W]
     const double* scale;     // MH_ISO: [1] std dev; MH_DIAG: [D] std devs; MH_FULL: [D][D] lower Cholesky factor, row-major
     uint64_t iter, seed;
-    int32_t Tl, W, D, rung_begin, kind;
+    int32_t Tl, W, D, rung_begin, kind, chol_lds;
 };
 // Philox mode: step = scale * z (isotropic / diagonal) or chol * z (full covariance), z ~ N(0, 1) by
 // Box-Muller from Philox counters keyed (iteration, global rung, walker, coordinate pair); the accept
@@ -985,37 +1016,34 @@ __global__ __launch_bounds__(256) void k_mh_draw(const MhDrawArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* z = reinterpret_cast<double*>(smem_raw);                  // [64][D + 1]
     const int D = A.D, W = A.W, ZS = D + 1;
+    double* chol = z + 64 * ZS;                                       // [D][D + 1] when A.chol_lds (odd stride: no bank conflicts)
     const int tl = blockIdx.y, w0 = blockIdx.x * 64;
     const uint32_t rung = (uint32_t)(A.rung_begin + tl);
     const int npair = (D + 1) / 2;
+    if (A.kind == MH_FULL && A.chol_lds)
+        for (int i = threadIdx.x; i < D * D; i += blockDim.x) chol[(i / D) * ZS + (i % D)] = A.scale[i];
     for (int i = threadIdx.x; i < 64 * npair; i += blockDim.x) {
         const int wl = i / npair, pr = i - wl * npair, w = w0 + wl;
         if (w >= W) continue;
-        const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), rung * (uint32_t)W + (uint32_t)w,
-                     PURPOSE_MH_NORMAL | ((uint32_t)pr << 8)};
-        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        const double u1 = 1.0 - u01(d.x, d.y);                        // (0, 1]
-        const double u2 = u01(d.z, d.w);
-        const double r = sqrt(-2.0 * log(u1));
-        double sn, cs;
-        sincospi(2.0 * u2, &sn, &cs);
-        z[wl * ZS + 2 * pr] = r * cs;
-        if (2 * pr + 1 < D) z[wl * ZS + 2 * pr + 1] = r * sn;
+        const double2 n2 = mh_normal_pair(A.seed, A.iter, rung * (uint32_t)W + (uint32_t)w, (uint32_t)pr);
+        z[wl * ZS + 2 * pr] = n2.x;
+        if (2 * pr + 1 < D) z[wl * ZS + 2 * pr + 1] = n2.y;
     }
     if (threadIdx.x < 64 && w0 + (int)threadIdx.x < W) {
         const int w = w0 + threadIdx.x;
-        const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), rung * (uint32_t)W + (uint32_t)w, PURPOSE_MH_ACC};
-        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        A.lu[(size_t)tl * W + w] = log(u01(d.x, d.y));               // mh.py:157
+        A.lu[(size_t)tl * W + w] = mh_log_uniform(A.seed, A.iter, rung * (uint32_t)W + (uint32_t)w);
     }
     __syncthreads();
+    const bool in_lds = A.kind == MH_FULL && A.chol_lds;
+    const double* cf = in_lds ? chol : A.scale;
+    const int CS = in_lds ? ZS : D;
     for (int i = threadIdx.x; i < 64 * D; i += blockDim.x) {
         const int wl = i / D, d = i - wl * D, w = w0 + wl;
         if (w >= W) continue;
         double v;
         if (A.kind == MH_FULL) {
             v = 0.0;
-            for (int k = 0; k <= d; ++k) v = fma(A.scale[(size_t)d * D + k], z[wl * ZS + k], v);
+            for (int k = 0; k <= d; ++k) v = fma(cf[(size_t)d * CS + k], z[wl * ZS + k], v);
         } else {
             v = (A.kind == MH_ISO ? A.scale[0] : A.scale[d]) * z[wl * ZS + d];
         }
