@@ -37,6 +37,13 @@ class HensTiming(C.Structure):
     ]
 
 
+class HensPipeRegions(C.Structure):
+    """struct hens_pipe_region_table (include/hipensemble.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("ldn_out", "ldn_rows_out", "ldn_in", "ldn_rows_in", "lup_out", "lup_in",
+                                          "rows_out", "rows_in", "cnt_out", "cnt_in")] + \
+               [("lp_doubles", C.c_int64), ("row_doubles", C.c_int64), ("cnt_words", C.c_int64), ("stream", C.c_void_p)]
+
+
 class HensDeviceBuffers(C.Structure):
     _fields_ = [
         ("logl", C.c_void_p), ("gather_logl", C.c_void_p), ("send_rows", C.c_void_p), ("recv_rows", C.c_void_p),
@@ -78,6 +85,9 @@ SIGNATURES = {
     "hens_pipe_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "hens_pipe_connect": (C.c_int, [_P, _P]),
     "hens_pipe_connect_local": (C.c_int, [_P, _P]),
+    "hens_pipe_connect_staged": (C.c_int, [_P]),
+    "hens_pipe_regions": (C.c_int, [_P, _P]),
+    "hens_pipe_stage": (C.c_int, [_P, C.c_int32]),
     "hens_pipe_selftest": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_double]),
     "hens_pipe_debug_stats": (C.c_int, [_P, _P, C.c_int32]),
     "hens_debug_trace": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),

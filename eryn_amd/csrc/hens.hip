@@ -94,6 +94,10 @@ struct hens_ctx_impl {
         std::vector<char*> boxes;          // every rank's mailbox as mapped into this process
         std::vector<char> opened;          // 1: mapped through hipIpcOpenMemHandle (to be closed)
         const double* pool_cold = nullptr; // cold neighbour's walker pool as mapped here
+        // staged transport (RCCL send/recv of the same messages, host-ordered): kernels write into local outboxes
+        bool staged = false;
+        char* out_hot = nullptr; char* out_cold = nullptr; char* out_cnt = nullptr;
+        double* ldn_rows = nullptr;        // [2][W][D] rows of the cold neighbour's boundary rung, as received
         bool pool_cold_opened = false;
         char** d_boxes = nullptr;
         double* Lcur = nullptr; double* Pcur = nullptr; int32_t* botsrc = nullptr;
@@ -442,6 +446,7 @@ PipeArgs pipe_args(hens_ctx_impl* c) {
     a.box_cold = pipe_has_bot(c) ? c->pipe.boxes[c->pipe.rank - 1] : nullptr;
     a.pool_cold = c->pipe.pool_cold;
     a.home_off = (c->parity ^ 1) * c->Tl * c->W;      // the stretch move of this iteration has already flipped parity
+    a.nowait = c->pipe.staged ? 1 : 0;
     a.boxes = c->pipe.d_boxes;
     a.Lcur = c->pipe.Lcur; a.Pcur = c->pipe.Pcur; a.botsrc = c->pipe.botsrc;
     a.swap_part = c->swap_part;
@@ -474,7 +479,7 @@ void pipe_wait(hens_ctx_impl* c, std::initializer_list<int> which, bool counts, 
 // pending) every rank's swap counts must be here.  The fast stretch kernel waits in its own prologue
 // (wmask); other row widths get a wait kernel.
 unsigned long long pipe_prewait_mask(const hens_ctx_impl* c) {
-    if (!pipe_active(c) || c->pipe.sweep == 0) return 0ull;
+    if (!pipe_active(c) || c->pipe.sweep == 0 || c->pipe.staged) return 0ull;
     unsigned long long m = 0;
     if (pipe_has_top(c)) m |= 1ull << PF_ROWS_TOP;
     if (c->adapt_pending && c->adapt_src != nullptr && c->pipe.nranks > 1)
@@ -502,22 +507,36 @@ void pipe_prewait(hens_ctx_impl* c) {
 }
 
 // one PT sweep of the sharded ladder (tempering.py:598-649 across ranks); see hens_kernels.h
-void pipe_sweep(hens_ctx_impl* c) {
-    const bool top = pipe_has_top(c), bot = pipe_has_bot(c);
-    const PipeArgs a = pipe_args(c);
-    const uint32_t done = c->pipe.sweep + 1;
-    const int TE = c->Tl + (top ? 1 : 0);
-    if (top && !pipe_publish_fused(c))   // (the fast stretch kernels publish from their accept phase)
+void pipe_launch_pub(hens_ctx_impl* c) {
+    if (pipe_has_top(c) && !pipe_publish_fused(c)) {   // (the fast stretch kernels publish from their accept phase)
+        const PipeArgs a = pipe_args(c);
         hipLaunchKernelGGL(k_pipe_pub, dim3(1), dim3(1024), 0, c->stream, a);                 // raises the neighbour's PF_LDN
+    }
+}
+void pipe_launch_walk(hens_ctx_impl* c) {
+    const PipeArgs a = pipe_args(c);
+    const int TE = c->Tl + (pipe_has_top(c) ? 1 : 0);
     // waits for PF_LUP; its last workgroup raises the cold neighbour's PF_LUP and publishes my swap counts
     hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);
-    if (bot)   // waits for PF_LDN (+ PF_ROWS_TOP); moves the rows both ways; its last workgroup raises the cold neighbour's PF_ROWS_TOP
-        hipLaunchKernelGGL(k_pipe_bottom, dim3((c->W + PIPE_COLS - 1) / PIPE_COLS), dim3(256), 0, c->stream, a);
+}
+void pipe_launch_bottom(hens_ctx_impl* c) {
+    if (!pipe_has_bot(c)) return;
+    const PipeArgs a = pipe_args(c);
+    // waits for PF_LDN (+ PF_ROWS_TOP); moves the rows both ways; its last workgroup raises the cold neighbour's PF_ROWS_TOP
+    hipLaunchKernelGGL(k_pipe_bottom, dim3((c->W + PIPE_COLS - 1) / PIPE_COLS), dim3(256), 0, c->stream, a);
+}
+void pipe_finish_sweep(hens_ctx_impl* c) {
     const PipeBox me = pipe_box(c->pipe.box, c->T, c->W, c->D);
     c->pipe.pend[c->pipe.npend++] = {me.counts + (size_t)(c->pipe.sweep & 3u) * c->T, c->pipe.sweep, c->cfg.adaptive != 0};
     c->cur ^= 1;
     c->pipe.sweep += 1;
     pipe_promote_pending(c, false);
+}
+void pipe_sweep(hens_ctx_impl* c) {
+    pipe_launch_pub(c);
+    pipe_launch_walk(c);
+    pipe_launch_bottom(c);
+    pipe_finish_sweep(c);
 }
 
 // apply the adaptations that are due (end of a hens_step call): each needs every rank's counts of its sweep.
@@ -527,7 +546,7 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
     for (;;) {
         pipe_promote_pending(c, false);
         if (!c->adapt_pending) break;
-        if (c->adapt_src && c->pipe.nranks > 1) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);
+        if (c->adapt_src && c->pipe.nranks > 1 && !c->pipe.staged) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);
         flush_adapt(c);
     }
 }
@@ -574,7 +593,8 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
         c->adapt_src = nullptr;
         c->bcur ^= 1;
     } else {
-        if (pipe_active(c) && c->adapt_src && c->pipe.nranks > 1) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);   // every rank's counts first
+        if (pipe_active(c) && !c->pipe.staged && c->adapt_src && c->pipe.nranks > 1)
+            pipe_wait(c, {}, true, c->pipe.due_sweep + 1);   // every rank's counts first
         flush_adapt(c);
         a.betas = c->betas[c->bcur];
     }
@@ -1225,6 +1245,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (c->Tl != c->T && !piped)
         return fail(c, HENS_ERR_STATE, "hens_step on a ladder shard needs the pipeline connected (hens_pipe_init / hens_pipe_connect)");
     if (piped && !has_pt(c)) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
+    if (piped && c->pipe.staged) return fail(c, HENS_ERR_STATE, "staged pipeline: step with hens_pipe_stage (the messages travel between the stages)");
     if (!piped && c->cfg.adaptation_delay != 0)
         return fail(c, HENS_ERR_UNSUPPORTED, "adaptation_delay is an option of the ladder pipeline (hens_pipe_*)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
@@ -1709,6 +1730,104 @@ int hens_pipe_connect(hens_ctx* ctx, const void* blobs) {
         }
     }
     return pipe_finish_connect(c);
+}
+
+// ---- staged transport: the same protocol with RCCL send/recv between the launches ---------------------
+// The kernels are unchanged; they store into LOCAL outboxes laid out like the peers' mailboxes, and the caller
+// (eryn_amd.ladder.StagedPipeline: torch.distributed point-to-point = grouped ncclSend/ncclRecv on ROCm) moves
+// the message regions between the stages.  RCCL cannot pull, so the LDN message carries the boundary rung's rows.
+int hens_pipe_connect_staged(hens_ctx* ctx) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
+    if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
+    if (c->cfg.adaptation_delay != 0) return fail(c, HENS_ERR_UNSUPPORTED, "the staged transport runs the reference's adaptation schedule");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t bytes = c->pipe.box_bytes;
+    int r;
+    if ((r = dalloc(c, &c->pipe.out_hot, bytes))) return r;
+    if ((r = dalloc(c, &c->pipe.out_cold, bytes))) return r;
+    if ((r = dalloc(c, &c->pipe.out_cnt, (size_t)(512 + pipe_round((size_t)4 * c->T * 4))))) return r;
+    if ((r = dalloc(c, &c->pipe.ldn_rows, (size_t)2 * c->W * c->D))) return r;
+    HIPCHK(c, hipMemsetAsync(c->pipe.out_cnt, 0, 512 + pipe_round((size_t)4 * c->T * 4), c->stream));
+    std::vector<char*> table((size_t)c->pipe.nranks, c->pipe.out_cnt);       // the walk kernel's count puts
+    for (int q = 0; q < c->pipe.nranks; ++q)
+        c->pipe.boxes[q] = q == c->pipe.rank + 1 ? c->pipe.out_hot : (q == c->pipe.rank - 1 ? c->pipe.out_cold : c->pipe.out_cnt);
+    c->pipe.boxes[c->pipe.rank] = c->pipe.box;
+    HIPCHK(c, hipMemcpyAsync(c->pipe.d_boxes, table.data(), table.size() * sizeof(char*), hipMemcpyHostToDevice, c->stream));
+    // the bottom kernel "pulls" out of pool_cold at row meta[par] + slot: here the received copy of the rung
+    c->pipe.pool_cold = c->pipe.ldn_rows;
+    const long long meta[2] = {0, (long long)c->W};
+    const PipeBox me = pipe_box(c->pipe.box, c->T, c->W, c->D);
+    HIPCHK(c, hipMemcpyAsync(me.meta, meta, sizeof meta, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pipe.staged = true;
+    c->pipe.connected = true;
+    return HENS_OK;
+}
+
+int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
+    const int W = c->W, D = c->D, T = c->T, par = (int)(c->pipe.sweep & 1u);
+    const PipeBox me = pipe_box(c->pipe.box, T, W, D);
+    const PipeBox oh = pipe_box(c->pipe.out_hot, T, W, D), oc = pipe_box(c->pipe.out_cold, T, W, D);
+    const PipeBox on = pipe_box(c->pipe.out_cnt, T, W, D);
+    // the rows of my hottest rung after THIS iteration's move: home `parity` before the move flips it
+    out->ldn_out = oh.lp_dn + (size_t)par * 2 * W;
+    out->ldn_rows_out = c->pool + ((size_t)c->parity * c->Tl * W + (size_t)(c->Tl - 1) * W) * D;
+    out->ldn_in = me.lp_dn + (size_t)par * 2 * W;
+    out->ldn_rows_in = c->pipe.ldn_rows + (size_t)par * W * D;
+    out->lup_out = oc.lp_up + (size_t)par * 2 * W;
+    out->lup_in = me.lp_up + (size_t)par * 2 * W;
+    out->rows_out = oc.guest + (size_t)(par * 2) * W * D;
+    out->rows_in = me.guest + (size_t)(par * 2) * W * D;
+    out->cnt_out = on.counts + (size_t)(c->pipe.sweep & 3u) * T;
+    out->cnt_in = me.counts + (size_t)(c->pipe.sweep & 3u) * T;
+    out->lp_doubles = 2 * (int64_t)W;
+    out->row_doubles = (int64_t)W * D;
+    out->cnt_words = T;
+    out->stream = c->stream;
+    return HENS_OK;
+}
+
+int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = ready(c, true);
+    if (r) return r;
+    if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    switch (stage) {
+        case 0: {           // the iteration's move (stretch halves or the MH proposal); publishes (L, P) of the boundary rung
+            c->N0 = (c->W + 1) / 2;
+            if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
+                launch_plan(c, c->stream, 0, c->iter, c->NB);
+                c->win_from = c->iter;
+                c->win_count = c->NB;
+            }
+            if (iteration_is_mh(c)) r = mh_iteration(c, nullptr);
+            else r = stretch_pair(c, 0, (int)(c->iter - c->win_from), nullptr);
+            if (r) return r;
+            pipe_launch_pub(c);
+            break;
+        }
+        case 1: {           // after LDN (from below) and LUP (from above) have been received
+            const PipeBox on = pipe_box(c->pipe.out_cnt, c->T, c->W, c->D);
+            HIPCHK(c, hipMemsetAsync(on.counts + (size_t)(c->pipe.sweep & 3u) * c->T, 0, (size_t)c->T * 4, c->stream));
+            pipe_launch_walk(c);
+            break;
+        }
+        case 2:             // decides the bottom pair, settles my coldest rung, fills the rows that go down
+            pipe_launch_bottom(c);
+            pipe_finish_sweep(c);
+            c->iter += 1;
+            break;
+        default:
+            return fail(c, HENS_ERR_INVALID, "stage must be 0 (move), 1 (walk) or 2 (bottom)");
+    }
+    HIPCHK(c, hipGetLastError());
+    return HENS_OK;
 }
 
 // ---- pipeline self-test --------------------------------------------------------------------------------

@@ -1692,6 +1692,7 @@ struct PipeArgs {
     long long budget;             // wall-clock ticks a flag wait may take
     int32_t T, W, D, Tl, rung_begin, idx_bits, par, nranks, rank;
     int32_t home_off;             // pool row of (rung 0, slot 0) after this iteration's stretch move
+    int32_t nowait;               // staged (RCCL) transport: messages arrive in stream order, nothing to spin on
 };
 
 __device__ __forceinline__ int pipe_slot(const PipeArgs& A, int g, int c) {
@@ -1761,7 +1762,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     const int c0 = blockIdx.x * PT_COLS;
     const PipeBox me = pipe_box(A.box, T, W, D);
 
-    if (has_top) {                                               // what the hot neighbour's columns carry must be here
+    if (has_top && !A.nowait) {                                  // what the hot neighbour's columns carry must be here
         if (tid == 0) pipe_spin(me.flags + PF_LUP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
         __syncthreads();
     }
@@ -1895,8 +1896,8 @@ __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     const bool has_top = A.rung_begin + A.Tl < A.T;
     // the cold neighbour's rung after ITS stretch move; a walker may fall through all my rungs in one sweep,
     // so the rows from above must have landed too
-    if (threadIdx.x == 0) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
-    if (threadIdx.x == 64 && has_top) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
+    if (threadIdx.x == 0 && !A.nowait) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
+    if (threadIdx.x == 64 && has_top && !A.nowait) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
     __syncthreads();
     if (threadIdx.x < PIPE_COLS) {
         const int c = c0 + threadIdx.x;

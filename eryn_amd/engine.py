@@ -248,6 +248,19 @@ class HipEnsemble:
         arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
         check(self.lib.hens_pipe_connect_local(self.ctx, C.cast(arr, C.c_void_p)), self.ctx)
 
+    def pipe_connect_staged(self):
+        """Staged transport: the pipeline's kernels write into local outboxes, the caller moves the messages."""
+        check(self.lib.hens_pipe_connect_staged(self.ctx), self.ctx)
+
+    def pipe_regions(self):
+        from ._lib import HensPipeRegions
+        r = HensPipeRegions()
+        check(self.lib.hens_pipe_regions(self.ctx, C.byref(r)), self.ctx)
+        return r
+
+    def pipe_stage(self, stage):
+        check(self.lib.hens_pipe_stage(self.ctx, int(stage)), self.ctx)
+
     def pipe_debug_stats(self, reset=True):
         """{site: (seconds waited summed over workgroups, waits)} - needs HENS_PIPE_STATS=1 at pipe_init."""
         raw = np.zeros(16, dtype=np.uint64)

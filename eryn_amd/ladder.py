@@ -245,6 +245,82 @@ class LadderPipeline:
         self.e.step(n_iters)
 
 
+class StagedPipeline:
+    """The ladder pipeline's protocol with RCCL point-to-point messages (include/hipensemble.h, "Staged transport").
+
+    Same kernels and message contents as :class:`LadderPipeline`; the stores go into local outboxes and
+    ``torch.distributed`` isend / irecv (grouped ncclSend / ncclRecv over xGMI on ROCm) carries them between the
+    stages, ordered by the host.  RCCL cannot pull, so the boundary rung's rows travel with the LDN message and the
+    rows that move down travel as a dense [W, D] block.  It exists for nodes without peer mappings; the one-sided
+    transport is faster (no host ordering, sparse rows, one library call per n iterations).
+    """
+
+    def __init__(self, engine, rank, nranks, dist, device, group=None):
+        import torch
+        self.torch, self.dist, self.group = torch, dist, group
+        self.e, self.rank, self.nranks, self.device = engine, int(rank), int(nranks), device
+        self.top, self.bot = self.rank + 1 < self.nranks, self.rank > 0
+        self.host_staged = dist.get_backend(group) == "gloo"       # gloo moves CPU tensors only (tests on one GPU)
+        # one stream for the kernels and the collectives: ordered without host synchronisation
+        self.stream = torch.cuda.Stream(device)
+        torch.cuda.set_stream(self.stream)
+        engine.set_stream(self.stream.cuda_stream)
+        engine.pipe_init(self.nranks, self.rank)
+        engine.pipe_connect_staged()
+
+    def _t(self, ptr, n, typestr="<f8"):
+        return self.torch.as_tensor(_DevArray(ptr, (int(n),), typestr), device=self.device)
+
+    def _exchange(self, sends, recvs):
+        """sends / recvs: [(tensor, peer)].  One grouped batch of point-to-point operations."""
+        dist, torch = self.dist, self.torch
+        if not sends and not recvs:
+            return
+        if self.host_staged:
+            torch.cuda.current_stream().synchronize()
+            bufs = [torch.empty(t.shape, dtype=t.dtype) for t, _ in recvs]
+            ops = [dist.P2POp(dist.isend, t.cpu(), p, group=self.group) for t, p in sends]
+            ops += [dist.P2POp(dist.irecv, b, p, group=self.group) for b, (_, p) in zip(bufs, recvs)]
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            for b, (t, _) in zip(bufs, recvs):
+                t.copy_(b)
+            return
+        ops = [dist.P2POp(dist.isend, t, p, group=self.group) for t, p in sends]
+        ops += [dist.P2POp(dist.irecv, t, p, group=self.group) for t, p in recvs]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+
+    def step(self, n_iters=1):
+        e, up, dn = self.e, self.rank + 1, self.rank - 1
+        for _ in range(int(n_iters)):
+            r = e.pipe_regions()
+            lp, rows, nc = r.lp_doubles, r.row_doubles, r.cnt_words
+            e.pipe_stage(0)                                                        # move; publishes the boundary rung
+            sends = [(self._t(r.ldn_out, lp), up), (self._t(r.ldn_rows_out, rows), up)] if self.top else []
+            recvs = [(self._t(r.ldn_in, lp), dn), (self._t(r.ldn_rows_in, rows), dn)] if self.bot else []
+            self._exchange(sends, recvs)                                           # LDN: cold -> hot
+            if self.top:
+                self._exchange([], [(self._t(r.lup_in, lp), up)])                  # LUP: hot -> cold
+            e.pipe_stage(1)                                                        # walk
+            if self.bot:
+                self._exchange([(self._t(r.lup_out, lp), dn)], [])
+            if self.top:                                                           # ROWS: hot -> cold.  Before my bottom
+                self._exchange([], [(self._t(r.rows_in, rows), up)])               # kernel: a walker may fall through all
+            e.pipe_stage(2)                                                        # my rungs in one sweep
+            if self.bot:
+                self._exchange([(self._t(r.rows_out, rows), dn)], [])
+            cnt = self._t(r.cnt_out, nc, "<i4")                                    # CNT: every pair's owner -> all
+            if self.nranks > 1:
+                if self.host_staged:
+                    c = cnt.cpu()
+                    self.dist.all_reduce(c, group=self.group)
+                    cnt.copy_(c)
+                else:
+                    self.dist.all_reduce(cnt, group=self.group)
+            self._t(r.cnt_in, nc, "<i4").copy_(cnt)
+
+
 def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
     """N-GPU leg of bench.py: weak scaling, one fixed-size ladder shard per GPU."""
     import os
@@ -309,6 +385,10 @@ def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
             stepper = None
     transport = ("xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline), ladder adaptation "
                  + ("on the reference's schedule" if delay == 0 else "applied one sweep late (adaptation_delay=1)"))
+    if stepper is None and mode == "rccl_neighbour" and not force:
+        stepper = StagedPipeline(eng, rank, world, dist, device)
+        transport = "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages)"
+
     def make_collective(eng):
         return ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank,
                              nranks=world)

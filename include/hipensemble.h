@@ -254,6 +254,34 @@ int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals
 int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_out /* HENS_PIPE_BLOB_BYTES or NULL */,
                    int64_t* mailbox_bytes_out);
 int hens_pipe_connect(hens_ctx* ctx, const void* blobs /* nranks * HENS_PIPE_BLOB_BYTES, rank order */);
+/* ---- Staged transport: the pipeline's messages over RCCL send/recv ------------------------------------
+ * Same kernels, same protocol, but the stores go into LOCAL outboxes and the caller moves the message regions
+ * between the stages with point-to-point sends (torch.distributed isend/irecv = grouped ncclSend/ncclRecv on
+ * ROCm; eryn_amd.ladder.StagedPipeline).  For nodes where peer mappings are unavailable, and as the literal
+ * "RCCL neighbour exchange" of the design brief; it costs host-ordered launches and dense (not sparse) row
+ * messages, so the one-sided transport above stays the default.  Per iteration:
+ *   hens_pipe_regions                      (pointers of this sweep's message regions)
+ *   hens_pipe_stage 0                      move
+ *   send ldn_out + ldn_rows_out up,  recv ldn_in + ldn_rows_in from below
+ *   recv lup_in from above
+ *   hens_pipe_stage 1                      walk
+ *   send lup_out down
+ *   recv rows_in from above                (before the bottom kernel: a walker may fall through all my rungs)
+ *   hens_pipe_stage 2                      bottom
+ *   send rows_out down
+ *   all-reduce(sum) cnt_out over the ranks, copy to cnt_in */
+typedef struct hens_pipe_region_table {
+    void* ldn_out;  void* ldn_rows_out;  void* ldn_in;  void* ldn_rows_in;   /* f64: lp_doubles, row_doubles each */
+    void* lup_out;  void* lup_in;                                           /* f64: lp_doubles                  */
+    void* rows_out; void* rows_in;                                          /* f64: row_doubles                 */
+    void* cnt_out;  void* cnt_in;                                           /* u32: cnt_words                   */
+    int64_t lp_doubles, row_doubles, cnt_words;
+    void* stream;
+} hens_pipe_region_table;
+int hens_pipe_connect_staged(hens_ctx* ctx);
+int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out);
+int hens_pipe_stage(hens_ctx* ctx, int32_t stage);
+
 /* Self-test of the peer accesses the pipeline relies on (one-sided put + flag into uncached memory, pull out of
  * ordinary device memory), between this process and its ladder neighbours' processes, which find each other
  * through files in `dir`.  Needs no context.  eryn_amd.ladder runs it in a throw-away process per rank before

@@ -2,6 +2,7 @@
 
   local <nranks> <T> <W> <D> <iters> <out.npz>       N shards in this process on one GPU
   ipc   <rank> <world> <T> <W> <D> <iters> <outdir>  one shard per PROCESS, mailboxes mapped through HIP IPC
+  staged <rank> <world> <T> <W> <D> <iters> <outdir> one shard per process, messages by torch.distributed point-to-point
   single <T> <W> <D> <iters> <out.npz>               the unsharded run both are compared with
 env PIPE_TEST_DELAY=1 runs everything with adaptation_delay = 1 (then "single" is a 1-rank pipeline).
   timeout                                            rank 1 never steps: rank 0 must raise, not hang
@@ -98,6 +99,23 @@ def main():
         _, bounds = rung_partition(T, world)
         e = make(T, W, D, bounds[rank])
         pipe = LadderPipeline(e, rank, world, dist=dist)
+        for n in (iters // 2, iters - iters // 2):
+            pipe.step(n)
+            e.synchronize()
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), **snapshot(e))
+        dist.barrier()
+        e.close()
+        dist.destroy_process_group()
+    elif mode == "staged":
+        # the same protocol with point-to-point messages between the stages (RCCL on a multi-GPU node; gloo here)
+        rank, world, T, W, D, iters = map(int, sys.argv[2:8])
+        outdir = sys.argv[8]
+        import torch.distributed as dist
+        from eryn_amd.ladder import StagedPipeline
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        _, bounds = rung_partition(T, world)
+        e = make(T, W, D, bounds[rank], delay=0)
+        pipe = StagedPipeline(e, rank, world, dist, torch.device("cuda", 0))
         for n in (iters // 2, iters - iters // 2):
             pipe.step(n)
             e.synchronize()

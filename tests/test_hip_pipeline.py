@@ -122,6 +122,35 @@ def test_pipeline_dead_neighbour_raises_instead_of_hanging():
     assert "did not answer" in r.stdout
 
 
+@pytest.mark.parametrize("world,T,W,D,iters,model", [(2, 4, 256, 32, 8, "gauss"), (3, 6, 128, 8, 7, "gauss"),
+                                                      (2, 4, 256, 128, 8, "rosen_mix")])
+def test_staged_transport_matches_single_context(tmp_path, world, T, W, D, iters, model):
+    """StagedPipeline: the pipeline's messages as point-to-point sends between the stages (grouped ncclSend/ncclRecv on
+    a multi-GPU node, gloo between processes sharing this GPU).  Bit-identical to the unsharded ladder."""
+    ref = _single(tmp_path, T, W, D, iters, model=model)
+    port = 29700 + (os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, WORKER, "staged", str(r), str(world), str(T), str(W), str(D), str(iters),
+                               str(tmp_path)], env=_env(port, model=model), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    snaps = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    got = {k: np.concatenate([s[k] for s in snaps], axis=0) for k in ("x", "L", "P", "accepted")}
+    for k in ("betas", "swaps_total", "swaps_last"):
+        for s in snaps[1:]:
+            assert np.array_equal(s[k], snaps[0][k])
+        got[k] = snaps[0][k]
+    _compare(ref, got)
+
+
 def test_pipe_selftest_helper_processes(tmp_path):
     """hens_pipe_selftest (what LadderPipeline runs in throw-away processes before connecting): three ranks put into
     and pull from their neighbours through HIP IPC; a rank whose neighbour never shows up fails instead of hanging."""
