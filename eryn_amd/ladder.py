@@ -9,7 +9,10 @@ uncached device memory that its two ladder neighbours store into directly (HIP I
 stores), followed by a flag the consumer kernel spins on.  ``torch.distributed`` only all-gathers the
 IPC handles once; after that ``step(n)`` is one library call per rank.  Philox draws only.  DESIGN 6.1.
 
-:class:`ShardedLadder` (fallback; also the teacher-forced path) - RCCL collectives per iteration:
+:class:`StagedPipeline` - the same protocol and kernels with RCCL point-to-point messages (grouped ncclSend /
+ncclRecv) between three host-ordered stages per iteration; for nodes without peer mappings.  DESIGN 6.2.
+
+:class:`ShardedLadder` (automatic fallback; also the teacher-forced path) - RCCL collectives per iteration:
 
   1. all-gather of the log-likelihoods  [Tl, W] -> [T, W]            RCCL all_gather
   2. EVERY rank replays the whole hot->cold cascade from the gathered ladder (one parallel kernel in
