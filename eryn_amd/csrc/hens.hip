@@ -179,11 +179,14 @@ size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)5 * c->W + 16; }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
-int fast_nw(int D) {
-    static const int nw64 = getenv("HENS_NW64") ? atoi(getenv("HENS_NW64")) : 8;
-    return D == 32 ? FAST_NW_32 : (D == 64 ? nw64 : 4);
+int fast_nw(int D) { return (D == 32 || D == 64 || D == 128) ? 8 : 4; }
+// row widths with a compile-time-width kernel (k_stretch_fast); D = 128 only without the dense quadratic form
+// (128 centred coordinates per lane do not fit the register file; it would need the blocked form of D = 64)
+bool fast_path(const hens_ctx_impl* c) {
+    const int D = c->D;
+    return D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && c->cfg.likelihood_kind != HENS_LIKE_GAUSS_DENSE &&
+                                                      c->cfg.likelihood_kind != HENS_LIKE_HOST);
 }
-bool is_fast_dim(int D) { return D == 8 || D == 16 || D == 32 || D == 64; }
 
 size_t generic_lds_bytes(int D, int* RS_out) {
     const int RS = (D % 2 == 0) ? D + 2 : D;
@@ -219,18 +222,21 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         if (c->pipe.on) LAUNCH_FAST_P(DT, NW, true);                                               \
         else LAUNCH_FAST_P(DT, NW, false);                                                         \
     } while (0)
+    bool launched = true;
     if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
     } else if (c->D == 64) {
-        static const int nw64 = getenv("HENS_NW64") ? atoi(getenv("HENS_NW64")) : 8;
-        if (nw64 == 4) LAUNCH_FAST(64, 4);
-        else if (nw64 == 16) LAUNCH_FAST(64, 16);
-        else LAUNCH_FAST(64, 8);
+        LAUNCH_FAST(64, 8);
     } else if (c->D == 16) {
         LAUNCH_FAST(16, 4);
     } else if (c->D == 8) {
         LAUNCH_FAST(8, 4);
+    } else if (c->D == 128 && LIKE != LIKE_DENSE) {
+        if constexpr (LIKE != LIKE_DENSE) LAUNCH_FAST(128, 8);
     } else {
+        launched = false;
+    }
+    if (!launched) {
         int RS;
         const size_t lds = generic_lds_bytes(c->D, &RS);
         if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
@@ -345,7 +351,7 @@ void flush_adapt(hens_ctx_impl* c) {
 // can the pending adaptation ride in the next split-0 stretch launch?
 bool can_fold_adapt(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FOLD") != nullptr;
-    if (off || !c->adapt_pending || !is_fast_dim(c->D) || c->T > 64) return false;
+    if (off || !c->adapt_pending || !fast_path(c) || c->T > 64) return false;
     const int nw = fast_nw(c->D);
     const int64_t nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     return nw >= 2 && nblocks * (c->T - 1) <= (int64_t)8 * nw * 64;
@@ -431,7 +437,7 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
 
 bool pipe_publish_fused(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_PIPE_SEPARATE_PUB") != nullptr;     // A/B knob
-    return !off && is_fast_dim(c->D);
+    return !off && fast_path(c);
 }
 
 PipeArgs pipe_args(hens_ctx_impl* c) {
@@ -501,7 +507,7 @@ void pipe_promote_pending(hens_ctx_impl* c, bool all) {
 }
 void pipe_prewait(hens_ctx_impl* c) {
     const unsigned long long m = pipe_prewait_mask(c);
-    if (!m || is_fast_dim(c->D)) return;
+    if (!m || fast_path(c)) return;
     if ((m >> PF_ROWS_TOP) & 1) pipe_wait(c, {PF_ROWS_TOP}, false, c->pipe.sweep);
     if ((m >> PF_CNT0) != 0) pipe_wait(c, {}, true, c->pipe.due_sweep + 1);
 }
@@ -571,7 +577,7 @@ hipEvent_t new_event(hens_ctx_impl* c) {
 // the first launch of an iteration: wait for the pipeline's arrivals in its prologue and carry the pending
 // ladder adaptation (or run it as a kernel of its own where it cannot be folded)
 void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
-    if (is_fast_dim(c->D)) {
+    if (fast_path(c)) {
         a.wmask = pipe_prewait_mask(c);
         if (a.wmask) {
             a.wflags = pipe_box(c->pipe.box, c->T, c->W, c->D).flags;
@@ -688,7 +694,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
 // axis-aligned proposals on the fast row widths are drawn inside the MH launch itself (one Box-Muller pair per
 // lane); a full covariance (Cholesky product) and the generic row widths go through k_mh_draw + the step buffer.
 int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
-    const bool inline_draws = c->mh_kind != MH_FULL && is_fast_dim(c->D);
+    const bool inline_draws = c->mh_kind != MH_FULL && fast_path(c);
     if (!inline_draws) {
         MhDrawArgs d{};
         d.step = c->mh_step; d.lu = c->mh_lu; d.scale = c->mh_scale;

@@ -99,8 +99,8 @@ def test_eval_state_matches_oracle():
     eng.close()
 
 
-def test_diag_likelihood():
-    T, W, D = 2, 128, 5
+@pytest.mark.parametrize("T,W,D", [(2, 128, 5), (2, 256, 32), (3, 512, 128)])     # generic / fast / D = 128 fast kernels
+def test_diag_likelihood(T, W, D):
     o, mu, invcov = pu.make_oracle(T, W, D, box=5.0, dense=False)
     eng = pu.make_engine(o, mu, invcov, dense=False)
     assert pu.run_parity(o, eng, 5, teacher_forced=True) == 0
@@ -153,7 +153,7 @@ def test_philox_permutations_are_uniform_bijections(W):
     eng.close()
 
 
-@pytest.mark.parametrize("T,W,D", [(3, 128, 8), (2, 100, 5), (2, 256, 32)])
+@pytest.mark.parametrize("T,W,D", [(3, 128, 8), (2, 100, 5), (2, 256, 32), (3, 512, 128)])
 def test_rosenbrock_likelihood(T, W, D):
     """The config-5 stress likelihood (not in the reference; defined in oracle.rosenbrock_log_like)
     through the same fused kernel, teacher-forced: low acceptance, generic and fast row widths."""

@@ -5,7 +5,7 @@ import time
 import numpy as np
 
 from eryn_amd.engine import HipEnsemble
-from eryn_amd.likelihood import GaussianLikelihood
+from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
 
 
 def problem(D):
@@ -34,7 +34,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     T, W, D = a.T, a.W, a.D
     mu, invcov, cov = problem(D)
-    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov if a.like == 'dense' else np.diag(invcov).copy()), -50.0, 50.0, seed=2024)
+    like = RosenbrockLikelihood(D) if a.like == 'rosen' else GaussianLikelihood(mu, invcov if a.like == 'dense' else np.diag(invcov).copy())
+    eng = HipEnsemble(T, W, D, like, -50.0 if a.like != 'rosen' else -5.0, 50.0 if a.like != 'rosen' else 5.0, seed=2024)
     x0 = np.random.RandomState(1).randn(T, W, D)
     eng.upload(x0, betas=ladder(D, T))
     eng.eval_state()
