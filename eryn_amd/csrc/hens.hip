@@ -180,12 +180,10 @@ size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)5 * c->W + 16; }
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
 int fast_nw(int D) { return (D == 32 || D == 64 || D == 128) ? 8 : 4; }
-// row widths with a compile-time-width kernel (k_stretch_fast); D = 128 only without the dense quadratic form
-// (128 centred coordinates per lane do not fit the register file; it would need the blocked form of D = 64)
+// row widths with a compile-time-width kernel (k_stretch_fast)
 bool fast_path(const hens_ctx_impl* c) {
     const int D = c->D;
-    return D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && c->cfg.likelihood_kind != HENS_LIKE_GAUSS_DENSE &&
-                                                      c->cfg.likelihood_kind != HENS_LIKE_HOST);
+    return D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && c->cfg.likelihood_kind != HENS_LIKE_HOST);
 }
 
 size_t generic_lds_bytes(int D, int* RS_out) {
@@ -231,8 +229,8 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         LAUNCH_FAST(16, 4);
     } else if (c->D == 8) {
         LAUNCH_FAST(8, 4);
-    } else if (c->D == 128 && LIKE != LIKE_DENSE) {
-        if constexpr (LIKE != LIKE_DENSE) LAUNCH_FAST(128, 8);
+    } else if (c->D == 128) {
+        LAUNCH_FAST(128, 8);
     } else {
         launched = false;
     }
@@ -952,6 +950,17 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
             pack_block(H, H, sym.data() + BLK);
             for (int i = 0; i < H; ++i)
                 for (int k = 0; k < H; ++k) sym[(size_t)2 * BLK + (size_t)i * H + k] = S(i, H + k);
+        } else if (D == 128) {
+            // four 32-blocks: [4 diagonal blocks][6 cross blocks (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)]
+            constexpr int H = 32, BLK = (H / 2) * (H + 2);
+            sym.assign((size_t)4 * BLK + (size_t)6 * H * H, 0.0);
+            for (int b = 0; b < 4; ++b) pack_block(b * H, H, sym.data() + (size_t)b * BLK);
+            int x = 0;
+            for (int bi = 0; bi < 4; ++bi)
+                for (int bk = bi + 1; bk < 4; ++bk, ++x)
+                    for (int i = 0; i < H; ++i)
+                        for (int k = 0; k < H; ++k)
+                            sym[(size_t)4 * BLK + (size_t)x * H * H + (size_t)i * H + k] = S(bi * H + i, bk * H + k);
         } else {
             sym.assign((size_t)(D / 2) * (D + 2), 0.0);
             pack_block(0, D, sym.data());

@@ -853,6 +853,43 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                         }
                     }
                 }
+            } else if (LIKE == LIKE_DENSE && DT == 128 && NW == 8) {
+                // D = 128: the same blocking with four 32-blocks: 4 symmetric diagonal blocks (528 FMAs each) and
+                // 6 cross blocks (1024 each).  Waves 0-5 take one cross block each, waves 6 and 7 two diagonal
+                // blocks each: 1024 / 1056 FMAs per lane, one 32-vector in registers at a time.
+                constexpr int H = 32, SB = (H / 2) * (H + 2);
+                const cptr_t psym = (cptr_t)(uintptr_t)A.prec_sym;
+                double qh[H];
+                if (wv < 6) {
+                    const int bi = wv < 3 ? 0 : (wv < 5 ? 1 : 2);                  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+                    const int bk = wv < 3 ? wv + 1 : (wv < 5 ? wv - 1 : 3);
+#pragma unroll
+                    for (int k = 0; k < H; k += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(qrow + bk * H + k);
+                        qh[k] = v.x - mu[bk * H + k];
+                        qh[k + 1] = v.y - mu[bk * H + k + 1];
+                    }
+                    const cptr_t cx = psym + 4 * SB + wv * H * H;
+#pragma unroll 4
+                    for (int r = 0; r < H; ++r) {
+                        double y = 0.0;
+#pragma unroll
+                        for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
+                        part = fma(qrow[bi * H + r] - mu[bi * H + r], y, part);
+                    }
+                } else {
+#pragma unroll
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int b = (wv - 6) * 2 + b2;
+#pragma unroll
+                        for (int k = 0; k < H; k += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(qrow + b * H + k);
+                            qh[k] = v.x - mu[b * H + k];
+                            qh[k + 1] = v.y - mu[b * H + k + 1];
+                        }
+                        part += sym_quad<H, 1, 0>(qh, psym + b * SB);
+                    }
+                }
             } else if (LIKE == LIKE_DENSE) {
                 double qreg[DT];
 #pragma unroll
