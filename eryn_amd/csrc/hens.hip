@@ -192,7 +192,7 @@ size_t generic_lds_bytes(int D, int* RS_out) {
     return (size_t)TILE * RS * 8 + (size_t)TILE * 8 + (size_t)4 * TILE * 8 + 4 * (size_t)TILE * 4;
 }
 size_t fast_lds_bytes(int D, int NW) {
-    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 64) * 8 + 5 * (size_t)TILE * 4;
+    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 128) * 8 + (4 * (size_t)TILE + 128) * 4;
 }
 
 template <int LIKE, int MODE>
@@ -349,7 +349,7 @@ void flush_adapt(hens_ctx_impl* c) {
 // can the pending adaptation ride in the next split-0 stretch launch?
 bool can_fold_adapt(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FOLD") != nullptr;
-    if (off || !c->adapt_pending || !fast_path(c) || c->T > 64) return false;
+    if (off || !c->adapt_pending || !fast_path(c) || c->T > 128) return false;
     const int nw = fast_nw(c->D);
     const int64_t nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     return nw >= 2 && nblocks * (c->T - 1) <= (int64_t)8 * nw * 64;

@@ -209,6 +209,12 @@ struct AdaptArgs {
     double lag, nu;
     int64_t time;               // adaptation steps taken so far (tempering.py:596)
     int32_t T, W, nblocks, moving;   // moving: adaptive and not past stop_adaptation (tempering.py:591)
+    // ladder pipeline (k_adapt only): the counts come from every rank - wait for their flags first
+    const unsigned* wait_flags;      // my mailbox's PF_CNT0.. words, or nullptr
+    unsigned* wait_err;
+    long long wait_budget;
+    uint32_t wait_target;
+    int32_t wait_n;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -599,12 +605,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
     double* s_zz = qtile + TILE * RS;                                    // [TILE]
     double* s_part = s_zz + TILE;                                        // [NW][TILE]
-    double* s_beta = s_part + NW * TILE;                                 // [64] adapted ladder (ad_on)
-    int32_t* s_rs = reinterpret_cast<int32_t*>(s_beta + 64);             // [TILE]
+    double* s_beta = s_part + NW * TILE;                                 // [128] adapted ladder (ad_on)
+    int32_t* s_rs = reinterpret_cast<int32_t*>(s_beta + 128);            // [TILE]
     int32_t* s_rc = s_rs + TILE;
     int32_t* s_dst = s_rc + TILE;
     int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
-    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [64] swap counts (ad_on)
+    unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [128] swap counts (ad_on)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -668,6 +674,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_flag[lane] = valid ? 4 : 0;
     } else if (ad_on && wv == 1) {
         s_cnt[lane] = 0;
+        s_cnt[lane + 64] = 0;
     }
     HENS_TRACE(1);
     lds_barrier();
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     unsigned adv[8];
-    double ad_b = 1.0;
+    double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
     if (ad_on) {                                   // the cascade's per-workgroup swap counts: <= 8 per thread
         const int total = A.ad.nblocks * (A.ad.T - 1);
 #pragma unroll
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             adv[q] = (e < total) ? A.ad.swap_part[e] : 0u;
         }
         if (wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
+        if (wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
     }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
@@ -760,41 +768,61 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     lds_barrier();
     HENS_TRACE(4);
 
-    // ---- ladder adaptation in one wavefront (tempering.py:563-596), T <= 64 ---------------------------
+    // ---- ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64 ------
     if (ad_on && wv == 1) {
         const int T = A.ad.T;
-        const double cntl = (lane < T - 1) ? (double)s_cnt[lane] : 0.0;
-        const double r = cntl / (double)A.ad.W;                             // :587
-        double bnew = ad_b;
+        const int e0 = lane, e1 = lane + 64;
+        const double cnt0 = (e0 < T - 1) ? (double)s_cnt[e0] : 0.0;
+        const double cnt1 = (e1 < T - 1) ? (double)s_cnt[e1] : 0.0;
+        const double r0 = cnt0 / (double)A.ad.W, r1 = cnt1 / (double)A.ad.W;       // :587
+        double bnew0 = ad_b, bnew1 = ad_b1;
         if (A.ad.moving) {
-            const double decay = A.ad.lag / ((double)A.ad.time + A.ad.lag); // :571
-            const double kappa = decay / A.ad.nu;                           // :572
-            const double r1 = __shfl_down(r, 1);
-            const double b1 = __shfl_down(ad_b, 1);
-            double dTl = 0.0;
-            if (lane + 2 < T) {
-                const double dS = kappa * (r - r1);                         // :575
-                dTl = 1.0 / b1 - 1.0 / ad_b;                                // :578
-                dTl *= exp(dS);
+            const double decay = A.ad.lag / ((double)A.ad.time + A.ad.lag);        // :571
+            const double kappa = decay / A.ad.nu;                                  // :572
+            // the value of the NEXT rung (e + 1): lane 63's successor is rung 64 = lane 0's second element
+            const double r0d = __shfl_down(r0, 1), r1first = __shfl(r1, 0);
+            const double b0d = __shfl_down(ad_b, 1), b1first = __shfl(ad_b1, 0);
+            const double r0n = lane < 63 ? r0d : r1first, b0n = lane < 63 ? b0d : b1first;
+            const double r1n = __shfl_down(r1, 1), b1n = __shfl_down(ad_b1, 1);
+            double dT0 = 0.0, dT1 = 0.0;
+            if (e0 + 2 < T) {
+                const double dS = kappa * (r0 - r0n);                              // :575
+                dT0 = 1.0 / b0n - 1.0 / ad_b;                                      // :578
+                dT0 *= exp(dS);
             }
-            double csum = 0.0;                                              // np.cumsum: left-to-right
+            if (e1 + 2 < T) {
+                const double dS = kappa * (r1 - r1n);
+                dT1 = 1.0 / b1n - 1.0 / ad_b1;
+                dT1 *= exp(dS);
+            }
+            double cs0 = 0.0, cs1 = 0.0;                                           // np.cumsum: left-to-right
             for (int i = 0; i + 2 < T; ++i) {
-                const double v = __shfl(dTl, i);
-                if (i == 0) csum = v;
-                else if (i <= lane) csum = csum + v;
+                const double v = i < 64 ? __shfl(dT0, i) : __shfl(dT1, i - 64);
+                if (i == 0) { cs0 = v; cs1 = v; }
+                else {
+                    if (i <= e0) cs0 = cs0 + v;
+                    if (i <= e1) cs1 = cs1 + v;
+                }
             }
             const double inv0 = 1.0 / __shfl(ad_b, 0);
-            const double bn = 1.0 / (csum + inv0);                          // :580, belongs to rung lane+1
-            const double upd = b1 + (bn - b1);                              // :583,:593
-            const double from_below = __shfl_up(upd, 1);
-            if (lane >= 1 && lane + 1 < T) bnew = from_below;
+            const double bn0 = 1.0 / (cs0 + inv0), bn1 = 1.0 / (cs1 + inv0);       // :580, belong to rungs e + 1
+            const double upd0 = b0n + (bn0 - b0n), upd1 = b1n + (bn1 - b1n);      // :583,:593
+            const double up0 = __shfl_up(upd0, 1), up1 = __shfl_up(upd1, 1), upd0last = __shfl(upd0, 63);
+            if (e0 >= 1 && e0 + 1 < T) bnew0 = up0;
+            if (e1 + 1 < T) bnew1 = lane >= 1 ? up1 : upd0last;
         }
-        if (lane < T) s_beta[lane] = bnew;
+        if (e0 < T) s_beta[e0] = bnew0;
+        if (e1 < T) s_beta[e1] = bnew1;
         if (blockIdx.x == 0 && blockIdx.y == 0) {
-            if (lane < T) A.ad.betas_out[lane] = bnew;
-            if (lane < T - 1) {
-                A.ad.swaps_last[lane] = cntl;
-                A.ad.swaps_total[lane] += cntl;
+            if (e0 < T) A.ad.betas_out[e0] = bnew0;
+            if (e1 < T) A.ad.betas_out[e1] = bnew1;
+            if (e0 < T - 1) {
+                A.ad.swaps_last[e0] = cnt0;
+                A.ad.swaps_total[e0] += cnt0;
+            }
+            if (e1 < T - 1) {
+                A.ad.swaps_last[e1] = cnt1;
+                A.ad.swaps_total[e1] += cnt1;
             }
         }
     }
@@ -1410,6 +1438,7 @@ __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
     double* bnew = dT + T;
     unsigned* cnt = reinterpret_cast<unsigned*>(bnew + T);
     for (int j = tid; j < T; j += NTHREADS) cnt[j] = 0;
+    if (A.wait_flags && tid < A.wait_n) pipe_spin(A.wait_flags + tid, A.wait_target, A.wait_budget, A.wait_err);
     __syncthreads();
     const int total = A.nblocks * (T - 1);
     for (int e0 = tid; e0 < total; e0 += 8 * NTHREADS) {

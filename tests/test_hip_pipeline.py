@@ -166,3 +166,22 @@ def test_pipe_selftest_helper_processes(tmp_path):
     r = subprocess.run([sys.executable, "-m", "eryn_amd.pipe_probe", "0", "0", "2", str(lone), "1"], cwd=root,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "never published" in r.stdout
+
+
+def test_folded_adaptation_long_ladders(tmp_path):
+    """Ladders of 65..128 rungs (8 GPUs x 16 rungs in bench.py): the adaptation folded into the stretch launch keeps two
+    rungs per lane.  It must equal the stand-alone adaptation kernel bit for bit, on one context and sharded."""
+    T, W, D, iters = 100, 64, 8, 9
+    ref = _single(tmp_path, T, W, D, iters)
+    env = _env()
+    env["HENS_NO_FOLD"] = "1"
+    out = tmp_path / "nofold.npz"
+    r = subprocess.run([sys.executable, WORKER, "single", str(T), str(W), str(D), str(iters), str(out)], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _compare(ref, np.load(out))
+    assert ref["swaps_total"].sum() > 0 and np.all(np.diff(ref["betas"]) < 0)      # the ladder really adapted, still ordered
+    out2 = tmp_path / "local.npz"
+    r = _run(["local", 4, T, W, D, iters, out2])
+    assert r.returncode == 0, r.stdout + r.stderr
+    _compare(ref, np.load(out2))
