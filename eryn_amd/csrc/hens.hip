@@ -51,6 +51,8 @@ struct hens_ctx_impl {
     uint32_t* swap_part = nullptr;   // [nblocks][T-1]
     double* swaps_last = nullptr;
     double* swaps_total = nullptr;
+    double* ad_ring = nullptr;       // [4][T] new ladders published by the adapting workgroup (fold mode 2), -1 = not yet
+    uint32_t ad_serial = 0;
 
     // model
     double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr; double* prec_sym = nullptr;
@@ -346,6 +348,15 @@ void flush_adapt(hens_ctx_impl* c) {
     c->adapt_src = nullptr;
 }
 
+// how the folded adaptation is shared out: 2 (default) = workgroup (0,0) reduces the counts and adapts once, the
+// others pick up their rung's beta from a ring while they compute the likelihood; 1 = every workgroup recomputes
+// it.  Measured at cfg 2: 31.2 vs 32.4 us per iteration; on a pipeline rank (the counts live in uncached mailbox
+// memory, one reader instead of hundreds) 108 vs 126 us at 64 rungs, 213 vs 288 us at 128 rungs.
+int fold_mode(const hens_ctx_impl*) {
+    static const int forced = getenv("HENS_FOLD_MODE") ? atoi(getenv("HENS_FOLD_MODE")) : 0;
+    return forced == 1 ? 1 : 2;
+}
+
 // can the pending adaptation ride in the next split-0 stretch launch?
 bool can_fold_adapt(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FOLD") != nullptr;
@@ -589,7 +600,11 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
     if (can_fold_adapt(c)) {
         // the previous cascade's ladder adaptation rides in this launch: every workgroup reads
         // the old ladder, workgroup (0,0) writes the new one into the other buffer
-        a.ad_on = 1;
+        a.ad_on = fold_mode(c);
+        if (a.ad_on == 2) {
+            a.ad_ring = c->ad_ring;
+            a.ad_serial = c->ad_serial++;
+        }
         a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
         a.betas = c->betas[c->bcur];
         if (c->adapt_pending_adaptive) c->adapt_time += 1;
@@ -805,6 +820,12 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRY(dalloc(c, &c->mu, (size_t)c->D));
     TRY(dalloc(c, &c->prec, (size_t)c->D * c->D));
     TRY(dalloc(c, &c->prec_sym, (size_t)(c->D / 2 + 1) * (c->D + 2)));
+    TRY(dalloc(c, &c->ad_ring, (size_t)4 * c->T));
+    {
+        std::vector<double> neg((size_t)4 * c->T, -1.0);
+        TRYHIP(hipMemcpyAsync(c->ad_ring, neg.data(), neg.size() * 8, hipMemcpyHostToDevice, c->stream));
+        TRYHIP(hipStreamSynchronize(c->stream));
+    }
     TRY(dalloc(c, &c->order, TW));
     TRY(dalloc(c, &c->d_rint, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->d_uzz, (size_t)c->Tl * c->N0));

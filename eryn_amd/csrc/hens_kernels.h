@@ -238,7 +238,10 @@ struct StretchArgs {
     unsigned long long* trace; // debug: per-workgroup phase timestamps (s_memtime), or nullptr
     double logp_in, fill, rosen_a, rosen_b;
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered, RS;
-    int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch
+    int32_t ad_on;             // fold the ladder adaptation of the previous cascade into this launch: 1 = every workgroup
+                               // recomputes it; 2 = workgroup (0,0) computes it and publishes every rung's beta in ad_ring
+    double* ad_ring;           // [4][T] (mode 2) slot ad_serial & 3 receives the new ladder; -1 = not there yet
+    uint32_t ad_serial;
     int64_t guest_delta;       // see row_off (0 when there is no pipeline)
     const double* mh_step;     // MODE_MH: [Tl][W][D] proposal steps, or nullptr: isotropic / axis-aligned steps drawn in place
     const double* mh_scale;    //   (mh_kind MH_ISO: [1], MH_DIAG: [D] standard deviations; Philox keys mh_iter, mh_seed)
@@ -621,10 +624,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const int s_off = (EVAL || MH) ? 0 : (A.split == 0 ? 0 : A.N0);
     const int k0 = blockIdx.x * TILE;
     const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
+    // mode 2: only workgroup (0,0) reduces the counts and adapts; everyone else reads its rung's beta from the ring
+    const bool ad_lead = ad_on && A.ad_on == 2;
+    const bool ad_here = ad_on && (!ad_lead || (blockIdx.x == 0 && blockIdx.y == 0));
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     HENS_TRACE(0);
     if (PIPE && !EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
-        if (wv == 0 && ((A.wmask >> lane) & 1ull))
+        if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || ad_here || !ad_lead))
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
                       A.wstats ? A.wstats + (lane >= PF_CNT0 ? 2 : 0) : nullptr);
         __syncthreads();
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_rc[lane] = rc;
         s_dst[lane] = A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
-    } else if (ad_on && wv == 1) {
+    } else if (ad_here && wv == 1) {
         s_cnt[lane] = 0;
         s_cnt[lane + 64] = 0;
     }
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     unsigned adv[8];
     double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
-    if (ad_on) {                                   // the cascade's per-workgroup swap counts: <= 8 per thread
+    if (ad_here) {                                 // the cascade's per-workgroup swap counts: <= 8 per thread
         const int total = A.ad.nblocks * (A.ad.T - 1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
         }
     }
-    if (ad_on) {
+    if (ad_here) {
         const int Tm1 = A.ad.T - 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(4);
 
     // ---- ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64 ------
-    if (ad_on && wv == 1) {
+    if (ad_here && wv == 1) {
         const int T = A.ad.T;
         const int e0 = lane, e1 = lane + 64;
         const double cnt0 = (e0 < T - 1) ? (double)s_cnt[e0] : 0.0;
@@ -813,6 +819,18 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         }
         if (e0 < T) s_beta[e0] = bnew0;
         if (e1 < T) s_beta[e1] = bnew1;
+        if (ad_lead) {       // publish: agent-scope stores (other XCDs read them with agent-scope loads); retire the slot after next
+            double* slot = A.ad_ring + (size_t)(A.ad_serial & 3u) * T;
+            double* clear = A.ad_ring + (size_t)((A.ad_serial + 2u) & 3u) * T;
+            if (e0 < T) {
+                __hip_atomic_store(clear + e0, -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + e0, bnew0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (e1 < T) {
+                __hip_atomic_store(clear + e1, -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(slot + e1, bnew1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (blockIdx.x == 0 && blockIdx.y == 0) {
             if (e0 < T) A.ad.betas_out[e0] = bnew0;
             if (e1 < T) A.ad.betas_out[e1] = bnew1;
@@ -825,6 +843,14 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 A.ad.swaps_total[e1] += cnt1;
             }
         }
+    }
+
+    // mode 2: the rung's new beta, requested now and consumed after the likelihood (phase D)
+    double beta_ring = -1.0;
+    const double* ring_slot = nullptr;
+    if (ad_lead && wv == 0) {
+        ring_slot = A.ad_ring + (size_t)(A.ad_serial & 3u) * A.ad.T + (A.rung_begin + tl);
+        beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
@@ -972,7 +998,18 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         } else {
             double logP, prevP;
             if (A.tempered) {                                  // tempering.py:304-306,343-349
-                const double beta = ad_on ? s_beta[A.rung_begin + tl] : beta_pre;
+                double beta = beta_pre;
+                if (ad_lead) {                                 // workgroup (0,0) may still be adapting: wait for the value
+                    const long long t0 = wall_clock64();
+                    while (beta_ring < 0.0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (wall_clock64() - t0 > 200000000LL) { atomicOr(A.flags, FLAG_PIPE_TIMEOUT); break; }
+                    }
+                    beta = beta_ring;
+                } else if (ad_on) {
+                    beta = s_beta[A.rung_begin + tl];
+                }
                 double lt = logl * beta;
                 if (lt != lt) lt = -INFINITY;
                 logP = lt + logp;

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                       # torch first: a process that uses both must load torch's HIP runtime before libhipensemble
+    import torch  # noqa: F401  (eryn_amd/_lib.py), whatever subset of the tests is selected
+except ImportError:        # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
