@@ -114,21 +114,6 @@ __device__ __forceinline__ double mh_log_uniform(uint64_t seed, uint64_t it, uin
 // mailbox flag words (sweep counters raised by the peers)
 enum { PF_LUP = 0, PF_LDN = 1, PF_ROWS_TOP = 2, PF_CNT0 = 8, PIPE_FLAG_WORDS = 64 };
 
-// Ticket: a workgroup whose own stores have completed takes a number; the call returns true in the LAST
-// workgroup of the launch, which may then raise flags on behalf of the whole grid (no extra launch, no
-// L2 write-back: the data the flags cover was written with write-through stores).
-__device__ __forceinline__ bool pipe_last_block(unsigned* ticket, unsigned nblocks, uint32_t sweep) {
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (old + 1u) == nblocks * (sweep + 1u);      // tickets are cumulative over the sweeps (mod 2^32)
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-
 // peer memory is written and read with system-scope accesses (sc0 sc1: nothing lingers in a cache)
 __device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -143,7 +128,9 @@ __device__ __forceinline__ void pipe_raise(unsigned* f, uint32_t v) {
     __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// same with an explicit cumulative target (launches of different grid sizes share one ticket)
+// Ticket: a workgroup whose own stores have completed takes a number; returns true in the workgroup that completes
+// the cumulative target (launches of different grid sizes share one ticket) - it may then raise flags on behalf of
+// the whole grid (no extra launch, no L2 write-back: the data the flags cover was written with write-through stores).
 __device__ __forceinline__ bool pipe_last_ticket(unsigned* ticket, uint32_t target) {
     __shared__ int s_last_t;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -169,6 +156,31 @@ __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, lo
         atomicAdd(stats, (unsigned long long)(wall_clock64() - t0));
         atomicAdd(stats + 1, 1ull);
     }
+}
+
+// Arrive / collect: every workgroup, once its own stores have completed, adds itself to the ticket and leaves
+// (a no-return atomic: nothing to wait for); workgroup 0 - dispatched first, so always resident - polls the ticket
+// until the whole grid has arrived and then acts for the launch.  Cheaper than "the last arriver acts": no
+// workgroup pays the round trip of a returning atomic on its way out.
+__device__ __forceinline__ bool pipe_arrive_collect(unsigned* ticket, unsigned nblocks, uint32_t sweep, long long budget,
+                                                    unsigned* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x != 0) return false;
+    if (threadIdx.x == 0) {
+        const unsigned target = nblocks * (sweep + 1u);              // cumulative over the sweeps (mod 2^32)
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > budget) {
+                atomicOr(err, FLAG_PIPE_TIMEOUT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
 }
 
 // loc >= 0: a row of the pool.  loc < 0: guest row ~loc of this rank's mailbox (a walker that arrived
@@ -1930,7 +1942,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
         int st;
-        if (bit(cc, t)) {
+        if (MW == 1) {                                            // TE <= 32: the whole column mask in one register
+            const uint32_t mw = smask[cc];
+            if ((mw >> t) & 1u) st = t - 1;                       // bit 0 is never set
+            else st = t + __builtin_ctz(~(mw >> 1 >> t));         // consecutive swapped pairs directly above
+        } else if (bit(cc, t)) {
             st = t - 1;
         } else {
             st = t;
@@ -1957,23 +1973,25 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
         __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- the last workgroup speaks for the launch: neighbour flags, then the swap counts of my pairs ------
-    if (!pipe_last_block(A.tickets + 0, gridDim.x, A.sweep)) return;
+    // ---- workgroup 0 speaks for the launch once everyone has arrived: neighbour flags, then the swap counts ------
+    const long long dbg_t0 = wall_clock64();
+    if (!pipe_arrive_collect(A.tickets + 0, gridDim.x, A.sweep, A.budget, A.flags)) return;
+    const long long dbg_t1 = wall_clock64();
     if (tid == 0 && has_bot) pipe_raise(cold.flags + PF_LUP, A.sweep + 1);
     const int NP = TE - 1;
     unsigned* s_n = reinterpret_cast<unsigned*>(smem_raw);           // [NP] (the column tables are dead)
     for (int i = tid; i < NP; i += PT_THREADS) s_n[i] = 0;
     __syncthreads();
     const int total = (int)gridDim.x * NP;
-    for (int e0 = tid; e0 < total; e0 += 4 * PT_THREADS) {
-        unsigned v[4];
+    for (int e0 = tid; e0 < total; e0 += 16 * PT_THREADS) {          // all of a thread's loads in flight at once
+        unsigned v[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 16; ++q) {
             const int e = e0 + q * PT_THREADS;
             v[q] = e < total ? __hip_atomic_load(&A.swap_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 16; ++q) {
             const int e = e0 + q * PT_THREADS;
             if (v[q]) atomicAdd(&s_n[e % NP], v[q]);
         }
@@ -1987,6 +2005,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < A.nranks) pipe_raise(pipe_box(A.boxes[tid], T, W, D).flags + PF_CNT0 + A.rank, A.sweep + 1);
+    if (A.stats && tid == 0) {            // debug: collector wait / tail, wall-clock ticks
+        atomicAdd(A.stats + 10, (unsigned long long)(dbg_t1 - dbg_t0));
+        atomicAdd(A.stats + 11, 1ull);
+        atomicAdd(A.stats + 12, (unsigned long long)(wall_clock64() - dbg_t1));
+        atomicAdd(A.stats + 13, 1ull);
+    }
 }
 
 // bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, push the rows that move down into
@@ -2034,7 +2058,8 @@ __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
         sys_store(dst + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
         mine[(size_t)(c0 + col) * D + d] = sys_load(A.pool_cold + (size_t)(cold_home + s_below[col]) * D + d);
     }
-    if (pipe_last_block(A.tickets + 1, gridDim.x, A.sweep) && threadIdx.x == 0) pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
+    if (pipe_arrive_collect(A.tickets + 1, gridDim.x, A.sweep, A.budget, A.flags) && threadIdx.x == 0)
+        pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
 }
 
 // ---- hens_pipe_selftest: the three access patterns the pipeline relies on, between two processes ----------

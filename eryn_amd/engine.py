@@ -265,7 +265,8 @@ class HipEnsemble:
         """{site: (seconds waited summed over workgroups, waits)} - needs HENS_PIPE_STATS=1 at pipe_init."""
         raw = np.zeros(16, dtype=np.uint64)
         check(self.lib.hens_pipe_debug_stats(self.ctx, ptr(raw), int(bool(reset))), self.ctx)
-        names = ["stretch:rows", "stretch:counts", "walk:columns", "bottom:cold rung", "bottom:rows from above"]
+        names = ["stretch:rows", "stretch:counts", "walk:columns", "bottom:cold rung", "bottom:rows from above",
+                 "walk:collector waits for the grid", "walk:collector tail"]
         return {n: (float(raw[2 * i]) * 1e-8, int(raw[2 * i + 1])) for i, n in enumerate(names)}
 
     def pt_finish_sharded(self, n_recv):
