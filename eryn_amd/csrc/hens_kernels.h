@@ -648,150 +648,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         __syncthreads();
     }
 
-    // ---- phase A (wave 0): indices and draws -------------------------------------------------------
-    double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
-    int own = 0;
-    bool valid = false;
-    if (wv == 0) {
-        const int k = k0 + lane;
-        valid = k < Ns;
-        double zz = 1.0;
-        int rs = 0, rc = 0;
-        if (!EVAL && A.tempered && !ad_on) beta_pre = A.betas[A.rung_begin + tl];   // off the phase-D critical path
-        if (valid) {
-            if (EVAL) {
-                own = k;
-                rs = A.loc[tl * W + own];
-                rc = rs;
-            } else if (MH) {                     // every walker proposes; no partner, no Hastings factor
-                own = k;
-                rs = A.loc[tl * W + own];
-                rc = rs;
-                lu = A.mh_step ? A.dr.lu[(size_t)tl * W + own]
-                               : mh_log_uniform(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)own);
-                Lold = A.L[tl * W + own];
-                Pold = A.P[tl * W + own];
-            } else {
-                const size_t di = (size_t)tl * W + s_off + k;
-                own = A.dr.own[di];
-                const int cw = A.dr.cw[di];
-                zz = A.dr.zz[di];
-                factors = A.dr.fac[di];
-                lu = A.dr.lu[di];
-                rs = A.loc[tl * W + own];
-                // split 1's complement walkers were all rewritten by split 0: their row is their home
-                rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
-                Lold = A.L[tl * W + own];
-                Pold = A.P[tl * W + own];
-            }
-        }
-        s_zz[lane] = zz;
-        s_rs[lane] = rs;
-        s_rc[lane] = rc;
-        s_dst[lane] = A.home_off + tl * W + own;
-        s_flag[lane] = valid ? 4 : 0;
-    } else if (ad_here && wv == 1) {
-        s_cnt[lane] = 0;
-        s_cnt[lane + 64] = 0;
-    }
-    HENS_TRACE(1);
-    lds_barrier();
-    HENS_TRACE(2);
-
-    // ---- phase B: lanes over d, all loads first -------------------------------------------------
-    const int jl = tid & (LPR - 1);
-    const int rsub = tid / LPR;
-    const double* __restrict__ pool_r = A.pool;
-    double2 sreg[NPASS], creg[NPASS];
-    bool rv[NPASS];
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
-        sreg[p] = double2{0.0, 0.0};
-        creg[p] = double2{0.0, 0.0};
-        if (rv[p]) {
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
-            if (MH) {
-                if (A.mh_step) {
-                    creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
-                } else {                         // one Box-Muller pair per lane: exactly the two coordinates it owns
-                    const double2 z = mh_normal_pair(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(k0 + r), (uint32_t)jl);
-                    const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];
-                    const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];
-                    creg[p] = double2{s0 * z.x, s1 * z.y};
-                }
-            }
-            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
-        }
-    }
-    const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
-    const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
-    unsigned adv[8];
-    double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
-    if (ad_here) {                                 // the cascade's per-workgroup swap counts: <= 8 per thread
-        const int total = A.ad.nblocks * (A.ad.T - 1);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = tid + q * NT;
-            adv[q] = (e < total) ? A.ad.swap_part[e] : 0u;
-        }
-        if (wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
-        if (wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
-    }
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        bool ok = true, finite = true;
-        if (rv[p]) {
-            double2 qv;
-            if (EVAL) {
-                qv = sreg[p];
-            } else {
-                const double zz = s_zz[r];
-                if (MH) {
-                    qv.x = sreg[p].x + creg[p].x;                    // gaussian.py:166-167
-                    qv.y = sreg[p].y + creg[p].y;
-                } else {
-                    qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; // stretch.py:143,145
-                    qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
-                }
-            }
-            ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
-            finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
-            // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
-            // overwrites only accepted rows, so the store tail after the accept test is short
-            if (!EVAL) {
-                if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
-                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
-            }
-        }
-        const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
-        const unsigned long long nonfin = __ballot(!finite);
-        const int gshift = lane & ~(LPR - 1);
-        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << (LPR & 63)) - 1ull) << gshift);
-        if (jl == 0 && rv[p]) {
-            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);
-            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
-        }
-    }
-    if (ad_here) {
-        const int Tm1 = A.ad.T - 1;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
-    }
-    HENS_TRACE(3);
-    lds_barrier();
-    HENS_TRACE(4);
-
-    // ---- ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64 ------
-    if (ad_here && wv == 1) {
+    // ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64
+    auto adapt_publish = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1) {
         const int T = A.ad.T;
         const int e0 = lane, e1 = lane + 64;
-        const double cnt0 = (e0 < T - 1) ? (double)s_cnt[e0] : 0.0;
-        const double cnt1 = (e1 < T - 1) ? (double)s_cnt[e1] : 0.0;
         const double r0 = cnt0 / (double)A.ad.W, r1 = cnt1 / (double)A.ad.W;       // :587
         double bnew0 = ad_b, bnew1 = ad_b1;
         if (A.ad.moving) {
@@ -855,6 +715,160 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 A.ad.swaps_total[e1] += cnt1;
             }
         }
+    };
+
+    // The counts are already reduced (one row: a pipeline rank's mailbox): wave 1 of the adapting workgroup
+    // adapts right away, while wave 0 fetches the draws, so the new ladder is in the ring long before anyone asks.
+    const bool ad_early = ad_here && ad_lead && A.ad.nblocks == 1;
+    if (ad_early && wv == 1) {
+        const int T = A.ad.T;
+        const double c0 = (lane < T - 1) ? (double)A.ad.swap_part[lane] : 0.0;
+        const double c1 = (lane + 64 < T - 1) ? (double)A.ad.swap_part[lane + 64] : 0.0;
+        adapt_publish(c0, c1, lane < T ? A.ad.betas_in[lane] : 1.0, lane + 64 < T ? A.ad.betas_in[lane + 64] : 1.0);
+    }
+
+    // ---- phase A (wave 0): indices and draws -------------------------------------------------------
+    double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
+    int own = 0;
+    bool valid = false;
+    if (wv == 0) {
+        const int k = k0 + lane;
+        valid = k < Ns;
+        double zz = 1.0;
+        int rs = 0, rc = 0;
+        if (!EVAL && A.tempered && !ad_on) beta_pre = A.betas[A.rung_begin + tl];   // off the phase-D critical path
+        if (valid) {
+            if (EVAL) {
+                own = k;
+                rs = A.loc[tl * W + own];
+                rc = rs;
+            } else if (MH) {                     // every walker proposes; no partner, no Hastings factor
+                own = k;
+                rs = A.loc[tl * W + own];
+                rc = rs;
+                lu = A.mh_step ? A.dr.lu[(size_t)tl * W + own]
+                               : mh_log_uniform(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)own);
+                Lold = A.L[tl * W + own];
+                Pold = A.P[tl * W + own];
+            } else {
+                const size_t di = (size_t)tl * W + s_off + k;
+                own = A.dr.own[di];
+                const int cw = A.dr.cw[di];
+                zz = A.dr.zz[di];
+                factors = A.dr.fac[di];
+                lu = A.dr.lu[di];
+                rs = A.loc[tl * W + own];
+                // split 1's complement walkers were all rewritten by split 0: their row is their home
+                rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
+                Lold = A.L[tl * W + own];
+                Pold = A.P[tl * W + own];
+            }
+        }
+        s_zz[lane] = zz;
+        s_rs[lane] = rs;
+        s_rc[lane] = rc;
+        s_dst[lane] = A.home_off + tl * W + own;
+        s_flag[lane] = valid ? 4 : 0;
+    } else if (ad_here && !ad_early && wv == 1) {
+        s_cnt[lane] = 0;
+        s_cnt[lane + 64] = 0;
+    }
+    HENS_TRACE(1);
+    lds_barrier();
+    HENS_TRACE(2);
+
+    // ---- phase B: lanes over d, all loads first -------------------------------------------------
+    const int jl = tid & (LPR - 1);
+    const int rsub = tid / LPR;
+    const double* __restrict__ pool_r = A.pool;
+    double2 sreg[NPASS], creg[NPASS];
+    bool rv[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
+        sreg[p] = double2{0.0, 0.0};
+        creg[p] = double2{0.0, 0.0};
+        if (rv[p]) {
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
+            if (MH) {
+                if (A.mh_step) {
+                    creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
+                } else {                         // one Box-Muller pair per lane: exactly the two coordinates it owns
+                    const double2 z = mh_normal_pair(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(k0 + r), (uint32_t)jl);
+                    const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];
+                    const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];
+                    creg[p] = double2{s0 * z.x, s1 * z.y};
+                }
+            }
+            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
+        }
+    }
+    const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
+    const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
+    unsigned adv[8];
+    double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
+    if (ad_here && !ad_early) {                    // the cascade's per-workgroup swap counts: <= 8 per thread
+        const int total = A.ad.nblocks * (A.ad.T - 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * NT;
+            adv[q] = (e < total) ? A.ad.swap_part[e] : 0u;
+        }
+        if (wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
+        if (wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        bool ok = true, finite = true;
+        if (rv[p]) {
+            double2 qv;
+            if (EVAL) {
+                qv = sreg[p];
+            } else {
+                const double zz = s_zz[r];
+                if (MH) {
+                    qv.x = sreg[p].x + creg[p].x;                    // gaussian.py:166-167
+                    qv.y = sreg[p].y + creg[p].y;
+                } else {
+                    qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; // stretch.py:143,145
+                    qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
+                }
+            }
+            ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
+            finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
+            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
+            // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
+            // overwrites only accepted rows, so the store tail after the accept test is short
+            if (!EVAL) {
+                if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
+                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
+            }
+        }
+        const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
+        const unsigned long long nonfin = __ballot(!finite);
+        const int gshift = lane & ~(LPR - 1);
+        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << (LPR & 63)) - 1ull) << gshift);
+        if (jl == 0 && rv[p]) {
+            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);
+            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
+        }
+    }
+    if (ad_here && !ad_early) {
+        const int Tm1 = A.ad.T - 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
+    }
+    HENS_TRACE(3);
+    lds_barrier();
+    HENS_TRACE(4);
+
+    // ---- ladder adaptation (unless the adapting workgroup already did it up front) ------------------------------
+    if (ad_here && !ad_early && wv == 1) {
+        const int T = A.ad.T;
+        adapt_publish((lane < T - 1) ? (double)s_cnt[lane] : 0.0, (lane + 64 < T - 1) ? (double)s_cnt[lane + 64] : 0.0, ad_b, ad_b1);
     }
 
     // mode 2: the rung's new beta, requested now and consumed after the likelihood (phase D)
