@@ -1868,7 +1868,7 @@ __global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
     if (threadIdx.x == 0) pipe_raise(hot.flags + PF_LDN, A.sweep + 1);
 }
 
-constexpr int PIPE_COLS = 64;       // columns per workgroup of the bottom-boundary kernel
+constexpr int PIPE_COLS = 16;       // columns per workgroup of the bottom-boundary kernel (W / 16 workgroups: every CU busy)
 constexpr int32_t PIPE_NOSEL = INT32_MIN;
 
 // The walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended
@@ -2065,12 +2065,33 @@ __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     double* dst = cold.guest + (size_t)(A.par * 2) * W * D;                     // rows that move down: push
     double* mine = me.guest + (size_t)(A.par * 2 + 1) * W * D;                  // rows that move up: pull
     const long long cold_home = __hip_atomic_load(me.meta + A.par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    for (int idx = threadIdx.x; idx < PIPE_COLS * D; idx += blockDim.x) {
-        const int col = idx / D, d = idx - col * D;
-        const int32_t src = s_src[col];
-        if (src == PIPE_NOSEL) continue;
-        sys_store(dst + (size_t)(c0 + col) * D + d, A.pool[row_off(src, D, A.guest_delta) + d]);
-        mine[(size_t)(c0 + col) * D + d] = sys_load(A.pool_cold + (size_t)(cold_home + s_below[col]) * D + d);
+    // all of a thread's loads first - the pulls cross xGMI, their latencies must overlap - then the stores
+    for (int base = 0; base < PIPE_COLS * D; base += 8 * (int)blockDim.x) {
+        double push[8], pull[8];
+        bool on[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = base + q * (int)blockDim.x + (int)threadIdx.x;
+            on[q] = false;
+            if (idx < PIPE_COLS * D) {
+                const int col = idx / D, d = idx - col * D;
+                const int32_t src = s_src[col];
+                if (src != PIPE_NOSEL) {
+                    on[q] = true;
+                    push[q] = A.pool[row_off(src, D, A.guest_delta) + d];
+                    pull[q] = sys_load(A.pool_cold + (size_t)(cold_home + s_below[col]) * D + d);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = base + q * (int)blockDim.x + (int)threadIdx.x;
+            if (on[q]) {
+                const int col = idx / D, d = idx - col * D;
+                sys_store(dst + (size_t)(c0 + col) * D + d, push[q]);
+                mine[(size_t)(c0 + col) * D + d] = pull[q];
+            }
+        }
     }
     if (pipe_arrive_collect(A.tickets + 1, gridDim.x, A.sweep, A.budget, A.flags) && threadIdx.x == 0)
         pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
