@@ -170,3 +170,23 @@ def test_host_likelihood_contract():
         hl.evaluate(np.full((1, 2, 3), np.inf), np.ones((1, 2), bool))
     per_walker = HostLikelihood(lambda x, s: -0.5 * ((x - s) ** 2).sum(), 3, args=[0.5], vectorize=False)
     assert np.array_equal(per_walker.evaluate(q, inbox)[inbox], ll[inbox])
+
+
+@pytest.mark.parametrize("cov,mode,factor", [(0.05, "vector", None), (0.2, "random", 2.0), (0.15, "sequential", None),
+                                             ("full", "vector", None), ("full", "vector", 1.5)])
+def test_gaussian_move_draws_match_the_pinned_restatement(cov, mode, factor):
+    """eryn_amd.moves.GaussianMove.get_step consumes the sampler's RandomState exactly like the oracle's
+    GaussianProposal, which tests/test_oracle_golden.py pins bit-for-bit on fixtures captured from the reference
+    (gaussian.py:161-176, 265-268) - so the host mirror's proposal steps are the reference's, draw for draw."""
+    from eryn_amd.moves import GaussianMove
+    from oracle import eryn_oracle as orc
+    D, n = 4, 37
+    if cov == "full":
+        a = np.random.RandomState(3).randn(D, D)
+        cov = 0.05 * (a @ a.T / D + np.eye(D))
+    mv = GaussianMove({"model_0": cov}, mode=mode, factor=factor)
+    pr = orc.GaussianProposal(cov, mode=mode, factor=factor)
+    r1, r2 = np.random.RandomState(11), np.random.RandomState(11)
+    for _ in range(5):                                  # several calls: the sequential mode's index advances
+        assert np.array_equal(mv.get_step(r1, n, D), pr.draw_step(r2, n, D))
+    assert np.array_equal(r1.rand(3), r2.rand(3))       # both streams ended in the same state
