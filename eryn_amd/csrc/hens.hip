@@ -449,6 +449,16 @@ bool pipe_publish_fused(const hens_ctx_impl* c) {
     return !off && fast_path(c);
 }
 
+// adaptation_delay = 1 leaves a whole iteration before a sweep's counts are needed: the adapting workgroup of the
+// next iteration's first launch reduces and publishes them, and the walk kernel needs no collector at all
+bool pipe_counts_in_stretch(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_PIPE_COUNT_TAIL") != nullptr;       // A/B knob
+    if (off || !pipe_active(c) || c->pipe.staged || c->cfg.adaptation_delay != 1 || !fast_path(c)) return false;
+    if (fold_mode(c) != 2 || fast_nw(c->D) < 2) return false;
+    const int np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
+    return np >= 1 && (int64_t)pt_blocks(c) * np <= (int64_t)8 * fast_nw(c->D) * 64;
+}
+
 PipeArgs pipe_args(hens_ctx_impl* c) {
     PipeArgs a{};
     a.pool = c->pool;
@@ -462,6 +472,7 @@ PipeArgs pipe_args(hens_ctx_impl* c) {
     a.pool_cold = c->pipe.pool_cold;
     a.home_off = (c->parity ^ 1) * c->Tl * c->W;      // the stretch move of this iteration has already flipped parity
     a.nowait = c->pipe.staged ? 1 : 0;
+    a.count_tail = pipe_counts_in_stretch(c) ? 0 : 1;
     a.boxes = c->pipe.d_boxes;
     a.Lcur = c->pipe.Lcur; a.Pcur = c->pipe.Pcur; a.botsrc = c->pipe.botsrc;
     a.swap_part = c->swap_part;
@@ -595,6 +606,17 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
             a.wbudget = c->pipe.budget;
             a.wstats = c->pipe.stats;
         }
+    }
+    if (pipe_counts_in_stretch(c) && c->pipe.sweep > 0) {      // the counts of the sweep that just ended
+        a.cnt_push = 1;
+        a.cp_rows = c->swap_part;
+        a.cp_boxes = c->pipe.d_boxes;
+        a.cp_sweep = c->pipe.sweep - 1;
+        a.cp_nblocks = pt_blocks(c);
+        a.cp_np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
+        a.cp_nranks = c->pipe.nranks;
+        a.cp_rank = c->pipe.rank;
+        a.cp_T = c->T;
     }
     if (!c->adapt_pending) return;
     if (can_fold_adapt(c)) {
@@ -1783,9 +1805,11 @@ int hens_pipe_connect_staged(hens_ctx* ctx) {
     int r;
     if ((r = dalloc(c, &c->pipe.out_hot, bytes))) return r;
     if ((r = dalloc(c, &c->pipe.out_cold, bytes))) return r;
-    if ((r = dalloc(c, &c->pipe.out_cnt, (size_t)(512 + pipe_round((size_t)4 * c->T * 4))))) return r;
+    const size_t cnt_bytes = (size_t)(reinterpret_cast<char*>(pipe_box(nullptr, c->T, c->W, c->D).counts) - static_cast<char*>(nullptr)) +
+                             pipe_round((size_t)4 * c->T * 4);        // a mailbox prefix: flags .. counts
+    if ((r = dalloc(c, &c->pipe.out_cnt, cnt_bytes))) return r;
     if ((r = dalloc(c, &c->pipe.ldn_rows, (size_t)2 * c->W * c->D))) return r;
-    HIPCHK(c, hipMemsetAsync(c->pipe.out_cnt, 0, 512 + pipe_round((size_t)4 * c->T * 4), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->pipe.out_cnt, 0, cnt_bytes, c->stream));
     std::vector<char*> table((size_t)c->pipe.nranks, c->pipe.out_cnt);       // the walk kernel's count puts
     for (int q = 0; q < c->pipe.nranks; ++q)
         c->pipe.boxes[q] = q == c->pipe.rank + 1 ? c->pipe.out_hot : (q == c->pipe.rank - 1 ? c->pipe.out_cold : c->pipe.out_cnt);

@@ -114,6 +114,37 @@ __device__ __forceinline__ double mh_log_uniform(uint64_t seed, uint64_t it, uin
 // mailbox flag words (sweep counters raised by the peers)
 enum { PF_LUP = 0, PF_LDN = 1, PF_ROWS_TOP = 2, PF_CNT0 = 8, PIPE_FLAG_WORDS = 64 };
 
+// one rank's mailbox (uncached device memory, peer-mapped through HIP IPC); the protocol is described at k_pipe_*
+struct PipeBox {
+    unsigned* flags;       // [PIPE_FLAG_WORDS] sweep counters raised by the peers
+    long long* meta;       // [32]: [par] = pool row of slot 0 of the cold neighbour's hottest rung after its stretch move
+    unsigned* lupf;        // [W / PT_COLS] sweep counters: block b of the hot neighbour's walk has stored its columns' lp_up
+    unsigned* counts;      // [4][T] accepted swaps per pair (index i-1 for pair (i, i-1)), written by the pair's owner; buffer = sweep & 3
+    double* lp_up;         // [2][2][W] (L, P) carried by each column of the hot neighbour (column order)
+    double* lp_dn;         // [2][2][W] (L, P) of the cold neighbour's hottest rung after its stretch move (slot order)
+    double* guest;         // [2][2][W][D] arrived rows: side 0 = from the hot neighbour, side 1 = from the cold one
+};
+__host__ __device__ inline size_t pipe_round(size_t n) { return (n + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t pipe_box_bytes(int T, int W, int D) {
+    return pipe_round(PIPE_FLAG_WORDS * 4) + 256 + pipe_round(((size_t)W / 16 + 1) * 4) + pipe_round((size_t)4 * T * 4) +
+           2 * pipe_round((size_t)4 * W * 8) +
+           pipe_round((size_t)4 * W * D * 8);
+}
+__host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
+    PipeBox b;
+    size_t off = 0;
+    b.flags = reinterpret_cast<unsigned*>(base + off); off += pipe_round(PIPE_FLAG_WORDS * 4);
+    b.meta = reinterpret_cast<long long*>(base + off); off += 256;
+    b.lupf = reinterpret_cast<unsigned*>(base + off); off += pipe_round(((size_t)W / 16 + 1) * 4);
+    b.counts = reinterpret_cast<unsigned*>(base + off); off += pipe_round((size_t)4 * T * 4);
+    b.lp_up = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
+    b.lp_dn = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
+    b.guest = reinterpret_cast<double*>(base + off);
+    return b;
+}
+// guest row index of column c (sweep parity par, side) and its `loc` encoding
+__host__ __device__ inline int32_t pipe_guest_loc(int par, int side, int W, int c) { return ~((par * 2 + side) * W + c); }
+
 // peer memory is written and read with system-scope accesses (sc0 sc1: nothing lingers in a cache)
 __device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
@@ -265,6 +296,12 @@ struct StretchArgs {
     unsigned* pub_ticket;
     uint32_t pub_target, pub_value;
     int32_t pub_final;
+    // ladder pipeline, adaptation_delay = 1: the adapting workgroup also reduces the per-workgroup swap counts of the
+    // sweep that just ended (rows of k_pipe_walk) and stores the sums into every rank's mailbox + raises their flags
+    const uint32_t* cp_rows;   // [cp_nblocks][cp_np]
+    char* const* cp_boxes;     // [cp_nranks]
+    uint32_t cp_sweep;
+    int32_t cnt_push, cp_nblocks, cp_np, cp_nranks, cp_rank, cp_T;
     int32_t sys_rung;          // local rung whose rows a peer will read (written through to memory, system scope), or -1
     long long* pub_meta;       // neighbour's meta[par]: receives the pool row of (hottest rung, slot 0) after this move
     // ladder pipeline: before touching the state, wait until the mailbox flags selected by wmask reach wtarget
@@ -720,6 +757,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // The counts are already reduced (one row: a pipeline rank's mailbox): wave 1 of the adapting workgroup
     // adapts right away, while wave 0 fetches the draws, so the new ladder is in the ring long before anyone asks.
     const bool ad_early = ad_here && ad_lead && A.ad.nblocks == 1;
+    // the same workgroup pushes the last sweep's swap counts to every rank (uses the count-reduction machinery below,
+    // which a pipeline rank's adaptation - counts already reduced - leaves idle)
+    const bool cnt_push = PIPE && !EVAL && NW >= 2 && A.cnt_push && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool red_on = (ad_here && !ad_early) || cnt_push;
     if (ad_early && wv == 1) {
         const int T = A.ad.T;
         const double c0 = (lane < T - 1) ? (double)A.ad.swap_part[lane] : 0.0;
@@ -769,7 +810,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_rc[lane] = rc;
         s_dst[lane] = A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
-    } else if (ad_here && !ad_early && wv == 1) {
+    } else if (red_on && wv == 1) {
         s_cnt[lane] = 0;
         s_cnt[lane + 64] = 0;
     }
@@ -808,15 +849,16 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     unsigned adv[8];
     double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
-    if (ad_here && !ad_early) {                    // the cascade's per-workgroup swap counts: <= 8 per thread
-        const int total = A.ad.nblocks * (A.ad.T - 1);
+    if (red_on) {                                  // the cascade's per-workgroup swap counts: <= 8 per thread
+        const uint32_t* rows = cnt_push ? A.cp_rows : A.ad.swap_part;
+        const int total = cnt_push ? A.cp_nblocks * A.cp_np : A.ad.nblocks * (A.ad.T - 1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + q * NT;
-            adv[q] = (e < total) ? A.ad.swap_part[e] : 0u;
+            adv[q] = (e < total) ? rows[e] : 0u;
         }
-        if (wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
-        if (wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
+        if (!cnt_push && wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
+        if (!cnt_push && wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
     }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
@@ -855,8 +897,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
         }
     }
-    if (ad_here && !ad_early) {
-        const int Tm1 = A.ad.T - 1;
+    if (red_on) {
+        const int Tm1 = cnt_push ? A.cp_np : A.ad.T - 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
@@ -869,6 +911,19 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     if (ad_here && !ad_early && wv == 1) {
         const int T = A.ad.T;
         adapt_publish((lane < T - 1) ? (double)s_cnt[lane] : 0.0, (lane + 64 < T - 1) ? (double)s_cnt[lane + 64] : 0.0, ad_b, ad_b1);
+    }
+
+    // ---- ladder pipeline: the sums of the last sweep's swap counts go to every rank's mailbox -----------------------
+    if (cnt_push && wv == 1) {
+        const int NP = A.cp_np;
+        for (int e = lane; e < A.cp_nranks * NP; e += 64) {
+            const int q = e / NP, j = e - q * NP;                    // local pair j+1 = global pair (rung_begin+j+1, rung_begin+j)
+            const PipeBox bx = pipe_box(A.cp_boxes[q], A.cp_T, W, D);
+            __hip_atomic_store(bx.counts + (size_t)(A.cp_sweep & 3u) * A.cp_T + (A.rung_begin + j), s_cnt[j], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < A.cp_nranks) pipe_raise(pipe_box(A.cp_boxes[lane], A.cp_T, W, D).flags + PF_CNT0 + A.cp_rank, A.cp_sweep + 1);
     }
 
     // mode 2: the rung's new beta, requested now and consumed after the likelihood (phase D)
@@ -1773,33 +1828,6 @@ __global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ l
 // ---------------------------------------------------------------------------------------------
 constexpr int PIPE_MAX_RANKS = PIPE_FLAG_WORDS - PF_CNT0;
 
-struct PipeBox {
-    unsigned* flags;       // [PIPE_FLAG_WORDS] sweep counters raised by the peers
-    long long* meta;       // [32]: [par] = pool row of slot 0 of the cold neighbour's hottest rung after its stretch move
-    unsigned* counts;      // [4][T] accepted swaps per pair (index i-1 for pair (i, i-1)), written by the pair's owner; buffer = sweep & 3
-    double* lp_up;         // [2][2][W] (L, P) carried by each column of the hot neighbour (column order)
-    double* lp_dn;         // [2][2][W] (L, P) of the cold neighbour's hottest rung after its stretch move (slot order)
-    double* guest;         // [2][2][W][D] arrived rows: side 0 = from the hot neighbour, side 1 = from the cold one
-};
-__host__ __device__ inline size_t pipe_round(size_t n) { return (n + 255) & ~(size_t)255; }
-__host__ __device__ inline size_t pipe_box_bytes(int T, int W, int D) {
-    return pipe_round(PIPE_FLAG_WORDS * 4) + 256 + pipe_round((size_t)4 * T * 4) + 2 * pipe_round((size_t)4 * W * 8) +
-           pipe_round((size_t)4 * W * D * 8);
-}
-__host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
-    PipeBox b;
-    size_t off = 0;
-    b.flags = reinterpret_cast<unsigned*>(base + off); off += pipe_round(PIPE_FLAG_WORDS * 4);
-    b.meta = reinterpret_cast<long long*>(base + off); off += 256;
-    b.counts = reinterpret_cast<unsigned*>(base + off); off += pipe_round((size_t)4 * T * 4);
-    b.lp_up = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
-    b.lp_dn = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
-    b.guest = reinterpret_cast<double*>(base + off);
-    return b;
-}
-// guest row index of column c (sweep parity par, side) and its `loc` encoding
-__host__ __device__ inline int32_t pipe_guest_loc(int par, int side, int W, int c) { return ~((par * 2 + side) * W + c); }
-
 struct PipeArgs {
     const double* pool;
     int64_t guest_delta;
@@ -1822,6 +1850,8 @@ struct PipeArgs {
     int32_t T, W, D, Tl, rung_begin, idx_bits, par, nranks, rank;
     int32_t home_off;             // pool row of (rung 0, slot 0) after this iteration's stretch move
     int32_t nowait;               // staged (RCCL) transport: messages arrive in stream order, nothing to spin on
+    int32_t count_tail;           // 1: workgroup 0 of the walk reduces and publishes the swap counts; 0: the adapting
+                                  // workgroup of the next iteration's first launch does (StretchArgs::cnt_push)
 };
 
 __device__ __forceinline__ int pipe_slot(const PipeArgs& A, int g, int c) {
@@ -1892,7 +1922,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     const PipeBox me = pipe_box(A.box, T, W, D);
 
     if (has_top && !A.nowait) {                                  // what the hot neighbour's columns carry must be here
-        if (tid == 0) pipe_spin(me.flags + PF_LUP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
+        if (tid == 0) pipe_spin(me.lupf + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
         __syncthreads();
     }
     for (int t = tid; t < TE; t += PT_THREADS) sbeta[t] = A.betas[A.rung_begin + t];
@@ -1986,12 +2016,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
         for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += bit(cc, i) ? 1u : 0u;
         __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // my 16 columns are in the cold neighbour's mailbox: its walk's block with the same index may start
+    if (has_bot) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) pipe_raise(cold.lupf + blockIdx.x, A.sweep + 1);
+    }
+    if (!A.count_tail) return;
 
-    // ---- workgroup 0 speaks for the launch once everyone has arrived: neighbour flags, then the swap counts ------
+    // ---- workgroup 0 speaks for the launch once everyone has arrived: the swap counts of my pairs ------
     const long long dbg_t0 = wall_clock64();
     if (!pipe_arrive_collect(A.tickets + 0, gridDim.x, A.sweep, A.budget, A.flags)) return;
     const long long dbg_t1 = wall_clock64();
-    if (tid == 0 && has_bot) pipe_raise(cold.flags + PF_LUP, A.sweep + 1);
     const int NP = TE - 1;
     unsigned* s_n = reinterpret_cast<unsigned*>(smem_raw);           // [NP] (the column tables are dead)
     for (int i = tid; i < NP; i += PT_THREADS) s_n[i] = 0;
