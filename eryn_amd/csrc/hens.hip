@@ -459,6 +459,13 @@ bool pipe_counts_in_stretch(const hens_ctx_impl* c) {
     return np >= 1 && (int64_t)pt_blocks(c) * np <= (int64_t)8 * fast_nw(c->D) * 64;
 }
 
+// one-sided transport: the bottom boundary is the walk kernel's last phase (one launch less on every rank that has a
+// cold neighbour); the staged transport needs the LUP message to leave between the two, so it keeps them apart
+bool pipe_fuse_bottom(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_PIPE_SEPARATE_BOTTOM") != nullptr;      // A/B knob
+    return !off && pipe_active(c) && !c->pipe.staged && pipe_has_bot(c);
+}
+
 PipeArgs pipe_args(hens_ctx_impl* c) {
     PipeArgs a{};
     a.pool = c->pool;
@@ -473,6 +480,7 @@ PipeArgs pipe_args(hens_ctx_impl* c) {
     a.home_off = (c->parity ^ 1) * c->Tl * c->W;      // the stretch move of this iteration has already flipped parity
     a.nowait = c->pipe.staged ? 1 : 0;
     a.count_tail = pipe_counts_in_stretch(c) ? 0 : 1;
+    a.fuse_bottom = pipe_fuse_bottom(c) ? 1 : 0;
     a.boxes = c->pipe.d_boxes;
     a.Lcur = c->pipe.Lcur; a.Pcur = c->pipe.Pcur; a.botsrc = c->pipe.botsrc;
     a.swap_part = c->swap_part;
@@ -546,7 +554,7 @@ void pipe_launch_walk(hens_ctx_impl* c) {
     hipLaunchKernelGGL(k_pipe_walk, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_layout(TE), c->stream, a);
 }
 void pipe_launch_bottom(hens_ctx_impl* c) {
-    if (!pipe_has_bot(c)) return;
+    if (!pipe_has_bot(c) || pipe_fuse_bottom(c)) return;
     const PipeArgs a = pipe_args(c);
     // waits for PF_LDN (+ PF_ROWS_TOP); moves the rows both ways; its last workgroup raises the cold neighbour's PF_ROWS_TOP
     hipLaunchKernelGGL(k_pipe_bottom, dim3((c->W + PIPE_COLS - 1) / PIPE_COLS), dim3(256), 0, c->stream, a);

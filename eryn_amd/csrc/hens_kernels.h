@@ -1850,6 +1850,7 @@ struct PipeArgs {
     int32_t T, W, D, Tl, rung_begin, idx_bits, par, nranks, rank;
     int32_t home_off;             // pool row of (rung 0, slot 0) after this iteration's stretch move
     int32_t nowait;               // staged (RCCL) transport: messages arrive in stream order, nothing to spin on
+    int32_t fuse_bottom;          // the walk kernel runs the bottom boundary as its own last phase (one-sided transport)
     int32_t count_tail;           // 1: workgroup 0 of the walk reduces and publishes the swap counts; 0: the adapting
                                   // workgroup of the next iteration's first launch does (StretchArgs::cnt_push)
 };
@@ -1901,6 +1902,77 @@ __global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
 constexpr int PIPE_COLS = 16;       // columns per workgroup of the bottom-boundary kernel (W / 16 workgroups: every CU busy)
 constexpr int32_t PIPE_NOSEL = INT32_MIN;
 
+// bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, push the rows that move down into
+// the cold neighbour's guest area and pull the rows that move up out of its pool.  One workgroup = PIPE_COLS
+// columns starting at c0.  sh_La / sh_bsrc: what each of the columns carries below my coldest rung, in LDS (when
+// the walk kernel runs this as its own last phase) or nullptr (stand-alone kernel: from A.Lcur / A.botsrc).
+__device__ __forceinline__ void pipe_bottom_block(const PipeArgs& A, const int c0, int32_t* s_src, int32_t* s_below,
+                                                  const double* sh_La, const int32_t* sh_bsrc) {
+    const int W = A.W, D = A.D;
+    const PipeBox me = pipe_box(A.box, A.T, W, D);
+    const bool has_top = A.rung_begin + A.Tl < A.T;
+    // the cold neighbour's rung after ITS stretch move; a walker may fall through all my rungs in one sweep,
+    // so the rows from above must have landed too
+    if (threadIdx.x == 0 && !A.nowait) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
+    if (threadIdx.x == 64 && has_top && !A.nowait) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
+    __syncthreads();
+    if (threadIdx.x < PIPE_COLS) {
+        const int c = c0 + threadIdx.x;
+        int32_t src = PIPE_NOSEL, sb = 0;
+        if (c < W) {
+            const int g = A.rung_begin;                              // my coldest rung; the pair is (g, g-1)
+            const int slot = pipe_slot(A, g, c), slot_below = pipe_slot(A, g - 1, c);
+            sb = slot_below;
+            const double La = sh_La ? sh_La[threadIdx.x] : A.Lcur[c];
+            const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
+            const double db = A.betas[g - 1] - A.betas[g];
+            if (db * (La - Lb) > pipe_logu(A, g, c)) {
+                src = sh_bsrc ? sh_bsrc[threadIdx.x] : A.botsrc[c];
+                A.Lnew[slot] = Lb;
+                A.Pnew[slot] = sys_load(me.lp_dn + (size_t)(A.par * 2 + 1) * W + slot_below);
+                A.locnew[slot] = pipe_guest_loc(A.par, 1, W, c);
+            }
+        }
+        s_src[threadIdx.x] = src;
+        s_below[threadIdx.x] = sb;
+    }
+    __syncthreads();
+    const PipeBox cold = pipe_box(A.box_cold, A.T, W, D);
+    double* dst = cold.guest + (size_t)(A.par * 2) * W * D;                     // rows that move down: push
+    double* mine = me.guest + (size_t)(A.par * 2 + 1) * W * D;                  // rows that move up: pull
+    const long long cold_home = __hip_atomic_load(me.meta + A.par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // all of a thread's loads first - the pulls cross xGMI, their latencies must overlap - then the stores
+    for (int base = 0; base < PIPE_COLS * D; base += 8 * (int)blockDim.x) {
+        double push[8], pull[8];
+        bool on[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = base + q * (int)blockDim.x + (int)threadIdx.x;
+            on[q] = false;
+            if (idx < PIPE_COLS * D) {
+                const int col = idx / D, d = idx - col * D;
+                const int32_t src = s_src[col];
+                if (src != PIPE_NOSEL) {
+                    on[q] = true;
+                    push[q] = A.pool[row_off(src, D, A.guest_delta) + d];
+                    pull[q] = sys_load(A.pool_cold + (size_t)(cold_home + s_below[col]) * D + d);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = base + q * (int)blockDim.x + (int)threadIdx.x;
+            if (on[q]) {
+                const int col = idx / D, d = idx - col * D;
+                sys_store(dst + (size_t)(c0 + col) * D + d, push[q]);
+                mine[(size_t)(c0 + col) * D + d] = pull[q];
+            }
+        }
+    }
+    // the last workgroup to get here tells the cold neighbour that its rows from above have landed
+    if (pipe_last_ticket(A.tickets + 1, gridDim.x * (A.sweep + 1u)) && threadIdx.x == 0) pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
+}
+
 // The walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended
 // ladder; the pair across my top boundary is the first step of every column.
 __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
@@ -1920,6 +1992,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
     const PipeBox me = pipe_box(A.box, T, W, D);
+    __shared__ double sh_La[PT_COLS];                            // what each column carries below my coldest rung
+    __shared__ int32_t sh_bsrc[PT_COLS], sh_src[PT_COLS], sh_below[PT_COLS];
 
     if (has_top && !A.nowait) {                                  // what the hot neighbour's columns carry must be here
         if (tid == 0) pipe_spin(me.lupf + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
@@ -2005,6 +2079,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
             A.Lcur[c] = Lc[se];
             A.Pcur[c] = Pc[se];
             A.botsrc[c] = locc[se];
+            sh_La[cc] = Lc[se];
+            sh_bsrc[cc] = locc[se];
             if (has_bot) {
                 sys_store(cold.lp_up + (size_t)(A.par * 2) * W + c, Lc[se]);
                 sys_store(cold.lp_up + (size_t)(A.par * 2 + 1) * W + c, Pc[se]);
@@ -2022,6 +2098,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
         __syncthreads();
         if (tid == 0) pipe_raise(cold.lupf + blockIdx.x, A.sweep + 1);
     }
+    // the pair across my bottom boundary for the same 16 columns (needs the cold neighbour's rung, not its walk)
+    static_assert(PIPE_COLS == PT_COLS, "the fused bottom phase works on the walk's columns");
+    if (A.fuse_bottom && has_bot) pipe_bottom_block(A, c0, sh_src, sh_below, sh_La, sh_bsrc);
     if (!A.count_tail) return;
 
     // ---- workgroup 0 speaks for the launch once everyone has arrived: the swap counts of my pairs ------
@@ -2063,74 +2142,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     }
 }
 
-// bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, push the rows that move down into
-// the cold neighbour's guest area and pull the rows that move up out of its pool
 __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     __shared__ int32_t s_src[PIPE_COLS];
     __shared__ int32_t s_below[PIPE_COLS];
-    const int W = A.W, D = A.D, c0 = blockIdx.x * PIPE_COLS;
-    const PipeBox me = pipe_box(A.box, A.T, W, D);
-    const bool has_top = A.rung_begin + A.Tl < A.T;
-    // the cold neighbour's rung after ITS stretch move; a walker may fall through all my rungs in one sweep,
-    // so the rows from above must have landed too
-    if (threadIdx.x == 0 && !A.nowait) pipe_spin(me.flags + PF_LDN, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
-    if (threadIdx.x == 64 && has_top && !A.nowait) pipe_spin(me.flags + PF_ROWS_TOP, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
-    __syncthreads();
-    if (threadIdx.x < PIPE_COLS) {
-        const int c = c0 + threadIdx.x;
-        int32_t src = PIPE_NOSEL, sb = 0;
-        if (c < W) {
-            const int g = A.rung_begin;                              // my coldest rung; the pair is (g, g-1)
-            const int slot = pipe_slot(A, g, c), slot_below = pipe_slot(A, g - 1, c);
-            sb = slot_below;
-            const double La = A.Lcur[c];
-            const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
-            const double db = A.betas[g - 1] - A.betas[g];
-            if (db * (La - Lb) > pipe_logu(A, g, c)) {
-                src = A.botsrc[c];
-                A.Lnew[slot] = Lb;
-                A.Pnew[slot] = sys_load(me.lp_dn + (size_t)(A.par * 2 + 1) * W + slot_below);
-                A.locnew[slot] = pipe_guest_loc(A.par, 1, W, c);
-            }
-        }
-        s_src[threadIdx.x] = src;
-        s_below[threadIdx.x] = sb;
-    }
-    __syncthreads();
-    const PipeBox cold = pipe_box(A.box_cold, A.T, W, D);
-    double* dst = cold.guest + (size_t)(A.par * 2) * W * D;                     // rows that move down: push
-    double* mine = me.guest + (size_t)(A.par * 2 + 1) * W * D;                  // rows that move up: pull
-    const long long cold_home = __hip_atomic_load(me.meta + A.par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // all of a thread's loads first - the pulls cross xGMI, their latencies must overlap - then the stores
-    for (int base = 0; base < PIPE_COLS * D; base += 8 * (int)blockDim.x) {
-        double push[8], pull[8];
-        bool on[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int idx = base + q * (int)blockDim.x + (int)threadIdx.x;
-            on[q] = false;
-            if (idx < PIPE_COLS * D) {
-                const int col = idx / D, d = idx - col * D;
-                const int32_t src = s_src[col];
-                if (src != PIPE_NOSEL) {
-                    on[q] = true;
-                    push[q] = A.pool[row_off(src, D, A.guest_delta) + d];
-                    pull[q] = sys_load(A.pool_cold + (size_t)(cold_home + s_below[col]) * D + d);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int idx = base + q * (int)blockDim.x + (int)threadIdx.x;
-            if (on[q]) {
-                const int col = idx / D, d = idx - col * D;
-                sys_store(dst + (size_t)(c0 + col) * D + d, push[q]);
-                mine[(size_t)(c0 + col) * D + d] = pull[q];
-            }
-        }
-    }
-    if (pipe_arrive_collect(A.tickets + 1, gridDim.x, A.sweep, A.budget, A.flags) && threadIdx.x == 0)
-        pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
+    pipe_bottom_block(A, blockIdx.x * PIPE_COLS, s_src, s_below, nullptr, nullptr);
 }
 
 // ---- hens_pipe_selftest: the three access patterns the pipeline relies on, between two processes ----------
