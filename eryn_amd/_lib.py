@@ -92,6 +92,8 @@ SIGNATURES = {
     "hens_pipe_debug_stats": (C.c_int, [_P, _P, C.c_int32]),
     "hens_debug_trace": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     "hens_debug_permutation": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    "hens_get_iteration": (C.c_int, [_P, _P]),
+    "hens_debug_draws": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hens_version": (C.c_char_p, []),
     "hens_device_count": (C.c_int, []),
 }

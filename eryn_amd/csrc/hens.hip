@@ -1506,6 +1506,79 @@ int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t i
     return HENS_OK;
 }
 
+int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !iter_out) return fail(c, HENS_ERR_INVALID, "null argument");
+    *iter_out = (int64_t)c->iter;
+    return HENS_OK;
+}
+
+int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, double* u_zz, double* u_acc,
+                     int32_t* pt_slot, double* u_swap, int32_t* is_mh, double* mh_step, double* mh_u) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || iter < 0) return fail(c, HENS_ERR_INVALID, "null context / negative iteration");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    struct Scratch {                      // debug path: plain allocations, freed on every exit
+        std::vector<void*> p;
+        ~Scratch() { for (void* q : p) (void)hipFree(q); }
+    } sc;
+    auto grab = [&](size_t bytes) -> void* {
+        void* q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+        sc.p.push_back(q);
+        return q;
+    };
+    const bool mh = [&] {
+        if (c->mh_kind < 0 || c->mh_weight <= 0.0) return false;
+        return c->mh_weight >= 1.0 || move_uniform(c->cfg.seed, (uint64_t)iter) < c->mh_weight;
+    }();
+    if (is_mh) *is_mh = mh ? 1 : 0;
+    if (own || cw || u_zz || u_acc) {     // the stretch plan of that iteration, exactly as hens_step's plan kernel makes it
+        PlanArgs pa{};
+        pa.dr.own = (int32_t*)grab(TW * 4); pa.dr.cw = (int32_t*)grab(TW * 4);
+        pa.dr.zz = (double*)grab(TW * 8); pa.dr.fac = (double*)grab(TW * 8); pa.dr.lu = (double*)grab(TW * 8);
+        pa.dbg_uzz = (double*)grab(TW * 8); pa.dbg_uacc = (double*)grab(TW * 8);
+        if (!pa.dr.own || !pa.dr.cw || !pa.dr.zz || !pa.dr.fac || !pa.dr.lu || !pa.dbg_uzz || !pa.dbg_uacc)
+            return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
+        pa.iter0 = (uint64_t)iter; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
+        pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits;
+        hipLaunchKernelGGL(k_plan, dim3(c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), c->stream, pa);
+        HIPCHK(c, hipGetLastError());
+        if (own) HIPCHK(c, hipMemcpyAsync(own, pa.dr.own, TW * 4, hipMemcpyDeviceToHost, c->stream));
+        if (cw) HIPCHK(c, hipMemcpyAsync(cw, pa.dr.cw, TW * 4, hipMemcpyDeviceToHost, c->stream));
+        if (u_zz) HIPCHK(c, hipMemcpyAsync(u_zz, pa.dbg_uzz, TW * 8, hipMemcpyDeviceToHost, c->stream));
+        if (u_acc) HIPCHK(c, hipMemcpyAsync(u_acc, pa.dbg_uacc, TW * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if ((pt_slot || u_swap) && c->T > 1) {
+        const size_t n = (size_t)c->T * c->W;
+        int32_t* ds = (int32_t*)grab(n * 4);
+        double* du = (double*)grab(n * 8);
+        if (!ds || !du) return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
+        hipLaunchKernelGGL(k_debug_pt, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, ds, du, c->T, c->W, c->idx_bits,
+                           c->cfg.seed, (uint64_t)iter);
+        HIPCHK(c, hipGetLastError());
+        if (pt_slot) HIPCHK(c, hipMemcpyAsync(pt_slot, ds, n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (u_swap) HIPCHK(c, hipMemcpyAsync(u_swap, du, (size_t)(c->T - 1) * c->W * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if ((mh_step || mh_u) && c->mh_kind >= 0) {
+        MhDrawArgs d{};
+        d.step = (double*)grab(TW * c->D * 8); d.lu = (double*)grab(TW * 8); d.dbg_u = (double*)grab(TW * 8);
+        if (!d.step || !d.lu || !d.dbg_u) return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
+        d.scale = c->mh_scale; d.iter = (uint64_t)iter; d.seed = c->cfg.seed;
+        d.Tl = c->Tl; d.W = c->W; d.D = c->D; d.rung_begin = c->cfg.rung_begin; d.kind = c->mh_kind;
+        d.chol_lds = 0;
+        hipLaunchKernelGGL(k_mh_draw, dim3((c->W + 63) / 64, c->Tl), dim3(256), (size_t)64 * (c->D + 1) * 8, c->stream, d);
+        HIPCHK(c, hipGetLastError());
+        if (mh_step) HIPCHK(c, hipMemcpyAsync(mh_step, d.step, TW * c->D * 8, hipMemcpyDeviceToHost, c->stream));
+        if (mh_u) HIPCHK(c, hipMemcpyAsync(mh_u, d.dbg_u, TW * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return HENS_OK;
+}
+
 // ---- ladder sharding ---------------------------------------------------------------------------------
 int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
     hens_ctx_impl* c = CTX(ctx);

@@ -86,9 +86,24 @@ __device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits,
     return x;
 }
 
+// (the PT helpers that use these follow the enum)
 enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
                   PURPOSE_PTU = 10, PURPOSE_MH_ACC = 11, PURPOSE_MH_NORMAL = 12, PURPOSE_MOVE = 13 };
 enum { MH_ISO = 0, MH_DIAG = 1, MH_FULL = 2 };
+
+// Philox-mode PT draws (one keyed matching per pair has the same distribution as the reference's two
+// permutations, tempering.py:526-532): column c of the cascade meets slot pt_slot(t, c) of global rung t (the
+// hottest rung is met in identity order), and pair (i, i-1) on column c consumes the uniform of row j = T-1-i.
+__device__ __forceinline__ int pt_slot(uint64_t seed, uint64_t it, int t, int T, int c, int idx_bits, int W) {
+    if (t == T - 1) return c;
+    const PrpKey K = prp_key(seed, it, PURPOSE_PTPERM, (uint32_t)t);
+    return (int)prp((uint32_t)c, K.k, idx_bits, (uint32_t)W);
+}
+__device__ __forceinline__ double pt_uniform(uint64_t seed, uint64_t it, int j, int W, int c) {   // tempering.py:535
+    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(j * W + c), PURPOSE_PTU};
+    const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return u01(d.x, d.y);
+}
 
 // One Box-Muller pair of standard normals for coordinates (2 pr, 2 pr + 1) of walker `wid` (= rung * W + walker)
 // in iteration `it`: the draw of the Gaussian MH move (k_mh_draw and the inline MODE_MH path share it).
@@ -102,11 +117,12 @@ __device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, ui
     sincospi(2.0 * u2, &sn, &cs);
     return double2{r * cs, r * sn};
 }
-__device__ __forceinline__ double mh_log_uniform(uint64_t seed, uint64_t it, uint32_t wid) {     // mh.py:157
+__device__ __forceinline__ double mh_uniform(uint64_t seed, uint64_t it, uint32_t wid) {         // mh.py:157
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_ACC};
     const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return log(u01(d.x, d.y));
+    return u01(d.x, d.y);
 }
+__device__ __forceinline__ double mh_log_uniform(uint64_t seed, uint64_t it, uint32_t wid) { return log(mh_uniform(seed, it, wid)); }
 
 // ---------------------------------------------------------------------------------------------
 // Ladder-pipeline primitives (used by the stretch kernels too; the protocol is described at k_pipe_*).
@@ -1191,6 +1207,7 @@ struct MhDrawArgs {
     const double* scale;     // MH_ISO: [1] std dev; MH_DIAG: [D] std devs; MH_FULL: [D][D] lower Cholesky factor, row-major
     uint64_t iter, seed;
     int32_t Tl, W, D, rung_begin, kind, chol_lds;
+    double* dbg_u;           // debug (hens_debug_draws): the raw accept uniforms [Tl][W], or nullptr
 };
 // Philox mode: step = scale * z (isotropic / diagonal) or chol * z (full covariance), z ~ N(0, 1) by
 // Box-Muller from Philox counters keyed (iteration, global rung, walker, coordinate pair); the accept
@@ -1215,6 +1232,7 @@ __global__ __launch_bounds__(256) void k_mh_draw(const MhDrawArgs A) {
     if (threadIdx.x < 64 && w0 + (int)threadIdx.x < W) {
         const int w = w0 + threadIdx.x;
         A.lu[(size_t)tl * W + w] = mh_log_uniform(A.seed, A.iter, rung * (uint32_t)W + (uint32_t)w);
+        if (A.dbg_u) A.dbg_u[(size_t)tl * W + w] = mh_uniform(A.seed, A.iter, rung * (uint32_t)W + (uint32_t)w);
     }
     __syncthreads();
     const bool in_lds = A.kind == MH_FULL && A.chol_lds;
@@ -1251,6 +1269,8 @@ struct PlanArgs {
     uint64_t seed;
     double a;
     int32_t Tl, W, D, rung_begin, idx_bits;
+    double* dbg_uzz;      // debug (hens_debug_draws): the raw uniforms behind zz / lu, [NB][Tl][W], or nullptr
+    double* dbg_uacc;
 };
 
 // exclusive scan of this thread's value across the workgroup (wave shuffles + one LDS hop)
@@ -1325,6 +1345,10 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
         const int r = (int)__umulhi(d.x, (uint32_t)Nc);
         const int cw = ord[(s0 ? N0 : 0) + r];
         make_draw(A.dr, base + p, own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
+        if (A.dbg_uzz) {
+            A.dbg_uzz[base + p] = u01(d.y, d.z);
+            A.dbg_uacc[base + p] = u01(e.x, e.y);
+        }
     }
 }
 
@@ -1425,17 +1449,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     for (int e = tid; e < (int)NE; e += PT_THREADS) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
-            int slot;
-            if (PHILOX) {
-                if (t == T - 1) {
-                    slot = c;                                    // hottest rung: identity
-                } else {
-                    const PrpKey K = prp_key(A.seed, it, PURPOSE_PTPERM, (uint32_t)t);
-                    slot = (int)prp((uint32_t)c, K.k, A.idx_bits, (uint32_t)W);
-                }
-            } else {
-                slot = A.colslot[(size_t)t * W + c];
-            }
+            const int slot = PHILOX ? pt_slot(A.seed, it, t, T, c, A.idx_bits, W) : A.colslot[(size_t)t * W + c];
             scol[e] = slot;
             Lc[e] = A.Lfull[(size_t)t * W + slot];
             const int tl = t - A.rung_begin;
@@ -1446,14 +1460,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
                 locc[e] = -1;                                    // walker owned by another rank
             }
             if (t < T - 1) {
-                double u;
-                if (PHILOX) {
-                    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(t * W + c), PURPOSE_PTU};
-                    const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                    u = u01(d.x, d.y);
-                } else {
-                    u = A.colu[(size_t)t * W + c];
-                }
+                const double u = PHILOX ? pt_uniform(A.seed, it, t, W, c) : A.colu[(size_t)t * W + c];
                 lu[e] = log(u);                                  // tempering.py:535
             }
         }
@@ -1610,6 +1617,17 @@ __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
             A.swaps_last[j] = (double)cnt[j];
             A.swaps_total[j] += (double)cnt[j];
         }
+    }
+}
+
+// debug (hens_debug_draws): the Philox-mode PT draws of iteration `it` in the form the cascade consumes them -
+// slot[t][c] = slot of rung t that column c visits, u[j][c] = the swap uniform of pair (T-1-j, T-2-j) on column c
+__global__ void k_debug_pt(int32_t* slot, double* u, int T, int W, int idx_bits, uint64_t seed, uint64_t it) {
+    const int64_t n = (int64_t)T * W;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e / W), c = (int)(e - (int64_t)t * W);
+        slot[e] = pt_slot(seed, it, t, T, c, idx_bits, W);
+        if (t < T - 1) u[e] = pt_uniform(seed, it, t, W, c);
     }
 }
 
@@ -1856,15 +1874,11 @@ struct PipeArgs {
 };
 
 __device__ __forceinline__ int pipe_slot(const PipeArgs& A, int g, int c) {
-    if (g == A.T - 1) return c;                                      // hottest rung of the ladder: identity
-    const PrpKey K = prp_key(A.seed, A.iter, PURPOSE_PTPERM, (uint32_t)g);
-    return (int)prp((uint32_t)c, K.k, A.idx_bits, (uint32_t)A.W);
+    return pt_slot(A.seed, A.iter, g, A.T, c, A.idx_bits, A.W);
 }
 // log-uniform of pair (i, i-1), column c - keyed exactly like k_pt_cascade (row T-1-i)
 __device__ __forceinline__ double pipe_logu(const PipeArgs& A, int i, int c) {
-    const u4 ctr{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), (uint32_t)((A.T - 1 - i) * A.W + c), PURPOSE_PTU};
-    const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-    return log(u01(d.x, d.y));                                       // tempering.py:535
+    return log(pt_uniform(A.seed, A.iter, A.T - 1 - i, A.W, c));     // tempering.py:535
 }
 
 struct PipeWaitArgs {

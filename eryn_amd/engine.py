@@ -157,6 +157,29 @@ class HipEnsemble:
         check(self.lib.hens_debug_permutation(self.ctx, int(which), int(rung), int(it), ptr(out)), self.ctx)
         return out
 
+    def iteration(self):
+        """Index of the next Philox iteration ``step`` will run."""
+        n = C.c_int64(0)
+        check(self.lib.hens_get_iteration(self.ctx, C.byref(n)), self.ctx)
+        return int(n.value)
+
+    def debug_draws(self, it, mh=False):
+        """The Philox draws ``step`` consumes in iteration ``it`` (include/hipensemble.h: hens_debug_draws)."""
+        T, Tl, W, D = self.T, self.Tl, self.W, self.D
+        out = dict(own=np.empty((Tl, W), dtype=np.int32), cw=np.empty((Tl, W), dtype=np.int32),
+                   u_zz=np.empty((Tl, W)), u_acc=np.empty((Tl, W)))
+        pt = self.tempered and T > 1
+        if pt:
+            out.update(pt_slot=np.empty((T, W), dtype=np.int32), u_swap=np.empty((T - 1, W)))
+        if mh:
+            out.update(mh_step=np.empty((Tl, W, D)), mh_u=np.empty((Tl, W)))
+        is_mh = C.c_int32(0)
+        check(self.lib.hens_debug_draws(self.ctx, int(it), ptr(out["own"]), ptr(out["cw"]), ptr(out["u_zz"]),
+                                        ptr(out["u_acc"]), ptr(out.get("pt_slot")), ptr(out.get("u_swap")),
+                                        C.byref(is_mh), ptr(out.get("mh_step")), ptr(out.get("mh_u"))), self.ctx)
+        out["is_mh"] = bool(is_mh.value)
+        return out
+
     def set_profiling(self, on):
         check(self.lib.hens_set_profiling(self.ctx, int(bool(on))), self.ctx)
 

@@ -98,7 +98,8 @@ class EnsembleSampler:
             if not isinstance(m, DeviceMove):
                 raise NotImplementedError("only eryn_amd.moves.StretchMove / GaussianMove run on the device path")
         stretch_moves = [m for m in self.moves if isinstance(m, StretchMove)]
-        live = any(m.live_dangerously for m in stretch_moves)
+        # the W >= 2 ndim guard belongs to the red-blue move (red_blue.py:108-114): without one it does not apply
+        live = any(m.live_dangerously for m in stretch_moves) or not stretch_moves
         a_vals = {m.a for m in stretch_moves} or {2.0}
         if len(a_vals) != 1:
             raise NotImplementedError("all device stretch moves must share one scale a")
@@ -244,26 +245,32 @@ class EnsembleSampler:
         prev_mh = eng.mh_counters() if mh_move is not None else None
         inds = state.branches[name].inds
         for _ in range(iterations):
-            eng.step(thin_by)
+            # the reference stores the LAST thinned step's accept mask and swap counts (ensemble.py:968-979,
+            # 1013-1024: `accepted` is re-zeroed every sub-iteration); the moves' own counters see every step
+            mid, mid_mh = prev, prev_mh
+            if thin_by > 1:
+                eng.step(thin_by - 1)
+                mid = eng.counters()
+                mid_mh = eng.mh_counters() if mh_move is not None else None
+            eng.step(1)
             x, L, P, betas = eng.download()
             c = eng.counters()
-            accepted = c["accepted"] - prev["accepted"]
+            accepted = c["accepted"] - mid["accepted"]
             if st_move is not None:
-                st_move.accepted += accepted
+                st_move.accepted += c["accepted"] - prev["accepted"]
                 st_move.num_proposals += c["num_proposals"] - prev["num_proposals"]
             if mh_move is not None:
                 cm = eng.mh_counters()
-                acc_mh = cm["accepted"] - prev_mh["accepted"]
-                mh_move.accepted += acc_mh
+                mh_move.accepted += cm["accepted"] - prev_mh["accepted"]
                 mh_move.num_proposals += cm["num_proposals"] - prev_mh["num_proposals"]
-                accepted = accepted + acc_mh
+                accepted = accepted + (cm["accepted"] - mid_mh["accepted"])
                 prev_mh = cm
             swaps = None
             if tc is not None:
                 tc.betas = betas
                 tc.time = c["adapt_time"]
                 tc.swaps_accepted = c["swaps_last"]
-                swaps = c["swaps_total"] - prev["swaps_total"]
+                swaps = c["swaps_last"]
             prev = c
             state = State({name: x[:, :, None, :]}, inds={name: inds}, log_like=L, log_prior=P,
                           betas=None if tc is None else betas, random_state=None)
@@ -283,8 +290,10 @@ class EnsembleSampler:
             bk.update(store=False, thin_by=1)
             for initial_state in self.sample(initial_state, iterations=burn, **bk):
                 pass
+        if nsteps == 0:                                    # ensemble.py:1095-1096
+            return initial_state
         results = None
-        if self.rng == "philox" and kwargs.get("store", True) is False and nsteps > 0:
+        if self.rng == "philox" and kwargs.get("store", True) is False:
             # nothing is stored: one device-resident call for all iterations, one download at the end
             kw = dict(kwargs)
             thin = int(kw.pop("thin_by", 1))

@@ -13,6 +13,9 @@ class DeviceMove(Move):
     """A move evaluated by libhipensemble.  Moves of one sampler share ONE device context
     (``attach_engine``) so the walkers stay resident between different moves of a weighted mix."""
 
+    # the W >= 2 ndim guard is the red-blue move's (red_blue.py:108-114); other moves create their context without it
+    needs_walker_guard = False
+
     def __init__(self, likelihood=None, prior_box=None, device_id=0, fill_value=-1e300, trust_resident=False,
                  a=2.0, live_dangerously=False, **kwargs):
         self.likelihood = likelihood
@@ -55,7 +58,7 @@ class DeviceMove(Move):
             kw = dict(adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag, adaptation_time=tc.adaptation_time,
                       stop_adaptation=tc.stop_adaptation)
         self.engine = HipEnsemble(T, W, D, self.likelihood, lo, hi, a=self._engine_a, tempered=tc is not None,
-                                  live_dangerously=self._engine_live, fill_value=self.fill_value,
+                                  live_dangerously=self._engine_live or not self.needs_walker_guard, fill_value=self.fill_value,
                                   device_id=self.device_id, **kw)
         return self.engine
 

@@ -29,6 +29,8 @@ class StretchMove(DeviceMove):
             returned last (safe when no host-side code mutates the State in between).
     """
 
+    needs_walker_guard = True          # red_blue.py:108-114
+
     def __init__(self, a=2.0, nsplits=2, randomize_split=True, live_dangerously=False, likelihood=None,
                  prior_box=None, device_id=0, fill_value=-1e300, trust_resident=False, return_gpu=False,
                  **kwargs):

@@ -306,6 +306,28 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
  * rung `rung`.  out[nwalkers] i32. */
 int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t iter, int32_t* out);
 
+/* The Philox iteration counter: the index of the NEXT iteration hens_step will run (iterations completed on this
+ * context so far, by hens_step or by the parity API). */
+int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out);
+
+/* Debug / parity: the Philox draws hens_step consumes in iteration `iter` (a pure function of seed, iteration,
+ * global rung and walker), exported in a form that maps one-to-one onto the reference's draws so that a
+ * production iteration can be replayed through the CPU oracle (tests/test_hip_replay.py):
+ *   own, cw [Tl][W] i32   moving walker / its complement walker at every split position; positions < ceil(W/2)
+ *                         belong to split 0 and list that half in ascending walker order like the reference's
+ *                         boolean masks (red_blue.py:119-124,150-197), so labels[own] = (position >= ceil(W/2)) and
+ *                         rint = index of cw in the ascending complement list (stretch.py:93-99)
+ *   u_zz, u_acc [Tl][W]   the raw uniforms behind zz (stretch.py:129-132) and the accept test (red_blue.py:294)
+ *   pt_slot [T][W] i32    slot of global rung t that cascade column c visits: for pair (i, i-1),
+ *                         iperm[k=c] = pt_slot[i][c] and i1perm[k=c] = pt_slot[i-1][c] (tempering.py:526-541)
+ *   u_swap [T-1][W]       row j = the uniforms of pair (T-1-j, T-2-j) in column order (tempering.py:535)
+ *   is_mh                 1 if the weighted move choice of that iteration (ensemble.py:971) picks the MH move
+ *   mh_step [Tl][W][D], mh_u [Tl][W]   the GaussianMove step rows (gaussian.py:166-167,265-268) and accept
+ *                         uniforms (mh.py:157), if hens_set_mh_proposal was called
+ * Any output pointer may be NULL.  Does not touch the sampler state. */
+int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, double* u_zz, double* u_acc,
+                     int32_t* pt_slot, double* u_swap, int32_t* is_mh, double* mh_step, double* mh_u);
+
 /* Static description of the build. */
 const char* hens_version(void);
 int hens_device_count(void);

@@ -19,6 +19,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _have_device():
+    try:
+        from eryn_amd import _lib
+        return _lib.load().hens_device_count() > 0
+    except Exception:                          # library missing / broken: do NOT skip - let the gpu tests fail loudly
+        return True
+
+
+def pytest_collection_modifyitems(config, items):
+    """Plain `pytest tests` on a box without an MI355X skips the gpu-marked tests instead of failing them
+    (the product itself still fails loudly without a device: eryn_amd has no CPU fallback)."""
+    if any("gpu" in item.keywords for item in items) and not _have_device():
+        skip = pytest.mark.skip(reason="no HIP device visible (gpu tests run on the MI355X box)")
+        for item in items:
+            if "gpu" in item.keywords:
+                item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -6,6 +6,7 @@
   single <T> <W> <D> <iters> <out.npz>               the unsharded run both are compared with
 env PIPE_TEST_DELAY=1 runs everything with adaptation_delay = 1 (then "single" is a 1-rank pipeline).
   timeout                                            rank 1 never steps: rank 0 must raise, not hang
+  replay <nranks> <T> <W> <D> <iters>                N local shards against the ORACLE fed with the exported Philox draws
 """
 import os
 import sys
@@ -123,6 +124,35 @@ def main():
         dist.barrier()
         e.close()
         dist.destroy_process_group()
+    elif mode == "replay":
+        # the sharded production path held to the oracle: the draws are a pure function of (seed, iteration, global
+        # rung, walker), so a whole-ladder context exports them and the oracle replays the pipeline's iterations
+        from oracle import eryn_oracle as orc
+        from tests import replay_utils as ru
+        nranks, T, W, D, iters = map(int, sys.argv[2:7])
+        mu, invcov, x0, betas0 = problem(T, W, D)
+        _, bounds = rung_partition(T, nranks)
+        engs = [make(T, W, D, b) for b in bounds]
+        LadderPipeline.connect_local(engs)
+        whole = make(T, W, D)                              # draws + the initial log-likelihoods the device computed
+        x, L, P, betas = whole.download()
+        st = ru.OracleState(x, L, P, betas)
+        fn = lambda q: orc.gaussian_log_like(q, mu, invcov)      # noqa: E731
+        done = 0
+        for n in (2, iters - 2):
+            for e in engs:
+                e.step(n)
+            for e in engs:
+                e.synchronize()
+            ru.replay(whole, st, done, n, fn, np.full(D, -6.0), np.full(D, 6.0))
+            done += n
+            snaps = [e.download() for e in engs]
+            cs = [e.counters() for e in engs]
+            cnt = dict(accepted=np.concatenate([c["accepted"] for c in cs], axis=0), swaps_total=cs[0]["swaps_total"],
+                       swaps_last=cs[0]["swaps_last"])
+            ru.assert_state_equal(st, *[np.concatenate([s[k] for s in snaps], axis=0) for k in range(3)], snaps[0][3],
+                                  counters=cnt, what=f"{nranks}-shard pipeline after {done} iterations")
+        assert st.swaps_total.sum() > 0 and st.min_margin > 1e-12
     elif mode == "timeout":
         # a neighbour that never steps: the waiting rank must fail with an error, not hang the GPU
         _, bounds = rung_partition(4, 2)

@@ -1,0 +1,145 @@
+"""Replay of PRODUCTION (Philox) iterations through the CPU oracle.
+
+``hens_step`` draws on the device; its draws are a pure function of (seed, iteration, global rung, walker) and
+``hens_debug_draws`` exports them in a form that maps one-to-one onto the reference's draws:
+
+    labels  <- which half of the position list a walker is in      (red_blue.py:119-124)
+    rint    <- index of the complement walker in the ascending complement list  (stretch.py:93-99)
+    u_zz, u_acc                                                    (stretch.py:129-132, red_blue.py:294)
+    iperm, i1perm <- slots that cascade column c visits on rungs i and i-1   (tempering.py:526-541)
+    u_swap                                                         (tempering.py:535)
+
+``oracle_iterations`` then runs the pinned NumPy restatement (oracle/eryn_oracle.py) with exactly those draws, so
+the code path the benchmark times (plan kernel, Philox cascade, folded ladder adaptation, pipeline) is held to the
+same oracle as the parity API.  The conversion asserts what the reference guarantees structurally: halves of size
+ceil(W/2) / floor(W/2) listed in ascending order, every complement walker in the OTHER half, permutations.
+"""
+import numpy as np
+
+from oracle import eryn_oracle as orc
+
+
+def is_permutation_rows(a, W):
+    return a.shape[-1] == W and np.array_equal(np.sort(a, axis=-1), np.broadcast_to(np.arange(W), a.shape))
+
+
+def draws_to_reference(d, T, W):
+    """hens_debug_draws output for the whole ladder -> dict(labels, rint0/1, u_zz0/1, u_acc0/1, iperm, i1perm, u_swap)."""
+    N0 = (W + 1) // 2
+    own, cw = d["own"].astype(np.int64), d["cw"].astype(np.int64)
+    assert own.shape == (T, W) and is_permutation_rows(own, W), "own must list every walker of a rung exactly once"
+    halves = (own[:, :N0], own[:, N0:])
+    for h in halves:                                   # boolean masks enumerate ascending (red_blue.py:150-154)
+        assert np.all(np.diff(h, axis=1) > 0), "split lists must be ascending"
+    labels = np.empty((T, W), dtype=np.int64)
+    tt = np.arange(T)[:, None]
+    labels[tt, halves[0]] = 0
+    labels[tt, halves[1]] = 1
+    assert np.all((labels == 0).sum(axis=1) == N0)     # arange(W) % 2 shuffled: ceil(W/2) zeros (red_blue.py:120-124)
+    out = dict(labels=labels)
+    for sp in (0, 1):
+        sl = slice(0, N0) if sp == 0 else slice(N0, W)
+        C = halves[1 - sp]                             # ascending complement list (red_blue.py:183-197)
+        cwp = cw[:, sl]
+        assert np.all(labels[tt, cwp] == 1 - sp), "a complement walker drawn from the moving half"
+        rint = np.stack([np.searchsorted(C[t], cwp[t]) for t in range(T)])
+        assert np.array_equal(C[tt, rint], cwp)
+        out[f"rint{sp}"] = rint
+        out[f"u_zz{sp}"] = d["u_zz"][:, sl]
+        out[f"u_acc{sp}"] = d["u_acc"][:, sl]
+        for k in ("u_zz", "u_acc"):
+            assert np.all((out[f"{k}{sp}"] >= 0.0) & (out[f"{k}{sp}"] < 1.0))
+    if T > 1 and "pt_slot" in d:
+        slot = d["pt_slot"].astype(np.int64)
+        assert slot.shape == (T, W) and is_permutation_rows(slot, W), "every rung's column map must be a permutation"
+        out["iperm"] = slot[:0:-1].copy()              # row j: pair i = T-1-j, hot slots
+        out["i1perm"] = slot[-2::-1].copy()            # cold slots of the same pairs
+        out["u_swap"] = d["u_swap"]
+        assert np.all((d["u_swap"] >= 0.0) & (d["u_swap"] < 1.0))
+    return out
+
+
+class OracleState:
+    def __init__(self, x, L, P, betas, time=0):
+        self.x, self.L, self.P = np.array(x, copy=True), np.array(L, copy=True), np.array(P, copy=True)
+        self.betas = None if betas is None else np.array(betas, copy=True)
+        self.time = int(time)
+        T, W, _ = self.x.shape
+        self.accepted = np.zeros((T, W))
+        self.mh_accepted = np.zeros((T, W))
+        self.swaps_total = np.zeros(max(T - 1, 0))
+        self.swaps_last = np.zeros(max(T - 1, 0))
+        self.min_margin = np.inf                        # closest accept / swap decision to its knife edge
+
+
+def _margin(st, lnpdiff, logu):
+    with np.errstate(invalid="ignore"):
+        m = np.abs(lnpdiff - logu) / np.maximum(1.0, np.abs(lnpdiff))
+    m = m[np.isfinite(m)]
+    if m.size:
+        st.min_margin = min(st.min_margin, float(m.min()))
+
+
+def oracle_iteration(st, ref, loglike, lo, hi, a=2.0, adaptive=True, lag=10000, nu=100, stop_adaptation=-1,
+                     mh=None):
+    """One sampler iteration on ``st`` with the given draws (ensemble.py:965-981): the stretch move's two halves
+    (or one Metropolis-Hastings proposal when ``mh = (step, u_acc)``), the PT cascade, the ladder adaptation."""
+    T, W, D = st.x.shape
+    tt = np.arange(T)[:, None]
+    if mh is not None:
+        out = orc.mh_step(st.x, st.L, st.P, st.betas, mh[0], mh[1], lo, hi, loglike)
+        st.mh_accepted += out["keep"]
+        with np.errstate(divide="ignore"):
+            _margin(st, out["lnpdiff"], np.log(mh[1]))
+    else:
+        for sp in (0, 1):
+            out = orc.stretch_split(st.x, st.L, st.P, st.betas, ref["labels"], sp, ref[f"rint{sp}"], ref[f"u_zz{sp}"],
+                                    ref[f"u_acc{sp}"], a, lo, hi, loglike)
+            acc = np.zeros((T, W))
+            acc[tt, out["S"]] = out["keep"]
+            st.accepted += acc
+            with np.errstate(divide="ignore"):
+                _margin(st, out["lnpdiff"], np.log(ref[f"u_acc{sp}"]))
+    if st.betas is not None and T > 1:
+        sel, sw = orc.pt_sweep(st.x, st.L, st.P, st.betas, ref["iperm"], ref["i1perm"], ref["u_swap"])
+        st.swaps_last = sw
+        st.swaps_total += sw
+        if adaptive:                                                     # tempering.py:632-633
+            if stop_adaptation < 0 or st.time < stop_adaptation:
+                st.betas = orc.adapt_ladder(st.betas, sw, W, st.time, lag, nu)
+            st.time += 1
+    return st
+
+
+def replay(eng_draws, st, it0, n, loglike, lo, hi, mh=False, **kw):
+    """Run the oracle over iterations it0 .. it0+n-1 with the draws exported by ``eng_draws`` (a whole-ladder
+    HipEnsemble).  Returns the list of per-iteration move kinds ("stretch" / "mh")."""
+    T, W, _ = st.x.shape
+    kinds = []
+    for it in range(it0, it0 + n):
+        d = eng_draws.debug_draws(it, mh=mh)
+        ref = draws_to_reference(d, T, W)
+        if d["is_mh"]:
+            oracle_iteration(st, ref, loglike, lo, hi, mh=(d["mh_step"], d["mh_u"]), **kw)
+            kinds.append("mh")
+        else:
+            oracle_iteration(st, ref, loglike, lo, hi, **kw)
+            kinds.append("stretch")
+    return kinds
+
+
+def assert_state_equal(st, x, L, P, betas, counters=None, mh_counters=None, rtol_l=1e-12, what=""):
+    """Bars of SURVEY 8c: positions / log-prior / counters exact, log-likelihood rtol 1e-12, betas rtol 1e-13."""
+    assert np.array_equal(x, st.x), f"{what}: x differs from the oracle in {int((x != st.x).any(axis=-1).sum())} walkers " \
+                                    f"(closest decision margin {st.min_margin:.2e})"
+    assert np.array_equal(P, st.P), f"{what}: log-prior differs"
+    np.testing.assert_allclose(L, st.L, rtol=rtol_l, atol=0, err_msg=f"{what}: log-likelihood")
+    if st.betas is not None:
+        np.testing.assert_allclose(betas, st.betas, rtol=1e-13, atol=0, err_msg=f"{what}: betas")
+    if counters is not None:
+        assert np.array_equal(counters["accepted"], st.accepted), f"{what}: accept counters"
+        if st.betas is not None and st.x.shape[0] > 1:
+            assert np.array_equal(counters["swaps_total"], st.swaps_total), f"{what}: swap totals"
+            assert np.array_equal(counters["swaps_last"], st.swaps_last), f"{what}: last sweep's swap counts"
+    if mh_counters is not None:
+        assert np.array_equal(mh_counters["accepted"], st.mh_accepted), f"{what}: MH accept counters"

@@ -1,0 +1,121 @@
+"""The code path the benchmark times, held to the oracle (-m gpu).
+
+``hens_step`` (Philox mode: plan kernel, inline-permutation cascade, ladder adaptation folded into the next
+launch) is replayed through ``oracle/eryn_oracle.py`` with the very draws it consumed (``hens_debug_draws`` ->
+``tests/replay_utils.py``): positions, log-prior, accept and swap counters exact; log-likelihood rtol 1e-12; betas
+rtol 1e-13.  Every case runs at least one call of >= 3 iterations so that the folded adaptation (a pending
+adaptation riding in the next iteration's first launch) is on the replayed path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import eryn_oracle as orc
+from tests import parity_utils as pu
+from tests import replay_utils as ru
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _engine(T, W, D, like, box, seed, **kw):
+    from eryn_amd.engine import HipEnsemble
+    return HipEnsemble(T, W, D, like, -box, box, seed=seed, **kw)
+
+
+def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_scale=1.0, mh=None, **kw):
+    from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
+    mu, invcov = pu.gaussian_problem(D, dense=(like_kind == "dense"))
+    if like_kind == "dense":
+        like, fn = GaussianLikelihood(mu, invcov), (lambda x: orc.gaussian_log_like(x, mu, invcov))
+    elif like_kind == "diag":
+        iv = np.diag(invcov).copy()
+        like, fn = GaussianLikelihood(mu, iv), (lambda x: orc.gaussian_diag_log_like(x, mu, iv))
+    else:
+        like, fn = RosenbrockLikelihood(D), (lambda x: orc.rosenbrock_log_like(x))
+    eng = _engine(T, W, D, like, box, seed, **kw)
+    lo, hi = np.full(D, -box), np.full(D, box)
+    x0 = x_scale * np.random.RandomState(3).randn(T, W, D)
+    tempered = T > 1
+    eng.upload(x0, betas=orc.make_ladder(D, ntemps=T) if tempered else None)
+    eng.eval_state()
+    if mh is not None:
+        eng.set_mh_proposal(*mh)
+    x, L, P, betas = eng.download()
+    st = ru.OracleState(x, L, P, betas, time=0)
+    kinds = []
+    done = 0
+    for n in calls:
+        it0 = eng.iteration()
+        eng.step(n)
+        eng.synchronize()
+        kinds += ru.replay(eng, st, it0, n, fn, lo, hi, mh=mh is not None,
+                           adaptive=kw.get("adaptive", True), stop_adaptation=kw.get("stop_adaptation", -1))
+        x, L, P, betas = eng.download()
+        ru.assert_state_equal(st, x, L, P, betas, counters=eng.counters(),
+                              mh_counters=eng.mh_counters() if mh is not None else None,
+                              what=f"({T},{W},{D}) {like_kind} after {done + n} iterations")
+        done += n
+        assert st.min_margin > 1e-12, "a decision sat on the knife edge; pick another seed for this case"
+    acc = st.accepted.sum() + st.mh_accepted.sum()
+    assert acc > 0, "nothing was ever accepted: the case does not exercise the update"
+    if tempered:
+        assert st.swaps_total.sum() > 0
+    eng.close()
+    return kinds
+
+
+def test_replay_config2_full_size():
+    """BASELINE config 2 at full size: one single-iteration call, then a 3-iteration call (folded adaptation)."""
+    _run_case(16, 4096, 32)
+
+
+def test_replay_ndim64():
+    _run_case(8, 1024, 64, calls=(4,))
+
+
+def test_replay_long_ladder_64_rungs():
+    """config 3's ladder length at reduced W: the 63-pair cascade and the multi-word swap bitmask."""
+    _run_case(64, 1024, 64, calls=(2, 3))
+
+
+def test_replay_rosenbrock_ndim128_move_mix():
+    """BASELINE config 5 in small: Rosenbrock, StretchMove + GaussianMove mixed by weight (ensemble.py:971)."""
+    kinds = _run_case(4, 512, 128, like_kind="rosen", box=6.0, calls=(3, 5), x_scale=0.5, mh=("iso", 0.01, 0.5))
+    assert "mh" in kinds and "stretch" in kinds
+
+
+def test_replay_diag_move_mix_axis_aligned():
+    kinds = _run_case(3, 256, 16, like_kind="diag", box=8.0, calls=(6,), mh=("diag", np.full(16, 0.3), 0.4))
+    assert "mh" in kinds and "stretch" in kinds
+
+
+@pytest.mark.parametrize("T,W,D", [(3, 257, 8), (3, 33, 4), (5, 100, 5)])
+def test_replay_odd_sizes(T, W, D):
+    """odd W (halves of ceil / floor size), W not a multiple of the tile, generic row widths"""
+    _run_case(T, W, D, calls=(1, 4))
+
+
+def test_replay_untempered():
+    _run_case(1, 64, 5, like_kind="diag", calls=(4,))
+
+
+def test_replay_narrow_box():
+    """many proposals outside the prior support: -inf prior, fill value, P inf -> 0 rule (move.py:526)"""
+    _run_case(4, 256, 16, box=2.0, calls=(2, 3), x_scale=0.8)
+
+
+def test_replay_adaptation_stops():
+    _run_case(4, 128, 8, calls=(5,), stop_adaptation=2)
+    _run_case(4, 128, 8, calls=(4,), adaptive=False)
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_replay_local_pipeline(tmp_path, nranks):
+    """N ladder shards stepping through the pipeline (one-sided puts, per-block hand-off flags) against the oracle"""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HENS_PIPE_TIMEOUT_S="10")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "pipeline_worker.py"), "replay", str(nranks), "8", "256", "32", "5"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
