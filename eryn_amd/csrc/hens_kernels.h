@@ -640,6 +640,134 @@ __device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attrib
     return part;
 }
 
+// Phase C of the stretch kernels: this wave's share of -2 log-likelihood of the proposal in row `lane` of the LDS tile
+// (lane per walker; the rows / blocks of the precision matrix are dealt to the NW waves, see sym_quad).  The
+// coefficients come through scalar loads (SGPR operands).  Returns the partial sum; the caller adds the NW parts.
+template <int DT, int LIKE, int NW>
+__device__ __forceinline__ double like_partial(const double* qtile, int lane, int wv, bool inbox, const double* mu_p,
+                                               const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b) {
+    constexpr int D = DT, RS = DT + 2;
+    double part = 0.0;
+    typedef const __attribute__((address_space(4))) double* cptr_t;   // read-only for the launch: SGPR scalar loads
+    const cptr_t mu = (cptr_t)(uintptr_t)mu_p;
+    const cptr_t prec = (cptr_t)(uintptr_t)prec_p;
+    const double* qrow = qtile + lane * RS;
+    if (LIKE == LIKE_ROSEN) {
+        if (wv == 0 && inbox) {
+            double acc = 0.0;
+            for (int i = 0; i + 1 < D; ++i) {
+                const double x0 = qrow[i], x1 = qrow[i + 1];
+                const double t1 = x1 - x0 * x0, t2 = rosen_a - x0;
+                acc += rosen_b * (t1 * t1) + t2 * t2;
+            }
+            part = 2.0 * acc;
+        }
+    } else if (inbox) {
+        constexpr int RB = (DT + NW - 1) / NW;
+        const int i0 = wv * RB;
+        if (LIKE == LIKE_DENSE && DT == 64 && NW == 8) {
+            // D = 64: a lane holding all 64 centred coordinates needs 128 VGPRs for them alone (165 in
+            // total: one workgroup per CU).  Blocked instead, every wave keeps ONE 32-vector:
+            //   waves 0,1: q_lo' A_lolo q_lo   waves 2,3: q_hi' A_hihi q_hi   (symmetric, sym_quad<32>)
+            //   waves 4-7: q_lo' (A_lohi + A_hilo') q_hi, 8 rows of the cross block each
+            // 264 / 264 / 264 FMAs per lane - the same balance as the row-pair deal, at half the registers.
+            constexpr int H = 32, BLK = (H / 2) * (H + 2);
+            const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
+            const int half = (wv == 0 || wv == 1) ? 0 : H;            // waves 2..7 hold q_hi
+            double qh[H];
+#pragma unroll
+            for (int k = 0; k < H; k += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(qrow + half + k);
+                qh[k] = v.x - mu[half + k];
+                qh[k + 1] = v.y - mu[half + k + 1];
+            }
+            switch (wv) {
+                case 0: part = sym_quad<H, 2, 0>(qh, psym); break;
+                case 1: part = sym_quad<H, 2, 1>(qh, psym); break;
+                case 2: part = sym_quad<H, 2, 0>(qh, psym + BLK); break;
+                case 3: part = sym_quad<H, 2, 1>(qh, psym + BLK); break;
+                default: {
+                    const int r0 = (wv - 4) * 8;
+                    const cptr_t cx = psym + 2 * BLK + r0 * H;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        double y = 0.0;
+#pragma unroll
+                        for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
+                        part = fma(qrow[r0 + r] - mu[r0 + r], y, part);
+                    }
+                }
+            }
+        } else if (LIKE == LIKE_DENSE && DT == 128 && NW == 8) {
+            // D = 128: the same blocking with four 32-blocks: 4 symmetric diagonal blocks (528 FMAs each) and
+            // 6 cross blocks (1024 each).  Waves 0-5 take one cross block each, waves 6 and 7 two diagonal
+            // blocks each: 1024 / 1056 FMAs per lane, one 32-vector in registers at a time.
+            constexpr int H = 32, SB = (H / 2) * (H + 2);
+            const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
+            double qh[H];
+            if (wv < 6) {
+                const int bi = wv < 3 ? 0 : (wv < 5 ? 1 : 2);                  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+                const int bk = wv < 3 ? wv + 1 : (wv < 5 ? wv - 1 : 3);
+#pragma unroll
+                for (int k = 0; k < H; k += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(qrow + bk * H + k);
+                    qh[k] = v.x - mu[bk * H + k];
+                    qh[k + 1] = v.y - mu[bk * H + k + 1];
+                }
+                const cptr_t cx = psym + 4 * SB + wv * H * H;
+#pragma unroll 4
+                for (int r = 0; r < H; ++r) {
+                    double y = 0.0;
+#pragma unroll
+                    for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
+                    part = fma(qrow[bi * H + r] - mu[bi * H + r], y, part);
+                }
+            } else {
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int b = (wv - 6) * 2 + b2;
+#pragma unroll
+                    for (int k = 0; k < H; k += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(qrow + b * H + k);
+                        qh[k] = v.x - mu[b * H + k];
+                        qh[k + 1] = v.y - mu[b * H + k + 1];
+                    }
+                    part += sym_quad<H, 1, 0>(qh, psym + b * SB);
+                }
+            }
+        } else if (LIKE == LIKE_DENSE) {
+            double qreg[DT];
+#pragma unroll
+            for (int k = 0; k < DT; k += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(qrow + k);
+                qreg[k] = v.x - mu[k];
+                qreg[k + 1] = v.y - mu[k + 1];
+            }
+            // q'^T A q' = sum_i q'_i (A_ii q'_i + sum_{k>i} (A_ik + A_ki) q'_k): half the FP64 FMAs of
+            // the full product (phase C is FP64-rate-bound: vector fp64 = 78.6 TF/s).  Rows are dealt
+            // to the waves in pairs (p, D-1-p) of equal total length; the wave index becomes a
+            // compile-time constant through the switch so every register index is static.
+            const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
+            switch (wv) {
+#define HENS_SYM_CASE(WI) case WI: part = sym_quad<DT, NW, WI>(qreg, psym); break;
+                HENS_SYM_CASE(0) HENS_SYM_CASE(1) HENS_SYM_CASE(2) HENS_SYM_CASE(3)
+                HENS_SYM_CASE(4) HENS_SYM_CASE(5) HENS_SYM_CASE(6) HENS_SYM_CASE(7)
+#undef HENS_SYM_CASE
+                default: break;
+            }
+        } else {
+            for (int ii = 0; ii < RB; ++ii) {
+                const int i = i0 + ii;
+                if (i < DT) {
+                    const double di = qrow[i] - mu[i];
+                    part = fma(di * prec[i], di, part);
+                }
+            }
+        }
+    }
+    return part;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
@@ -953,124 +1081,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        double part = 0.0;
-        typedef const __attribute__((address_space(4))) double* cptr_t;   // read-only for the launch: SGPR scalar loads
-        const cptr_t mu = (cptr_t)(uintptr_t)A.mu;
-        const cptr_t prec = (cptr_t)(uintptr_t)A.prec;
-        const double* qrow = qtile + lane * RS;
-        if (LIKE == LIKE_ROSEN) {
-            if (wv == 0 && inbox) {
-                double acc = 0.0;
-                for (int i = 0; i + 1 < D; ++i) {
-                    const double x0 = qrow[i], x1 = qrow[i + 1];
-                    const double t1 = x1 - x0 * x0, t2 = A.rosen_a - x0;
-                    acc += A.rosen_b * (t1 * t1) + t2 * t2;
-                }
-                part = 2.0 * acc;
-            }
-        } else if (inbox) {
-            constexpr int RB = (DT + NW - 1) / NW;
-            const int i0 = wv * RB;
-            if (LIKE == LIKE_DENSE && DT == 64 && NW == 8) {
-                // D = 64: a lane holding all 64 centred coordinates needs 128 VGPRs for them alone (165 in
-                // total: one workgroup per CU).  Blocked instead, every wave keeps ONE 32-vector:
-                //   waves 0,1: q_lo' A_lolo q_lo   waves 2,3: q_hi' A_hihi q_hi   (symmetric, sym_quad<32>)
-                //   waves 4-7: q_lo' (A_lohi + A_hilo') q_hi, 8 rows of the cross block each
-                // 264 / 264 / 264 FMAs per lane - the same balance as the row-pair deal, at half the registers.
-                constexpr int H = 32, BLK = (H / 2) * (H + 2);
-                const cptr_t psym = (cptr_t)(uintptr_t)A.prec_sym;
-                const int half = (wv == 0 || wv == 1) ? 0 : H;            // waves 2..7 hold q_hi
-                double qh[H];
-#pragma unroll
-                for (int k = 0; k < H; k += 2) {
-                    const double2 v = *reinterpret_cast<const double2*>(qrow + half + k);
-                    qh[k] = v.x - mu[half + k];
-                    qh[k + 1] = v.y - mu[half + k + 1];
-                }
-                switch (wv) {
-                    case 0: part = sym_quad<H, 2, 0>(qh, psym); break;
-                    case 1: part = sym_quad<H, 2, 1>(qh, psym); break;
-                    case 2: part = sym_quad<H, 2, 0>(qh, psym + BLK); break;
-                    case 3: part = sym_quad<H, 2, 1>(qh, psym + BLK); break;
-                    default: {
-                        const int r0 = (wv - 4) * 8;
-                        const cptr_t cx = psym + 2 * BLK + r0 * H;
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            double y = 0.0;
-#pragma unroll
-                            for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                            part = fma(qrow[r0 + r] - mu[r0 + r], y, part);
-                        }
-                    }
-                }
-            } else if (LIKE == LIKE_DENSE && DT == 128 && NW == 8) {
-                // D = 128: the same blocking with four 32-blocks: 4 symmetric diagonal blocks (528 FMAs each) and
-                // 6 cross blocks (1024 each).  Waves 0-5 take one cross block each, waves 6 and 7 two diagonal
-                // blocks each: 1024 / 1056 FMAs per lane, one 32-vector in registers at a time.
-                constexpr int H = 32, SB = (H / 2) * (H + 2);
-                const cptr_t psym = (cptr_t)(uintptr_t)A.prec_sym;
-                double qh[H];
-                if (wv < 6) {
-                    const int bi = wv < 3 ? 0 : (wv < 5 ? 1 : 2);                  // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
-                    const int bk = wv < 3 ? wv + 1 : (wv < 5 ? wv - 1 : 3);
-#pragma unroll
-                    for (int k = 0; k < H; k += 2) {
-                        const double2 v = *reinterpret_cast<const double2*>(qrow + bk * H + k);
-                        qh[k] = v.x - mu[bk * H + k];
-                        qh[k + 1] = v.y - mu[bk * H + k + 1];
-                    }
-                    const cptr_t cx = psym + 4 * SB + wv * H * H;
-#pragma unroll 4
-                    for (int r = 0; r < H; ++r) {
-                        double y = 0.0;
-#pragma unroll
-                        for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                        part = fma(qrow[bi * H + r] - mu[bi * H + r], y, part);
-                    }
-                } else {
-#pragma unroll
-                    for (int b2 = 0; b2 < 2; ++b2) {
-                        const int b = (wv - 6) * 2 + b2;
-#pragma unroll
-                        for (int k = 0; k < H; k += 2) {
-                            const double2 v = *reinterpret_cast<const double2*>(qrow + b * H + k);
-                            qh[k] = v.x - mu[b * H + k];
-                            qh[k + 1] = v.y - mu[b * H + k + 1];
-                        }
-                        part += sym_quad<H, 1, 0>(qh, psym + b * SB);
-                    }
-                }
-            } else if (LIKE == LIKE_DENSE) {
-                double qreg[DT];
-#pragma unroll
-                for (int k = 0; k < DT; k += 2) {
-                    const double2 v = *reinterpret_cast<const double2*>(qrow + k);
-                    qreg[k] = v.x - mu[k];
-                    qreg[k + 1] = v.y - mu[k + 1];
-                }
-                // q'^T A q' = sum_i q'_i (A_ii q'_i + sum_{k>i} (A_ik + A_ki) q'_k): half the FP64 FMAs of
-                // the full product (phase C is FP64-rate-bound: vector fp64 = 78.6 TF/s).  Rows are dealt
-                // to the waves in pairs (p, D-1-p) of equal total length; the wave index becomes a
-                // compile-time constant through the switch so every register index is static.
-                const cptr_t psym = (cptr_t)(uintptr_t)A.prec_sym;
-                switch (wv) {
-#define HENS_SYM_CASE(WI) case WI: part = sym_quad<DT, NW, WI>(qreg, psym); break;
-                    HENS_SYM_CASE(0) HENS_SYM_CASE(1) HENS_SYM_CASE(2) HENS_SYM_CASE(3)
-                    HENS_SYM_CASE(4) HENS_SYM_CASE(5) HENS_SYM_CASE(6) HENS_SYM_CASE(7)
-#undef HENS_SYM_CASE
-                    default: break;
-                }
-            } else {
-                for (int ii = 0; ii < RB; ++ii) {
-                    const int i = i0 + ii;
-                    if (i < DT) {
-                        const double di = qrow[i] - mu[i];
-                        part = fma(di * prec[i], di, part);
-                    }
-                }
-            }
-        }
+        const double part = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
         s_part[wv * TILE + lane] = part;
     }
     HENS_TRACE(5);

@@ -37,7 +37,8 @@ def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_sca
         like, fn = RosenbrockLikelihood(D), (lambda x: orc.rosenbrock_log_like(x))
     eng = _engine(T, W, D, like, box, seed, **kw)
     lo, hi = np.full(D, -box), np.full(D, box)
-    x0 = x_scale * np.random.RandomState(3).randn(T, W, D)
+    # inside the prior support: the reference refuses a start with an infinite log-prior (ensemble.py:930-946)
+    x0 = np.clip(x_scale * np.random.RandomState(3).randn(T, W, D), -0.95 * box, 0.95 * box)
     tempered = T > 1
     eng.upload(x0, betas=orc.make_ladder(D, ntemps=T) if tempered else None)
     eng.eval_state()
