@@ -23,6 +23,7 @@ thread_local std::string g_last_error;
 
 struct DrawBuf {                     // one batch of planned iterations
     Draws d{};
+    DrawRec* rec = nullptr;          // the same draws by walker id (fused second half-step + cascade launch)
 };
 
 struct hens_ctx_impl {
@@ -53,6 +54,8 @@ struct hens_ctx_impl {
     double* swaps_total = nullptr;
     double* ad_ring = nullptr;       // [4][T] new ladders published by the adapting workgroup (fold mode 2), -1 = not yet
     uint32_t ad_serial = 0;
+    int label_cb = 0, label_cb_shift = 0;   // block-balanced split labels: cascade columns per block (0 = legacy labels)
+    uint32_t* swap_acc = nullptr;    // [SWAP_ACC_ROWS][T-1] swap counts accumulated by k_split1_pt
 
     // model
     double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr; double* prec_sym = nullptr;
@@ -328,12 +331,13 @@ StretchArgs base_args(hens_ctx_impl* c) {
 
 AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* out) {
     AdaptArgs a{};
-    a.swap_part = c->adapt_src ? c->adapt_src : c->swap_part;
+    a.swap_part = const_cast<uint32_t*>(c->adapt_src ? c->adapt_src : c->swap_part);
     a.betas_in = in; a.betas_out = out;
     a.swaps_last = c->swaps_last; a.swaps_total = c->swaps_total;
     a.lag = c->cfg.adaptation_lag; a.nu = c->cfg.adaptation_time;
     a.time = c->adapt_time;
     a.T = c->T; a.W = c->W; a.nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
+    a.zero_after = (c->adapt_src != nullptr && c->adapt_src == c->swap_acc) ? 1 : 0;
     a.moving = (adaptive && (c->cfg.stop_adaptation < 0 || c->adapt_time < c->cfg.stop_adaptation)) ? 1 : 0;
     return a;
 }
@@ -361,6 +365,7 @@ int fold_mode(const hens_ctx_impl*) {
 bool can_fold_adapt(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FOLD") != nullptr;
     if (off || !c->adapt_pending || !fast_path(c) || c->T > 128) return false;
+    if (c->adapt_src && c->adapt_src == c->swap_acc && fold_mode(c) != 2) return false;   // ONE reader clears the rows
     const int nw = fast_nw(c->D);
     const int64_t nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     return nw >= 2 && nblocks * (c->T - 1) <= (int64_t)8 * nw * 64;
@@ -592,6 +597,7 @@ void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int
     pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
     pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin;
     pa.idx_bits = c->idx_bits;
+    pa.T = c->T; pa.cb = c->label_cb; pa.rec = c->db[which].rec;
     hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
 }
 
@@ -692,6 +698,104 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
     return HENS_OK;
 }
 
+
+// ---- fused second half-step + cascade (k_split1_pt) ----------------------------------------------------------
+// whole ladder resident, tempered, block-balanced labels, compile-time row width, device likelihood
+bool fused_ok(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_NO_FUSED") != nullptr;             // A/B knob: three launches per iteration
+    return !off && c->label_cb > 0 && has_pt(c) && c->Tl == c->T && !c->pipe.on && fast_path(c) &&
+           c->cfg.likelihood_kind != HENS_LIKE_HOST;
+}
+
+template <int LIKE>
+int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid(c->W / c->label_cb);
+#define LAUNCH_FUSED(DT, NW)                                                                       \
+    do {                                                                                           \
+        const size_t lds = fused_lds_bytes(DT, NW);                                                \
+        if (lds > 60000) {                                                                         \
+            static bool attr_done = false;                                                         \
+            if (!attr_done) {                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                attr_done = true;                                                                  \
+            }                                                                                      \
+        }                                                                                          \
+        if (e0)                                                                                    \
+            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW>), grid, dim3(NW * 64), lds, c->stream, f); \
+    } while (0)
+    switch (c->D) {
+        case 8: LAUNCH_FUSED(8, 4); break;
+        case 16: LAUNCH_FUSED(16, 4); break;
+        case 32: LAUNCH_FUSED(32, FAST_NW_32); break;
+        case 64: LAUNCH_FUSED(64, 8); break;
+        case 128: LAUNCH_FUSED(128, 8); break;
+        default: return fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for ndim %d", c->D);
+    }
+#undef LAUNCH_FUSED
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_split1_pt launch failed: %s", hipGetErrorString(e));
+    return HENS_OK;
+}
+
+// one Philox iteration in two launches: first half-step (k_stretch_fast, carrying the pending ladder adaptation), then
+// second half-step + cascade + swap counts (k_split1_pt)
+int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
+    const int T = c->T, W = c->W;
+    {
+        StretchArgs a = base_args(c);
+        a.dr = draws_at(c->db[which], (size_t)ib * T * W);
+        a.split = 0;
+        a.home_off = c->parity * T * W;
+        attach_iteration_head(c, a);
+        if (evs) {
+            c->ext_start = new_event(c);
+            c->ext_stop = new_event(c);
+            evs->push_back(c->ext_start);
+            evs->push_back(c->ext_stop);
+        }
+        const int r = launch_stretch<MODE_STRETCH>(c, a, (c->N0 + TILE - 1) / TILE);
+        c->ext_start = c->ext_stop = nullptr;
+        if (r) return r;
+    }
+    FusedArgs f{};
+    f.pool = c->pool;
+    f.loc = c->loc[c->cur]; f.L = c->L[c->cur]; f.P = c->P[c->cur];
+    f.locnew = c->loc[c->cur ^ 1]; f.Lnew = c->L[c->cur ^ 1]; f.Pnew = c->P[c->cur ^ 1];
+    f.betas = c->betas[c->bcur];
+    f.rec = c->db[which].rec + (size_t)ib * T * W;
+    f.accepted = c->accepted;
+    f.swap_acc = c->swap_acc;
+    f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
+    f.flags = c->flags;
+    f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;
+    f.iter = c->iter; f.seed = c->cfg.seed;
+    f.T = T; f.W = W; f.home_off = c->parity * T * W; f.idx_bits = c->idx_bits;
+    f.cb = c->label_cb; f.cb_shift = c->label_cb_shift;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (evs) {
+        e0 = new_event(c); e1 = new_event(c);
+        evs->push_back(e0); evs->push_back(e1);
+    }
+    int r;
+    switch (c->cfg.likelihood_kind) {
+        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1); break;
+        default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
+    }
+    if (r) return r;
+    c->parity ^= 1;
+    c->num_proposals += 1;
+    c->cur ^= 1;
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = c->cfg.adaptive != 0;
+    c->adapt_src = c->swap_acc;                    // SWAP_ACC_ROWS rows, cleared by whoever reduces them
+    c->adapt_nblocks = SWAP_ACC_ROWS;
+    return HENS_OK;
+}
 
 int ensure_mh_buffers(hens_ctx_impl* c) {
     if (c->mh_step) return HENS_OK;
@@ -862,12 +966,23 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRY(dalloc(c, &c->d_uacc, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->d_keep, (size_t)c->Tl * c->N0));
     TRY(dalloc(c, &c->xtmp, TW * c->D));
-    // plan batches: two buffers of NB iterations, each kept under ~48 MiB
+    // plan batches: two buffers of NB iterations, each kept under ~96 MiB
     c->NP2 = 1; c->idx_bits = 0;
     while (c->NP2 < c->W) { c->NP2 <<= 1; c->idx_bits++; }
+    // Block-balanced split labels (see block_rank): ladders of 2..64 rungs whose length divides 128, walker counts
+    // that are a multiple of the block.  A property of (T, W) only, so every rank of a sharded ladder agrees.
+    if (cfg->tempered && c->T >= 2 && c->T <= 64 && (c->T & (c->T - 1)) == 0 && !getenv("HENS_LEGACY_LABELS")) {
+        const int cb = 2 * TILE / c->T;
+        if (c->W % cb == 0) {
+            c->label_cb = cb;
+            while ((1 << c->label_cb_shift) < cb) c->label_cb_shift++;
+        }
+    }
+    TRY(dalloc(c, &c->swap_acc, (size_t)SWAP_ACC_ROWS * c->T));
+    TRYHIP(hipMemsetAsync(c->swap_acc, 0, (size_t)SWAP_ACC_ROWS * c->T * 4, c->stream));
     {
-        const size_t per_iter = TW * 32;
-        size_t nb = (48u << 20) / std::max<size_t>(per_iter, 1);
+        const size_t per_iter = TW * 64;
+        size_t nb = (96u << 20) / std::max<size_t>(per_iter, 1);
         nb = std::max<size_t>(2, std::min<size_t>(nb, 32));
         nb &= ~(size_t)1;
         c->NB = (int)nb;
@@ -879,6 +994,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->db[b].d.zz, n));
         TRY(dalloc(c, &c->db[b].d.fac, n));
         TRY(dalloc(c, &c->db[b].d.lu, n));
+        TRY(dalloc(c, &c->db[b].rec, n));
         TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
     }
@@ -1323,7 +1439,9 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     c->win_count = 0;
     const bool pt = has_pt(c);
     const bool prof = c->per_kernel_events;
+    const bool fused = fused_ok(c);
     std::vector<hipEvent_t> evs;
+    std::vector<char> ev_kind;                // per event pair: 0 stretch launch, 1 cascade launch, 2 fused half-step + cascade
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
     c->evpool.clear();
     c->timing = hens_timing{};
@@ -1354,21 +1472,29 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             const bool mh = iteration_is_mh(c);
             if (mh) {
                 r = mh_iteration(c, prof ? &evs : nullptr);
-                if (prof) { evs.push_back(evs[evs.size() - 2]); evs.push_back(evs[evs.size() - 2]); }   // one launch, two timing slots
+                if (prof) ev_kind.push_back(0);
+            } else if (fused) {
+                r = fused_iteration(c, which, ib, prof ? &evs : nullptr);
+                if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
+                if (r) return r;
+                c->iter += 1;
+                continue;
             } else {
                 r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
+                if (prof) { ev_kind.push_back(0); ev_kind.push_back(0); }
             }
             if (r) return r;
             if (piped) {
                 if (prof) { hipEvent_t e0 = new_event(c); evs.push_back(e0); (void)hipEventRecord(e0, c->stream); }
                 pipe_sweep(c);
-                if (prof) { hipEvent_t e1 = new_event(c); evs.push_back(e1); (void)hipEventRecord(e1, c->stream); }
+                if (prof) { hipEvent_t e1 = new_event(c); evs.push_back(e1); (void)hipEventRecord(e1, c->stream); ev_kind.push_back(1); }
             } else if (pt) {
                 PtArgs p = pt_args(c, nullptr, false);
                 if (prof) {
                     hipEvent_t e0 = new_event(c), e1 = new_event(c);
                     evs.push_back(e0);
                     evs.push_back(e1);
+                    ev_kind.push_back(1);
                     hipExtLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), (uint32_t)pt_lds_bytes(T),
                                           c->stream, e0, e1, 0, p);
                 } else {
@@ -1378,6 +1504,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 c->cur ^= 1;
                 c->adapt_pending = true;
                 c->adapt_pending_adaptive = c->cfg.adaptive != 0;
+                c->adapt_src = nullptr;
             }
             c->iter += 1;
         }
@@ -1389,17 +1516,12 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     c->timing.n_iters = n_iters;
     if (prof) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        size_t e = 0;
         float ms = 0;
-        for (int64_t i = 0; i < n_iters; ++i) {
-            for (int s = 0; s < 2; ++s) {
-                (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
-                c->timing.stretch_ms += ms; c->timing.n_stretch += 1;
-            }
-            if (pt) {
-                (void)hipEventElapsedTime(&ms, evs[e], evs[e + 1]); e += 2;
-                c->timing.pt_ms += ms; c->timing.n_pt += 1;
-            }
+        for (size_t k = 0; k < ev_kind.size() && 2 * k + 1 < evs.size(); ++k) {
+            (void)hipEventElapsedTime(&ms, evs[2 * k], evs[2 * k + 1]);
+            if (ev_kind[k] == 0) { c->timing.stretch_ms += ms; c->timing.n_stretch += 1; }
+            else if (ev_kind[k] == 1) { c->timing.pt_ms += ms; c->timing.n_pt += 1; }
+            else { c->timing.fused_ms += ms; c->timing.n_fused += 1; }
         }
     }
     return HENS_OK;
@@ -1543,6 +1665,7 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
             return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
         pa.iter0 = (uint64_t)iter; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
         pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits;
+        pa.T = c->T; pa.cb = c->label_cb;
         hipLaunchKernelGGL(k_plan, dim3(c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), c->stream, pa);
         HIPCHK(c, hipGetLastError());
         if (own) HIPCHK(c, hipMemcpyAsync(own, pa.dr.own, TW * 4, hipMemcpyDeviceToHost, c->stream));

@@ -86,6 +86,22 @@ __device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits,
     return x;
 }
 
+// inverse of prp: walk the cycle backwards until the value is inside [0, W) again
+__device__ __forceinline__ uint32_t prp_inv(uint32_t y, const uint32_t* k, int bits, uint32_t W) {
+    const int lb = bits >> 1, rb = bits - lb;
+    const uint32_t lm = (1u << lb) - 1u, rm = (1u << rb) - 1u;
+    do {
+        uint32_t L = y >> rb, R = y & rm;
+#pragma unroll
+        for (int r = 6; r >= 0; r -= 2) {
+            R ^= fmix32(L ^ k[r + 1]) & rm;
+            L ^= fmix32(R ^ k[r]) & lm;
+        }
+        y = (L << rb) | R;
+    } while (y >= W);
+    return y;
+}
+
 // (the PT helpers that use these follow the enum)
 enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 8, PURPOSE_PTPERM = 9,
                   PURPOSE_PTU = 10, PURPOSE_MH_ACC = 11, PURPOSE_MH_NORMAL = 12, PURPOSE_MOVE = 13 };
@@ -98,6 +114,26 @@ __device__ __forceinline__ int pt_slot(uint64_t seed, uint64_t it, int t, int T,
     if (t == T - 1) return c;
     const PrpKey K = prp_key(seed, it, PURPOSE_PTPERM, (uint32_t)t);
     return (int)prp((uint32_t)c, K.k, idx_bits, (uint32_t)W);
+}
+// Block-balanced split labelling (Philox mode, ladders whose length divides 128).  The cascade's columns are cut into
+// blocks of cb consecutive columns; on every rung exactly cb/2 of the cb walkers a block meets are labelled 1: the
+// walker that column c meets has label (rank of hash(c) among the block's cb hashes) >= cb/2.  Because the column map
+// of a rung is a uniform permutation, this is a uniformly random balanced labelling of the rung like the reference's
+// shuffle of arange(W) % 2 (red_blue.py:119-124) - and one workgroup that owns a block of columns owns exactly
+// 64 = (cb/2) * T walkers of the second half-step plus everything the cascade of those columns touches, so the second
+// half-step and the cascade run as ONE launch (k_split1_pt).  x -> fmix32(a ^ x) is a bijection: no ties.
+__device__ __forceinline__ int block_rank(const uint32_t* kpt, int c, int cb) {
+    const uint32_t a0 = kpt[0] ^ 0x7f4a7c15u;
+    const uint32_t my = fmix32(a0 ^ (uint32_t)c);
+    const int base = c & ~(cb - 1);
+    int rank = 0;
+    for (int j = 0; j < cb; ++j) rank += fmix32(a0 ^ (uint32_t)(base + j)) < my ? 1 : 0;
+    return rank;
+}
+// label of WALKER w on global rung t (the plan kernel's view): find the column that meets it, then its block rank
+__device__ __forceinline__ int block_label_of_walker(const uint32_t* kpt, int t, int T, int w, int cb, int idx_bits, int W) {
+    const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
+    return block_rank(kpt, c, cb) >= (cb >> 1) ? 1 : 0;
 }
 __device__ __forceinline__ double pt_uniform(uint64_t seed, uint64_t it, int j, int W, int c) {   // tempering.py:535
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(j * W + c), PURPOSE_PTU};
@@ -245,6 +281,12 @@ struct Draws {
     double* lu;      // [Tl][W] log of the accept uniform
 };
 
+// the same per walker id instead of per split position (k_split1_pt finds its walkers through the cascade's column map)
+struct __attribute__((aligned(16))) DrawRec {
+    double zz, fac, lu;
+    int32_t cw, pad;
+};
+
 __device__ __forceinline__ void make_draw(const Draws& d, size_t idx, int own, int cw, double uz, double ua,
                                           double a, int D) {
     double zz = (a - 1.0) * uz + 1.0;              // stretch.py:129-132 (mul, add, square, divide)
@@ -260,7 +302,8 @@ __device__ __forceinline__ void make_draw(const Draws& d, size_t idx, int own, i
 // Ladder adaptation (tempering.py:563-596) from the per-workgroup swap counts of the cascade.
 // ---------------------------------------------------------------------------------------------
 struct AdaptArgs {
-    const uint32_t* swap_part;  // [nblocks][T-1] per-workgroup swap counts of the last cascade
+    uint32_t* swap_part;        // [nblocks][T-1] per-workgroup swap counts of the last cascade
+    int32_t zero_after;         // the rows are accumulated with atomics (k_split1_pt): the reader clears them
     const double* betas_in;     // [T]
     double* betas_out;          // [T] (may alias betas_in when run as its own kernel)
     double* swaps_last;         // [T-1]
@@ -1001,6 +1044,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             const int e = tid + q * NT;
             adv[q] = (e < total) ? rows[e] : 0u;
         }
+        if (!cnt_push && A.ad.zero_after) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + q * NT;
+                if (e < total && adv[q]) A.ad.swap_part[e] = 0u;
+            }
+        }
         if (!cnt_push && wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
         if (!cnt_push && wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
     }
@@ -1280,6 +1330,8 @@ struct PlanArgs {
     uint64_t seed;
     double a;
     int32_t Tl, W, D, rung_begin, idx_bits;
+    int32_t T, cb;        // cb > 0: block-balanced labelling with cb columns per block (see block_rank); 0: label = prp >= N0
+    DrawRec* rec;         // [NB][Tl][W] the draws by walker id, or nullptr
     double* dbg_uzz;      // debug (hens_debug_draws): the raw uniforms behind zz / lu, [NB][Tl][W], or nullptr
     double* dbg_uacc;
 };
@@ -1323,14 +1375,18 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     int32_t* ord = reinterpret_cast<int32_t*>(smem_raw);             // [W] ordered walker ids
     uint8_t* lab = reinterpret_cast<uint8_t*>(ord + W);              // [W] split labels
     if (tid < 64) {                                                  // one wave draws the rung's round keys
-        const PrpKey K = prp_key(A.seed, it, PURPOSE_SPLIT, rung);
+        const PrpKey K = prp_key(A.seed, it, A.cb ? PURPOSE_PTPERM : PURPOSE_SPLIT, rung);
         if (tid < 8) skey[tid] = K.k[tid];
     }
     __syncthreads();
     uint32_t key[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) key[r] = skey[r];
-    for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 1 : 0;
+    if (A.cb) {
+        for (int i = tid; i < W; i += nt) lab[i] = (uint8_t)block_label_of_walker(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
+    } else {
+        for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 1 : 0;
+    }
     __syncthreads();
     const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
     const int lo = min(W, tid * chunk), hi = min(W, lo + chunk);
@@ -1356,6 +1412,12 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
         const int r = (int)__umulhi(d.x, (uint32_t)Nc);
         const int cw = ord[(s0 ? N0 : 0) + r];
         make_draw(A.dr, base + p, own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
+        if (A.rec) {
+            DrawRec rc;
+            rc.zz = A.dr.zz[base + p]; rc.fac = A.dr.fac[base + p]; rc.lu = A.dr.lu[base + p];
+            rc.cw = cw; rc.pad = s0 ? 0 : 1;
+            A.rec[base + own] = rc;
+        }
         if (A.dbg_uzz) {
             A.dbg_uzz[base + p] = u01(d.y, d.z);
             A.dbg_uacc[base + p] = u01(e.x, e.y);
@@ -1561,6 +1623,260 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
 #undef PT_TRACE
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second half-step + PT cascade + swap counts in ONE launch (Philox mode, block-balanced labels).
+//
+// One workgroup owns cb consecutive cascade columns on all T rungs: NE = cb * T = 128 slots.  Exactly
+// TILE = 64 of the walkers in those slots carry label 1 (block_rank), i.e. they are this workgroup's
+// share of the second red/blue half-step; the other 64 were moved by the first half-step's launch.
+// After the accept test the workgroup holds the post-move (L, P, loc) of all 128 slots in LDS - exactly
+// what the cascade of its columns reads - so the hot -> cold walk follows immediately, without the
+// launch boundary, the ramp and the gathers of a separate cascade kernel:
+//   A  thread per slot : column map (Feistel), label rank, {loc, L, P} and - for the moving walkers - their
+//                        draw record by walker id; the complement of a second-half walker sits in its home row
+//   B  lanes over d    : row gathers, q = c - (c - s) zz, box test by ballot, old row -> new home   (as k_stretch_fast)
+//   C  lane per walker : likelihood (like_partial)
+//   D  lane per walker : tempered accept test; the result goes into the cascade's LDS tables
+//   E  lanes over d    : accepted rows
+//   F  lane per column : the walk (k_pt_cascade phase 2)
+//   G  thread per slot : permuted L / P / loc into the next buffers; swap counts by atomics into
+//                        SWAP_ACC_ROWS rows (the adapting workgroup of the next launch reduces and clears them)
+// ---------------------------------------------------------------------------------------------
+constexpr int SWAP_ACC_ROWS = 64;
+
+struct FusedArgs {
+    double* pool;
+    const int32_t* loc; const double* L; const double* P;     // current buffers: the first half-step is already in
+    int32_t* locnew; double* Lnew; double* Pnew;              // next buffers: after the cascade
+    const double* betas;                                      // [T]
+    const DrawRec* rec;                                       // [T][W] this iteration's draws by walker id
+    uint32_t* accepted;                                       // [T][W]
+    uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
+    const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
+    unsigned* flags;
+    double logp_in, fill, rosen_a, rosen_b;
+    uint64_t iter, seed;
+    int32_t T, W, home_off, idx_bits, cb, cb_shift;
+};
+
+__host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
+    return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64) * 8 + (2 * 2 * TILE + 5 * TILE + 64) * 4;
+}
+
+template <int DT, int LIKE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
+    static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
+    constexpr int NE = 2 * TILE;
+    static_assert(NT >= NE, "one thread per slot");
+    double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
+    double* s_part = qtile + TILE * RS;                                  // [NW][TILE]
+    double* s_zz = s_part + NW * TILE;                                   // [TILE] per moving walker
+    double* s_fac = s_zz + TILE;
+    double* s_lu = s_fac + TILE;
+    double* s_Lold = s_lu + TILE;
+    double* s_Pold = s_Lold + TILE;
+    double* Lc = s_Pold + TILE;                                          // [NE] cascade tables, element e = t * cb + cc
+    double* Pc = Lc + NE;
+    double* lupt = Pc + NE;                                              // [NE] log-uniform of pair T-1-t on column cc
+    double* sbeta = lupt + NE;                                           // [64]
+    int32_t* locc = reinterpret_cast<int32_t*>(sbeta + 64);              // [NE]
+    int32_t* scol = locc + NE;                                           // [NE] slot of the element
+    int32_t* s_rs = scol + NE;                                           // [TILE]
+    int32_t* s_rc = s_rs + TILE;
+    int32_t* s_dst = s_rc + TILE;
+    int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep
+    int32_t* s_el = s_flag + TILE;                                       // [TILE] element of the moving walker
+    uint32_t* smask = reinterpret_cast<uint32_t*>(s_el + TILE);          // [cb][MW] swap bitmask per column
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = A.T, W = A.W, CB = A.cb, CS = A.cb_shift;
+    const int c0 = blockIdx.x * CB;
+    const int MW = (T + 31) >> 5;
+
+    // ---- phase A: one thread per slot ----------------------------------------------------------------------
+    if (tid < NE) {
+        const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
+        const PrpKey K = prp_key(A.seed, A.iter, PURPOSE_PTPERM, (uint32_t)t);
+        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, K.k, A.idx_bits, (uint32_t)W);
+        const size_t gi = (size_t)t * W + slot;
+        const int32_t loc_e = A.loc[gi];
+        const double L_e = A.L[gi], P_e = A.P[gi];
+        const int rank = block_rank(K.k, c, CB);
+        const bool member = rank >= (CB >> 1);
+        scol[e] = slot;
+        if (member) {
+            const DrawRec rc = A.rec[gi];
+            const int m = t * (CB >> 1) + rank - (CB >> 1);              // 0 .. 63, each exactly once
+            s_rs[m] = loc_e;
+            s_rc[m] = A.home_off + t * W + rc.cw;                        // its complement moved in the first half-step: at home
+            s_dst[m] = A.home_off + (int32_t)gi;
+            s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
+            s_Lold[m] = L_e; s_Pold[m] = P_e;
+            s_flag[m] = 0;
+            s_el[m] = e;
+        } else {
+            Lc[e] = L_e; Pc[e] = P_e; locc[e] = loc_e;
+        }
+        if (t < T - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, t, W, c));   // tempering.py:535 (row j = t: pair T-1-t)
+        if (e < T) sbeta[e] = A.betas[e];
+    }
+    lds_barrier();
+
+    // ---- phase B: lanes over d, all loads first ----------------------------------------------------------
+    const int jl = tid & (LPR - 1);
+    const int rsub = tid / LPR;
+    const double* __restrict__ pool_r = A.pool;
+    double2 sreg[NPASS], creg[NPASS];
+    bool rv[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        rv[p] = r < TILE;
+        sreg[p] = double2{0.0, 0.0};
+        creg[p] = double2{0.0, 0.0};
+        if (rv[p]) {
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)s_rs[r] * D + jl * 2);
+            creg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)s_rc[r] * D + jl * 2);
+        }
+    }
+    const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
+    const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        bool ok = true, finite = true;
+        if (rv[p]) {
+            const double zz = s_zz[r];
+            double2 qv;
+            qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz;             // stretch.py:143,145
+            qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
+            ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
+            finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
+            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
+            store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);     // the old row to its new home now
+        }
+        const unsigned long long bad = __ballot(!ok);                    // prior.py:80-88, row-wide AND
+        const unsigned long long nonfin = __ballot(!finite);
+        const int gshift = lane & ~(LPR - 1);
+        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << (LPR & 63)) - 1ull) << gshift);
+        if (jl == 0 && rv[p]) {
+            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);
+            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
+        }
+    }
+    lds_barrier();
+
+    // ---- phase C: likelihood ------------------------------------------------------------------------------
+    {
+        const bool inbox = (s_flag[lane] & 1) != 0;
+        s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+    }
+    lds_barrier();
+
+    // ---- phase D: accept / update into the cascade's tables (wave 0, lane = moving walker) -----------------
+    if (wv == 0) {
+        const bool inbox = (s_flag[lane] & 1) != 0;
+        double acc = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + lane];
+        double logl = inbox ? -0.5 * acc : A.fill;                      // ensemble.py:1486-1513
+        if (logl != logl) {                                             // red_blue.py:279-281
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+        const double logp = inbox ? A.logp_in : -INFINITY;              // prior.py:80-88
+        const int e = s_el[lane];
+        const double beta = sbeta[e >> CS];
+        const double Lold = s_Lold[lane], Pold = s_Pold[lane];
+        double lt = logl * beta;                                        // tempering.py:304-306,343-349
+        if (lt != lt) lt = -INFINITY;
+        const double logP = lt + logp;
+        double lo_ = Lold * beta;
+        if (lo_ != lo_) lo_ = -INFINITY;
+        const double prevP = lo_ + Pold;
+        const double lnpdiff = s_fac[lane] + logP - prevP;              // red_blue.py:292
+        const bool keep = lnpdiff > s_lu[lane];                         // red_blue.py:294
+        const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;      // move.py:513-532
+        Lc[e] = keep ? logl : Lold;
+        Pc[e] = keep ? newP : Pold;
+        locc[e] = s_dst[lane];
+        if (keep) {
+            atomicAdd(&A.accepted[s_dst[lane] - A.home_off], 1u);
+            s_flag[lane] |= 2;
+        }
+    }
+    lds_barrier();
+
+    // ---- phase E: accepted rows only -------------------------------------------------------------------------
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        if (!rv[p]) continue;
+        if ((s_flag[r] & 2) == 0) continue;
+        const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+        store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, qv);
+    }
+
+    // ---- phase F: one lane per column walks hot -> cold (tempering.py:515-541) ---------------------------------
+    if (wv == (NW > 1 ? 1 : 0) && lane < CB) {
+        const int cc = lane;
+        double cL = Lc[(size_t)(T - 1) * CB + cc];
+        uint32_t m = 0;
+        for (int i0 = T - 1; i0 >= 1; i0 -= 8) {
+            double Lb[8], lv[8], db[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = (i0 - q >= 1) ? i0 - q : 1;
+                Lb[q] = Lc[(size_t)(i - 1) * CB + cc];
+                lv[q] = lupt[(size_t)(T - 1 - i) * CB + cc];
+                db[q] = sbeta[i - 1] - sbeta[i];                         // tempering.py:518-522
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = i0 - q;
+                if (i >= 1) {
+                    const double pacc = db[q] * (cL - Lb[q]);            // tempering.py:538
+                    const bool sw = pacc > lv[q];                        // tempering.py:541
+                    m |= sw ? (1u << (i & 31)) : 0u;
+                    cL = sw ? cL : Lb[q];
+                    if ((i & 31) == 0 || i == 1) {
+                        smask[cc * MW + (i >> 5)] = m;
+                        m = 0;
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
+    auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
+    if (tid < NE) {
+        const int e = tid, t = e >> CS, cc = e & (CB - 1);
+        int st;
+        if (bit(cc, t)) {
+            st = t - 1;
+        } else {
+            st = t;
+            while (bit(cc, st + 1)) ++st;
+        }
+        const int se = st * CB + cc;
+        const size_t di = (size_t)t * W + scol[e];
+        A.Lnew[di] = Lc[se];
+        A.Pnew[di] = Pc[se];
+        A.locnew[di] = locc[se];
+    }
+    for (int i = 1 + tid; i < T; i += NT) {                              // pair (i, i-1) -> index i-1
+        unsigned n = 0;
+        for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
+        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (SWAP_ACC_ROWS - 1)) * (T - 1) + (i - 1)], n);
+    }
+}
+
 // Stand-alone ladder adaptation (one workgroup): used where it cannot ride in the next stretch
 // launch (parity API, sharded ladder, generic row widths, T > 64, end of a hens_step call).
 // Lane-parallel where the reference's arithmetic allows: ratios, dS, deltaT per lane; the cumsum
@@ -1587,7 +1903,10 @@ __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = e0 + q * NTHREADS;
-            if (v[q]) atomicAdd(&cnt[e % (T - 1)], v[q]);
+            if (v[q]) {
+                atomicAdd(&cnt[e % (T - 1)], v[q]);
+                if (A.zero_after) A.swap_part[e] = 0u;
+            }
         }
     }
     __syncthreads();

@@ -175,6 +175,8 @@ typedef struct hens_timing {
     int64_t n_pt;
     int64_t n_plan;
     int64_t n_iters;
+    double fused_ms;          /* launches that run the second half-step and the cascade together (k_split1_pt) */
+    int64_t n_fused;
 } hens_timing;
 int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events);
 int hens_get_timing(hens_ctx* ctx, hens_timing* out);
