@@ -3,17 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one sampler iteration = StretchMove.propose (both red/blue halves) + the hot->cold
-PT swap cascade + ladder adaptation (ensemble.py:965-1041), over every walker of the ladder.
-N = 1: BASELINE config 2 (ntemps=16, nwalkers=4096, ndim=32 dense Gaussian).  N > 1: the ladder
-is sharded and grows with N (weak scaling): every GPU owns one config-2-sized shard (16 rungs x 4096
-walkers x 32 dims, ntemps = 16 N).  --workload cfg3 selects BASELINE config 3's shards instead
-(8 rungs x 16384 x 64 per GPU, ntemps = 8 N).
-Prints ONE JSON line (rank 0).
+One "step" = one sampler iteration = StretchMove.propose (both red/blue halves) + the hot->cold PT swap cascade +
+ladder adaptation (ensemble.py:965-1041), over every walker of the ladder.
+
+N = 1: BASELINE config 2 (ntemps=16, nwalkers=4096, ndim=32 dense Gaussian) on one MI355X.
+N > 1: one process per GPU over RCCL (the driver starts them with torch.distributed.run; a plain
+       ``python bench.py --gpus N`` starts them itself).  The ladder is sharded and grows with N (weak scaling): every
+       GPU owns one shard of BASELINE config 3 (8 rungs x 16384 walkers x 64 dims; N = 8 is config 3 itself,
+       ntemps = 64).  ``--workload cfg2`` shards config 2 instead (16 rungs x 4096 x 32 per GPU).  Both ladder-
+       adaptation schedules are timed: the reference's (``value``) and the pipeline's one-sweep-late schedule
+       (``delayed_adaptation``); ``weak_base`` is one such shard alone on one GPU, the N = 1 point of the same series.
+
+W untimed warm-up steps, then BLOCKS (5) timed blocks of exactly K steps each, every block bracketed by a barrier +
+synchronize on both sides and reduced with MAX over ranks; ``ms_per_step`` / ``value`` come from the MEDIAN block
+(``block_ms`` lists all of them).  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BLOCKS = 5
+METRIC = "walker-steps/sec (ntemps x nwalkers x iters/s), Gaussian logL"
 
 
 def gaussian_problem(D):
@@ -37,18 +48,27 @@ def gaussian_problem(D):
 
 
 def b_stretch(D):
-    """Algorithmic bytes per walker-step of the stretch kernels: own row + complement
-    row + written row + log-like/log-prior read and write."""
+    """Algorithmic bytes per walker-step of the stretch move: own row + complement row + written row +
+    log-like / log-prior read and write."""
     return 24 * D + 32
 
 
 def b_pt(T, D, f_sw):
+    """Algorithmic bytes per walker-step of the PT cascade in the reference's accounting."""
     return (2.0 * (T - 1) / T) * (8 + f_sw * (16 * D + 32)) if T > 1 else 0.0
 
 
+def static_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
+
+
 def cpu_baseline(T, W, D, seconds=12.0):
-    """Eryn-faithful NumPy restatement (oracle/, pinned bit-exact to the reference) timed on the
-    host cores on a bounded sample of the same workload."""
+    """Eryn-faithful NumPy restatement (oracle/, pinned bit-exact to the reference) timed on the host cores on a
+    bounded sample of the same workload."""
     from oracle import eryn_oracle as orc
     mu, invcov = gaussian_problem(D)
     R, G = np.random.RandomState(123), np.random.RandomState(456)
@@ -69,23 +89,84 @@ def cpu_baseline(T, W, D, seconds=12.0):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         pass
-    return {"value": T * W * n / dt, "unit": "walker-steps/s", "cores": int(threads), "kind": "port",
-            # the real reference is 1.76x slower than this port on identical inputs (BASELINE.md section 5,
-            # measured in the build container where /root/reference can be imported)
-            "reference_over_port": 1.76,
-            "sample": f"{n} iterations of the same (ntemps={T}, nwalkers={W}, ndim={D}) workload, "
-                      f"NumPy oracle (BLAS threads={threads}, os.cpu_count()={os.cpu_count()}), {dt:.1f} s"}
+    out = {"value": T * W * n / dt, "unit": "walker-steps/s", "cores": int(threads), "kind": "port",
+           "sample": f"{n} iterations of (ntemps={T}, nwalkers={W}, ndim={D}), NumPy oracle "
+                     f"(BLAS threads={threads}, os.cpu_count()={os.cpu_count()}), {dt:.1f} s"}
+    ratio = static_json("cpu_reference_ratio.json")      # measured where /root/reference can be imported; not in this run
+    if ratio:
+        out["reference_over_port"] = {"value": ratio.get("reference_over_port"), "source": "profiles/cpu_reference_ratio.json "
+                                      "(static: tools/measure_reference_ratio.py in the build container)"}
+    return out
 
 
-def load_traffic():
-    """HBM bytes per stretch launch from the committed rocprofv3 --pmc passes, if present."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
+def kernel_roofline(tm, T_local, T, W, D, f_sw):
+    """Per-kernel durations (HIP events on the engine's own stream, one pair per launch) -> achieved algorithmic GB/s.
+
+    Algorithmic bytes per launch: a stretch half-step launch moves T_local*W/2 walkers at
+    B_stretch bytes each; the fused launch k_split1_pt does that AND the cascade over all T_local*W walkers
+    (B_pt bytes per walker-step in the reference's accounting); a cascade-only launch just the latter."""
+    tw = T_local * W
+    ks = []
+    if tm["n_stretch"]:
+        us = tm["stretch_ms"] / tm["n_stretch"] * 1e3
+        ks.append({"kernel": "k_stretch_fast (red/blue half-step)", "launches_per_iteration": tm["n_stretch"] / tm["n_iters"],
+                   "avg_launch_us": us, "algorithmic_bytes_per_launch": b_stretch(D) * tw / 2})
+    if tm["n_fused"]:
+        us = tm["fused_ms"] / tm["n_fused"] * 1e3
+        ks.append({"kernel": "k_split1_pt (second half-step + PT cascade + swap counts)",
+                   "launches_per_iteration": tm["n_fused"] / tm["n_iters"], "avg_launch_us": us,
+                   "algorithmic_bytes_per_launch": b_stretch(D) * tw / 2 + b_pt(T, D, f_sw) * tw,
+                   "stretch_bytes_only": b_stretch(D) * tw / 2})
+    if tm["n_pt"]:
+        us = tm["pt_ms"] / tm["n_pt"] * 1e3
+        ks.append({"kernel": "PT cascade launch(es)", "launches_per_iteration": tm["n_pt"] / tm["n_iters"],
+                   "avg_launch_us": us, "algorithmic_bytes_per_launch": b_pt(T, D, f_sw) * tw})
+    for k in ks:
+        k["achieved_GBps"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
+        k["frac"] = k["achieved_GBps"] / HBM_PEAK_GBS
+    dom = max(ks, key=lambda k: k["avg_launch_us"] * k["launches_per_iteration"])
+    traffic = static_json("traffic.json") or {}
+    roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac"], "traffic": traffic.get(dom["kernel"].split(" ")[0]),
+            "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, tools/profile_bench.sh; "
+                              "not measured in this run)",
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
+            "kernels": ks}
+    if "stretch_bytes_only" in dom:
+        roof["frac_stretch_bytes_only"] = dom["stretch_bytes_only"] / (dom["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+    return roof
+
+
+def timed_blocks(step, sync, steps, dist=None, device=None):
+    """BLOCKS blocks of exactly `steps` steps; per block MAX over ranks.  Every rank runs the same collectives
+    whether or not its own stepping raised (a flag wait that timed out), and learns whether ALL ranks are fine."""
+    times, ok = [], 1
+    for _ in range(BLOCKS):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         try:
-            return json.load(open(p)).get("stretch_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+            if ok:
+                step(steps)
+                sync()
+        except RuntimeError as exc:
+            print(f"[bench] stepping failed: {exc}", file=sys.stderr, flush=True)
+            ok = 0
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt, float(ok)], dtype=torch.float64, device=device)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            dt, ok = float(tmax[0].item()), int(t[1].item())
+        times.append(dt)
+    return times, bool(ok)
 
 
 def run_single(args):
@@ -101,44 +182,33 @@ def run_single(args):
     eng.step(args.warmup)
     eng.synchronize()
     eng.reset_counters()
-
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.step(args.steps)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times, _ = timed_blocks(eng.step, eng.synchronize, args.steps)
+    dt = float(np.median(times))
     c = eng.counters()
-    f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps, 1))) if T > 1 else 0.0
+    nit = max(args.steps * BLOCKS, 1)
+    f_sw = float(np.mean(c["swaps_total"] / W / nit)) if T > 1 else 0.0
     acc = float(c["accepted"].mean() / max(c["num_proposals"], 1))
 
-    # dominant kernel (k_stretch): per-launch duration from HIP events on the engine's own stream,
-    # over a second pass of the same K steps with an event pair around every launch
+    # per-launch durations: a further pass of K steps with a HIP event pair around every launch, on the engine's stream
     eng.set_profiling(True)
     eng.step(args.steps)
     eng.synchronize()
     tm = eng.timing()
     eng.set_profiling(False)
-    stretch_us = tm["stretch_ms"] / max(tm["n_stretch"], 1) * 1e3
-    walkers_per_launch = T * W / 2.0
-    alg_bytes = b_stretch(D) * walkers_per_launch
-    achieved = alg_bytes / (stretch_us * 1e-6) / 1e9
     eng.close()
     value = T * W * args.steps / dt
+    whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
+    roof = kernel_roofline(tm, T, T, W, D, f_sw)
+    roof.update(whole_path_GBps=whole, whole_path_frac=whole / HBM_PEAK_GBS)
     out = {
-        "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Gaussian logL",
-        "value": value, "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "metric": METRIC, "value": value, "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "block_ms": [t * 1e3 for t in times], "timing": f"median of {BLOCKS} blocks of {args.steps} steps",
         "config": {"workload": f"config 2: ntemps={T}, nwalkers={W}, ndim={D} dense-covariance Gaussian, box prior +-50, "
                                f"StretchMove(a=2)+adaptive PT, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
                    "parallelism": "single GPU", "stretch_acceptance": acc, "swap_fraction": f_sw},
-        "roofline": {"bound": "hbm", "kernel": "k_stretch", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(),
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": stretch_us,
-                     "pt_kernel_avg_us": tm["pt_ms"] / max(tm["n_pt"], 1) * 1e3,
-                     "whole_path_GBps": (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9,
-                     "whole_path_frac": (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9 / HBM_PEAK_GBS},
+        "roofline": roof,
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(T, W, D, seconds=args.cpu_seconds)
@@ -147,37 +217,216 @@ def run_single(args):
 
 
 def run_sharded(args):
-    from eryn_amd.ladder import bench_sharded
-    return bench_sharded(args, gaussian_problem, b_stretch, b_pt, HBM_PEAK_GBS)
+    """N-GPU leg: weak scaling, one fixed-size ladder shard per GPU, one process per GPU."""
+    import torch.distributed as dist
+
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.ladder import HipShardEngine, LadderPipeline, ShardedLadder, StagedPipeline, rung_partition
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves.tempering import make_ladder
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # "nccl" = RCCL.  HENS_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): a dry run of this
+    # exact code path on a single-GPU box, never a measurement.
+    backend = os.environ.get("HENS_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py --gpus {world}: this box shows {ndev} GPU(s); one RCCL rank per GPU is required "
+                         f"(HENS_DIST_BACKEND=gloo runs a dry run with the ranks sharing a GPU)")
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) % max(ndev, 1)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    assert dist.get_world_size() == world
+    tdev = device if backend == "nccl" else torch.device("cpu")     # gloo reduces host tensors
+    T, W, D = args.ntemps, args.nwalkers, args.ndim
+    _, bounds = rung_partition(T, world)
+    r0, r1 = bounds[rank]
+    Tl = r1 - r0
+    mu, invcov = gaussian_problem(D)
+    x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
+    mode = os.environ.get("HENS_SHARD_MODE", "pipeline")
+
+    def make_engine(delay, rung_range=(r0, r1), ntemps=T, x=x0):
+        e = HipEnsemble(ntemps, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=rung_range,
+                        device_id=local_rank, adaptation_delay=delay)
+        e.upload(x, betas=make_ladder(D, ntemps=ntemps))
+        e.eval_state()
+        return e
+
+    def measure(stepper, eng):
+        ok = 1
+        try:
+            stepper.step(args.warmup)
+            eng.synchronize()
+        except RuntimeError as exc:
+            print(f"[rank {rank}] warm-up failed: {exc}", file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            return None, False
+        eng.reset_counters()
+        return timed_blocks(stepper.step, eng.synchronize, args.steps, dist, tdev)
+
+    def pipeline_run(delay):
+        """The ladder pipeline (one-sided neighbour puts over xGMI) on the given adaptation schedule."""
+        eng = make_engine(delay)
+        try:
+            stepper = LadderPipeline(eng, rank, world, dist=dist, device_id=local_rank)     # failure-atomic across ranks
+        except Exception as exc:                      # noqa: BLE001 - every rank raises together
+            print(f"[rank {rank}] ladder pipeline unavailable ({exc})", file=sys.stderr, flush=True)
+            eng.close()
+            return None
+        times, ok = measure(stepper, eng)
+        if not ok:
+            eng.close()
+            return None
+        return eng, times
+
+    def fallback_run():
+        eng = make_engine(0)
+        if mode == "rccl_neighbour":
+            stepper, transport = StagedPipeline(eng, rank, world, dist, device), \
+                "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages)"
+        else:
+            stepper, transport = ShardedLadder(HipShardEngine(eng, device), T, dist=dist, rank=rank, nranks=world), \
+                "RCCL all-gather(logL) + all-to-all(rows)"
+        times, ok = measure(stepper, eng)
+        if not ok:
+            raise SystemExit("bench.py: the RCCL fallback failed too")
+        return eng, times, transport
+
+    # weak-scaling base: ONE shard of the same size alone on this GPU (rank 0's), the N = 1 point of the series
+    base = None
+    if rank == 0 and not args.no_base:
+        e = make_engine(0, rung_range=(0, Tl), ntemps=Tl, x=np.random.RandomState(1).randn(Tl, W, D))
+        e.step(args.warmup)
+        e.synchronize()
+        bt, _ = timed_blocks(e.step, e.synchronize, args.steps)
+        e.close()
+        bdt = float(np.median(bt))
+        base = {"value": Tl * W * args.steps / bdt, "ms_per_step": bdt / args.steps * 1e3,
+                "workload": f"one shard alone on one GPU: ntemps={Tl}, nwalkers={W}, ndim={D} (a {Tl}-rung ladder of its own)"}
+    dist.barrier()
+
+    result, delayed, transport = None, None, None
+    if mode == "pipeline":
+        result = pipeline_run(0)
+        if result is not None:
+            transport = "xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline)"
+            d = pipeline_run(1)
+            if d is not None:
+                ddt = float(np.median(d[1]))
+                delayed = {"value": T * W * args.steps / ddt, "ms_per_step": ddt / args.steps * 1e3,
+                           "block_ms": [t * 1e3 for t in d[1]],
+                           "schedule": "adaptation_delay=1: the swap ratios of sweep s move the ladder before iteration s+2 "
+                                       "(not the reference's schedule; lets the ranks pipeline)"}
+                d[0].close()
+    if result is None:
+        eng, times, transport = fallback_run()
+    else:
+        eng, times = result
+    dt = float(np.median(times))
+    c = eng.counters()
+    f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps * BLOCKS, 1)))
+    tm = None
+    if mode == "pipeline" and result is not None:     # per-launch durations of this rank's kernels
+        eng.set_profiling(True)
+        try:
+            eng.step(args.steps)
+            eng.synchronize()
+            tm = eng.timing()
+        except RuntimeError:
+            tm = None
+        eng.set_profiling(False)
+    dist.barrier()
+    value = T * W * args.steps / dt
+    out = None
+    if rank == 0:
+        whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
+        roof = kernel_roofline(tm, Tl, T, W, D, f_sw) if tm and tm["n_iters"] else \
+            {"bound": "hbm", "kernel": "whole path (per GPU)", "achieved": whole / world, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": whole / world / HBM_PEAK_GBS, "traffic": None}
+        roof.update(per_gpu=True, whole_path_GBps_per_gpu=whole / world, whole_path_frac_per_gpu=whole / world / HBM_PEAK_GBS)
+        cfgname = "config 3" if (W, D) == (16384, 64) and T == 64 else ("config-3 shards" if (W, D) == (16384, 64) else "config-2 shards")
+        out = {
+            "metric": METRIC, "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "block_ms": [t * 1e3 for t in times], "timing": f"median of {BLOCKS} blocks of {args.steps} steps, max over ranks",
+            "config": {"workload": f"{cfgname}: ladder sharded over {world} GPU(s), ntemps={T} ({Tl} rungs/GPU), nwalkers={W}, "
+                                   f"ndim={D} dense-covariance Gaussian, StretchMove(a=2)+adaptive PT on the reference's "
+                                   f"adaptation schedule, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
+                       "parallelism": f"ladder-shard x{world}", "transport": transport, "dist_backend": backend,
+                       "world_size_seen_by_backend": dist.get_world_size(), "swap_fraction": f_sw},
+            "roofline": roof,
+        }
+        if delayed:
+            out["delayed_adaptation"] = delayed
+        if base:
+            out["weak_base"] = base
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(Tl, W, D, seconds=args.cpu_seconds)
+            out["cpu_baseline"]["sample"] += " = one GPU's shard as a ladder of its own"
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--ntemps", type=int, default=None)
     ap.add_argument("--nwalkers", type=int, default=None)
     ap.add_argument("--ndim", type=int, default=None)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3"])
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-base", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
-        n = max(args.gpus, world)
-        if args.workload == "cfg3":
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    n = max(args.gpus, world, 1)
+    if n > 1 and world == 0:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver would
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+               "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+    if n > 1 and world != n:
+        raise SystemExit(f"bench.py --gpus {args.gpus} started with WORLD_SIZE={world}: they must agree")
+    if n > 1:
+        wl = args.workload or "cfg3"
+        if wl == "cfg3":
             args.ntemps, args.nwalkers, args.ndim = args.ntemps or 8 * n, args.nwalkers or 16384, args.ndim or 64
+            args.steps = args.steps or 500
         else:
             args.ntemps, args.nwalkers, args.ndim = args.ntemps or 16 * n, args.nwalkers or 4096, args.ndim or 32
+            args.steps = args.steps or 2000
         out = run_sharded(args)
     else:
         args.ntemps = args.ntemps or 16
         args.nwalkers = args.nwalkers or 4096
         args.ndim = args.ndim or 32
+        args.steps = args.steps or 2000
         out = run_single(args)
     if out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -132,7 +132,7 @@ struct hens_ctx_impl {
     // debug / timing
     unsigned long long* d_trace = nullptr;
     int64_t trace_words = 0;
-    bool tracing = false, trace_pt = false;
+    bool tracing = false, trace_pt = false, trace_fused = false;
     bool per_kernel_events = false;
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -316,7 +316,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.accepted = c->accepted;
     a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec; a.prec_sym = c->prec_sym;
     a.flags = c->flags;
-    a.trace = (c->tracing && !c->trace_pt) ? c->d_trace : nullptr;
+    a.trace = (c->tracing && !c->trace_pt && !c->trace_fused) ? c->d_trace : nullptr;
     a.logp_in = c->logp_in;
     a.fill = c->cfg.fill_value;
     a.rosen_a = c->rosen_a; a.rosen_b = c->rosen_b;
@@ -770,6 +770,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.swap_acc = c->swap_acc;
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
     f.flags = c->flags;
+    f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
     f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;
     f.iter = c->iter; f.seed = c->cfg.seed;
     f.T = T; f.W = W; f.home_off = c->parity * T * W; f.idx_bits = c->idx_bits;
@@ -1604,7 +1605,8 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
         }
         HIPCHK(c, hipMemsetAsync(c->d_trace, 0, (size_t)words * 8, c->stream));
         c->tracing = true;
-        c->trace_pt = enable == 2;           // 1: stretch kernel, 2: PT cascade
+        c->trace_pt = enable == 2;           // 1: stretch kernel, 2: PT cascade, 3: fused half-step + cascade
+        c->trace_fused = enable == 3;
         return HENS_OK;
     }
     c->tracing = false;

@@ -1654,6 +1654,7 @@ struct FusedArgs {
     uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
     unsigned* flags;
+    unsigned long long* trace;                                // debug: 8 phase timestamps per workgroup, or nullptr
     double logp_in, fill, rosen_a, rosen_b;
     uint64_t iter, seed;
     int32_t T, W, home_off, idx_bits, cb, cb_shift;
@@ -1696,6 +1697,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const int T = A.T, W = A.W, CB = A.cb, CS = A.cb_shift;
     const int c0 = blockIdx.x * CB;
     const int MW = (T + 31) >> 5;
+#define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    FUSED_TRACE(0);
 
     // ---- phase A: one thread per slot ----------------------------------------------------------------------
     if (tid < NE) {
@@ -1724,7 +1727,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         if (t < T - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, t, W, c));   // tempering.py:535 (row j = t: pair T-1-t)
         if (e < T) sbeta[e] = A.betas[e];
     }
+    FUSED_TRACE(1);
     lds_barrier();
+    FUSED_TRACE(2);
 
     // ---- phase B: lanes over d, all loads first ----------------------------------------------------------
     const int jl = tid & (LPR - 1);
@@ -1768,6 +1773,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
         }
     }
+    FUSED_TRACE(3);
     lds_barrier();
 
     // ---- phase C: likelihood ------------------------------------------------------------------------------
@@ -1775,6 +1781,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const bool inbox = (s_flag[lane] & 1) != 0;
         s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }
+    FUSED_TRACE(4);
     lds_barrier();
 
     // ---- phase D: accept / update into the cascade's tables (wave 0, lane = moving walker) -----------------
@@ -1809,6 +1816,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             s_flag[lane] |= 2;
         }
     }
+    FUSED_TRACE(5);
     lds_barrier();
 
     // ---- phase E: accepted rows only -------------------------------------------------------------------------
@@ -1851,6 +1859,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             }
         }
     }
+    FUSED_TRACE(6);
     lds_barrier();
 
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
@@ -1875,6 +1884,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (SWAP_ACC_ROWS - 1)) * (T - 1) + (i - 1)], n);
     }
+    FUSED_TRACE(7);
+#undef FUSED_TRACE
 }
 
 // Stand-alone ladder adaptation (one workgroup): used where it cannot ride in the next stretch

@@ -201,14 +201,34 @@ class LadderPipeline:
             raise ValueError("nranks > 1 needs torch.distributed to exchange the mailbox handles")
         if self.nranks > 1 and selftest:
             self._selftest(dist, group, device_id)
-        handle = engine.pipe_init(self.nranks, self.rank)
         if self.nranks == 1:
+            engine.pipe_init(1, 0)
             engine.pipe_connect_local([engine])
             return
-        handles = [None] * self.nranks
-        dist.all_gather_object(handles, handle, group=group)
-        engine.pipe_connect(b"".join(handles))
-        dist.barrier(group=group)          # nobody stores into a mailbox that is not mapped everywhere yet
+        # Failure-atomic across ranks: every rank runs the SAME sequence of collectives whether or not its own
+        # pipe_init / pipe_connect worked (e.g. hipIpcOpenMemHandle refused), and all of them raise together - a
+        # rank that left early would leave its peers inside a collective that never completes.
+        handle, err = None, None
+        try:
+            handle = engine.pipe_init(self.nranks, self.rank)
+        except Exception as exc:                      # noqa: BLE001
+            err = f"pipe_init: {exc}"
+        got = [None] * self.nranks
+        dist.all_gather_object(got, (handle, err), group=group)
+        self._raise_if_any(got, "hens_pipe_init")
+        try:
+            engine.pipe_connect(b"".join(h for h, _ in got))
+        except Exception as exc:                      # noqa: BLE001
+            err = f"pipe_connect: {exc}"
+        got2 = [None] * self.nranks
+        dist.all_gather_object(got2, (None, err), group=group)     # also the barrier: nobody stores into a mailbox
+        self._raise_if_any(got2, "hens_pipe_connect")               # that is not mapped everywhere yet
+
+    @staticmethod
+    def _raise_if_any(results, what):
+        bad = [(q, e) for q, (_, e) in enumerate(results) if e]
+        if bad:
+            raise RuntimeError(f"ladder pipeline: {what} failed on ranks {[q for q, _ in bad]}: {bad[0][1]}")
 
     def _selftest(self, dist, group, device_id, timeout_s=30.0):
         """hens_pipe_selftest in a throw-away process per rank: a node where peer mappings do not work must show
@@ -322,144 +342,3 @@ class StagedPipeline:
                 else:
                     self.dist.all_reduce(cnt, group=self.group)
             self._t(r.cnt_in, nc, "<i4").copy_(cnt)
-
-
-def bench_sharded(args, gaussian_problem, b_stretch, b_pt, hbm_peak):
-    """N-GPU leg of bench.py: weak scaling, one fixed-size ladder shard per GPU."""
-    import os
-    import time
-
-    import torch
-    import torch.distributed as dist
-
-    from .engine import HipEnsemble
-    from .likelihood import GaussianLikelihood
-    from .moves.tempering import make_ladder
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    force = bool(int(os.environ.get("HENS_FORCE_COLLECTIVES", "0")))
-    # "nccl" = RCCL.  HENS_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): used to
-    # exercise this exact code path on a single-GPU box.
-    backend = os.environ.get("HENS_DIST_BACKEND", "nccl")
-    if (world > 1 or force) and not dist.is_initialized():
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
-    T, W, D = args.ntemps, args.nwalkers, args.ndim
-    _, bounds = rung_partition(T, world)
-    r0, r1 = bounds[rank]
-    mu, invcov = gaussian_problem(D)
-    x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
-
-    mode = os.environ.get("HENS_SHARD_MODE", "pipeline")
-    # With the reference's schedule (delay 0) every rank needs the swap ratios of the WHOLE cascade before its next
-    # accept test, which serialises the ranks; the pipeline's delayed schedule applies them one sweep later.
-    delay = int(os.environ.get("HENS_ADAPT_DELAY", "1")) if (mode == "pipeline" and world > 1 and not force) else 0
-
-    def make_engine(delay=delay):
-        e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=(r0, r1),
-                        device_id=local_rank, adaptation_delay=delay)
-        e.upload(x0, betas=make_ladder(D, ntemps=T))
-        e.eval_state()
-        return e
-
-    eng = make_engine()
-    # Stepping: the ladder pipeline (one-sided neighbour puts over xGMI) unless HENS_SHARD_MODE=collective or
-    # the mailboxes cannot be mapped on this node, in which case every rank falls back to the RCCL
-    # all-gather / all-to-all orchestration.
-    stepper = None
-    if mode == "pipeline" and not force:
-        ok = 1
-        try:
-            stepper = LadderPipeline(eng, rank, world, dist=dist if world > 1 else None, device_id=local_rank)
-        except Exception as exc:                      # noqa: BLE001 - any failure means "use the collective path"
-            print(f"[rank {rank}] ladder pipeline unavailable ({exc}); falling back to RCCL collectives", flush=True)
-            ok = 0
-        if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if not ok:
-            stepper = None
-    transport = ("xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline), ladder adaptation "
-                 + ("on the reference's schedule" if delay == 0 else "applied one sweep late (adaptation_delay=1)"))
-    if stepper is None and mode == "rccl_neighbour" and not force:
-        stepper = StagedPipeline(eng, rank, world, dist, device)
-        transport = "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages)"
-
-    def make_collective(eng):
-        return ShardedLadder(HipShardEngine(eng, device), T, dist=dist if (world > 1 or force) else None, rank=rank,
-                             nranks=world)
-
-    def timed_run(stp, eng):
-        stp.step(args.warmup)
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        stp.step(args.steps)
-        eng.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
-
-    if stepper is None:
-        if delay:
-            eng.close()
-            eng = make_engine(0)
-        stepper = make_collective(eng)
-        transport = "RCCL all-gather(logL) + all-to-all(rows)"
-        dt = timed_run(stepper, eng)
-    else:
-        ok, dt = 1, 0.0
-        try:
-            dt = timed_run(stepper, eng)
-        except RuntimeError as exc:                   # a flag wait timed out: a neighbour never answered
-            print(f"[rank {rank}] ladder pipeline failed ({exc}); re-running on RCCL collectives", flush=True)
-            ok = 0
-        if world > 1:
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if not ok:
-            eng.close()
-            eng = make_engine(0)                      # a fresh context: no mailbox, no pending flags
-            stepper = make_collective(eng)
-            transport = "RCCL all-gather(logL) + all-to-all(rows) (pipeline failed on this node)"
-            dt = timed_run(stepper, eng)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    c = eng.counters()
-    f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps + args.warmup, 1)))
-    value = T * W * args.steps / dt
-    out = None
-    if rank == 0:
-        whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
-        out = {
-            "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Gaussian logL",
-            "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"ladder sharded over {world} GPU(s): ntemps={T} ({T // world} rungs/GPU), nwalkers={W}, "
-                                   f"ndim={D} dense-covariance Gaussian, StretchMove(a=2)+adaptive PT, Philox RNG, "
-                                   f"{transport}",
-                       "ntemps": T, "nwalkers": W, "ndim": D, "parallelism": f"ladder-shard x{world}",
-                       "swap_fraction": f_sw},
-            "roofline": {"bound": "hbm", "kernel": "whole path (per GPU)", "achieved": whole / world, "peak": hbm_peak,
-                         "unit": "GB/s", "frac": whole / world / hbm_peak, "traffic": None},
-        }
-    eng.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
-    return out

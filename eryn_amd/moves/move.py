@@ -8,9 +8,7 @@ class Move:
                  random_seed=None, **kwargs):
         if gibbs_sampling_setup is not None:
             raise NotImplementedError("gibbs sampling is outside the device hot path")
-        if periodic is not None:
-            raise NotImplementedError("periodic parameters are outside the device hot path")
-        self.periodic = None
+        self.periodic = periodic
         self.prevent_swaps = prevent_swaps
         self.is_rj = is_rj
         self.num_proposals = 0
@@ -19,6 +17,17 @@ class Move:
         if random_seed is not None:          # move.py:94-96: seeds the *global* stream
             np.random.seed(random_seed)
         self.temperature_control = temperature_control
+
+    # -- periodic parameters: the reference's sampler assigns this attribute after construction when it was given a
+    #    periodic container (ensemble.py:528-536); the device path has none, so a non-None value must not pass silently
+    @property
+    def periodic(self):
+        return None
+
+    @periodic.setter
+    def periodic(self, periodic):
+        if periodic is not None:
+            raise NotImplementedError("periodic parameters are outside the device hot path")
 
     # -- counters (move.py:404-421) --------------------------------------------------------------
     @property

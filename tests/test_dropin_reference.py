@@ -1,0 +1,170 @@
+"""The HIP-backed move under the REAL reference sampler (build container only; CPU).
+
+``INTEGRATION.md`` section 1 claims ``eryn.ensemble.EnsembleSampler(..., moves=eryn_amd.moves.StretchMove(...))`` is a
+drop-in.  Here the unmodified reference (imported from /root/reference/src, never copied) drives
+``eryn_amd.moves.StretchMove`` / ``GaussianMove`` through ``run_mcmc``: constructor-time attribute injection
+(ensemble.py:517-544), move choice and ``propose`` (:971-984), ``temperature_control.swaps_accepted`` (:977), backend
+``save_step``.  The device context is replaced by a stand-in with the same method surface whose compute is the pinned
+oracle - this container has no GPU, and what is under test is the plugin protocol, not the kernels (those are pinned by
+the -m gpu parity tests).  The chain must equal the fixtures captured from the reference's own StretchMove.
+
+Skipped where /root/reference does not exist (the GPU box)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/src"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree exists in the build container only")
+
+
+@pytest.fixture(scope="module")
+def eryn():
+    for m in ("corner", "seaborn"):            # imported unconditionally by eryn/utils/plot.py
+        sys.modules.setdefault(m, types.ModuleType(m))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    old = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True             # the reference tree is read-only
+    try:
+        import eryn.ensemble
+        import eryn.prior
+    finally:
+        sys.dont_write_bytecode = old
+    return sys.modules["eryn"]
+
+
+class OracleEngine:
+    """Stand-in for eryn_amd.engine.HipEnsemble: the methods the moves call, computed by the oracle."""
+
+    def __init__(self, T, W, D, loglike, lo, hi, a=2.0, adaptive=True, lag=10000, nu=100, stop=-1):
+        from eryn_amd.likelihood import GaussianLikelihood
+        self.T, self.W, self.D, self.Tl = T, W, D, T
+        self.likelihood = GaussianLikelihood(np.zeros(D), np.ones(D))      # only its type matters here
+        self.loglike, self.lo, self.hi, self.a = loglike, np.full(D, lo), np.full(D, hi), a
+        self.adaptive, self.lag, self.nu, self.stop, self.time = adaptive, lag, nu, stop, 0
+        self.calls = []
+
+    def upload(self, x, logl=None, logp=None, betas=None):
+        self.x, self.L, self.P = np.array(x, copy=True), np.array(logl, copy=True), np.array(logp, copy=True)
+        self.betas = None if betas is None else np.array(betas, copy=True)
+        self.calls.append("upload")
+
+    def set_adapt_time(self, t):
+        self.time = int(t)
+
+    def stretch_split(self, split, labels, rint, u_zz, u_acc):
+        from oracle import eryn_oracle as orc
+        out = orc.stretch_split(self.x, self.L, self.P, self.betas, np.asarray(labels), split, rint, u_zz, u_acc, self.a,
+                                self.lo, self.hi, self.loglike)
+        return out["keep"]
+
+    def mh_step(self, step, u_acc):
+        from oracle import eryn_oracle as orc
+        return orc.mh_step(self.x, self.L, self.P, self.betas, np.asarray(step), np.asarray(u_acc), self.lo, self.hi,
+                           self.loglike)["keep"]
+
+    def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
+        from oracle import eryn_oracle as orc
+        sel, sw = orc.pt_sweep(self.x, self.L, self.P, self.betas, iperm, i1perm, u_swap)
+        if adapt and self.adaptive:
+            if self.stop < 0 or self.time < self.stop:
+                self.betas = orc.adapt_ladder(self.betas, sw, self.W, self.time, self.lag, self.nu)
+            self.time += 1
+        return sel, sw
+
+    def download(self, want_x=True):
+        return self.x.copy(), self.L.copy(), self.P.copy(), None if self.betas is None else self.betas.copy()
+
+
+def _fixture(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+def _loglike(x, mu, invcov):                   # tests/test_eryn.py:33-35, batched
+    diff = x - mu
+    return -0.5 * (diff * np.dot(invcov, diff.T).T).sum(axis=1)
+
+
+def _reference_sampler(eryn, fx, move, **kw):
+    from eryn.ensemble import EnsembleSampler
+    from eryn.prior import ProbDistContainer, uniform_dist
+    T, W, D, box = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"])
+    np.random.seed(int(fx["seed_construct"]))  # R := snapshot of the global stream at construction
+    priors = ProbDistContainer({i: uniform_dist(-box, box) for i in range(D)})
+    if T > 1:
+        kw["tempering_kwargs"] = dict(ntemps=T)
+    return EnsembleSampler(W, D, _loglike, priors, args=[fx["mu"], fx["invcov"]], vectorize=True, moves=move, **kw)
+
+
+@pytest.mark.parametrize("name", ["f2_pt", "f3_oddW", "f4_narrowbox"])
+def test_hip_stretch_move_under_the_real_sampler_reproduces_the_fixture(eryn, golden_dir, name):
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import StretchMove
+    fx = _fixture(golden_dir, name)
+    T, W, D, box, n = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"]), int(fx["nsteps"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    move = StretchMove(a=float(fx["a"]), likelihood=GaussianLikelihood(mu, invcov), prior_box=(-box, box))
+    eng = OracleEngine(T, W, D, lambda x: _loglike(x, mu, invcov), -box, box, a=float(fx["a"]))
+    move.attach_engine(eng)
+    s = _reference_sampler(eryn, fx, move)
+    # what the constructor injected (ensemble.py:517-544)
+    assert move.temperature_control is s.temperature_control and move.ntemps == T
+    assert move.accepted.shape == (T, W) and move.periodic is None
+    np.random.seed(int(fx["seed_run"]))
+    state = s.run_mcmc(fx["x0"], n, store=True)
+    last = f"it{n - 1}_"
+    assert np.array_equal(state.branches["model_0"].coords[:, :, 0, :], fx[last + "x"])
+    assert np.array_equal(state.log_like, fx[last + "L"]) and np.array_equal(state.log_prior, fx[last + "P"])
+    assert np.array_equal(state.betas, fx[last + "betas"])
+    assert np.array_equal(s.temperature_control.betas, fx[last + "betas"])
+    assert np.array_equal(s.temperature_control.swaps_accepted, fx[last + "swaps_accepted"])
+    assert np.array_equal(move.accepted, fx["accepted_total"]) and move.num_proposals == int(fx["num_proposals"])
+    # the reference's backend stored the chain the move produced (backend.py:1014-1091)
+    chain = s.get_chain()["model_0"]
+    assert chain.shape == (n, T, W, 1, D)
+    for it in (0, n // 2, n - 1):
+        assert np.array_equal(chain[it][:, :, 0, :], fx[f"it{it}_x"])
+    assert np.array_equal(s.backend.accepted, fx["accepted_total"])
+    assert "upload" in eng.calls
+
+
+def test_hip_move_mix_under_the_real_sampler(eryn, golden_dir):
+    """StretchMove + GaussianMove by weight (ensemble.py:971): the m6 fixture was captured from the reference's own moves"""
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import GaussianMove, StretchMove
+    fx = _fixture(golden_dir, "m6_mix")
+    T, W, D, box, n = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"]), int(fx["nsteps"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    like = GaussianLikelihood(mu, invcov)
+    eng = OracleEngine(T, W, D, lambda x: _loglike(x, mu, invcov), -box, box)
+    assert str(fx["move0_kind"]) == "stretch" and str(fx["move1_kind"]) == "gauss" and str(fx["move1_mode"]) == "vector"
+    mvs = [(StretchMove(likelihood=like, prior_box=(-box, box)), float(fx["weights"][0])),
+           (GaussianMove({"model_0": float(fx["move1_cov"])}, likelihood=like, prior_box=(-box, box)), float(fx["weights"][1]))]
+    for m, _ in mvs:
+        m.attach_engine(eng)
+    s = _reference_sampler(eryn, fx, mvs)
+    np.random.seed(int(fx["seed_run"]))
+    state = s.run_mcmc(fx["x0"], n, store=False)
+    last = f"it{n - 1}_"
+    assert np.array_equal(state.branches["model_0"].coords[:, :, 0, :], fx[last + "x"])
+    assert np.array_equal(state.log_like, fx[last + "L"])
+    assert np.array_equal(mvs[0][0].accepted, fx["move0_accepted"]) and mvs[0][0].num_proposals == int(fx["move0_num_proposals"])
+    assert np.array_equal(mvs[1][0].accepted, fx["move1_accepted"]) and mvs[1][0].num_proposals == int(fx["move1_num_proposals"])
+
+
+def test_unsupported_injections_fail_loudly(eryn, golden_dir):
+    """The real sampler assigns move.periodic after construction (ensemble.py:528-536): the device path has no periodic
+    parameters, so the assignment itself must raise instead of being ignored."""
+    from eryn.utils import PeriodicContainer
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import StretchMove
+    fx = _fixture(golden_dir, "f2_pt")
+    box = float(fx["box"])
+    move = StretchMove(likelihood=GaussianLikelihood(fx["mu"], fx["invcov"]), prior_box=(-box, box))
+    with pytest.raises(NotImplementedError):
+        _reference_sampler(eryn, fx, move, periodic=PeriodicContainer({"model_0": {0: 2 * np.pi}}))
+    move.periodic = None                       # the no-op assignment stays legal

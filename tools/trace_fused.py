@@ -1,0 +1,39 @@
+"""Debug: per-phase timing of the fused half-step + cascade kernel (k_split1_pt) from in-kernel s_memtime stamps."""
+import ctypes as C
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from tools.quick_bench import problem, ladder
+from eryn_amd.engine import HipEnsemble
+from eryn_amd.likelihood import GaussianLikelihood
+from eryn_amd import _lib
+
+T, W, D = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (16, 4096, 32)))
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 3          # 3: fused kernel, 1: first half-step kernel
+mu, invcov, cov = problem(D)
+eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024)
+eng.upload(np.random.RandomState(1).randn(T, W, D), betas=ladder(D, T))
+eng.eval_state()
+eng.step(200)
+eng.synchronize()
+_lib.check(eng.lib.hens_debug_trace(eng.ctx, mode, None, 0, None), eng.ctx)
+eng.step(2)
+eng.synchronize()
+n = T * ((W + 63) // 64) * 8
+out = np.zeros(n, dtype=np.uint64)
+nout = C.c_int64(0)
+_lib.check(eng.lib.hens_debug_trace(eng.ctx, 0, _lib.ptr(out), n, C.byref(nout)), eng.ctx)
+tr = out.reshape(-1, 8).astype(np.int64)
+tr = tr[(tr[:, 0] > 0) & (tr[:, 7] > 0)]
+t0 = tr[:, 0].min()
+names = ["start", "A done", "bar1", "B done", "C done", "D done", "F done", "end"] if mode == 3 else \
+        ["start", "A done", "bar1", "B done", "bar2", "C done", "D done", "end"]
+print("workgroups traced:", len(tr), " kernel span ticks (100 MHz):", tr[:, 7].max() - t0)
+for i, nm in enumerate(names):
+    rel = tr[:, i] - t0
+    print(f"{nm:8s} mean {rel.mean():9.1f}  min {rel.min():7d}  max {rel.max():7d}")
+d = np.diff(tr, axis=1)
+print("phase durations mean:", dict(zip(names[1:], np.round(d.mean(0), 1))))
+print("wg lifetime mean", (tr[:, 7] - tr[:, 0]).mean(), "start spread", tr[:, 0].max() - t0)
