@@ -329,6 +329,10 @@ def run_sharded(args):
                                        "(not the reference's schedule; lets the ranks pipeline)"}
                 d[0].close()
     if result is None:
+        if backend != "nccl":
+            raise SystemExit("bench.py: the ladder pipeline did not come up in this dry run (ranks that share ONE GPU can "
+                             "starve each other's flag waits at full shard size: use small --ntemps/--nwalkers/--ndim); the "
+                             "RCCL fallback needs the nccl backend")
         eng, times, transport = fallback_run()
     else:
         eng, times = result

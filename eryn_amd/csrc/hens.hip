@@ -24,6 +24,7 @@ thread_local std::string g_last_error;
 struct DrawBuf {                     // one batch of planned iterations
     Draws d{};
     DrawRec* rec = nullptr;          // the same draws by walker id (fused second half-step + cascade launch)
+    uint32_t* keys = nullptr;        // [NB][T][8] round keys of the cascade's column maps
 };
 
 struct hens_ctx_impl {
@@ -55,7 +56,8 @@ struct hens_ctx_impl {
     double* ad_ring = nullptr;       // [4][T] new ladders published by the adapting workgroup (fold mode 2), -1 = not yet
     uint32_t ad_serial = 0;
     int label_cb = 0, label_cb_shift = 0;   // block-balanced split labels: cascade columns per block (0 = legacy labels)
-    uint32_t* swap_acc = nullptr;    // [SWAP_ACC_ROWS][T-1] swap counts accumulated by k_split1_pt
+    uint32_t* swap_acc[2] = {nullptr, nullptr};   // [SWAP_ACC_ROWS][T-1] swap counts accumulated by k_split1_pt, by sweep parity
+    int acc_cur = 0;                 // buffer the NEXT fused launch accumulates into (the other one is clean or being read)
 
     // model
     double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr; double* prec_sym = nullptr;
@@ -215,10 +217,10 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
             }                                                                                      \
         }                                                                                          \
         if (c->ext_start)                                                                          \
-            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
+            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(stretch_fast_waves(DT, NW, PIPE) * 64), (uint32_t)lds, c->stream, \
                                   c->ext_start, c->ext_stop, 0, a);                                \
         else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), lds, c->stream, a); \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(stretch_fast_waves(DT, NW, PIPE) * 64), lds, c->stream, a); \
     } while (0)
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \
@@ -337,15 +339,22 @@ AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* 
     a.lag = c->cfg.adaptation_lag; a.nu = c->cfg.adaptation_time;
     a.time = c->adapt_time;
     a.T = c->T; a.W = c->W; a.nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
-    a.zero_after = (c->adapt_src != nullptr && c->adapt_src == c->swap_acc) ? 1 : 0;
+    a.zero_after = 0;
+    a.zero_rows = nullptr;
     a.moving = (adaptive && (c->cfg.stop_adaptation < 0 || c->adapt_time < c->cfg.stop_adaptation)) ? 1 : 0;
     return a;
 }
 
+bool is_acc_buffer(const hens_ctx_impl* c, const uint32_t* p) { return p && (p == c->swap_acc[0] || p == c->swap_acc[1]); }
+
 // reduce the pending cascade's swap counts and adapt the ladder as a kernel of its own
 void flush_adapt(hens_ctx_impl* c) {
     if (!c->adapt_pending) return;
-    const AdaptArgs a = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur]);
+    AdaptArgs a = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur]);
+    if (is_acc_buffer(c, c->adapt_src)) {            // a one-workgroup kernel, nothing else running: clear both buffers
+        a.zero_after = 1;
+        a.zero_rows = c->swap_acc[c->adapt_src == c->swap_acc[0] ? 1 : 0];
+    }
     hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), (size_t)c->T * 28 + 16, c->stream, a);
     if (c->adapt_pending_adaptive) c->adapt_time += 1;               // tempering.py:596
     c->adapt_pending = false;
@@ -365,7 +374,6 @@ int fold_mode(const hens_ctx_impl*) {
 bool can_fold_adapt(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FOLD") != nullptr;
     if (off || !c->adapt_pending || !fast_path(c) || c->T > 128) return false;
-    if (c->adapt_src && c->adapt_src == c->swap_acc && fold_mode(c) != 2) return false;   // ONE reader clears the rows
     const int nw = fast_nw(c->D);
     const int64_t nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     return nw >= 2 && nblocks * (c->T - 1) <= (int64_t)8 * nw * 64;
@@ -597,7 +605,7 @@ void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int
     pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
     pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin;
     pa.idx_bits = c->idx_bits;
-    pa.T = c->T; pa.cb = c->label_cb; pa.rec = c->db[which].rec;
+    pa.T = c->T; pa.cb = c->label_cb; pa.rec = c->db[which].rec; pa.keys = c->db[which].keys;
     hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
 }
 
@@ -636,12 +644,17 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
     if (can_fold_adapt(c)) {
         // the previous cascade's ladder adaptation rides in this launch: every workgroup reads
         // the old ladder, workgroup (0,0) writes the new one into the other buffer
-        a.ad_on = fold_mode(c);
+        // counts accumulated by the fused launch (a handful of rows): EVERY workgroup's second wave adapts the ladder from
+        // them while its first wave fetches indices - no hand-off between workgroups (a ring published by one workgroup
+        // reaches the others' accept phase ~5 us late under the row-gather load); other sources: one workgroup + ring
+        const bool acc = is_acc_buffer(c, c->adapt_src);
+        a.ad_on = acc ? 1 : fold_mode(c);
         if (a.ad_on == 2) {
             a.ad_ring = c->ad_ring;
             a.ad_serial = c->ad_serial++;
         }
         a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
+        if (acc) a.ad.zero_rows = c->swap_acc[c->adapt_src == c->swap_acc[0] ? 1 : 0];
         a.betas = c->betas[c->bcur];
         if (c->adapt_pending_adaptive) c->adapt_time += 1;
         c->adapt_pending = false;
@@ -766,8 +779,9 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.locnew = c->loc[c->cur ^ 1]; f.Lnew = c->L[c->cur ^ 1]; f.Pnew = c->P[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
     f.rec = c->db[which].rec + (size_t)ib * T * W;
+    f.keys = c->db[which].keys + (size_t)ib * T * 8;
     f.accepted = c->accepted;
-    f.swap_acc = c->swap_acc;
+    f.swap_acc = c->swap_acc[c->acc_cur];
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
     f.flags = c->flags;
     f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
@@ -793,8 +807,9 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     c->cur ^= 1;
     c->adapt_pending = true;
     c->adapt_pending_adaptive = c->cfg.adaptive != 0;
-    c->adapt_src = c->swap_acc;                    // SWAP_ACC_ROWS rows, cleared by whoever reduces them
+    c->adapt_src = c->swap_acc[c->acc_cur];        // SWAP_ACC_ROWS rows; the next launch's adaptation clears the other buffer
     c->adapt_nblocks = SWAP_ACC_ROWS;
+    c->acc_cur ^= 1;
     return HENS_OK;
 }
 
@@ -979,8 +994,10 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
             while ((1 << c->label_cb_shift) < cb) c->label_cb_shift++;
         }
     }
-    TRY(dalloc(c, &c->swap_acc, (size_t)SWAP_ACC_ROWS * c->T));
-    TRYHIP(hipMemsetAsync(c->swap_acc, 0, (size_t)SWAP_ACC_ROWS * c->T * 4, c->stream));
+    for (int b = 0; b < 2; ++b) {
+        TRY(dalloc(c, &c->swap_acc[b], (size_t)SWAP_ACC_ROWS * c->T));
+        TRYHIP(hipMemsetAsync(c->swap_acc[b], 0, (size_t)SWAP_ACC_ROWS * c->T * 4, c->stream));
+    }
     {
         const size_t per_iter = TW * 64;
         size_t nb = (96u << 20) / std::max<size_t>(per_iter, 1);
@@ -996,6 +1013,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->db[b].d.fac, n));
         TRY(dalloc(c, &c->db[b].d.lu, n));
         TRY(dalloc(c, &c->db[b].rec, n));
+        TRY(dalloc(c, &c->db[b].keys, (size_t)c->NB * c->T * 8));
         TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
     }

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hens {
 
@@ -227,6 +228,8 @@ __device__ __forceinline__ bool pipe_last_ticket(unsigned* ticket, uint32_t targ
 // instead of hanging the GPU); callers follow with __syncthreads()
 __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, long long budget, unsigned* err,
                                           unsigned long long* stats = nullptr) {
+    // the wall clock (s_memrealtime) takes ~1.5 us to read: start it only if the flag is not there yet
+    if (!stats && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= target) return;
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
         __builtin_amdgcn_s_sleep(2);
@@ -251,7 +254,7 @@ __device__ __forceinline__ bool pipe_arrive_collect(unsigned* ticket, unsigned n
     __syncthreads();
     if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (blockIdx.x != 0) return false;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nblocks * (sweep + 1u)) {
         const unsigned target = nblocks * (sweep + 1u);              // cumulative over the sweeps (mod 2^32)
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
@@ -298,12 +301,21 @@ __device__ __forceinline__ void make_draw(const Draws& d, size_t idx, int own, i
     d.lu[idx] = log(ua);                           // red_blue.py:294
 }
 
+// value of x in lane l, l wave-uniform (v_readlane: a few cycles; __shfl with a runtime lane is a ds_bpermute, ~100)
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ladder adaptation (tempering.py:563-596) from the per-workgroup swap counts of the cascade.
 // ---------------------------------------------------------------------------------------------
 struct AdaptArgs {
     uint32_t* swap_part;        // [nblocks][T-1] per-workgroup swap counts of the last cascade
-    int32_t zero_after;         // the rows are accumulated with atomics (k_split1_pt): the reader clears them
+    int32_t zero_after;         // the rows are accumulated with atomics (k_split1_pt): the (single) reader clears them
+    uint32_t* zero_rows;        // rows to clear besides (the OTHER accumulation buffer: nobody reads or writes it during
+                                // this launch), nblocks * (T-1) words, or nullptr
     const double* betas_in;     // [T]
     double* betas_out;          // [T] (may alias betas_in when run as its own kernel)
     double* swaps_last;         // [T-1]
@@ -829,8 +841,19 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 // ---------------------------------------------------------------------------------------------
 // PIPE: the context is a rank of the ladder pipeline (guest rows, flag waits, boundary-rung publishing);
 // compiled out of the single-GPU instantiation, where those hooks cost ~6 % at config 2.
+// Extra wave (XW): outside the pipeline a workgroup carries one more wavefront than its NW working ones.  It takes no
+// part in the row phases (it only joins the barriers); when every workgroup adapts the ladder for itself (ad_defer) it
+// runs that ~4000-cycle FP64 chain while the working waves wait for their row gathers, so the adaptation is off every
+// working wave's path.
+// Two 9-wave workgroups per CU put 5 waves on a SIMD, so the kernel must stay within 512 / 5 -> 96 VGPRs (the second
+// launch-bounds argument); the wider rows (D >= 64) need more registers than that and keep 8 waves.
+// (measured: a 9-wave workgroup does not pack two per CU - the dispatcher wants 3 of its waves on one SIMD twice - and
+// one workgroup per CU costs more than the adaptation saved, so no instantiation uses the extra wave at present)
+__host__ __device__ constexpr int stretch_fast_waves(int DT, int NW, bool PIPE) { return NW + 0 * (DT + (PIPE ? 1 : 0)); }
+__host__ __device__ constexpr int stretch_fast_min_waves(int DT, int NW, bool PIPE) { return stretch_fast_waves(DT, NW, PIPE) > NW ? 5 : 1; }
+
 template <int DT, int LIKE, int MODE, int NW, bool PIPE>
-__global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
+__global__ __launch_bounds__(stretch_fast_waves(DT, NW, PIPE) * 64, stretch_fast_min_waves(DT, NW, PIPE)) void k_stretch_fast(const StretchArgs A) {
     constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -854,6 +877,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool XW = stretch_fast_waves(DT, NW, PIPE) > NW;
+    constexpr int ADW = XW ? NW : 1;            // the wave that runs the early ladder adaptation
+    const bool work = !XW || wv < NW;           // false in the extra wave
     const int tl = blockIdx.y;
     const int W = A.W;
     const int Ns = (EVAL || MH) ? W : (A.split == 0 ? A.N0 : W - A.N0);
@@ -899,7 +925,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             }
             double cs0 = 0.0, cs1 = 0.0;                                           // np.cumsum: left-to-right
             for (int i = 0; i + 2 < T; ++i) {
-                const double v = i < 64 ? __shfl(dT0, i) : __shfl(dT1, i - 64);
+                const double v = i < 64 ? readlane_f64(dT0, i) : readlane_f64(dT1, i - 64);
                 if (i == 0) { cs0 = v; cs1 = v; }
                 else {
                     if (i <= e0) cs0 = cs0 + v;
@@ -943,16 +969,51 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 
     // The counts are already reduced (one row: a pipeline rank's mailbox): wave 1 of the adapting workgroup
     // adapts right away, while wave 0 fetches the draws, so the new ladder is in the ring long before anyone asks.
-    const bool ad_early = ad_here && ad_lead && A.ad.nblocks == 1;
+    const bool ad_early = ad_here && A.ad.nblocks <= 8;
     // the same workgroup pushes the last sweep's swap counts to every rank (uses the count-reduction machinery below,
     // which a pipeline rank's adaptation - counts already reduced - leaves idle)
     const bool cnt_push = PIPE && !EVAL && NW >= 2 && A.cnt_push && blockIdx.x == 0 && blockIdx.y == 0;
     const bool red_on = (ad_here && !ad_early) || cnt_push;
-    if (ad_early && wv == 1) {
-        const int T = A.ad.T;
-        const double c0 = (lane < T - 1) ? (double)A.ad.swap_part[lane] : 0.0;
-        const double c1 = (lane + 64 < T - 1) ? (double)A.ad.swap_part[lane + 64] : 0.0;
-        adapt_publish(c0, c1, lane < T ? A.ad.betas_in[lane] : 1.0, lane + 64 < T ? A.ad.betas_in[lane + 64] : 1.0);
+    // a handful of rows (one: a pipeline rank's mailbox; SWAP_ACC_ROWS: the fused half-step + cascade launch, which
+    // accumulates them with atomics): all loads in flight at once, no LDS, no barrier.  The adaptation itself is a
+    // ~4000-cycle dependent chain of FP64 divides and exps on one wave: a rank of the pipeline runs it right away (its
+    // ring feeds the other workgroups), otherwise (every workgroup adapts for itself) the wave issues its row gathers
+    // first and adapts while they are in flight.
+    unsigned ad_u0[8], ad_u1[8];
+    double ad_bi0 = 1.0, ad_bi1 = 1.0;
+    const bool ad_defer = ad_early && !PIPE && !ad_lead;
+    auto adapt_early = [&]() {
+        const int T = A.ad.T, NR = A.ad.nblocks;
+        unsigned s0 = 0, s1 = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { s0 += ad_u0[r]; s1 += ad_u1[r]; }
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (A.ad.zero_after) {                   // sole reader (mode 2 / a pipeline rank): clear what was read
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r < NR && lane < T - 1 && ad_u0[r]) A.ad.swap_part[(size_t)r * (T - 1) + lane] = 0u;
+                    if (r < NR && lane + 64 < T - 1 && ad_u1[r]) A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] = 0u;
+                }
+            }
+            if (A.ad.zero_rows)                      // every workgroup reads the rows: clear the buffer of the NEXT sweep
+                for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
+        }
+        adapt_publish((double)s0, (double)s1, ad_bi0, ad_bi1);
+    };
+    if (ad_early && wv == ADW) {
+        const int T = A.ad.T, NR = A.ad.nblocks;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            ad_u0[r] = (r < NR && lane < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane] : 0u;
+            ad_u1[r] = (r < NR && lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
+        }
+        if (lane < T) ad_bi0 = A.ad.betas_in[lane];
+        if (lane + 64 < T) ad_bi1 = A.ad.betas_in[lane + 64];
+        // Wait for these loads HERE (the wave has nothing else to do before the first barrier), with the builtin the
+        // compiler's wait-count pass understands: otherwise it guards the deferred computation with a wait that also
+        // covers the row gathers issued in between, and the adaptation no longer overlaps them.
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
+        if (!ad_defer) adapt_early();
     }
 
     // ---- phase A (wave 0): indices and draws -------------------------------------------------------
@@ -1014,7 +1075,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
-        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
+        rv[p] = work && (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
@@ -1034,6 +1095,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
+    if (ad_defer && wv == ADW) adapt_early();      // the working waves' row gathers are in flight
     unsigned adv[8];
     double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
     if (red_on) {                                  // the cascade's per-workgroup swap counts: <= 8 per thread
@@ -1042,13 +1104,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + q * NT;
-            adv[q] = (e < total) ? rows[e] : 0u;
+            adv[q] = (work && e < total) ? rows[e] : 0u;
         }
         if (!cnt_push && A.ad.zero_after) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int e = tid + q * NT;
-                if (e < total && adv[q]) A.ad.swap_part[e] = 0u;
+                if (work && e < total && adv[q]) A.ad.swap_part[e] = 0u;
             }
         }
         if (!cnt_push && wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
@@ -1131,8 +1193,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        const double part = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
-        s_part[wv * TILE + lane] = part;
+        if (work) {
+            const double part = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+            s_part[wv * TILE + lane] = part;
+        }
     }
     HENS_TRACE(5);
     lds_barrier();
@@ -1158,11 +1222,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (A.tempered) {                                  // tempering.py:304-306,343-349
                 double beta = beta_pre;
                 if (ad_lead) {                                 // workgroup (0,0) may still be adapting: wait for the value
-                    const long long t0 = wall_clock64();
-                    while (beta_ring < 0.0) {
-                        __builtin_amdgcn_s_sleep(1);
-                        beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (wall_clock64() - t0 > 200000000LL) { atomicOr(A.flags, FLAG_PIPE_TIMEOUT); break; }
+                    if (beta_ring < 0.0) {                     // (rare; reading the wall clock costs ~1.5 us: only when waiting)
+                        const long long t0 = wall_clock64();
+                        while (beta_ring < 0.0) {
+                            __builtin_amdgcn_s_sleep(1);
+                            beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (wall_clock64() - t0 > 200000000LL) { atomicOr(A.flags, FLAG_PIPE_TIMEOUT); break; }
+                        }
                     }
                     beta = beta_ring;
                 } else if (ad_on) {
@@ -1332,6 +1398,7 @@ struct PlanArgs {
     int32_t Tl, W, D, rung_begin, idx_bits;
     int32_t T, cb;        // cb > 0: block-balanced labelling with cb columns per block (see block_rank); 0: label = prp >= N0
     DrawRec* rec;         // [NB][Tl][W] the draws by walker id, or nullptr
+    uint32_t* keys;       // [NB][T][8] round keys of every rung's cascade column map (cb > 0), or nullptr
     double* dbg_uzz;      // debug (hens_debug_draws): the raw uniforms behind zz / lu, [NB][Tl][W], or nullptr
     double* dbg_uacc;
 };
@@ -1383,6 +1450,7 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) key[r] = skey[r];
     if (A.cb) {
+        if (A.keys && tid < 8) A.keys[((size_t)ib * A.T + rung) * 8 + tid] = key[tid];
         for (int i = tid; i < W; i += nt) lab[i] = (uint8_t)block_label_of_walker(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
     } else {
         for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 1 : 0;
@@ -1642,7 +1710,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
 //   G  thread per slot : permuted L / P / loc into the next buffers; swap counts by atomics into
 //                        SWAP_ACC_ROWS rows (the adapting workgroup of the next launch reduces and clears them)
 // ---------------------------------------------------------------------------------------------
-constexpr int SWAP_ACC_ROWS = 64;
+constexpr int SWAP_ACC_ROWS = 8;       // <= 8: the adapting workgroup sums them straight out of memory (ad_early)
 
 struct FusedArgs {
     double* pool;
@@ -1650,6 +1718,7 @@ struct FusedArgs {
     int32_t* locnew; double* Lnew; double* Pnew;              // next buffers: after the cascade
     const double* betas;                                      // [T]
     const DrawRec* rec;                                       // [T][W] this iteration's draws by walker id
+    const uint32_t* keys;                                     // [T][8] round keys of the rungs' column maps (from the plan)
     uint32_t* accepted;                                       // [T][W]
     uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
@@ -1670,7 +1739,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
     constexpr int NE = 2 * TILE;
-    static_assert(NT >= NE, "one thread per slot");
+    static_assert(NT >= 2 * NE, "one thread per slot + one per cascade uniform");
+    constexpr bool WIDE = NT >= 2 * NE + 64;              // a further wave for the ladder, else the slot threads fetch it
     double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
     double* s_part = qtile + TILE * RS;                                  // [NW][TILE]
     double* s_zz = s_part + NW * TILE;                                   // [TILE] per moving walker
@@ -1701,18 +1771,24 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     FUSED_TRACE(0);
 
     // ---- phase A: one thread per slot ----------------------------------------------------------------------
+    // The critical chain is key -> slot -> {loc, L, P, draw record} -> rows.  The round keys come from the plan (a
+    // 32-byte load that hits L2 after the first workgroup of an XCD; two Philox calls in place cost 3x as long on the
+    // two waves that run this phase), every load that hangs off the slot is issued before anything else is computed,
+    // and the label rank and the cascade's log-uniforms are computed while those loads are in flight.
     if (tid < NE) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
-        const PrpKey K = prp_key(A.seed, A.iter, PURPOSE_PTPERM, (uint32_t)t);
-        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, K.k, A.idx_bits, (uint32_t)W);
+        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
+        const uint4 ka = kp[0], kb = kp[1];
+        const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
         const size_t gi = (size_t)t * W + slot;
         const int32_t loc_e = A.loc[gi];
         const double L_e = A.L[gi], P_e = A.P[gi];
-        const int rank = block_rank(K.k, c, CB);
+        const DrawRec rc = A.rec[gi];                                    // used by the moving walkers only (32 B)
+        const int rank = block_rank(key, c, CB);
         const bool member = rank >= (CB >> 1);
         scol[e] = slot;
         if (member) {
-            const DrawRec rc = A.rec[gi];
             const int m = t * (CB >> 1) + rank - (CB >> 1);              // 0 .. 63, each exactly once
             s_rs[m] = loc_e;
             s_rc[m] = A.home_off + t * W + rc.cw;                        // its complement moved in the first half-step: at home
@@ -1724,8 +1800,14 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         } else {
             Lc[e] = L_e; Pc[e] = P_e; locc[e] = loc_e;
         }
+        if (!WIDE && e < T) sbeta[e] = A.betas[e];
+    } else if (tid < 2 * NE) {
+        // the cascade's log-uniforms (a Philox call and a log per element: ~1700 cycles of dependent ALU) on the two
+        // waves that would otherwise idle until the barrier, not in the shadow of the slot chain above
+        const int e = tid - NE, t = e >> CS, c = c0 + (e & (CB - 1));
         if (t < T - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, t, W, c));   // tempering.py:535 (row j = t: pair T-1-t)
-        if (e < T) sbeta[e] = A.betas[e];
+    } else if (WIDE && tid < 2 * NE + 64) {
+        if (lane < T) sbeta[lane] = A.betas[lane];
     }
     FUSED_TRACE(1);
     lds_barrier();
@@ -1819,28 +1901,23 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     FUSED_TRACE(5);
     lds_barrier();
 
-    // ---- phase E: accepted rows only -------------------------------------------------------------------------
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        if (!rv[p]) continue;
-        if ((s_flag[r] & 2) == 0) continue;
-        const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-        store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, qv);
-    }
-
     // ---- phase F: one lane per column walks hot -> cold (tempering.py:515-541) ---------------------------------
-    if (wv == (NW > 1 ? 1 : 0) && lane < CB) {
+    // (a serial chain of T-1 compare / select steps; with the ladder length a compile-time constant every LDS address
+    // is an immediate and the loop is straight-line code)
+    auto walk = [&](auto tt) {
+        constexpr int TT = decltype(tt)::value;                          // 0: runtime ladder length
+        const int Tn = TT ? TT : T;
         const int cc = lane;
-        double cL = Lc[(size_t)(T - 1) * CB + cc];
+        double cL = Lc[((Tn - 1) << CS) + cc];
         uint32_t m = 0;
-        for (int i0 = T - 1; i0 >= 1; i0 -= 8) {
+#pragma unroll
+        for (int i0 = Tn - 1; i0 >= 1; i0 -= 8) {
             double Lb[8], lv[8], db[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int i = (i0 - q >= 1) ? i0 - q : 1;
-                Lb[q] = Lc[(size_t)(i - 1) * CB + cc];
-                lv[q] = lupt[(size_t)(T - 1 - i) * CB + cc];
+                Lb[q] = Lc[((i - 1) << CS) + cc];
+                lv[q] = lupt[((Tn - 1 - i) << CS) + cc];
                 db[q] = sbeta[i - 1] - sbeta[i];                         // tempering.py:518-522
             }
 #pragma unroll
@@ -1858,22 +1935,32 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
                 }
             }
         }
+    };
+    if (wv == (NW > 1 ? 1 : 0) && lane < CB) {
+        if (T == 16) walk(std::integral_constant<int, 16>{});
+        else if (T == 8) walk(std::integral_constant<int, 8>{});
+        else if (T == 32) walk(std::integral_constant<int, 32>{});
+        else walk(std::integral_constant<int, 0>{});
     }
-    FUSED_TRACE(6);
     lds_barrier();
+    FUSED_TRACE(6);
 
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
     if (tid < NE) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1);
         int st;
-        if (bit(cc, t)) {
+        if (MW == 1) {                                            // T <= 32: the whole column mask in one register
+            const uint32_t mw = smask[cc];
+            if ((mw >> t) & 1u) st = t - 1;                       // bit 0 is never set
+            else st = t + __builtin_ctz(~(mw >> 1 >> t));         // consecutive swapped pairs directly above
+        } else if (bit(cc, t)) {
             st = t - 1;
         } else {
             st = t;
             while (bit(cc, st + 1)) ++st;
         }
-        const int se = st * CB + cc;
+        const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
         A.Lnew[di] = Lc[se];
         A.Pnew[di] = Pc[se];
@@ -1884,6 +1971,16 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (SWAP_ACC_ROWS - 1)) * (T - 1) + (i - 1)], n);
     }
+    // ---- phase E (last: nothing waits behind these stores): accepted rows only -------------------------------------
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int r = p * RPP + rsub;
+        if (!rv[p]) continue;
+        if ((s_flag[r] & 2) == 0) continue;
+        const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+        store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, qv);
+    }
+
     FUSED_TRACE(7);
 #undef FUSED_TRACE
 }
@@ -1952,6 +2049,8 @@ __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
         }
         __syncthreads();
     }
+    if (A.zero_rows)
+        for (int e = tid; e < total; e += NTHREADS) A.zero_rows[e] = 0u;
     for (int j = tid; j < T; j += NTHREADS) {
         A.betas_out[j] = bnew[j];
         if (j < T - 1) {

@@ -25,8 +25,10 @@ n = T * ((W + 63) // 64) * 8
 out = np.zeros(n, dtype=np.uint64)
 nout = C.c_int64(0)
 _lib.check(eng.lib.hens_debug_trace(eng.ctx, 0, _lib.ptr(out), n, C.byref(nout)), eng.ctx)
-tr = out.reshape(-1, 8).astype(np.int64)
-tr = tr[(tr[:, 0] > 0) & (tr[:, 7] > 0)]
+tr_all = out.reshape(-1, 8).astype(np.int64)
+ok = (tr_all[:, 0] > 0) & (tr_all[:, 7] > 0)
+tr = tr_all[ok]
+wg = np.flatnonzero(ok)
 t0 = tr[:, 0].min()
 names = ["start", "A done", "bar1", "B done", "C done", "D done", "F done", "end"] if mode == 3 else \
         ["start", "A done", "bar1", "B done", "bar2", "C done", "D done", "end"]
@@ -37,3 +39,19 @@ for i, nm in enumerate(names):
 d = np.diff(tr, axis=1)
 print("phase durations mean:", dict(zip(names[1:], np.round(d.mean(0), 1))))
 print("wg lifetime mean", (tr[:, 7] - tr[:, 0]).mean(), "start spread", tr[:, 0].max() - t0)
+
+print("percentiles (10/50/90/99/max) per phase:")
+for i, nm in enumerate(names[1:]):
+    print(f"  {nm:8s}", np.percentile(d[:, i], [10, 50, 90, 99, 100]).astype(int))
+life = tr[:, 7] - tr[:, 0]
+print("lifetime percentiles:", np.percentile(life, [10, 50, 90, 99, 100]).astype(int))
+# the launch as seen from the first workgroup's start (drop the other iteration's stamps: keep the later launch)
+late = tr[:, 0] > np.median(tr[:, 0]) if (tr[:, 0].max() - tr[:, 0].min()) > 10 * life.max() else np.ones(len(tr), bool)
+tl = tr[late]
+print("later launch: workgroups", len(tl), " span start->last end", tl[:, 7].max() - tl[:, 0].min(), " start spread", tl[:, 0].max() - tl[:, 0].min())
+k = 6 if mode == 1 else 6
+print("phase index", k, "duration by XCD (wg % 8):", [float(np.round(np.nan_to_num(d[late][(wg[late] % 8) == x, k - 1].mean()))) for x in range(8)])
+print("first 8 workgroups, phase durations:")
+print(d[late][:8])
+
+
