@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Golden fixtures for the reversible-jump leaf-packing path from the REAL reference.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_rj.py
+
+Drives the reference's ``EnsembleSampler`` (imported read-only from /root/reference/src) on the model of its own
+``test_rj_multiple_branches`` (tests/test_eryn.py:341-507) in small: two branches (Gaussian pulses + sine waves) with a
+variable number of leaves, in-model ``GaussianMove`` on the packed active leaves, ``DistributionGenerateRJ`` birth /
+death per branch ("separate_branches"), tempering.  Recorded per iteration: the state after the in-model move and after
+the RJ move (coordinates of every leaf slot, ``inds``, log-like, log-prior), both moves' accept masks, betas, swap counts.
+The draws themselves are not stored: NumPy's legacy ``RandomState`` streams are version-stable, so the oracle
+(oracle/eryn_oracle_rj.py) regenerates them from the two seeds and must land on the same states bit for bit - which also
+pins the ORDER in which the path consumes the sampler's stream R and the global stream G.
+The files are data only (inputs + expected outputs).
+"""
+import os
+import sys
+import types
+
+for _m in ("corner", "seaborn"):
+    sys.modules[_m] = types.ModuleType(_m)
+sys.path.insert(0, "/root/reference/src")
+
+import numpy as np                                   # noqa: E402
+from eryn.ensemble import EnsembleSampler            # noqa: E402
+from eryn.moves import GaussianMove                  # noqa: E402
+from eryn.prior import uniform_dist                  # noqa: E402
+from eryn.state import State                         # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def gaussian_pulse(x, a, b, c):                      # tests/test_eryn.py:38-40
+    return a * np.exp(-((x - b) ** 2) / (2 * c ** 2))
+
+
+def combine_gaussians(t, params):                    # tests/test_eryn.py:43-47
+    template = np.zeros_like(t)
+    for param in params:
+        template += gaussian_pulse(t, *param)
+    return template
+
+
+def sine(x, a, b, c):                                # tests/test_eryn.py:67-69
+    return a * np.sin(2 * np.pi * b * x + c)
+
+
+def combine_sine(t, params):
+    template = np.zeros_like(t)
+    for param in params:
+        template += sine(t, *param)
+    return template
+
+
+def log_like_fn_gauss_and_sine(params_both, t, data, sigma):      # tests/test_eryn.py:79-92
+    params_gauss, params_sine = params_both
+    template = np.zeros_like(t)
+    if params_gauss is not None:
+        template += combine_gaussians(t, params_gauss)
+    if params_sine is not None:
+        template += combine_sine(t, params_sine)
+    return -0.5 * np.sum(((template - data) / sigma) ** 2, axis=-1)
+
+
+GAUSS_BOX = [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)]               # tests/test_eryn.py:432-443
+SINE_BOX = [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]
+
+
+def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=1e-4, n_init=(2, 1),
+            seed_data=42, seed_construct=135, seed_run=246):
+    branch_names = ["gauss", "sine"]
+    ndims = {"gauss": 3, "sine": 3}
+    nleaves_max = dict(zip(branch_names, nl_max))
+    nleaves_min = dict(zip(branch_names, nl_min))
+    t = np.linspace(-1, 1, ndata)
+    gauss_inj = np.array([[3.3, -0.2, 0.1], [2.6, -0.1, 0.1], [3.4, 0.0, 0.1], [2.9, 0.3, 0.1]])
+    sine_inj = np.array([[1.3, 10.1, 1.0], [0.8, 4.6, 1.2]])
+    rs = np.random.RandomState(seed_data)
+    y = combine_gaussians(t, gauss_inj[:n_init[0]]) + combine_sine(t, sine_inj[:n_init[1]]) + sigma * rs.randn(ndata)
+    coords = {k: np.zeros((T, W, nleaves_max[k], 3)) for k in branch_names}
+    inds = {k: np.zeros((T, W, nleaves_max[k]), dtype=bool) for k in branch_names}
+    for nn in range(n_init[0]):
+        coords["gauss"][:, :, nn] = rs.multivariate_normal(gauss_inj[nn], np.diag(np.ones(3) * 1e-4), size=(T, W))
+        inds["gauss"][:, :, nn] = True
+    for nn in range(n_init[1]):
+        coords["sine"][:, :, nn] = rs.multivariate_normal(sine_inj[nn], np.diag(np.ones(3) * 1e-4), size=(T, W))
+        inds["sine"][:, :, nn] = True
+    priors = {"gauss": {i: uniform_dist(*GAUSS_BOX[i]) for i in range(3)},
+              "sine": {i: uniform_dist(*SINE_BOX[i]) for i in range(3)}}
+    cov = {k: np.diag(np.ones(3)) * cov_factor for k in branch_names}
+
+    np.random.seed(seed_construct)          # R := snapshot of G at construction (ensemble.py:604,651-652)
+    s = EnsembleSampler(W, ndims, log_like_fn_gauss_and_sine, priors, args=[t, y, sigma],
+                        tempering_kwargs=dict(ntemps=T), nbranches=2, branch_names=branch_names,
+                        nleaves_max=nleaves_max, nleaves_min=nleaves_min, moves=GaussianMove(cov),
+                        rj_moves="separate_branches")
+    logp0 = s.compute_log_prior(coords, inds=inds)
+    logl0 = s.compute_log_like(coords, inds=inds, logp=logp0)[0]
+    state = State(coords, log_like=logl0, log_prior=logp0, inds=inds)
+
+    out = dict(T=T, W=W, ndata=ndata, sigma=float(sigma), nsteps=nsteps, t=t, y=y, nl_max=np.array(nl_max),
+               nl_min=np.array(nl_min), cov_factor=float(cov_factor), seed_construct=seed_construct, seed_run=seed_run,
+               gauss_box=np.array(GAUSS_BOX), sine_box=np.array(SINE_BOX), betas0=np.array(s.temperature_control.betas),
+               L0=logl0, P0=logp0)
+    for k in branch_names:
+        out[f"x0_{k}"], out[f"inds0_{k}"] = coords[k].copy(), inds[k].copy()
+
+    log = []
+
+    def snap(st):
+        d = {f"x_{k}": st.branches[k].coords.copy() for k in branch_names}
+        d.update({f"inds_{k}": st.branches[k].inds.copy() for k in branch_names})
+        d.update(L=st.log_like.copy(), P=st.log_prior.copy())
+        return d
+
+    def wrap(move, tag):
+        orig = move.propose
+
+        def propose(model, st):
+            new, acc = orig(model, st)
+            rec = snap(new)
+            rec.update(tag=tag, accepted=np.array(acc, copy=True), betas=np.array(s.temperature_control.betas),
+                       swaps=np.array(s.temperature_control.swaps_accepted))
+            log.append(rec)
+            return new, acc
+        move.propose = propose
+
+    wrap(s.moves[0], "mh")
+    for i, m in enumerate(s.rj_moves):
+        wrap(m, f"rj{i}")
+
+    np.random.seed(seed_run)                # G for the run
+    it = 0
+    for st in s.sample(state, iterations=nsteps, store=False):
+        assert [r["tag"][:2] for r in log] == ["mh", "rj"], [r["tag"] for r in log]
+        for r in log:
+            pre = f"it{it}_{r['tag'][:2]}_"
+            for k, v in r.items():
+                if k == "tag":
+                    out[pre + "branch"] = int(r["tag"][2:]) if r["tag"].startswith("rj") else -1
+                else:
+                    out[pre + k] = v
+        log.clear()
+        it += 1
+    out["mh_accepted_total"] = np.array(s.moves[0].accepted)
+    out["rj_accepted_total"] = np.stack([np.array(m.accepted) for m in s.rj_moves])
+    out["rj_num_proposals"] = np.array([m.num_proposals for m in s.rj_moves])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    nl = [int(out[f"it{nsteps - 1}_rj_inds_{k}"].sum()) for k in branch_names]
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB; in-model accept {out['mh_accepted_total'].mean() / nsteps:.2f}, "
+          f"rj accept {out['rj_accepted_total'].sum(0).mean() / nsteps:.2f}, leaves at the end {nl}")
+
+
+if __name__ == "__main__":
+    # the reference test's shape in small: leaf counts free between 0 and the maximum
+    capture("rj1_two_branches", T=3, W=8, nl_max=(4, 3), nl_min=(0, 0), nsteps=20)
+    # a floor under one branch (edge factors at kmin, rj.py:258-266) and a wider step so that in-model moves are rejected too
+    capture("rj2_min_leaves", T=4, W=6, nl_max=(5, 2), nl_min=(1, 0), nsteps=16, cov_factor=4e-3, sigma=1.0, seed_run=99)
+    # config-4-like leaf budget (nleaves_max = 10: numpy's 8-way pairwise reduction over the leaf axis of the prior)
+    capture("rj3_ten_leaves", T=2, W=6, nl_max=(10, 10), nl_min=(0, 0), nsteps=12, n_init=(4, 2), ndata=60)

@@ -1,0 +1,61 @@
+"""Pin oracle/eryn_oracle_rj.py (the reversible-jump leaf-packing restatement) to the reference.
+
+tests/golden/make_golden_rj.py ran the REAL reference on three scenarios and recorded the state after every in-model
+move and every RJ move.  The oracle gets only the configuration, the initial state and the two seeds; it must land on
+every recorded array BIT FOR BIT (coordinates of every leaf slot - dead ones included -, inds, log-like, log-prior,
+accept masks, betas, swap counts), which pins the arithmetic and the order of every draw of both streams."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import eryn_oracle_rj as orj
+
+NAMES = ["rj1_two_branches", "rj2_min_leaves", "rj3_ten_leaves"]
+
+
+def load_rj(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+def make_rj_oracle(fx, record=False):
+    cov = np.diag(np.ones(3)) * float(fx["cov_factor"])
+    branches = [orj.Branch("gauss", orj.KIND_PULSE, fx["gauss_box"], int(fx["nl_max"][0]), int(fx["nl_min"][0]), cov),
+                orj.Branch("sine", orj.KIND_SINE, fx["sine_box"], int(fx["nl_max"][1]), int(fx["nl_min"][1]), cov)]
+    R = np.random.RandomState(int(fx["seed_construct"]))      # R := snapshot of the global stream at construction
+    G = np.random.RandomState(int(fx["seed_run"]))
+    x0 = {b.name: fx[f"x0_{b.name}"] for b in branches}
+    inds0 = {b.name: fx[f"inds0_{b.name}"] for b in branches}
+    return orj.OracleRJSampler(branches, x0, inds0, fx["t"], fx["y"], float(fx["sigma"]), R, G, fx["betas0"],
+                               record=record)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rj_oracle_reproduces_the_reference(golden_dir, name):
+    fx = load_rj(golden_dir, name)
+    o = make_rj_oracle(fx)
+    assert np.array_equal(o.st.P, fx["P0"]) and np.array_equal(o.st.L, fx["L0"])
+    for it in range(int(fx["nsteps"])):
+        acc = o.mh_move()
+        pre = f"it{it}_mh_"
+        assert np.array_equal(acc, fx[pre + "accepted"]), f"{pre}accepted"
+        for b in o.branches:
+            assert np.array_equal(o.st.x[b.name], fx[pre + f"x_{b.name}"]), f"{pre}x_{b.name}"
+            assert np.array_equal(o.st.inds[b.name], fx[pre + f"inds_{b.name}"])
+        assert np.array_equal(o.st.L, fx[pre + "L"]) and np.array_equal(o.st.P, fx[pre + "P"]), pre
+        assert np.array_equal(o.st.betas, fx[pre + "betas"]) and np.array_equal(o.swaps_accepted, fx[pre + "swaps"])
+        bi, racc = o.rj_move()
+        pre = f"it{it}_rj_"
+        assert bi == int(fx[pre + "branch"])
+        assert np.array_equal(racc, fx[pre + "accepted"]), f"{pre}accepted"
+        for b in o.branches:
+            assert np.array_equal(o.st.x[b.name], fx[pre + f"x_{b.name}"]), f"{pre}x_{b.name}"
+            assert np.array_equal(o.st.inds[b.name], fx[pre + f"inds_{b.name}"]), f"{pre}inds_{b.name}"
+        assert np.array_equal(o.st.L, fx[pre + "L"]) and np.array_equal(o.st.P, fx[pre + "P"]), pre
+        assert np.array_equal(o.st.betas, fx[pre + "betas"]) and np.array_equal(o.swaps_accepted, fx[pre + "swaps"])
+    assert np.array_equal(o.mh_accepted, fx["mh_accepted_total"])
+    assert np.array_equal(np.stack(o.rj_accepted), fx["rj_accepted_total"])
+    assert np.array_equal(np.array(o.rj_num_proposals), fx["rj_num_proposals"])
+    # the scenarios do what they are there for
+    assert fx["rj_accepted_total"].sum() > 0 and fx["mh_accepted_total"].sum() > 0
