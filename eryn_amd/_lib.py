@@ -16,7 +16,7 @@ from ._build import LIB_PATH
 
 HENS_OK = 0
 ERR_INVALID, ERR_HIP, ERR_STATE, ERR_TOO_FEW_WALKERS, ERR_NONFINITE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
-LIKE_GAUSS_DENSE, LIKE_GAUSS_DIAG, LIKE_ROSENBROCK, LIKE_HOST = 0, 1, 2, 3
+LIKE_GAUSS_DENSE, LIKE_GAUSS_DIAG, LIKE_ROSENBROCK, LIKE_HOST, LIKE_TEMPLATE = 0, 1, 2, 3, 4
 
 
 class HensConfig(C.Structure):
@@ -93,6 +93,12 @@ SIGNATURES = {
     "hens_pipe_debug_stats": (C.c_int, [_P, _P, C.c_int32]),
     "hens_debug_trace": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     "hens_debug_permutation": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int64, _P]),
+    "hens_rj_set_model": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_double]),
+    "hens_rj_set_mh_scale": (C.c_int, [_P, _P]),
+    "hens_rj_mh_step": (C.c_int, [_P, _P, _P, _P]),
+    "hens_rj_bd_step": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "hens_rj_step": (C.c_int, [_P, C.c_int64]),
+    "hens_rj_get_counters": (C.c_int, [_P, _P, _P, _P]),
     "hens_get_iteration": (C.c_int, [_P, _P]),
     "hens_debug_draws": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hens_version": (C.c_char_p, []),

@@ -2,6 +2,7 @@
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
 #include "../../include/hipensemble.h"
 #include "hens_kernels.h"
+#include "hens_rj.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -128,6 +129,14 @@ struct hens_ctx_impl {
     int mh_kind = -1;                      // -1: hens_step runs the stretch move only
     double mh_weight = 0.0;                // probability that an iteration of hens_step is an MH proposal
     int64_t num_proposals_mh = 0;
+    // reversible-jump leaf packing (HENS_LIKE_TEMPLATE, hens_rj_*)
+    RjModel rj{};
+    double* rj_t = nullptr; double* rj_y = nullptr;        // [ndata] data of the template likelihood
+    double* rj_step = nullptr; double* rj_u = nullptr; double* rj_birth = nullptr;   // parity staging
+    int8_t* rj_change = nullptr; int32_t* rj_leaf = nullptr; uint8_t* rj_keep = nullptr;
+    uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
+    int64_t rj_num_mh = 0, rj_num_bd = 0;
+    bool rj_have_scale = false;
     const uint32_t* adapt_src = nullptr;   // pending swap counts: swap_part (nullptr) or the mailbox's reduced counts
     int adapt_nblocks = 0;
 
@@ -284,6 +293,8 @@ int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
         case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, MODE>(c, a, ntiles);
         case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, MODE>(c, a, ntiles);
         case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, MODE>(c, a, ntiles);
+        case HENS_LIKE_TEMPLATE:
+            return fail(c, HENS_ERR_STATE, "leaf-packing context: step with hens_rj_* (the stretch move is not defined on variable-dimension records)");
         case HENS_LIKE_HOST:
             if (MODE == MODE_EVAL) return launch_hostlike_eval(c, a, ntiles);
             return fail(c, HENS_ERR_STATE, "host-likelihood context: use hens_propose_split / hens_accept_split");
@@ -891,6 +902,64 @@ bool iteration_is_mh(const hens_ctx_impl* c) {
     return c->mh_weight >= 1.0 || move_uniform(c->cfg.seed, c->iter) < c->mh_weight;
 }
 
+// ---- reversible-jump leaf packing ---------------------------------------------------------------------------------------
+int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const int8_t* change, const int32_t* leaf,
+              const double* birth, const double* u_acc, uint8_t* keep) {
+    RjArgs a{};
+    a.pool = c->pool; a.loc = c->loc[c->cur]; a.L = c->L[c->cur]; a.P = c->P[c->cur];
+    a.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
+    a.accepted = mode == RJ_MODE_BD ? c->rj_acc_bd : c->accepted;
+    a.keep_out = keep;
+    a.tdata = c->rj_t; a.ydata = c->rj_y;
+    a.step = step; a.change = change; a.leaf = leaf; a.birth = birth; a.u_acc = u_acc;
+    a.flags = c->flags;
+    a.M = c->rj;
+    a.fill = c->cfg.fill_value;
+    a.iter = c->iter; a.seed = c->cfg.seed;
+    a.Tl = c->Tl; a.W = c->W; a.rung_begin = c->cfg.rung_begin; a.tempered = c->cfg.tempered; a.mode = mode; a.branch = branch;
+    const int64_t n = (int64_t)c->Tl * c->W;
+    hipLaunchKernelGGL(k_rj, dim3((unsigned)((n + RJ_WAVES - 1) / RJ_WAVES)), dim3(RJ_WAVES * 64), 0, c->stream, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_rj launch failed: %s", hipGetErrorString(e));
+    return HENS_OK;
+}
+
+int rj_ready(hens_ctx_impl* c) {
+    int r = ready(c, true);
+    if (r) return r;
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
+    if (c->Tl != c->T) return fail(c, HENS_ERR_UNSUPPORTED, "the leaf-packing path runs on the whole ladder of one GPU");
+    if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
+    return HENS_OK;
+}
+
+int rj_ensure_staging(hens_ctx_impl* c) {
+    if (c->rj_u) return HENS_OK;
+    const size_t TW = (size_t)c->Tl * c->W;
+    int r;
+    if ((r = dalloc(c, &c->rj_step, TW * c->D))) return r;
+    if ((r = dalloc(c, &c->rj_u, TW))) return r;
+    if ((r = dalloc(c, &c->rj_birth, TW * RJ_ND))) return r;
+    if ((r = dalloc(c, &c->rj_change, TW))) return r;
+    if ((r = dalloc(c, &c->rj_leaf, TW))) return r;
+    if ((r = dalloc(c, &c->rj_keep, TW))) return r;
+    return HENS_OK;
+}
+
+// the cascade + (optionally adapting) ladder update after a leaf-packing move; `key` separates the two cascades of one iteration
+void rj_cascade(hens_ctx_impl* c, uint64_t key, bool adapt) {
+    if (!has_pt(c)) return;
+    flush_adapt(c);
+    PtArgs p = pt_args(c, nullptr, false);
+    p.iter = key;
+    hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(c->T), c->stream, p);
+    c->cur ^= 1;
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = adapt && c->cfg.adaptive != 0;      // rj.py:381-382: swaps without adaptation after the RJ move
+    c->adapt_src = nullptr;
+    flush_adapt(c);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -919,7 +988,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     if (cfg->rung_begin < 0 || cfg->rung_end > cfg->ntemps || cfg->rung_begin >= cfg->rung_end)
         return fail(nullptr, HENS_ERR_INVALID, "invalid ladder shard [%d, %d) of %d", cfg->rung_begin,
                     cfg->rung_end, cfg->ntemps);
-    if (cfg->likelihood_kind < 0 || cfg->likelihood_kind > HENS_LIKE_HOST)
+    if (cfg->likelihood_kind < 0 || cfg->likelihood_kind > HENS_LIKE_TEMPLATE)
         return fail(nullptr, HENS_ERR_INVALID, "unknown likelihood kind %d", cfg->likelihood_kind);
     if (!(cfg->a > 1.0)) return fail(nullptr, HENS_ERR_INVALID, "stretch scale a must be > 1");
     if (cfg->ntemps > 1 && !cfg->tempered)
@@ -941,6 +1010,10 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     c->Tl = cfg->rung_end - cfg->rung_begin;
     c->N0 = (c->W + 1) / 2;
     c->have_like = cfg->likelihood_kind == HENS_LIKE_HOST;
+    if (cfg->likelihood_kind == HENS_LIKE_TEMPLATE && cfg->ndim > RJ_MAX_RW) {
+        delete c;
+        return fail(nullptr, HENS_ERR_UNSUPPORTED, "leaf-packing record wider than %d doubles", RJ_MAX_RW);
+    }
     hens_ctx* h = reinterpret_cast<hens_ctx*>(c);
 #define TRY(x) do { int r_ = (x); if (r_) { g_last_error = c->err; hens_destroy(h); return r_; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(c, HENS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); g_last_error = c->err; hens_destroy(h); return HENS_ERR_HIP; } } while (0)
@@ -1219,6 +1292,14 @@ int hens_eval_state(hens_ctx* ctx) {
     int r = ready(c, false);
     if (r) return r;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE) {
+        r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (r) return r;
+        r = check_flags(c, true);
+        if (r) return r;
+        c->have_logs = true;
+        return HENS_OK;
+    }
     StretchArgs a = base_args(c);
     a.split = 0;
     a.home_off = 0;
@@ -1719,6 +1800,150 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
         if (mh_u) HIPCHK(c, hipMemcpyAsync(mh_u, d.dbg_u, TW * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    return HENS_OK;
+}
+
+// ---- reversible-jump leaf packing ----------------------------------------------------------
+int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, const int32_t* nleaves_max,
+                      const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp,
+                      int32_t ndata, const double* t, const double* y, double sigma) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !kinds || !nleaves_max || !nleaves_min || !lo || !hi || !leaf_logp || !t || !y)
+        return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_set_model needs HENS_LIKE_TEMPLATE");
+    if (nbranches < 1 || nbranches > RJ_MAX_BRANCH) return fail(c, HENS_ERR_INVALID, "1..%d branches", RJ_MAX_BRANCH);
+    if (ndata < 1 || !(sigma > 0.0)) return fail(c, HENS_ERR_INVALID, "invalid data");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    RjModel M{};
+    M.nb = nbranches; M.ndata = ndata; M.sigma = sigma;
+    int off = 0;
+    for (int b = 0; b < nbranches; ++b) {
+        if (kinds[b] != RJ_KIND_PULSE && kinds[b] != RJ_KIND_SINE) return fail(c, HENS_ERR_INVALID, "unknown leaf kind %d", kinds[b]);
+        if (nleaves_max[b] < 1 || nleaves_max[b] > 32 || nleaves_min[b] < 0 || nleaves_min[b] > nleaves_max[b])
+            return fail(c, HENS_ERR_INVALID, "branch %d: need 0 <= nleaves_min <= nleaves_max <= 32", b);
+        M.kind[b] = kinds[b]; M.nl[b] = nleaves_max[b]; M.nlmin[b] = nleaves_min[b]; M.off[b] = off;
+        off += nleaves_max[b] * RJ_ND;
+        for (int d = 0; d < RJ_ND; ++d) {
+            M.lo[b][d] = lo[b * RJ_ND + d]; M.hi[b][d] = hi[b * RJ_ND + d];
+            if (!(M.hi[b][d] > M.lo[b][d])) return fail(c, HENS_ERR_INVALID, "branch %d: empty prior box", b);
+        }
+        M.leaf_logp[b] = leaf_logp[b];
+    }
+    M.ind_off = off;
+    M.RW = c->D;
+    if (off + nbranches > c->D) return fail(c, HENS_ERR_INVALID, "record width ndim = %d cannot hold %d coordinates + %d masks", c->D, off, nbranches);
+    c->rj = M;
+    int r;
+    if (!c->rj_t) {
+        if ((r = dalloc(c, &c->rj_t, (size_t)ndata))) return r;
+        if ((r = dalloc(c, &c->rj_y, (size_t)ndata))) return r;
+        if ((r = dalloc(c, &c->rj_acc_bd, (size_t)c->Tl * c->W))) return r;
+        HIPCHK(c, hipMemsetAsync(c->rj_acc_bd, 0, (size_t)c->Tl * c->W * 4, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->rj_t, t, (size_t)ndata * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_y, y, (size_t)ndata * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_like = true;
+    c->have_prior = true;
+    return HENS_OK;
+}
+
+int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !scale) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || !c->have_like) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
+    for (int b = 0; b < c->rj.nb; ++b)
+        for (int d = 0; d < RJ_ND; ++d) c->rj.mh_scale[b][d] = scale[b * RJ_ND + d];
+    c->rj_have_scale = true;
+    return HENS_OK;
+}
+
+int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = rj_ready(c);
+    if (r) return r;
+    if (!step || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
+    if ((r = rj_ensure_staging(c))) return r;
+    const size_t TW = (size_t)c->Tl * c->W;
+    HIPCHK(c, hipMemcpyAsync(c->rj_step, step, TW * c->rj.ind_off * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    if ((r = rj_launch(c, RJ_MODE_MH, 0, c->rj_step, nullptr, nullptr, nullptr, c->rj_u, c->rj_keep))) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
+    if ((r = check_flags(c, false))) return r;
+    c->rj_num_mh += 1;
+    if (!has_pt(c)) c->iter += 1;
+    return HENS_OK;
+}
+
+int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const int32_t* leaf, const double* birth,
+                    const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = rj_ready(c);
+    if (r) return r;
+    if (!change || !leaf || !birth || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (branch < 0 || branch >= c->rj.nb) return fail(c, HENS_ERR_INVALID, "branch %d out of range", branch);
+    const size_t TW = (size_t)c->Tl * c->W;
+    for (size_t i = 0; i < TW; ++i) {
+        if (change[i] < -1 || change[i] > 1) return fail(c, HENS_ERR_INVALID, "change must be -1, 0 or +1");
+        if (change[i] != 0 && (leaf[i] < 0 || leaf[i] >= c->rj.nl[branch])) return fail(c, HENS_ERR_INVALID, "leaf slot out of range");
+    }
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
+    if ((r = rj_ensure_staging(c))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->rj_change, change, TW, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_leaf, leaf, TW * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, TW * RJ_ND * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, c->rj_change, c->rj_leaf, c->rj_birth, c->rj_u, c->rj_keep))) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
+    if ((r = check_flags(c, false))) return r;
+    c->rj_num_bd += 1;
+    return HENS_OK;
+}
+
+int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = rj_ready(c);
+    if (r) return r;
+    if (n_iters < 0) return fail(c, HENS_ERR_INVALID, "n_iters < 0");
+    if (!c->rj_have_scale) return fail(c, HENS_ERR_STATE, "in-model step scale not set (hens_rj_set_mh_scale)");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    c->timing = hens_timing{};
+    for (int64_t i = 0; i < n_iters; ++i) {
+        // in-model Gaussian move on the packed leaves, then swaps + adaptation (mh.py:190-191)
+        if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        c->rj_num_mh += 1;
+        rj_cascade(c, 2 * c->iter, true);
+        // one branch's birth / death move (ensemble.py:988-990, "separate_branches"), then swaps without adaptation
+        const int branch = std::min(c->rj.nb - 1, (int)(move_uniform(c->cfg.seed ^ 0x9E3779B97F4A7C15ull, c->iter) * c->rj.nb));
+        if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        c->rj_num_bd += 1;
+        rj_cascade(c, 2 * c->iter + 1, false);
+        c->iter += 1;
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timing.n_iters = n_iters;
+    return HENS_OK;
+}
+
+int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, int64_t* num_bd) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || !c->rj_acc_bd) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    if (accepted_bd) {
+        std::vector<uint32_t> acc(TW);
+        HIPCHK(c, hipMemcpyAsync(acc.data(), c->rj_acc_bd, TW * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < TW; ++i) accepted_bd[i] = (double)acc[i];
+    }
+    if (num_mh) *num_mh = c->rj_num_mh;
+    if (num_bd) *num_bd = c->rj_num_bd;
     return HENS_OK;
 }
 

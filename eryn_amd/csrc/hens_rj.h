@@ -1,0 +1,301 @@
+// hens_rj.h - reversible-jump leaf packing on gfx950 (BASELINE config 4).
+//
+// A walker of a variable-dimension model is one RECORD of the walker pool (the same pool, `loc` indirection, L / P /
+// betas buffers, PT cascade, ladder adaptation and counters as everywhere else - the cascade permutes `loc`, so a swap
+// carries every branch's leaves and masks along, tempering.py:376-480):
+//
+//   record = [ branch 0: nleaves_max_0 x 3 coordinates | branch 1: ... | leaf mask of branch 0 | mask of branch 1 | pad ]
+//
+// The leaf masks are the reference's `inds[t, w, :]` (state.py:330-562) packed into one integer per branch, stored as
+// a double value (exact below 2^53) so that a record is a plain row of doubles for upload / download / the cascade.
+// Leaves are "packed" in registers and LDS, never in memory: a dead leaf keeps its coordinates in place exactly as in
+// the reference (distgenrj.py:120: "they just sit in the state").
+//
+// One WAVEFRONT per walker: the 64 lanes split the data points of the template likelihood (the reference tests'
+// Gaussian pulses + sine waves, tests/test_eryn.py:38-92), everything per walker (proposal, prior over the active
+// leaves, accept test) is wave-uniform.  Modes: evaluation of the resident state, the in-model GaussianMove on all
+// active leaves (mh.py:56-193, gaussian.py:68-115), and the birth / death move of DistributionGenerateRJ on one branch
+// (distgenrj.py:35-222, rj.py:145-388 incl. edge factors and fix_logp_gibbs, move.py:368-402).  Draws come from the
+// caller (parity mode: the reference's R / G draws) or from Philox counters (production).
+// All file:line citations are relative to /root/reference/src/eryn unless they name tests/.
+#pragma once
+#include "hens_kernels.h"
+
+namespace hens {
+
+constexpr int RJ_MAX_BRANCH = 4, RJ_ND = 3, RJ_MAX_RW = 128;
+enum { RJ_KIND_PULSE = 0, RJ_KIND_SINE = 1 };
+enum { RJ_MODE_EVAL = 0, RJ_MODE_MH = 1, RJ_MODE_BD = 2 };
+enum : uint32_t { PURPOSE_RJ_NORMAL = 20, PURPOSE_RJ_ACC = 21, PURPOSE_RJ_BD = 22, PURPOSE_RJ_BIRTH = 23, PURPOSE_RJ_BRANCH = 24 };
+
+struct RjModel {
+    int32_t nb, RW, ndata, ind_off;                 // branches, record width (doubles), data points, offset of the first mask
+    int32_t kind[RJ_MAX_BRANCH], nl[RJ_MAX_BRANCH], nlmin[RJ_MAX_BRANCH], off[RJ_MAX_BRANCH];
+    double lo[RJ_MAX_BRANCH][RJ_ND], hi[RJ_MAX_BRANCH][RJ_ND];
+    double leaf_logp[RJ_MAX_BRANCH];                // sum_d log(1 / (hi_d - lo_d)) accumulated by the host in the reference's order
+    double mh_scale[RJ_MAX_BRANCH][RJ_ND];          // Philox mode: standard deviations of the in-model Gaussian step
+    double sigma;
+};
+
+struct RjArgs {
+    double* pool; const int32_t* loc; double* L; double* P; const double* betas;
+    uint32_t* accepted;                 // [Tl][W] accept counts of this move
+    uint8_t* keep_out;                  // [Tl][W] or nullptr
+    const double* tdata; const double* ydata;
+    const double* step;                 // parity in-model move: [Tl][W][ind_off] steps in record layout; nullptr: Philox
+    const int8_t* change;               // parity birth / death: [Tl][W] +1 / -1 / 0 after the edge rule (distgenrj.py:69-73)
+    const int32_t* leaf;                // [Tl][W] slot that is born or dies
+    const double* birth;                // [Tl][W][3] coordinates of the born leaf (generate_dist.rvs)
+    const double* u_acc;                // [Tl][W] accept uniforms; nullptr: Philox
+    unsigned* flags;
+    RjModel M;
+    double fill;
+    uint64_t iter, seed;
+    int32_t Tl, W, rung_begin, tempered, mode, branch;
+};
+
+// ndarray.sum(axis=-1) of v[0..n): NumPy's pairwise order (n < 8: a plain loop from 0.0; 8 <= n <= 128: eight partial
+// sums, the tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail).  Checked against NumPy for n = 1..20.
+__device__ __forceinline__ double numpy_sum(const double* v, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r = r + v[i];
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = r[j] + v[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res = res + v[i];
+    return res;
+}
+
+// index of the k-th set bit of m (k < popcount(m))
+__device__ __forceinline__ int nth_set_bit(uint32_t m, int k) {
+    for (int j = 0; j < k; ++j) m &= m - 1u;
+    return __builtin_ctz(m);
+}
+
+constexpr int RJ_WAVES = 4;        // walkers per workgroup
+
+__global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
+    __shared__ double s_cur[RJ_WAVES][RJ_MAX_RW];
+    __shared__ double s_q[RJ_WAVES][RJ_MAX_RW];
+    __shared__ double s_leafv[RJ_WAVES][32];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gw = (int64_t)blockIdx.x * RJ_WAVES + wv;
+    if (gw >= (int64_t)A.Tl * A.W) return;                  // whole wavefront (nothing below synchronises across waves)
+    const RjModel& M = A.M;
+    const int tl = (int)(gw / A.W);
+    const int RW = M.RW;
+    double* cur = s_cur[wv];
+    double* q = s_q[wv];
+    double* leafv = s_leafv[wv];
+    double* row = A.pool + (size_t)A.loc[gw] * RW;
+    for (int i = lane; i < RW; i += 64) {
+        const double v = row[i];
+        cur[i] = v;
+        q[i] = v;
+    }
+#define RJ_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    RJ_LDS_SYNC();
+    uint32_t mask_old[RJ_MAX_BRANCH], mask[RJ_MAX_BRANCH];
+    for (int b = 0; b < M.nb; ++b) mask[b] = mask_old[b] = (uint32_t)cur[M.ind_off + b];
+    const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
+
+    // ---- proposal -----------------------------------------------------------------------------------------------------
+    double factors = 0.0;
+    if (A.mode == RJ_MODE_MH) {
+        // every active leaf of every branch moves: q = x + step (gaussian.py:96-104, 265-268; factors = 0)
+        for (int i = lane; i < M.ind_off; i += 64) {
+            int b = 0;
+            while (b + 1 < M.nb && i >= M.off[b + 1]) ++b;
+            const int n = (i - M.off[b]) / RJ_ND, d = (i - M.off[b]) - n * RJ_ND;
+            if ((mask[b] >> n) & 1u) {
+                double st;
+                if (A.step) {
+                    st = A.step[(size_t)gw * M.ind_off + i];
+                } else {                                             // one Box-Muller pair per coordinate, first value used
+                    const double2 z = mh_normal_pair(A.seed, A.iter, wid, (uint32_t)i | 0x10000u);
+                    st = M.mh_scale[b][d] * z.x;
+                }
+                q[i] = cur[i] + st;
+            }
+        }
+    } else if (A.mode == RJ_MODE_BD) {
+        const int B = A.branch;
+        const int nold = __builtin_popcount(mask_old[B]);
+        int c, lf;
+        if (A.change) {
+            c = A.change[gw];
+            lf = A.leaf[gw];
+        } else {
+            const u4 d = philox4x32_10(u4{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), wid, PURPOSE_RJ_BD}, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+            c = (d.x & 1u) ? +1 : -1;                                 // distgenrj.py:63-66
+            if (M.nlmin[B] == M.nl[B]) c = 0;
+            else if (nold == M.nlmin[B]) c = +1;                      // :69-73
+            else if (nold == M.nl[B]) c = -1;
+            const uint32_t full = M.nl[B] >= 32 ? 0xffffffffu : ((1u << M.nl[B]) - 1u);
+            const uint32_t pool_bits = c > 0 ? (~mask_old[B] & full) : mask_old[B];
+            const int cnt = __builtin_popcount(pool_bits);
+            lf = cnt ? nth_set_bit(pool_bits, (int)__umulhi(d.y, (uint32_t)cnt)) : 0;    // uniform over the candidates (:97-112)
+        }
+        if (c < 0) {                                                  // death: factor +log q(leaf) (:188-197)
+            mask[B] &= ~(1u << lf);
+            bool in = true;
+            for (int d = 0; d < RJ_ND; ++d) {
+                const double v = cur[M.off[B] + lf * RJ_ND + d];
+                in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
+            }
+            factors = 0.0 + (in ? M.leaf_logp[B] : -INFINITY);
+        } else if (c > 0) {                                           // birth from the prior: factor -log q(leaf) (:199-214)
+            mask[B] |= (1u << lf);
+            bool in = true;
+            for (int d = 0; d < RJ_ND; ++d) {
+                double v;
+                if (A.birth) {
+                    v = A.birth[(size_t)gw * RJ_ND + d];
+                } else {
+                    const u4 e = philox4x32_10(u4{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), wid, PURPOSE_RJ_BIRTH | ((uint32_t)d << 8)},
+                                               (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                    v = u01(e.x, e.y) * (M.hi[B][d] - M.lo[B][d]) + M.lo[B][d];          // prior.py:60-66
+                }
+                in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
+                if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
+            }
+            factors = 0.0 - (in ? M.leaf_logp[B] : -INFINITY);
+        }
+        if (!(M.nlmin[B] == M.nl[B] || M.nlmin[B] + 1 == M.nl[B])) {  // edge factors (rj.py:236-270)
+            const int nnew = __builtin_popcount(mask[B]);
+            const double lh = log(1 / 2.0);
+            double edge = 0.0;
+            if (nold == M.nlmin[B]) edge += lh;
+            if (nold == M.nl[B]) edge += lh;
+            if (nnew == M.nlmin[B]) edge -= lh;
+            if (nnew == M.nl[B]) edge -= lh;
+            factors += edge;
+        }
+        if (lane == 0) q[M.ind_off + B] = (double)mask[B];
+    }
+    RJ_LDS_SYNC();
+
+    // ---- log-prior over the leaf slots (ensemble.py:1189-1210): dead slots count 0.0, NumPy's sum order per branch ------
+    double logp = 0.0;
+    int total_leaves = 0;
+    for (int b = 0; b < M.nb; ++b) {
+        if (lane < M.nl[b]) {
+            double v = 0.0;
+            if ((mask[b] >> lane) & 1u) {
+                bool in = true;
+                for (int d = 0; d < RJ_ND; ++d) {
+                    const double x = q[M.off[b] + lane * RJ_ND + d];
+                    in = in && (x >= M.lo[b][d]) && (x <= M.hi[b][d]);
+                    if (!(fabs(x) < INFINITY)) atomicOr(A.flags, FLAG_NONFINITE_X);
+                }
+                v = in ? M.leaf_logp[b] : -INFINITY;
+            }
+            leafv[lane] = v;
+        }
+        RJ_LDS_SYNC();
+        logp = logp + numpy_sum(leafv, M.nl[b]);
+        RJ_LDS_SYNC();
+        total_leaves += __builtin_popcount(mask[b]);
+    }
+    {   // Move.fix_logp_gibbs (move.py:368-402): the branches under proposal are all of them (in-model) or one (RJ)
+        const int here = A.mode == RJ_MODE_BD ? __builtin_popcount(mask[A.branch]) : total_leaves;
+        if (A.mode != RJ_MODE_EVAL) {
+            if (total_leaves != 0 && here == 0) logp = -INFINITY;
+            if (total_leaves == 0 && here == 0) logp = 0.0;
+        }
+    }
+
+    // ---- template likelihood: lanes over the data points ------------------------------------------------------------------
+    double logl;
+    const bool evaluated = total_leaves > 0 && !(fabs(logp) == INFINITY);   // ensemble.py:1278-1306, 1486-1513
+    if (evaluated) {
+        double acc = 0.0;
+        for (int i = lane; i < M.ndata; i += 64) {
+            const double ti = A.tdata[i];
+            double tm = 0.0;
+            for (int b = 0; b < M.nb; ++b) {
+                double sub = 0.0;
+                uint32_t m = mask[b];
+                while (m) {
+                    const int n = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const double a = q[M.off[b] + n * RJ_ND], bb = q[M.off[b] + n * RJ_ND + 1], c = q[M.off[b] + n * RJ_ND + 2];
+                    double f;
+                    if (M.kind[b] == RJ_KIND_PULSE) {
+                        const double dx = ti - bb;
+                        f = a * exp(-(dx * dx) / (2 * (c * c)));                           // tests/test_eryn.py:38-40
+                    } else {
+                        f = a * sin(2 * M_PI * bb * ti + c);                               // tests/test_eryn.py:67-69
+                    }
+                    sub += f;
+                }
+                tm += sub;
+            }
+            const double r = (tm - A.ydata[i]) / M.sigma;
+            acc += r * r;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        logl = -0.5 * acc;
+        if (logl != logl) {
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+    } else {
+        logl = A.fill;
+    }
+
+    // ---- evaluation / accept + update ----------------------------------------------------------------------------------------
+    if (A.mode == RJ_MODE_EVAL) {
+        if (lane == 0) {
+            A.L[gw] = logl;
+            A.P[gw] = logp;
+        }
+        return;
+    }
+    const double Lold = A.L[gw], Pold = A.P[gw];
+    double logP, prevP;
+    if (A.tempered) {                                                  // tempering.py:304-306,343-349
+        const double beta = A.betas[A.rung_begin + tl];
+        double lt = logl * beta;
+        if (lt != lt) lt = -INFINITY;
+        logP = lt + logp;
+        double lo_ = Lold * beta;
+        if (lo_ != lo_) lo_ = -INFINITY;
+        prevP = lo_ + Pold;
+    } else {
+        logP = logl + logp;
+        prevP = Lold + Pold;
+    }
+    const double lnpdiff = factors + logP - prevP;                     // mh.py:155, rj.py:330
+    double lu;
+    if (A.u_acc) {
+        lu = log(A.u_acc[gw]);
+    } else {
+        const u4 d = philox4x32_10(u4{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), wid, PURPOSE_RJ_ACC | ((uint32_t)A.mode << 8)},
+                                   (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        lu = log(u01(d.x, d.y));
+    }
+    const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
+    if (keep) {                                                        // Move.update (move.py:472-703)
+        for (int i = lane; i < RW; i += 64) row[i] = q[i];
+        if (lane == 0) {
+            A.L[gw] = logl;
+            A.P[gw] = (fabs(logp) == INFINITY) ? 0.0 : logp;
+            A.accepted[gw] += 1u;
+        }
+    }
+    if (lane == 0 && A.keep_out) A.keep_out[gw] = keep ? 1 : 0;
+#undef RJ_LDS_SYNC
+}
+
+}  // namespace hens

@@ -47,7 +47,8 @@ typedef enum hens_likelihood {
     HENS_LIKE_GAUSS_DENSE = 0,      /* -0.5 (x-mu)^T P (x-mu), tests/test_eryn.py:33-35 */
     HENS_LIKE_GAUSS_DIAG = 1,       /* same with diagonal precision (test_base's identity covariance) */
     HENS_LIKE_ROSENBROCK = 2,       /* -(sum b (x[i+1]-x[i]^2)^2 + (a-x[i])^2), BASELINE config 5 */
-    HENS_LIKE_HOST = 3              /* arbitrary caller-side log_like_fn: hens_propose_split / hens_accept_split */
+    HENS_LIKE_HOST = 3,             /* arbitrary caller-side log_like_fn: hens_propose_split / hens_accept_split */
+    HENS_LIKE_TEMPLATE = 4          /* variable-dimension template model on leaf-packing records: hens_rj_*  */
 } hens_likelihood;
 
 /* Construction parameters.  Mirrors the keyword arguments that reach the path:
@@ -307,6 +308,39 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
  * which = 0 the PT column map of global rung `rung`, which = 1 the split labelling permutation of
  * rung `rung`.  out[nwalkers] i32. */
 int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t iter, int32_t* out);
+
+/* Reversible-jump leaf packing (BASELINE config 4).  A context created with HENS_LIKE_TEMPLATE holds
+ * variable-dimension walkers as RECORDS of ndim doubles:
+ *     [ branch 0: nleaves_max_0 x 3 coordinates | branch 1: ... | leaf mask of branch 0 | mask of branch 1 | ... | pad ]
+ * where a mask is the reference's inds[t, w, :] (state.py:330-562, backends/backend.py:1049-1059) as an integer stored
+ * in a double (bit n = leaf slot n in use).  hens_upload_state / hens_download_state / hens_eval_state / hens_pt_sweep /
+ * hens_get_counters work on records unchanged: a PT swap carries all leaves and masks of a walker (tempering.py:376-480).
+ *
+ * hens_rj_set_model: the model of the reference's own RJ tests (tests/test_eryn.py:38-92, 341-507): per branch a leaf
+ *   kind (0 Gaussian pulse a exp(-(t-b)^2 / 2c^2), 1 sine a sin(2 pi b t + c)), leaf budget [nleaves_min, nleaves_max],
+ *   a uniform box prior per leaf parameter (lo / hi [nbranches][3]; leaf_logp[b] = sum_d log(1/(hi-lo)) accumulated by
+ *   the caller in the reference's order, prior.py:364-383) and the data (t, y)[ndata], sigma of
+ *   logL = -1/2 sum(((template - y) / sigma)^2).
+ * hens_rj_mh_step: the in-model GaussianMove on the packed active leaves of every branch (mh.py:56-193,
+ *   gaussian.py:68-115,265-268) with the caller's draws: step[Tl][W][ncoord] in record layout (zero on unused slots),
+ *   u_acc[Tl][W].  Replaces compute_log_prior / compute_log_like with inds (ensemble.py:1127-1217, 1219-1545,
+ *   utils/utility.py:8-40 leaf grouping), the accept test and Move.update (move.py:472-703).
+ * hens_rj_bd_step: DistributionGenerateRJ on one branch (distgenrj.py:35-222, rj.py:145-388): change[Tl][W] in
+ *   {-1, 0, +1} after the edge rule (distgenrj.py:69-73), leaf[Tl][W] the slot that is born or dies, birth[Tl][W][3] the
+ *   prior draw of a born leaf, u_acc[Tl][W].  The library adds the proposal factors -/+ log q(leaf), the edge factors
+ *   (rj.py:236-270) and the fix_logp_gibbs rule (move.py:368-402).  Follow it with hens_pt_sweep(adapt = 0) (rj.py:381-382).
+ * hens_rj_set_mh_scale + hens_rj_step: production: n iterations of (in-model move, swaps + adaptation, birth / death on
+ *   a uniformly chosen branch, swaps) with device-side Philox draws of the same distributions.
+ * hens_rj_get_counters: accept counts of the birth / death move (hens_get_counters has the in-model move's). */
+int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, const int32_t* nleaves_max,
+                      const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp,
+                      int32_t ndata, const double* t, const double* y, double sigma);
+int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale);
+int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out);
+int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const int32_t* leaf, const double* birth,
+                    const double* u_acc, uint8_t* keep_out);
+int hens_rj_step(hens_ctx* ctx, int64_t n_iters);
+int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, int64_t* num_bd);
 
 /* The Philox iteration counter: the index of the NEXT iteration hens_step will run (iterations completed on this
  * context so far, by hens_step or by the parity API). */
