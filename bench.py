@@ -216,6 +216,63 @@ def run_single(args):
     return out
 
 
+def run_cfg4(args):
+    """BASELINE config 4: reversible-jump leaf packing - 2 branches (Gaussian pulses + sine waves, the reference tests'
+    model) x nleaves_max = 10, ntemps = 8, nwalkers = 2048, 500 data points - on one GPU.  One step = in-model Gaussian
+    move on the packed leaves + swaps + adaptation + birth/death on one branch + swaps (ensemble.py:963-1024)."""
+    from eryn_amd.moves.tempering import make_ladder
+    from eryn_amd.rj import RJEngine, TemplateBranch
+    T, W, N, NL = args.ntemps or 8, args.nwalkers or 2048, 500, 10
+    t = np.linspace(-1, 1, N)
+    rs = np.random.RandomState(42)
+    gauss_inj = np.array([[3.3, -0.2, 0.1], [2.6, -0.1, 0.1], [3.4, 0.0, 0.1], [2.9, 0.3, 0.1]])      # tests/test_eryn.py:356-366
+    sine_inj = np.array([[1.3, 10.1, 1.0], [0.8, 4.6, 1.2]])
+    y = sum(a * np.exp(-((t - b) ** 2) / (2 * c ** 2)) for a, b, c in gauss_inj) + \
+        sum(a * np.sin(2 * np.pi * b * t + c) for a, b, c in sine_inj) + 2.0 * rs.randn(N)
+    brs = [TemplateBranch("gauss", "pulse", [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)], NL, 0),
+           TemplateBranch("sine", "sine", [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)], NL, 0)]
+    eng = RJEngine(T, W, brs, t, y, 2.0, seed=2024)
+    x = {"gauss": np.zeros((T, W, NL, 3)), "sine": np.zeros((T, W, NL, 3))}
+    inds = {k: np.zeros((T, W, NL), dtype=bool) for k in x}
+    for n in range(4):
+        x["gauss"][:, :, n] = gauss_inj[n] + 1e-2 * rs.randn(T, W, 3) * [1, 1, 0.1]
+        inds["gauss"][:, :, n] = True
+    for n in range(2):
+        x["sine"][:, :, n] = sine_inj[n] + 1e-2 * rs.randn(T, W, 3)
+        inds["sine"][:, :, n] = True
+    eng.upload(x, inds, betas=make_ladder(18, ntemps=T))
+    eng.eval_state()
+    eng.set_mh_scale(np.full((2, 3), 1e-2) * [[1, 1, 0.1], [1, 1, 1]])
+    eng.step(args.warmup)
+    eng.synchronize()
+    times, _ = timed_blocks(eng.step, eng.synchronize, args.steps)
+    dt = float(np.median(times))
+    _, inds1, _, _, _ = eng.download()
+    c = eng.counters()
+    leaves = float(sum(v.sum() for v in inds1.values())) / (T * W)
+    eng.close()
+    value = T * W * args.steps / dt
+    evals = 2 * leaves * N * value                   # template point evaluations per second (two likelihoods per step)
+    rw = 2 * NL * 3 + 2
+    alg = 2 * (2 * rw * 8 + 32) + N * 16 * 2         # per walker-step: two moves x (record read + write + L, P) + the data
+    return {
+        "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), RJ Gaussian-pulse model", "value": value,
+        "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "block_ms": [t_ * 1e3 for t_ in times],
+        "timing": f"median of {BLOCKS} blocks of {args.steps} steps",
+        "config": {"workload": f"config 4: RJ multi-branch template model (Gaussian pulses + sines, 2 branches x nleaves_max={NL}), "
+                               f"ntemps={T}, nwalkers={W}, {N} data points, in-model Gaussian move + birth/death + PT, Philox RNG",
+                   "ntemps": T, "nwalkers": W, "mean_active_leaves_per_walker": leaves,
+                   "accept_in_model": float(c["accepted_mh"].mean() / max(c["num_mh"], 1)),
+                   "accept_birth_death": float(c["accepted_bd"].mean() / max(c["num_bd"], 1))},
+        "roofline": {"bound": "hbm", "kernel": "k_rj (one wavefront per walker)", "achieved": alg * value / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg * value / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "note": "this path is bound by FP64 transcendental throughput, not by HBM: "
+                             f"{evals:.3e} template-point evaluations/s (one exp or sin + ~8 flops each)"},
+    }
+
+
 def run_sharded(args):
     """N-GPU leg: weak scaling, one fixed-size ladder shard per GPU, one process per GPU."""
     import torch.distributed as dist
@@ -400,13 +457,19 @@ def main():
     ap.add_argument("--ntemps", type=int, default=None)
     ap.add_argument("--nwalkers", type=int, default=None)
     ap.add_argument("--ndim", type=int, default=None)
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3"])
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-base", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "0"))
     n = max(args.gpus, world, 1)
+    if args.workload == "cfg4":
+        if n > 1:
+            raise SystemExit("bench.py --workload cfg4 is a single-GPU workload")
+        args.steps = args.steps or 200
+        print(json.dumps(run_cfg4(args)), flush=True)
+        return
     if n > 1 and world == 0:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver would
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",

@@ -207,6 +207,11 @@ __device__ __forceinline__ double sys_load(const double* p) { return __hip_atomi
 // so raising a flag only needs those stores COMPLETE (s_waitcnt vmcnt(0)), not an L2 write-back: the
 // compiler's system-scope release would write back the whole L2 - megabytes of dirty walker rows that
 // no peer ever reads - and costs ~5 us per flag.
+// Release side: the asm wait (with its memory clobber: also a compiler barrier) holds the flag back until every
+// earlier store of this wave has been ACKNOWLEDGED; a write-through system-scope store is acknowledged by the memory it
+// targets (the peer's HBM over xGMI), i.e. when it is visible to a cache-bypassing reader there.  The flag itself is a
+// system-scope store behind that wait.  (Assumption stated in DESIGN.md 6.1; the self-test hens_pipe_selftest checks
+// the three access patterns on the actual node before the pipeline is used.)
 __device__ __forceinline__ void pipe_raise(unsigned* f, uint32_t v) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -229,7 +234,10 @@ __device__ __forceinline__ bool pipe_last_ticket(unsigned* ticket, uint32_t targ
 __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, long long budget, unsigned* err,
                                           unsigned long long* stats = nullptr) {
     // the wall clock (s_memrealtime) takes ~1.5 us to read: start it only if the flag is not there yet
-    if (!stats && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= target) return;
+    if (!stats && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= target) {
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        return;
+    }
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
         __builtin_amdgcn_s_sleep(2);
@@ -242,6 +250,10 @@ __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, lo
         atomicAdd(stats, (unsigned long long)(wall_clock64() - t0));
         atomicAdd(stats + 1, 1ull);
     }
+    // Acquire side of the hand-off.  Hardware: the wave has waited for the flag's value (the branch depends on it), and
+    // everything it reads from a peer afterwards is a system-scope (sc0 sc1) load that no cache serves, issued after
+    // this point in program order.  Compiler: nothing may be moved above the spin.
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
 }
 
 // Arrive / collect: every workgroup, once its own stores have completed, adds itself to the ticket and leaves
