@@ -1,0 +1,75 @@
+"""BASELINE configs 3 and 5 at FULL size on one GPU (-m gpu).
+
+config 3 = (ntemps 64, nwalkers 16384, ndim 64) dense Gaussian: two iterations of one context holding the whole ladder
+(the fused two-launch path with 2-column blocks) replayed through the oracle at full size; and the 64-rung ladder as 8
+shards of 8 rungs stepping through the pipeline against one context, bit-identical - at nwalkers = 2048, because 8 ranks
+that share ONE GPU starve each other's flag waits at full width (on a node every rank has a GPU of its own).  config 5 = (32, 8192, 128) Rosenbrock with the StretchMove + GaussianMove mix:
+properties at full size (both moves used, low acceptance, state consistent with its own re-evaluation) and an oracle
+replay of one 4-rung shard of it."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import test_hip_replay as rp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "pipeline_worker.py")
+KEYS = ("x", "L", "P", "betas", "accepted", "swaps_total", "swaps_last")
+
+
+def _worker(args, timeout=900):
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HENS_PIPE_TIMEOUT_S="60", PIPE_TEST_DELAY="0", PIPE_TEST_MODEL="gauss")
+    r = subprocess.run([sys.executable, WORKER] + [str(a) for a in args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_config3_ladder_single_context_equals_8_shard_pipeline(tmp_path):
+    T, W, D, iters = 64, 2048, 64, 4
+    _worker(["single", T, W, D, iters, tmp_path / "single.npz"])
+    _worker(["local", 8, T, W, D, iters, tmp_path / "local.npz"])
+    with np.load(tmp_path / "single.npz") as a, np.load(tmp_path / "local.npz") as b:
+        for k in KEYS:
+            assert np.array_equal(a[k], b[k]), f"{k}: whole ladder vs 8 shards"
+        assert a["swaps_total"].min() > 0 and a["accepted"].sum() > 0
+        assert np.isfinite(a["x"]).all() and (np.abs(a["x"]) <= 6.0).all()
+
+
+def test_config3_full_size_replayed_through_the_oracle():
+    rp._run_case(64, 16384, 64, calls=(2,))
+
+
+def test_config5_full_size_rosenbrock_move_mix():
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import RosenbrockLikelihood
+    from eryn_amd.moves.tempering import make_ladder
+    T, W, D = 32, 8192, 128
+    eng = HipEnsemble(T, W, D, RosenbrockLikelihood(D), -5.0, 5.0, seed=9)
+    x0 = np.clip(1.0 + 0.05 * np.random.RandomState(2).randn(T, W, D), -4.9, 4.9)
+    eng.upload(x0, betas=make_ladder(D, ntemps=T))
+    eng.eval_state()
+    eng.set_mh_proposal("iso", 5e-3, 0.5)
+    eng.step(40)
+    eng.synchronize()
+    x, L, P, betas = eng.download()
+    c, m = eng.counters(), eng.mh_counters()
+    assert c["num_proposals"] > 5 and m["num_proposals"] > 5 and c["num_proposals"] + m["num_proposals"] == 40
+    acc_s = c["accepted"].mean() / c["num_proposals"]
+    acc_m = m["accepted"].mean() / m["num_proposals"]
+    assert 0.0 < acc_s < 0.6 and 0.0 < acc_m < 0.95, (acc_s, acc_m)           # the low-acceptance stress target
+    assert np.isfinite(x).all() and (np.abs(x) <= 5.0).all() and np.isfinite(L).all()
+    assert betas[0] == 1.0 and np.all(np.diff(betas) < 0) and c["swaps_total"].sum() > 0
+    eng.upload(x, betas=betas)                                              # the stored logL / logP are those of the stored x
+    eng.eval_state()
+    _, L2, P2, _ = eng.download(want_x=False)
+    np.testing.assert_allclose(L2, L, rtol=1e-12, atol=0)
+    assert np.array_equal(P2, P)
+    eng.close()
+
+
+def test_config5_shard_replayed_through_the_oracle():
+    kinds = rp._run_case(4, 8192, 128, like_kind="rosen", box=5.0, calls=(4,), x_scale=0.3, mh=("iso", 2e-3, 0.5))
+    assert "mh" in kinds and "stretch" in kinds

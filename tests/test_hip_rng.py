@@ -1,0 +1,133 @@
+"""Evidence for the production (Philox) randomness (-m gpu): the draws hens_step consumes, exported with
+hens_debug_draws, against the distributions the reference draws from (red_blue.py:119-124, stretch.py:93-99,
+tempering.py:526-535), and a config-2-scale run against the analytic tempered Gaussian."""
+import numpy as np
+import pytest
+
+from tests import parity_utils as pu
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(T, W, D, seed):
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import GaussianLikelihood
+    mu, invcov = pu.gaussian_problem(D)
+    return HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=seed)
+
+
+def _chi2_z(counts, expected):
+    """chi-square statistic as a z-score (large dof: chi2 ~ N(dof, 2 dof))."""
+    chi2 = float(((counts - expected) ** 2 / expected).sum())
+    dof = counts.size - 1
+    return (chi2 - dof) / np.sqrt(2.0 * dof)
+
+
+@pytest.mark.parametrize("T,W,iters", [(2, 64, 6000), (4, 100, 4000)])
+def test_complement_and_matching_pairs_are_uniform(T, W, iters):
+    """Every walker's complement is uniform over the OTHER walkers of its rung (uniform balanced split x uniform index),
+    and the cascade matches slot a of rung i with slot b of rung i-1 uniformly; consecutive iterations' labels are
+    independent.  ~1e4+ keys per case."""
+    eng = _engine(T, W, 8, seed=123)
+    pair = np.zeros((W, W))
+    match = np.zeros((W, W))
+    same_label = 0
+    prev = None
+    N0 = (W + 1) // 2
+    for it in range(iters):
+        d = eng.debug_draws(it)
+        own, cw, slot = d["own"].astype(np.int64), d["cw"].astype(np.int64), d["pt_slot"].astype(np.int64)
+        np.add.at(pair, (own.ravel(), cw.ravel()), 1)
+        for i in range(1, T):
+            np.add.at(match, (slot[i], slot[i - 1]), 1)
+        lab = np.zeros((T, W), dtype=np.int8)
+        lab[np.arange(T)[:, None], own[:, N0:]] = 1
+        if prev is not None:
+            same_label += int((lab == prev).sum())
+        prev = lab
+    eng.close()
+    assert np.all(np.diag(pair) == 0)
+    off = pair[~np.eye(W, dtype=bool)]
+    n_picks = iters * T * W
+    assert abs(_chi2_z(off, n_picks / (W * (W - 1)))) < 5.0, "complement pairs are not uniform"
+    assert abs(_chi2_z(match.ravel(), iters * (T - 1) * W / W ** 2)) < 5.0, "PT matching is not uniform"
+    # a walker keeps its label between two INDEPENDENT balanced labellings with probability P(0)^2 + P(1)^2 (the
+    # binomial variance below is an upper bound: labels inside one labelling are negatively correlated)
+    p_same = (N0 / W) ** 2 + ((W - N0) / W) ** 2
+    n = (iters - 1) * T * W
+    z = (same_label - n * p_same) / np.sqrt(n * p_same * (1 - p_same))
+    assert abs(z) < 5.0, f"labels of consecutive iterations are correlated (z = {z:.1f})"
+
+
+def test_large_ensemble_draws_binned():
+    """W = 4096 (config 2's rung size): complement index differences and matching displacements in 64 bins each"""
+    T, W, iters = 2, 4096, 300
+    eng = _engine(T, W, 32, seed=77)
+    diff = np.zeros(64)
+    disp = np.zeros(64)
+    u_all = []
+    for it in range(iters):
+        d = eng.debug_draws(it)
+        own, cw, slot = d["own"].astype(np.int64), d["cw"].astype(np.int64), d["pt_slot"].astype(np.int64)
+        diff += np.bincount((((cw - own) % W) * 64 // W).ravel(), minlength=64)
+        disp += np.bincount((((slot[0] - slot[1]) % W) * 64 // W), minlength=64)
+        u_all.append(np.concatenate([d["u_zz"].ravel()[::16], d["u_acc"].ravel()[::16], d["u_swap"].ravel()[::16]]))
+    eng.close()
+    # (cw - own) mod W is uniform over 1 .. W-1: bin 0 holds W/64 - 1 of the W - 1 values
+    e = np.full(64, diff.sum() * (W / 64) / (W - 1))
+    e[0] = diff.sum() * (W / 64 - 1) / (W - 1)
+    assert abs(_chi2_z(diff, e)) < 5.0
+    assert abs(_chi2_z(disp, disp.sum() / 64)) < 5.0
+    u = np.concatenate(u_all)
+    hist = np.bincount((u * 100).astype(int), minlength=100)[:100]
+    assert abs(_chi2_z(hist, u.size / 100)) < 5.0 and 0.0 <= u.min() and u.max() < 1.0
+
+
+def test_config2_scale_stationary_distribution():
+    """16 x 4096 x 32 on a FIXED ladder (adaptive = False, so that every rung has one target for the whole run): every
+    rung whose tempered Gaussian sits well inside the box has <logL> = -D / (2 beta) (x ~ N(mu, Sigma / beta)), the cold
+    chain has the right mean and covariance, swap and accept rates are sane.  Errors from batch means over snapshots."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves.tempering import make_ladder
+    T, W, D = 16, 4096, 32
+    mu, invcov = pu.gaussian_problem(D)
+    cov = np.linalg.inv(invcov)
+    betas0 = make_ladder(D, ntemps=T)
+    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, adaptive=False)
+    # start every rung from its own target (no long expansion phase for the hot rungs), then burn in
+    rs = np.random.RandomState(1)
+    Lc = np.linalg.cholesky(cov)
+    x0 = mu + (rs.randn(T, W, D) @ Lc.T) / np.sqrt(betas0)[:, None, None]
+    eng.upload(np.clip(x0, -49.0, 49.0), betas=betas0)
+    eng.eval_state()
+    eng.step(600)
+    eng.reset_counters()
+    nsnap, gap = 80, 25
+    Lm = np.zeros((nsnap, T))
+    xs = []
+    for k in range(nsnap):
+        eng.step(gap)
+        x, L, P, betas = eng.download()
+        Lm[k] = L.mean(axis=1)
+        xs.append(x[0])
+    c = eng.counters()
+    eng.close()
+    assert np.array_equal(betas, betas0)
+    ok = np.sqrt(np.diag(cov).max() / betas) * 6 < 50.0          # rungs whose 6-sigma extent fits the +-50 box
+    assert ok.sum() >= 8
+    expect = -D / (2 * betas)
+    # batch means: the snapshots are `gap` iterations apart; allow for residual correlation with a factor 2 on the error
+    se = 2.0 * Lm.std(axis=0, ddof=1) / np.sqrt(nsnap)
+    z = (Lm.mean(axis=0) - expect) / se
+    assert np.all(np.abs(z[ok]) < 5.0), f"<logL> per rung off: z = {np.round(z, 1)} (ok = {ok})"
+    rel = np.abs(Lm.mean(axis=0) - expect) / np.abs(expect)
+    assert np.all(rel[ok] < 0.01), rel
+    xc = np.concatenate(xs)
+    assert np.abs(xc.mean(0) - mu).max() < 6 * np.sqrt(np.diag(cov).max() / (len(xc) / 20.0))
+    relc = np.linalg.norm(np.cov(xc.T) - cov) / np.linalg.norm(cov)
+    assert relc < 0.05, f"cold-chain covariance off by {relc:.3f}"
+    frac = c["swaps_total"] / W / (nsnap * gap)
+    assert np.all((frac > 0.05) & (frac < 0.7)), frac
+    acc = c["accepted"].mean(axis=1) / c["num_proposals"]
+    assert np.all((acc > 0.1) & (acc < 0.7)), acc
