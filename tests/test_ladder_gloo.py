@@ -90,3 +90,64 @@ def test_rung_partition():
     assert list(rk) == [0, 0, 1, 1, 2, 2, 3, 3] and b == [(0, 2), (2, 4), (4, 6), (6, 8)]
     with pytest.raises(ValueError):
         rung_partition(6, 4)
+
+
+# ---- LadderPipeline construction is failure-atomic across ranks (world_size 2, gloo) --------------------------------
+class _FakeEngine:
+    """The three calls LadderPipeline.__init__ makes on a shard engine; `fail` makes this rank's step raise."""
+
+    def __init__(self, fail):
+        self.fail = fail
+
+    def pipe_init(self, nranks, rank):
+        if self.fail == "init":
+            raise RuntimeError("hipIpcGetMemHandle refused")
+        return bytes([rank]) * 128
+
+    def pipe_connect(self, handles):
+        assert len(handles) == 2 * 128
+        if self.fail == "connect":
+            raise RuntimeError("hipIpcOpenMemHandle refused")
+
+
+def _pipe_worker(rank, world, port, fail_rank, fail, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from eryn_amd.ladder import LadderPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            LadderPipeline(_FakeEngine(fail if rank == fail_rank else None), rank, world, dist=dist, selftest=False)
+            out = "ok"
+        except RuntimeError as exc:
+            out = f"raised: {exc}"
+        # every rank is still in step with the others: a further collective completes
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        q.put((rank, out, float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [None, "init", "connect"])
+def test_ladder_pipeline_constructor_is_failure_atomic(fail):
+    """One rank's pipe_init / pipe_connect fails: EVERY rank must raise (nobody is left inside a collective its peer
+    never enters), and the process group must still be usable afterwards (the bench's fallback relies on it)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, 1, fail, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, total in res:
+        assert total == world
+        if fail is None:
+            assert out == "ok"
+        else:
+            assert out.startswith("raised") and "ranks [1]" in out, out
