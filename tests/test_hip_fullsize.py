@@ -2,8 +2,9 @@
 
 config 3 = (ntemps 64, nwalkers 16384, ndim 64) dense Gaussian: two iterations of one context holding the whole ladder
 (the fused two-launch path with 2-column blocks) replayed through the oracle at full size; and the 64-rung ladder as 8
-shards of 8 rungs stepping through the pipeline against one context, bit-identical - at nwalkers = 2048, because 8 ranks
-that share ONE GPU starve each other's flag waits at full width (on a node every rank has a GPU of its own).  config 5 = (32, 8192, 128) Rosenbrock with the StretchMove + GaussianMove mix:
+shards of 8 rungs stepping through the pipeline against one context, bit-identical - at nwalkers = 512: the kernels of 8
+ranks that share ONE GPU must all be resident at once (a resident kernel that spins on a flag whose producer cannot get a CU
+never finishes; at nwalkers = 2048 this deadlocks two runs out of three - on a node every rank has a GPU of its own).  config 5 = (32, 8192, 128) Rosenbrock with the StretchMove + GaussianMove mix:
 properties at full size (both moves used, low acceptance, state consistent with its own re-evaluation) and an oracle
 replay of one 4-rung shard of it."""
 import os
@@ -28,7 +29,7 @@ def _worker(args, timeout=900):
 
 
 def test_config3_ladder_single_context_equals_8_shard_pipeline(tmp_path):
-    T, W, D, iters = 64, 2048, 64, 4
+    T, W, D, iters = 64, 512, 64, 6
     _worker(["single", T, W, D, iters, tmp_path / "single.npz"])
     _worker(["local", 8, T, W, D, iters, tmp_path / "local.npz"])
     with np.load(tmp_path / "single.npz") as a, np.load(tmp_path / "local.npz") as b:
