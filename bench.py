@@ -216,6 +216,51 @@ def run_single(args):
     return out
 
 
+def run_cfg5(args):
+    """BASELINE config 5 on ONE GPU (the reference config names 8; the ladder would shard as in config 3): Rosenbrock
+    ndim = 128, ntemps = 32, nwalkers = 8192, StretchMove + GaussianMove mixed 50 / 50 by weight - the low-acceptance
+    stress case.  One step = one iteration of the mix (ensemble.py:971) + swaps + adaptation."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import RosenbrockLikelihood
+    from eryn_amd.moves.tempering import make_ladder
+    T, W, D = args.ntemps or 32, args.nwalkers or 8192, args.ndim or 128
+    eng = HipEnsemble(T, W, D, RosenbrockLikelihood(D), -5.0, 5.0, seed=2024)
+    x0 = np.clip(1.0 + 0.05 * np.random.RandomState(1).randn(T, W, D), -4.9, 4.9)
+    eng.upload(x0, betas=make_ladder(D, ntemps=T))
+    eng.eval_state()
+    eng.set_mh_proposal("iso", 5e-3, 0.5)
+    eng.step(args.warmup)
+    eng.synchronize()
+    eng.reset_counters()
+    times, _ = timed_blocks(eng.step, eng.synchronize, args.steps)
+    dt = float(np.median(times))
+    c, m = eng.counters(), eng.mh_counters()
+    f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps * BLOCKS, 1)))
+    eng.set_profiling(True)
+    eng.step(args.steps)
+    eng.synchronize()
+    tm = eng.timing()
+    eng.close()
+    value = T * W * args.steps / dt
+    roof = kernel_roofline(tm, T, T, W, D, f_sw)
+    whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
+    roof.update(whole_path_GBps=whole, whole_path_frac=whole / HBM_PEAK_GBS)
+    return {
+        "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Rosenbrock logL, move mix", "value": value,
+        "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "block_ms": [t_ * 1e3 for t_ in times],
+        "timing": f"median of {BLOCKS} blocks of {args.steps} steps",
+        "config": {"workload": f"config 5 on one GPU: Rosenbrock ndim={D}, ntemps={T}, nwalkers={W}, StretchMove(a=2) + "
+                               f"GaussianMove(iso, sigma=5e-3) 50/50 + adaptive PT, Philox RNG", "ntemps": T, "nwalkers": W,
+                   "ndim": D, "stretch_acceptance": float(c["accepted"].mean() / max(c["num_proposals"], 1)),
+                   "gaussian_acceptance": float(m["accepted"].mean() / max(m["num_proposals"], 1)),
+                   "stretch_iterations": int(c["num_proposals"]), "gaussian_iterations": int(m["num_proposals"]),
+                   "swap_fraction": f_sw},
+        "roofline": roof,
+    }
+
+
 def run_cfg4(args):
     """BASELINE config 4: reversible-jump leaf packing - 2 branches (Gaussian pulses + sine waves, the reference tests'
     model) x nleaves_max = 10, ntemps = 8, nwalkers = 2048, 500 data points - on one GPU.  One step = in-model Gaussian
@@ -457,7 +502,7 @@ def main():
     ap.add_argument("--ntemps", type=int, default=None)
     ap.add_argument("--nwalkers", type=int, default=None)
     ap.add_argument("--ndim", type=int, default=None)
-    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-base", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -469,6 +514,10 @@ def main():
             raise SystemExit("bench.py --workload cfg4 is a single-GPU workload")
         args.steps = args.steps or 200
         print(json.dumps(run_cfg4(args)), flush=True)
+        return
+    if args.workload == "cfg5" and n == 1:
+        args.steps = args.steps or 500
+        print(json.dumps(run_cfg5(args)), flush=True)
         return
     if n > 1 and world == 0:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver would

@@ -149,10 +149,14 @@ __device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, ui
     const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
     const double u1 = 1.0 - u01(d.x, d.y);                            // (0, 1]
     const double u2 = u01(d.z, d.w);
-    const double r = sqrt(-2.0 * log(u1));
-    double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
-    return double2{r * cs, r * sn};
+    // The transcendental part in single precision on the hardware units (v_log_f32, v_sin_f32 / v_cos_f32 take the angle in
+    // revolutions): a proposal step needs the N(0, 1) shape, not 53 bits - the FP64 log / sqrt / sincospi made a launch
+    // that draws its normals in place ALU-bound (config 5: 33.5 M normals per launch).  The proposal stays symmetric
+    // (cos / sin of a uniform angle), which is all detailed balance asks of it.
+    const float lf = __builtin_amdgcn_logf((float)u1) * 0.69314718056f;       // ln u1 <= 0
+    const float r = __builtin_sqrtf(-2.0f * lf);
+    const float ang = (float)u2;
+    return double2{(double)(r * __builtin_amdgcn_cosf(ang)), (double)(r * __builtin_amdgcn_sinf(ang))};
 }
 __device__ __forceinline__ double mh_uniform(uint64_t seed, uint64_t it, uint32_t wid) {         // mh.py:157
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_ACC};
