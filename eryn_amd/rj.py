@@ -165,3 +165,206 @@ class RJEngine:
         check(self.lib.hens_rj_get_counters(self.ctx, ptr(bd), C.byref(n_mh), C.byref(n_bd)), self.ctx)
         c.update(accepted_mh=c["accepted"], accepted_bd=bd, num_mh=int(n_mh.value), num_bd=int(n_bd.value))
         return c
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Sampler-level mirror: the reference's multi-branch ``EnsembleSampler`` contract for this path
+# ---------------------------------------------------------------------------------------------------------------------
+class TemplateLikelihood:
+    """Stands where the reference takes ``log_like_fn`` + ``args=[t, y, sigma]`` (tests/test_eryn.py:79-92, 467-470):
+    the template model lives inside the kernel.  ``kinds``: ``{branch_name: "pulse" | "sine"}``."""
+
+    def __init__(self, kinds, t, y, sigma):
+        self.kinds = {k: _KINDS[v] for k, v in kinds.items()}
+        self.t, self.y, self.sigma = f64(t), f64(y), float(sigma)
+
+
+class GaussianLeafMove:
+    """``GaussianMove(cov_all)`` of the reference on leaf-packing records (gaussian.py:9-66): ``cov_all[name]`` is the
+    3 x 3 proposal covariance of a leaf of that branch (the reference's ``_proposal``: ``multivariate_normal``)."""
+
+    def __init__(self, cov_all):
+        self.cov = {k: np.atleast_2d(np.asarray(v, dtype=np.float64)) for k, v in cov_all.items()}
+        for k, c in self.cov.items():
+            if c.shape != (3, 3):
+                raise NotImplementedError("a leaf's proposal covariance must be a 3 x 3 matrix")
+        self.accepted, self.num_proposals = None, 0
+
+
+class RJEnsembleSampler:
+    """``EnsembleSampler(nwalkers, ndims, log_like_fn, priors, tempering_kwargs=..., branch_names=..., nleaves_max=...,
+    nleaves_min=..., moves=GaussianMove(cov), rj_moves="separate_branches")`` (ensemble.py:211-681) for the template model,
+    stepping on the MI355X.  One iteration = one in-model move + one RJ move of a uniformly chosen branch
+    (ensemble.py:963-1024 with the default ``num_repeats_in_model = num_repeats_rj = 1``).
+
+    rng="numpy":  the reference's streams (the sampler-owned RandomState cloned from the global ``np.random`` at
+                  construction + the global stream) are drawn on the host IN THE REFERENCE'S ORDER and handed to the device:
+                  same seeds => the reference's chain (tests/test_hip_rj.py against the rj* fixtures).
+    rng="philox": device-side draws, ``thin_by`` iterations per host call (``hens_rj_step``)."""
+
+    def __init__(self, nwalkers, ndims, log_like_fn, priors, tempering_kwargs=None, nbranches=None, branch_names=None,
+                 nleaves_max=None, nleaves_min=None, moves=None, rj_moves="separate_branches", rng="numpy", seed=None,
+                 device_id=0, **unused):
+        from .moves.tempering import TemperatureControl
+        if not isinstance(log_like_fn, TemplateLikelihood):
+            raise NotImplementedError("the device RJ path runs the template model: pass an eryn_amd.rj.TemplateLikelihood")
+        if rj_moves != "separate_branches":
+            raise NotImplementedError('rj_moves must be "separate_branches" (one DistributionGenerateRJ per branch)')
+        if not isinstance(moves, GaussianLeafMove):
+            raise NotImplementedError("the in-model move must be an eryn_amd.rj.GaussianLeafMove")
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.branch_names = list(branch_names if branch_names is not None else ndims.keys())
+        if nbranches is not None and nbranches != len(self.branch_names):
+            raise ValueError("nbranches does not match branch_names")
+        nleaves_min = nleaves_min or {k: 0 for k in self.branch_names}            # ensemble.py:388-389
+        self.nwalkers, self.ndims = int(nwalkers), dict(ndims)
+        self.nleaves_max, self.nleaves_min = dict(nleaves_max), dict(nleaves_min)
+        self.branches = []
+        for k in self.branch_names:
+            if self.ndims[k] != 3:
+                raise NotImplementedError("a leaf of the template model has three parameters")
+            pr = priors[k]
+            box = pr.box_bounds() if hasattr(pr, "box_bounds") else \
+                ([pr[i].min_val for i in range(3)], [pr[i].max_val for i in range(3)])
+            self.branches.append(TemplateBranch(k, log_like_fn.kinds[k], list(zip(box[0], box[1])), self.nleaves_max[k],
+                                                self.nleaves_min[k]))
+        total_ndim = sum(self.nleaves_max[k] * self.ndims[k] for k in self.branch_names)     # ensemble.py:325-329
+        tk = dict(tempering_kwargs or {})
+        if not tk:
+            raise NotImplementedError("the device RJ path is tempered (pass tempering_kwargs=dict(ntemps=...))")
+        self.temperature_control = tc = TemperatureControl(total_ndim, self.nwalkers, **tk)
+        self.ntemps = tc.ntemps
+        self.moves, self.rng = [moves], rng
+        if seed is None:
+            seed = int(np.random.randint(0, 2**31 - 1)) if rng == "philox" else 0
+        self.engine = RJEngine(self.ntemps, self.nwalkers, self.branches, log_like_fn.t, log_like_fn.y, log_like_fn.sigma,
+                               seed=seed, device_id=device_id, adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag,
+                               adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation)
+        if rng == "philox":
+            self.engine.set_mh_scale(np.stack([np.sqrt(np.diag(moves.cov[k])) for k in self.branch_names]))
+        moves.accepted = np.zeros((self.ntemps, self.nwalkers))
+        self.rj_accepted = [np.zeros((self.ntemps, self.nwalkers)) for _ in self.branch_names]
+        self.rj_num_proposals = [0 for _ in self.branch_names]
+        self._random = np.random.mtrand.RandomState()
+        self._random.set_state(np.random.get_state())          # R := snapshot of the global stream (ensemble.py:604,651-652)
+        self.iteration, self.chain = 0, []
+        self._previous_state = None
+
+    # -- the reference's evaluation entry points, with inds (ensemble.py:1127-1217, 1219-1545) -----------------------
+    def _eval(self, coords, inds):
+        self.engine.upload(coords, inds, betas=self.temperature_control.betas)
+        self.engine.eval_state()
+        _, _, L, P, _ = self.engine.download()
+        return L, P
+
+    def compute_log_prior(self, coords, inds=None, **kw):
+        return self._eval(coords, inds)[1]
+
+    def compute_log_like(self, coords, inds=None, logp=None, **kw):
+        return self._eval(coords, inds)[0], None
+
+    # -- one iteration with the reference's draws ------------------------------------------------------------------------
+    def _iteration_numpy(self):
+        eng, tc, R, T, W = self.engine, self.temperature_control, self._random, self.ntemps, self.nwalkers
+        mv = self.moves[0]
+        x, inds, _, _, _ = eng.download()
+        # in-model move: move choice (ensemble.py:971), per branch one multivariate_normal over the packed leaves
+        # (gaussian.py:96-104, 265-268), the accept uniforms (mh.py:157)
+        R.choice(1, p=np.ones(1))
+        steps = {}
+        for b in self.branches:
+            n = int(inds[b.name].sum())
+            s = np.zeros(x[b.name].shape)
+            s[inds[b.name]] = 1.0 * R.multivariate_normal(np.zeros(3), mv.cov[b.name], size=n)
+            steps[b.name] = s
+        acc = eng.mh_step(steps, R.rand(T, W))
+        mv.accepted += acc
+        mv.num_proposals += 1
+        iperm, i1perm, u = tc.draw_swap_randoms()                               # mh.py:190-191
+        _, swaps = eng.pt_sweep(iperm, i1perm, u, adapt=bool(tc.adaptive))
+        tc.swaps_accepted = swaps
+        if tc.adaptive:
+            tc.time += 1
+        # reversible jump on one branch (ensemble.py:988-990; distgenrj.py:35-222)
+        x, inds, _, _, betas = eng.download()
+        tc.betas = betas
+        nb = len(self.branches)
+        bi = int(R.choice(nb, p=np.full(nb, 1.0 / nb)))
+        b = self.branches[bi]
+        ib = inds[b.name]
+        nleaves = ib.sum(axis=-1)
+        change = np.zeros((T, W), dtype=np.int64)
+        leaf = np.zeros((T, W), dtype=np.int64)
+        birth = np.zeros((T, W, 3))
+        if b.nleaves_min != b.nleaves_max:
+            change = R.choice([-1, +1], size=nleaves.shape)                     # distgenrj.py:63-66
+            change = (change * ((nleaves != b.nleaves_min) & (nleaves != b.nleaves_max))
+                      + (+1) * (nleaves == b.nleaves_min) + (-1) * (nleaves == b.nleaves_max))       # :69-73
+            for t in range(T):                                                  # one draw per walker, in order (:85-121)
+                for w in range(W):
+                    if change[t, w] == +1:
+                        leaf[t, w] = R.choice(np.where(~ib[t, w])[0])
+                    elif change[t, w] == -1:
+                        leaf[t, w] = R.choice(np.where(ib[t, w])[0])
+            nbirth = int((change == +1).sum())
+            draws = np.zeros((nbirth, 3))
+            for d in range(3):                                                  # ProbDistContainer.rvs: GLOBAL stream, per parameter
+                draws[:, d] = np.random.rand(nbirth) * (b.hi[d] - b.lo[d]) + b.lo[d]      # prior.py:60-66, 432-497
+            birth[change == +1] = draws
+        racc = eng.bd_step(bi, change, leaf, birth, R.rand(T, W))               # rj.py:332
+        self.rj_accepted[bi] += racc
+        self.rj_num_proposals[bi] += 1
+        iperm, i1perm, u = tc.draw_swap_randoms()
+        eng.pt_sweep(iperm, i1perm, u, adapt=False)                             # rj.py:381-382
+        return acc, racc
+
+    def _state(self, nan_fill=False):
+        from .state import State
+        x, inds, L, P, betas = self.engine.download(nan_fill=nan_fill)
+        return State(x, inds=inds, log_like=L, log_prior=P, betas=betas)
+
+    def run_mcmc(self, initial_state, nsteps, burn=None, thin_by=1, store=True, **unused):
+        """ensemble.py:1047-1125; returns the last State.  Stored steps keep the reference's NaN fill of unused leaves
+        (backends/backend.py:1049-1059) in ``self.chain`` (a list of States)."""
+        from .state import State
+        tc = self.temperature_control
+        if initial_state is None:
+            if self._previous_state is None:
+                raise ValueError("Cannot have `initial_state=None` if run_mcmc has never been called.")
+            initial_state = self._previous_state
+        st = State(initial_state, copy=True)
+        coords, inds = st.branches_coords, st.branches_inds
+        for b in self.branches:
+            if coords[b.name].shape != (self.ntemps, self.nwalkers, b.nleaves_max, 3):
+                raise ValueError("incompatible input dimensions")
+        if st.betas is not None:
+            tc.betas = np.array(st.betas, dtype=np.float64)
+        if st.log_like is None or st.log_prior is None:
+            L, P = self._eval(coords, inds)
+            st.log_like = L if st.log_like is None else st.log_like
+            st.log_prior = P if st.log_prior is None else st.log_prior
+        if np.any(np.isinf(st.log_prior)):
+            raise ValueError("The initial log_prior was +/- infinite")
+        self.engine.upload(coords, inds, st.log_like, st.log_prior, tc.betas)
+        self.engine.set_adapt_time(tc.time)
+        for phase, n, keep in (("burn", burn or 0, False), ("run", nsteps, store)):
+            for _ in range(n):
+                if self.rng == "philox":
+                    self.engine.step(thin_by if phase == "run" else 1)
+                else:
+                    for _ in range(thin_by if phase == "run" else 1):
+                        self._iteration_numpy()
+                if keep:
+                    self.chain.append(self._state(nan_fill=True))
+                self.iteration += 1
+        out = self._state()
+        tc.betas = out.betas
+        if self.rng == "philox":
+            c = self.engine.counters()
+            tc.time, tc.swaps_accepted = c["adapt_time"], c["swaps_last"]
+        self._previous_state = out
+        return out
+
+    def get_nleaves(self):
+        return {b.name: np.stack([s.branches[b.name].nleaves for s in self.chain]) for b in self.branches}

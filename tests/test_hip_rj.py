@@ -148,3 +148,78 @@ def test_rj_philox_run_config4_shape():
     np.testing.assert_allclose(L2, L1, rtol=1e-12, atol=0)
     assert np.array_equal(P2, P1)
     eng.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rj_sampler_reproduces_the_reference_chain(golden_dir, name):
+    """The sampler-level mirror (eryn_amd.rj.RJEnsembleSampler, the reference's constructor contract for this path)
+    free-running with the reference's seeds lands on the reference's chain: every leaf slot (dead ones included) and
+    log-prior exact, leaf masks exact, log-like rtol 1e-12, betas rtol 1e-13, accept counters exact."""
+    from eryn_amd.prior import uniform_dist
+    from eryn_amd.rj import GaussianLeafMove, RJEnsembleSampler, TemplateLikelihood
+    from eryn_amd.state import State
+    fx = load_rj(golden_dir, name)
+    names = ["gauss", "sine"]
+    n = int(fx["nsteps"])
+    priors = {"gauss": {i: uniform_dist(*fx["gauss_box"][i]) for i in range(3)},
+              "sine": {i: uniform_dist(*fx["sine_box"][i]) for i in range(3)}}
+    cov = {k: np.diag(np.ones(3)) * float(fx["cov_factor"]) for k in names}
+    np.random.seed(int(fx["seed_construct"]))          # R := snapshot of the global stream at construction
+    s = RJEnsembleSampler(int(fx["W"]), {k: 3 for k in names}, TemplateLikelihood({"gauss": "pulse", "sine": "sine"},
+                          fx["t"], fx["y"], float(fx["sigma"])), priors, tempering_kwargs=dict(ntemps=int(fx["T"])),
+                          nbranches=2, branch_names=names, nleaves_max=dict(zip(names, map(int, fx["nl_max"]))),
+                          nleaves_min=dict(zip(names, map(int, fx["nl_min"]))), moves=GaussianLeafMove(cov),
+                          rj_moves="separate_branches")
+    assert np.array_equal(s.temperature_control.betas, fx["betas0"])
+    coords = {k: fx[f"x0_{k}"] for k in names}
+    inds = {k: fx[f"inds0_{k}"] for k in names}
+    logp = s.compute_log_prior(coords, inds=inds)
+    logl = s.compute_log_like(coords, inds=inds, logp=logp)[0]
+    assert np.array_equal(logp, fx["P0"])
+    np.testing.assert_allclose(logl, fx["L0"], rtol=RTOL_L, atol=0)
+    np.random.seed(int(fx["seed_run"]))
+    last = s.run_mcmc(State(coords, log_like=fx["L0"], log_prior=logp, inds=inds), n, store=True)
+    pre = f"it{n - 1}_rj_"
+    for k in names:
+        assert np.array_equal(last.branches[k].inds, fx[pre + f"inds_{k}"]), f"inds of {k}"
+        assert np.array_equal(last.branches[k].coords, fx[pre + f"x_{k}"]), f"coordinates of {k}"
+    assert np.array_equal(last.log_prior, fx[pre + "P"])
+    np.testing.assert_allclose(last.log_like, fx[pre + "L"], rtol=RTOL_L, atol=0)
+    np.testing.assert_allclose(last.betas, fx[pre + "betas"], rtol=1e-13, atol=0)
+    assert np.array_equal(s.moves[0].accepted, fx["mh_accepted_total"])
+    assert np.array_equal(np.stack(s.rj_accepted), fx["rj_accepted_total"])
+    assert np.array_equal(np.array(s.rj_num_proposals), fx["rj_num_proposals"])
+    # stored steps carry the reference's NaN fill of unused leaves (backend.py:1049-1059)
+    assert len(s.chain) == n
+    mid = s.chain[n // 2]
+    for k in names:
+        assert np.array_equal(mid.branches[k].inds, fx[f"it{n // 2}_rj_inds_{k}"])
+        assert np.isnan(mid.branches[k].coords[~mid.branches[k].inds]).all()
+    s.engine.close()
+
+
+def test_rj_sampler_philox_mode():
+    from eryn_amd.prior import uniform_dist
+    from eryn_amd.rj import GaussianLeafMove, RJEnsembleSampler, TemplateLikelihood
+    from eryn_amd.state import State
+    T, W, N = 4, 64, 100
+    t = np.linspace(-1, 1, N)
+    rs = np.random.RandomState(3)
+    y = 3.0 * np.exp(-((t - 0.1) ** 2) / (2 * 0.1 ** 2)) + 1.0 * np.sin(2 * np.pi * 5.0 * t + 1.0) + 1.5 * rs.randn(N)
+    names = ["gauss", "sine"]
+    priors = {"gauss": {0: uniform_dist(2.5, 3.5), 1: uniform_dist(-1, 1), 2: uniform_dist(0.01, 0.21)},
+              "sine": {0: uniform_dist(0.5, 1.5), 1: uniform_dist(1.0, 20.0), 2: uniform_dist(0.0, 2 * np.pi)}}
+    s = RJEnsembleSampler(W, {k: 3 for k in names}, TemplateLikelihood({"gauss": "pulse", "sine": "sine"}, t, y, 1.5), priors,
+                          tempering_kwargs=dict(ntemps=T), branch_names=names, nleaves_max={"gauss": 4, "sine": 3},
+                          moves=GaussianLeafMove({k: np.eye(3) * 1e-4 for k in names}), rng="philox", seed=8)
+    coords = {"gauss": np.zeros((T, W, 4, 3)), "sine": np.zeros((T, W, 3, 3))}
+    inds = {"gauss": np.zeros((T, W, 4), dtype=bool), "sine": np.zeros((T, W, 3), dtype=bool)}
+    coords["gauss"][:, :, 0] = [3.0, 0.1, 0.1]
+    coords["sine"][:, :, 0] = [1.0, 5.0, 1.0]
+    inds["gauss"][:, :, 0] = inds["sine"][:, :, 0] = True
+    last = s.run_mcmc(State(coords, inds=inds), 30, burn=5, thin_by=2, store=True)
+    assert len(s.chain) == 30 and s.iteration == 35
+    nl = s.get_nleaves()
+    assert nl["gauss"].shape == (30, T, W) and nl["gauss"].max() <= 4 and nl["sine"].max() <= 3
+    assert np.isfinite(last.log_like).all() and (nl["gauss"][-1] != 1).any()
+    s.engine.close()
