@@ -226,10 +226,10 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
             }                                                                                      \
         }                                                                                          \
         if (c->ext_start)                                                                          \
-            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(stretch_fast_waves(DT, NW, PIPE) * 64), (uint32_t)lds, c->stream, \
+            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
                                   c->ext_start, c->ext_stop, 0, a);                                \
         else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(stretch_fast_waves(DT, NW, PIPE) * 64), lds, c->stream, a); \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \

@@ -861,19 +861,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 // ---------------------------------------------------------------------------------------------
 // PIPE: the context is a rank of the ladder pipeline (guest rows, flag waits, boundary-rung publishing);
 // compiled out of the single-GPU instantiation, where those hooks cost ~6 % at config 2.
-// Extra wave (XW): outside the pipeline a workgroup carries one more wavefront than its NW working ones.  It takes no
-// part in the row phases (it only joins the barriers); when every workgroup adapts the ladder for itself (ad_defer) it
-// runs that ~4000-cycle FP64 chain while the working waves wait for their row gathers, so the adaptation is off every
-// working wave's path.
-// Two 9-wave workgroups per CU put 5 waves on a SIMD, so the kernel must stay within 512 / 5 -> 96 VGPRs (the second
-// launch-bounds argument); the wider rows (D >= 64) need more registers than that and keep 8 waves.
-// (measured: a 9-wave workgroup does not pack two per CU - the dispatcher wants 3 of its waves on one SIMD twice - and
-// one workgroup per CU costs more than the adaptation saved, so no instantiation uses the extra wave at present)
-__host__ __device__ constexpr int stretch_fast_waves(int DT, int NW, bool PIPE) { return NW + 0 * (DT + (PIPE ? 1 : 0)); }
-__host__ __device__ constexpr int stretch_fast_min_waves(int DT, int NW, bool PIPE) { return stretch_fast_waves(DT, NW, PIPE) > NW ? 5 : 1; }
-
 template <int DT, int LIKE, int MODE, int NW, bool PIPE>
-__global__ __launch_bounds__(stretch_fast_waves(DT, NW, PIPE) * 64, stretch_fast_min_waves(DT, NW, PIPE)) void k_stretch_fast(const StretchArgs A) {
+__global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -897,9 +886,8 @@ __global__ __launch_bounds__(stretch_fast_waves(DT, NW, PIPE) * 64, stretch_fast
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr bool XW = stretch_fast_waves(DT, NW, PIPE) > NW;
-    constexpr int ADW = XW ? NW : 1;            // the wave that runs the early ladder adaptation
-    const bool work = !XW || wv < NW;           // false in the extra wave
+    constexpr int ADW = 1;                      // the wave that runs the early ladder adaptation (a 9th, adaptation-only
+                                                // wave was measured: two 9-wave workgroups do not pack onto one CU)
     const int tl = blockIdx.y;
     const int W = A.W;
     const int Ns = (EVAL || MH) ? W : (A.split == 0 ? A.N0 : W - A.N0);
@@ -1095,7 +1083,7 @@ __global__ __launch_bounds__(stretch_fast_waves(DT, NW, PIPE) * 64, stretch_fast
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
-        rv[p] = work && (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
+        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
@@ -1124,13 +1112,13 @@ __global__ __launch_bounds__(stretch_fast_waves(DT, NW, PIPE) * 64, stretch_fast
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int e = tid + q * NT;
-            adv[q] = (work && e < total) ? rows[e] : 0u;
+            adv[q] = (e < total) ? rows[e] : 0u;
         }
         if (!cnt_push && A.ad.zero_after) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int e = tid + q * NT;
-                if (work && e < total && adv[q]) A.ad.swap_part[e] = 0u;
+                if (e < total && adv[q]) A.ad.swap_part[e] = 0u;
             }
         }
         if (!cnt_push && wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
@@ -1213,10 +1201,8 @@ __global__ __launch_bounds__(stretch_fast_waves(DT, NW, PIPE) * 64, stretch_fast
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        if (work) {
-            const double part = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
-            s_part[wv * TILE + lane] = part;
-        }
+        const double part = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        s_part[wv * TILE + lane] = part;
     }
     HENS_TRACE(5);
     lds_barrier();

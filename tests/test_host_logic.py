@@ -190,3 +190,37 @@ def test_gaussian_move_draws_match_the_pinned_restatement(cov, mode, factor):
     for _ in range(5):                                  # several calls: the sequential mode's index advances
         assert np.array_equal(mv.get_step(r1, n, D), pr.draw_step(r2, n, D))
     assert np.array_equal(r1.rand(3), r2.rand(3))       # both streams ended in the same state
+
+
+def test_rj_records_pack_and_unpack_roundtrip():
+    """Leaf-packing records (eryn_amd.rj): branches + inds -> records -> branches, leaf masks as integers, the reference's
+    NaN fill of unused leaves on snapshots (backends/backend.py:1049-1059) - host logic only, no device."""
+    from eryn_amd.rj import RJEngine, TemplateBranch
+    eng = RJEngine.__new__(RJEngine)                       # packing needs no context
+    eng.branches = [TemplateBranch("gauss", "pulse", [(2.5, 3.5), (-1, 1), (0.01, 0.21)], 10, 0),
+                    TemplateBranch("sine", "sine", [(0.5, 1.5), (1, 20), (0, 2 * np.pi)], 4, 1)]
+    eng.T, eng.W = 3, 5
+    eng.ncoord = 10 * 3 + 4 * 3
+    eng.RW = eng.ncoord + 2
+    eng.off = np.array([0, 30])
+    rs = np.random.RandomState(0)
+    x = {"gauss": rs.randn(3, 5, 10, 3), "sine": rs.randn(3, 5, 4, 3)}
+    inds = {"gauss": rs.rand(3, 5, 10) < 0.4, "sine": rs.rand(3, 5, 4) < 0.6}
+    rec = eng.pack(x, inds)
+    assert rec.shape == (3, 5, 44) and eng.RW % 2 == 0
+    assert np.array_equal(rec[:, :, 42], (inds["gauss"] * (1 << np.arange(10))).sum(-1))
+    x2, inds2 = eng.unpack(rec)
+    for k in x:
+        assert np.array_equal(x2[k], x[k]) and np.array_equal(inds2[k], inds[k])
+    x3, _ = eng.unpack(rec, nan_fill=True)
+    assert np.isnan(x3["gauss"][~inds["gauss"]]).all() and np.array_equal(x3["sine"][inds["sine"]], x["sine"][inds["sine"]])
+    assert np.array_equal(eng.pack(x3, inds), np.where(np.isnan(eng.pack(x3, inds)), 0, eng.pack(x3, inds)))   # NaN never reaches a record
+    # leaf prior accumulated like the reference's container (prior.py:364-383)
+    b = eng.branches[0]
+    acc = np.zeros(1)
+    for d in range(3):
+        acc += np.log(1 / (b.hi[d] - b.lo[d]))
+    assert b.leaf_logp == acc[0]
+    steps = {"gauss": np.ones((3, 5, 10, 3)), "sine": 2 * np.ones((3, 5, 4, 3))}
+    sr = eng.steps_to_records(steps)
+    assert sr.shape == (3, 5, 42) and np.all(sr[:, :, :30] == 1) and np.all(sr[:, :, 30:] == 2)
