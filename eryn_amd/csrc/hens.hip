@@ -40,6 +40,8 @@ struct hens_ctx_impl {
     int32_t* loc[2] = {nullptr, nullptr};
     double* L[2] = {nullptr, nullptr};
     double* P[2] = {nullptr, nullptr};
+    WalkerRec* wrec[2] = {nullptr, nullptr};   // the same three as one record per walker (two-launch iterations of hens_step)
+    bool packed = false;             // wrec[cur] holds the state, L/P/loc[cur] are stale (inside hens_step only)
     int cur = 0;                     // which of the double-buffered L/P/loc is current
     int parity = 0;                  // home half the NEXT iteration writes into
     double* betas[2] = {nullptr, nullptr};   // [T]; bcur is current
@@ -191,7 +193,7 @@ int plan_threads(const hens_ctx_impl* c) {
     static const int cap = getenv("HENS_PLAN_THREADS") ? atoi(getenv("HENS_PLAN_THREADS")) : 1024;
     return std::min(cap, std::max(64, c->NP2 / 4));
 }
-size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)5 * c->W + 16; }
+size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)6 * c->W + 16; }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
@@ -610,13 +612,15 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
 }
 
 // plan nb iterations starting at iteration `iter0` into draw buffer `which`
-void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb) {
+void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool fused = false) {
     PlanArgs pa{};
     pa.dr = c->db[which].d;
     pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
     pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin;
     pa.idx_bits = c->idx_bits;
-    pa.T = c->T; pa.cb = c->label_cb; pa.rec = c->db[which].rec; pa.keys = c->db[which].keys;
+    pa.T = c->T; pa.cb = c->label_cb; pa.keys = c->db[which].keys;
+    pa.rec = fused ? c->db[which].rec : nullptr;          // (only k_split1_pt reads the block-ordered records)
+    pa.rec_only = fused ? 1 : 0;
     hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
 }
 
@@ -766,10 +770,28 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
 
 // one Philox iteration in two launches: first half-step (k_stretch_fast, carrying the pending ladder adaptation), then
 // second half-step + cascade + swap counts (k_split1_pt)
+// the state as one record per walker (k_split1_pt, k_stretch_fast with StretchArgs::wrec) <-> by-field arrays (everything else)
+void state_to_records(hens_ctx_impl* c) {
+    if (c->packed) return;
+    const int64_t n = (int64_t)c->T * c->W;
+    hipLaunchKernelGGL(k_pack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
+                       c->wrec[c->cur], n);
+    c->packed = true;
+}
+void state_to_fields(hens_ctx_impl* c) {
+    if (!c->packed) return;
+    const int64_t n = (int64_t)c->T * c->W;
+    hipLaunchKernelGGL(k_unpack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], c->L[c->cur], c->P[c->cur],
+                       c->loc[c->cur], n);
+    c->packed = false;
+}
+
 int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
     const int T = c->T, W = c->W;
+    state_to_records(c);
     {
         StretchArgs a = base_args(c);
+        a.wrec = c->wrec[c->cur];
         a.dr = draws_at(c->db[which], (size_t)ib * T * W);
         a.split = 0;
         a.home_off = c->parity * T * W;
@@ -786,10 +808,10 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     }
     FusedArgs f{};
     f.pool = c->pool;
-    f.loc = c->loc[c->cur]; f.L = c->L[c->cur]; f.P = c->P[c->cur];
-    f.locnew = c->loc[c->cur ^ 1]; f.Lnew = c->L[c->cur ^ 1]; f.Pnew = c->P[c->cur ^ 1];
+    f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
+    f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
-    f.rec = c->db[which].rec + (size_t)ib * T * W;
+    f.rec = c->db[which].rec + (size_t)ib * (T * W / 2);
     f.keys = c->db[which].keys + (size_t)ib * T * 8;
     f.accepted = c->accepted;
     f.swap_acc = c->swap_acc[c->acc_cur];
@@ -798,7 +820,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
     f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;
     f.iter = c->iter; f.seed = c->cfg.seed;
-    f.T = T; f.W = W; f.home_off = c->parity * T * W; f.idx_bits = c->idx_bits;
+    f.T = T; f.W = W; f.idx_bits = c->idx_bits;
     f.cb = c->label_cb; f.cb_shift = c->label_cb_shift;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (evs) {
@@ -813,7 +835,8 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
     if (r) return r;
-    c->parity ^= 1;
+    // (no change of c->parity: the rows were updated in place, the half of the pool that the copying launches of the
+    // other paths write next is still the free one)
     c->num_proposals += 1;
     c->cur ^= 1;
     c->adapt_pending = true;
@@ -1068,6 +1091,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         }
     }
     for (int b = 0; b < 2; ++b) {
+        if (c->label_cb) TRY(dalloc(c, &c->wrec[b], TW));
         TRY(dalloc(c, &c->swap_acc[b], (size_t)SWAP_ACC_ROWS * c->T));
         TRYHIP(hipMemsetAsync(c->swap_acc[b], 0, (size_t)SWAP_ACC_ROWS * c->T * 4, c->stream));
     }
@@ -1085,7 +1109,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->db[b].d.zz, n));
         TRY(dalloc(c, &c->db[b].d.fac, n));
         TRY(dalloc(c, &c->db[b].d.lu, n));
-        TRY(dalloc(c, &c->db[b].rec, n));
+        if (c->label_cb) TRY(dalloc(c, &c->db[b].rec, n / 2));
         TRY(dalloc(c, &c->db[b].keys, (size_t)c->NB * c->T * 8));
         TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
@@ -1100,7 +1124,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     {   // kernels that may need > 64 KiB of dynamic LDS
         const size_t plan_lds = plan_lds_bytes(c);
         if (plan_lds > 160 * 1024) {
-            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS split plan (5 bytes of LDS per walker: max %d)", c->W, (160 * 1024 - 16) / 5);
+            fail(c, HENS_ERR_UNSUPPORTED, "nwalkers %d exceeds the in-LDS split plan (6 bytes of LDS per walker: max %d)", c->W, (160 * 1024 - 16) / 6);
             g_last_error = c->err; hens_destroy(h); return HENS_ERR_UNSUPPORTED;
         }
         TRYHIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds));
@@ -1540,6 +1564,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     const bool pt = has_pt(c);
     const bool prof = c->per_kernel_events;
     const bool fused = fused_ok(c);
+    state_to_fields(c);                       // (only after a call that failed half-way)
     std::vector<hipEvent_t> evs;
     std::vector<char> ev_kind;                // per event pair: 0 stretch launch, 1 cascade launch, 2 fused half-step + cascade
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -1552,7 +1577,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (nbatch > 0) {
         HIPCHK(c, hipEventRecord(c->ev_used[0], c->stream));      // earlier work may still read buffer 0
         HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[0], 0));
-        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0));
+        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0), fused);
         HIPCHK(c, hipEventRecord(c->ev_plan[0], c->plan_stream));
         c->timing.n_plan += 1;
     }
@@ -1562,7 +1587,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
             HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));
-            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1));
+            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), fused);
             HIPCHK(c, hipEventRecord(c->ev_plan[nxt], c->plan_stream));
             c->timing.n_plan += 1;
         }
@@ -1571,6 +1596,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             if (piped) pipe_prewait(c);
             const bool mh = iteration_is_mh(c);
             if (mh) {
+                state_to_fields(c);
                 r = mh_iteration(c, prof ? &evs : nullptr);
                 if (prof) ev_kind.push_back(0);
             } else if (fused) {
@@ -1609,6 +1635,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             c->iter += 1;
         }
     }
+    state_to_fields(c);
     if (piped) pipe_flush_adapt(c);
     else flush_adapt(c);      // the ladder and the swap counters are final when the call's work completes
     HIPCHK(c, hipGetLastError());

@@ -136,6 +136,12 @@ __device__ __forceinline__ int block_label_of_walker(const uint32_t* kpt, int t,
     const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
     return block_rank(kpt, c, cb) >= (cb >> 1) ? 1 : 0;
 }
+// the same, with the place of a label-1 walker among its block's moving walkers: block * (cb / 2) + (rank - cb / 2), or -1
+__device__ __forceinline__ int block_member_code(const uint32_t* kpt, int t, int T, int w, int cb, int idx_bits, int W) {
+    const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
+    const int rank = block_rank(kpt, c, cb);
+    return rank >= (cb >> 1) ? (c >> (__ffs(cb) - 1)) * (cb >> 1) + rank - (cb >> 1) : -1;   // cb is a power of two
+}
 __device__ __forceinline__ double pt_uniform(uint64_t seed, uint64_t it, int j, int W, int c) {   // tempering.py:535
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(j * W + c), PURPOSE_PTU};
     const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -300,21 +306,38 @@ struct Draws {
     double* lu;      // [Tl][W] log of the accept uniform
 };
 
-// the same per walker id instead of per split position (k_split1_pt finds its walkers through the cascade's column map)
+// The draws of the second half-step once more, one 32-byte record per moving walker in the order k_split1_pt consumes
+// them: workgroup (= column block) b reads records [64 b, 64 b + 64), record m = t * (cb / 2) + (label rank - cb / 2)
+// belongs to the m-th moving walker of the block (block_rank) - one coalesced 2 KiB load that depends on nothing.
 struct __attribute__((aligned(16))) DrawRec {
     double zz, fac, lu;
-    int32_t cw, pad;
+    int32_t cw, own;
 };
 
-__device__ __forceinline__ void make_draw(const Draws& d, size_t idx, int own, int cw, double uz, double ua,
-                                          double a, int D) {
+// {log-likelihood, log-prior, pool row} of one walker as ONE 32-byte record (the two-launch iteration of hens_step).
+// k_split1_pt finds its 128 walkers through a random column map: in the by-field arrays every field of every walker
+// costs a cache line of its own, and the phase that gathers them is bound by the number of lines, not by bytes.
+struct __attribute__((aligned(32))) WalkerRec {
+    double L, P;
+    int32_t loc, pad0, pad1, pad2;
+};
+__device__ __forceinline__ WalkerRec make_wrec(double L, double P, int32_t loc) { return WalkerRec{L, P, loc, 0, 0, 0}; }
+
+__device__ __forceinline__ DrawRec draw_values(int own, int cw, double uz, double ua, double a, int D) {
     double zz = (a - 1.0) * uz + 1.0;              // stretch.py:129-132 (mul, add, square, divide)
     zz = zz * zz / a;
-    d.own[idx] = own;
-    d.cw[idx] = cw;
-    d.zz[idx] = zz;
-    d.fac[idx] = ((double)D - 1.0) * log(zz);      // stretch.py:223
-    d.lu[idx] = log(ua);                           // red_blue.py:294
+    return DrawRec{zz, ((double)D - 1.0) * log(zz) /* stretch.py:223 */, log(ua) /* red_blue.py:294 */, cw, own};
+}
+__device__ __forceinline__ void store_draw(const Draws& d, size_t idx, const DrawRec& r) {
+    d.own[idx] = r.own;
+    d.cw[idx] = r.cw;
+    d.zz[idx] = r.zz;
+    d.fac[idx] = r.fac;
+    d.lu[idx] = r.lu;
+}
+__device__ __forceinline__ void make_draw(const Draws& d, size_t idx, int own, int cw, double uz, double ua,
+                                          double a, int D) {
+    store_draw(d, idx, draw_values(own, cw, uz, ua, a, D));
 }
 
 // value of x in lane l, l wave-uniform (v_readlane: a few cycles; __shfl with a runtime lane is a ds_bpermute, ~100)
@@ -355,6 +378,10 @@ struct StretchArgs {
     int32_t* loc;
     double* L;
     double* P;
+    WalkerRec* wrec;           // k_stretch_fast, red/blue half-steps of the two-launch iteration (else nullptr): {L, P} live
+                               // here, `loc` is read-only, and the rows are updated IN PLACE - an accepted proposal
+                               // overwrites the walker's current row (nobody reads it during the launch: complements come
+                               // from the other set), a rejected one writes nothing
     const double* betas;       // [T] or nullptr when not tempered
     Draws dr;
     uint32_t* accepted;        // [Tl][W] cumulative accept counts
@@ -907,30 +934,45 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
 
     // ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64
-    auto adapt_publish = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1) {
+    // Two parts, so that a wave can run the first one (ratios, dS, exp, deltaT: ~2500 cycles of dependent FP64 divides
+    // that need the counts but not the cumulative sum) while it would otherwise idle before the first barrier, and only
+    // the second one (cumsum, reciprocals, update) in the shadow of the row gathers.
+    double ad_c0 = 0.0, ad_c1 = 0.0, ad_dT0 = 0.0, ad_dT1 = 0.0, ad_b0n = 1.0, ad_b1n = 1.0, ad_bb0 = 1.0, ad_bb1 = 1.0;
+    auto adapt_part1 = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1) {
         const int T = A.ad.T;
         const int e0 = lane, e1 = lane + 64;
-        const double r0 = cnt0 / (double)A.ad.W, r1 = cnt1 / (double)A.ad.W;       // :587
+        ad_c0 = cnt0; ad_c1 = cnt1; ad_bb0 = ad_b; ad_bb1 = ad_b1;
+        if (!A.ad.moving) return;
+        const bool two = T > 64;                                                   // wave-uniform: rungs 64.. exist
+        const double r0 = cnt0 / (double)A.ad.W, r1 = two ? cnt1 / (double)A.ad.W : 0.0;   // :587
+        const double decay = A.ad.lag / ((double)A.ad.time + A.ad.lag);            // :571
+        const double kappa = decay / A.ad.nu;                                      // :572
+        // the value of the NEXT rung (e + 1): lane 63's successor is rung 64 = lane 0's second element
+        const double r0d = __shfl_down(r0, 1), r1first = __shfl(r1, 0);
+        const double b0d = __shfl_down(ad_b, 1), b1first = __shfl(ad_b1, 0);
+        const double r0n = lane < 63 ? r0d : r1first, b0n = lane < 63 ? b0d : b1first;
+        const double r1n = __shfl_down(r1, 1), b1n = __shfl_down(ad_b1, 1);
+        ad_b0n = b0n; ad_b1n = b1n;
+        double dT0 = 0.0, dT1 = 0.0;
+        if (e0 + 2 < T) {
+            const double dS = kappa * (r0 - r0n);                                  // :575
+            dT0 = 1.0 / b0n - 1.0 / ad_b;                                          // :578
+            dT0 *= exp(dS);
+        }
+        if (two && e1 + 2 < T) {
+            const double dS = kappa * (r1 - r1n);
+            dT1 = 1.0 / b1n - 1.0 / ad_b1;
+            dT1 *= exp(dS);
+        }
+        ad_dT0 = dT0; ad_dT1 = dT1;
+    };
+    auto adapt_part2 = [&]() {
+        const int T = A.ad.T;
+        const int e0 = lane, e1 = lane + 64;
+        const double cnt0 = ad_c0, cnt1 = ad_c1, ad_b = ad_bb0, ad_b1 = ad_bb1;
         double bnew0 = ad_b, bnew1 = ad_b1;
         if (A.ad.moving) {
-            const double decay = A.ad.lag / ((double)A.ad.time + A.ad.lag);        // :571
-            const double kappa = decay / A.ad.nu;                                  // :572
-            // the value of the NEXT rung (e + 1): lane 63's successor is rung 64 = lane 0's second element
-            const double r0d = __shfl_down(r0, 1), r1first = __shfl(r1, 0);
-            const double b0d = __shfl_down(ad_b, 1), b1first = __shfl(ad_b1, 0);
-            const double r0n = lane < 63 ? r0d : r1first, b0n = lane < 63 ? b0d : b1first;
-            const double r1n = __shfl_down(r1, 1), b1n = __shfl_down(ad_b1, 1);
-            double dT0 = 0.0, dT1 = 0.0;
-            if (e0 + 2 < T) {
-                const double dS = kappa * (r0 - r0n);                              // :575
-                dT0 = 1.0 / b0n - 1.0 / ad_b;                                      // :578
-                dT0 *= exp(dS);
-            }
-            if (e1 + 2 < T) {
-                const double dS = kappa * (r1 - r1n);
-                dT1 = 1.0 / b1n - 1.0 / ad_b1;
-                dT1 *= exp(dS);
-            }
+            const double dT0 = ad_dT0, dT1 = ad_dT1, b0n = ad_b0n, b1n = ad_b1n;
             double cs0 = 0.0, cs1 = 0.0;                                           // np.cumsum: left-to-right
             for (int i = 0; i + 2 < T; ++i) {
                 const double v = i < 64 ? readlane_f64(dT0, i) : readlane_f64(dT1, i - 64);
@@ -941,7 +983,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 }
             }
             const double inv0 = 1.0 / __shfl(ad_b, 0);
-            const double bn0 = 1.0 / (cs0 + inv0), bn1 = 1.0 / (cs1 + inv0);       // :580, belong to rungs e + 1
+            const double bn0 = 1.0 / (cs0 + inv0), bn1 = T > 64 ? 1.0 / (cs1 + inv0) : 0.0;   // :580, belong to rungs e + 1
             const double upd0 = b0n + (bn0 - b0n), upd1 = b1n + (bn1 - b1n);      // :583,:593
             const double up0 = __shfl_up(upd0, 1), up1 = __shfl_up(upd1, 1), upd0last = __shfl(upd0, 63);
             if (e0 >= 1 && e0 + 1 < T) bnew0 = up0;
@@ -973,6 +1015,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 A.ad.swaps_total[e1] += cnt1;
             }
         }
+    };
+    auto adapt_publish = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1) {
+        adapt_part1(cnt0, cnt1, ad_b, ad_b1);
+        adapt_part2();
     };
 
     // The counts are already reduced (one row: a pipeline rank's mailbox): wave 1 of the adapting workgroup
@@ -1006,7 +1052,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (A.ad.zero_rows)                      // every workgroup reads the rows: clear the buffer of the NEXT sweep
                 for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
         }
-        adapt_publish((double)s0, (double)s1, ad_bi0, ad_bi1);
+        adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1);
     };
     if (ad_early && wv == ADW) {
         const int T = A.ad.T, NR = A.ad.nblocks;
@@ -1021,7 +1067,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         // compiler's wait-count pass understands: otherwise it guards the deferred computation with a wait that also
         // covers the row gathers issued in between, and the adaptation no longer overlaps them.
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
-        if (!ad_defer) adapt_early();
+        adapt_early();                           // first part: this wave has nothing else to do before the barrier
+        if (!ad_defer) adapt_part2();
     }
 
     // ---- phase A (wave 0): indices and draws -------------------------------------------------------
@@ -1054,17 +1101,26 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 zz = A.dr.zz[di];
                 factors = A.dr.fac[di];
                 lu = A.dr.lu[di];
-                rs = A.loc[tl * W + own];
-                // split 1's complement walkers were all rewritten by split 0: their row is their home
-                rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
-                Lold = A.L[tl * W + own];
-                Pold = A.P[tl * W + own];
+                if (A.wrec) {
+                    // (row indices from the compact by-field array, which k_split1_pt keeps current: a rung's 4 W bytes
+                    // stay in L2, its 32 W bytes of records would be fetched once per XCD for 4 of them)
+                    rs = A.loc[tl * W + own];
+                    rc = A.loc[tl * W + cw];
+                    const WalkerRec* o = A.wrec + (tl * W + own);
+                    Lold = o->L; Pold = o->P;
+                } else {
+                    rs = A.loc[tl * W + own];
+                    // split 1's complement walkers were all rewritten by split 0: their row is their home
+                    rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
+                    Lold = A.L[tl * W + own];
+                    Pold = A.P[tl * W + own];
+                }
             }
         }
         s_zz[lane] = zz;
         s_rs[lane] = rs;
         s_rc[lane] = rc;
-        s_dst[lane] = A.home_off + tl * W + own;
+        s_dst[lane] = A.wrec ? rs : A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
     } else if (red_on && wv == 1) {
         s_cnt[lane] = 0;
@@ -1103,7 +1159,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
-    if (ad_defer && wv == ADW) adapt_early();      // the working waves' row gathers are in flight
+    if (ad_defer && wv == ADW) adapt_part2();      // second part: the working waves' row gathers are in flight
     unsigned adv[8];
     double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
     if (red_on) {                                  // the cascade's per-workgroup swap counts: <= 8 per thread
@@ -1147,7 +1203,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
-            if (!EVAL) {
+            if (!EVAL && !A.wrec) {
                 if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
                 else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
             }
@@ -1254,8 +1310,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             const bool keep = lnpdiff > lu;                    // red_blue.py:294
             const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;
             if (keep) {                                        // move.py:513-532
-                A.L[gi] = logl;
-                A.P[gi] = newP;
+                if (A.wrec) {
+                    *reinterpret_cast<double2*>(&A.wrec[gi].L) = double2{logl, newP};
+                } else {
+                    A.L[gi] = logl;
+                    A.P[gi] = newP;
+                }
                 atomicAdd(&A.accepted[gi], 1u);
                 atomicOr(&s_flag[lane], 2);
             }
@@ -1263,7 +1323,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 sys_store(A.pub_lp + own, keep ? logl : Lold);
                 sys_store(A.pub_lp + W + own, keep ? newP : Pold);
             }
-            A.loc[gi] = s_dst[lane];
+            if (!A.wrec) A.loc[gi] = s_dst[lane];
             if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
         }
     }
@@ -1302,6 +1362,19 @@ __global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __
         const int64_t r = i / D;
         const int d = (int)(i - r * D);
         dst[i] = pool[row_off(loc[r], D, guest_delta) + d];
+    }
+}
+
+__global__ void k_pack_state(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
+                             WalkerRec* __restrict__ w, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        w[i] = make_wrec(L[i], P[i], loc[i]);
+}
+__global__ void k_unpack_state(const WalkerRec* __restrict__ w, double* __restrict__ L, double* __restrict__ P,
+                               int32_t* __restrict__ loc, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const WalkerRec r = w[i];
+        L[i] = r.L; P[i] = r.P; loc[i] = r.loc;
     }
 }
 
@@ -1403,7 +1476,8 @@ struct PlanArgs {
     double a;
     int32_t Tl, W, D, rung_begin, idx_bits;
     int32_t T, cb;        // cb > 0: block-balanced labelling with cb columns per block (see block_rank); 0: label = prp >= N0
-    DrawRec* rec;         // [NB][Tl][W] the draws by walker id, or nullptr
+    DrawRec* rec;         // [NB][W / cb][64] the second half-step's draws in k_split1_pt's order (see DrawRec), or nullptr
+    int32_t rec_only;     // with rec: the by-position arrays of the second half-step are not needed (nobody reads them)
     uint32_t* keys;       // [NB][T][8] round keys of every rung's cascade column map (cb > 0), or nullptr
     double* dbg_uzz;      // debug (hens_debug_draws): the raw uniforms behind zz / lu, [NB][Tl][W], or nullptr
     double* dbg_uacc;
@@ -1446,7 +1520,8 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     const uint32_t rung = (uint32_t)(A.rung_begin + job);
     const int N0 = (W + 1) / 2;
     int32_t* ord = reinterpret_cast<int32_t*>(smem_raw);             // [W] ordered walker ids
-    uint8_t* lab = reinterpret_cast<uint8_t*>(ord + W);              // [W] split labels
+    uint16_t* lab = reinterpret_cast<uint16_t*>(ord + W);            // [W] split label: 0xFFFF = first half-step, else the
+                                                                     // walker's block_member_code (or 0: legacy labels)
     if (tid < 64) {                                                  // one wave draws the rung's round keys
         const PrpKey K = prp_key(A.seed, it, A.cb ? PURPOSE_PTPERM : PURPOSE_SPLIT, rung);
         if (tid < 8) skey[tid] = K.k[tid];
@@ -1457,19 +1532,19 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     for (int r = 0; r < 8; ++r) key[r] = skey[r];
     if (A.cb) {
         if (A.keys && tid < 8) A.keys[((size_t)ib * A.T + rung) * 8 + tid] = key[tid];
-        for (int i = tid; i < W; i += nt) lab[i] = (uint8_t)block_label_of_walker(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
+        for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
     } else {
-        for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 1 : 0;
+        for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 0 : 0xFFFFu;
     }
     __syncthreads();
     const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
     const int lo = min(W, tid * chunk), hi = min(W, lo + chunk);
     uint32_t z = 0;
-    for (int i = lo; i < hi; ++i) z += (lab[i] == 0);
-    uint32_t z0 = block_excl_scan(z, wtot, tid, nt);                 // zeros before this thread's chunk
-    uint32_t o0 = (uint32_t)lo - z0;                                 // ones before it
+    for (int i = lo; i < hi; ++i) z += (lab[i] == 0xFFFFu);
+    uint32_t z0 = block_excl_scan(z, wtot, tid, nt);                 // first-half walkers before this thread's chunk
+    uint32_t o0 = (uint32_t)lo - z0;                                 // second-half walkers before it
     for (int i = lo; i < hi; ++i) {
-        if (lab[i] == 0) ord[z0++] = i;
+        if (lab[i] == 0xFFFFu) ord[z0++] = i;
         else ord[N0 + o0++] = i;
     }
     __syncthreads();
@@ -1485,12 +1560,12 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
         const int Nc = s0 ? W - N0 : N0;
         const int r = (int)__umulhi(d.x, (uint32_t)Nc);
         const int cw = ord[(s0 ? N0 : 0) + r];
-        make_draw(A.dr, base + p, own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
-        if (A.rec) {
-            DrawRec rc;
-            rc.zz = A.dr.zz[base + p]; rc.fac = A.dr.fac[base + p]; rc.lu = A.dr.lu[base + p];
-            rc.cw = cw; rc.pad = s0 ? 0 : 1;
-            A.rec[base + own] = rc;
+        const DrawRec rc = draw_values(own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
+        if (s0 || !(A.rec && A.rec_only)) store_draw(A.dr, base + p, rc);
+        if (A.rec && !s0) {
+            const int hb = A.cb >> 1, code = lab[own];               // block * hb + place among the block's moving walkers
+            const int blk = code >> (__ffs(hb) - 1), ml = code & (hb - 1);   // cb is a power of two
+            A.rec[((size_t)ib * (W / A.cb) + blk) * TILE + (size_t)rung * hb + ml] = rc;
         }
         if (A.dbg_uzz) {
             A.dbg_uzz[base + p] = u01(d.y, d.z);
@@ -1720,10 +1795,12 @@ constexpr int SWAP_ACC_ROWS = 8;       // <= 8: the adapting workgroup sums them
 
 struct FusedArgs {
     double* pool;
-    const int32_t* loc; const double* L; const double* P;     // current buffers: the first half-step is already in
-    int32_t* locnew; double* Lnew; double* Pnew;              // next buffers: after the cascade
+    const WalkerRec* wrec;                                    // current buffer: the first half-step is already in
+    WalkerRec* wrecnew;                                       // next buffer: after the cascade
+    const int32_t* loc;                                       // [T][W] the row of every walker once more, compact (a rung's
+    int32_t* locnew;                                          // 4 W bytes stay in L2): where the complements are looked up
     const double* betas;                                      // [T]
-    const DrawRec* rec;                                       // [T][W] this iteration's draws by walker id
+    const DrawRec* rec;                                       // [W / cb][64] this iteration's draws in block order (see DrawRec)
     const uint32_t* keys;                                     // [T][8] round keys of the rungs' column maps (from the plan)
     uint32_t* accepted;                                       // [T][W]
     uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
@@ -1732,7 +1809,7 @@ struct FusedArgs {
     unsigned long long* trace;                                // debug: 8 phase timestamps per workgroup, or nullptr
     double logp_in, fill, rosen_a, rosen_b;
     uint64_t iter, seed;
-    int32_t T, W, home_off, idx_bits, cb, cb_shift;
+    int32_t T, W, idx_bits, cb, cb_shift;
 };
 
 __host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
@@ -1777,34 +1854,39 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     FUSED_TRACE(0);
 
     // ---- phase A: one thread per slot ----------------------------------------------------------------------
-    // The critical chain is key -> slot -> {loc, L, P, draw record} -> rows.  The round keys come from the plan (a
-    // 32-byte load that hits L2 after the first workgroup of an XCD; two Philox calls in place cost 3x as long on the
-    // two waves that run this phase), every load that hangs off the slot is issued before anything else is computed,
-    // and the label rank and the cascade's log-uniforms are computed while those loads are in flight.
+    // The phase is bound by the number of cache lines it pulls in, and the critical chain is draw record -> walker
+    // record -> rows: the 64 draw records arrive in block order (one coalesced load, k_plan), each names its walker, whose
+    // {L, P, row} is one 32-byte record.  The column map (key -> slot) is only needed for the walkers that do not move
+    // (cascade tables) and for the addresses phase G writes to; the round keys come from the plan (a 32-byte load that
+    // hits L2; two Philox calls in place cost 3x as long), the cascade's log-uniforms are computed on two other waves.
     if (tid < NE) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
+        const int HB = CB >> 1;
+        // wave 0 first: the draw records of the block's 64 moving walkers (coalesced, independent of everything)
+        DrawRec rc{};
+        if (tid < TILE) rc = A.rec[(size_t)blockIdx.x * TILE + tid];
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
-        const size_t gi = (size_t)t * W + slot;
-        const int32_t loc_e = A.loc[gi];
-        const double L_e = A.L[gi], P_e = A.P[gi];
-        const DrawRec rc = A.rec[gi];                                    // used by the moving walkers only (32 B)
-        const int rank = block_rank(key, c, CB);
-        const bool member = rank >= (CB >> 1);
-        scol[e] = slot;
-        if (member) {
-            const int m = t * (CB >> 1) + rank - (CB >> 1);              // 0 .. 63, each exactly once
-            s_rs[m] = loc_e;
-            s_rc[m] = A.home_off + t * W + rc.cw;                        // its complement moved in the first half-step: at home
-            s_dst[m] = A.home_off + (int32_t)gi;
+        if (tid < TILE) {                                                // lane m: the block's m-th moving walker, by its record
+            const int m = tid, tm = m >> (CS - 1);
+            const int32_t gi = tm * W + rc.own;
+            const WalkerRec wr = A.wrec[gi];
+            s_rs[m] = wr.loc;
+            s_rc[m] = A.loc[tm * W + rc.cw];
+            s_dst[m] = gi;                                               // (walker index: the accept counters)
             s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
-            s_Lold[m] = L_e; s_Pold[m] = P_e;
+            s_Lold[m] = wr.L; s_Pold[m] = wr.P;
             s_flag[m] = 0;
-            s_el[m] = e;
-        } else {
-            Lc[e] = L_e; Pc[e] = P_e; locc[e] = loc_e;
+        }
+        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+        const int rank = block_rank(key, c, CB);
+        scol[e] = slot;
+        if (rank >= HB) {
+            s_el[t * HB + rank - HB] = e;                                // 0 .. 63, each exactly once: where phase D puts the result
+        } else {                                                         // not moving: straight into the cascade's tables
+            const WalkerRec wr = A.wrec[(size_t)t * W + slot];
+            Lc[e] = wr.L; Pc[e] = wr.P; locc[e] = wr.loc;
         }
         if (!WIDE && e < T) sbeta[e] = A.betas[e];
     } else if (tid < 2 * NE) {
@@ -1850,7 +1932,6 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
-            store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);     // the old row to its new home now
         }
         const unsigned long long bad = __ballot(!ok);                    // prior.py:80-88, row-wide AND
         const unsigned long long nonfin = __ballot(!finite);
@@ -1898,9 +1979,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;      // move.py:513-532
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;
-        locc[e] = s_dst[lane];
+        locc[e] = s_rs[lane];                                           // rows are updated in place (see StretchArgs::wrec)
         if (keep) {
-            atomicAdd(&A.accepted[s_dst[lane] - A.home_off], 1u);
+            atomicAdd(&A.accepted[s_dst[lane]], 1u);
             s_flag[lane] |= 2;
         }
     }
@@ -1968,8 +2049,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         }
         const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
-        A.Lnew[di] = Lc[se];
-        A.Pnew[di] = Pc[se];
+        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se]);
         A.locnew[di] = locc[se];
     }
     for (int i = 1 + tid; i < T; i += NT) {                              // pair (i, i-1) -> index i-1
@@ -1984,7 +2064,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;
         const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-        store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, qv);
+        store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2, qv);
     }
 
     FUSED_TRACE(7);
