@@ -741,6 +741,9 @@ __device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attrib
 // Phase C of the stretch kernels: this wave's share of -2 log-likelihood of the proposal in row `lane` of the LDS tile
 // (lane per walker; the rows / blocks of the precision matrix are dealt to the NW waves, see sym_quad).  The
 // coefficients come through scalar loads (SGPR operands).  Returns the partial sum; the caller adds the NW parts.
+// For the Gaussian likelihoods the tile holds the CENTRED proposal q - mu (phase B subtracts once per element while it
+// has the element in a register; every wave subtracting for itself was a quarter of this phase's FP64 issue slots).
+constexpr bool like_centred(int LIKE) { return LIKE == LIKE_DENSE || LIKE == LIKE_DIAG; }
 template <int DT, int LIKE, int NW>
 __device__ __forceinline__ double like_partial(const double* qtile, int lane, int wv, bool inbox, const double* mu_p,
                                                const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b) {
@@ -780,8 +783,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
             for (int k = 0; k < H; k += 2) {
                 const double2 v = *reinterpret_cast<const double2*>(qrow + half + k);
-                qh[k] = v.x - mu[half + k];
-                qh[k + 1] = v.y - mu[half + k + 1];
+                qh[k] = v.x;
+                qh[k + 1] = v.y;
             }
             switch (wv) {
                 case 0: part = sym_quad<H, 2, 0>(qh, psym); break;
@@ -796,7 +799,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
                         double y = 0.0;
 #pragma unroll
                         for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                        part = fma(qrow[r0 + r] - mu[r0 + r], y, part);
+                        part = fma(qrow[r0 + r], y, part);
                     }
                 }
             }
@@ -813,8 +816,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
                 for (int k = 0; k < H; k += 2) {
                     const double2 v = *reinterpret_cast<const double2*>(qrow + bk * H + k);
-                    qh[k] = v.x - mu[bk * H + k];
-                    qh[k + 1] = v.y - mu[bk * H + k + 1];
+                    qh[k] = v.x;
+                    qh[k + 1] = v.y;
                 }
                 const cptr_t cx = psym + 4 * SB + wv * H * H;
 #pragma unroll 4
@@ -822,7 +825,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
                     double y = 0.0;
 #pragma unroll
                     for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                    part = fma(qrow[bi * H + r] - mu[bi * H + r], y, part);
+                    part = fma(qrow[bi * H + r], y, part);
                 }
             } else {
 #pragma unroll
@@ -831,8 +834,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
                     for (int k = 0; k < H; k += 2) {
                         const double2 v = *reinterpret_cast<const double2*>(qrow + b * H + k);
-                        qh[k] = v.x - mu[b * H + k];
-                        qh[k + 1] = v.y - mu[b * H + k + 1];
+                        qh[k] = v.x;
+                        qh[k + 1] = v.y;
                     }
                     part += sym_quad<H, 1, 0>(qh, psym + b * SB);
                 }
@@ -842,8 +845,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
             for (int k = 0; k < DT; k += 2) {
                 const double2 v = *reinterpret_cast<const double2*>(qrow + k);
-                qreg[k] = v.x - mu[k];
-                qreg[k + 1] = v.y - mu[k + 1];
+                qreg[k] = v.x;
+                qreg[k + 1] = v.y;
             }
             // q'^T A q' = sum_i q'_i (A_ii q'_i + sum_{k>i} (A_ik + A_ki) q'_k): half the FP64 FMAs of
             // the full product (phase C is FP64-rate-bound: vector fp64 = 78.6 TF/s).  Rows are dealt
@@ -861,7 +864,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
             for (int ii = 0; ii < RB; ++ii) {
                 const int i = i0 + ii;
                 if (i < DT) {
-                    const double di = qrow[i] - mu[i];
+                    const double di = qrow[i];
                     part = fma(di * prec[i], di, part);
                 }
             }
@@ -1159,6 +1162,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
+    double2 muv = double2{0.0, 0.0};
+    if (like_centred(LIKE)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
+    double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
     if (ad_defer && wv == ADW) adapt_part2();      // second part: the working waves' row gathers are in flight
     unsigned adv[8];
     double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
@@ -1200,7 +1206,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
+            qkeep[p] = qv;
+            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
             if (!EVAL && !A.wrec) {
@@ -1338,7 +1345,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
-        const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+        const double2 qv = qkeep[p];
         if (PIPE && tl == A.sys_rung) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
         else store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
     }
@@ -1920,6 +1927,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
+    double2 muv = double2{0.0, 0.0};
+    if (like_centred(LIKE)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
+    double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
@@ -1931,7 +1941,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = qv;
+            qkeep[p] = qv;
+            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
         }
         const unsigned long long bad = __ballot(!ok);                    // prior.py:80-88, row-wide AND
         const unsigned long long nonfin = __ballot(!finite);
@@ -2063,8 +2074,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;
-        const double2 qv = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-        store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2, qv);
+        store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2, qkeep[p]);
     }
 
     FUSED_TRACE(7);
