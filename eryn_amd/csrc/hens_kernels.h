@@ -1861,40 +1861,52 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     FUSED_TRACE(0);
 
     // ---- phase A: one thread per slot ----------------------------------------------------------------------
-    // The phase is bound by the number of cache lines it pulls in, and the critical chain is draw record -> walker
-    // record -> rows: the 64 draw records arrive in block order (one coalesced load, k_plan), each names its walker, whose
-    // {L, P, row} is one 32-byte record.  The column map (key -> slot) is only needed for the walkers that do not move
-    // (cascade tables) and for the addresses phase G writes to; the round keys come from the plan (a 32-byte load that
-    // hits L2; two Philox calls in place cost 3x as long), the cascade's log-uniforms are computed on two other waves.
+    // Two memory round trips in front of the row gathers: {draw records, round keys} -> {walker records, complement
+    // rows}.  The 64 draw records arrive in block order (one coalesced load, k_plan), each names its walker, whose
+    // {L, P, row} is one 32-byte record (the phase is bound by the number of cache lines it pulls in: one per walker, not
+    // three by-field arrays).  The column map (key -> slot) serves the walkers that do not move (cascade tables) and the
+    // addresses phase G writes to; the round keys come from the plan (a 32-byte load that hits L2; two Philox calls in
+    // place cost 3x as long), the cascade's log-uniforms are computed on two other waves.
+    // Program order matters: the column map is computed BEFORE the second-hop loads are issued (its cycle-walking loop
+    // makes the compiler wait for every load in flight: issued earlier, they would serialise into a third round trip),
+    // those loads are unconditional so that the wait counts in front of the LDS writes stay exact, and what phase B does
+    // not need ({L, P} of the moving walkers: registers of the lane that runs phase D; the records of the walkers that
+    // stay: cascade tables) is consumed after the row gathers have been issued.
+    double Lold_m = 0.0, Pold_m = 0.0;                                   // wave 0, lane m
+    WalkerRec wr_n{};                                                    // slot threads: the record of the walker in the slot
+    bool stays = false;
     if (tid < NE) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
         const int HB = CB >> 1;
-        // wave 0 first: the draw records of the block's 64 moving walkers (coalesced, independent of everything)
+        const bool mv = wv == 0;                                         // wave 0: lane m = the block's m-th moving walker
         DrawRec rc{};
-        if (tid < TILE) rc = A.rec[(size_t)blockIdx.x * TILE + tid];
+        if (mv) rc = A.rec[(size_t)blockIdx.x * TILE + lane];
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        if (tid < TILE) {                                                // lane m: the block's m-th moving walker, by its record
-            const int m = tid, tm = m >> (CS - 1);
-            const int32_t gi = tm * W + rc.own;
-            const WalkerRec wr = A.wrec[gi];
-            s_rs[m] = wr.loc;
-            s_rc[m] = A.loc[tm * W + rc.cw];
-            s_dst[m] = gi;                                               // (walker index: the accept counters)
-            s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
-            s_Lold[m] = wr.L; s_Pold[m] = wr.P;
-            s_flag[m] = 0;
-        }
         const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
         const int rank = block_rank(key, c, CB);
-        scol[e] = slot;
-        if (rank >= HB) {
-            s_el[t * HB + rank - HB] = e;                                // 0 .. 63, each exactly once: where phase D puts the result
-        } else {                                                         // not moving: straight into the cascade's tables
-            const WalkerRec wr = A.wrec[(size_t)t * W + slot];
-            Lc[e] = wr.L; Pc[e] = wr.P; locc[e] = wr.loc;
+        stays = rank < HB;
+        const int tm = lane >> (CS - 1);                                 // (wave 0: rung of the m-th moving walker)
+        const int32_t gi = tm * W + rc.own;
+        int32_t rs_m = 0, rc_m = 0;
+        if (mv) {
+            rs_m = A.wrec[gi].loc;
+            rc_m = A.loc[tm * W + rc.cw];
+            const double2 lp = *reinterpret_cast<const double2*>(&A.wrec[gi].L);
+            Lold_m = lp.x; Pold_m = lp.y;
         }
+        wr_n = A.wrec[(size_t)t * W + slot];                             // (a moving walker's record: unused, same lines)
+        if (mv) {
+            const int m = lane;
+            s_rs[m] = rs_m;
+            s_rc[m] = rc_m;
+            s_dst[m] = gi;                                               // (walker index: the accept counters)
+            s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
+            s_flag[m] = 0;
+        }
+        scol[e] = slot;
+        if (!stays) s_el[t * HB + rank - HB] = e;                        // 0 .. 63, each exactly once: where phase D puts the result
         if (!WIDE && e < T) sbeta[e] = A.betas[e];
     } else if (tid < 2 * NE) {
         // the cascade's log-uniforms (a Philox call and a log per element: ~1700 cycles of dependent ALU) on the two
@@ -1930,6 +1942,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     double2 muv = double2{0.0, 0.0};
     if (like_centred(LIKE)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
+    if (tid < NE && stays) {                       // (loaded before the row gathers were issued: it arrives before them)
+        Lc[tid] = wr_n.L; Pc[tid] = wr_n.P; locc[tid] = wr_n.loc;
+    }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
@@ -1978,7 +1993,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const double logp = inbox ? A.logp_in : -INFINITY;              // prior.py:80-88
         const int e = s_el[lane];
         const double beta = sbeta[e >> CS];
-        const double Lold = s_Lold[lane], Pold = s_Pold[lane];
+        const double Lold = Lold_m, Pold = Pold_m;
         double lt = logl * beta;                                        // tempering.py:304-306,343-349
         if (lt != lt) lt = -INFINITY;
         const double logP = lt + logp;

@@ -19,7 +19,7 @@ eng.eval_state()
 eng.step(200)
 eng.synchronize()
 _lib.check(eng.lib.hens_debug_trace(eng.ctx, mode, None, 0, None), eng.ctx)
-eng.step(2)
+eng.step(int(sys.argv[5]) if len(sys.argv) > 5 else 2)      # 1: every stamp comes from the same launch
 eng.synchronize()
 n = T * ((W + 63) // 64) * 8
 out = np.zeros(n, dtype=np.uint64)
@@ -32,7 +32,10 @@ wg = np.flatnonzero(ok)
 t0 = tr[:, 0].min()
 names = ["start", "A done", "bar1", "B done", "C done", "D done", "F done", "end"] if mode == 3 else \
         ["start", "A done", "bar1", "B done", "bar2", "C done", "D done", "end"]
-print("workgroups traced:", len(tr), " kernel span ticks (100 MHz):", tr[:, 7].max() - t0)
+print("workgroups traced:", len(tr), " launch span (first start -> last end):", tr[:, 7].max() - t0,
+      " start spread:", tr[:, 0].max() - t0, " end spread:", tr[:, 7].max() - tr[:, 7].min())
+print("start percentiles (10/50/90/99/max):", np.percentile(tr[:, 0] - t0, [10, 50, 90, 99, 100]).astype(int))
+print("end percentiles (0/10/50/90/max):", np.percentile(tr[:, 7] - t0, [0, 10, 50, 90, 100]).astype(int))
 for i, nm in enumerate(names):
     rel = tr[:, i] - t0
     print(f"{nm:8s} mean {rel.mean():9.1f}  min {rel.min():7d}  max {rel.max():7d}")
