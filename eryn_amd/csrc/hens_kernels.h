@@ -2049,7 +2049,19 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             }
         }
     };
-    if (wv == (NW > 1 ? 1 : 0) && lane < CB) {
+    // (the accepted rows - phase E - go out in the walk's shadow from every wave but the walking one)
+    const bool walking = wv == (NW > 1 ? 1 : 0);
+    auto store_accepted = [&]() {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int r = p * RPP + rsub;
+            if (!rv[p]) continue;
+            if ((s_flag[r] & 2) == 0) continue;
+            store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2, qkeep[p]);
+        }
+    };
+    if (!walking) store_accepted();
+    if (walking && lane < CB) {
         if (T == 16) walk(std::integral_constant<int, 16>{});
         else if (T == 8) walk(std::integral_constant<int, 8>{});
         else if (T == 32) walk(std::integral_constant<int, 32>{});
@@ -2083,14 +2095,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (SWAP_ACC_ROWS - 1)) * (T - 1) + (i - 1)], n);
     }
-    // ---- phase E (last: nothing waits behind these stores): accepted rows only -------------------------------------
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        if (!rv[p]) continue;
-        if ((s_flag[r] & 2) == 0) continue;
-        store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2, qkeep[p]);
-    }
+    // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
+    if (walking) store_accepted();
 
     FUSED_TRACE(7);
 #undef FUSED_TRACE
