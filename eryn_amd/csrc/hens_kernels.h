@@ -743,7 +743,9 @@ __device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attrib
 // coefficients come through scalar loads (SGPR operands).  Returns the partial sum; the caller adds the NW parts.
 // For the Gaussian likelihoods the tile holds the CENTRED proposal q - mu (phase B subtracts once per element while it
 // has the element in a register; every wave subtracting for itself was a quarter of this phase's FP64 issue slots).
-constexpr bool like_centred(int LIKE) { return LIKE == LIKE_DENSE || LIKE == LIKE_DIAG; }
+// (Rows up to 32 doubles: wider rows need the registers that would hold the proposal for phase E - 135 VGPRs at
+// D = 64 instead of 119, one workgroup per CU instead of two - and keep the uncentred tile.)
+constexpr bool like_centred(int LIKE, int DT) { return (LIKE == LIKE_DENSE || LIKE == LIKE_DIAG) && DT <= 32; }
 template <int DT, int LIKE, int NW>
 __device__ __forceinline__ double like_partial(const double* qtile, int lane, int wv, bool inbox, const double* mu_p,
                                                const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b) {
@@ -783,8 +785,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
             for (int k = 0; k < H; k += 2) {
                 const double2 v = *reinterpret_cast<const double2*>(qrow + half + k);
-                qh[k] = v.x;
-                qh[k + 1] = v.y;
+                qh[k] = v.x - mu[half + k];
+                qh[k + 1] = v.y - mu[half + k + 1];
             }
             switch (wv) {
                 case 0: part = sym_quad<H, 2, 0>(qh, psym); break;
@@ -799,7 +801,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
                         double y = 0.0;
 #pragma unroll
                         for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                        part = fma(qrow[r0 + r], y, part);
+                        part = fma(qrow[r0 + r] - mu[r0 + r], y, part);
                     }
                 }
             }
@@ -816,8 +818,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
                 for (int k = 0; k < H; k += 2) {
                     const double2 v = *reinterpret_cast<const double2*>(qrow + bk * H + k);
-                    qh[k] = v.x;
-                    qh[k + 1] = v.y;
+                    qh[k] = v.x - mu[bk * H + k];
+                    qh[k + 1] = v.y - mu[bk * H + k + 1];
                 }
                 const cptr_t cx = psym + 4 * SB + wv * H * H;
 #pragma unroll 4
@@ -825,7 +827,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
                     double y = 0.0;
 #pragma unroll
                     for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                    part = fma(qrow[bi * H + r], y, part);
+                    part = fma(qrow[bi * H + r] - mu[bi * H + r], y, part);
                 }
             } else {
 #pragma unroll
@@ -834,8 +836,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
                     for (int k = 0; k < H; k += 2) {
                         const double2 v = *reinterpret_cast<const double2*>(qrow + b * H + k);
-                        qh[k] = v.x;
-                        qh[k + 1] = v.y;
+                        qh[k] = v.x - mu[b * H + k];
+                        qh[k + 1] = v.y - mu[b * H + k + 1];
                     }
                     part += sym_quad<H, 1, 0>(qh, psym + b * SB);
                 }
@@ -864,7 +866,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
             for (int ii = 0; ii < RB; ++ii) {
                 const int i = i0 + ii;
                 if (i < DT) {
-                    const double di = qrow[i];
+                    const double di = like_centred(LIKE, DT) ? qrow[i] : qrow[i] - mu[i];
                     part = fma(di * prec[i], di, part);
                 }
             }
@@ -1163,7 +1165,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     double2 muv = double2{0.0, 0.0};
-    if (like_centred(LIKE)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
+    if (like_centred(LIKE, DT)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
     if (ad_defer && wv == ADW) adapt_part2();      // second part: the working waves' row gathers are in flight
     unsigned adv[8];
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            qkeep[p] = qv;
+            if (like_centred(LIKE, DT)) qkeep[p] = qv;
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
@@ -1345,7 +1347,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
-        const double2 qv = qkeep[p];
+        const double2 qv = like_centred(LIKE, DT) ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
         if (PIPE && tl == A.sys_rung) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
         else store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
     }
@@ -1538,7 +1540,7 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) key[r] = skey[r];
     if (A.cb) {
-        if (A.keys && tid < 8) A.keys[((size_t)ib * A.T + rung) * 8 + tid] = key[tid];
+        if (A.keys && tid < 8) A.keys[((size_t)ib * A.T + rung) * 8 + tid] = skey[tid];   // (key[tid] would put the array in scratch)
         for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
     } else {
         for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 0 : 0xFFFFu;
@@ -1940,7 +1942,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     double2 muv = double2{0.0, 0.0};
-    if (like_centred(LIKE)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
+    if (like_centred(LIKE, DT)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
     if (tid < NE && stays) {                       // (loaded before the row gathers were issued: it arrives before them)
         Lc[tid] = wr_n.L; Pc[tid] = wr_n.P; locc[tid] = wr_n.loc;
@@ -1956,7 +1958,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            qkeep[p] = qv;
+            if (like_centred(LIKE, DT)) qkeep[p] = qv;
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
         }
         const unsigned long long bad = __ballot(!ok);                    // prior.py:80-88, row-wide AND
@@ -2057,7 +2059,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             const int r = p * RPP + rsub;
             if (!rv[p]) continue;
             if ((s_flag[r] & 2) == 0) continue;
-            store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2, qkeep[p]);
+            store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2,
+                        like_centred(LIKE, DT) ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
         }
     };
     if (!walking) store_accepted();
