@@ -464,6 +464,7 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
     p.seed = c->cfg.seed;
     p.T = c->T; p.W = c->W; p.Tl = c->Tl; p.rung_begin = c->cfg.rung_begin; p.idx_bits = c->idx_bits;
     p.srcfull = sharded ? c->srcglob : nullptr;
+    if (c->packed && !sharded) { p.wrec = c->wrec[c->cur]; p.wrecnew = c->wrec[c->cur ^ 1]; }
     p.trace = (c->tracing && c->trace_pt) ? c->d_trace : nullptr;
     return p;
 }
@@ -866,6 +867,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
     StretchArgs a = base_args(c);
     a.split = 0;
     a.home_off = c->parity * c->Tl * c->W;
+    if (c->packed) a.wrec = c->wrec[c->cur];       // hens_step's record mode: {L, P} in the records, rows in place
     a.mh_step = inline_draws ? nullptr : c->mh_step;
     a.mh_scale = c->mh_scale; a.mh_kind = c->mh_kind; a.mh_iter = c->iter; a.mh_seed = c->cfg.seed;
     a.dr.lu = c->mh_lu;
@@ -882,7 +884,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
     const int r = launch_stretch<MODE_MH>(c, a, (c->W + TILE - 1) / TILE);
     c->ext_start = c->ext_stop = nullptr;
     if (r) return r;
-    c->parity ^= 1;
+    if (!c->packed) c->parity ^= 1;                // (in place: the free half of the pool stays the free one)
     c->num_proposals_mh += 1;
     return HENS_OK;
 }
@@ -1596,7 +1598,9 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             if (piped) pipe_prewait(c);
             const bool mh = iteration_is_mh(c);
             if (mh) {
-                state_to_fields(c);
+                // (the fast kernels and the cascade read the walker records too; other MH launches want the by-field arrays)
+                if (fused && fast_path(c)) state_to_records(c);
+                else state_to_fields(c);
                 r = mh_iteration(c, prof ? &evs : nullptr);
                 if (prof) ev_kind.push_back(0);
             } else if (fused) {

@@ -746,7 +746,7 @@ __device__ __forceinline__ double sym_quad(const double (&q)[DT], const __attrib
 // (Rows up to 32 doubles: wider rows need the registers that would hold the proposal for phase E - 135 VGPRs at
 // D = 64 instead of 119, one workgroup per CU instead of two - and keep the uncentred tile.)
 constexpr bool like_centred(int LIKE, int DT) { return (LIKE == LIKE_DENSE || LIKE == LIKE_DIAG) && DT <= 32; }
-template <int DT, int LIKE, int NW>
+template <int DT, int LIKE, int NW, bool CEN>
 __device__ __forceinline__ double like_partial(const double* qtile, int lane, int wv, bool inbox, const double* mu_p,
                                                const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b) {
     constexpr int D = DT, RS = DT + 2;
@@ -847,8 +847,8 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 #pragma unroll
             for (int k = 0; k < DT; k += 2) {
                 const double2 v = *reinterpret_cast<const double2*>(qrow + k);
-                qreg[k] = v.x;
-                qreg[k + 1] = v.y;
+                qreg[k] = CEN ? v.x : v.x - mu[k];
+                qreg[k + 1] = CEN ? v.y : v.y - mu[k + 1];
             }
             // q'^T A q' = sum_i q'_i (A_ii q'_i + sum_{k>i} (A_ik + A_ki) q'_k): half the FP64 FMAs of
             // the full product (phase C is FP64-rate-bound: vector fp64 = 78.6 TF/s).  Rows are dealt
@@ -866,7 +866,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
             for (int ii = 0; ii < RB; ++ii) {
                 const int i = i0 + ii;
                 if (i < DT) {
-                    const double di = like_centred(LIKE, DT) ? qrow[i] : qrow[i] - mu[i];
+                    const double di = CEN ? qrow[i] : qrow[i] - mu[i];
                     part = fma(di * prec[i], di, part);
                 }
             }
@@ -896,6 +896,7 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 template <int DT, int LIKE, int MODE, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
+    constexpr bool CEN = like_centred(LIKE, DT) && !MH;   // (the MH launch draws its normals in phase B: it lost 4 us with it)
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int D = DT;
@@ -1097,8 +1098,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 rc = rs;
                 lu = A.mh_step ? A.dr.lu[(size_t)tl * W + own]
                                : mh_log_uniform(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)own);
-                Lold = A.L[tl * W + own];
-                Pold = A.P[tl * W + own];
+                if (A.wrec) {
+                    const double2 lp = *reinterpret_cast<const double2*>(&A.wrec[tl * W + own].L);
+                    Lold = lp.x; Pold = lp.y;
+                } else {
+                    Lold = A.L[tl * W + own];
+                    Pold = A.P[tl * W + own];
+                }
             } else {
                 const size_t di = (size_t)tl * W + s_off + k;
                 own = A.dr.own[di];
@@ -1165,7 +1171,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     double2 muv = double2{0.0, 0.0};
-    if (like_centred(LIKE, DT)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
+    if (CEN) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
     if (ad_defer && wv == ADW) adapt_part2();      // second part: the working waves' row gathers are in flight
     unsigned adv[8];
@@ -1208,7 +1214,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            if (like_centred(LIKE, DT)) qkeep[p] = qv;
+            if (CEN) qkeep[p] = qv;
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
@@ -1266,7 +1272,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        const double part = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        const double part = like_partial<DT, LIKE, NW, CEN>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
         s_part[wv * TILE + lane] = part;
     }
     HENS_TRACE(5);
@@ -1347,7 +1353,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
         if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
-        const double2 qv = like_centred(LIKE, DT) ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+        const double2 qv = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
         if (PIPE && tl == A.sys_rung) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
         else store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
     }
@@ -1632,6 +1638,8 @@ struct PtArgs {
     double* Lnew;               // local next buffers
     double* Pnew;
     int32_t* locnew;
+    const WalkerRec* wrec;      // whole ladder resident, inside hens_step's record mode: {L, P, loc} come from / go to the
+    WalkerRec* wrecnew;         // walker records (and locnew, the compact row table), L / P / loc above are not touched
     const double* betas;        // [T]
     const int32_t* colslot;     // [T][W]
     const double* colu;         // [T-1][W] uniforms in column order (parity) or nullptr (Philox)
@@ -1682,13 +1690,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         if (c < W) {
             const int slot = PHILOX ? pt_slot(A.seed, it, t, T, c, A.idx_bits, W) : A.colslot[(size_t)t * W + c];
             scol[e] = slot;
-            Lc[e] = A.Lfull[(size_t)t * W + slot];
             const int tl = t - A.rung_begin;
-            if (tl >= 0 && tl < A.Tl) {
-                Pc[e] = A.P[(size_t)tl * W + slot];
-                locc[e] = A.loc[(size_t)tl * W + slot];
+            if (A.wrec) {
+                const WalkerRec wr = A.wrec[(size_t)t * W + slot];
+                Lc[e] = wr.L; Pc[e] = wr.P; locc[e] = wr.loc;
             } else {
-                locc[e] = -1;                                    // walker owned by another rank
+                Lc[e] = A.Lfull[(size_t)t * W + slot];
+                if (tl >= 0 && tl < A.Tl) {
+                    Pc[e] = A.P[(size_t)tl * W + slot];
+                    locc[e] = A.loc[(size_t)tl * W + slot];
+                } else {
+                    locc[e] = -1;                                // walker owned by another rank
+                }
             }
             if (t < T - 1) {
                 const double u = PHILOX ? pt_uniform(A.seed, it, t, W, c) : A.colu[(size_t)t * W + c];
@@ -1768,6 +1781,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         const int tl = t - A.rung_begin;
         if (tl < 0 || tl >= A.Tl) continue;
         const size_t di = (size_t)tl * W + dslot;
+        if (A.wrecnew) {
+            A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se]);
+            A.locnew[di] = locc[se];
+            continue;
+        }
         A.Lnew[di] = Lc[se];
         A.locnew[di] = locc[se];      // -1: row + log-prior arrive from another rank (hens_pt_finish_sharded)
         if (locc[se] >= 0) A.Pnew[di] = Pc[se];
@@ -1829,6 +1847,7 @@ template <int DT, int LIKE, int NW>
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr bool CEN = like_centred(LIKE, DT);
     constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
     constexpr int NE = 2 * TILE;
     static_assert(NT >= 2 * NE, "one thread per slot + one per cascade uniform");
@@ -1942,7 +1961,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
     double2 muv = double2{0.0, 0.0};
-    if (like_centred(LIKE, DT)) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
+    if (CEN) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
     if (tid < NE && stays) {                       // (loaded before the row gathers were issued: it arrives before them)
         Lc[tid] = wr_n.L; Pc[tid] = wr_n.P; locc[tid] = wr_n.loc;
@@ -1958,7 +1977,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            if (like_centred(LIKE, DT)) qkeep[p] = qv;
+            if (CEN) qkeep[p] = qv;
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
         }
         const unsigned long long bad = __ballot(!ok);                    // prior.py:80-88, row-wide AND
@@ -1976,7 +1995,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // ---- phase C: likelihood ------------------------------------------------------------------------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW, CEN>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }
     FUSED_TRACE(4);
     lds_barrier();
@@ -2060,7 +2079,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             if (!rv[p]) continue;
             if ((s_flag[r] & 2) == 0) continue;
             store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2,
-                        like_centred(LIKE, DT) ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
+                        CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
         }
     };
     if (!walking) store_accepted();
