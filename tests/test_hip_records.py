@@ -1,0 +1,138 @@
+"""The record mode of ``hens_step`` (-m gpu).
+
+Inside a ``hens_step`` call the two-launch iteration keeps {L, P, row} in one 32-byte record per walker and updates
+rows in place; every other entry point works on the by-field arrays and the two-home copying scheme.  The boundary
+between the two must be invisible:
+
+* splitting a run into calls changes nothing (pack / unpack at the ends of every call),
+* the by-field arrays are whole after a call: the teacher-forced parity API continues from that state and agrees with
+  the oracle, then ``hens_step`` continues from the parity API's state (copying launches flip the pool half, in-place
+  iterations must leave the free half free),
+* the three-launch path (``HENS_NO_FUSED=1``: copying half-steps + stand-alone cascade on the same draws) reaches the
+  same state bit for bit, with and without the Metropolis-Hastings move in the mix.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import eryn_oracle as orc
+from tests import parity_utils as pu
+from tests import replay_utils as ru
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _engine(T, W, D, seed=5, mh=None, like_kind="dense"):
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
+    mu, invcov = pu.gaussian_problem(D)
+    like = GaussianLikelihood(mu, invcov) if like_kind == "dense" else RosenbrockLikelihood(D)
+    box = 50.0 if like_kind == "dense" else 5.0
+    eng = HipEnsemble(T, W, D, like, -box, box, seed=seed)
+    eng.upload(np.clip(np.random.RandomState(11).randn(T, W, D), -0.9 * box, 0.9 * box), betas=orc.make_ladder(D, ntemps=T))
+    eng.eval_state()
+    if mh is not None:
+        eng.set_mh_proposal(*mh)
+    return eng, mu, invcov
+
+
+def _reference_draws(rs, T, W):
+    """One iteration's draws in the reference's own form (red_blue.py:119-124, stretch.py:93-132, tempering.py:526-541)."""
+    N0 = (W + 1) // 2
+    d = dict(labels=np.stack([rs.permutation(np.arange(W) % 2) for _ in range(T)]))
+    for sp in (0, 1):
+        Ns = N0 if sp == 0 else W - N0
+        d[f"rint{sp}"] = rs.randint(W - Ns, size=(T, Ns))
+        d[f"u_zz{sp}"] = rs.rand(T, Ns)
+        d[f"u_acc{sp}"] = rs.rand(T, Ns)
+    d["iperm"] = np.stack([rs.permutation(W) for _ in range(T - 1)])
+    d["i1perm"] = np.stack([rs.permutation(W) for _ in range(T - 1)])
+    d["u_swap"] = rs.rand(T - 1, W)
+    return d
+
+
+def _snapshot(eng, mh=False):
+    x, L, P, betas = eng.download()
+    c = eng.counters()
+    out = dict(x=x, L=L, P=P, betas=betas, accepted=c["accepted"], swaps_total=c["swaps_total"])
+    if mh:
+        out["accepted_mh"] = eng.mh_counters()["accepted"]
+    return out
+
+
+def _assert_same(a, b, what):
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"{what}: {k} differs"
+
+
+@pytest.mark.parametrize("T,W,D,mh", [(8, 64, 8, None), (16, 128, 32, ("iso", 0.3, 0.5)), (4, 96, 16, ("diag", None, 0.4)),
+                                      (2, 128, 64, None)])
+def test_call_splitting_is_invisible(T, W, D, mh):
+    if mh is not None and mh[1] is None:
+        mh = (mh[0], np.full(D, 0.2), mh[2])
+    a, *_ = _engine(T, W, D, mh=mh)
+    b, *_ = _engine(T, W, D, mh=mh)
+    a.step(9)
+    for n in (1, 1, 3, 4):
+        b.step(n)
+    _assert_same(_snapshot(a, mh is not None), _snapshot(b, mh is not None), f"({T},{W},{D}) one call of 9 vs 1+1+3+4")
+    a.close()
+    b.close()
+
+
+def test_parity_api_continues_from_a_stepped_state_and_back():
+    """step (records, in place) -> teacher-forced half-steps + sweep (by-field arrays, copying) -> step again."""
+    T, W, D = 8, 64, 16
+    eng, mu, invcov = _engine(T, W, D)
+    fn = lambda x: orc.gaussian_log_like(x, mu, invcov)          # noqa: E731
+    lo, hi = np.full(D, -50.0), np.full(D, 50.0)
+    x, L, P, betas = eng.download()
+    st = ru.OracleState(x, L, P, betas)
+    it0 = eng.iteration()
+    eng.step(3)
+    ru.replay(eng, st, it0, 3, fn, lo, hi)
+    rs = np.random.RandomState(4)
+    for _ in range(2):                                           # the reference's own draws through the parity API
+        draws = _reference_draws(rs, T, W)
+        for sp in (0, 1):
+            eng.stretch_split(sp, draws["labels"], draws[f"rint{sp}"], draws[f"u_zz{sp}"], draws[f"u_acc{sp}"])
+        eng.pt_sweep(draws["iperm"], draws["i1perm"], draws["u_swap"], adapt=True)
+        ru.oracle_iteration(st, draws, fn, lo, hi)
+    x, L, P, betas = eng.download()
+    ru.assert_state_equal(st, x, L, P, betas, what="parity API after 3 production iterations")
+    it0 = eng.iteration()
+    eng.step(4)
+    ru.replay(eng, st, it0, 4, fn, lo, hi)
+    x, L, P, betas = eng.download()
+    ru.assert_state_equal(st, x, L, P, betas, what="production iterations after the parity API")
+    eng.close()
+
+
+_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.test_hip_records import _engine, _snapshot
+T, W, D, use_mh, like = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+eng, *_ = _engine(T, W, D, mh=("iso", 0.05 if like == "rosen" else 0.3, 0.5) if use_mh else None, like_kind=like)
+eng.step(2); eng.step(5)
+np.savez(sys.argv[7], **_snapshot(eng, bool(use_mh)))
+"""
+
+
+@pytest.mark.parametrize("T,W,D,use_mh,like", [(16, 256, 32, 0, "dense"), (8, 128, 64, 1, "dense"), (32, 256, 128, 1, "rosen")])
+def test_record_mode_equals_the_copying_three_launch_path(T, W, D, use_mh, like, tmp_path):
+    outs = []
+    for tag, env in (("fused", {}), ("three", {"HENS_NO_FUSED": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        e.pop("HENS_NO_FUSED", None) if tag == "fused" else None
+        r = subprocess.run([sys.executable, "-c", _WORKER, ROOT, str(T), str(W), str(D), str(use_mh), like, out],
+                           env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(dict(np.load(out)))
+    _assert_same(outs[0], outs[1], f"({T},{W},{D}) two-launch record mode vs three copying launches")
