@@ -209,6 +209,15 @@ __host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
 __host__ __device__ inline int32_t pipe_guest_loc(int par, int side, int W, int c) { return ~((par * 2 + side) * W + c); }
 
 // peer memory is written and read with system-scope accesses (sc0 sc1: nothing lingers in a cache)
+// debug stamps (hens_debug_trace): the shader clock (s_memtime: per XCD, not synchronised) or - compiled with
+// -DHENS_TRACE_REALTIME, tools/trace_skew.py - the 100 MHz wall clock, which all XCDs share
+__device__ __forceinline__ unsigned long long trace_stamp() {
+#ifdef HENS_TRACE_REALTIME
+    return (unsigned long long)wall_clock64();
+#else
+    return __builtin_amdgcn_s_memtime();
+#endif
+}
 __device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // mode 2: only workgroup (0,0) reduces the counts and adapts; everyone else reads its rung's beta from the ring
     const bool ad_lead = ad_on && A.ad_on == 2;
     const bool ad_here = ad_on && (!ad_lead || (blockIdx.x == 0 && blockIdx.y == 0));
-#define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = trace_stamp(); } while (0)
     HENS_TRACE(0);
     if (PIPE && !EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
         if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || ad_here || !ad_lead))
@@ -1679,7 +1688,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * PT_COLS;
     const uint64_t it = A.iter;
-#define PT_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PT_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     PT_TRACE(0);
 
     // phase 1: column slots (Philox: computed in place from the rung's keys), then everything the
@@ -1878,7 +1887,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const int T = A.T, W = A.W, CB = A.cb, CS = A.cb_shift;
     const int c0 = blockIdx.x * CB;
     const int MW = (T + 31) >> 5;
-#define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     FUSED_TRACE(0);
 
     // ---- phase A: one thread per slot ----------------------------------------------------------------------
