@@ -126,10 +126,11 @@ def kernel_roofline(tm, T_local, T, W, D, f_sw):
         k["frac"] = k["achieved_GBps"] / HBM_PEAK_GBS
     dom = max(ks, key=lambda k: k["avg_launch_us"] * k["launches_per_iteration"])
     traffic = static_json("traffic.json") or {}
+    same_shape = list(traffic.get("shape", [])) == [T_local, W, D] and T_local == T       # the PMC passes ran config 2
     roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["frac"], "traffic": traffic.get(dom["kernel"].split(" ")[0]),
+            "frac": dom["frac"], "traffic": traffic.get(dom["kernel"].split(" ")[0]) if same_shape else None,
             "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, tools/profile_bench.sh; "
-                              "not measured in this run)",
+                              "not measured in this run)" if same_shape else None,
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
             "kernels": ks}
     if "stretch_bytes_only" in dom:

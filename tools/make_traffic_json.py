@@ -30,6 +30,7 @@ cal_write = mean_of(Wf, r"k_stretch_fast<32, 0, 1,")
 known_read = 16 * 4096 * 32 * 8          # eval launch: every row once
 known_write = 2 * 16 * 4096 * 8          # eval launch: logl + logp
 out = {
+    "shape": [16, 4096, 32],                 # (ntemps, nwalkers, ndim) of the profiled command: bench.py's default
     "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/{tag}_pmc_*.txt",
     "fetch_correction": 2.0,
     "calibration": {"eval_kernel_fetch_kb_reported": cal_fetch, "eval_kernel_known_read_bytes": known_read,
