@@ -702,12 +702,14 @@ void attach_publish(hens_ctx_impl* c, StretchArgs& a, bool final, int ntiles) {
 }
 
 // both halves of one Philox iteration from draw buffer `which`, batch slot `ib`
-int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
+// inplace (hens_step on one GPU, compile-time row widths): rows are updated where they are, see StretchArgs::inplace
+int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs, bool inplace = false) {
     const int Tl = c->Tl, W = c->W;
     for (int split = 0; split < 2; ++split) {
         StretchArgs a = base_args(c);
         a.dr = draws_at(c->db[which], (size_t)ib * Tl * W);
         a.split = split;
+        a.inplace = inplace ? 1 : 0;
         a.home_off = c->parity * Tl * W;
         if (split == 0) attach_iteration_head(c, a);
         const int Ns = split == 0 ? c->N0 : W - c->N0;
@@ -722,7 +724,7 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
         c->ext_start = c->ext_stop = nullptr;
         if (r) return r;
     }
-    c->parity ^= 1;
+    if (!inplace) c->parity ^= 1;                  // (in place: the free half of the pool stays the free one)
     c->num_proposals += 1;
     return HENS_OK;
 }
@@ -793,6 +795,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     {
         StretchArgs a = base_args(c);
         a.wrec = c->wrec[c->cur];
+        a.inplace = 1;
         a.dr = draws_at(c->db[which], (size_t)ib * T * W);
         a.split = 0;
         a.home_off = c->parity * T * W;
@@ -863,11 +866,12 @@ int ensure_mh_buffers(hens_ctx_impl* c) {
 }
 
 // one full-ensemble MH proposal from the step rows / log-uniforms already in mh_step / mh_lu (mh.py:56-193)
-int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bool inline_draws = false) {
+int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bool inline_draws = false, bool inplace = false) {
     StretchArgs a = base_args(c);
     a.split = 0;
     a.home_off = c->parity * c->Tl * c->W;
-    if (c->packed) a.wrec = c->wrec[c->cur];       // hens_step's record mode: {L, P} in the records, rows in place
+    if (c->packed) { a.wrec = c->wrec[c->cur]; inplace = true; }  // hens_step's record mode: {L, P} in the records
+    a.inplace = inplace ? 1 : 0;
     a.mh_step = inline_draws ? nullptr : c->mh_step;
     a.mh_scale = c->mh_scale; a.mh_kind = c->mh_kind; a.mh_iter = c->iter; a.mh_seed = c->cfg.seed;
     a.dr.lu = c->mh_lu;
@@ -884,7 +888,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
     const int r = launch_stretch<MODE_MH>(c, a, (c->W + TILE - 1) / TILE);
     c->ext_start = c->ext_stop = nullptr;
     if (r) return r;
-    if (!c->packed) c->parity ^= 1;                // (in place: the free half of the pool stays the free one)
+    if (!inplace) c->parity ^= 1;                  // (in place: the free half of the pool stays the free one)
     c->num_proposals_mh += 1;
     return HENS_OK;
 }
@@ -892,7 +896,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
 // Philox mode: draw the iteration's steps and accept uniforms on the device, then propose.  Isotropic and
 // axis-aligned proposals on the fast row widths are drawn inside the MH launch itself (one Box-Muller pair per
 // lane); a full covariance (Cholesky product) and the generic row widths go through k_mh_draw + the step buffer.
-int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
+int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool inplace = false) {
     const bool inline_draws = c->mh_kind != MH_FULL && fast_path(c);
     if (!inline_draws) {
         MhDrawArgs d{};
@@ -904,7 +908,7 @@ int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         if (d.chol_lds) lds += (size_t)c->D * (c->D + 1) * 8;
         hipLaunchKernelGGL(k_mh_draw, dim3((c->W + 63) / 64, c->Tl), dim3(256), lds, c->stream, d);
     }
-    return mh_launch(c, false, evs, inline_draws);
+    return mh_launch(c, false, evs, inline_draws, inplace);
 }
 
 // host-side move choice of hens_step (ensemble.py:971 in Philox form): one counter-based uniform per iteration
@@ -1276,6 +1280,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     c->cur = 0;
+    c->packed = false;
     c->parity = 1;            // rows live in home 0, the next iteration writes home 1
     c->expect_split = 0;
     c->pt_pending = false;
@@ -1601,7 +1606,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 // (the fast kernels and the cascade read the walker records too; other MH launches want the by-field arrays)
                 if (fused && fast_path(c)) state_to_records(c);
                 else state_to_fields(c);
-                r = mh_iteration(c, prof ? &evs : nullptr);
+                r = mh_iteration(c, prof ? &evs : nullptr, !piped && fast_path(c));
                 if (prof) ev_kind.push_back(0);
             } else if (fused) {
                 r = fused_iteration(c, which, ib, prof ? &evs : nullptr);
@@ -1610,7 +1615,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 c->iter += 1;
                 continue;
             } else {
-                r = stretch_pair(c, which, ib, prof ? &evs : nullptr);
+                r = stretch_pair(c, which, ib, prof ? &evs : nullptr, !piped && fast_path(c));
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(0); }
             }
             if (r) return r;

@@ -387,10 +387,10 @@ struct StretchArgs {
     int32_t* loc;
     double* L;
     double* P;
-    WalkerRec* wrec;           // k_stretch_fast, red/blue half-steps of the two-launch iteration (else nullptr): {L, P} live
-                               // here, `loc` is read-only, and the rows are updated IN PLACE - an accepted proposal
+    WalkerRec* wrec;           // k_stretch_fast inside hens_step's record mode (else nullptr): {L, P} live in the walker records
+    int32_t inplace;           // k_stretch_fast: rows are updated IN PLACE and `loc` is read-only - an accepted proposal
                                // overwrites the walker's current row (nobody reads it during the launch: complements come
-                               // from the other set), a rejected one writes nothing
+                               // from the other set), a rejected one writes nothing.  0: the two-home copying scheme
     const double* betas;       // [T] or nullptr when not tempered
     Draws dr;
     uint32_t* accepted;        // [Tl][W] cumulative accept counts
@@ -1121,17 +1121,15 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 zz = A.dr.zz[di];
                 factors = A.dr.fac[di];
                 lu = A.dr.lu[di];
+                // (row indices from the compact by-field array also in record mode, where k_split1_pt keeps it current: a
+                // rung's 4 W bytes stay in L2, its 32 W bytes of records would be fetched once per XCD for 4 of them)
+                rs = A.loc[tl * W + own];
+                // copying scheme: split 1's complement walkers were all rewritten by split 0, their row is their home
+                rc = (A.split == 1 && !A.inplace) ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
                 if (A.wrec) {
-                    // (row indices from the compact by-field array, which k_split1_pt keeps current: a rung's 4 W bytes
-                    // stay in L2, its 32 W bytes of records would be fetched once per XCD for 4 of them)
-                    rs = A.loc[tl * W + own];
-                    rc = A.loc[tl * W + cw];
                     const WalkerRec* o = A.wrec + (tl * W + own);
                     Lold = o->L; Pold = o->P;
                 } else {
-                    rs = A.loc[tl * W + own];
-                    // split 1's complement walkers were all rewritten by split 0: their row is their home
-                    rc = A.split == 1 ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
                     Lold = A.L[tl * W + own];
                     Pold = A.P[tl * W + own];
                 }
@@ -1140,7 +1138,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_zz[lane] = zz;
         s_rs[lane] = rs;
         s_rc[lane] = rc;
-        s_dst[lane] = A.wrec ? rs : A.home_off + tl * W + own;
+        s_dst[lane] = A.inplace ? rs : A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
     } else if (red_on && wv == 1) {
         s_cnt[lane] = 0;
@@ -1227,7 +1225,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
             // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
             // overwrites only accepted rows, so the store tail after the accept test is short
-            if (!EVAL && !A.wrec) {
+            if (!EVAL && !A.inplace) {
                 if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
                 else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
             }
@@ -1347,7 +1345,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 sys_store(A.pub_lp + own, keep ? logl : Lold);
                 sys_store(A.pub_lp + W + own, keep ? newP : Pold);
             }
-            if (!A.wrec) A.loc[gi] = s_dst[lane];
+            if (!A.inplace) A.loc[gi] = s_dst[lane];
             if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
         }
     }
