@@ -100,7 +100,10 @@ def test_replay_odd_sizes(T, W, D):
 
 
 def test_replay_untempered():
-    _run_case(1, 64, 5, like_kind="diag", calls=(4,))
+    _run_case(1, 64, 5, like_kind="diag", calls=(4,))                  # generic row width: copying launches
+    _run_case(1, 256, 16, calls=(2, 3))                                # compile-time row width: rows updated in place
+    kinds = _run_case(1, 512, 32, calls=(3, 4), mh=("iso", 0.3, 0.5))   # ... with the MH move in the mix
+    assert "mh" in kinds and "stretch" in kinds
 
 
 def test_replay_narrow_box():
