@@ -1,0 +1,154 @@
+"""NumPy specification of the PRODUCTION random draws of ``hens_step`` (test infrastructure).
+
+Not a restatement of the reference (that is ``oracle/``): the reference draws from NumPy's global Mersenne Twister,
+which a device cannot reproduce in parallel.  Production stepping draws from Philox4x32-10 (Salmon et al. 2011), a
+pure function of (seed, iteration, purpose, global rung, walker), and builds its permutations from a keyed Feistel
+network.  This file states that construction independently of the HIP code (eryn_amd/csrc/hens_kernels.h:
+philox4x32_10, u01, prp_key, prp, prp_inv, block_rank, k_plan, pt_slot, pt_uniform) so that
+
+* the generator can be pinned on CPU against the published known-answer vectors of Random123 (test_host_logic), and
+* ``hens_debug_draws`` - hence the draws the timed path consumes - can be compared with it bit for bit on the GPU.
+
+Distributional equivalence with the reference's draws (balanced random halves, uniform complement, uniform matchings,
+uniform accept numbers) is what tests/test_hip_rng.py measures; tests/replay_utils.py turns these draws into the
+reference's own variables and replays them through the oracle.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = 0x9E3779B9, 0xBB67AE85
+MASK = np.uint64(0xFFFFFFFF)
+PURPOSE_STRETCH, PURPOSE_STRETCH_ACC, PURPOSE_SPLIT, PURPOSE_PTPERM, PURPOSE_PTU = 0, 2, 8, 9, 10
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised over the counter words (arrays or scalars of any broadcastable shape); returns four uint32 arrays."""
+    c = [np.asarray(v, dtype=np.uint64) & MASK for v in np.broadcast_arrays(c0, c1, c2, c3)]
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0)) & MASK, p1 & MASK,
+             ((p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1)) & MASK, p0 & MASK]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return [v.astype(np.uint32) for v in c]
+
+
+def u01(hi, lo):
+    """53-bit uniform in [0, 1) from two words."""
+    v = (np.asarray(hi, dtype=np.uint64) << np.uint64(32)) | np.asarray(lo, dtype=np.uint64)
+    return (v >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def fmix32(h):
+    h = np.asarray(h, dtype=np.uint64) & MASK
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & MASK
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & MASK
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def prp_key(seed, it, purpose, rung):
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    a = philox4x32_10(it & 0xFFFFFFFF, it >> 32, rung, purpose, lo, hi)
+    b = philox4x32_10(it & 0xFFFFFFFF, it >> 32, rung, purpose ^ 0x100, lo, hi)
+    return [int(v) for v in a + b]
+
+
+def idx_bits_of(W):
+    b, n = 0, 1
+    while n < W:
+        n <<= 1
+        b += 1
+    return b
+
+
+def _feistel(x, key, bits, inverse):
+    lb = bits >> 1
+    rb = bits - lb
+    lm, rm = np.uint64((1 << lb) - 1), np.uint64((1 << rb) - 1)
+    L, R = x >> np.uint64(rb), x & rm
+    rounds = range(6, -1, -2) if inverse else range(0, 8, 2)
+    for r in rounds:
+        if inverse:
+            R = R ^ (fmix32(L ^ np.uint64(key[r + 1])) & rm)
+            L = L ^ (fmix32(R ^ np.uint64(key[r])) & lm)
+        else:
+            L = L ^ (fmix32(R ^ np.uint64(key[r])) & lm)
+            R = R ^ (fmix32(L ^ np.uint64(key[r + 1])) & rm)
+    return (L << np.uint64(rb)) | R
+
+
+def prp(x, key, bits, W, inverse=False):
+    """Keyed permutation of [0, W): 8-round alternating Feistel network on ``bits`` bits, cycle-walked into range."""
+    x = np.array(x, dtype=np.uint64, copy=True)
+    out = _feistel(x, key, bits, inverse)
+    while True:
+        bad = out >= np.uint64(W)
+        if not bad.any():
+            return out.astype(np.int64)
+        out[bad] = _feistel(out[bad], key, bits, inverse)
+
+
+def block_rank(key, c, cb):
+    a0 = np.uint64(key[0] ^ 0x7F4A7C15)
+    c = np.asarray(c, dtype=np.int64)
+    my = fmix32(a0 ^ c.astype(np.uint64))
+    base = c & ~(cb - 1)
+    rank = np.zeros(c.shape, dtype=np.int64)
+    for j in range(cb):
+        rank += fmix32(a0 ^ (base + j).astype(np.uint64)) < my
+    return rank
+
+
+def label_cb(T, W, tempered=True):
+    """Columns per block of the block-balanced labelling, or 0 (hens_create)."""
+    if tempered and 2 <= T <= 64 and (T & (T - 1)) == 0 and W % (128 // T) == 0:
+        return 128 // T
+    return 0
+
+
+def plan(seed, it, T, W, cb):
+    """own, cw, u_zz, u_acc of iteration ``it`` for the whole ladder, [T][W] by split position (k_plan)."""
+    bits, N0 = idx_bits_of(W), (W + 1) // 2
+    own = np.empty((T, W), dtype=np.int64)
+    cw = np.empty((T, W), dtype=np.int64)
+    uz = np.empty((T, W))
+    ua = np.empty((T, W))
+    w = np.arange(W)
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    for t in range(T):
+        key = prp_key(seed, it, PURPOSE_PTPERM if cb else PURPOSE_SPLIT, t)
+        if cb:
+            col = w if t == T - 1 else prp(w, key, bits, W, inverse=True)       # the column that meets walker w
+            lab = (block_rank(key, col, cb) >= cb // 2).astype(np.int64)
+        else:
+            lab = (prp(w, key, bits, W) >= N0).astype(np.int64)
+        order = np.concatenate([w[lab == 0], w[lab == 1]])                       # both halves ascending
+        assert (lab == 0).sum() == N0
+        own[t] = order
+        d = philox4x32_10(it & 0xFFFFFFFF, it >> 32, t * W + order, PURPOSE_STRETCH, lo, hi)
+        e = philox4x32_10(it & 0xFFFFFFFF, it >> 32, t * W + order, PURPOSE_STRETCH_ACC, lo, hi)
+        s0 = np.arange(W) < N0
+        Nc = np.where(s0, W - N0, N0).astype(np.uint64)
+        r = ((d[0].astype(np.uint64) * Nc) >> np.uint64(32)).astype(np.int64)  # umulhi: uniform index into the other half
+        cw[t] = order[np.where(s0, N0, 0) + r]
+        uz[t] = u01(d[1], d[2])
+        ua[t] = u01(e[0], e[1])
+    return dict(own=own, cw=cw, u_zz=uz, u_acc=ua)
+
+
+def pt_draws(seed, it, T, W):
+    """pt_slot [T][W] (column c meets slot pt_slot[t, c]) and u_swap [T-1][W] (row j: pair T-1-j)."""
+    bits = idx_bits_of(W)
+    c = np.arange(W)
+    slot = np.empty((T, W), dtype=np.int64)
+    for t in range(T):
+        slot[t] = c if t == T - 1 else prp(c, prp_key(seed, it, PURPOSE_PTPERM, t), bits, W)
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    u = np.empty((T - 1, W))
+    for j in range(T - 1):
+        d = philox4x32_10(it & 0xFFFFFFFF, it >> 32, j * W + c, PURPOSE_PTU, lo, hi)
+        u[j] = u01(d[0], d[1])
+    return slot, u
