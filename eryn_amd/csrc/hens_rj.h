@@ -219,29 +219,53 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     const bool evaluated = total_leaves > 0 && !(fabs(logp) == INFINITY);   // ensemble.py:1278-1306, 1486-1513
     if (evaluated) {
         double acc = 0.0;
-        for (int i = lane; i < M.ndata; i += 64) {
-            const double ti = A.tdata[i];
-            double tm = 0.0;
+        // Leaves outside, NPT data points per lane inside: a leaf's three parameters are read (LDS) and its 1 / (2 c^2)
+        // formed once per chunk instead of once per point (the FP64 division was a third of the work per template
+        // point).  Per point the leaves are still summed branch by branch in ascending slot order, and the lane's points in
+        // ascending order, like the reference's NumPy sums over the leaf and the data axes.
+        constexpr int NPT = 4;
+        for (int i0 = 0; i0 < M.ndata; i0 += 64 * NPT) {
+            double ti[NPT], tm[NPT];
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int i = i0 + k * 64 + lane;
+                ti[k] = i < M.ndata ? A.tdata[i] : 0.0;
+                tm[k] = 0.0;
+            }
             for (int b = 0; b < M.nb; ++b) {
-                double sub = 0.0;
+                double sub[NPT];
+#pragma unroll
+                for (int k = 0; k < NPT; ++k) sub[k] = 0.0;
                 uint32_t m = mask[b];
+                const bool pulse = M.kind[b] == RJ_KIND_PULSE;
                 while (m) {
                     const int n = __builtin_ctz(m);
                     m &= m - 1u;
                     const double a = q[M.off[b] + n * RJ_ND], bb = q[M.off[b] + n * RJ_ND + 1], c = q[M.off[b] + n * RJ_ND + 2];
-                    double f;
-                    if (M.kind[b] == RJ_KIND_PULSE) {
-                        const double dx = ti - bb;
-                        f = a * exp(-(dx * dx) / (2 * (c * c)));                           // tests/test_eryn.py:38-40
+                    if (pulse) {
+                        const double inv = 1.0 / (2 * (c * c));
+#pragma unroll
+                        for (int k = 0; k < NPT; ++k) {
+                            const double dx = ti[k] - bb;
+                            sub[k] += a * exp(-(dx * dx) * inv);                               // tests/test_eryn.py:38-40
+                        }
                     } else {
-                        f = a * sin(2 * M_PI * bb * ti + c);                               // tests/test_eryn.py:67-69
+                        const double w = 2 * M_PI * bb;
+#pragma unroll
+                        for (int k = 0; k < NPT; ++k) sub[k] += a * sin(w * ti[k] + c);          // tests/test_eryn.py:67-69
                     }
-                    sub += f;
                 }
-                tm += sub;
+#pragma unroll
+                for (int k = 0; k < NPT; ++k) tm[k] += sub[k];
             }
-            const double r = (tm - A.ydata[i]) / M.sigma;
-            acc += r * r;
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int i = i0 + k * 64 + lane;
+                if (i < M.ndata) {
+                    const double r = (tm[k] - A.ydata[i]) / M.sigma;
+                    acc += r * r;
+                }
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
