@@ -325,9 +325,10 @@ def run_sharded(args):
 
     from eryn_amd.engine import HipEnsemble
     from eryn_amd.ladder import HipShardEngine, LadderPipeline, ShardedLadder, StagedPipeline, rung_partition
-    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
     from eryn_amd.moves.tempering import make_ladder
 
+    rosen = args.workload == "cfg5"               # BASELINE config 5: Rosenbrock + Stretch / Gaussian move mix
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # "nccl" = RCCL.  HENS_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses that): a dry run of this
@@ -352,14 +353,23 @@ def run_sharded(args):
     r0, r1 = bounds[rank]
     Tl = r1 - r0
     mu, invcov = gaussian_problem(D)
-    x0 = np.random.RandomState(1).randn(T, W, D)[r0:r1]
+
+    def start(ntemps):
+        if rosen:
+            return np.clip(1.0 + 0.05 * np.random.RandomState(1).randn(ntemps, W, D), -4.9, 4.9)
+        return np.random.RandomState(1).randn(ntemps, W, D)
+
+    x0 = start(T)[r0:r1]
     mode = os.environ.get("HENS_SHARD_MODE", "pipeline")
 
     def make_engine(delay, rung_range=(r0, r1), ntemps=T, x=x0):
-        e = HipEnsemble(ntemps, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=rung_range,
+        like, box = (RosenbrockLikelihood(D), 5.0) if rosen else (GaussianLikelihood(mu, invcov), 50.0)
+        e = HipEnsemble(ntemps, W, D, like, -box, box, seed=2024, rung_range=rung_range,
                         device_id=local_rank, adaptation_delay=delay)
         e.upload(x, betas=make_ladder(D, ntemps=ntemps))
         e.eval_state()
+        if rosen:
+            e.set_mh_proposal("iso", 5e-3, 0.5)
         return e
 
     def measure(stepper, eng):
@@ -408,7 +418,7 @@ def run_sharded(args):
     # weak-scaling base: ONE shard of the same size alone on this GPU (rank 0's), the N = 1 point of the series
     base = None
     if rank == 0 and not args.no_base:
-        e = make_engine(0, rung_range=(0, Tl), ntemps=Tl, x=np.random.RandomState(1).randn(Tl, W, D))
+        e = make_engine(0, rung_range=(0, Tl), ntemps=Tl, x=start(Tl))
         e.step(args.warmup)
         e.synchronize()
         bt, _ = timed_blocks(e.step, e.synchronize, args.steps)
@@ -462,13 +472,17 @@ def run_sharded(args):
              "frac": whole / world / HBM_PEAK_GBS, "traffic": None}
         roof.update(per_gpu=True, whole_path_GBps_per_gpu=whole / world, whole_path_frac_per_gpu=whole / world / HBM_PEAK_GBS)
         cfgname = "config 3" if (W, D) == (16384, 64) and T == 64 else ("config-3 shards" if (W, D) == (16384, 64) else "config-2 shards")
+        model = "dense-covariance Gaussian, StretchMove(a=2)"
+        if rosen:
+            cfgname = "config 5" if (T, W, D) == (32, 8192, 128) else "config-5 shards"
+            model = "Rosenbrock, StretchMove(a=2) + GaussianMove(iso, sigma=5e-3) 50/50"
         out = {
-            "metric": METRIC, "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
+            "metric": METRIC.replace("Gaussian logL", "Rosenbrock logL, move mix") if rosen else METRIC, "value": value, "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "block_ms": [t * 1e3 for t in times], "timing": f"median of {BLOCKS} blocks of {args.steps} steps, max over ranks",
             "config": {"workload": f"{cfgname}: ladder sharded over {world} GPU(s), ntemps={T} ({Tl} rungs/GPU), nwalkers={W}, "
-                                   f"ndim={D} dense-covariance Gaussian, StretchMove(a=2)+adaptive PT on the reference's "
+                                   f"ndim={D} {model}+adaptive PT on the reference's "
                                    f"adaptation schedule, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
                        "parallelism": f"ladder-shard x{world}", "transport": transport, "dist_backend": backend,
                        "world_size_seen_by_backend": dist.get_world_size(), "swap_fraction": f_sw},
@@ -478,7 +492,7 @@ def run_sharded(args):
             out["delayed_adaptation"] = delayed
         if base:
             out["weak_base"] = base
-        if not args.no_cpu:
+        if not args.no_cpu and not rosen:             # (the CPU leg times the Gaussian stretch + PT oracle)
             out["cpu_baseline"] = cpu_baseline(Tl, W, D, seconds=args.cpu_seconds)
             out["cpu_baseline"]["sample"] += " = one GPU's shard as a ladder of its own"
     eng.close()
@@ -529,9 +543,13 @@ def main():
         raise SystemExit(f"bench.py --gpus {args.gpus} started with WORLD_SIZE={world}: they must agree")
     if n > 1:
         wl = args.workload or "cfg3"
+        args.workload = wl
         if wl == "cfg3":
             args.ntemps, args.nwalkers, args.ndim = args.ntemps or 8 * n, args.nwalkers or 16384, args.ndim or 64
             args.steps = args.steps or 500
+        elif wl == "cfg5":
+            args.ntemps, args.nwalkers, args.ndim = args.ntemps or 4 * n, args.nwalkers or 8192, args.ndim or 128
+            args.steps = args.steps or 300
         else:
             args.ntemps, args.nwalkers, args.ndim = args.ntemps or 16 * n, args.nwalkers or 4096, args.ndim or 32
             args.steps = args.steps or 2000
