@@ -888,8 +888,10 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
 //     flight) - the kernel is latency-bound at config-2 size, memory-level parallelism buys time;
-//   * the old row goes to its new home right after the gathers (most proposals are rejected), the
-//     accept test only adds the accepted rows; barriers order LDS only, so stores stay in flight;
+//   * copying launches (StretchArgs::inplace == 0): the old row goes to its new home right after the gathers (most
+//     proposals are rejected), the accept test only adds the accepted rows; in-place launches (hens_step on one GPU)
+//     write the accepted rows only, where the walker's row already is; barriers order LDS only, so stores stay in
+//     flight;
 //   * scalar-load (SGPR) precision rows beat both an LDS copy and a v_readlane broadcast (measured);
 //   * measured and rejected: a single fused launch for both halves (write-through rows + per-rung
 //     flags: polling + sc1 traffic cost more than the boundary), and a row-resident variant that keeps
