@@ -1,0 +1,30 @@
+import sys, os, numpy as np, subprocess
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+W = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tools.quick_bench import problem, ladder
+from eryn_amd.engine import HipEnsemble
+from eryn_amd.likelihood import GaussianLikelihood
+T, W, D, n, mh = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+mu, invcov, cov = problem(D)
+eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=99)
+eng.upload(np.random.RandomState(1).randn(T, W, D), betas=ladder(D, T)); eng.eval_state()
+if mh: eng.set_mh_proposal("iso", 0.3, 0.3)
+done = 0
+while done < n:
+    k = min(7777, n - done); eng.step(k); done += k
+x, L, P, b = eng.download(); c = eng.counters()
+np.savez(sys.argv[7], x=x, L=L, P=P, b=b, acc=c["accepted"], sw=c["swaps_total"])
+print("finite", np.isfinite(x).all(), np.isfinite(L).all(), "acc", c["accepted"].mean() / max(c["num_proposals"], 1))
+'''
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+for (T, Wk, D, n, mh) in ((16, 4096, 32, 200000, 0), (8, 2048, 64, 60000, 1), (32, 1024, 16, 100000, 1)):
+    outs = []
+    for tag, env in (("fused", {}), ("three", {"HENS_NO_FUSED": "1"})):
+        out = f"/tmp/soak_{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", W, root, str(T), str(Wk), str(D), str(n), str(mh), out], env=dict(os.environ, **env), capture_output=True, text=True)
+        print(tag, r.stdout.strip()[-200:], r.stderr.strip()[-300:])
+        outs.append(dict(np.load(out)))
+    same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+    print(f"({T},{Wk},{D}) {n} iterations mh={mh}: record mode == three copying launches:", same)
