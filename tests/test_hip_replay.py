@@ -99,6 +99,12 @@ def test_replay_odd_sizes(T, W, D):
     _run_case(T, W, D, calls=(1, 4))
 
 
+@pytest.mark.parametrize("T,W,D", [(16, 40, 8), (8, 48, 16), (32, 20, 8), (64, 16, 8), (2, 64, 8)])
+def test_replay_small_two_launch_shapes(T, W, D):
+    """block-balanced shapes with fewer walkers per half than a tile, few column blocks, cb = 2 ... 64"""
+    _run_case(T, W, D, calls=(2, 3), x_scale=0.5)
+
+
 def test_replay_untempered():
     _run_case(1, 64, 5, like_kind="diag", calls=(4,))                  # generic row width: copying launches
     _run_case(1, 256, 16, calls=(2, 3))                                # compile-time row width: rows updated in place
