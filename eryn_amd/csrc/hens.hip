@@ -1231,17 +1231,10 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
                     for (int k = i; k < H; ++k) row[o++] = S(base + i, base + k);
             }
         };
-        if (D == 64) {
-            // blocked form (see k_stretch_fast phase C, DT = 64): [lo-lo block][hi-hi block][32 x 32 cross block]
-            constexpr int H = 32, BLK = (H / 2) * (H + 2);
-            sym.assign((size_t)2 * BLK + (size_t)H * H, 0.0);
-            pack_block(0, H, sym.data());
-            pack_block(H, H, sym.data() + BLK);
-            for (int i = 0; i < H; ++i)
-                for (int k = 0; k < H; ++k) sym[(size_t)2 * BLK + (size_t)i * H + k] = S(i, H + k);
-        } else if (D == 128) {
-            // four 32-blocks: [4 diagonal blocks][6 cross blocks (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)]
-            constexpr int H = 32, BLK = (H / 2) * (H + 2);
+        if (D == 64 || D == 128) {
+            // blocked form (see like_partial): four H = D / 4 blocks: [4 diagonal blocks][6 cross blocks (0,1) (0,2) (0,3)
+            // (1,2) (1,3) (2,3)]
+            const int H = D / 4, BLK = (H / 2) * (H + 2);
             sym.assign((size_t)4 * BLK + (size_t)6 * H * H, 0.0);
             for (int b = 0; b < 4; ++b) pack_block(b * H, H, sym.data() + (size_t)b * BLK);
             int x = 0;

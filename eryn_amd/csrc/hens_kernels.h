@@ -781,44 +781,13 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
     } else if (inbox) {
         constexpr int RB = (DT + NW - 1) / NW;
         const int i0 = wv * RB;
-        if (LIKE == LIKE_DENSE && DT == 64 && NW == 8) {
-            // D = 64: a lane holding all 64 centred coordinates needs 128 VGPRs for them alone (165 in
-            // total: one workgroup per CU).  Blocked instead, every wave keeps ONE 32-vector:
-            //   waves 0,1: q_lo' A_lolo q_lo   waves 2,3: q_hi' A_hihi q_hi   (symmetric, sym_quad<32>)
-            //   waves 4-7: q_lo' (A_lohi + A_hilo') q_hi, 8 rows of the cross block each
-            // 264 / 264 / 264 FMAs per lane - the same balance as the row-pair deal, at half the registers.
-            constexpr int H = 32, BLK = (H / 2) * (H + 2);
-            const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
-            const int half = (wv == 0 || wv == 1) ? 0 : H;            // waves 2..7 hold q_hi
-            double qh[H];
-#pragma unroll
-            for (int k = 0; k < H; k += 2) {
-                const double2 v = *reinterpret_cast<const double2*>(qrow + half + k);
-                qh[k] = v.x - mu[half + k];
-                qh[k + 1] = v.y - mu[half + k + 1];
-            }
-            switch (wv) {
-                case 0: part = sym_quad<H, 2, 0>(qh, psym); break;
-                case 1: part = sym_quad<H, 2, 1>(qh, psym); break;
-                case 2: part = sym_quad<H, 2, 0>(qh, psym + BLK); break;
-                case 3: part = sym_quad<H, 2, 1>(qh, psym + BLK); break;
-                default: {
-                    const int r0 = (wv - 4) * 8;
-                    const cptr_t cx = psym + 2 * BLK + r0 * H;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        double y = 0.0;
-#pragma unroll
-                        for (int k = 0; k < H; ++k) y = fma(cx[r * H + k], qh[k], y);
-                        part = fma(qrow[r0 + r] - mu[r0 + r], y, part);
-                    }
-                }
-            }
-        } else if (LIKE == LIKE_DENSE && DT == 128 && NW == 8) {
-            // D = 128: the same blocking with four 32-blocks: 4 symmetric diagonal blocks (528 FMAs each) and
-            // 6 cross blocks (1024 each).  Waves 0-5 take one cross block each, waves 6 and 7 two diagonal
-            // blocks each: 1024 / 1056 FMAs per lane, one 32-vector in registers at a time.
-            constexpr int H = 32, SB = (H / 2) * (H + 2);
+        if (LIKE == LIKE_DENSE && (DT == 64 || DT == 128) && NW == 8) {
+            // D = 64 / 128: a lane holding all the centred coordinates needs 2 D VGPRs for them alone (D = 64: 165 in
+            // total, one workgroup per CU).  Blocked instead into four H = D / 4 blocks: 4 symmetric diagonal blocks
+            // (sym_quad<H>) and 6 cross blocks (H x H, A_ik + A_ki).  Waves 0-5 take one cross block each, waves 6 and 7 two
+            // diagonal blocks each (D = 64: 272 / 304 FMAs per lane, D = 128: 1024 / 1056), one H-vector in registers at
+            // a time - at D = 64 that is 32 VGPRs instead of the 64 of a two-block form.
+            constexpr int H = DT / 4, SB = (H / 2) * (H + 2);
             const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
             double qh[H];
             if (wv < 6) {
