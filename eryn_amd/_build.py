@@ -8,7 +8,7 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.environ.get("HENS_LIB") or os.path.join(LIB_DIR, "libhipensemble.so")
 SOURCES = [os.path.join(SRC_DIR, "hens.hip")]
-DEPS = SOURCES + [os.path.join(SRC_DIR, "hens_kernels.h"), os.path.join(SRC_DIR, "hens_rj.h"),
+DEPS = SOURCES + [os.path.join(SRC_DIR, "hens_kernels.h"), os.path.join(SRC_DIR, "hens_rj.h"), os.path.join(SRC_DIR, "hens_iter.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 

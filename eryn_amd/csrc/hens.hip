@@ -3,6 +3,7 @@
 #include "../../include/hipensemble.h"
 #include "hens_kernels.h"
 #include "hens_rj.h"
+#include "hens_iter.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -25,6 +26,8 @@ thread_local std::string g_last_error;
 struct DrawBuf {                     // one batch of planned iterations
     Draws d{};
     DrawRec* rec = nullptr;          // the same draws by walker id (fused second half-step + cascade launch)
+    DrawRec* rec1 = nullptr;         // one-launch iteration (k_iter): first half-step draws in block order,
+    DrawRec* rec3 = nullptr;         //   and the first half-step draws of every second-half walker's complement
     uint32_t* keys = nullptr;        // [NB][T][8] round keys of the cascade's column maps
 };
 
@@ -59,8 +62,12 @@ struct hens_ctx_impl {
     double* ad_ring = nullptr;       // [4][T] new ladders published by the adapting workgroup (fold mode 2), -1 = not yet
     uint32_t ad_serial = 0;
     int label_cb = 0, label_cb_shift = 0;   // block-balanced split labels: cascade columns per block (0 = legacy labels)
-    uint32_t* swap_acc[2] = {nullptr, nullptr};   // [SWAP_ACC_ROWS][T-1] swap counts accumulated by k_split1_pt, by sweep parity
-    int acc_cur = 0;                 // buffer the NEXT fused launch accumulates into (the other one is clean or being read)
+    // [SWAP_ACC_ROWS][T-1] swap counts accumulated with atomics by k_split1_pt / k_iter, three buffers in rotation: the
+    // launch that folds the adaptation in reads one (every workgroup: it cannot clear it), the cascade accumulates into a
+    // clean one, and the buffer read one launch earlier is cleared meanwhile
+    uint32_t* swap_acc[3] = {nullptr, nullptr, nullptr};
+    int acc_state[3] = {0, 0, 0};    // 0 clean, 1 pending (= adapt_src: the last cascade's counts), 2 read, not yet cleared
+    bool rows_mixed = false;         // k_iter ran: current rows live in both halves of the pool (folded back by state_to_fields)
 
     // model
     double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr; double* prec_sym = nullptr;
@@ -358,17 +365,41 @@ AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* 
     return a;
 }
 
-bool is_acc_buffer(const hens_ctx_impl* c, const uint32_t* p) { return p && (p == c->swap_acc[0] || p == c->swap_acc[1]); }
+bool is_acc_buffer(const hens_ctx_impl* c, const uint32_t* p) {
+    return p && (p == c->swap_acc[0] || p == c->swap_acc[1] || p == c->swap_acc[2]);
+}
+int acc_pick(const hens_ctx_impl* c, int state) {
+    for (int i = 0; i < 3; ++i) if (c->acc_state[i] == state) return i;
+    return -1;
+}
+// the launch being built folds the adaptation of the pending accumulation buffer in: it may clear the buffer that was read
+// one launch earlier (nobody touches that one meanwhile); the buffer it reads becomes the next one to clear
+void acc_fold(hens_ctx_impl* c, AdaptArgs& ad) {
+    const int z = acc_pick(c, 2), r = acc_pick(c, 1);
+    ad.zero_rows = z >= 0 ? c->swap_acc[z] : nullptr;
+    if (z >= 0) c->acc_state[z] = 0;
+    if (r >= 0) c->acc_state[r] = 2;
+}
+// the buffer the cascade being launched accumulates into; its counts are the next pending adaptation
+// (k_iter folds and accumulates in ONE launch: it takes its buffer BEFORE acc_fold hands out the one that launch clears)
+uint32_t* acc_take(hens_ctx_impl* c) {
+    const int a = acc_pick(c, 0);            // (at most one pending and one uncleared: one of three is always clean)
+    c->acc_state[a] = 3;                     // (taken; pending once the launch is queued: acc_commit)
+    return c->swap_acc[a];
+}
+void acc_commit(hens_ctx_impl* c) {
+    for (int i = 0; i < 3; ++i) if (c->acc_state[i] == 3) c->acc_state[i] = 1;
+}
 
 // reduce the pending cascade's swap counts and adapt the ladder as a kernel of its own
 void flush_adapt(hens_ctx_impl* c) {
     if (!c->adapt_pending) return;
     AdaptArgs a = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur]);
-    if (is_acc_buffer(c, c->adapt_src)) {            // a one-workgroup kernel, nothing else running: clear both buffers
-        a.zero_after = 1;
-        a.zero_rows = c->swap_acc[c->adapt_src == c->swap_acc[0] ? 1 : 0];
-    }
     hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), (size_t)c->T * 28 + 16, c->stream, a);
+    if (is_acc_buffer(c, c->adapt_src)) {            // nothing else is running: all three accumulation buffers start clean again
+        (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS * c->T * 4, c->stream);
+        c->acc_state[0] = c->acc_state[1] = c->acc_state[2] = 0;
+    }
     if (c->adapt_pending_adaptive) c->adapt_time += 1;               // tempering.py:596
     c->adapt_pending = false;
     c->adapt_src = nullptr;
@@ -613,7 +644,7 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
 }
 
 // plan nb iterations starting at iteration `iter0` into draw buffer `which`
-void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool fused = false) {
+void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool fused = false, bool iter1 = false) {
     PlanArgs pa{};
     pa.dr = c->db[which].d;
     pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
@@ -622,6 +653,7 @@ void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int
     pa.T = c->T; pa.cb = c->label_cb; pa.keys = c->db[which].keys;
     pa.rec = fused ? c->db[which].rec : nullptr;          // (only k_split1_pt reads the block-ordered records)
     pa.rec_only = fused ? 1 : 0;
+    if (iter1) { pa.rec1 = c->db[which].rec1; pa.rec3 = c->db[which].rec3; }   // (k_iter reads nothing else)
     hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
 }
 
@@ -670,7 +702,7 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
             a.ad_serial = c->ad_serial++;
         }
         a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
-        if (acc) a.ad.zero_rows = c->swap_acc[c->adapt_src == c->swap_acc[0] ? 1 : 0];
+        if (acc) acc_fold(c, a.ad);
         a.betas = c->betas[c->bcur];
         if (c->adapt_pending_adaptive) c->adapt_time += 1;
         c->adapt_pending = false;
@@ -787,6 +819,11 @@ void state_to_fields(hens_ctx_impl* c) {
     hipLaunchKernelGGL(k_unpack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], c->L[c->cur], c->P[c->cur],
                        c->loc[c->cur], n);
     c->packed = false;
+    if (c->rows_mixed) {          // k_iter left accepted rows in the half the copying launches write next: fold them back
+        hipLaunchKernelGGL(k_fold_rows, dim3(grid_for(n * (c->D / 2))), dim3(256), 0, c->stream, c->pool, c->loc[c->cur], n, c->D,
+                           (int32_t)n, (int32_t)(c->parity * n));
+        c->rows_mixed = false;
+    }
 }
 
 int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
@@ -818,7 +855,8 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.rec = c->db[which].rec + (size_t)ib * (T * W / 2);
     f.keys = c->db[which].keys + (size_t)ib * T * 8;
     f.accepted = c->accepted;
-    f.swap_acc = c->swap_acc[c->acc_cur];
+    f.swap_acc = acc_take(c);
+    acc_commit(c);
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
     f.flags = c->flags;
     f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
@@ -845,9 +883,101 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     c->cur ^= 1;
     c->adapt_pending = true;
     c->adapt_pending_adaptive = c->cfg.adaptive != 0;
-    c->adapt_src = c->swap_acc[c->acc_cur];        // SWAP_ACC_ROWS rows; the next launch's adaptation clears the other buffer
+    c->adapt_src = f.swap_acc;                     // SWAP_ACC_ROWS rows (see hens_ctx_impl::swap_acc)
     c->adapt_nblocks = SWAP_ACC_ROWS;
-    c->acc_cur ^= 1;
+    return HENS_OK;
+}
+
+// ---- one launch per iteration (k_iter, hens_iter.h) ----------------------------------------------------------------
+// the shapes of fused_ok whose launches are a single round of workgroups (latency-bound: see hens_iter.h), row widths
+// with three tiles in half a CU's LDS
+bool iter_ok(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_NO_ITER") != nullptr;               // A/B knob: two launches per iteration
+    static const long max_tw = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : 65536;
+    return !off && fused_ok(c) && (c->D == 16 || c->D == 32) && c->T <= 128 && c->W <= 32768 &&
+           (long)c->T * c->W <= max_tw && c->db[0].rec1 != nullptr;
+}
+
+template <int LIKE>
+int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEvent_t e1) {
+    const dim3 grid(c->W / c->label_cb);
+#define LAUNCH_ITER(DT, NW)                                                                        \
+    do {                                                                                           \
+        const size_t lds = iter_lds_bytes(DT, NW);                                                 \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        if (e0)                                                                                    \
+            hipExtLaunchKernelGGL((k_iter<DT, LIKE, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_iter<DT, LIKE, NW>), grid, dim3(NW * 64), lds, c->stream, f);    \
+    } while (0)
+    switch (c->D) {
+        case 16: LAUNCH_ITER(16, 8); break;
+        case 32: LAUNCH_ITER(32, 8); break;
+        default: return fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for ndim %d", c->D);
+    }
+#undef LAUNCH_ITER
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_iter launch failed: %s", hipGetErrorString(e));
+    return HENS_OK;
+}
+
+int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
+    const int T = c->T, W = c->W;
+    state_to_records(c);
+    if (c->adapt_pending && !(is_acc_buffer(c, c->adapt_src) && c->T <= 128)) flush_adapt(c);   // (counts of an MH iteration's cascade)
+    IterArgs f{};
+    f.pool = c->pool;
+    f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
+    f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
+    const size_t roff = (size_t)ib * (T * W / 2);
+    f.rec1 = c->db[which].rec1 + roff; f.rec2 = c->db[which].rec + roff; f.rec3 = c->db[which].rec3 + roff;
+    f.keys = c->db[which].keys + (size_t)ib * T * 8;
+    f.accepted = c->accepted;
+    f.betas = c->betas[c->bcur];
+    f.swap_acc = acc_take(c);
+    if (c->adapt_pending) {
+        f.ad_on = 1;
+        f.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
+        acc_fold(c, f.ad);
+        if (c->adapt_pending_adaptive) c->adapt_time += 1;
+        c->adapt_pending = false;
+        c->adapt_src = nullptr;
+        c->bcur ^= 1;
+    }
+    acc_commit(c);
+    f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
+    f.flags = c->flags;
+    f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
+    f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;
+    f.iter = c->iter; f.seed = c->cfg.seed;
+    f.T = T; f.W = W; f.idx_bits = c->idx_bits;
+    f.cb = c->label_cb; f.cb_shift = c->label_cb_shift;
+    f.half_rows = T * W;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (evs) {
+        e0 = new_event(c); e1 = new_event(c);
+        evs->push_back(e0); evs->push_back(e1);
+    }
+    int r;
+    switch (c->cfg.likelihood_kind) {
+        case HENS_LIKE_GAUSS_DENSE: r = launch_iter_like<LIKE_DENSE>(c, f, e0, e1); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_iter_like<LIKE_DIAG>(c, f, e0, e1); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_iter_like<LIKE_ROSEN>(c, f, e0, e1); break;
+        default: r = fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for likelihood kind %d", c->cfg.likelihood_kind);
+    }
+    if (r) return r;
+    c->rows_mixed = true;
+    c->num_proposals += 1;
+    c->cur ^= 1;
+    c->adapt_pending = true;
+    c->adapt_pending_adaptive = c->cfg.adaptive != 0;
+    c->adapt_src = f.swap_acc;
+    c->adapt_nblocks = SWAP_ACC_ROWS;
     return HENS_OK;
 }
 
@@ -1096,11 +1226,12 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
             while ((1 << c->label_cb_shift) < cb) c->label_cb_shift++;
         }
     }
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 2; ++b)
         if (c->label_cb) TRY(dalloc(c, &c->wrec[b], TW));
-        TRY(dalloc(c, &c->swap_acc[b], (size_t)SWAP_ACC_ROWS * c->T));
-        TRYHIP(hipMemsetAsync(c->swap_acc[b], 0, (size_t)SWAP_ACC_ROWS * c->T * 4, c->stream));
-    }
+    TRY(dalloc(c, &c->swap_acc[0], (size_t)3 * SWAP_ACC_ROWS * c->T));
+    c->swap_acc[1] = c->swap_acc[0] + (size_t)SWAP_ACC_ROWS * c->T;
+    c->swap_acc[2] = c->swap_acc[1] + (size_t)SWAP_ACC_ROWS * c->T;
+    TRYHIP(hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS * c->T * 4, c->stream));
     {
         const size_t per_iter = TW * 64;
         size_t nb = (96u << 20) / std::max<size_t>(per_iter, 1);
@@ -1116,6 +1247,10 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->db[b].d.fac, n));
         TRY(dalloc(c, &c->db[b].d.lu, n));
         if (c->label_cb) TRY(dalloc(c, &c->db[b].rec, n / 2));
+        if (c->label_cb && c->Tl == c->T && (c->D == 16 || c->D == 32) && c->W <= 32768 && TW <= ((size_t)1 << 20)) {
+            TRY(dalloc(c, &c->db[b].rec1, n / 2));       // (one-launch iteration, see iter_ok)
+            TRY(dalloc(c, &c->db[b].rec3, n / 2));
+        }
         TRY(dalloc(c, &c->db[b].keys, (size_t)c->NB * c->T * 8));
         TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
         TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
@@ -1564,6 +1699,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     const bool pt = has_pt(c);
     const bool prof = c->per_kernel_events;
     const bool fused = fused_ok(c);
+    const bool iter1 = iter_ok(c);
     state_to_fields(c);                       // (only after a call that failed half-way)
     std::vector<hipEvent_t> evs;
     std::vector<char> ev_kind;                // per event pair: 0 stretch launch, 1 cascade launch, 2 fused half-step + cascade
@@ -1577,7 +1713,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (nbatch > 0) {
         HIPCHK(c, hipEventRecord(c->ev_used[0], c->stream));      // earlier work may still read buffer 0
         HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[0], 0));
-        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0), fused);
+        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0), fused, iter1);
         HIPCHK(c, hipEventRecord(c->ev_plan[0], c->plan_stream));
         c->timing.n_plan += 1;
     }
@@ -1587,7 +1723,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
             HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));
-            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), fused);
+            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), fused, iter1);
             HIPCHK(c, hipEventRecord(c->ev_plan[nxt], c->plan_stream));
             c->timing.n_plan += 1;
         }
@@ -1601,6 +1737,12 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 else state_to_fields(c);
                 r = mh_iteration(c, prof ? &evs : nullptr, !piped && fast_path(c));
                 if (prof) ev_kind.push_back(0);
+            } else if (iter1) {
+                r = iter_iteration(c, which, ib, prof ? &evs : nullptr);
+                if (prof) ev_kind.push_back(3);
+                if (r) return r;
+                c->iter += 1;
+                continue;
             } else if (fused) {
                 r = fused_iteration(c, which, ib, prof ? &evs : nullptr);
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }

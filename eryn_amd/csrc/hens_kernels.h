@@ -142,6 +142,13 @@ __device__ __forceinline__ int block_member_code(const uint32_t* kpt, int t, int
     const int rank = block_rank(kpt, c, cb);
     return rank >= (cb >> 1) ? (c >> (__ffs(cb) - 1)) * (cb >> 1) + rank - (cb >> 1) : -1;   // cb is a power of two
 }
+// both halves (the one-launch iteration, k_iter): bit 15 = the walker moves in the FIRST half-step, low bits = block * (cb / 2)
+// + its place among the block's walkers of that half-step (rank, or rank - cb / 2)
+__device__ __forceinline__ int block_member_code2(const uint32_t* kpt, int t, int T, int w, int cb, int idx_bits, int W) {
+    const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
+    const int rank = block_rank(kpt, c, cb), hb = cb >> 1;
+    return (rank < hb ? 0x8000 : 0) | ((c >> (__ffs(cb) - 1)) * hb + (rank & (hb - 1)));
+}
 __device__ __forceinline__ double pt_uniform(uint64_t seed, uint64_t it, int j, int W, int c) {   // tempering.py:535
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(j * W + c), PURPOSE_PTU};
     const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -1471,6 +1478,9 @@ struct PlanArgs {
     int32_t T, cb;        // cb > 0: block-balanced labelling with cb columns per block (see block_rank); 0: label = prp >= N0
     DrawRec* rec;         // [NB][W / cb][64] the second half-step's draws in k_split1_pt's order (see DrawRec), or nullptr
     int32_t rec_only;     // with rec: the by-position arrays of the second half-step are not needed (nobody reads them)
+    DrawRec* rec1;        // one-launch iteration (k_iter; with rec, W <= 65536): [NB][W / cb][64] the FIRST half-step's draws in
+    DrawRec* rec3;        //   block order, and for every second-half walker the first-half draws of ITS complement (k_iter
+                          //   replays that walker's first half-step itself); no by-position arrays at all
     uint32_t* keys;       // [NB][T][8] round keys of every rung's cascade column map (cb > 0), or nullptr
     double* dbg_uzz;      // debug (hens_debug_draws): the raw uniforms behind zz / lu, [NB][Tl][W], or nullptr
     double* dbg_uacc;
@@ -1525,19 +1535,21 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     for (int r = 0; r < 8; ++r) key[r] = skey[r];
     if (A.cb) {
         if (A.keys && tid < 8) A.keys[((size_t)ib * A.T + rung) * 8 + tid] = skey[tid];   // (key[tid] would put the array in scratch)
-        for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
+        if (A.rec1) for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code2(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
+        else for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
     } else {
         for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 0 : 0xFFFFu;
     }
     __syncthreads();
     const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
     const int lo = min(W, tid * chunk), hi = min(W, lo + chunk);
+    const uint32_t fmask = A.rec1 ? 0x8000u : 0xFFFFu;               // (lab & fmask) == fmask: first half-step
     uint32_t z = 0;
-    for (int i = lo; i < hi; ++i) z += (lab[i] == 0xFFFFu);
+    for (int i = lo; i < hi; ++i) z += ((lab[i] & fmask) == fmask);
     uint32_t z0 = block_excl_scan(z, wtot, tid, nt);                 // first-half walkers before this thread's chunk
     uint32_t o0 = (uint32_t)lo - z0;                                 // second-half walkers before it
     for (int i = lo; i < hi; ++i) {
-        if (lab[i] == 0xFFFFu) ord[z0++] = i;
+        if ((lab[i] & fmask) == fmask) ord[z0++] = i;
         else ord[N0 + o0++] = i;
     }
     __syncthreads();
@@ -1554,6 +1566,25 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
         const int r = (int)__umulhi(d.x, (uint32_t)Nc);
         const int cw = ord[(s0 ? N0 : 0) + r];
         const DrawRec rc = draw_values(own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
+        if (A.rec1) {                                                // k_iter: everything in block order
+            const int hb = A.cb >> 1, code = lab[own] & 0x7FFF;
+            const int blk = code >> (__ffs(hb) - 1), ml = code & (hb - 1);
+            const size_t ri = ((size_t)ib * (W / A.cb) + blk) * TILE + (size_t)rung * hb + ml;
+            if (s0) {
+                A.rec1[ri] = rc;
+            } else {
+                A.rec[ri] = rc;
+                // the complement is a first-half walker: its own draws once more (same counters -> same values)
+                u4 c1 = ctr;
+                c1.z = rung * (uint32_t)W + (uint32_t)cw;
+                const u4 d1 = philox4x32_10(c1, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                c1.w = PURPOSE_STRETCH_ACC;
+                const u4 e1 = philox4x32_10(c1, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+                const int c2 = ord[N0 + (int)__umulhi(d1.x, (uint32_t)(W - N0))];
+                A.rec3[ri] = draw_values(cw, c2, u01(d1.y, d1.z), u01(e1.x, e1.y), A.a, A.D);
+            }
+            continue;
+        }
         if (s0 || !(A.rec && A.rec_only)) store_draw(A.dr, base + p, rc);
         if (A.rec && !s0) {
             const int hb = A.cb >> 1, code = lab[own];               // block * hb + place among the block's moving walkers
