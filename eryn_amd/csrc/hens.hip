@@ -889,13 +889,18 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
 }
 
 // ---- one launch per iteration (k_iter, hens_iter.h) ----------------------------------------------------------------
-// the shapes of fused_ok whose launches are a single round of workgroups (latency-bound: see hens_iter.h), row widths
-// with three tiles in half a CU's LDS
+// the shapes of fused_ok that leave the chip half empty (latency-bound: see hens_iter.h), row widths with three tiles in
+// half a CU's LDS.  Measured on one box (tools/iter_sweep.sh, us per iteration, one launch vs two):
+//   4 x 4096 x 32  14.7 / 18.2     8 x 4096 x 32  15.5 / 18.8    16 x 2048 x 32  15.6 / 18.3    32 x 1024 x 32  17.1 / 20.1
+//   16 x 4096 x 16  16.4 / 19.7   16 x 4096 x 32 (config 2)  22.4 / 22.5     8 x 8192 x 32  22.0 / 22.7
+//   32 x 2048 x 32  23.9 / 23.8   16 x 6144 x 32  33.5 / 34.5
+// Up to one workgroup per CU (T W D <= 2^20 doubles of state) the single launch wins 15-19 %; with two workgroups per
+// CU its extra gathers and likelihoods cost what the second launch did, and the profiled two-launch path stays.
 bool iter_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_ITER") != nullptr;               // A/B knob: two launches per iteration
-    static const long max_tw = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : 65536;
+    static const long max_twd = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : (1L << 20);
     return !off && fused_ok(c) && (c->D == 16 || c->D == 32) && c->T <= 128 && c->W <= 32768 &&
-           (long)c->T * c->W <= max_tw && c->db[0].rec1 != nullptr;
+           (long)c->T * c->W * c->D <= max_twd && c->db[0].rec1 != nullptr;
 }
 
 template <int LIKE>

@@ -136,6 +136,9 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
     constexpr int NE = 2 * TILE;
+    // the likelihood's rows are dealt to the waves exactly as in k_stretch_fast / k_split1_pt for this row width (4 waves at
+    // D = 16): the same partial sums in the same order, so an iteration gives the same bits whichever path runs it
+    constexpr int LNW = DT >= 32 ? NW : 4;
     double* tileA = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS] first half-step proposals
     double* tileX = tileA + TILE * RS;                                   // replayed first half-step of the complements
     double* tileB = tileX + TILE * RS;                                   // second half-step proposals
@@ -297,8 +300,10 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     // ---- phase C1: likelihood of the first half-step proposals and of the replayed ones ---------------------------
     {
         const bool inA = (s_flag[lane] & 1) != 0, inX = (s_flag[TILE + lane] & 1) != 0;
-        s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW, false>(tileA, lane, wv, inA, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
-        s_part[(NW + wv) * TILE + lane] = like_partial<DT, LIKE, NW, false>(tileX, lane, wv, inX, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        if (wv < LNW) {
+            s_part[wv * TILE + lane] = like_partial<DT, LIKE, LNW, false>(tileA, lane, wv, inA, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+            s_part[(NW + wv) * TILE + lane] = like_partial<DT, LIKE, LNW, false>(tileX, lane, wv, inX, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        }
     }
     ITER_TRACE(3);
     lds_barrier();
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         const bool inbox = (flagw & 1) != 0;
         double acc = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) acc += part[w2 * TILE + lane];
+        for (int w2 = 0; w2 < LNW; ++w2) acc += part[w2 * TILE + lane];
         double logl = inbox ? -0.5 * acc : A.fill;                      // ensemble.py:1486-1513
         if (logl != logl) {                                             // red_blue.py:279-281
             logl = -1e300;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     // ---- phase C2 / D2 ------------------------------------------------------------------------------------------
     {
         const bool inB = (s_flag[2 * TILE + lane] & 1) != 0;
-        s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW, false>(tileB, lane, wv, inB, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        if (wv < LNW) s_part[wv * TILE + lane] = like_partial<DT, LIKE, LNW, false>(tileB, lane, wv, inB, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }
     ITER_TRACE(5);
     lds_barrier();

@@ -9,7 +9,9 @@ between the two must be invisible:
   the oracle, then ``hens_step`` continues from the parity API's state (copying launches flip the pool half, in-place
   iterations must leave the free half free),
 * the three-launch path (``HENS_NO_FUSED=1``: copying half-steps + stand-alone cascade on the same draws) reaches the
-  same state bit for bit, with and without the Metropolis-Hastings move in the mix.
+  same state bit for bit, with and without the Metropolis-Hastings move in the mix,
+* so does the one-launch iteration of small shapes (``k_iter``: versioned rows, replayed complements) against the two
+  launches (``HENS_NO_ITER=1``).
 """
 import os
 import subprocess
@@ -136,3 +138,40 @@ def test_record_mode_equals_the_copying_three_launch_path(T, W, D, use_mh, like,
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(dict(np.load(out)))
     _assert_same(outs[0], outs[1], f"({T},{W},{D}) two-launch record mode vs three copying launches")
+
+
+def _one_launch(eng, n=3):
+    """True when hens_step runs the iterations of this context as single launches (k_iter): no stretch launch of its own."""
+    eng.set_profiling(True)
+    eng.step(n)
+    tm = eng.timing()
+    eng.set_profiling(False)
+    return tm["n_stretch"] == 0 and tm["n_fused"] == n
+
+
+@pytest.mark.parametrize("T,W,D,use_mh,like", [(8, 4096, 32, 0, "dense"), (16, 256, 32, 1, "dense"), (4, 1024, 16, 1, "dense"),
+                                              (32, 512, 32, 0, "rosen"), (2, 128, 32, 0, "dense")])
+def test_one_launch_iteration_equals_the_two_launch_path(T, W, D, use_mh, like, tmp_path):
+    """k_iter (hens_iter.h) against k_stretch_fast + k_split1_pt from the same seed: positions, log-probabilities, ladder,
+    accept and swap counters bit for bit, across two calls (rows folded back into one half in between) and with the
+    Metropolis-Hastings move in the mix (its cascade's counts are adapted stand-alone before the next single launch)."""
+    eng, *_ = _engine(T, W, D)
+    assert _one_launch(eng), "this shape was expected to step in one launch per iteration"
+    eng.close()
+    outs = []
+    for tag, env in (("one", {}), ("two", {"HENS_NO_ITER": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ, **env)
+        if tag == "one":
+            e.pop("HENS_NO_ITER", None)
+        r = subprocess.run([sys.executable, "-c", _WORKER, ROOT, str(T), str(W), str(D), str(use_mh), like, out],
+                           env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(dict(np.load(out)))
+    _assert_same(outs[0], outs[1], f"({T},{W},{D}) one launch per iteration vs two")
+
+
+def test_config2_keeps_the_two_launch_path():
+    eng, *_ = _engine(16, 4096, 32)
+    assert not _one_launch(eng)
+    eng.close()

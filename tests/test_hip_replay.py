@@ -122,6 +122,13 @@ def test_replay_adaptation_stops():
     _run_case(4, 128, 8, calls=(4,), adaptive=False)
 
 
+@pytest.mark.parametrize("T,W,D,like", [(8, 4096, 32, "dense"), (16, 2048, 16, "dense"), (4, 512, 32, "diag"), (32, 256, 32, "rosen")])
+def test_replay_one_launch_shapes(T, W, D, like):
+    """shapes that step in ONE launch per iteration (k_iter: replayed complements, versioned rows, three count buffers in
+    rotation - four consecutive iterations in a call cover a whole turn of them)"""
+    _run_case(T, W, D, like_kind=like, box=6.0 if like == "rosen" else 50.0, calls=(1, 4, 2), x_scale=0.5 if like == "rosen" else 1.0)
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_replay_local_pipeline(tmp_path, nranks):
     """N ladder shards stepping through the pipeline (one-sided puts, per-block hand-off flags) against the oracle"""
