@@ -60,6 +60,7 @@ SIGNATURES = {
     "hens_last_error": (C.c_char_p, [_P]),
     "hens_synchronize": (C.c_int, [_P]),
     "hens_set_prior_box": (C.c_int, [_P, _P, _P, C.c_double]),
+    "hens_set_periodic": (C.c_int, [_P, _P]),
     "hens_set_gaussian": (C.c_int, [_P, _P, _P]),
     "hens_set_rosenbrock": (C.c_int, [_P, C.c_double, C.c_double]),
     "hens_upload_state": (C.c_int, [_P, _P, _P, _P, _P]),

@@ -71,6 +71,8 @@ struct hens_ctx_impl {
 
     // model
     double* lo = nullptr; double* hi = nullptr; double* mu = nullptr; double* prec = nullptr; double* prec_sym = nullptr;
+    double* period = nullptr;        // [D] periods of the periodic parameters (hens_set_periodic), nullptr: none
+    double* period_buf = nullptr;
     double logp_in = 0.0, rosen_a = 1.0, rosen_b = 100.0;
     bool have_prior = false, have_like = false, have_state = false, have_logs = false;
 
@@ -208,6 +210,7 @@ int fast_nw(int D) { return (D == 32 || D == 64 || D == 128) ? 8 : 4; }
 // row widths with a compile-time-width kernel (k_stretch_fast)
 bool fast_path(const hens_ctx_impl* c) {
     const int D = c->D;
+    if (c->period) return false;      // periodic parameters: the generic-width kernel measures distances / wraps (k_stretch)
     return D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && c->cfg.likelihood_kind != HENS_LIKE_HOST);
 }
 
@@ -246,7 +249,9 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         else LAUNCH_FAST_P(DT, NW, false);                                                         \
     } while (0)
     bool launched = true;
-    if (c->D == 32) {
+    if (!fast_path(c)) {
+        launched = false;
+    } else if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
     } else if (c->D == 64) {
         LAUNCH_FAST(64, 8);
@@ -337,6 +342,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     a.dr = c->db[0].d;
     a.accepted = c->accepted;
     a.lo = c->lo; a.hi = c->hi; a.mu = c->mu; a.prec = c->prec; a.prec_sym = c->prec_sym;
+    a.period = c->period;
     a.flags = c->flags;
     a.trace = (c->tracing && !c->trace_pt && !c->trace_fused) ? c->d_trace : nullptr;
     a.logp_in = c->logp_in;
@@ -1346,6 +1352,35 @@ int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double
     return HENS_OK;
 }
 
+int hens_set_periodic(hens_ctx* ctx, const double* period) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE)
+        return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters are not defined on leaf-packing records");
+    if (c->pipe.on) return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters on a rank of the ladder pipeline");
+    bool any = false;
+    if (period)
+        for (int d = 0; d < c->D; ++d) {
+            if (!(period[d] >= 0.0) || !(period[d] < INFINITY)) return fail(c, HENS_ERR_INVALID, "period of dimension %d must be finite and >= 0", d);
+            any = any || period[d] > 0.0;
+        }
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    flush_adapt(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!any) {                       // back to the compile-time-width kernels
+        c->period = nullptr;
+        return HENS_OK;
+    }
+    if (!c->period_buf) {
+        int r = dalloc(c, &c->period_buf, (size_t)c->D);
+        if (r) return r;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->period_buf, period, c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->period = c->period_buf;
+    return HENS_OK;
+}
+
 int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c || !mu || !prec) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -1566,7 +1601,7 @@ static HostLikeArgs hostlike_args(hens_ctx_impl* c, int32_t split) {
     h.pool = c->pool; h.loc = c->loc[c->cur]; h.L = c->L[c->cur]; h.P = c->P[c->cur];
     h.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
     h.dr = c->db[0].d;
-    h.lo = c->lo; h.hi = c->hi;
+    h.lo = c->lo; h.hi = c->hi; h.period = c->period;
     h.qbuf = c->xtmp;                                   // [Tl*W][D] scratch: Ns <= W rows per rung
     h.inbox = c->d_keep;                                // [Tl][N0] scratch (keep flags go to hl_keep)
     h.rs_old = c->hl_rs; h.keep = c->hl_keep;

@@ -313,6 +313,30 @@ __device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_del
     return loc >= 0 ? (int64_t)loc * D : guest_delta + (int64_t)(~loc) * D;
 }
 
+// Periodic parameters (utils/periodic.py, used by stretch.py:136-154 and gaussian.py:110-115); period <= 0: not periodic.
+// distance(p1 = s, p2 = c): c - s, measured the short way round when it exceeds half a period (periodic.py:80-113: the moving
+// point is shifted by one period towards the complement - new_s = -(period - s) or period + s - and the difference taken
+// again); wrap: NumPy's float remainder (periodic.py:143-145; npy_divmod: fmod, shifted by the divisor when the signs
+// differ, +0 of the divisor's sign when exact).  fmod is exact, so both reproduce the reference bit for bit.
+__device__ __forceinline__ double periodic_diff(double s, double c, double period) {
+    double diff = c - s;
+    if (period > 0.0 && fabs(diff) > period / 2.0) {
+        const double new_s = diff < 0.0 ? -(period - s) : period + s;
+        diff = c - new_s;
+    }
+    return diff;
+}
+__device__ __forceinline__ double periodic_wrap(double q, double period) {
+    if (!(period > 0.0)) return q;
+    double m = fmod(q, period);
+    if (m != 0.0) {
+        if (m < 0.0) m += period;
+    } else {
+        m = 0.0;                                  // copysign(0, period), period > 0
+    }
+    return m;
+}
+
 // The state-independent part of one proposal (stretch.py:129-132,223; red_blue.py:294).
 struct Draws {
     int32_t* own;    // [Tl][W] moving walker at each split position (positions < N0: split 0)
@@ -404,6 +428,7 @@ struct StretchArgs {
     uint8_t* keep_out;         // [Tl][Ns] or nullptr
     const double* lo;
     const double* hi;
+    const double* period;      // [D] periods of the periodic parameters (0: not periodic), or nullptr: none (generic kernel only)
     const double* mu;
     const double* prec;
     const double* prec_sym;    // packed symmetric rows for the fast kernel (see sym_quad), dense only
@@ -542,9 +567,16 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                         if (MH) {
                             qv.x = sv.x + cv.x;               // gaussian.py:166-167
                             qv.y = sv.y + cv.y;
+                        } else if (A.period) {                // stretch.py:136-145 with periodic parameters
+                            qv.x = cv.x - periodic_diff(sv.x, cv.x, A.period[e]) * zz;
+                            qv.y = cv.y - periodic_diff(sv.y, cv.y, A.period[e + 1]) * zz;
                         } else {
                             qv.x = cv.x - (cv.x - sv.x) * zz; // stretch.py:143,145
                             qv.y = cv.y - (cv.y - sv.y) * zz;
+                        }
+                        if (A.period) {                       // stretch.py:149-154, gaussian.py:110-115
+                            qv.x = periodic_wrap(qv.x, A.period[e]);
+                            qv.y = periodic_wrap(qv.y, A.period[e + 1]);
                         }
                     }
                     const double2 lov = *reinterpret_cast<const double2*>(A.lo + e);
@@ -559,7 +591,10 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                         qv = sv;
                     } else {
                         const double cv = pc[e];
-                        qv = MH ? sv + cv : cv - (cv - sv) * zz;
+                        if (MH) qv = sv + cv;
+                        else if (A.period) qv = cv - periodic_diff(sv, cv, A.period[e]) * zz;
+                        else qv = cv - (cv - sv) * zz;
+                        if (A.period) qv = periodic_wrap(qv, A.period[e]);
                     }
                     ok = ok && (qv >= A.lo[e]) && (qv <= A.hi[e]);
                     finite = finite && (fabs(qv) < INFINITY);
@@ -2240,6 +2275,7 @@ struct HostLikeArgs {
     Draws dr;
     const double* lo;
     const double* hi;
+    const double* period;    // [D] or nullptr (see StretchArgs::period)
     double* qbuf;            // [Tl][Ns][D] proposed points
     uint8_t* inbox;          // [Tl][Ns] 1 = inside the prior box
     int32_t* rs_old;         // [Tl][Ns] pool row of the moving walker before the update
@@ -2264,7 +2300,8 @@ __global__ void k_propose(const HostLikeArgs A) {
         const double zz = A.dr.zz[di];
         const double sv = A.pool[(size_t)A.loc[tl * A.W + own] * A.D + d];
         const double cv = A.pool[(size_t)A.loc[tl * A.W + cw] * A.D + d];
-        const double qv = cv - (cv - sv) * zz;                       // stretch.py:143,145
+        double qv = cv - (cv - sv) * zz;                             // stretch.py:143,145
+        if (A.period) qv = periodic_wrap(cv - periodic_diff(sv, cv, A.period[d]) * zz, A.period[d]);   // stretch.py:136-154
         A.qbuf[i] = qv;
         if (!((qv >= A.lo[d]) && (qv <= A.hi[d]))) A.inbox[wk] = 0;  // prior.py:80-88 (inbox preset to 1)
         if (!(fabs(qv) < INFINITY)) atomicOr(A.flags, FLAG_NONFINITE_X);

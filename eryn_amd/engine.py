@@ -50,6 +50,16 @@ class HipEnsemble:
         self.likelihood = likelihood
         self.N0 = (self.W + 1) // 2
 
+    def set_periodic(self, period):
+        """Periods of the periodic parameters, ``[ndim]`` (0 = not periodic), or None for none: the ``periodic``
+        argument of the reference's sampler / moves for the single branch (ensemble.py:165-168, utils/periodic.py)."""
+        if period is None:
+            check(self.lib.hens_set_periodic(self.ctx, None), self.ctx)
+            self.period = None
+            return
+        self.period = f64(period, (self.D,))
+        check(self.lib.hens_set_periodic(self.ctx, ptr(self.period)), self.ctx)
+
     def close(self):
         if getattr(self, "ctx", None):
             self.lib.hens_destroy(self.ctx)

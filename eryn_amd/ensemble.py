@@ -15,13 +15,14 @@ from .backend import Backend
 from .engine import HipEnsemble
 from .model import Model
 from .moves import DeviceMove, GaussianMove, MHMove, StretchMove, TemperatureControl
+from .periodic import PeriodicContainer, period_vector
 from .prior import ProbDistContainer
 from .state import State
 
 
 class EnsembleSampler:
     def __init__(self, nwalkers, ndims, log_like_fn, priors, tempering_kwargs={}, branch_names=None,
-                 nleaves_max=1, moves=None, args=None, kwargs=None, backend=None, vectorize=True,
+                 nleaves_max=1, moves=None, args=None, kwargs=None, backend=None, vectorize=True, periodic=None,
                  fill_zero_leaves_val=-1e300, rng="numpy", seed=None, device_id=0, info={}, **unused):
         # -- shapes: a single branch with one leaf (ensemble.py:265-317 normalises to dicts)
         if isinstance(ndims, dict):
@@ -77,9 +78,17 @@ class EnsembleSampler:
             self.ntemps = self.temperature_control.ntemps
         tc = self.temperature_control
 
+        # -- periodic parameters (ensemble.py:338-347): a dict becomes a container; moves without one of their own get it
+        if periodic is not None:
+            if isinstance(periodic, dict):
+                periodic = PeriodicContainer(periodic)
+            elif not (hasattr(periodic, "inds_periodic") and hasattr(periodic, "periods")):
+                raise ValueError("periodic must be PeriodicContainer or dict if not None.")
+        self.periodic = periodic
+
         # -- moves (ensemble.py:350-378, 517-544)
         if moves is None:
-            moves = [StretchMove(a=2.0)]
+            moves = [StretchMove(a=2.0, periodic=periodic)]
         elif not isinstance(moves, (list, tuple)):
             moves = [moves]
         self.moves, weights = [], []
@@ -112,6 +121,8 @@ class EnsembleSampler:
         for m in self.moves:
             if m.temperature_control is None:
                 m.temperature_control = tc
+            if periodic is not None and m.periodic is None:          # ensemble.py:528-536
+                m.periodic = periodic
             m.attach_engine(self.engine, self._resident)
             m.trust_resident = True
             m.accepted = np.zeros((self.ntemps, self.nwalkers))
@@ -241,6 +252,12 @@ class EnsembleSampler:
         if tc is not None:
             eng.set_adapt_time(tc.time)
         st_move, mh_move = self._philox_moves
+        # one context steps both moves of the mix: they must agree on the periodic parameters
+        pers = [period_vector(m.periodic, name, self.ndim) for m in (st_move, mh_move) if m is not None]
+        if len(pers) == 2 and not ((pers[0] is None and pers[1] is None) or
+                                   (pers[0] is not None and pers[1] is not None and np.array_equal(pers[0], pers[1]))):
+            raise NotImplementedError("rng='philox': the moves of a mix must share their periodic parameters")
+        eng.set_periodic(pers[0] if pers else None)
         prev = eng.counters()
         prev_mh = eng.mh_counters() if mh_move is not None else None
         inds = state.branches[name].inds

@@ -3,6 +3,7 @@ parallel-tempering tail every in-model move ends with (red_blue.py:330-331, mh.p
 import numpy as np
 
 from ..engine import HipEnsemble
+from ..periodic import period_vector
 from ..state import State
 from .move import Move
 
@@ -61,6 +62,14 @@ class DeviceMove(Move):
                                   live_dangerously=self._engine_live or not self.needs_walker_guard, fill_value=self.fill_value,
                                   device_id=self.device_id, **kw)
         return self.engine
+
+    def _apply_periodic(self, eng, name, D):
+        """The context measures distances / wraps proposals with this move's periodic parameters (stretch.py:136-154,
+        gaussian.py:110-115); moves of one sampler may differ, so every proposal states its own."""
+        per = period_vector(self.periodic, name, D)
+        cur = getattr(eng, "period", None)
+        if (per is None) != (cur is None) or (per is not None and not np.array_equal(per, cur)):
+            eng.set_periodic(per)
 
     @staticmethod
     def _single_branch(state):

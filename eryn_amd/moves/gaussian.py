@@ -24,6 +24,7 @@ class MHMove(DeviceMove):
         eng = self._ensure_engine(T, W, D)
         if hasattr(eng.likelihood, "evaluate"):
             raise NotImplementedError("MH moves on the device need a device likelihood")
+        self._apply_periodic(eng, name, D)
         self._upload_if_needed(eng, state, br)
         step = self.get_step(model.random, T * W, D)                   # gaussian.py:116 (all leaves active)
         u_acc = model.random.rand(T, W)                                # mh.py:157

@@ -18,16 +18,19 @@ class Move:
             np.random.seed(random_seed)
         self.temperature_control = temperature_control
 
-    # -- periodic parameters: the reference's sampler assigns this attribute after construction when it was given a
-    #    periodic container (ensemble.py:528-536); the device path has none, so a non-None value must not pass silently
+    # -- periodic parameters (move.py:24-26,82): a PeriodicContainer (this package's or the reference's) or None.  The
+    #    reference's sampler also assigns this attribute after construction when it was given one (ensemble.py:528-536).
+    #    The device moves hand the periods to their context before every proposal (DeviceMove._apply_periodic).
     @property
     def periodic(self):
-        return None
+        return self._periodic
 
     @periodic.setter
     def periodic(self, periodic):
-        if periodic is not None:
-            raise NotImplementedError("periodic parameters are outside the device hot path")
+        if periodic is not None and not isinstance(periodic, dict) and not (
+                hasattr(periodic, "inds_periodic") and hasattr(periodic, "periods")):
+            raise ValueError("periodic must be PeriodicContainer or dict if not None.")
+        self._periodic = periodic
 
     # -- counters (move.py:404-421) --------------------------------------------------------------
     @property

@@ -48,6 +48,7 @@ class StretchMove(DeviceMove):
     def propose(self, model, state):
         name, br, T, W, D = self._single_branch(state)
         eng = self._ensure_engine(T, W, D)
+        self._apply_periodic(eng, name, D)
         self._upload_if_needed(eng, state, br)
 
         accepted = np.zeros((T, W), dtype=bool)

@@ -94,6 +94,13 @@ int hens_synchronize(hens_ctx* ctx);
  *   (tests/test_eryn.py:33-35,100-104).  prec has D*D entries (dense) or D (diag).
  * hens_set_rosenbrock: constants of the config-5 stress likelihood. */
 int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double logp_inside);
+/* hens_set_periodic: the `periodic` argument of EnsembleSampler / Move (ensemble.py:165-168,338-347,528-536; a
+ *   PeriodicContainer, utils/periodic.py:11-151) for the single branch: period[d] > 0 makes parameter d periodic - the
+ *   stretch move measures c - s the short way round (stretch.py:136-141 -> periodic.py:49-116) and every proposal is
+ *   wrapped into [0, period) with NumPy's remainder (stretch.py:149-154, gaussian.py:110-115 -> periodic.py:118-151);
+ *   0 = not periodic; NULL or all zeros = no periodic parameters.  Contexts with periodic parameters step through the
+ *   generic-width kernel (every entry point; results are bit-identical to the reference's, the launches are slower). */
+int hens_set_periodic(hens_ctx* ctx, const double* period);
 int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec);
 int hens_set_rosenbrock(hens_ctx* ctx, double a, double b);
 

@@ -186,12 +186,39 @@ def split_index_lists(labels, split):
     return S, C
 
 
+def periodic_distance(s, c, period):
+    """``PeriodicContainer.distance(p1 = s, p2 = c)`` for one branch (utils/periodic.py:49-116): ``c - s``, taken the
+    short way round where it exceeds half a period.  ``period``: [D], 0 = not periodic, or None."""
+    diff = c - s                                                          # periodic.py:80
+    if period is None:
+        return diff
+    idx = np.flatnonzero(np.asarray(period) > 0)
+    if idx.size:
+        per = np.asarray(period, dtype=np.float64)[idx]
+        dp = diff[..., idx]                                               # periodic.py:93
+        fix = np.abs(dp) > per / 2.0                                      # periodic.py:96-98
+        new_s = -(per - s[..., idx]) * (dp < 0.0) + (per + s[..., idx]) * (dp >= 0.0)   # periodic.py:101-107
+        dp[fix] = c[..., idx][fix] - new_s[fix]                           # periodic.py:110-112
+        diff[..., idx] = dp
+    return diff
+
+
+def periodic_wrap(q, period):
+    """``PeriodicContainer.wrap`` for one branch (utils/periodic.py:118-151): NumPy's remainder on the periodic
+    parameters, in place."""
+    if period is not None:
+        idx = np.flatnonzero(np.asarray(period) > 0)
+        if idx.size:
+            q[..., idx] = q[..., idx] % np.asarray(period, dtype=np.float64)[idx]   # periodic.py:143-145
+    return q
+
+
 def stretch_split(x, L, P, betas, labels, split, rint, u_zz, u_acc, a, lo, hi,
-                  loglike, fill=-1e300):
+                  loglike, fill=-1e300, period=None):
     """One red/blue half-step, all rungs; mutates x, L, P in place.
 
     Returns a dict of intermediates (q, logp, logl, factors, lnpdiff, keep).
-    SURVEY 3.2 step 3 a-j.
+    SURVEY 3.2 step 3 a-j.  ``period``: periodic parameters (stretch.py:136-154), see ``periodic_distance``.
     """
     T, W, D = x.shape
     S, C = split_index_lists(labels, split)
@@ -201,8 +228,9 @@ def stretch_split(x, L, P, betas, labels, split, rint, u_zz, u_acc, a, lo, hi,
     s = x[tt, S]                                   # [T, Ns, D]
     c = x[tt, C[tt, rint]]                         # stretch.py:93-100
     zz = ((a - 1.0) * u_zz + 1) ** 2.0 / a         # stretch.py:129-132
-    diff = c - s                                   # stretch.py:143
+    diff = periodic_distance(s, c, period)         # stretch.py:136-143
     q = c - diff * zz[:, :, None]                  # stretch.py:145
+    q = periodic_wrap(q, period)                   # stretch.py:149-154
     factors = (D - 1.0) * np.log(zz)               # stretch.py:223
 
     logp = box_log_prior(q.reshape(-1, D), lo, hi).reshape(T, Ns)
@@ -287,14 +315,14 @@ class GaussianProposal:
         return out
 
 
-def mh_step(x, L, P, betas, step, u_acc, lo, hi, loglike, fill=-1e300):
+def mh_step(x, L, P, betas, step, u_acc, lo, hi, loglike, fill=-1e300, period=None):
     """One full-ensemble Metropolis-Hastings proposal q = x + step; mutates x, L, P in place.
 
     ``MHMove.propose`` (mh.py:56-193) for a single branch with every leaf active: no red/blue split,
     factors = 0 (gaussian.py:131), same tempered accept test and ``Move.update`` as the stretch move.
     """
     T, W, D = x.shape
-    q = x + step.reshape(T, W, D)
+    q = periodic_wrap(x + step.reshape(T, W, D), period)                  # gaussian.py:110-115
     logp = box_log_prior(q.reshape(-1, D), lo, hi).reshape(T, W)          # mh.py:120
     if np.any(np.isnan(logp)):
         raise ValueError("The prior function is returning Nan.")
@@ -370,7 +398,7 @@ class OracleSampler:
     def __init__(self, x0, loglike, lo, hi, R, G, betas=None, a=2.0,
                  adaptive=True, permute=True, adaptation_lag=10000,
                  adaptation_time=100, stop_adaptation=-1, randomize_split=True,
-                 live_dangerously=False, fill=-1e300, record=False, moves=None):
+                 live_dangerously=False, fill=-1e300, record=False, moves=None, period=None):
         # moves: [("stretch" | GaussianProposal, weight), ...]; default the reference's single StretchMove
         self.moves = [("stretch", 1.0)] if moves is None else list(moves)
         w = np.atleast_1d([m[1] for m in self.moves]).astype(float)
@@ -390,6 +418,7 @@ class OracleSampler:
         self.randomize_split = randomize_split
         self.live_dangerously = live_dangerously
         self.fill = fill
+        self.period = None if period is None else np.asarray(period, dtype=np.float64)   # periodic parameters (0: none)
         self.time = 0
         self.record = record
         self.trace = []
@@ -463,7 +492,7 @@ class OracleSampler:
         step = prop.draw_step(self.R, T * W, D).reshape(T, W, D)
         u_acc = self.R.rand(T, W)                                     # mh.py:157
         out = mh_step(self.x, self.L, self.P, self.betas, step, u_acc, self.lo, self.hi, self.loglike,
-                      fill=self.fill)
+                      fill=self.fill, period=self.period)
         if self.record:
             rec.update(mh_step=step, mh_u_acc=u_acc, mh_q=out["q"], mh_logp=out["logp"], mh_logl=out["logl"],
                        mh_lnpdiff=out["lnpdiff"], mh_keep=out["keep"])
@@ -487,7 +516,7 @@ class OracleSampler:
             u_acc = self.R.rand(T, Ns)
             out = stretch_split(self.x, self.L, self.P, self.betas, labels, split, rint,
                                 u_zz, u_acc, self.a, self.lo, self.hi, self.loglike,
-                                fill=self.fill)
+                                fill=self.fill, period=self.period)
             accepted[tt, out["S"]] = out["keep"]
             if self.record:
                 rec[f"rint{split}"], rec[f"u_zz{split}"], rec[f"u_acc{split}"] = rint, u_zz, u_acc

@@ -51,8 +51,10 @@ class RLog:
         return wrapped
 
 
-def capture(name, T, W, D, nsteps, moves_spec, box=6.0, seed_construct=321, seed_run=654, tempering_kwargs=None):
-    """moves_spec: list of ("stretch", weight) | ("gauss", weight, dict(cov=..., mode=..., factor=...))."""
+def capture(name, T, W, D, nsteps, moves_spec, box=6.0, seed_construct=321, seed_run=654, tempering_kwargs=None,
+            periodic=None):
+    """moves_spec: list of ("stretch", weight) | ("gauss", weight, dict(cov=..., mode=..., factor=...)).
+    periodic: {parameter index: period} of the single branch (ensemble.py:165-168) or None."""
     mu, invcov = gaussian_problem(D)
     np.random.seed(seed_construct)
     priors = ProbDistContainer({i: uniform_dist(-box, box) for i in range(D)})
@@ -69,6 +71,8 @@ def capture(name, T, W, D, nsteps, moves_spec, box=6.0, seed_construct=321, seed
         tk = dict(ntemps=T)
         tk.update(tempering_kwargs or {})
         kw["tempering_kwargs"] = tk
+    if periodic is not None:
+        kw["periodic"] = {"model_0": dict(periodic)}
     s = EnsembleSampler(W, D, log_like_vec, priors, args=[mu, invcov], vectorize=True, moves=moves, **kw)
     h = min(2.0, 0.9 * box)
     x0 = np.random.RandomState(1).uniform(-h, h, size=(T, W, D))
@@ -131,6 +135,8 @@ def capture(name, T, W, D, nsteps, moves_spec, box=6.0, seed_construct=321, seed
             out[f"move{i}_factor"] = float(spec[2]["factor"]) if spec[2].get("factor") is not None else np.nan
     if tc is not None:
         out["betas0"] = np.array(tc.betas, copy=True)
+    if periodic is not None:
+        out["period"] = np.array([float(periodic.get(d, 0.0)) for d in range(D)])
     np.random.seed(seed_run)
     np.random.shuffle, np.random.permutation, np.random.uniform = shuffle, permutation, uniform
     try:
@@ -182,3 +188,10 @@ if __name__ == "__main__":
     capture("m6_mix", 4, 24, D, 12, [("stretch", 0.5), ("gauss", 0.5, dict(cov=0.05))])
     capture("m7_gauss_untempered", 1, 20, D, 5, [("gauss", 1.0, dict(cov=0.05))])
     capture("m8_mix_narrowbox", 3, 16, D, 8, [("stretch", 0.5), ("gauss", 0.5, dict(cov=0.5))], box=1.5, seed_run=655)
+    # periodic parameters (ensemble.py:165-168, utils/periodic.py): distances the short way round in the stretch move
+    # (stretch.py:136-141), every proposal wrapped into [0, period) (stretch.py:149-154, gaussian.py:110-115); the walkers
+    # start on both sides of 0 and spread over more than half a period, so both branches of `distance` are taken
+    capture("p1_stretch_periodic", 3, 16, D, 10, [("stretch", 1.0)], periodic={0: 2 * np.pi, 2: 1.5}, seed_run=656)
+    capture("p2_mix_periodic", 4, 24, D, 12, [("stretch", 0.5), ("gauss", 0.5, dict(cov=0.3))],
+            periodic={1: 2 * np.pi, 3: 3.0}, seed_run=657)
+    capture("p3_stretch_periodic_untempered", 1, 20, 5, 8, [("stretch", 1.0)], periodic={4: 1.0}, seed_run=658)

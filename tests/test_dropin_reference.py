@@ -45,7 +45,11 @@ class OracleEngine:
         self.likelihood = GaussianLikelihood(np.zeros(D), np.ones(D))      # only its type matters here
         self.loglike, self.lo, self.hi, self.a = loglike, np.full(D, lo), np.full(D, hi), a
         self.adaptive, self.lag, self.nu, self.stop, self.time = adaptive, lag, nu, stop, 0
+        self.period = None
         self.calls = []
+
+    def set_periodic(self, period):
+        self.period = None if period is None else np.array(period, dtype=np.float64)
 
     def upload(self, x, logl=None, logp=None, betas=None):
         self.x, self.L, self.P = np.array(x, copy=True), np.array(logl, copy=True), np.array(logp, copy=True)
@@ -58,13 +62,13 @@ class OracleEngine:
     def stretch_split(self, split, labels, rint, u_zz, u_acc):
         from oracle import eryn_oracle as orc
         out = orc.stretch_split(self.x, self.L, self.P, self.betas, np.asarray(labels), split, rint, u_zz, u_acc, self.a,
-                                self.lo, self.hi, self.loglike)
+                                self.lo, self.hi, self.loglike, period=self.period)
         return out["keep"]
 
     def mh_step(self, step, u_acc):
         from oracle import eryn_oracle as orc
         return orc.mh_step(self.x, self.L, self.P, self.betas, np.asarray(step), np.asarray(u_acc), self.lo, self.hi,
-                           self.loglike)["keep"]
+                           self.loglike, period=self.period)["keep"]
 
     def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
         from oracle import eryn_oracle as orc
@@ -156,15 +160,43 @@ def test_hip_move_mix_under_the_real_sampler(eryn, golden_dir):
     assert np.array_equal(mvs[1][0].accepted, fx["move1_accepted"]) and mvs[1][0].num_proposals == int(fx["move1_num_proposals"])
 
 
-def test_unsupported_injections_fail_loudly(eryn, golden_dir):
-    """The real sampler assigns move.periodic after construction (ensemble.py:528-536): the device path has no periodic
-    parameters, so the assignment itself must raise instead of being ignored."""
+def test_periodic_container_injected_by_the_real_sampler(eryn, golden_dir):
+    """The real sampler turns ``periodic={branch: {index: period}}`` into its own PeriodicContainer and assigns it to
+    every move that has none (ensemble.py:338-347,528-536).  The device moves read the container's ``inds_periodic`` /
+    ``periods`` and hand the periods to their context before every proposal: the chain must equal the p2 fixture,
+    captured from the reference's own StretchMove + GaussianMove with the same periodic parameters."""
     from eryn.utils import PeriodicContainer
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import GaussianMove, StretchMove
+    fx = _fixture(golden_dir, "p2_mix_periodic")
+    T, W, D, box, n = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"]), int(fx["nsteps"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    like = GaussianLikelihood(mu, invcov)
+    eng = OracleEngine(T, W, D, lambda x: _loglike(x, mu, invcov), -box, box)
+    mvs = [(StretchMove(likelihood=like, prior_box=(-box, box)), float(fx["weights"][0])),
+           (GaussianMove({"model_0": float(fx["move1_cov"])}, likelihood=like, prior_box=(-box, box)), float(fx["weights"][1]))]
+    for m, _ in mvs:
+        m.attach_engine(eng)
+    per = {int(d): float(p) for d, p in enumerate(fx["period"]) if p > 0}
+    s = _reference_sampler(eryn, fx, mvs, periodic={"model_0": per})
+    assert all(isinstance(m.periodic, PeriodicContainer) for m, _ in mvs)
+    np.random.seed(int(fx["seed_run"]))
+    state = s.run_mcmc(fx["x0"], n, store=False)
+    last = f"it{n - 1}_"
+    assert np.array_equal(eng.period, fx["period"])
+    assert np.array_equal(state.branches["model_0"].coords[:, :, 0, :], fx[last + "x"])
+    assert np.array_equal(state.log_like, fx[last + "L"]) and np.array_equal(state.log_prior, fx[last + "P"])
+    assert np.array_equal(state.betas, fx[last + "betas"])
+    for i, (m, _) in enumerate(mvs):
+        assert np.array_equal(m.accepted, fx[f"move{i}_accepted"]) and m.num_proposals == int(fx[f"move{i}_num_proposals"])
+
+
+def test_invalid_periodic_injection_fails_loudly(eryn, golden_dir):
     from eryn_amd.likelihood import GaussianLikelihood
     from eryn_amd.moves import StretchMove
     fx = _fixture(golden_dir, "f2_pt")
     box = float(fx["box"])
     move = StretchMove(likelihood=GaussianLikelihood(fx["mu"], fx["invcov"]), prior_box=(-box, box))
-    with pytest.raises(NotImplementedError):
-        _reference_sampler(eryn, fx, move, periodic=PeriodicContainer({"model_0": {0: 2 * np.pi}}))
+    with pytest.raises(ValueError):
+        move.periodic = 3.0                    # neither a container nor a dict (ensemble.py:340-345)
     move.periodic = None                       # the no-op assignment stays legal

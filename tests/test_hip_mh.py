@@ -30,6 +30,8 @@ def _sampler_from_fixture(fx, **kw):
     priors = ProbDistContainer({i: uniform_dist(-box, box) for i in range(D)})
     if "betas0" in fx.files:
         kw["tempering_kwargs"] = dict(ntemps=T)
+    if "period" in fx.files:                                   # ensemble.py:165-168
+        kw["periodic"] = {"model_0": {int(d): float(p) for d, p in enumerate(fx["period"]) if p > 0}}
     return EnsembleSampler(W, D, GaussianLikelihood(fx["mu"], fx["invcov"]), priors, moves=moves, **kw)
 
 
@@ -56,7 +58,69 @@ def test_dropin_sampler_reproduces_reference_chain_with_mh_moves(name, golden_di
         assert np.array_equal(m.accepted, fx[f"move{i}_accepted"])
 
 
-@pytest.mark.parametrize("name", ["m1_gauss_iso", "m3_gauss_full", "m8_mix_narrowbox"])
+@pytest.mark.parametrize("name", ["p1_stretch_periodic", "p2_mix_periodic", "p3_stretch_periodic_untempered"])
+def test_stretch_split_teacher_forced_with_periodic_parameters(name, golden_dir):
+    """hens_stretch_split with hens_set_periodic, one half-step at a time from the oracle's state, against the oracle's
+    intermediates (which reproduce the reference's chain on these fixtures, tests/test_oracle_golden.py): distances the
+    short way round and wrapped proposals (stretch.py:136-154) -> accept masks and positions bit for bit."""
+    from eryn_amd.engine import HipEnsemble
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    T, W, D, box = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"])
+    o = build_mh_oracle(fx)
+    eng = HipEnsemble(T, W, D, GaussianLikelihood(fx["mu"], fx["invcov"]), -box, box, tempered=o.tempered)
+    eng.set_periodic(fx["period"])
+    nst = 0
+    for it in range(int(fx["nsteps"])):
+        prev = (o.x.copy(), o.L.copy(), o.P.copy(), None if o.betas is None else o.betas.copy())
+        o.iteration()
+        rec = o.trace[-1]
+        if "labels" not in rec:
+            continue
+        nst += 1
+        eng.upload(*prev)
+        for sp in (0, 1):
+            keep = eng.stretch_split(sp, rec["labels"], rec[f"rint{sp}"], rec[f"u_zz{sp}"], rec[f"u_acc{sp}"])
+            knife = np.abs(rec[f"lnpdiff{sp}"] - np.log(rec[f"u_acc{sp}"])) < 1e-12
+            assert not knife.any(), "a decision on the knife edge: pick another seed for this fixture"
+            assert np.array_equal(keep, rec[f"keep{sp}"]), f"iteration {it} split {sp}: accept mask"
+            x, L, P, _ = eng.download()
+            assert np.array_equal(x, rec[f"x_after{sp}"]), f"iteration {it} split {sp}: positions"
+        np.testing.assert_allclose(L, rec["L_stretch"], rtol=1e-12, atol=0)
+        assert np.array_equal(P, rec["P_stretch"])
+    assert nst >= 4
+    eng.close()
+
+
+def test_philox_stepping_with_periodic_parameters_stays_on_the_circle():
+    """hens_step (Philox) with periodic parameters runs through the generic-width kernel: every accepted proposal is
+    wrapped (stretch.py:149-154, gaussian.py:110-115), and a von-Mises-like target on the circle is sampled without
+    the seam at 0 / period showing (distance the short way round, stretch.py:136-141)."""
+    from eryn_amd.engine import HipEnsemble
+    T, W, D = 2, 2048, 4
+    per = np.array([2 * np.pi, 0.0, 0.0, 0.0])
+    # likelihood centred ON the seam of the periodic parameter: without periodic distances / wrapping the walkers on the two
+    # sides of 0 = 2 pi would be 2 pi apart
+    mu = np.array([0.05, 0.0, 0.0, 0.0])
+    like = GaussianLikelihood(mu, np.diag([4.0, 1.0, 1.0, 1.0]))
+    eng = HipEnsemble(T, W, D, like, np.array([-0.5, -50, -50, -50.0]), np.array([2 * np.pi + 0.5, 50, 50, 50.0]), seed=7)
+    eng.set_periodic(per)
+    x0 = np.random.RandomState(2).randn(T, W, D) * 0.3
+    x0[..., 0] = np.random.RandomState(3).uniform(0.0, 2 * np.pi, size=(T, W))
+    eng.upload(x0, betas=np.array([1.0, 0.5]))
+    eng.eval_state()
+    eng.set_mh_proposal("iso", 0.3, 0.3)
+    eng.step(300)
+    x, L, P, _ = eng.download()
+    assert np.all((x[..., 0] >= 0.0) & (x[..., 0] < 2 * np.pi))
+    assert np.isfinite(L).all() and np.isfinite(P).all()
+    c = eng.counters()
+    assert c["accepted"].sum() > 0 and eng.mh_counters()["accepted"].sum() > 0
+    eng.set_periodic(None)                                     # back to the compile-time-width kernels
+    eng.step(3)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["m1_gauss_iso", "m3_gauss_full", "m8_mix_narrowbox", "p2_mix_periodic"])
 def test_mh_step_teacher_forced_against_oracle(name, golden_dir):
     """hens_mh_step through the C ABI, one proposal at a time, against the oracle's intermediates."""
     from eryn_amd.engine import HipEnsemble
@@ -64,6 +128,8 @@ def test_mh_step_teacher_forced_against_oracle(name, golden_dir):
     T, W, D, box = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"])
     o = build_mh_oracle(fx)
     eng = HipEnsemble(T, W, D, GaussianLikelihood(fx["mu"], fx["invcov"]), -box, box, tempered=o.tempered)
+    if "period" in fx.files:
+        eng.set_periodic(fx["period"])                         # gaussian.py:110-115: q = wrap(x + step)
     for it in range(int(fx["nsteps"])):
         prev = (o.x.copy(), o.L.copy(), o.P.copy(), None if o.betas is None else o.betas.copy())
         o.iteration()

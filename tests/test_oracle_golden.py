@@ -109,7 +109,9 @@ def test_fill_path_exercised(golden_dir):
 
 # ---- Metropolis-Hastings moves: fixtures from tests/golden/make_golden_mh.py -----------------
 MH_FIXTURES = ["m1_gauss_iso", "m3_gauss_full", "m4_gauss_random_factor", "m5_gauss_sequential", "m6_mix",
-               "m7_gauss_untempered", "m8_mix_narrowbox"]
+               "m7_gauss_untempered", "m8_mix_narrowbox",
+               # periodic parameters (utils/periodic.py through stretch.py:136-154 / gaussian.py:110-115)
+               "p1_stretch_periodic", "p2_mix_periodic", "p3_stretch_periodic_untempered"]
 
 
 def mh_moves_from_fixture(fx, make_gauss):
@@ -133,6 +135,8 @@ def build_mh_oracle(fx, record=True):
     kw = {}
     if "betas0" in fx.files:
         kw.update(betas=fx["betas0"])
+    if "period" in fx.files:
+        kw.update(period=fx["period"])
     moves = mh_moves_from_fixture(fx, lambda cov, mode, factor: orc.GaussianProposal(cov, mode=mode, factor=factor))
     return orc.OracleSampler(fx["x0"], lambda x: orc.gaussian_log_like(x, mu, invcov), np.full(D, -box), np.full(D, box),
                              R, G, record=record, moves=moves, **kw)
@@ -166,3 +170,25 @@ def test_oracle_reproduces_reference_mh(name, golden_dir):
     for i in range(int(fx["nmoves"])):
         assert o.move_num_proposals[i] == int(fx[f"move{i}_num_proposals"]) == picked[i]
         _same(o.move_accepted[i], fx[f"move{i}_accepted"], f"move{i}.accepted")
+
+
+def test_periodic_fixtures_take_both_branches_of_the_distance(golden_dir):
+    """The periodic fixtures must wrap proposals and measure distances the short way round (periodic.py:96-112): the
+    chains live in [0, period) on the periodic parameters after the first accepted move, and the oracle's distance
+    differs from the plain difference somewhere."""
+    fx = np.load(os.path.join(golden_dir, "p1_stretch_periodic.npz"))
+    per = fx["period"]
+    idx = np.flatnonzero(per > 0)
+    assert idx.size == 2
+    x_last = fx[f"it{int(fx['nsteps']) - 1}_x"]
+    inside = lambda x: ((x[..., idx] >= 0.0) & (x[..., idx] < per[idx])).mean()      # noqa: E731
+    # (a walker that never accepted a move keeps its unwrapped start, and swaps carry such walkers between rungs)
+    assert inside(fx["x0"]) < 0.6 and inside(x_last) > 0.9
+    rs = np.random.RandomState(0)
+    scale = np.where(per > 0, per, 2.0)                # inside one period: a single shift reaches the short way round
+    s, c = rs.uniform(0, 1, size=(50, 4)) * scale, rs.uniform(0, 1, size=(50, 4)) * scale
+    d = orc.periodic_distance(s, c, per)
+    assert np.array_equal(d[:, per == 0], (c - s)[:, per == 0])
+    assert np.all(np.abs(d[:, idx]) <= per[idx] / 2.0 + 1e-12) and not np.array_equal(d, c - s)
+    q = orc.periodic_wrap(np.array([[-0.25, 7.0, -3.0, 1.0]]), per)
+    assert np.array_equal(q, np.array([[-0.25 % per[0], 7.0, -3.0 % 1.5, 1.0]]))
