@@ -129,6 +129,17 @@ def test_replay_one_launch_shapes(T, W, D, like):
     _run_case(T, W, D, like_kind=like, box=6.0 if like == "rosen" else 50.0, calls=(1, 4, 2), x_scale=0.5 if like == "rosen" else 1.0)
 
 
+def test_replay_one_launch_variants():
+    """k_iter with the adaptation stopping / switched off (the launch still carries the swap counters), on the 64-rung
+    ladder (two-word swap masks, one column pair per workgroup) and with the Metropolis-Hastings move in the mix (its
+    cascade's counts are adapted by a kernel of their own before the next single launch)"""
+    _run_case(4, 128, 16, calls=(5,), stop_adaptation=2)
+    _run_case(8, 64, 32, calls=(4,), adaptive=False)
+    _run_case(64, 64, 32, calls=(2, 3), x_scale=0.5)
+    kinds = _run_case(8, 256, 32, calls=(3, 6), mh=("iso", 0.3, 0.5))
+    assert "mh" in kinds and "stretch" in kinds
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 def test_replay_local_pipeline(tmp_path, nranks):
     """N ladder shards stepping through the pipeline (one-sided puts, per-block hand-off flags) against the oracle"""
