@@ -111,7 +111,13 @@ def kernel_roofline(tm, T_local, T, W, D, f_sw):
         us = tm["stretch_ms"] / tm["n_stretch"] * 1e3
         ks.append({"kernel": "k_stretch_fast (red/blue half-step)", "launches_per_iteration": tm["n_stretch"] / tm["n_iters"],
                    "avg_launch_us": us, "algorithmic_bytes_per_launch": b_stretch(D) * tw / 2})
-    if tm["n_fused"]:
+    if tm["n_fused"] and not tm["n_stretch"] and tm["n_fused"] == tm["n_iters"]:
+        # shapes up to one workgroup per CU: the whole iteration is ONE launch (k_iter)
+        us = tm["fused_ms"] / tm["n_fused"] * 1e3
+        ks.append({"kernel": "k_iter (both half-steps + PT cascade + swap counts in one launch)", "launches_per_iteration": 1.0,
+                   "avg_launch_us": us, "algorithmic_bytes_per_launch": (b_stretch(D) + b_pt(T, D, f_sw)) * tw,
+                   "stretch_bytes_only": b_stretch(D) * tw})
+    elif tm["n_fused"]:
         us = tm["fused_ms"] / tm["n_fused"] * 1e3
         ks.append({"kernel": "k_split1_pt (second half-step + PT cascade + swap counts)",
                    "launches_per_iteration": tm["n_fused"] / tm["n_iters"], "avg_launch_us": us,
@@ -206,7 +212,7 @@ def run_single(args):
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "block_ms": [t * 1e3 for t in times], "timing": f"median of {BLOCKS} blocks of {args.steps} steps",
-        "config": {"workload": f"config 2: ntemps={T}, nwalkers={W}, ndim={D} dense-covariance Gaussian, box prior +-50, "
+        "config": {"workload": f"{'config 2' if (T, W, D) == (16, 4096, 32) else 'custom shape'}: ntemps={T}, nwalkers={W}, ndim={D} dense-covariance Gaussian, box prior +-50, "
                                f"StretchMove(a=2)+adaptive PT, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
                    "parallelism": "single GPU", "stretch_acceptance": acc, "swap_fraction": f_sw},
         "roofline": roof,

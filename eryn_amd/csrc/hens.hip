@@ -210,7 +210,6 @@ int fast_nw(int D) { return (D == 32 || D == 64 || D == 128) ? 8 : 4; }
 // row widths with a compile-time-width kernel (k_stretch_fast)
 bool fast_path(const hens_ctx_impl* c) {
     const int D = c->D;
-    if (c->period) return false;      // periodic parameters: the generic-width kernel measures distances / wraps (k_stretch)
     return D == 8 || D == 16 || D == 32 || D == 64 || (D == 128 && c->cfg.likelihood_kind != HENS_LIKE_HOST);
 }
 
@@ -864,6 +863,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.swap_acc = acc_take(c);
     acc_commit(c);
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
+    f.period = c->period;
     f.flags = c->flags;
     f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
     f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;
@@ -905,7 +905,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
 bool iter_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_ITER") != nullptr;               // A/B knob: two launches per iteration
     static const long max_twd = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : (1L << 20);
-    return !off && fused_ok(c) && (c->D == 16 || c->D == 32) && c->T <= 128 && c->W <= 32768 &&
+    return !off && fused_ok(c) && !c->period && (c->D == 16 || c->D == 32) && c->T <= 128 && c->W <= 32768 &&
            (long)c->T * c->W * c->D <= max_twd && c->db[0].rec1 != nullptr;
 }
 

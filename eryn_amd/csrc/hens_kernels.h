@@ -428,7 +428,7 @@ struct StretchArgs {
     uint8_t* keep_out;         // [Tl][Ns] or nullptr
     const double* lo;
     const double* hi;
-    const double* period;      // [D] periods of the periodic parameters (0: not periodic), or nullptr: none (generic kernel only)
+    const double* period;      // [D] periods of the periodic parameters (0: not periodic), or nullptr: none
     const double* mu;
     const double* prec;
     const double* prec_sym;    // packed symmetric rows for the fast kernel (see sym_quad), dense only
@@ -1231,6 +1231,15 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; // stretch.py:143,145
                     qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
                 }
+                if (A.period) {                                      // periodic parameters (wave-uniform; see periodic_diff)
+                    const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);
+                    if (!MH) {                                       // stretch.py:136-145
+                        qv.x = creg[p].x - periodic_diff(sreg[p].x, creg[p].x, pv.x) * zz;
+                        qv.y = creg[p].y - periodic_diff(sreg[p].y, creg[p].y, pv.y) * zz;
+                    }
+                    qv.x = periodic_wrap(qv.x, pv.x);                // stretch.py:149-154, gaussian.py:110-115
+                    qv.y = periodic_wrap(qv.y, pv.y);
+                }
             }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
@@ -1876,6 +1885,7 @@ struct FusedArgs {
     uint32_t* accepted;                                       // [T][W]
     uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
+    const double* period;                                     // [D] periodic parameters (see StretchArgs::period), or nullptr
     unsigned* flags;
     unsigned long long* trace;                                // debug: 8 phase timestamps per workgroup, or nullptr
     double logp_in, fill, rosen_a, rosen_b;
@@ -2019,6 +2029,11 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             double2 qv;
             qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz;             // stretch.py:143,145
             qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
+            if (A.period) {                                              // periodic parameters: stretch.py:136-154
+                const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);
+                qv.x = periodic_wrap(creg[p].x - periodic_diff(sreg[p].x, creg[p].x, pv.x) * zz, pv.x);
+                qv.y = periodic_wrap(creg[p].y - periodic_diff(sreg[p].y, creg[p].y, pv.y) * zz, pv.y);
+            }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
             if (CEN) qkeep[p] = qv;

@@ -81,20 +81,20 @@ def _margin(st, lnpdiff, logu):
 
 
 def oracle_iteration(st, ref, loglike, lo, hi, a=2.0, adaptive=True, lag=10000, nu=100, stop_adaptation=-1,
-                     mh=None):
+                     mh=None, period=None):
     """One sampler iteration on ``st`` with the given draws (ensemble.py:965-981): the stretch move's two halves
     (or one Metropolis-Hastings proposal when ``mh = (step, u_acc)``), the PT cascade, the ladder adaptation."""
     T, W, D = st.x.shape
     tt = np.arange(T)[:, None]
     if mh is not None:
-        out = orc.mh_step(st.x, st.L, st.P, st.betas, mh[0], mh[1], lo, hi, loglike)
+        out = orc.mh_step(st.x, st.L, st.P, st.betas, mh[0], mh[1], lo, hi, loglike, period=period)
         st.mh_accepted += out["keep"]
         with np.errstate(divide="ignore"):
             _margin(st, out["lnpdiff"], np.log(mh[1]))
     else:
         for sp in (0, 1):
             out = orc.stretch_split(st.x, st.L, st.P, st.betas, ref["labels"], sp, ref[f"rint{sp}"], ref[f"u_zz{sp}"],
-                                    ref[f"u_acc{sp}"], a, lo, hi, loglike)
+                                    ref[f"u_acc{sp}"], a, lo, hi, loglike, period=period)
             acc = np.zeros((T, W))
             acc[tt, out["S"]] = out["keep"]
             st.accepted += acc

@@ -25,7 +25,7 @@ def _engine(T, W, D, like, box, seed, **kw):
     return HipEnsemble(T, W, D, like, -box, box, seed=seed, **kw)
 
 
-def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_scale=1.0, mh=None, **kw):
+def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_scale=1.0, mh=None, period=None, **kw):
     from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
     mu, invcov = pu.gaussian_problem(D, dense=(like_kind == "dense"))
     if like_kind == "dense":
@@ -44,6 +44,8 @@ def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_sca
     eng.eval_state()
     if mh is not None:
         eng.set_mh_proposal(*mh)
+    if period is not None:
+        eng.set_periodic(period)
     x, L, P, betas = eng.download()
     st = ru.OracleState(x, L, P, betas, time=0)
     kinds = []
@@ -52,7 +54,7 @@ def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_sca
         it0 = eng.iteration()
         eng.step(n)
         eng.synchronize()
-        kinds += ru.replay(eng, st, it0, n, fn, lo, hi, mh=mh is not None,
+        kinds += ru.replay(eng, st, it0, n, fn, lo, hi, mh=mh is not None, period=period,
                            adaptive=kw.get("adaptive", True), stop_adaptation=kw.get("stop_adaptation", -1))
         x, L, P, betas = eng.download()
         ru.assert_state_equal(st, x, L, P, betas, counters=eng.counters(),
@@ -138,6 +140,23 @@ def test_replay_one_launch_variants():
     _run_case(64, 64, 32, calls=(2, 3), x_scale=0.5)
     kinds = _run_case(8, 256, 32, calls=(3, 6), mh=("iso", 0.3, 0.5))
     assert "mh" in kinds and "stretch" in kinds
+
+
+@pytest.mark.parametrize("T,W,D,like,mh", [(16, 4096, 32, "dense", None), (8, 256, 16, "dense", ("iso", 0.4, 0.5)),
+                                           (4, 512, 64, "dense", None), (4, 256, 128, "dense", ("iso", 0.05, 0.5)),
+                                           (3, 130, 6, "diag", ("diag", None, 0.4))])
+def test_replay_periodic_parameters(T, W, D, like, mh):
+    """hens_step with periodic parameters through the oracle: the compile-time-width kernels of the two-launch iteration
+    (distances the short way round, wrapped proposals: stretch.py:136-154; MH proposals wrapped: gaussian.py:110-115) and
+    the generic-width kernel.  A third of the parameters is periodic with periods small enough that the walkers spread
+    over more than half of them."""
+    period = np.zeros(D)
+    period[::3] = np.linspace(1.5, 4.0, len(period[::3]))
+    if mh is not None and mh[1] is None:
+        mh = (mh[0], np.full(D, 0.2), mh[2])
+    kinds = _run_case(T, W, D, like_kind=like, box=6.0 if like == "rosen" else 50.0, calls=(1, 3),
+                      x_scale=0.5 if like == "rosen" else 1.0, mh=mh, period=period)
+    assert "stretch" in kinds
 
 
 @pytest.mark.parametrize("nranks", [2, 4])
