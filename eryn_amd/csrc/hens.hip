@@ -225,27 +225,31 @@ size_t fast_lds_bytes(int D, int NW) {
 template <int LIKE, int MODE>
 int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
-#define LAUNCH_FAST_P(DT, NW, PIPE)                                                                \
+#define LAUNCH_FAST_P(DT, NW, PIPE, PER)                                                           \
     do {                                                                                           \
         const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
         if (c->ext_start)                                                                          \
-            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
+            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
                                   c->ext_start, c->ext_stop, 0, a);                                \
         else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE>), grid, dim3(NW * 64), lds, c->stream, a); \
+            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), grid, dim3(NW * 64), lds, c->stream, a); \
     } while (0)
+    // (periodic parameters: an instantiation of their own, never on a pipeline rank - hens_set_periodic / hens_pipe_init
+    //  refuse the combination - and not for the evaluation launch, which proposes nothing)
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \
-        if (c->pipe.on) LAUNCH_FAST_P(DT, NW, true);                                               \
-        else LAUNCH_FAST_P(DT, NW, false);                                                         \
+        if (c->pipe.on) LAUNCH_FAST_P(DT, NW, true, false);                                        \
+        else if (MODE != MODE_EVAL && c->period) {                                                 \
+            if constexpr (MODE != MODE_EVAL) LAUNCH_FAST_P(DT, NW, false, true);                   \
+        } else LAUNCH_FAST_P(DT, NW, false, false);                                                \
     } while (0)
     bool launched = true;
     if (!fast_path(c)) {
@@ -778,21 +782,26 @@ bool fused_ok(const hens_ctx_impl* c) {
 template <int LIKE>
 int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(c->W / c->label_cb);
-#define LAUNCH_FUSED(DT, NW)                                                                       \
+#define LAUNCH_FUSED_P(DT, NW, PER)                                                                \
     do {                                                                                           \
         const size_t lds = fused_lds_bytes(DT, NW);                                                \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
         if (e0)                                                                                    \
-            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
-            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW>), grid, dim3(NW * 64), lds, c->stream, f); \
+            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER>), grid, dim3(NW * 64), lds, c->stream, f); \
+    } while (0)
+#define LAUNCH_FUSED(DT, NW)                                                                       \
+    do {                                                                                           \
+        if (f.period) LAUNCH_FUSED_P(DT, NW, true);                                                \
+        else LAUNCH_FUSED_P(DT, NW, false);                                                        \
     } while (0)
     switch (c->D) {
         case 8: LAUNCH_FUSED(8, 4); break;
@@ -803,6 +812,7 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
         default: return fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for ndim %d", c->D);
     }
 #undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_P
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_split1_pt launch failed: %s", hipGetErrorString(e));
     return HENS_OK;
@@ -2371,6 +2381,7 @@ int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_ou
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->pipe.on) return fail(c, HENS_ERR_STATE, "pipeline already initialised");
     if (!c->cfg.tempered || c->T < 2) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
+    if (c->period) return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters on a rank of the ladder pipeline");
     if (nranks < 1 || nranks > PIPE_MAX_RANKS || my_rank < 0 || my_rank >= nranks)
         return fail(c, HENS_ERR_INVALID, "nranks must be in [1, %d] and my_rank inside it", PIPE_MAX_RANKS);
     if ((my_rank == 0) != (c->cfg.rung_begin == 0) || (my_rank == nranks - 1) != (c->cfg.rung_end == c->T))

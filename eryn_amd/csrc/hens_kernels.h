@@ -915,7 +915,9 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 // ---------------------------------------------------------------------------------------------
 // PIPE: the context is a rank of the ladder pipeline (guest rows, flag waits, boundary-rung publishing);
 // compiled out of the single-GPU instantiation, where those hooks cost ~6 % at config 2.
-template <int DT, int LIKE, int MODE, int NW, bool PIPE>
+// PER: the context has periodic parameters (hens_set_periodic).  An instantiation of its own: as a run-time branch in the
+// proposal phase it cost the D = 64 kernel 6 VGPRs and 20 % (26.8 -> 32.2 us per launch at 8 x 16384 x 64).
+template <int DT, int LIKE, int MODE, int NW, bool PIPE, bool PER = false>
 __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     constexpr bool EVAL = MODE == MODE_EVAL, MH = MODE == MODE_MH;
     constexpr bool CEN = like_centred(LIKE, DT) && !MH;   // (the MH launch draws its normals in phase B: it lost 4 us with it)
@@ -1231,7 +1233,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; // stretch.py:143,145
                     qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
                 }
-                if (A.period) {                                      // periodic parameters (wave-uniform; see periodic_diff)
+                if (PER) {                                           // periodic parameters (see periodic_diff)
                     const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);
                     if (!MH) {                                       // stretch.py:136-145
                         qv.x = creg[p].x - periodic_diff(sreg[p].x, creg[p].x, pv.x) * zz;
@@ -1897,7 +1899,7 @@ __host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
     return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64) * 8 + (2 * 2 * TILE + 5 * TILE + 64) * 4;
 }
 
-template <int DT, int LIKE, int NW>
+template <int DT, int LIKE, int NW, bool PER = false>
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2029,7 +2031,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             double2 qv;
             qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz;             // stretch.py:143,145
             qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
-            if (A.period) {                                              // periodic parameters: stretch.py:136-154
+            if (PER) {                                                   // periodic parameters: stretch.py:136-154
                 const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);
                 qv.x = periodic_wrap(creg[p].x - periodic_diff(sreg[p].x, creg[p].x, pv.x) * zz, pv.x);
                 qv.y = periodic_wrap(creg[p].y - periodic_diff(sreg[p].y, creg[p].y, pv.y) * zz, pv.y);
