@@ -24,7 +24,7 @@ class HensConfig(C.Structure):
         ("ntemps", C.c_int32), ("nwalkers", C.c_int32), ("ndim", C.c_int32),
         ("rung_begin", C.c_int32), ("rung_end", C.c_int32), ("device_id", C.c_int32),
         ("likelihood_kind", C.c_int32), ("tempered", C.c_int32), ("live_dangerously", C.c_int32),
-        ("adaptive", C.c_int32), ("adaptation_delay", C.c_int32), ("reserved1", C.c_int32),
+        ("adaptive", C.c_int32), ("adaptation_delay", C.c_int32), ("ndim_active", C.c_int32),
         ("stop_adaptation", C.c_int64), ("a", C.c_double), ("fill_value", C.c_double),
         ("adaptation_lag", C.c_double), ("adaptation_time", C.c_double), ("seed", C.c_uint64),
     ]

@@ -198,6 +198,10 @@ int grid_for(int64_t n, int block = 256) {
 
 int pt_blocks(const hens_ctx_impl* c) { return (c->W + PT_COLS - 1) / PT_COLS; }
 bool has_pt(const hens_ctx_impl* c) { return c->cfg.tempered && c->T > 1; }
+// number of real parameters: rows may be padded to a compile-time width (hens_config::ndim_active); only the Hastings
+// factor (D - 1) log zz counts them (PlanArgs::D and k_prep_draws' D are used for nothing else)
+int dim_active(const hens_ctx_impl* c) { return c->cfg.ndim_active ? c->cfg.ndim_active : c->D; }
+
 int plan_threads(const hens_ctx_impl* c) {
     static const int cap = getenv("HENS_PLAN_THREADS") ? atoi(getenv("HENS_PLAN_THREADS")) : 1024;
     return std::min(cap, std::max(64, c->NP2 / 4));
@@ -657,7 +661,7 @@ void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int
     PlanArgs pa{};
     pa.dr = c->db[which].d;
     pa.iter0 = iter0; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
-    pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin;
+    pa.Tl = c->Tl; pa.W = c->W; pa.D = dim_active(c); pa.rung_begin = c->cfg.rung_begin;
     pa.idx_bits = c->idx_bits;
     pa.T = c->T; pa.cb = c->label_cb; pa.keys = c->db[which].keys;
     pa.rec = fused ? c->db[which].rec : nullptr;          // (only k_split1_pt reads the block-ordered records)
@@ -1174,7 +1178,9 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     if (cfg->ntemps > 1 && !cfg->tempered)
         return fail(nullptr, HENS_ERR_INVALID, "ntemps > 1 requires tempered = 1");
     if (cfg->ntemps > 4096) return fail(nullptr, HENS_ERR_UNSUPPORTED, "ntemps > 4096 not supported");
-    if (!cfg->live_dangerously && cfg->nwalkers < 2 * cfg->ndim)   // red_blue.py:108-114
+    if (cfg->ndim_active < 0 || cfg->ndim_active > cfg->ndim)
+        return fail(nullptr, HENS_ERR_INVALID, "ndim_active must be 0 (= ndim) or in [1, ndim]");
+    if (!cfg->live_dangerously && cfg->nwalkers < 2 * (cfg->ndim_active ? cfg->ndim_active : cfg->ndim))   // red_blue.py:108-114
         return fail(nullptr, HENS_ERR_TOO_FEW_WALKERS,
                     "It is unadvisable to use a red-blue move with fewer walkers than twice the number of "
                     "dimensions. If you would like to do this, please set live_dangerously to True.");
@@ -1568,7 +1574,7 @@ static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels,
     if (u_acc) HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
     c->win_count = 0;
     hipLaunchKernelGGL(k_prep_draws, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, c->order, c->d_rint, c->d_uzz,
-                       u_acc ? c->d_uacc : c->d_uzz, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, c->D);
+                       u_acc ? c->d_uacc : c->d_uzz, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, dim_active(c));
     *Ns_out = Ns;
     return HENS_OK;
 }
@@ -1986,7 +1992,7 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
         if (!pa.dr.own || !pa.dr.cw || !pa.dr.zz || !pa.dr.fac || !pa.dr.lu || !pa.dbg_uzz || !pa.dbg_uacc)
             return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
         pa.iter0 = (uint64_t)iter; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
-        pa.Tl = c->Tl; pa.W = c->W; pa.D = c->D; pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits;
+        pa.Tl = c->Tl; pa.W = c->W; pa.D = dim_active(c); pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits;
         pa.T = c->T; pa.cb = c->label_cb;
         hipLaunchKernelGGL(k_plan, dim3(c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), c->stream, pa);
         HIPCHK(c, hipGetLastError());

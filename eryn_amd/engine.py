@@ -1,5 +1,6 @@
 """HipEnsemble: thin object wrapper over the C ABI (one context = one GPU = one ladder shard)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -16,11 +17,33 @@ def box_logp_inside(lo, hi):
     return float(acc[0])
 
 
+FAST_WIDTHS = (8, 16, 32, 64, 128)       # row widths with compile-time-width kernels (csrc/hens.hip: fast_path)
+
+
+def padded_width(ndim, likelihood):
+    """Row width of the device pool for ``ndim`` real parameters.
+
+    The compile-time-width kernels (in-place two-launch / one-launch iterations) serve rows of 8, 16, 32, 64 and 128
+    doubles; other widths run the generic kernel in three copying launches (measured at 16 x 4096: D = 11 39.1 us,
+    D = 12 34.5 us, D = 24 46.1 us per iteration against 16.1 us at D = 16 and 22.4 us at D = 32).  So rows of a Gaussian
+    likelihood are padded up to the next such width with coordinates that never change: zeros, inside a (-inf, +inf) prior
+    interval, meeting zero rows / columns of the precision matrix (``hens_config::ndim_active`` keeps the Hastings factor
+    and the walker-count guard on the real dimension).  Not for the Rosenbrock likelihood (its coupled sum would see the
+    pad) and host-callable likelihoods (their proposals travel to the host unpadded).  A property of (ndim, likelihood
+    kind) only: every rank of a sharded ladder pads alike, so shards stay bit-identical to the whole ladder and agree on
+    the row width of their messages.  ``HENS_NO_PAD=1`` switches it off."""
+    if os.environ.get("HENS_NO_PAD") or ndim in FAST_WIDTHS or ndim > FAST_WIDTHS[-1]:
+        return ndim
+    if likelihood.kind not in (_lib.LIKE_GAUSS_DENSE, _lib.LIKE_GAUSS_DIAG):
+        return ndim
+    return next(w for w in FAST_WIDTHS if w >= ndim)
+
+
 class HipEnsemble:
     def __init__(self, ntemps, nwalkers, ndim, likelihood, lo, hi, a=2.0, tempered=None,
                  adaptive=True, adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1,
                  live_dangerously=False, fill_value=-1e300, seed=0, rung_range=None, device_id=0,
-                 adaptation_delay=0):
+                 adaptation_delay=0, pad_rows=True):
         self.lib = _lib.load()
         self.T, self.W, self.D = int(ntemps), int(nwalkers), int(ndim)
         if tempered is None:
@@ -29,7 +52,11 @@ class HipEnsemble:
         self.rung_begin, self.rung_end, self.Tl = r0, r1, r1 - r0
         if likelihood.ndim != self.D:
             raise ValueError("likelihood dimension does not match ndim")
-        cfg = HensConfig(ntemps=self.T, nwalkers=self.W, ndim=self.D, rung_begin=r0, rung_end=r1,
+        # RW: width of a device row (>= D, see padded_width); every array with a parameter axis is padded on the way in and
+        # stripped on the way out, the caller only ever sees D
+        self.RW = padded_width(self.D, likelihood) if pad_rows else self.D
+        cfg = HensConfig(ntemps=self.T, nwalkers=self.W, ndim=self.RW, ndim_active=self.D if self.RW != self.D else 0,
+                         rung_begin=r0, rung_end=r1,
                          device_id=int(device_id), likelihood_kind=int(likelihood.kind),
                          tempered=int(bool(tempered)), live_dangerously=int(bool(live_dangerously)),
                          adaptive=int(bool(adaptive)), adaptation_delay=int(adaptation_delay),
@@ -45,10 +72,22 @@ class HipEnsemble:
         self.lo = f64(np.broadcast_to(lo, (self.D,)))
         self.hi = f64(np.broadcast_to(hi, (self.D,)))
         self.logp_inside = box_logp_inside(self.lo, self.hi)
-        check(self.lib.hens_set_prior_box(self.ctx, ptr(self.lo), ptr(self.hi), self.logp_inside), self.ctx)
-        likelihood._install(self.lib, self.ctx)
+        lo_w, hi_w = self._pad(self.lo, -np.inf), self._pad(self.hi, np.inf)
+        check(self.lib.hens_set_prior_box(self.ctx, ptr(lo_w), ptr(hi_w), self.logp_inside), self.ctx)
+        if self.RW != self.D:
+            likelihood._install(self.lib, self.ctx, row_width=self.RW)
+        else:
+            likelihood._install(self.lib, self.ctx)
         self.likelihood = likelihood
         self.N0 = (self.W + 1) // 2
+
+    def _pad(self, a, fill=0.0):
+        """``a[..., D]`` -> C-contiguous ``[..., RW]`` with ``fill`` on the pads (the array itself when nothing is padded)."""
+        if self.RW == self.D:
+            return a
+        out = np.full(a.shape[:-1] + (self.RW,), fill, dtype=np.float64)
+        out[..., :self.D] = a
+        return out
 
     def set_periodic(self, period):
         """Periods of the periodic parameters, ``[ndim]`` (0 = not periodic), or None for none: the ``periodic``
@@ -58,7 +97,7 @@ class HipEnsemble:
             self.period = None
             return
         self.period = f64(period, (self.D,))
-        check(self.lib.hens_set_periodic(self.ctx, ptr(self.period)), self.ctx)
+        check(self.lib.hens_set_periodic(self.ctx, ptr(self._pad(self.period))), self.ctx)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -73,18 +112,20 @@ class HipEnsemble:
 
     # -- state ---------------------------------------------------------------------------------
     def upload(self, x, logl=None, logp=None, betas=None):
-        x = f64(x, (self.Tl, self.W, self.D))
+        x = self._pad(f64(x, (self.Tl, self.W, self.D)))
         logl = None if logl is None else f64(logl, (self.Tl, self.W))
         logp = None if logp is None else f64(logp, (self.Tl, self.W))
         betas = None if betas is None else f64(betas, (self.T,))
         check(self.lib.hens_upload_state(self.ctx, ptr(x), ptr(logl), ptr(logp), ptr(betas)), self.ctx)
 
     def download(self, want_x=True):
-        x = np.empty((self.Tl, self.W, self.D)) if want_x else None
+        x = np.empty((self.Tl, self.W, self.RW)) if want_x else None
         logl = np.empty((self.Tl, self.W))
         logp = np.empty((self.Tl, self.W))
         betas = np.empty(self.T) if self.tempered else None
         check(self.lib.hens_download_state(self.ctx, ptr(x), ptr(logl), ptr(logp), ptr(betas)), self.ctx)
+        if want_x and self.RW != self.D:
+            x = np.ascontiguousarray(x[..., :self.D])
         return x, logl, logp, betas
 
     def eval_state(self):
@@ -182,12 +223,14 @@ class HipEnsemble:
         if pt:
             out.update(pt_slot=np.empty((T, W), dtype=np.int32), u_swap=np.empty((T - 1, W)))
         if mh:
-            out.update(mh_step=np.empty((Tl, W, D)), mh_u=np.empty((Tl, W)))
+            out.update(mh_step=np.empty((Tl, W, self.RW)), mh_u=np.empty((Tl, W)))
         is_mh = C.c_int32(0)
         check(self.lib.hens_debug_draws(self.ctx, int(it), ptr(out["own"]), ptr(out["cw"]), ptr(out["u_zz"]),
                                         ptr(out["u_acc"]), ptr(out.get("pt_slot")), ptr(out.get("u_swap")),
                                         C.byref(is_mh), ptr(out.get("mh_step")), ptr(out.get("mh_u"))), self.ctx)
         out["is_mh"] = bool(is_mh.value)
+        if mh and self.RW != D:
+            out["mh_step"] = np.ascontiguousarray(out["mh_step"][..., :D])
         return out
 
     def set_profiling(self, on):
@@ -237,7 +280,7 @@ class HipEnsemble:
     # -- Metropolis-Hastings proposals (include/hipensemble.h: hens_mh_*) --------------------------------
     def mh_step(self, step, u_acc):
         """One full-ensemble proposal q = x + step with the caller's draws; returns the accept mask [Tl, W]."""
-        step = np.ascontiguousarray(step, dtype=np.float64).reshape(self.Tl, self.W, self.D)
+        step = self._pad(np.ascontiguousarray(step, dtype=np.float64).reshape(self.Tl, self.W, self.D))
         u_acc = np.ascontiguousarray(u_acc, dtype=np.float64).reshape(self.Tl, self.W)
         keep = np.empty((self.Tl, self.W), dtype=np.uint8)
         check(self.lib.hens_mh_step(self.ctx, ptr(step), ptr(u_acc), ptr(keep)), self.ctx)
@@ -254,6 +297,14 @@ class HipEnsemble:
         need = {0: 1, 1: self.D, 2: self.D * self.D}[k]
         if scale.size != need:
             raise ValueError(f"{kind} proposal needs {need} scale value(s)")
+        if self.RW != self.D and k == 0:                       # no step on the pads: the same normals, per-parameter scales
+            k, scale = 1, self._pad(np.full(self.D, float(scale[0])))
+        elif self.RW != self.D and k == 1:
+            scale = self._pad(scale)
+        elif self.RW != self.D and k == 2:
+            full = np.zeros((self.RW, self.RW))
+            full[:self.D, :self.D] = scale.reshape(self.D, self.D)
+            scale = full
         check(self.lib.hens_set_mh_proposal(self.ctx, k, ptr(scale), float(weight)), self.ctx)
 
     def mh_counters(self):

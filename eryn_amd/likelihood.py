@@ -26,8 +26,21 @@ class GaussianLikelihood:
             raise ValueError("invcov must have shape (D, D) or (D,)")
         self.ndim = D
 
-    def _install(self, lib, ctx):
-        _lib.check(lib.hens_set_gaussian(ctx, _lib.ptr(self.mu), _lib.ptr(self.invcov)), ctx)
+    def _install(self, lib, ctx, row_width=None):
+        """``row_width`` > ndim: the context's rows are padded (engine.HipEnsemble): zero mean and zero rows / columns of the
+        precision matrix on the pads, which therefore never enter the quadratic form."""
+        mu, prec = self.mu, self.invcov
+        if row_width is not None and row_width != self.ndim:
+            D, R = self.ndim, int(row_width)
+            mu = np.zeros(R)
+            mu[:D] = self.mu
+            prec = np.zeros((R, R) if self.invcov.ndim == 2 else R)
+            if self.invcov.ndim == 2:
+                prec[:D, :D] = self.invcov
+            else:
+                prec[:D] = self.invcov
+        self._installed = (np.ascontiguousarray(mu), np.ascontiguousarray(prec))     # (alive for the duration of the call)
+        _lib.check(lib.hens_set_gaussian(ctx, _lib.ptr(self._installed[0]), _lib.ptr(self._installed[1])), ctx)
 
 
 class RosenbrockLikelihood:

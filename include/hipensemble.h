@@ -71,7 +71,12 @@ typedef struct hens_config {
     int32_t adaptation_delay;  /* ladder pipeline only: 0 = the reference's schedule (the swap ratios of sweep s move the
                                 * ladder before iteration s+1 - every rank then waits for the whole cascade);
                                 * 1 = they move it before iteration s+2, which lets the ranks pipeline          */
-    int32_t reserved1;
+    int32_t ndim_active;       /* 0: = ndim.  Otherwise the number of REAL parameters in rows that the caller padded to a
+                                * width the compile-time-width kernels serve (8, 16, 32, 64, 128): the pads hold zeros,
+                                * lie in a (-inf, +inf) prior interval and meet zero rows / columns of the precision
+                                * matrix, so they never change; only the Hastings factor (ndim - 1) log zz
+                                * (stretch.py:223) and the W >= 2 ndim guard (red_blue.py:108-114) count real
+                                * parameters.  eryn_amd.engine.HipEnsemble pads on upload and strips on download. */
     int64_t stop_adaptation;   /* < 0: never stop (tempering.py:591)                     */
     double a;                  /* stretch scale                                          */
     double fill_value;         /* likelihood of walkers outside the prior support        */

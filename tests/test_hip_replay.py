@@ -142,6 +142,31 @@ def test_replay_one_launch_variants():
     assert "mh" in kinds and "stretch" in kinds
 
 
+@pytest.mark.parametrize("T,W,D,like,mh", [(5, 100, 5, "dense", None), (8, 2048, 11, "dense", None),
+                                           (4, 256, 24, "diag", ("diag", None, 0.4)), (2, 512, 12, "dense", ("iso", 0.3, 0.5)),
+                                           (4, 144, 70, "dense", None)])
+def test_replay_padded_rows(T, W, D, like, mh):
+    """Row widths without a compile-time-width kernel are padded to the next one (engine.padded_width: zeros under a
+    (-inf, +inf) prior interval and zero rows of the precision matrix; hens_config::ndim_active keeps the Hastings
+    factor (D - 1) log zz on the real dimension): hens_step through the oracle, which knows nothing of the pads."""
+    from eryn_amd.engine import FAST_WIDTHS, padded_width
+    if mh is not None and mh[1] is None:
+        mh = (mh[0], np.full(D, 0.2), mh[2])
+    kinds = _run_case(T, W, D, like_kind=like, calls=(1, 4), mh=mh)
+    assert "stretch" in kinds
+
+    class K:
+        kind = 0
+    assert padded_width(D, K) in FAST_WIDTHS and padded_width(D, K) >= D
+
+
+@pytest.mark.parametrize("T,W,D,mh", [(3, 33, 4, None), (5, 100, 5, None), (4, 128, 12, ("iso", 0.3, 0.5))])
+def test_replay_generic_width_kernel_unpadded(T, W, D, mh):
+    """the generic-width kernel itself (pad_rows=False: what Rosenbrock / host-likelihood contexts and widths above 128
+    run), three copying launches per iteration"""
+    _run_case(T, W, D, calls=(1, 4), mh=mh, pad_rows=False)
+
+
 @pytest.mark.parametrize("T,W,D,like,mh", [(16, 4096, 32, "dense", None), (8, 256, 16, "dense", ("iso", 0.4, 0.5)),
                                            (4, 512, 64, "dense", None), (4, 256, 128, "dense", ("iso", 0.05, 0.5)),
                                            (3, 130, 6, "diag", ("diag", None, 0.4))])

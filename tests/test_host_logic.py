@@ -224,3 +224,22 @@ def test_rj_records_pack_and_unpack_roundtrip():
     steps = {"gauss": np.ones((3, 5, 10, 3)), "sine": 2 * np.ones((3, 5, 4, 3))}
     sr = eng.steps_to_records(steps)
     assert sr.shape == (3, 5, 42) and np.all(sr[:, :, :30] == 1) and np.all(sr[:, :, 30:] == 2)
+
+
+def test_padded_row_width_policy(monkeypatch):
+    """Rows of Gaussian-likelihood contexts are padded to the next compile-time kernel width; Rosenbrock (coupled sum),
+    host-callable likelihoods (proposals travel unpadded) and widths above 128 are not (eryn_amd/engine.py)."""
+    from eryn_amd import _lib
+    from eryn_amd.engine import padded_width
+
+    class L:
+        def __init__(self, kind):
+            self.kind = kind
+    monkeypatch.delenv("HENS_NO_PAD", raising=False)
+    g, gd = L(_lib.LIKE_GAUSS_DENSE), L(_lib.LIKE_GAUSS_DIAG)
+    assert [padded_width(d, g) for d in (1, 5, 8, 9, 16, 17, 33, 64, 65, 128, 129, 200)] == \
+        [8, 8, 8, 16, 16, 32, 64, 64, 128, 128, 129, 200]
+    assert padded_width(11, gd) == 16
+    assert padded_width(11, L(_lib.LIKE_ROSENBROCK)) == 11 and padded_width(11, L(_lib.LIKE_HOST)) == 11
+    monkeypatch.setenv("HENS_NO_PAD", "1")
+    assert padded_width(11, g) == 11
