@@ -202,6 +202,10 @@ bool has_pt(const hens_ctx_impl* c) { return c->cfg.tempered && c->T > 1; }
 // factor (D - 1) log zz counts them (PlanArgs::D and k_prep_draws' D are used for nothing else)
 int dim_active(const hens_ctx_impl* c) { return c->cfg.ndim_active ? c->cfg.ndim_active : c->D; }
 
+// draw records of one planned iteration in block order: 64 places per column block (k_split1_pt / k_iter), of which
+// cb T / 2 are used
+size_t rec_per_iter(const hens_ctx_impl* c) { return c->label_cb ? (size_t)(c->W / c->label_cb) * TILE : 0; }
+
 int plan_threads(const hens_ctx_impl* c) {
     static const int cap = getenv("HENS_PLAN_THREADS") ? atoi(getenv("HENS_PLAN_THREADS")) : 1024;
     return std::min(cap, std::max(64, c->NP2 / 4));
@@ -396,7 +400,14 @@ void acc_fold(hens_ctx_impl* c, AdaptArgs& ad) {
 // the buffer the cascade being launched accumulates into; its counts are the next pending adaptation
 // (k_iter folds and accumulates in ONE launch: it takes its buffer BEFORE acc_fold hands out the one that launch clears)
 uint32_t* acc_take(hens_ctx_impl* c) {
-    const int a = acc_pick(c, 0);            // (at most one pending and one uncleared: one of three is always clean)
+    int a = acc_pick(c, 0);                  // (at most one pending and one uncleared: one of three is always clean)
+    if (a < 0) {                             // cannot happen by the rotation's invariant; never hand a wild pointer to a kernel
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS * c->T * 4, c->stream);
+        c->acc_state[0] = c->acc_state[1] = c->acc_state[2] = 0;
+        c->adapt_src = nullptr;
+        a = 0;
+    }
     c->acc_state[a] = 3;                     // (taken; pending once the launch is queued: acc_commit)
     return c->swap_acc[a];
 }
@@ -871,7 +882,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
     f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
-    f.rec = c->db[which].rec + (size_t)ib * (T * W / 2);
+    f.rec = c->db[which].rec + (size_t)ib * rec_per_iter(c);
     f.keys = c->db[which].keys + (size_t)ib * T * 8;
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
@@ -959,7 +970,7 @@ int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>*
     f.pool = c->pool;
     f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
     f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
-    const size_t roff = (size_t)ib * (T * W / 2);
+    const size_t roff = (size_t)ib * rec_per_iter(c);
     f.rec1 = c->db[which].rec1 + roff; f.rec2 = c->db[which].rec + roff; f.rec3 = c->db[which].rec3 + roff;
     f.keys = c->db[which].keys + (size_t)ib * T * 8;
     f.accepted = c->accepted;
@@ -1246,9 +1257,12 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     while (c->NP2 < c->W) { c->NP2 <<= 1; c->idx_bits++; }
     // Block-balanced split labels (see block_rank): ladders of 2..64 rungs whose length divides 128, walker counts
     // that are a multiple of the block.  A property of (T, W) only, so every rank of a sharded ladder agrees.
-    if (cfg->tempered && c->T >= 2 && c->T <= 64 && (c->T & (c->T - 1)) == 0 && !getenv("HENS_LEGACY_LABELS")) {
-        const int cb = 2 * TILE / c->T;
-        if (c->W % cb == 0) {
+    // (round 2, end: ladders whose length does not divide 128 too - cb = the largest power of two with cb T <= 128, the
+    //  workgroups of k_split1_pt / k_iter then hold cb T <= 128 slots and cb T / 2 <= 64 moving walkers)
+    if (cfg->tempered && c->T >= 2 && c->T <= 64 && !getenv("HENS_LEGACY_LABELS")) {
+        int cb = 1;
+        while (cb * 2 * c->T <= 2 * TILE) cb *= 2;
+        if (cb >= 2 && c->W % cb == 0) {
             c->label_cb = cb;
             while ((1 << c->label_cb_shift) < cb) c->label_cb_shift++;
         }
@@ -1273,10 +1287,11 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRY(dalloc(c, &c->db[b].d.zz, n));
         TRY(dalloc(c, &c->db[b].d.fac, n));
         TRY(dalloc(c, &c->db[b].d.lu, n));
-        if (c->label_cb) TRY(dalloc(c, &c->db[b].rec, n / 2));
+        const size_t nrec = c->label_cb ? (size_t)c->NB * rec_per_iter(c) : 0;   // (>= n / 2: short tiles keep their 64 places)
+        if (c->label_cb) TRY(dalloc(c, &c->db[b].rec, nrec));
         if (c->label_cb && c->Tl == c->T && (c->D == 16 || c->D == 32) && c->W <= 32768 && TW <= ((size_t)1 << 20)) {
-            TRY(dalloc(c, &c->db[b].rec1, n / 2));       // (one-launch iteration, see iter_ok)
-            TRY(dalloc(c, &c->db[b].rec3, n / 2));
+            TRY(dalloc(c, &c->db[b].rec1, nrec));        // (one-launch iteration, see iter_ok)
+            TRY(dalloc(c, &c->db[b].rec3, nrec));
         }
         TRY(dalloc(c, &c->db[b].keys, (size_t)c->NB * c->T * 8));
         TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));

@@ -164,6 +164,9 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     const int MW = (T + 31) >> 5;
     const int H = A.half_rows;
     const bool lead = blockIdx.x == 0;
+    // ladders whose length does not divide 128: NEr = cb T <= 128 slots, NM = NEr / 2 <= 64 walkers per half-step; the
+    // lanes / rows beyond them idle (see k_split1_pt)
+    const int NEr = T << CS, NM = NEr >> 1;
 #define ITER_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     ITER_TRACE(0);
 
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     int32_t gi_m = 0;
     const int tm = lane >> (CS - 1);                                     // rung of the m-th walker of a half
     LadderFold fold;
-    if (wv < 3) {
+    if (wv < 3) s_flag[wv * TILE + lane] = 0;
+    if (wv < 3 && lane < NM) {
         const DrawRec* src = wv == 0 ? A.rec1 : (wv == 1 ? A.rec3 : A.rec2);
         const DrawRec rc = src[(size_t)blockIdx.x * TILE + lane];
         gi_m = tm * W + rc.own;
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         s_rs[wv * TILE + lane] = rs;
         if (wv < 2) s_rc[wv * TILE + lane] = rcw;
         s_zz[wv * TILE + lane] = rc.zz;
-        s_flag[wv * TILE + lane] = 0;
+    } else if (wv < 3) {
+        // (idle lanes of a short tile)
     } else if (wv < 5) {
         const int e = tid - 3 * 64, t = e >> CS, c = c0 + (e & (CB - 1));
         if (t < T - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, t, W, c));   // tempering.py:535 (row j = t: pair T-1-t)
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
             if (lane < T) sbeta[lane] = A.betas[lane];
             if (lane + 64 < T) sbeta[lane + 64] = A.betas[lane + 64];
         }
-    } else {
+    } else if (tid - 6 * 64 < NEr) {
         const int e = tid - 6 * 64, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
         const uint4 ka = kp[0], kb = kp[1];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
-        rv[p] = r < TILE;
+        rv[p] = r < NM;
         sA[p] = cA[p] = double2{0.0, 0.0};
         if (rv[p]) {
             sA[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)s_rs[r] * D + jl * 2);
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         return lnpdiff > lu;                                            // red_blue.py:294
     };
     auto alt_row = [&](const int32_t r) -> int32_t { return r < H ? r + H : r - H; };
-    if (wv == 0) {                                                       // the block's own first-half walkers: results count
+    if (wv == 0 && lane < NM) {                                          // the block's own first-half walkers: results count
         double logl, newP;
         const bool keep = accept(s_part, s_flag[lane], logl, newP);
         const int e = s_el[lane];
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
             atomicAdd(&A.accepted[gi_m], 1u);
             s_flag[lane] |= 2;
         }
-    } else if (wv == 1) {                                                // replay: only the decision is needed
+    } else if (wv == 1 && lane < NM) {                                   // replay: only the decision is needed
         double logl, newP;
         if (accept(s_part + NW * TILE, s_flag[TILE + lane], logl, newP)) s_flag[TILE + lane] |= 2;
     }
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     }
     ITER_TRACE(5);
     lds_barrier();
-    if (wv == 2) {
+    if (wv == 2 && lane < NM) {
         double logl, newP;
         const bool keep = accept(s_part, s_flag[2 * TILE + lane], logl, newP);
         const int e = s_el[TILE + lane];
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
 
     // ---- phase G: permuted records of the 128 slots, swap counts ------------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
-    if (tid < NE) {
+    if (tid < NEr) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1);
         int st;
         if (MW == 1) {

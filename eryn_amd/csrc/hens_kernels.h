@@ -1934,6 +1934,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const int T = A.T, W = A.W, CB = A.cb, CS = A.cb_shift;
     const int c0 = blockIdx.x * CB;
     const int MW = (T + 31) >> 5;
+    // ladders whose length does not divide 128: cb = the largest power of two with cb T <= 128, so a workgroup holds
+    // NEr = cb T <= 128 slots and NM = NEr / 2 <= 64 moving walkers; the lanes / rows beyond them idle
+    const int NEr = T << CS, NM = NEr >> 1;
 #define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     FUSED_TRACE(0);
 
@@ -1952,10 +1955,12 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     double Lold_m = 0.0, Pold_m = 0.0;                                   // wave 0, lane m
     WalkerRec wr_n{};                                                    // slot threads: the record of the walker in the slot
     bool stays = false;
+    if (wv == 0) s_flag[lane] = 0;                                       // (also the idle lanes of a short tile: never in the box)
     if (tid < NE) {
+      if (tid < NEr) {                                                   // (short ladders: the slots beyond cb T do not exist)
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
         const int HB = CB >> 1;
-        const bool mv = wv == 0;                                         // wave 0: lane m = the block's m-th moving walker
+        const bool mv = wv == 0 && lane < NM;                            // wave 0: lane m = the block's m-th moving walker
         DrawRec rc{};
         if (mv) rc = A.rec[(size_t)blockIdx.x * TILE + lane];
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
@@ -1980,11 +1985,11 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             s_rc[m] = rc_m;
             s_dst[m] = gi;                                               // (walker index: the accept counters)
             s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
-            s_flag[m] = 0;
         }
         scol[e] = slot;
         if (!stays) s_el[t * HB + rank - HB] = e;                        // 0 .. 63, each exactly once: where phase D puts the result
         if (!WIDE && e < T) sbeta[e] = A.betas[e];
+      }
     } else if (tid < 2 * NE) {
         // the cascade's log-uniforms (a Philox call and a log per element: ~1700 cycles of dependent ALU) on the two
         // waves that would otherwise idle until the barrier, not in the shadow of the slot chain above
@@ -2006,7 +2011,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
-        rv[p] = r < TILE;
+        rv[p] = r < NM;
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
@@ -2019,7 +2024,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     double2 muv = double2{0.0, 0.0};
     if (CEN) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
-    if (tid < NE && stays) {                       // (loaded before the row gathers were issued: it arrives before them)
+    if (tid < NEr && stays) {                       // (loaded before the row gathers were issued: it arrives before them)
         Lc[tid] = wr_n.L; Pc[tid] = wr_n.P; locc[tid] = wr_n.loc;
     }
 #pragma unroll
@@ -2062,7 +2067,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     lds_barrier();
 
     // ---- phase D: accept / update into the cascade's tables (wave 0, lane = moving walker) -----------------
-    if (wv == 0) {
+    if (wv == 0 && lane < NM) {
         const bool inbox = (s_flag[lane] & 1) != 0;
         double acc = 0.0;
 #pragma unroll
@@ -2155,7 +2160,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
 
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
-    if (tid < NE) {
+    if (tid < NEr) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1);
         int st;
         if (MW == 1) {                                            // T <= 32: the whole column mask in one register

@@ -126,7 +126,8 @@ np.savez(sys.argv[7], **_snapshot(eng, bool(use_mh)))
 """
 
 
-@pytest.mark.parametrize("T,W,D,use_mh,like", [(16, 256, 32, 0, "dense"), (8, 128, 64, 1, "dense"), (32, 256, 128, 1, "rosen")])
+@pytest.mark.parametrize("T,W,D,use_mh,like", [(16, 256, 32, 0, "dense"), (8, 128, 64, 1, "dense"), (32, 256, 128, 1, "rosen"),
+                                              (10, 512, 64, 1, "dense"), (12, 8192, 32, 0, "dense"), (20, 256, 128, 1, "rosen")])
 def test_record_mode_equals_the_copying_three_launch_path(T, W, D, use_mh, like, tmp_path):
     outs = []
     for tag, env in (("fused", {}), ("three", {"HENS_NO_FUSED": "1"})):
@@ -134,7 +135,7 @@ def test_record_mode_equals_the_copying_three_launch_path(T, W, D, use_mh, like,
         e = dict(os.environ, **env)
         e.pop("HENS_NO_FUSED", None) if tag == "fused" else None
         r = subprocess.run([sys.executable, "-c", _WORKER, ROOT, str(T), str(W), str(D), str(use_mh), like, out],
-                           env=e, capture_output=True, text=True, timeout=600)
+                           env=e, capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(dict(np.load(out)))
     _assert_same(outs[0], outs[1], f"({T},{W},{D}) two-launch record mode vs three copying launches")
@@ -150,7 +151,8 @@ def _one_launch(eng, n=3):
 
 
 @pytest.mark.parametrize("T,W,D,use_mh,like", [(8, 4096, 32, 0, "dense"), (16, 256, 32, 1, "dense"), (4, 1024, 16, 1, "dense"),
-                                              (32, 512, 32, 0, "rosen"), (2, 128, 32, 0, "dense")])
+                                              (32, 512, 32, 0, "rosen"), (2, 128, 32, 0, "dense"), (10, 2048, 32, 1, "dense"),
+                                              (5, 512, 16, 0, "dense")])
 def test_one_launch_iteration_equals_the_two_launch_path(T, W, D, use_mh, like, tmp_path):
     """k_iter (hens_iter.h) against k_stretch_fast + k_split1_pt from the same seed: positions, log-probabilities, ladder,
     accept and swap counters bit for bit, across two calls (rows folded back into one half in between) and with the
@@ -165,7 +167,7 @@ def test_one_launch_iteration_equals_the_two_launch_path(T, W, D, use_mh, like, 
         if tag == "one":
             e.pop("HENS_NO_ITER", None)
         r = subprocess.run([sys.executable, "-c", _WORKER, ROOT, str(T), str(W), str(D), str(use_mh), like, out],
-                           env=e, capture_output=True, text=True, timeout=600)
+                           env=e, capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(dict(np.load(out)))
     _assert_same(outs[0], outs[1], f"({T},{W},{D}) one launch per iteration vs two")

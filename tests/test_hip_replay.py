@@ -160,6 +160,17 @@ def test_replay_padded_rows(T, W, D, like, mh):
     assert padded_width(D, K) in FAST_WIDTHS and padded_width(D, K) >= D
 
 
+@pytest.mark.parametrize("T,W,D,mh", [(10, 4096, 32, None), (12, 512, 64, None), (20, 2048, 32, None), (24, 256, 8, None),
+                                      (3, 4096, 32, None), (5, 2048, 16, None), (6, 256, 32, ("iso", 0.3, 0.5)),
+                                      (10, 256, 16, None), (48, 64, 32, None), (7, 256, 128, None), (33, 130, 16, None)])
+def test_replay_ladders_that_do_not_divide_128(T, W, D, mh):
+    """Block-balanced labels with cb = the largest power of two with cb T <= 128 (ntemps = 10, 20, ... are what people
+    use): short tiles - cb T / 2 < 64 moving walkers per workgroup - through the two-launch iteration (k_split1_pt) and,
+    for the small shapes, the one-launch iteration (k_iter); 33+ rungs take two-word swap masks."""
+    kinds = _run_case(T, W, D, calls=(1, 4), mh=mh, x_scale=0.7)
+    assert "stretch" in kinds
+
+
 @pytest.mark.parametrize("T,W,D,mh", [(3, 33, 4, None), (5, 100, 5, None), (4, 128, 12, ("iso", 0.3, 0.5))])
 def test_replay_generic_width_kernel_unpadded(T, W, D, mh):
     """the generic-width kernel itself (pad_rows=False: what Rosenbrock / host-likelihood contexts and widths above 128
