@@ -67,6 +67,7 @@ struct hens_ctx_impl {
     // clean one, and the buffer read one launch earlier is cleared meanwhile
     uint32_t* swap_acc[3] = {nullptr, nullptr, nullptr};
     int acc_state[3] = {0, 0, 0};    // 0 clean, 1 pending (= adapt_src: the last cascade's counts), 2 read, not yet cleared
+    int num_cu = 256;                // compute units of the device (MI355X: 256)
     bool rows_mixed = false;         // k_iter ran: current rows live in both halves of the pool (folded back by state_to_fields)
 
     // model
@@ -925,13 +926,17 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
 //   4 x 4096 x 32  14.7 / 18.2     8 x 4096 x 32  15.5 / 18.8    16 x 2048 x 32  15.6 / 18.3    32 x 1024 x 32  17.1 / 20.1
 //   16 x 4096 x 16  16.4 / 19.7   16 x 4096 x 32 (config 2)  22.4 / 22.5     8 x 8192 x 32  22.0 / 22.7
 //   32 x 2048 x 32  23.9 / 23.8   16 x 6144 x 32  33.5 / 34.5
-// Up to one workgroup per CU (T W D <= 2^20 doubles of state) the single launch wins 15-19 %; with two workgroups per
-// CU its extra gathers and likelihoods cost what the second launch did, and the profiled two-launch path stays.
+// Up to one workgroup per CU at D = 32 (two at D = 16, whose workgroups are half as heavy) the single launch wins
+// 15-19 %; with two D = 32 workgroups per CU its extra gathers and likelihoods cost what the second launch did, and the
+// profiled two-launch path stays.  The grid is W / cb workgroups (short tiles of ladders that do not divide 128 included:
+// 10 x 2048 x 32 15.2 / 18.5, 6 x 4096 x 32 15.0 / 18.1).
 bool iter_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_ITER") != nullptr;               // A/B knob: two launches per iteration
-    static const long max_twd = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : (1L << 20);
-    return !off && fused_ok(c) && !c->period && (c->D == 16 || c->D == 32) && c->T <= 128 && c->W <= 32768 &&
-           (long)c->T * c->W * c->D <= max_twd && c->db[0].rec1 != nullptr;
+    static const long per_cu = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : 0;   // workgroups per CU allowed
+    if (off || !fused_ok(c) || c->period || !(c->D == 16 || c->D == 32) || c->T > 128 || c->W > 32768 || !c->db[0].rec1)
+        return false;
+    const long nwg = c->W / c->label_cb, allow = per_cu ? per_cu : (c->D == 16 ? 2 : 1);
+    return nwg <= allow * (long)c->num_cu;
 }
 
 template <int LIKE>
@@ -1269,6 +1274,10 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     }
     for (int b = 0; b < 2; ++b)
         if (c->label_cb) TRY(dalloc(c, &c->wrec[b], TW));
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && ncu > 0) c->num_cu = ncu;
+    }
     TRY(dalloc(c, &c->swap_acc[0], (size_t)3 * SWAP_ACC_ROWS * c->T));
     c->swap_acc[1] = c->swap_acc[0] + (size_t)SWAP_ACC_ROWS * c->T;
     c->swap_acc[2] = c->swap_acc[1] + (size_t)SWAP_ACC_ROWS * c->T;
