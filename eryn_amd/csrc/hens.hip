@@ -798,26 +798,29 @@ bool fused_ok(const hens_ctx_impl* c) {
 template <int LIKE>
 int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(c->W / c->label_cb);
-#define LAUNCH_FUSED_P(DT, NW, PER)                                                                \
+#define LAUNCH_FUSED_P(DT, NW, PER, SHORT)                                                         \
     do {                                                                                           \
         const size_t lds = fused_lds_bytes(DT, NW);                                                \
         if (lds > 60000) {                                                                         \
             static bool attr_done = false;                                                         \
             if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done = true;                                                                  \
             }                                                                                      \
         }                                                                                          \
         if (e0)                                                                                    \
-            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
-            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER>), grid, dim3(NW * 64), lds, c->stream, f); \
+            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT>), grid, dim3(NW * 64), lds, c->stream, f); \
     } while (0)
 #define LAUNCH_FUSED(DT, NW)                                                                       \
     do {                                                                                           \
-        if (f.period) LAUNCH_FUSED_P(DT, NW, true);                                                \
-        else LAUNCH_FUSED_P(DT, NW, false);                                                        \
+        const bool short_tiles = c->T * c->label_cb != 2 * TILE;                                   \
+        if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true);                           \
+        else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false);                                    \
+        else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true);                                 \
+        else LAUNCH_FUSED_P(DT, NW, false, false);                                                 \
     } while (0)
     switch (c->D) {
         case 8: LAUNCH_FUSED(8, 4); break;

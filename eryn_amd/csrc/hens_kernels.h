@@ -1899,7 +1899,10 @@ __host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
     return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64) * 8 + (2 * 2 * TILE + 5 * TILE + 64) * 4;
 }
 
-template <int DT, int LIKE, int NW, bool PER = false>
+// SHORT: the ladder length does not divide 128 - cb T < 128 slots and cb T / 2 < 64 moving walkers per workgroup.  An
+// instantiation of its own: with run-time bounds the full-tile launch lost its compile-time-true row guards, 0.2 us at
+// config 2 (tools/ab3.sh: 22.4 / 22.6 / 22.5 us per iteration before / with run-time bounds / with this parameter).
+template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false>
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1936,7 +1939,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const int MW = (T + 31) >> 5;
     // ladders whose length does not divide 128: cb = the largest power of two with cb T <= 128, so a workgroup holds
     // NEr = cb T <= 128 slots and NM = NEr / 2 <= 64 moving walkers; the lanes / rows beyond them idle
-    const int NEr = T << CS, NM = NEr >> 1;
+    const int NEr = SHORT ? (T << CS) : 2 * TILE, NM = SHORT ? (NEr >> 1) : TILE;
 #define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     FUSED_TRACE(0);
 
