@@ -104,8 +104,12 @@ def block_rank(key, c, cb):
 
 def label_cb(T, W, tempered=True):
     """Columns per block of the block-balanced labelling, or 0 (hens_create)."""
-    if tempered and 2 <= T <= 64 and (T & (T - 1)) == 0 and W % (128 // T) == 0:
-        return 128 // T
+    if tempered and 2 <= T <= 64:
+        cb = 1
+        while cb * 2 * T <= 128:          # the largest power of two with cb T <= 128 (= 128 / T where T divides 128)
+            cb *= 2
+        if cb >= 2 and W % cb == 0:
+            return cb
     return 0
 
 

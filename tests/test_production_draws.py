@@ -38,7 +38,8 @@ def test_feistel_permutation_is_a_bijection_with_inverse(W):
     assert np.array_equal(pd.prp(y, key, bits, W, inverse=True), x)
 
 
-@pytest.mark.parametrize("T,W", [(16, 256), (8, 64), (64, 128), (2, 128), (3, 100), (5, 33)])
+@pytest.mark.parametrize("T,W", [(16, 256), (8, 64), (64, 128), (2, 128), (3, 100), (5, 33), (10, 256), (3, 96), (20, 64),
+                                 (48, 66)])
 def test_plan_structure(T, W):
     cb = pd.label_cb(T, W)
     N0 = (W + 1) // 2
@@ -59,7 +60,8 @@ def test_plan_structure(T, W):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,W,D,its", [(16, 256, 32, (0, 5)), (64, 128, 8, (3,)), (2, 128, 16, (1,)), (3, 100, 8, (0, 4)),
-                                       (8, 4096, 16, ((1 << 32) + 3,))])
+                                       (8, 4096, 16, ((1 << 32) + 3,)), (10, 256, 32, (2,)), (3, 96, 16, (0,)),
+                                       (24, 64, 8, (7,))])
 def test_device_draws_equal_the_specification(T, W, D, its):
     from eryn_amd.engine import HipEnsemble
     from eryn_amd.likelihood import GaussianLikelihood
