@@ -66,6 +66,33 @@ def test_philox_sampler_targets_the_gaussian():
     assert s.temperature_control.time == 300 + 200
 
 
+@pytest.mark.parametrize("T,W,D,periodic", [(10, 1024, 11, None), (5, 2048, 16, None), (6, 1024, 8, {2: 40.0})])
+def test_philox_sampler_targets_the_gaussian_on_padded_rows_and_short_tiles(T, W, D, periodic):
+    """The same statistical check on what the end of round 2 added to the production path: ladders that do not divide 128
+    (short tiles, one launch per iteration), rows padded from D = 11 to 16, and a periodic parameter whose period is far
+    wider than the target (wrapping must not disturb the interior of the distribution).  Every rung's mean log-likelihood
+    is that of the tempered Gaussian, -D / 2 / max(beta, ...) -> L beta = -D / 2."""
+    rs = np.random.RandomState(0)
+    A = rs.randn(D, D)
+    mu = 0.1 * rs.randn(D)
+    if periodic:
+        mu[list(periodic)] = 20.0                                       # mid-period: the wrap is far away
+    cov = A @ A.T / D + np.eye(D)
+    priors = {i: uniform_dist(-50.0, 50.0) for i in range(D)}
+    kw = dict(periodic={"model_0": periodic}) if periodic else {}
+    s = EnsembleSampler(W, D, GaussianLikelihood(mu, np.linalg.inv(cov)), priors,
+                        tempering_kwargs=dict(ntemps=T), rng="philox", seed=23, **kw)
+    x0 = mu + np.random.RandomState(1).randn(T, W, D)
+    state = s.run_mcmc(x0, 20, burn=400, thin_by=10)
+    chain = s.get_chain()["model_0"][:, 0, :, 0, :].reshape(-1, D)
+    assert np.abs(chain.mean(0) - mu).max() < 0.06
+    assert np.linalg.norm(np.cov(chain.T) - cov) / np.linalg.norm(cov) < 0.06
+    tempered = (state.log_like * state.betas[:, None]).mean(axis=1)      # E[beta L] = -D / 2 on every rung
+    assert np.all(np.abs(tempered[state.betas > 0.05] + D / 2) < 0.12 * D / 2 + 0.3)
+    assert np.all(np.diff(state.betas) < 0) and state.betas[0] == 1.0
+    assert 0.15 < s.moves[0].acceptance_fraction[0].mean() < 0.8
+
+
 def test_state_round_trip_and_errors():
     D, W = 4, 16
     like = GaussianLikelihood(np.zeros(D), np.eye(D))
