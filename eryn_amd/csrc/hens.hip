@@ -936,7 +936,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
 bool iter_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_ITER") != nullptr;               // A/B knob: two launches per iteration
     static const long per_cu = getenv("HENS_ITER_MAX") ? atol(getenv("HENS_ITER_MAX")) : 0;   // workgroups per CU allowed
-    if (off || !fused_ok(c) || c->period || !(c->D == 16 || c->D == 32) || c->T > 128 || c->W > 32768 || !c->db[0].rec1)
+    if (off || !fused_ok(c) || !(c->D == 16 || c->D == 32) || c->T > 128 || c->W > 32768 || !c->db[0].rec1)
         return false;
     const long nwg = c->W / c->label_cb, allow = per_cu ? per_cu : (c->D == 16 ? 2 : 1);
     return nwg <= allow * (long)c->num_cu;
@@ -945,19 +945,24 @@ bool iter_ok(const hens_ctx_impl* c) {
 template <int LIKE>
 int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(c->W / c->label_cb);
-#define LAUNCH_ITER(DT, NW)                                                                        \
+#define LAUNCH_ITER_P(DT, NW, PER)                                                                 \
     do {                                                                                           \
         const size_t lds = iter_lds_bytes(DT, NW);                                                 \
         static bool attr_done = false;                                                             \
         if (!attr_done) {                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW>),         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW, PER>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
             attr_done = true;                                                                      \
         }                                                                                          \
         if (e0)                                                                                    \
-            hipExtLaunchKernelGGL((k_iter<DT, LIKE, NW>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+            hipExtLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
-            hipLaunchKernelGGL((k_iter<DT, LIKE, NW>), grid, dim3(NW * 64), lds, c->stream, f);    \
+            hipLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), lds, c->stream, f);    \
+    } while (0)
+#define LAUNCH_ITER(DT, NW)                                                                        \
+    do {                                                                                           \
+        if (f.period) LAUNCH_ITER_P(DT, NW, true);                                                 \
+        else LAUNCH_ITER_P(DT, NW, false);                                                         \
     } while (0)
     switch (c->D) {
         case 16: LAUNCH_ITER(16, 8); break;
@@ -965,6 +970,7 @@ int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEven
         default: return fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for ndim %d", c->D);
     }
 #undef LAUNCH_ITER
+#undef LAUNCH_ITER_P
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_iter launch failed: %s", hipGetErrorString(e));
     return HENS_OK;
@@ -995,6 +1001,7 @@ int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>*
     }
     acc_commit(c);
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
+    f.period = c->period;
     f.flags = c->flags;
     f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
     f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;

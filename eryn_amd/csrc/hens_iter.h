@@ -44,6 +44,7 @@ struct IterArgs {
     uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1] this cascade's counts (clean on entry)
     const double* betas;                                      // [T] (ad_on == 0)
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
+    const double* period;                                     // [D] periodic parameters (StretchArgs::period), PER instantiations
     unsigned* flags;
     unsigned long long* trace;
     double logp_in, fill, rosen_a, rosen_b;
@@ -129,7 +130,8 @@ struct LadderFold {
     }
 };
 
-template <int DT, int LIKE, int NW>
+// PER: periodic parameters (hens_set_periodic), an instantiation of its own as in k_stretch_fast / k_split1_pt
+template <int DT, int LIKE, int NW, bool PER = false>
 __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     static_assert(DT == 16 || DT == 32, "row widths with three tiles in half a CU's LDS");
     static_assert(NW == 8, "one wave per role in the index phase");
@@ -276,8 +278,14 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         bool ok = true, finite = true;
         if (on) {
             double2 qv;
-            qv.x = c.x - (c.x - s.x) * zz;
-            qv.y = c.y - (c.y - s.y) * zz;
+            if (PER) {                                                   // periodic parameters: stretch.py:136-154
+                const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);
+                qv.x = periodic_wrap(c.x - periodic_diff(s.x, c.x, pv.x) * zz, pv.x);
+                qv.y = periodic_wrap(c.y - periodic_diff(s.y, c.y, pv.y) * zz, pv.y);
+            } else {
+                qv.x = c.x - (c.x - s.x) * zz;
+                qv.y = c.y - (c.y - s.y) * zz;
+            }
             ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
             finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
             *reinterpret_cast<double2*>(tile + r * RS + jl * 2) = qv;

@@ -179,6 +179,7 @@ def test_replay_generic_width_kernel_unpadded(T, W, D, mh):
 
 
 @pytest.mark.parametrize("T,W,D,like,mh", [(16, 4096, 32, "dense", None), (8, 256, 16, "dense", ("iso", 0.4, 0.5)),
+                                           (8, 512, 32, "dense", None), (10, 256, 11, "dense", None),
                                            (4, 512, 64, "dense", None), (4, 256, 128, "dense", ("iso", 0.05, 0.5)),
                                            (3, 130, 6, "diag", ("diag", None, 0.4))])
 def test_replay_periodic_parameters(T, W, D, like, mh):
