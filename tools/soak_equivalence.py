@@ -19,6 +19,19 @@ np.savez(sys.argv[7], x=x, L=L, P=P, b=b, acc=c["accepted"], sw=c["swaps_total"]
 print("finite", np.isfinite(x).all(), np.isfinite(L).all(), "acc", c["accepted"].mean() / max(c["num_proposals"], 1))
 '''
 root = os.environ.get("GRAFT_REPO_ROOT", ".")
+if len(sys.argv) > 1 and sys.argv[1] == "iter":
+    # the one-launch iteration (k_iter: versioned rows, replayed complements, three count buffers, short tiles, padded rows)
+    # against the two launches from the same seed
+    for (T, Wk, D, n, mh) in ((8, 4096, 32, 200000, 0), (10, 2048, 11, 100000, 1), (16, 4096, 16, 100000, 1)):
+        outs = []
+        for tag, env in (("one", {}), ("two", {"HENS_NO_ITER": "1"})):
+            out = f"/tmp/soak_{tag}.npz"
+            r = subprocess.run([sys.executable, "-c", W, root, str(T), str(Wk), str(D), str(n), str(mh), out], env=dict(os.environ, **env), capture_output=True, text=True)
+            print(tag, r.stdout.strip()[-200:], r.stderr.strip()[-300:])
+            outs.append(dict(np.load(out)))
+        same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+        print(f"({T},{Wk},{D}) {n} iterations mh={mh}: one launch per iteration == two launches:", same)
+    sys.exit(0)
 for (T, Wk, D, n, mh) in ((16, 4096, 32, 200000, 0), (8, 2048, 64, 60000, 1), (32, 1024, 16, 100000, 1)):
     outs = []
     for tag, env in (("fused", {}), ("three", {"HENS_NO_FUSED": "1"})):
