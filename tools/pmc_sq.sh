@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(f[0])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r['Kernel_Name']
-    if 'k_stretch_fast' in k and ', 0, 8' in k or 'k_pt_cascade' in k:
+    if ('k_stretch_fast' in k and ', 0, 8' in k) or 'k_pt_cascade' in k or 'k_split1_pt' in k or 'k_iter' in k:
         agg[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     print(k)
