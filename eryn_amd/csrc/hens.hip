@@ -81,6 +81,11 @@ struct hens_ctx_impl {
     DrawBuf db[2];
     int NB = 0, NP2 = 1, idx_bits = 0;
     hipEvent_t ev_plan[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    // speculative plan of the NEXT hens_step call (short calls pay ~25 us of plan latency up front otherwise): iterations
+    // [spec_iter0, spec_iter0 + spec_nb) planned into db[spec_buf] on plan_stream while the current call steps
+    bool spec_valid = false, spec_fused = false, spec_iter1 = false;
+    int spec_buf = 0, spec_nb = 0;
+    uint64_t spec_iter0 = 0;
     uint64_t win_from = 0; int win_count = 0;   // iterations planned in db[0] for hens_stretch_iter / sharded PT
 
     // parity staging
@@ -669,6 +674,14 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
 }
 
 // plan nb iterations starting at iteration `iter0` into draw buffer `which`
+// another user of the plan buffers (parity API, sharded stepping) is about to write them on the main stream: order it
+// behind a speculative plan that may still be in flight, and forget that plan
+void spec_cancel(hens_ctx_impl* c) {
+    if (!c->spec_valid) return;
+    (void)hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0);
+    c->spec_valid = false;
+}
+
 void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool fused = false, bool iter1 = false) {
     PlanArgs pa{};
     pa.dr = c->db[which].d;
@@ -1570,6 +1583,7 @@ static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels,
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     if (c->propose_pending) return fail(c, HENS_ERR_STATE, "hens_propose_split without its hens_accept_split");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    spec_cancel(c);               // (the draws of this half-step go into plan buffer 0)
     flush_adapt(c);
     const int Tl = c->Tl, W = c->W;
     if (split == 0) {
@@ -1800,15 +1814,36 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // the plan of batch b+1 runs on plan_stream while batch b steps on the main stream
     const int64_t nbatch = (n_iters + c->NB - 1) / c->NB;
     auto batch_size = [&](int64_t b) { return (int)std::min<int64_t>(c->NB, n_iters - b * c->NB); };
-    if (nbatch > 0) {
-        HIPCHK(c, hipEventRecord(c->ev_used[0], c->stream));      // earlier work may still read buffer 0
-        HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[0], 0));
-        launch_plan(c, c->plan_stream, 0, c->iter, batch_size(0), fused, iter1);
-        HIPCHK(c, hipEventRecord(c->ev_plan[0], c->plan_stream));
+    // A call of at most one batch may find its plan ready: the previous call planned it speculatively (a pure function of
+    // seed, iteration and path) while it stepped.  And it plans the iterations that follow its own for the next call.
+    static const bool spec_on = getenv("HENS_NO_SPEC") == nullptr;
+    int first_buf = 0;
+    bool spec_hit = false;
+    if (nbatch == 1 && c->spec_valid && c->spec_iter0 == c->iter && c->spec_nb >= n_iters && c->spec_fused == fused &&
+        c->spec_iter1 == iter1) {
+        first_buf = c->spec_buf;
+        spec_hit = true;
+    }
+    c->spec_valid = false;      // (a speculative plan that does not fit stays ordered in front of the new one on plan_stream)
+    if (nbatch > 0 && !spec_hit) {
+        HIPCHK(c, hipEventRecord(c->ev_used[first_buf], c->stream));      // earlier work may still read the buffer
+        HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[first_buf], 0));
+        launch_plan(c, c->plan_stream, first_buf, c->iter, batch_size(0), fused, iter1);
+        HIPCHK(c, hipEventRecord(c->ev_plan[first_buf], c->plan_stream));
         c->timing.n_plan += 1;
     }
+    if (spec_on && nbatch == 1 && !piped) {
+        const int sb = first_buf ^ 1;
+        HIPCHK(c, hipEventRecord(c->ev_used[sb], c->stream));             // its last readers: the previous call's launches
+        HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[sb], 0));
+        launch_plan(c, c->plan_stream, sb, c->iter + (uint64_t)n_iters, (int)n_iters, fused, iter1);
+        HIPCHK(c, hipEventRecord(c->ev_plan[sb], c->plan_stream));
+        c->timing.n_plan += 1;
+        c->spec_valid = true; c->spec_buf = sb; c->spec_iter0 = c->iter + (uint64_t)n_iters; c->spec_nb = (int)n_iters;
+        c->spec_fused = fused; c->spec_iter1 = iter1;
+    }
     for (int64_t b = 0; b < nbatch; ++b) {
-        const int which = (int)(b & 1), nb = batch_size(b);
+        const int which = (int)((first_buf + b) & 1), nb = batch_size(b);
         if (b + 1 < nbatch) {
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
@@ -2233,6 +2268,7 @@ int hens_stretch_iter(hens_ctx* ctx) {
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST) return fail(c, HENS_ERR_UNSUPPORTED, "hens_stretch_iter needs a device likelihood");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    spec_cancel(c);
     flush_adapt(c);
     c->N0 = (c->W + 1) / 2;
     if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
@@ -2571,6 +2607,7 @@ int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     switch (stage) {
         case 0: {           // the iteration's move (stretch halves or the MH proposal); publishes (L, P) of the boundary rung
+            spec_cancel(c);
             c->N0 = (c->W + 1) / 2;
             if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
                 launch_plan(c, c->stream, 0, c->iter, c->NB);
