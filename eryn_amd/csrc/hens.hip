@@ -1905,8 +1905,10 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         }
     }
     state_to_fields(c);
+    // The last cascade's ladder adaptation stays pending on one GPU: the next hens_step call folds it into its first
+    // launch (no kernel of its own, ~12 us per call with its count-buffer reset), and every entry point that reads the ladder,
+    // the swap counters or the state settles it first (flush_adapt at their head) - same bits either way.
     if (piped) pipe_flush_adapt(c);
-    else flush_adapt(c);      // the ladder and the swap counters are final when the call's work completes
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;
