@@ -258,6 +258,9 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     } while (0)
     // (periodic parameters: an instantiation of their own, never on a pipeline rank - hens_set_periodic / hens_pipe_init
     //  refuse the combination - and not for the evaluation launch, which proposes nothing)
+#ifdef HENS_DEV_BUILD
+#define LAUNCH_FAST(DT, NW) LAUNCH_FAST_P(DT, NW, false, false)
+#else
 #define LAUNCH_FAST(DT, NW)                                                                        \
     do {                                                                                           \
         if (c->pipe.on) LAUNCH_FAST_P(DT, NW, true, false);                                        \
@@ -265,11 +268,13 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
             if constexpr (MODE != MODE_EVAL) LAUNCH_FAST_P(DT, NW, false, true);                   \
         } else LAUNCH_FAST_P(DT, NW, false, false);                                                \
     } while (0)
+#endif
     bool launched = true;
     if (!fast_path(c)) {
         launched = false;
     } else if (c->D == 32) {
         LAUNCH_FAST(32, FAST_NW_32);
+#ifndef HENS_DEV_BUILD
     } else if (c->D == 64) {
         LAUNCH_FAST(64, 8);
     } else if (c->D == 16) {
@@ -278,6 +283,7 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         LAUNCH_FAST(8, 4);
     } else if (c->D == 128) {
         LAUNCH_FAST(128, 8);
+#endif
     } else {
         launched = false;
     }
@@ -322,8 +328,10 @@ template <int MODE>
 int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, MODE>(c, a, ntiles);
+#ifndef HENS_DEV_BUILD       // (dev build, tools/devbuild.sh: the dense-Gaussian D = 32 kernels only - seconds instead of minutes)
         case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, MODE>(c, a, ntiles);
         case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, MODE>(c, a, ntiles);
+#endif
         case HENS_LIKE_TEMPLATE:
             return fail(c, HENS_ERR_STATE, "leaf-packing context: step with hens_rj_* (the stretch move is not defined on variable-dimension records)");
         case HENS_LIKE_HOST:
@@ -682,6 +690,18 @@ void spec_cancel(hens_ctx_impl* c) {
     c->spec_valid = false;
 }
 
+// block-balanced labels: keys -> places -> draws (small short workgroups, see k_plan_cols); other shapes: k_plan
+void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, int nb) {
+    if (!pa.cb) {
+        hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
+        return;
+    }
+    const dim3 grid((c->W + 255) / 256, nb * c->Tl);
+    hipLaunchKernelGGL(k_plan_keys, dim3((nb * c->Tl + 63) / 64), dim3(64), 0, s, pa, nb);
+    hipLaunchKernelGGL(k_plan_cols, grid, dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(k_plan_draws, grid, dim3(256), 0, s, pa);
+}
+
 void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int nb, bool fused = false, bool iter1 = false) {
     PlanArgs pa{};
     pa.dr = c->db[which].d;
@@ -692,7 +712,7 @@ void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int
     pa.rec = fused ? c->db[which].rec : nullptr;          // (only k_split1_pt reads the block-ordered records)
     pa.rec_only = fused ? 1 : 0;
     if (iter1) { pa.rec1 = c->db[which].rec1; pa.rec3 = c->db[which].rec3; }   // (k_iter reads nothing else)
-    hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
+    launch_plan_kernels(c, s, pa, nb);
 }
 
 hipEvent_t new_event(hens_ctx_impl* c) {
@@ -827,6 +847,9 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
         else                                                                                       \
             hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT>), grid, dim3(NW * 64), lds, c->stream, f); \
     } while (0)
+#ifdef HENS_DEV_BUILD
+#define LAUNCH_FUSED(DT, NW) LAUNCH_FUSED_P(DT, NW, false, false)
+#else
 #define LAUNCH_FUSED(DT, NW)                                                                       \
     do {                                                                                           \
         const bool short_tiles = c->T * c->label_cb != 2 * TILE;                                   \
@@ -835,12 +858,15 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
         else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true);                                 \
         else LAUNCH_FUSED_P(DT, NW, false, false);                                                 \
     } while (0)
+#endif
     switch (c->D) {
+        case 32: LAUNCH_FUSED(32, FAST_NW_32); break;
+#ifndef HENS_DEV_BUILD
         case 8: LAUNCH_FUSED(8, 4); break;
         case 16: LAUNCH_FUSED(16, 4); break;
-        case 32: LAUNCH_FUSED(32, FAST_NW_32); break;
         case 64: LAUNCH_FUSED(64, 8); break;
         case 128: LAUNCH_FUSED(128, 8); break;
+#endif
         default: return fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for ndim %d", c->D);
     }
 #undef LAUNCH_FUSED
@@ -920,14 +946,20 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     int r;
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1); break;
+#ifndef HENS_DEV_BUILD
         case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1); break;
         case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1); break;
+#endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
     if (r) return r;
     // (no change of c->parity: the rows were updated in place, the half of the pool that the copying launches of the
     // other paths write next is still the free one)
     c->num_proposals += 1;
+#ifdef HENS_DEV_BUILD
+    static const bool noflip = getenv("HENS_DEBUG_NOFLIP") != nullptr;    // timing experiments with cut kernels (HENS_CUT_F)
+    if (!noflip)
+#endif
     c->cur ^= 1;
     c->adapt_pending = true;
     c->adapt_pending_adaptive = c->cfg.adaptive != 0;
@@ -972,14 +1004,20 @@ int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEven
         else                                                                                       \
             hipLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), lds, c->stream, f);    \
     } while (0)
+#ifdef HENS_DEV_BUILD
+#define LAUNCH_ITER(DT, NW) LAUNCH_ITER_P(DT, NW, false)
+#else
 #define LAUNCH_ITER(DT, NW)                                                                        \
     do {                                                                                           \
         if (f.period) LAUNCH_ITER_P(DT, NW, true);                                                 \
         else LAUNCH_ITER_P(DT, NW, false);                                                         \
     } while (0)
+#endif
     switch (c->D) {
-        case 16: LAUNCH_ITER(16, 8); break;
         case 32: LAUNCH_ITER(32, 8); break;
+#ifndef HENS_DEV_BUILD
+        case 16: LAUNCH_ITER(16, 8); break;
+#endif
         default: return fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for ndim %d", c->D);
     }
 #undef LAUNCH_ITER
@@ -1030,8 +1068,10 @@ int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>*
     int r;
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: r = launch_iter_like<LIKE_DENSE>(c, f, e0, e1); break;
+#ifndef HENS_DEV_BUILD
         case HENS_LIKE_GAUSS_DIAG: r = launch_iter_like<LIKE_DIAG>(c, f, e0, e1); break;
         case HENS_LIKE_ROSENBROCK: r = launch_iter_like<LIKE_ROSEN>(c, f, e0, e1); break;
+#endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
     if (r) return r;
@@ -1844,13 +1884,27 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     }
     for (int64_t b = 0; b < nbatch; ++b) {
         const int which = (int)((first_buf + b) & 1), nb = batch_size(b);
+#ifdef HENS_DEV_BUILD
+        static const bool plan_once = getenv("HENS_DEBUG_PLAN_ONCE") != nullptr;   // timing only: both buffers planned once, reused
+        static const int fake_slots = getenv("HENS_DEBUG_FAKE_PLAN") ? atoi(getenv("HENS_DEBUG_FAKE_PLAN")) : 0;
+        static const int fake_threads = getenv("HENS_DEBUG_FAKE_THREADS") ? atoi(getenv("HENS_DEBUG_FAKE_THREADS")) : 256;
+        if (plan_once && b >= 1 && fake_slots > 0 && b + 1 < nbatch) {            // a stand-in of known ALU work, small workgroups
+            const int64_t n = (int64_t)c->T * c->W * batch_size(b + 1);
+            hipLaunchKernelGGL(k_fake_plan, dim3((unsigned)((n + fake_threads - 1) / fake_threads)), dim3(fake_threads), 0, c->plan_stream,
+                               reinterpret_cast<uint32_t*>(c->xtmp), fake_slots, n);
+        }
+        if (b + 1 < nbatch && !(plan_once && b >= 1)) {
+#else
         if (b + 1 < nbatch) {
+#endif
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
             HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));
             launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), fused, iter1);
             HIPCHK(c, hipEventRecord(c->ev_plan[nxt], c->plan_stream));
             c->timing.n_plan += 1;
+            static const bool plan_serial = getenv("HENS_PLAN_SERIAL") != nullptr;     // A/B knob: the plan runs alone
+            if (plan_serial) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[nxt], 0));
         }
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
         for (int ib = 0; ib < nb; ++ib) {
@@ -2065,7 +2119,11 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
         pa.iter0 = (uint64_t)iter; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
         pa.Tl = c->Tl; pa.W = c->W; pa.D = dim_active(c); pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits;
         pa.T = c->T; pa.cb = c->label_cb;
-        hipLaunchKernelGGL(k_plan, dim3(c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), c->stream, pa);
+        if (pa.cb) {
+            pa.keys = (uint32_t*)grab((size_t)c->T * 8 * 4);
+            if (!pa.keys) return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
+        }
+        launch_plan_kernels(c, c->stream, pa, 1);
         HIPCHK(c, hipGetLastError());
         if (own) HIPCHK(c, hipMemcpyAsync(own, pa.dr.own, TW * 4, hipMemcpyDeviceToHost, c->stream));
         if (cw) HIPCHK(c, hipMemcpyAsync(cw, pa.dr.cw, TW * 4, hipMemcpyDeviceToHost, c->stream));

@@ -155,6 +155,20 @@ __device__ __forceinline__ double pt_uniform(uint64_t seed, uint64_t it, int j, 
     return u01(d.x, d.y);
 }
 
+// Everything random about one stretch proposal from ONE Philox4x32 call keyed by (iteration, global rung, walker): the two
+// 53-bit uniforms behind zz (stretch.py:129-132) and the accept test (red_blue.py:294), and - from the 2 x 11 low bits the
+// uniforms do not use - a 22-bit number that indexes the complement half (stretch.py:93-99; a second call for the accept
+// uniform alone was a quarter of the plan's instructions).
+struct StretchDraw { double uz, ua; uint32_t r22; };
+constexpr int STRETCH_INDEX_BITS = 22;
+__device__ __forceinline__ StretchDraw stretch_draw(uint64_t seed, uint64_t it, uint32_t wid) {
+    const u4 d = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_STRETCH}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return StretchDraw{u01(d.x, d.y), u01(d.z, d.w), ((d.y & 0x7FFu) << 11) | (d.w & 0x7FFu)};
+}
+__device__ __forceinline__ int stretch_index(uint32_t r22, int Nc) {          // uniform on [0, Nc), Nc <= 2^22
+    return (int)(((uint64_t)r22 * (uint64_t)Nc) >> STRETCH_INDEX_BITS);
+}
+
 // One Box-Muller pair of standard normals for coordinates (2 pr, 2 pr + 1) of walker `wid` (= rung * W + walker)
 // in iteration `it`: the draw of the Gaussian MH move (k_mh_draw and the inline MODE_MH path share it).
 __device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t wid, uint32_t pr) {
@@ -734,6 +748,14 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
 // every outstanding global STORE (CDNA4 counts stores in vmcnt); the stretch kernel deliberately leaves
 // row stores in flight across its phases.  Global loads are still waited for where their values are used.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// dev builds (tools/devbuild.sh -DHENS_CUT_S=n / -DHENS_CUT_F=n): the first / second launch returns after phase n - cumulative
+// phase timings without trace stamps (results are wrong; run with HENS_DEBUG_NOFLIP=1 so the state stays addressable)
+#ifndef HENS_CUT_S
+#define HENS_CUT_S 0
+#endif
+#ifndef HENS_CUT_F
+#define HENS_CUT_F 0
+#endif
 
 // 16-byte row store, variant selected at build time for the experiment:
 //   HENS_ROWSTORE 0 plain (write-back L2), 1 sc1 write-through (asm), 2 nontemporal
@@ -956,6 +978,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const bool ad_here = ad_on && (!ad_lead || (blockIdx.x == 0 && blockIdx.y == 0));
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = trace_stamp(); } while (0)
     HENS_TRACE(0);
+    if (HENS_CUT_S == 9 && !EVAL && !PIPE && A.inplace) return;
+    if (HENS_CUT_S == 8 && !EVAL && !PIPE && A.inplace) {          // a launch of known length: every workgroup spins 6 us
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 600) __builtin_amdgcn_s_sleep(4);
+        return;
+    }
     if (PIPE && !EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
         if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || ad_here || !ad_lead))
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
@@ -1162,6 +1190,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(1);
     lds_barrier();
     HENS_TRACE(2);
+    if (HENS_CUT_S == 1 && !EVAL && !PIPE && A.inplace) return;
 
     // ---- phase B: lanes over d, all loads first -------------------------------------------------
     const int jl = tid & (LPR - 1);
@@ -1272,6 +1301,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(3);
     lds_barrier();
     HENS_TRACE(4);
+    if (HENS_CUT_S == 2 && !EVAL && !PIPE && A.inplace) return;
 
     // ---- ladder adaptation (unless the adapting workgroup already did it up front) ------------------------------
     if (ad_here && !ad_early && wv == 1) {
@@ -1308,6 +1338,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     HENS_TRACE(5);
     lds_barrier();
+    if (HENS_CUT_S == 3 && !EVAL && !PIPE && A.inplace) return;
 
     // ---- phase D: accept / update (wave 0) -------------------------------------------------------
     if (wv == 0 && valid) {
@@ -1376,6 +1407,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     if (EVAL) return;
     HENS_TRACE(6);
     lds_barrier();
+    if (HENS_CUT_S == 4 && !PIPE && A.inplace) return;
 
     // ---- phase E: accepted rows only (the old rows went out right after phase B) ------------------------
     double* __restrict__ pool_w = A.pool;
@@ -1557,6 +1589,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, 
 }
 
 __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
+    // shapes WITHOUT block-balanced labels (untempered ensembles, ladders above 64 rungs, walker counts that are not a
+    // multiple of the block): label = prp(w) >= ceil(W/2), both halves listed in ascending walker order through a scan
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t skey[8];
@@ -1569,80 +1603,142 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     const uint32_t rung = (uint32_t)(A.rung_begin + job);
     const int N0 = (W + 1) / 2;
     int32_t* ord = reinterpret_cast<int32_t*>(smem_raw);             // [W] ordered walker ids
-    uint16_t* lab = reinterpret_cast<uint16_t*>(ord + W);            // [W] split label: 0xFFFF = first half-step, else the
-                                                                     // walker's block_member_code (or 0: legacy labels)
+    uint16_t* lab = reinterpret_cast<uint16_t*>(ord + W);            // [W] 1: first half-step
     if (tid < 64) {                                                  // one wave draws the rung's round keys
-        const PrpKey K = prp_key(A.seed, it, A.cb ? PURPOSE_PTPERM : PURPOSE_SPLIT, rung);
+        const PrpKey K = prp_key(A.seed, it, PURPOSE_SPLIT, rung);
         if (tid < 8) skey[tid] = K.k[tid];
     }
     __syncthreads();
     uint32_t key[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) key[r] = skey[r];
-    if (A.cb) {
-        if (A.keys && tid < 8) A.keys[((size_t)ib * A.T + rung) * 8 + tid] = skey[tid];   // (key[tid] would put the array in scratch)
-        if (A.rec1) for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code2(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
-        else for (int i = tid; i < W; i += nt) lab[i] = (uint16_t)block_member_code(key, (int)rung, A.T, i, A.cb, A.idx_bits, W);
-    } else {
-        for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 0 : 0xFFFFu;
-    }
+    for (int i = tid; i < W; i += nt) lab[i] = prp((uint32_t)i, key, A.idx_bits, (uint32_t)W) >= (uint32_t)N0 ? 0 : 1;
     __syncthreads();
     const int chunk = (W + nt - 1) / nt;                   // consecutive ids per thread
     const int lo = min(W, tid * chunk), hi = min(W, lo + chunk);
-    const uint32_t fmask = A.rec1 ? 0x8000u : 0xFFFFu;               // (lab & fmask) == fmask: first half-step
     uint32_t z = 0;
-    for (int i = lo; i < hi; ++i) z += ((lab[i] & fmask) == fmask);
+    for (int i = lo; i < hi; ++i) z += lab[i];
     uint32_t z0 = block_excl_scan(z, wtot, tid, nt);                 // first-half walkers before this thread's chunk
     uint32_t o0 = (uint32_t)lo - z0;                                 // second-half walkers before it
     for (int i = lo; i < hi; ++i) {
-        if ((lab[i] & fmask) == fmask) ord[z0++] = i;
+        if (lab[i]) ord[z0++] = i;
         else ord[N0 + o0++] = i;
     }
     __syncthreads();
     const size_t base = ((size_t)ib * A.Tl + job) * W;
     for (int p = tid; p < W; p += nt) {
         const int own = ord[p];
-        const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * (uint32_t)W + (uint32_t)own, PURPOSE_STRETCH};
-        const u4 d = philox4x32_10(ctr, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        u4 ctr2 = ctr;
-        ctr2.w = PURPOSE_STRETCH_ACC;
-        const u4 e = philox4x32_10(ctr2, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+        const StretchDraw sd = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)own);
         const bool s0 = p < N0;
-        const int Nc = s0 ? W - N0 : N0;
-        const int r = (int)__umulhi(d.x, (uint32_t)Nc);
-        const int cw = ord[(s0 ? N0 : 0) + r];
-        const DrawRec rc = draw_values(own, cw, u01(d.y, d.z), u01(e.x, e.y), A.a, A.D);
-        if (A.rec1) {                                                // k_iter: everything in block order
-            const int hb = A.cb >> 1, code = lab[own] & 0x7FFF;
-            const int blk = code >> (__ffs(hb) - 1), ml = code & (hb - 1);
-            const size_t ri = ((size_t)ib * (W / A.cb) + blk) * TILE + (size_t)rung * hb + ml;
-            if (s0) {
-                A.rec1[ri] = rc;
-            } else {
-                A.rec[ri] = rc;
-                // the complement is a first-half walker: its own draws once more (same counters -> same values)
-                u4 c1 = ctr;
-                c1.z = rung * (uint32_t)W + (uint32_t)cw;
-                const u4 d1 = philox4x32_10(c1, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                c1.w = PURPOSE_STRETCH_ACC;
-                const u4 e1 = philox4x32_10(c1, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                const int c2 = ord[N0 + (int)__umulhi(d1.x, (uint32_t)(W - N0))];
-                A.rec3[ri] = draw_values(cw, c2, u01(d1.y, d1.z), u01(e1.x, e1.y), A.a, A.D);
-            }
-            continue;
-        }
-        if (s0 || !(A.rec && A.rec_only)) store_draw(A.dr, base + p, rc);
-        if (A.rec && !s0) {
-            const int hb = A.cb >> 1, code = lab[own];               // block * hb + place among the block's moving walkers
-            const int blk = code >> (__ffs(hb) - 1), ml = code & (hb - 1);   // cb is a power of two
-            A.rec[((size_t)ib * (W / A.cb) + blk) * TILE + (size_t)rung * hb + ml] = rc;
-        }
+        const int cw = ord[(s0 ? N0 : 0) + stretch_index(sd.r22, s0 ? W - N0 : N0)];
+        store_draw(A.dr, base + p, draw_values(own, cw, sd.uz, sd.ua, A.a, A.D));
         if (A.dbg_uzz) {
-            A.dbg_uzz[base + p] = u01(d.y, d.z);
-            A.dbg_uacc[base + p] = u01(e.x, e.y);
+            A.dbg_uzz[base + p] = sd.uz;
+            A.dbg_uacc[base + p] = sd.ua;
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// The plan of shapes WITH block-balanced labels (k_plan_keys -> k_plan_cols -> k_plan_draws), round 3.
+// Round 2's plan was one 1024-thread workgroup per (iteration, rung) - inverse Feistel network per walker, block rank from
+// eight hashes, a scan for ascending lists, two Philox calls, ~40 us of life on a CU: run beside the stepping kernels it
+// cost them 2.8 us per iteration at config 2 (a stepping workgroup that cannot start until a plan workgroup leaves its CU
+// doubles its launch), run alone 4 us.  Now nothing is ordered and nothing is shared inside a workgroup:
+//   k_plan_cols    one thread per (iteration, rung, column c): the walker the column meets (slot = prp(c), the cascade's
+//                  own map), its rank among the cb hashes of its block (own hash + cb - 1 lane exchanges), hence its half
+//                  h = rank >= cb/2 and its PLACE p = block * cb/2 + rank mod cb/2 in that half - written as own[h N0 + p]
+//   k_plan_draws   one thread per (iteration, rung, place): one Philox call (stretch_draw), the complement = the walker at
+//                  a uniform place of the other half, zz / (D - 1) log zz / log u; records in block order for
+//                  k_split1_pt / k_iter, whose workgroup b consumes the places [b cb/2, (b + 1) cb/2) of every rung
+// 256-thread workgroups that live a microsecond or two: they fit beside the stepping workgroups or leave quickly.
+// The halves are listed by place, not by ascending walker id (any enumeration of the other half makes a uniform place a
+// uniform complement; tests/replay_utils.py sorts them into the reference's order).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_plan_keys(const PlanArgs A, int nb) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nb * A.Tl) return;
+    const int ib = g / A.Tl, job = g - ib * A.Tl;
+    const uint32_t rung = (uint32_t)(A.rung_begin + job);
+    const PrpKey K = prp_key(A.seed, A.iter0 + (uint64_t)ib, PURPOSE_PTPERM, rung);
+    uint32_t* dst = A.keys + ((size_t)ib * A.T + rung) * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dst[r] = K.k[r];
+}
+
+__global__ __launch_bounds__(256) void k_plan_cols(const PlanArgs A) {
+    const int ib = blockIdx.y / A.Tl, job = blockIdx.y - ib * A.Tl;
+    const int rung = A.rung_begin + job;
+    const int W = A.W, cb = A.cb, hb = cb >> 1, N0 = W >> 1;
+    const int c = blockIdx.x * 256 + threadIdx.x;           // (cb divides 64 and W: a block's columns sit in one wavefront,
+    const bool live = c < W;                                //  all inside or all outside the ladder)
+    const uint4* kp = reinterpret_cast<const uint4*>(A.keys + ((size_t)ib * A.T + rung) * 8);
+    const uint4 ka = kp[0], kb = kp[1];
+    const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+    const int cc = live ? c : 0;
+    const int slot = (rung == A.T - 1) ? cc : (int)prp((uint32_t)cc, key, A.idx_bits, (uint32_t)W);
+    const uint32_t my = fmix32((key[0] ^ 0x7f4a7c15u) ^ (uint32_t)c);     // block_rank, the other hashes from the neighbours
+    int rank = 0;
+    for (int j = 1; j < cb; ++j) rank += __shfl_xor(my, j) < my ? 1 : 0;
+    if (!live) return;
+    const int h = rank >= hb ? 1 : 0, p = (c / cb) * hb + (rank & (hb - 1));
+    A.dr.own[((size_t)ib * A.Tl + job) * W + h * N0 + p] = slot;
+}
+
+__global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
+    const int ib = blockIdx.y / A.Tl, job = blockIdx.y - ib * A.Tl;
+    const uint32_t rung = (uint32_t)(A.rung_begin + job);
+    const uint64_t it = A.iter0 + (uint64_t)ib;
+    const int W = A.W, hb = A.cb >> 1, N0 = W >> 1;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= W) return;
+    const size_t base = ((size_t)ib * A.Tl + job) * W;
+    const int32_t* __restrict__ tab = A.dr.own + base;      // walker at every place (k_plan_cols)
+    const bool s0 = q < N0;
+    const int p = s0 ? q : q - N0;
+    const int own = tab[q];
+    const StretchDraw sd = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)own);
+    const int cw = tab[(s0 ? N0 : 0) + stretch_index(sd.r22, N0)];
+    const DrawRec rc = draw_values(own, cw, sd.uz, sd.ua, A.a, A.D);
+    const int blk = p / hb, ml = p - blk * hb;
+    const size_t ri = ((size_t)ib * (W / A.cb) + blk) * TILE + (size_t)rung * hb + ml;
+    if (A.rec1) {                                            // k_iter: everything in block order
+        if (s0) {
+            A.rec1[ri] = rc;
+        } else {
+            A.rec[ri] = rc;
+            // the complement is a first-half walker: its own draws once more (same counter -> same values)
+            const StretchDraw s1 = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)cw);
+            const int c2 = tab[N0 + stretch_index(s1.r22, N0)];
+            A.rec3[ri] = draw_values(cw, c2, s1.uz, s1.ua, A.a, A.D);
+        }
+        return;
+    }
+    if (s0 || !(A.rec && A.rec_only)) {
+        A.dr.cw[base + q] = rc.cw;
+        A.dr.zz[base + q] = rc.zz;
+        A.dr.fac[base + q] = rc.fac;
+        A.dr.lu[base + q] = rc.lu;
+    }
+    if (A.rec && !s0) A.rec[ri] = rc;
+    if (A.dbg_uzz) {
+        A.dbg_uzz[base + q] = sd.uz;
+        A.dbg_uacc[base + q] = sd.ua;
+    }
+}
+
+#ifdef HENS_DEV_BUILD
+// timing experiment: a side-stream kernel of known ALU work per walker (full-rate integer ops), small short workgroups
+__global__ void k_fake_plan(uint32_t* out, int slots, int64_t n) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = (uint32_t)g * 2654435761u + 1u, y = (uint32_t)(g >> 3) ^ 0x9E3779B9u;
+    for (int i = 0; i < slots; i += 4) {
+        x = (x ^ (y >> 7)) + 0x85EBCA6Bu;
+        y = (y + (x << 3)) ^ 0xC2B2AE35u;
+    }
+    if (g < n && (x ^ y) == 0x12345u) out[g & 1023] = x;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // PT cascade in column form.
@@ -1942,6 +2038,12 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const int NEr = SHORT ? (T << CS) : 2 * TILE, NM = SHORT ? (NEr >> 1) : TILE;
 #define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     FUSED_TRACE(0);
+    if (HENS_CUT_F == 9) return;
+    if (HENS_CUT_F == 8) {
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 600) __builtin_amdgcn_s_sleep(4);
+        return;
+    }
 
     // ---- phase A: one thread per slot ----------------------------------------------------------------------
     // Two memory round trips in front of the row gathers: {draw records, round keys} -> {walker records, complement
@@ -2004,6 +2106,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     FUSED_TRACE(1);
     lds_barrier();
     FUSED_TRACE(2);
+    if (HENS_CUT_F == 1) return;
 
     // ---- phase B: lanes over d, all loads first ----------------------------------------------------------
     const int jl = tid & (LPR - 1);
@@ -2060,6 +2163,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     FUSED_TRACE(3);
     lds_barrier();
+    if (HENS_CUT_F == 2) return;
 
     // ---- phase C: likelihood ------------------------------------------------------------------------------
     {
@@ -2068,6 +2172,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     FUSED_TRACE(4);
     lds_barrier();
+    if (HENS_CUT_F == 3) return;
 
     // ---- phase D: accept / update into the cascade's tables (wave 0, lane = moving walker) -----------------
     if (wv == 0 && lane < NM) {
@@ -2103,6 +2208,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     FUSED_TRACE(5);
     lds_barrier();
+    if (HENS_CUT_F == 4) return;
 
     // ---- phase F: one lane per column walks hot -> cold (tempering.py:515-541) ---------------------------------
     // (a serial chain of T-1 compare / select steps; with the ladder length a compile-time constant every LDS address
@@ -2160,6 +2266,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     lds_barrier();
     FUSED_TRACE(6);
+    if (HENS_CUT_F == 5) return;
 
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };

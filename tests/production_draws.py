@@ -4,7 +4,7 @@ Not a restatement of the reference (that is ``oracle/``): the reference draws fr
 which a device cannot reproduce in parallel.  Production stepping draws from Philox4x32-10 (Salmon et al. 2011), a
 pure function of (seed, iteration, purpose, global rung, walker), and builds its permutations from a keyed Feistel
 network.  This file states that construction independently of the HIP code (eryn_amd/csrc/hens_kernels.h:
-philox4x32_10, u01, prp_key, prp, prp_inv, block_rank, k_plan, pt_slot, pt_uniform) so that
+philox4x32_10, u01, stretch_draw, prp_key, prp, block_rank, k_plan, k_plan_cols, k_plan_draws, pt_slot, pt_uniform) so that
 
 * the generator can be pinned on CPU against the published known-answer vectors of Random123 (test_host_logic), and
 * ``hens_debug_draws`` - hence the draws the timed path consumes - can be compared with it bit for bit on the GPU.
@@ -113,33 +113,44 @@ def label_cb(T, W, tempered=True):
     return 0
 
 
+def stretch_draw(seed, it, wid):
+    """(u_zz, u_acc, r22) of walker id ``wid`` = rung * W + walker: ONE Philox call (stretch_draw in hens_kernels.h) - two
+    53-bit uniforms and, from the 2 x 11 low bits they do not use, a 22-bit number that indexes the complement half."""
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    d = philox4x32_10(it & 0xFFFFFFFF, it >> 32, wid, PURPOSE_STRETCH, lo, hi)
+    r22 = ((d[1].astype(np.uint64) & np.uint64(0x7FF)) << np.uint64(11)) | (d[3].astype(np.uint64) & np.uint64(0x7FF))
+    return u01(d[0], d[1]), u01(d[2], d[3]), r22
+
+
 def plan(seed, it, T, W, cb):
-    """own, cw, u_zz, u_acc of iteration ``it`` for the whole ladder, [T][W] by split position (k_plan)."""
+    """own, cw, u_zz, u_acc of iteration ``it`` for the whole ladder, [T][W] by split position (k_plan; with block-balanced
+    labels k_plan_cols / k_plan_draws).  Without block labels both halves are listed in ascending walker order; with them
+    a walker's place in its half is block * cb/2 + (block rank mod cb/2) of the column that meets it."""
     bits, N0 = idx_bits_of(W), (W + 1) // 2
     own = np.empty((T, W), dtype=np.int64)
     cw = np.empty((T, W), dtype=np.int64)
     uz = np.empty((T, W))
     ua = np.empty((T, W))
     w = np.arange(W)
-    lo, hi = seed & 0xFFFFFFFF, seed >> 32
     for t in range(T):
         key = prp_key(seed, it, PURPOSE_PTPERM if cb else PURPOSE_SPLIT, t)
         if cb:
-            col = w if t == T - 1 else prp(w, key, bits, W, inverse=True)       # the column that meets walker w
-            lab = (block_rank(key, col, cb) >= cb // 2).astype(np.int64)
+            hb = cb // 2
+            slot = w if t == T - 1 else prp(w, key, bits, W)                     # the walker that column c meets
+            rank = block_rank(key, w, cb)
+            place = (rank >= hb) * N0 + (w // cb) * hb + (rank % hb)
+            order = np.empty(W, dtype=np.int64)
+            order[place] = slot
         else:
             lab = (prp(w, key, bits, W) >= N0).astype(np.int64)
-        order = np.concatenate([w[lab == 0], w[lab == 1]])                       # both halves ascending
-        assert (lab == 0).sum() == N0
+            order = np.concatenate([w[lab == 0], w[lab == 1]])                   # both halves ascending
+            assert (lab == 0).sum() == N0
         own[t] = order
-        d = philox4x32_10(it & 0xFFFFFFFF, it >> 32, t * W + order, PURPOSE_STRETCH, lo, hi)
-        e = philox4x32_10(it & 0xFFFFFFFF, it >> 32, t * W + order, PURPOSE_STRETCH_ACC, lo, hi)
+        uz[t], ua[t], r22 = stretch_draw(seed, it, t * W + order)
         s0 = np.arange(W) < N0
         Nc = np.where(s0, W - N0, N0).astype(np.uint64)
-        r = ((d[0].astype(np.uint64) * Nc) >> np.uint64(32)).astype(np.int64)  # umulhi: uniform index into the other half
+        r = ((r22 * Nc) >> np.uint64(22)).astype(np.int64)                       # uniform index into the other half
         cw[t] = order[np.where(s0, N0, 0) + r]
-        uz[t] = u01(d[1], d[2])
-        ua[t] = u01(e[0], e[1])
     return dict(own=own, cw=cw, u_zz=uz, u_acc=ua)
 
 

@@ -12,7 +12,8 @@
 ``oracle_iterations`` then runs the pinned NumPy restatement (oracle/eryn_oracle.py) with exactly those draws, so
 the code path the benchmark times (plan kernel, Philox cascade, folded ladder adaptation, pipeline) is held to the
 same oracle as the parity API.  The conversion asserts what the reference guarantees structurally: halves of size
-ceil(W/2) / floor(W/2) listed in ascending order, every complement walker in the OTHER half, permutations.
+ceil(W/2) / floor(W/2), every complement walker in the OTHER half, permutations - and sorts the per-place draws into the
+ascending order in which the reference's boolean masks enumerate a half.
 """
 import numpy as np
 
@@ -28,9 +29,7 @@ def draws_to_reference(d, T, W):
     N0 = (W + 1) // 2
     own, cw = d["own"].astype(np.int64), d["cw"].astype(np.int64)
     assert own.shape == (T, W) and is_permutation_rows(own, W), "own must list every walker of a rung exactly once"
-    halves = (own[:, :N0], own[:, N0:])
-    for h in halves:                                   # boolean masks enumerate ascending (red_blue.py:150-154)
-        assert np.all(np.diff(h, axis=1) > 0), "split lists must be ascending"
+    halves = (own[:, :N0], own[:, N0:])                # by place (block labels) or ascending (k_plan)
     labels = np.empty((T, W), dtype=np.int64)
     tt = np.arange(T)[:, None]
     labels[tt, halves[0]] = 0
@@ -39,14 +38,17 @@ def draws_to_reference(d, T, W):
     out = dict(labels=labels)
     for sp in (0, 1):
         sl = slice(0, N0) if sp == 0 else slice(N0, W)
-        C = halves[1 - sp]                             # ascending complement list (red_blue.py:183-197)
-        cwp = cw[:, sl]
+        # the reference enumerates both sets through boolean masks, i.e. in ascending walker order (red_blue.py:150-154,
+        # 183-197): its k-th draw belongs to the k-th smallest moving walker, rint indexes the ascending complement list
+        order = np.argsort(halves[sp], axis=1, kind="stable")
+        C = np.sort(halves[1 - sp], axis=1)
+        cwp = np.take_along_axis(cw[:, sl], order, axis=1)
         assert np.all(labels[tt, cwp] == 1 - sp), "a complement walker drawn from the moving half"
         rint = np.stack([np.searchsorted(C[t], cwp[t]) for t in range(T)])
         assert np.array_equal(C[tt, rint], cwp)
         out[f"rint{sp}"] = rint
-        out[f"u_zz{sp}"] = d["u_zz"][:, sl]
-        out[f"u_acc{sp}"] = d["u_acc"][:, sl]
+        out[f"u_zz{sp}"] = np.take_along_axis(d["u_zz"][:, sl], order, axis=1)
+        out[f"u_acc{sp}"] = np.take_along_axis(d["u_acc"][:, sl], order, axis=1)
         for k in ("u_zz", "u_acc"):
             assert np.all((out[f"{k}{sp}"] >= 0.0) & (out[f"{k}{sp}"] < 1.0))
     if T > 1 and "pt_slot" in d:
