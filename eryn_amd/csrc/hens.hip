@@ -698,7 +698,6 @@ void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, in
     }
     const dim3 grid((c->W + 255) / 256, nb * c->Tl);
     hipLaunchKernelGGL(k_plan_keys, dim3((nb * c->Tl + 63) / 64), dim3(64), 0, s, pa, nb);
-    hipLaunchKernelGGL(k_plan_cols, grid, dim3(256), 0, s, pa);
     hipLaunchKernelGGL(k_plan_draws, grid, dim3(256), 0, s, pa);
 }
 

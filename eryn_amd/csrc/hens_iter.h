@@ -228,11 +228,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
-        const int rank = block_rank(key, c, CB);
-        scol[e] = slot;
-        if (rank < HB) s_el[t * HB + rank] = e;
-        else s_el[TILE + t * HB + rank - HB] = e;
+        scol[e] = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
     }
     ITER_TRACE(1);
     lds_barrier();
@@ -349,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     if (wv == 0 && lane < NM) {                                          // the block's own first-half walkers: results count
         double logl, newP;
         const bool keep = accept(s_part, s_flag[lane], logl, newP);
-        const int e = s_el[lane];
+        const int e = (tm << CS) + (lane & (HB - 1));                   // first-half walkers: the block's first cb/2 columns
         const int32_t rs = s_rs[lane];
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;
@@ -385,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     if (wv == 2 && lane < NM) {
         double logl, newP;
         const bool keep = accept(s_part, s_flag[2 * TILE + lane], logl, newP);
-        const int e = s_el[TILE + lane];
+        const int e = (tm << CS) + HB + (lane & (HB - 1));
         const int32_t rs = s_rs[2 * TILE + lane];
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;

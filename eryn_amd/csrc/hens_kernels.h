@@ -58,14 +58,23 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {   // 53-bit un
     const uint64_t v = ((uint64_t)hi << 32) | lo;
     return (double)(v >> 11) * (1.0 / 9007199254740992.0);
 }
-// Keyed pseudo-random permutation of [0, W): an 8-round alternating Feistel network on idx_bits bits
-// (round function = murmur3 finaliser of the half-block xor a Philox-drawn round key), cycle-walked
-// into [0, W).  A bijection for every key, no memory, no sort: position c of rung t's permutation is
-// prp(c) wherever it is needed, and every rank of a sharded ladder computes the same value.
+// Keyed pseudo-random permutation of [0, W): an 8-round alternating Feistel network on idx_bits bits, cycle-walked into
+// [0, W).  A bijection for every key, no memory, no sort: position c of rung t's permutation is prp(c) wherever it is
+// needed, and every rank of a sharded ladder computes the same value.  Round function (round 3): two 24-bit multiplies
+// with a shift-xor between them - v_mul_u32_u24 issues at full rate, the 32-bit multiplies of the murmur3 finaliser used
+// before at a quarter of it, and this network sits on the critical path of every launch that maps columns to walkers
+// (half-blocks have at most 11 bits; the round key supplies the rest of the 24).  tools/rng_validate.py: first- and
+// second-order uniformity of the permutations as good as with the finaliser, also at 6 rounds; 8 are kept.
 struct PrpKey { uint32_t k[8]; };
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
+}
+__device__ __forceinline__ uint32_t pmix(uint32_t x, uint32_t k) {
+    uint32_t h = __umul24(x ^ k, 0x9E3779u);              // (the low 24 bits of either operand)
+    h ^= h >> 15;
+    h = __umul24(h, 0x85EBCBu);
+    return h >> 11;
 }
 __device__ __forceinline__ PrpKey prp_key(uint64_t seed, uint64_t it, uint32_t purpose, uint32_t rung) {
     const u4 a = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), rung, purpose}, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -79,8 +88,8 @@ __device__ __forceinline__ uint32_t prp(uint32_t x, const uint32_t* k, int bits,
         uint32_t L = x >> rb, R = x & rm;
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
-            L ^= fmix32(R ^ k[r]) & lm;
-            R ^= fmix32(L ^ k[r + 1]) & rm;
+            L ^= pmix(R, k[r]) & lm;
+            R ^= pmix(L, k[r + 1]) & rm;
         }
         x = (L << rb) | R;
     } while (x >= W);                                     // cycle walking keeps it a bijection on [0, W)
@@ -95,8 +104,8 @@ __device__ __forceinline__ uint32_t prp_inv(uint32_t y, const uint32_t* k, int b
         uint32_t L = y >> rb, R = y & rm;
 #pragma unroll
         for (int r = 6; r >= 0; r -= 2) {
-            R ^= fmix32(L ^ k[r + 1]) & rm;
-            L ^= fmix32(R ^ k[r]) & lm;
+            R ^= pmix(L, k[r + 1]) & rm;
+            L ^= pmix(R, k[r]) & lm;
         }
         y = (L << rb) | R;
     } while (y >= W);
@@ -108,46 +117,26 @@ enum : uint32_t { PURPOSE_STRETCH = 0, PURPOSE_STRETCH_ACC = 2, PURPOSE_SPLIT = 
                   PURPOSE_PTU = 10, PURPOSE_MH_ACC = 11, PURPOSE_MH_NORMAL = 12, PURPOSE_MOVE = 13 };
 enum { MH_ISO = 0, MH_DIAG = 1, MH_FULL = 2 };
 
-// Philox-mode PT draws (one keyed matching per pair has the same distribution as the reference's two
-// permutations, tempering.py:526-532): column c of the cascade meets slot pt_slot(t, c) of global rung t (the
-// hottest rung is met in identity order), and pair (i, i-1) on column c consumes the uniform of row j = T-1-i.
+// Philox-mode PT draws: column c of the cascade meets slot pt_slot(t, c) of global rung t - every rung its own keyed
+// permutation, i.e. pair (i, i-1) is matched through two permutations like the reference's (tempering.py:526-532) - and
+// pair (i, i-1) on column c consumes the uniform of row j = T-1-i.
 __device__ __forceinline__ int pt_slot(uint64_t seed, uint64_t it, int t, int T, int c, int idx_bits, int W) {
-    if (t == T - 1) return c;
     const PrpKey K = prp_key(seed, it, PURPOSE_PTPERM, (uint32_t)t);
     return (int)prp((uint32_t)c, K.k, idx_bits, (uint32_t)W);
 }
-// Block-balanced split labelling (Philox mode, ladders whose length divides 128).  The cascade's columns are cut into
-// blocks of cb consecutive columns; on every rung exactly cb/2 of the cb walkers a block meets are labelled 1: the
-// walker that column c meets has label (rank of hash(c) among the block's cb hashes) >= cb/2.  Because the column map
-// of a rung is a uniform permutation, this is a uniformly random balanced labelling of the rung like the reference's
-// shuffle of arange(W) % 2 (red_blue.py:119-124) - and one workgroup that owns a block of columns owns exactly
-// 64 = (cb/2) * T walkers of the second half-step plus everything the cascade of those columns touches, so the second
-// half-step and the cascade run as ONE launch (k_split1_pt).  x -> fmix32(a ^ x) is a bijection: no ties.
-__device__ __forceinline__ int block_rank(const uint32_t* kpt, int c, int cb) {
-    const uint32_t a0 = kpt[0] ^ 0x7f4a7c15u;
-    const uint32_t my = fmix32(a0 ^ (uint32_t)c);
-    const int base = c & ~(cb - 1);
-    int rank = 0;
-    for (int j = 0; j < cb; ++j) rank += fmix32(a0 ^ (uint32_t)(base + j)) < my ? 1 : 0;
-    return rank;
-}
-// label of WALKER w on global rung t (the plan kernel's view): find the column that meets it, then its block rank
-__device__ __forceinline__ int block_label_of_walker(const uint32_t* kpt, int t, int T, int w, int cb, int idx_bits, int W) {
-    const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
-    return block_rank(kpt, c, cb) >= (cb >> 1) ? 1 : 0;
-}
-// the same, with the place of a label-1 walker among its block's moving walkers: block * (cb / 2) + (rank - cb / 2), or -1
-__device__ __forceinline__ int block_member_code(const uint32_t* kpt, int t, int T, int w, int cb, int idx_bits, int W) {
-    const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
-    const int rank = block_rank(kpt, c, cb);
-    return rank >= (cb >> 1) ? (c >> (__ffs(cb) - 1)) * (cb >> 1) + rank - (cb >> 1) : -1;   // cb is a power of two
-}
-// both halves (the one-launch iteration, k_iter): bit 15 = the walker moves in the FIRST half-step, low bits = block * (cb / 2)
-// + its place among the block's walkers of that half-step (rank, or rank - cb / 2)
-__device__ __forceinline__ int block_member_code2(const uint32_t* kpt, int t, int T, int w, int cb, int idx_bits, int W) {
-    const int c = (t == T - 1) ? w : (int)prp_inv((uint32_t)w, kpt, idx_bits, (uint32_t)W);
-    const int rank = block_rank(kpt, c, cb), hb = cb >> 1;
-    return (rank < hb ? 0x8000 : 0) | ((c >> (__ffs(cb) - 1)) * hb + (rank & (hb - 1)));
+// Block-balanced split labelling (Philox mode, tempered ladders of up to 64 rungs).  The cascade's columns are cut into
+// blocks of cb consecutive columns; on every rung the walkers met by the first cb/2 columns of a block move in the first
+// half-step, those met by the other cb/2 in the second.  Because a rung's column map is a uniform permutation, this is a
+// uniformly random balanced labelling of the rung like the reference's shuffle of arange(W) % 2 (red_blue.py:119-124) -
+// and one workgroup that owns a block of columns owns exactly 64 = (cb/2) * T walkers of the second half-step plus
+// everything the cascade of those columns touches, so the second half-step and the cascade run as ONE launch
+// (k_split1_pt).  A half is enumerated by PLACE p = block * cb/2 + member; the walker at place p of half h on rung t is
+// prp_t(place_column(h, p)) - a closed form, so whoever needs a walker's complement computes it in registers (round 2
+// ranked per-block hashes: a uniform place of the other half then needed a table of the whole rung, i.e. a plan kernel).
+// Split and matching of one iteration come from the same permutation (each uniform on its own; any state-independent
+// choice of partition and matching leaves the chain's stationary distribution untouched).
+__device__ __forceinline__ int place_column(int h, int p, int hb_shift) {      // hb = cb / 2 = 1 << hb_shift
+    return ((p >> hb_shift) << (hb_shift + 1)) + (h << hb_shift) + (p & ((1 << hb_shift) - 1));
 }
 __device__ __forceinline__ double pt_uniform(uint64_t seed, uint64_t it, int j, int W, int c) {   // tempering.py:535
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), (uint32_t)(j * W + c), PURPOSE_PTU};
@@ -1628,7 +1617,7 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     const size_t base = ((size_t)ib * A.Tl + job) * W;
     for (int p = tid; p < W; p += nt) {
         const int own = ord[p];
-        const StretchDraw sd = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)own);
+        const StretchDraw sd = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)p);
         const bool s0 = p < N0;
         const int cw = ord[(s0 ? N0 : 0) + stretch_index(sd.r22, s0 ? W - N0 : N0)];
         store_draw(A.dr, base + p, draw_values(own, cw, sd.uz, sd.ua, A.a, A.D));
@@ -1640,20 +1629,13 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The plan of shapes WITH block-balanced labels (k_plan_keys -> k_plan_cols -> k_plan_draws), round 3.
+// The plan of shapes WITH block-balanced labels (k_plan_keys -> k_plan_draws), round 3: for the launches that read their
+// draws from memory (copying launches, pipeline ranks, k_iter) and for hens_debug_draws; the two-launch iteration of
+// hens_step computes the same values in registers (stretch_draws_at) and needs the round keys only.
 // Round 2's plan was one 1024-thread workgroup per (iteration, rung) - inverse Feistel network per walker, block rank from
 // eight hashes, a scan for ascending lists, two Philox calls, ~40 us of life on a CU: run beside the stepping kernels it
 // cost them 2.8 us per iteration at config 2 (a stepping workgroup that cannot start until a plan workgroup leaves its CU
-// doubles its launch), run alone 4 us.  Now nothing is ordered and nothing is shared inside a workgroup:
-//   k_plan_cols    one thread per (iteration, rung, column c): the walker the column meets (slot = prp(c), the cascade's
-//                  own map), its rank among the cb hashes of its block (own hash + cb - 1 lane exchanges), hence its half
-//                  h = rank >= cb/2 and its PLACE p = block * cb/2 + rank mod cb/2 in that half - written as own[h N0 + p]
-//   k_plan_draws   one thread per (iteration, rung, place): one Philox call (stretch_draw), the complement = the walker at
-//                  a uniform place of the other half, zz / (D - 1) log zz / log u; records in block order for
-//                  k_split1_pt / k_iter, whose workgroup b consumes the places [b cb/2, (b + 1) cb/2) of every rung
-// 256-thread workgroups that live a microsecond or two: they fit beside the stepping workgroups or leave quickly.
-// The halves are listed by place, not by ascending walker id (any enumeration of the other half makes a uniform place a
-// uniform complement; tests/replay_utils.py sorts them into the reference's order).
+// doubles its launch), run alone 4 us.  Now one thread per (iteration, rung, place), nothing ordered, nothing shared.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_plan_keys(const PlanArgs A, int nb) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1666,54 +1648,50 @@ __global__ void k_plan_keys(const PlanArgs A, int nb) {
     for (int r = 0; r < 8; ++r) dst[r] = K.k[r];
 }
 
-__global__ __launch_bounds__(256) void k_plan_cols(const PlanArgs A) {
-    const int ib = blockIdx.y / A.Tl, job = blockIdx.y - ib * A.Tl;
-    const int rung = A.rung_begin + job;
-    const int W = A.W, cb = A.cb, hb = cb >> 1, N0 = W >> 1;
-    const int c = blockIdx.x * 256 + threadIdx.x;           // (cb divides 64 and W: a block's columns sit in one wavefront,
-    const bool live = c < W;                                //  all inside or all outside the ladder)
-    const uint4* kp = reinterpret_cast<const uint4*>(A.keys + ((size_t)ib * A.T + rung) * 8);
-    const uint4 ka = kp[0], kb = kp[1];
-    const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-    const int cc = live ? c : 0;
-    const int slot = (rung == A.T - 1) ? cc : (int)prp((uint32_t)cc, key, A.idx_bits, (uint32_t)W);
-    const uint32_t my = fmix32((key[0] ^ 0x7f4a7c15u) ^ (uint32_t)c);     // block_rank, the other hashes from the neighbours
-    int rank = 0;
-    for (int j = 1; j < cb; ++j) rank += __shfl_xor(my, j) < my ? 1 : 0;
-    if (!live) return;
-    const int h = rank >= hb ? 1 : 0, p = (c / cb) * hb + (rank & (hb - 1));
-    A.dr.own[((size_t)ib * A.Tl + job) * W + h * N0 + p] = slot;
+// Everything about split position q = h N0 + p of rung `rung` in iteration `it`: the walker there, its complement - the
+// walker at a uniform place of the other half - and the two uniforms (one Philox call keyed by the POSITION, so it does
+// not wait for the round keys).
+struct PlaceDraw { int own, cw; double uz, ua; int r; };
+__device__ __forceinline__ PlaceDraw stretch_draws_at(uint64_t seed, uint64_t it, uint32_t rung, int q, const uint32_t* key,
+                                                      int W, int idx_bits, int hb_shift) {
+    const int N0 = W >> 1;
+    const int h = q >= N0 ? 1 : 0, p = q - h * N0;
+    const StretchDraw sd = stretch_draw(seed, it, rung * (uint32_t)W + (uint32_t)q);
+    const int r = stretch_index(sd.r22, N0);
+    const int own = (int)prp((uint32_t)place_column(h, p, hb_shift), key, idx_bits, (uint32_t)W);
+    const int cw = (int)prp((uint32_t)place_column(1 - h, r, hb_shift), key, idx_bits, (uint32_t)W);
+    return PlaceDraw{own, cw, sd.uz, sd.ua, r};
 }
 
 __global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
     const int ib = blockIdx.y / A.Tl, job = blockIdx.y - ib * A.Tl;
     const uint32_t rung = (uint32_t)(A.rung_begin + job);
     const uint64_t it = A.iter0 + (uint64_t)ib;
-    const int W = A.W, hb = A.cb >> 1, N0 = W >> 1;
+    const int W = A.W, hb = A.cb >> 1, hb_shift = __ffs(hb) - 1, N0 = W >> 1;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= W) return;
+    const uint4* kp = reinterpret_cast<const uint4*>(A.keys + ((size_t)ib * A.T + rung) * 8);
+    const uint4 ka = kp[0], kb = kp[1];
+    const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
     const size_t base = ((size_t)ib * A.Tl + job) * W;
-    const int32_t* __restrict__ tab = A.dr.own + base;      // walker at every place (k_plan_cols)
     const bool s0 = q < N0;
     const int p = s0 ? q : q - N0;
-    const int own = tab[q];
-    const StretchDraw sd = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)own);
-    const int cw = tab[(s0 ? N0 : 0) + stretch_index(sd.r22, N0)];
-    const DrawRec rc = draw_values(own, cw, sd.uz, sd.ua, A.a, A.D);
-    const int blk = p / hb, ml = p - blk * hb;
+    const PlaceDraw pd = stretch_draws_at(A.seed, it, rung, q, key, W, A.idx_bits, hb_shift);
+    const DrawRec rc = draw_values(pd.own, pd.cw, pd.uz, pd.ua, A.a, A.D);
+    const int blk = p >> hb_shift, ml = p & (hb - 1);
     const size_t ri = ((size_t)ib * (W / A.cb) + blk) * TILE + (size_t)rung * hb + ml;
     if (A.rec1) {                                            // k_iter: everything in block order
         if (s0) {
             A.rec1[ri] = rc;
         } else {
             A.rec[ri] = rc;
-            // the complement is a first-half walker: its own draws once more (same counter -> same values)
-            const StretchDraw s1 = stretch_draw(A.seed, it, rung * (uint32_t)W + (uint32_t)cw);
-            const int c2 = tab[N0 + stretch_index(s1.r22, N0)];
-            A.rec3[ri] = draw_values(cw, c2, s1.uz, s1.ua, A.a, A.D);
+            // the complement sits at place pd.r of the first half: its own draws once more (same counter -> same values)
+            const PlaceDraw p1 = stretch_draws_at(A.seed, it, rung, pd.r, key, W, A.idx_bits, hb_shift);
+            A.rec3[ri] = draw_values(p1.own, p1.cw, p1.uz, p1.ua, A.a, A.D);
         }
         return;
     }
+    A.dr.own[base + q] = rc.own;
     if (s0 || !(A.rec && A.rec_only)) {
         A.dr.cw[base + q] = rc.cw;
         A.dr.zz[base + q] = rc.zz;
@@ -1722,8 +1700,8 @@ __global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
     }
     if (A.rec && !s0) A.rec[ri] = rc;
     if (A.dbg_uzz) {
-        A.dbg_uzz[base + q] = sd.uz;
-        A.dbg_uacc[base + q] = sd.ua;
+        A.dbg_uzz[base + q] = pd.uz;
+        A.dbg_uacc[base + q] = pd.ua;
     }
 }
 
@@ -2071,9 +2049,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        const int slot = (t == T - 1) ? c : (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
-        const int rank = block_rank(key, c, CB);
-        stays = rank < HB;
+        const int slot = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+        stays = cc < HB;                                                 // (the block's first cb/2 columns: place_column)
         const int tm = lane >> (CS - 1);                                 // (wave 0: rung of the m-th moving walker)
         const int32_t gi = tm * W + rc.own;
         int32_t rs_m = 0, rc_m = 0;
@@ -2092,7 +2069,6 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
         }
         scol[e] = slot;
-        if (!stays) s_el[t * HB + rank - HB] = e;                        // 0 .. 63, each exactly once: where phase D puts the result
         if (!WIDE && e < T) sbeta[e] = A.betas[e];
       }
     } else if (tid < 2 * NE) {
@@ -2186,7 +2162,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             atomicOr(A.flags, FLAG_NAN_LOGL);
         }
         const double logp = inbox ? A.logp_in : -INFINITY;              // prior.py:80-88
-        const int e = s_el[lane];
+        const int e = ((lane >> (CS - 1)) << CS) + (CB >> 1) + (lane & ((CB >> 1) - 1));   // the m-th moving walker's element
         const double beta = sbeta[e >> CS];
         const double Lold = Lold_m, Pold = Pold_m;
         double lt = logl * beta;                                        // tempering.py:304-306,343-349

@@ -4,7 +4,8 @@ Not a restatement of the reference (that is ``oracle/``): the reference draws fr
 which a device cannot reproduce in parallel.  Production stepping draws from Philox4x32-10 (Salmon et al. 2011), a
 pure function of (seed, iteration, purpose, global rung, walker), and builds its permutations from a keyed Feistel
 network.  This file states that construction independently of the HIP code (eryn_amd/csrc/hens_kernels.h:
-philox4x32_10, u01, stretch_draw, prp_key, prp, block_rank, k_plan, k_plan_cols, k_plan_draws, pt_slot, pt_uniform) so that
+philox4x32_10, u01, stretch_draw, prp_key, pmix, prp, place_column, k_plan, k_plan_draws, stretch_draws_at, pt_slot,
+pt_uniform) so that
 
 * the generator can be pinned on CPU against the published known-answer vectors of Random123 (test_host_logic), and
 * ``hens_debug_draws`` - hence the draws the timed path consumes - can be compared with it bit for bit on the GPU.
@@ -64,6 +65,15 @@ def idx_bits_of(W):
     return b
 
 
+def pmix(x, k):
+    """Round function of the Feistel network: two 24-bit multiplies with a shift-xor between them (hens_kernels.h: pmix)."""
+    m24 = np.uint64(0xFFFFFF)
+    h = (((np.asarray(x, dtype=np.uint64) ^ np.uint64(k)) & m24) * np.uint64(0x9E3779)) & MASK
+    h ^= h >> np.uint64(15)
+    h = ((h & m24) * np.uint64(0x85EBCB)) & MASK
+    return h >> np.uint64(11)
+
+
 def _feistel(x, key, bits, inverse):
     lb = bits >> 1
     rb = bits - lb
@@ -72,16 +82,17 @@ def _feistel(x, key, bits, inverse):
     rounds = range(6, -1, -2) if inverse else range(0, 8, 2)
     for r in rounds:
         if inverse:
-            R = R ^ (fmix32(L ^ np.uint64(key[r + 1])) & rm)
-            L = L ^ (fmix32(R ^ np.uint64(key[r])) & lm)
+            R = R ^ (pmix(L, key[r + 1]) & rm)
+            L = L ^ (pmix(R, key[r]) & lm)
         else:
-            L = L ^ (fmix32(R ^ np.uint64(key[r])) & lm)
-            R = R ^ (fmix32(L ^ np.uint64(key[r + 1])) & rm)
+            L = L ^ (pmix(R, key[r]) & lm)
+            R = R ^ (pmix(L, key[r + 1]) & rm)
     return (L << np.uint64(rb)) | R
 
 
 def prp(x, key, bits, W, inverse=False):
-    """Keyed permutation of [0, W): 8-round alternating Feistel network on ``bits`` bits, cycle-walked into range."""
+    """Keyed permutation of [0, W): 8-round alternating Feistel network on ``bits`` bits (round function pmix),
+    cycle-walked into range."""
     x = np.array(x, dtype=np.uint64, copy=True)
     out = _feistel(x, key, bits, inverse)
     while True:
@@ -91,15 +102,10 @@ def prp(x, key, bits, W, inverse=False):
         out[bad] = _feistel(out[bad], key, bits, inverse)
 
 
-def block_rank(key, c, cb):
-    a0 = np.uint64(key[0] ^ 0x7F4A7C15)
-    c = np.asarray(c, dtype=np.int64)
-    my = fmix32(a0 ^ c.astype(np.uint64))
-    base = c & ~(cb - 1)
-    rank = np.zeros(c.shape, dtype=np.int64)
-    for j in range(cb):
-        rank += fmix32(a0 ^ (base + j).astype(np.uint64)) < my
-    return rank
+def place_column(h, p, cb):
+    """Column that meets the walker at place p of half h: block * cb + h * cb/2 + member (hens_kernels.h: place_column)."""
+    hb = cb // 2
+    return (p // hb) * cb + h * hb + (p % hb)
 
 
 def label_cb(T, W, tempered=True):
@@ -114,8 +120,9 @@ def label_cb(T, W, tempered=True):
 
 
 def stretch_draw(seed, it, wid):
-    """(u_zz, u_acc, r22) of walker id ``wid`` = rung * W + walker: ONE Philox call (stretch_draw in hens_kernels.h) - two
-    53-bit uniforms and, from the 2 x 11 low bits they do not use, a 22-bit number that indexes the complement half."""
+    """(u_zz, u_acc, r22) of split position ``wid`` = rung * W + position: ONE Philox call (stretch_draw in
+    hens_kernels.h) - two 53-bit uniforms and, from the 2 x 11 low bits they do not use, a 22-bit number that indexes the
+    complement half."""
     lo, hi = seed & 0xFFFFFFFF, seed >> 32
     d = philox4x32_10(it & 0xFFFFFFFF, it >> 32, wid, PURPOSE_STRETCH, lo, hi)
     r22 = ((d[1].astype(np.uint64) & np.uint64(0x7FF)) << np.uint64(11)) | (d[3].astype(np.uint64) & np.uint64(0x7FF))
@@ -124,30 +131,25 @@ def stretch_draw(seed, it, wid):
 
 def plan(seed, it, T, W, cb):
     """own, cw, u_zz, u_acc of iteration ``it`` for the whole ladder, [T][W] by split position (k_plan; with block-balanced
-    labels k_plan_cols / k_plan_draws).  Without block labels both halves are listed in ascending walker order; with them
-    a walker's place in its half is block * cb/2 + (block rank mod cb/2) of the column that meets it."""
+    labels k_plan_draws / stretch_draws_at).  Without block labels both halves are listed in ascending walker order; with
+    them the walker at place p of half h is the one the column place_column(h, p) meets."""
     bits, N0 = idx_bits_of(W), (W + 1) // 2
     own = np.empty((T, W), dtype=np.int64)
     cw = np.empty((T, W), dtype=np.int64)
     uz = np.empty((T, W))
     ua = np.empty((T, W))
     w = np.arange(W)
+    s0 = w < N0
     for t in range(T):
         key = prp_key(seed, it, PURPOSE_PTPERM if cb else PURPOSE_SPLIT, t)
         if cb:
-            hb = cb // 2
-            slot = w if t == T - 1 else prp(w, key, bits, W)                     # the walker that column c meets
-            rank = block_rank(key, w, cb)
-            place = (rank >= hb) * N0 + (w // cb) * hb + (rank % hb)
-            order = np.empty(W, dtype=np.int64)
-            order[place] = slot
+            order = prp(place_column((~s0).astype(np.int64), np.where(s0, w, w - N0), cb), key, bits, W)
         else:
             lab = (prp(w, key, bits, W) >= N0).astype(np.int64)
             order = np.concatenate([w[lab == 0], w[lab == 1]])                   # both halves ascending
             assert (lab == 0).sum() == N0
         own[t] = order
-        uz[t], ua[t], r22 = stretch_draw(seed, it, t * W + order)
-        s0 = np.arange(W) < N0
+        uz[t], ua[t], r22 = stretch_draw(seed, it, t * W + w)
         Nc = np.where(s0, W - N0, N0).astype(np.uint64)
         r = ((r22 * Nc) >> np.uint64(22)).astype(np.int64)                       # uniform index into the other half
         cw[t] = order[np.where(s0, N0, 0) + r]
@@ -160,7 +162,7 @@ def pt_draws(seed, it, T, W):
     c = np.arange(W)
     slot = np.empty((T, W), dtype=np.int64)
     for t in range(T):
-        slot[t] = c if t == T - 1 else prp(c, prp_key(seed, it, PURPOSE_PTPERM, t), bits, W)
+        slot[t] = prp(c, prp_key(seed, it, PURPOSE_PTPERM, t), bits, W)
     lo, hi = seed & 0xFFFFFFFF, seed >> 32
     u = np.empty((T - 1, W))
     for j in range(T - 1):

@@ -52,9 +52,10 @@ def test_plan_structure(T, W):
         assert all(int(c) not in first for c in cw[:N0]) and all(int(c) in first for c in cw[N0:])
         if cb:                                            # cb/2 walkers of each half per block and rung, listed block by block
             key = pd.prp_key(2024, 11, pd.PURPOSE_PTPERM, t)
-            for half in (own[:N0], own[N0:]):
-                col = half if t == T - 1 else pd.prp(half, key, bits, W, inverse=True)
+            for h, half in enumerate((own[:N0], own[N0:])):
+                col = pd.prp(half, key, bits, W, inverse=True)
                 assert np.array_equal(col // cb, np.arange(N0) // (cb // 2))
+                assert np.all((col % cb >= cb // 2) == bool(h))
         else:
             assert np.all(np.diff(own[:N0]) > 0) and np.all(np.diff(own[N0:]) > 0)     # ascending halves
     assert np.all((d["u_zz"] >= 0) & (d["u_zz"] < 1) & (d["u_acc"] >= 0) & (d["u_acc"] < 1))
