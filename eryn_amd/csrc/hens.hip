@@ -691,13 +691,14 @@ void spec_cancel(hens_ctx_impl* c) {
 }
 
 // block-balanced labels: keys -> places -> draws (small short workgroups, see k_plan_cols); other shapes: k_plan
-void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, int nb) {
+void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, int nb, bool keys_only = false) {
     if (!pa.cb) {
         hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
         return;
     }
     const dim3 grid((c->W + 255) / 256, nb * c->Tl);
     hipLaunchKernelGGL(k_plan_keys, dim3((nb * c->Tl + 63) / 64), dim3(64), 0, s, pa, nb);
+    if (keys_only) return;          // (the two-launch iteration computes its draws in registers)
     hipLaunchKernelGGL(k_plan_draws, grid, dim3(256), 0, s, pa);
 }
 
@@ -711,7 +712,7 @@ void launch_plan(hens_ctx_impl* c, hipStream_t s, int which, uint64_t iter0, int
     pa.rec = fused ? c->db[which].rec : nullptr;          // (only k_split1_pt reads the block-ordered records)
     pa.rec_only = fused ? 1 : 0;
     if (iter1) { pa.rec1 = c->db[which].rec1; pa.rec3 = c->db[which].rec3; }   // (k_iter reads nothing else)
-    launch_plan_kernels(c, s, pa, nb);
+    launch_plan_kernels(c, s, pa, nb, fused && !iter1);
 }
 
 hipEvent_t new_event(hens_ctx_impl* c) {
@@ -905,7 +906,9 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
         StretchArgs a = base_args(c);
         a.wrec = c->wrec[c->cur];
         a.inplace = 1;
-        a.dr = draws_at(c->db[which], (size_t)ib * T * W);
+        a.ikeys = c->db[which].keys + (size_t)ib * T * 8;             // draws in registers (stretch_draws_at)
+        a.iseed = c->cfg.seed; a.iiter = c->iter; a.ia = c->cfg.a;
+        a.idx_bits = c->idx_bits; a.hb_shift = c->label_cb_shift - 1; a.ndim_active = dim_active(c);
         a.split = 0;
         a.home_off = c->parity * T * W;
         attach_iteration_head(c, a);
@@ -924,8 +927,8 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
     f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
-    f.rec = c->db[which].rec + (size_t)ib * rec_per_iter(c);
     f.keys = c->db[which].keys + (size_t)ib * T * 8;
+    f.a = c->cfg.a; f.ndim_active = dim_active(c);
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
     acc_commit(c);
@@ -1856,9 +1859,20 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // A call of at most one batch may find its plan ready: the previous call planned it speculatively (a pure function of
     // seed, iteration and path) while it stepped.  And it plans the iterations that follow its own for the next call.
     static const bool spec_on = getenv("HENS_NO_SPEC") == nullptr;
+    // Round 3: the plan of a batch ON THE MAIN STREAM, right in front of the batch - always for the two-launch iteration, which
+    // computes its draws in registers and needs the round keys only (a few hundred threads per batch).  A plan on the side
+    // stream costs two cross-stream event waits per batch whatever its size: 31 us per batch of 22 iterations at config 2
+    // (1.4 us per iteration) with nothing but the keys kernel on it.  HENS_PLAN_INLINE=0/1 forces either form (A/B knob).
+    static const int inline_env = getenv("HENS_PLAN_INLINE") ? atoi(getenv("HENS_PLAN_INLINE")) : -1;
+    const bool plan_inline = !piped && (inline_env >= 0 ? inline_env != 0 : (fused && !iter1));
+    if (plan_inline && c->spec_valid) {          // (a speculative plan of an earlier call may still be writing a buffer)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0));
+        c->spec_valid = false;
+    }
     int first_buf = 0;
     bool spec_hit = false;
-    if (nbatch == 1 && c->spec_valid && c->spec_iter0 == c->iter && c->spec_nb >= n_iters && c->spec_fused == fused &&
+    if (plan_inline) spec_hit = true;            // (no plan ahead of the loop, no speculation)
+    else if (nbatch == 1 && c->spec_valid && c->spec_iter0 == c->iter && c->spec_nb >= n_iters && c->spec_fused == fused &&
         c->spec_iter1 == iter1) {
         first_buf = c->spec_buf;
         spec_hit = true;
@@ -1871,7 +1885,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         HIPCHK(c, hipEventRecord(c->ev_plan[first_buf], c->plan_stream));
         c->timing.n_plan += 1;
     }
-    if (spec_on && nbatch == 1 && !piped) {
+    if (spec_on && nbatch == 1 && !piped && !plan_inline) {
         const int sb = first_buf ^ 1;
         HIPCHK(c, hipEventRecord(c->ev_used[sb], c->stream));             // its last readers: the previous call's launches
         HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[sb], 0));
@@ -1882,7 +1896,11 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         c->spec_fused = fused; c->spec_iter1 = iter1;
     }
     for (int64_t b = 0; b < nbatch; ++b) {
-        const int which = (int)((first_buf + b) & 1), nb = batch_size(b);
+        const int which = plan_inline ? 0 : (int)((first_buf + b) & 1), nb = batch_size(b);
+        if (plan_inline) {
+            launch_plan(c, c->stream, 0, c->iter, nb, fused, iter1);
+            c->timing.n_plan += 1;
+        }
 #ifdef HENS_DEV_BUILD
         static const bool plan_once = getenv("HENS_DEBUG_PLAN_ONCE") != nullptr;   // timing only: both buffers planned once, reused
         static const int fake_slots = getenv("HENS_DEBUG_FAKE_PLAN") ? atoi(getenv("HENS_DEBUG_FAKE_PLAN")) : 0;
@@ -1892,9 +1910,9 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             hipLaunchKernelGGL(k_fake_plan, dim3((unsigned)((n + fake_threads - 1) / fake_threads)), dim3(fake_threads), 0, c->plan_stream,
                                reinterpret_cast<uint32_t*>(c->xtmp), fake_slots, n);
         }
-        if (b + 1 < nbatch && !(plan_once && b >= 1)) {
+        if (b + 1 < nbatch && !(plan_once && b >= 1) && !plan_inline) {
 #else
-        if (b + 1 < nbatch) {
+        if (b + 1 < nbatch && !plan_inline) {
 #endif
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
@@ -1905,7 +1923,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             static const bool plan_serial = getenv("HENS_PLAN_SERIAL") != nullptr;     // A/B knob: the plan runs alone
             if (plan_serial) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[nxt], 0));
         }
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
+        if (!plan_inline) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
         for (int ib = 0; ib < nb; ++ib) {
             if (piped) pipe_prewait(c);
             const bool mh = iteration_is_mh(c);

@@ -158,6 +158,21 @@ __device__ __forceinline__ int stretch_index(uint32_t r22, int Nc) {          //
     return (int)(((uint64_t)r22 * (uint64_t)Nc) >> STRETCH_INDEX_BITS);
 }
 
+// Everything about split position q = h N0 + p of rung `rung` in iteration `it`: the walker there, its complement - the
+// walker at a uniform place of the other half - and the two uniforms (one Philox call keyed by the POSITION, so it does
+// not wait for the round keys).
+struct PlaceDraw { int own, cw; double uz, ua; int r; };
+__device__ __forceinline__ PlaceDraw stretch_draws_at(uint64_t seed, uint64_t it, uint32_t rung, int q, const uint32_t* key,
+                                                      int W, int idx_bits, int hb_shift) {
+    const int N0 = W >> 1;
+    const int h = q >= N0 ? 1 : 0, p = q - h * N0;
+    const StretchDraw sd = stretch_draw(seed, it, rung * (uint32_t)W + (uint32_t)q);
+    const int r = stretch_index(sd.r22, N0);
+    const int own = (int)prp((uint32_t)place_column(h, p, hb_shift), key, idx_bits, (uint32_t)W);
+    const int cw = (int)prp((uint32_t)place_column(1 - h, r, hb_shift), key, idx_bits, (uint32_t)W);
+    return PlaceDraw{own, cw, sd.uz, sd.ua, r};
+}
+
 // One Box-Muller pair of standard normals for coordinates (2 pr, 2 pr + 1) of walker `wid` (= rung * W + walker)
 // in iteration `it`: the draw of the Gaussian MH move (k_mh_draw and the inline MODE_MH path share it).
 __device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t wid, uint32_t pr) {
@@ -468,6 +483,12 @@ struct StretchArgs {
     long long wbudget;
     uint32_t wtarget, wtarget_cnt;   // rows flags / swap-count flags (PF_CNT0..)
     unsigned long long* wstats;      // debug wait statistics or nullptr
+    // hens_step's two-launch iteration on block-balanced labels: no planned draws - the launch computes them in registers
+    // from the iteration's round keys (stretch_draws_at; `dr` is not read)
+    const uint32_t* ikeys;           // [T][8] round keys of this iteration's column maps (k_plan_keys), or nullptr
+    uint64_t iseed, iiter;
+    double ia;                       // stretch scale a
+    int32_t idx_bits, hb_shift, ndim_active;
     AdaptArgs ad;
 };
 
@@ -520,6 +541,20 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                 lu = A.dr.lu[(size_t)tl * W + own];
                 Lold = A.L[tl * W + own];
                 Pold = A.P[tl * W + own];
+            } else if (A.ikeys) {
+                // in registers: the Philox call first (it needs no key: the scalar load of the rung's round keys is in
+                // flight), then the walker at this place -> its record, then the logarithms while that load is in flight
+                const uint32_t* kp = A.ikeys + (size_t)(A.rung_begin + tl) * 8;
+                const uint32_t key[8] = {kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+                const int q = s_off + k;
+                const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)q);
+                own = (int)prp((uint32_t)place_column(A.split, k, A.hb_shift), key, A.idx_bits, (uint32_t)W);
+                const WalkerRec* o = A.wrec + (tl * W + own);
+                const double2 lp = *reinterpret_cast<const double2*>(&o->L);
+                rs = o->loc;
+                const DrawRec dv = draw_values(own, 0, sd.uz, sd.ua, A.ia, A.ndim_active);
+                zz = dv.zz; factors = dv.fac; lu = dv.lu;
+                Lold = lp.x; Pold = lp.y;
             } else {
                 const size_t di = (size_t)tl * W + s_off + k;
                 own = A.dr.own[di];
@@ -1146,6 +1181,20 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     Lold = A.L[tl * W + own];
                     Pold = A.P[tl * W + own];
                 }
+            } else if (A.ikeys) {
+                // in registers: the Philox call first (it needs no key: the scalar load of the rung's round keys is in
+                // flight), then the walker at this place -> its record, then the logarithms while that load is in flight
+                const uint32_t* kp = A.ikeys + (size_t)(A.rung_begin + tl) * 8;
+                const uint32_t key[8] = {kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+                const int q = s_off + k;
+                const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)q);
+                own = (int)prp((uint32_t)place_column(A.split, k, A.hb_shift), key, A.idx_bits, (uint32_t)W);
+                const WalkerRec* o = A.wrec + (tl * W + own);
+                const double2 lp = *reinterpret_cast<const double2*>(&o->L);
+                rs = o->loc;
+                const DrawRec dv = draw_values(own, 0, sd.uz, sd.ua, A.ia, A.ndim_active);
+                zz = dv.zz; factors = dv.fac; lu = dv.lu;
+                Lold = lp.x; Pold = lp.y;
             } else {
                 const size_t di = (size_t)tl * W + s_off + k;
                 own = A.dr.own[di];
@@ -1169,9 +1218,22 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         }
         s_zz[lane] = zz;
         s_rs[lane] = rs;
-        s_rc[lane] = rc;
+        if (!(MODE == MODE_STRETCH && A.ikeys)) s_rc[lane] = rc;
         s_dst[lane] = A.inplace ? rs : A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
+    } else if (MODE == MODE_STRETCH && A.ikeys && wv == 2) {
+        // the complement's row on a wave of its own (same Philox call, the other half of its output): two dependent chains
+        // {draw -> walker -> record} side by side instead of one after the other
+        const int k = k0 + lane;
+        int rc = 0;
+        if (k < Ns) {
+            const uint32_t* kp = A.ikeys + (size_t)(A.rung_begin + tl) * 8;
+            const uint32_t key[8] = {kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
+            const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(s_off + k));
+            const int cw = (int)prp((uint32_t)place_column(1 - A.split, stretch_index(sd.r22, W >> 1), A.hb_shift), key, A.idx_bits, (uint32_t)W);
+            rc = A.loc[tl * W + cw];
+        }
+        s_rc[lane] = rc;
     } else if (red_on && wv == 1) {
         s_cnt[lane] = 0;
         s_cnt[lane + 64] = 0;
@@ -1648,21 +1710,6 @@ __global__ void k_plan_keys(const PlanArgs A, int nb) {
     for (int r = 0; r < 8; ++r) dst[r] = K.k[r];
 }
 
-// Everything about split position q = h N0 + p of rung `rung` in iteration `it`: the walker there, its complement - the
-// walker at a uniform place of the other half - and the two uniforms (one Philox call keyed by the POSITION, so it does
-// not wait for the round keys).
-struct PlaceDraw { int own, cw; double uz, ua; int r; };
-__device__ __forceinline__ PlaceDraw stretch_draws_at(uint64_t seed, uint64_t it, uint32_t rung, int q, const uint32_t* key,
-                                                      int W, int idx_bits, int hb_shift) {
-    const int N0 = W >> 1;
-    const int h = q >= N0 ? 1 : 0, p = q - h * N0;
-    const StretchDraw sd = stretch_draw(seed, it, rung * (uint32_t)W + (uint32_t)q);
-    const int r = stretch_index(sd.r22, N0);
-    const int own = (int)prp((uint32_t)place_column(h, p, hb_shift), key, idx_bits, (uint32_t)W);
-    const int cw = (int)prp((uint32_t)place_column(1 - h, r, hb_shift), key, idx_bits, (uint32_t)W);
-    return PlaceDraw{own, cw, sd.uz, sd.ua, r};
-}
-
 __global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
     const int ib = blockIdx.y / A.Tl, job = blockIdx.y - ib * A.Tl;
     const uint32_t rung = (uint32_t)(A.rung_begin + job);
@@ -1956,8 +2003,7 @@ struct FusedArgs {
     const int32_t* loc;                                       // [T][W] the row of every walker once more, compact (a rung's
     int32_t* locnew;                                          // 4 W bytes stay in L2): where the complements are looked up
     const double* betas;                                      // [T]
-    const DrawRec* rec;                                       // [W / cb][64] this iteration's draws in block order (see DrawRec)
-    const uint32_t* keys;                                     // [T][8] round keys of the rungs' column maps (from the plan)
+    const uint32_t* keys;                                     // [T][8] round keys of the rungs' column maps (k_plan_keys)
     uint32_t* accepted;                                       // [T][W]
     uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
@@ -1965,8 +2011,9 @@ struct FusedArgs {
     unsigned* flags;
     unsigned long long* trace;                                // debug: 8 phase timestamps per workgroup, or nullptr
     double logp_in, fill, rosen_a, rosen_b;
+    double a;                                                 // stretch scale (stretch.py:129-132)
     uint64_t iter, seed;
-    int32_t T, W, idx_bits, cb, cb_shift;
+    int32_t T, W, idx_bits, cb, cb_shift, ndim_active;
 };
 
 __host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
@@ -2023,61 +2070,63 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         return;
     }
 
-    // ---- phase A: one thread per slot ----------------------------------------------------------------------
-    // Two memory round trips in front of the row gathers: {draw records, round keys} -> {walker records, complement
-    // rows}.  The 64 draw records arrive in block order (one coalesced load, k_plan), each names its walker, whose
-    // {L, P, row} is one 32-byte record (the phase is bound by the number of cache lines it pulls in: one per walker, not
-    // three by-field arrays).  The column map (key -> slot) serves the walkers that do not move (cascade tables) and the
-    // addresses phase G writes to; the round keys come from the plan (a 32-byte load that hits L2; two Philox calls in
-    // place cost 3x as long), the cascade's log-uniforms are computed on two other waves.
-    // Program order matters: the column map is computed BEFORE the second-hop loads are issued (its cycle-walking loop
-    // makes the compiler wait for every load in flight: issued earlier, they would serialise into a third round trip),
-    // those loads are unconditional so that the wait counts in front of the LDS writes stay exact, and what phase B does
-    // not need ({L, P} of the moving walkers: registers of the lane that runs phase D; the records of the walkers that
-    // stay: cascade tables) is consumed after the row gathers have been issued.
-    double Lold_m = 0.0, Pold_m = 0.0;                                   // wave 0, lane m
+    // ---- phase A: one thread per slot, the moving walkers' draws on waves of their own -----------------------------------
+    // One memory round trip of round keys (a 32-byte load per rung that hits L2, k_plan_keys) and one of walker records in
+    // front of the row gathers; no planned draws (round 3).  Slot thread e = (rung t, column cc of the block): the column
+    // map gives the walker in the slot, whose {L, P, row} is one 32-byte record (the phase is bound by the number of
+    // cache lines it pulls in).  The block's last cb/2 columns meet the walkers that MOVE in this half-step
+    // (place_column): their slot threads keep the record for phase D and are the lanes that run it; walker m = t cb/2 +
+    // (cc - cb/2) of the tile.  What is random about walker m comes from one Philox call keyed by its split position
+    // (stretch_draws_at), computed twice on otherwise idle waves - one turns it into the complement's row (second Feistel
+    // network, a lookup in the compact row table), one into zz / (D - 1) log zz / log u - while the round keys are in flight.
+    // Program order matters in the slot threads: the column map is computed BEFORE the record loads are issued (its
+    // cycle-walking loop makes the compiler wait for every load in flight), and the records of the walkers that stay
+    // (cascade tables) are consumed after the row gathers have been issued.
     WalkerRec wr_n{};                                                    // slot threads: the record of the walker in the slot
     bool stays = false;
+    int slot_n = 0;
+    const int HB = CB >> 1;
+    constexpr int CWW = WIDE ? 5 : 2, FLW = WIDE ? 6 : 3;               // the waves of the moving walkers' draws
     if (wv == 0) s_flag[lane] = 0;                                       // (also the idle lanes of a short tile: never in the box)
-    if (tid < NE) {
-      if (tid < NEr) {                                                   // (short ladders: the slots beyond cb T do not exist)
+    if (tid < NEr) {                                                     // (short ladders: the slots beyond cb T do not exist)
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
-        const int HB = CB >> 1;
-        const bool mv = wv == 0 && lane < NM;                            // wave 0: lane m = the block's m-th moving walker
-        DrawRec rc{};
-        if (mv) rc = A.rec[(size_t)blockIdx.x * TILE + lane];
         const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        const int slot = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
-        stays = cc < HB;                                                 // (the block's first cb/2 columns: place_column)
-        const int tm = lane >> (CS - 1);                                 // (wave 0: rung of the m-th moving walker)
-        const int32_t gi = tm * W + rc.own;
-        int32_t rs_m = 0, rc_m = 0;
-        if (mv) {
-            rs_m = A.wrec[gi].loc;
-            rc_m = A.loc[tm * W + rc.cw];
-            const double2 lp = *reinterpret_cast<const double2*>(&A.wrec[gi].L);
-            Lold_m = lp.x; Pold_m = lp.y;
+        slot_n = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+        stays = cc < HB;
+        wr_n = A.wrec[(size_t)t * W + slot_n];
+        if (!stays) {
+            const int m = (t << (CS - 1)) + cc - HB;
+            s_rs[m] = wr_n.loc;
+            s_dst[m] = t * W + slot_n;                                   // (walker index: the accept counters)
         }
-        wr_n = A.wrec[(size_t)t * W + slot];                             // (a moving walker's record: unused, same lines)
-        if (mv) {
-            const int m = lane;
-            s_rs[m] = rs_m;
-            s_rc[m] = rc_m;
-            s_dst[m] = gi;                                               // (walker index: the accept counters)
-            s_zz[m] = rc.zz; s_fac[m] = rc.fac; s_lu[m] = rc.lu;
-        }
-        scol[e] = slot;
+        scol[e] = slot_n;
         if (!WIDE && e < T) sbeta[e] = A.betas[e];
-      }
-    } else if (tid < 2 * NE) {
+    }
+    if (tid >= NE && tid < 2 * NE) {
         // the cascade's log-uniforms (a Philox call and a log per element: ~1700 cycles of dependent ALU) on the two
         // waves that would otherwise idle until the barrier, not in the shadow of the slot chain above
         const int e = tid - NE, t = e >> CS, c = c0 + (e & (CB - 1));
         if (t < T - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, t, W, c));   // tempering.py:535 (row j = t: pair T-1-t)
-    } else if (WIDE && tid < 2 * NE + 64) {
+    }
+    if (WIDE && tid >= 2 * NE && tid < 2 * NE + 64) {
         if (lane < T) sbeta[lane] = A.betas[lane];
+    }
+    if ((wv == CWW || wv == FLW) && lane < NM) {
+        const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HB + (m & (HB - 1));   // split position (second half)
+        const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)t * (uint32_t)W + (uint32_t)q);
+        if (wv == CWW) {
+            const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
+            const uint4 ka = kp[0], kb = kp[1];
+            const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+            const int cw = (int)prp((uint32_t)place_column(0, stretch_index(sd.r22, W >> 1), CS - 1), key, A.idx_bits, (uint32_t)W);
+            s_rc[m] = A.loc[t * W + cw];
+        }
+        if (wv == FLW || CWW == FLW) {
+            const DrawRec dv = draw_values(0, 0, sd.uz, sd.ua, A.a, A.ndim_active);
+            s_zz[m] = dv.zz; s_fac[m] = dv.fac; s_lu[m] = dv.lu;
+        }
     }
     FUSED_TRACE(1);
     lds_barrier();
@@ -2150,36 +2199,36 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     lds_barrier();
     if (HENS_CUT_F == 3) return;
 
-    // ---- phase D: accept / update into the cascade's tables (wave 0, lane = moving walker) -----------------
-    if (wv == 0 && lane < NM) {
-        const bool inbox = (s_flag[lane] & 1) != 0;
+    // ---- phase D: accept / update into the cascade's tables (the moving walkers' slot threads) ---------------------
+    if (tid < NEr && !stays) {
+        const int e = tid, t = e >> CS, m = (t << (CS - 1)) + (e & (CB - 1)) - HB;
+        const bool inbox = (s_flag[m] & 1) != 0;
         double acc = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + lane];
+        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + m];
         double logl = inbox ? -0.5 * acc : A.fill;                      // ensemble.py:1486-1513
         if (logl != logl) {                                             // red_blue.py:279-281
             logl = -1e300;
             atomicOr(A.flags, FLAG_NAN_LOGL);
         }
         const double logp = inbox ? A.logp_in : -INFINITY;              // prior.py:80-88
-        const int e = ((lane >> (CS - 1)) << CS) + (CB >> 1) + (lane & ((CB >> 1) - 1));   // the m-th moving walker's element
-        const double beta = sbeta[e >> CS];
-        const double Lold = Lold_m, Pold = Pold_m;
+        const double beta = sbeta[t];
+        const double Lold = wr_n.L, Pold = wr_n.P;
         double lt = logl * beta;                                        // tempering.py:304-306,343-349
         if (lt != lt) lt = -INFINITY;
         const double logP = lt + logp;
         double lo_ = Lold * beta;
         if (lo_ != lo_) lo_ = -INFINITY;
         const double prevP = lo_ + Pold;
-        const double lnpdiff = s_fac[lane] + logP - prevP;              // red_blue.py:292
-        const bool keep = lnpdiff > s_lu[lane];                         // red_blue.py:294
+        const double lnpdiff = s_fac[m] + logP - prevP;                 // red_blue.py:292
+        const bool keep = lnpdiff > s_lu[m];                            // red_blue.py:294
         const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;      // move.py:513-532
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;
-        locc[e] = s_rs[lane];                                           // rows are updated in place (see StretchArgs::wrec)
+        locc[e] = wr_n.loc;                                             // rows are updated in place (see StretchArgs::wrec)
         if (keep) {
-            atomicAdd(&A.accepted[s_dst[lane]], 1u);
-            s_flag[lane] |= 2;
+            atomicAdd(&A.accepted[t * W + slot_n], 1u);
+            s_flag[m] |= 2;
         }
     }
     FUSED_TRACE(5);
