@@ -382,6 +382,7 @@ StretchArgs base_args(hens_ctx_impl* c) {
     return a;
 }
 
+bool is_acc_buffer(const hens_ctx_impl* c, const uint32_t* p);
 AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* out) {
     AdaptArgs a{};
     a.swap_part = const_cast<uint32_t*>(c->adapt_src ? c->adapt_src : c->swap_part);
@@ -392,6 +393,7 @@ AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* 
     a.T = c->T; a.W = c->W; a.nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     a.zero_after = 0;
     a.zero_rows = nullptr;
+    a.row_groups = (c->adapt_src && is_acc_buffer(c, c->adapt_src)) ? std::max(1, (int)(a.nblocks / 8)) : 1;
     a.moving = (adaptive && (c->cfg.stop_adaptation < 0 || c->adapt_time < c->cfg.stop_adaptation)) ? 1 : 0;
     return a;
 }
@@ -417,7 +419,7 @@ uint32_t* acc_take(hens_ctx_impl* c) {
     int a = acc_pick(c, 0);                  // (at most one pending and one uncleared: one of three is always clean)
     if (a < 0) {                             // cannot happen by the rotation's invariant; never hand a wild pointer to a kernel
         (void)hipStreamSynchronize(c->stream);
-        (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS * c->T * 4, c->stream);
+        (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS_MAX * c->T * 4, c->stream);
         c->acc_state[0] = c->acc_state[1] = c->acc_state[2] = 0;
         c->adapt_src = nullptr;
         a = 0;
@@ -435,7 +437,7 @@ void flush_adapt(hens_ctx_impl* c) {
     AdaptArgs a = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur]);
     hipLaunchKernelGGL(k_adapt, dim3(1), dim3(256), (size_t)c->T * 28 + 16, c->stream, a);
     if (is_acc_buffer(c, c->adapt_src)) {            // nothing else is running: all three accumulation buffers start clean again
-        (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS * c->T * 4, c->stream);
+        (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS_MAX * c->T * 4, c->stream);
         c->acc_state[0] = c->acc_state[1] = c->acc_state[2] = 0;
     }
     if (c->adapt_pending_adaptive) c->adapt_time += 1;               // tempering.py:596
@@ -883,14 +885,14 @@ void state_to_records(hens_ctx_impl* c) {
     if (c->packed) return;
     const int64_t n = (int64_t)c->T * c->W;
     hipLaunchKernelGGL(k_pack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
-                       c->wrec[c->cur], n);
+                       c->accepted, c->wrec[c->cur], n);
     c->packed = true;
 }
 void state_to_fields(hens_ctx_impl* c) {
     if (!c->packed) return;
     const int64_t n = (int64_t)c->T * c->W;
     hipLaunchKernelGGL(k_unpack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], c->L[c->cur], c->P[c->cur],
-                       c->loc[c->cur], n);
+                       c->loc[c->cur], c->accepted, n);
     c->packed = false;
     if (c->rows_mixed) {          // k_iter left accepted rows in the half the copying launches write next: fold them back
         hipLaunchKernelGGL(k_fold_rows, dim3(grid_for(n * (c->D / 2))), dim3(256), 0, c->stream, c->pool, c->loc[c->cur], n, c->D,
@@ -931,6 +933,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.a = c->cfg.a; f.ndim_active = dim_active(c);
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
+    f.acc_rows = 8 * acc_row_groups(c->T);
     acc_commit(c);
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
     f.period = c->period;
@@ -965,8 +968,8 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     c->cur ^= 1;
     c->adapt_pending = true;
     c->adapt_pending_adaptive = c->cfg.adaptive != 0;
-    c->adapt_src = f.swap_acc;                     // SWAP_ACC_ROWS rows (see hens_ctx_impl::swap_acc)
-    c->adapt_nblocks = SWAP_ACC_ROWS;
+    c->adapt_src = f.swap_acc;                     // acc_rows rows (see hens_ctx_impl::swap_acc)
+    c->adapt_nblocks = f.acc_rows;
     return HENS_OK;
 }
 
@@ -1043,6 +1046,7 @@ int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>*
     f.accepted = c->accepted;
     f.betas = c->betas[c->bcur];
     f.swap_acc = acc_take(c);
+    f.acc_rows = 8 * acc_row_groups(c->T);
     if (c->adapt_pending) {
         f.ad_on = 1;
         f.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur ^ 1]);
@@ -1083,7 +1087,7 @@ int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>*
     c->adapt_pending = true;
     c->adapt_pending_adaptive = c->cfg.adaptive != 0;
     c->adapt_src = f.swap_acc;
-    c->adapt_nblocks = SWAP_ACC_ROWS;
+    c->adapt_nblocks = f.acc_rows;
     return HENS_OK;
 }
 
@@ -1343,10 +1347,10 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && ncu > 0) c->num_cu = ncu;
     }
-    TRY(dalloc(c, &c->swap_acc[0], (size_t)3 * SWAP_ACC_ROWS * c->T));
-    c->swap_acc[1] = c->swap_acc[0] + (size_t)SWAP_ACC_ROWS * c->T;
-    c->swap_acc[2] = c->swap_acc[1] + (size_t)SWAP_ACC_ROWS * c->T;
-    TRYHIP(hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS * c->T * 4, c->stream));
+    TRY(dalloc(c, &c->swap_acc[0], (size_t)3 * SWAP_ACC_ROWS_MAX * c->T));
+    c->swap_acc[1] = c->swap_acc[0] + (size_t)SWAP_ACC_ROWS_MAX * c->T;
+    c->swap_acc[2] = c->swap_acc[1] + (size_t)SWAP_ACC_ROWS_MAX * c->T;
+    TRYHIP(hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS_MAX * c->T * 4, c->stream));
     {
         const size_t per_iter = TW * 64;
         size_t nb = (96u << 20) / std::max<size_t>(per_iter, 1);

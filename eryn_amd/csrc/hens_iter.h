@@ -41,7 +41,7 @@ struct IterArgs {
     const DrawRec* rec3;                                      // [W / cb][64] first half-step draws of rec2[i].cw
     const uint32_t* keys;                                     // [T][8]
     uint32_t* accepted;                                       // [T][W]
-    uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1] this cascade's counts (clean on entry)
+    uint32_t* swap_acc;                                       // [acc_rows][T-1] this cascade's counts (clean on entry)
     const double* betas;                                      // [T] (ad_on == 0)
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
     const double* period;                                     // [D] periodic parameters (StretchArgs::period), PER instantiations
@@ -50,6 +50,7 @@ struct IterArgs {
     double logp_in, fill, rosen_a, rosen_b;
     uint64_t iter, seed;
     int32_t T, W, idx_bits, cb, cb_shift;
+    int32_t acc_rows;                                         // rows of swap_acc (FusedArgs::acc_rows)
     int32_t half_rows;                                        // T * W: rows r and r ^ half belong to the same walker
     int32_t ad_on;                                            // the previous cascade's ladder adaptation rides in this launch
     AdaptArgs ad;                                             //   (every workgroup recomputes it from the accumulated counts)
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     int32_t* s_rs = scol + NE;                                           // [3][TILE] own row: A, X, B
     int32_t* s_rc = s_rs + 3 * TILE;                                     // [2][TILE] complement row: A, X
     int32_t* s_flag = s_rc + 2 * TILE;                                   // [3][TILE] bit0 inbox, bit1 keep
-    int32_t* s_el = s_flag + 3 * TILE;                                   // [2][TILE] element of the m-th walker: A, B
+    int32_t* s_el = s_flag + 3 * TILE;                                   // [NE] accept counter of the slot of element e
     uint32_t* smask = reinterpret_cast<uint32_t*>(s_el + 2 * TILE);      // [cb][MW]
 
     const int tid = threadIdx.x;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     //   waves 6, 7      : column map of the 128 slots (where phase G writes, which element a walker is)
     double Lold = 0.0, Pold = 0.0, fac = 0.0, lu = 0.0;                  // waves 0-2, lane m
     int32_t gi_m = 0;
+    uint32_t acc_m = 0;                                                  // the slot's accept counter (WalkerRec::acc)
     const int tm = lane >> (CS - 1);                                     // rung of the m-th walker of a half
     LadderFold fold;
     if (wv < 3) s_flag[wv * TILE + lane] = 0;
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         const DrawRec rc = src[(size_t)blockIdx.x * TILE + lane];
         gi_m = tm * W + rc.own;
         const int32_t rs = A.wrec[gi_m].loc;
+        acc_m = A.wrec[gi_m].acc;
         int32_t rcw = 0;
         if (wv < 2) rcw = A.loc[tm * W + rc.cw];
         const double2 lp = *reinterpret_cast<const double2*>(&A.wrec[gi_m].L);
@@ -203,10 +206,11 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     } else if (wv == 5) {
         if (A.ad_on) {
             const int NR = A.ad.nblocks;
+            const int G = A.ad.row_groups, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;   // (see k_stretch_fast)
             unsigned u0[8], u1[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                u0[r] = (r < NR && lane < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane] : 0u;
+                u0[r] = (r * G + g < NR && p < T - 1) ? A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] : 0u;
                 u1[r] = (r < NR && lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
             }
             double b0 = 1.0, b1 = 1.0;
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
             unsigned s0 = 0, s1 = 0;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { s0 += u0[r]; s1 += u1[r]; }
+            for (int m = P2; m < 64; m <<= 1) s0 += __shfl_xor(s0, m);
             if (lead && A.ad.zero_rows)              // the buffer nobody reads or writes during this launch
                 for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
             fold.part1(A.ad, lane, (double)s0, (double)s1, b0, b1);
@@ -350,10 +355,8 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;
         locc[e] = keep ? alt_row(rs) : rs;
-        if (keep) {
-            atomicAdd(&A.accepted[gi_m], 1u);
-            s_flag[lane] |= 2;
-        }
+        s_el[e] = (int32_t)(acc_m + (keep ? 1u : 0u));                  // (every slot moves once per iteration)
+        if (keep) s_flag[lane] |= 2;
     } else if (wv == 1 && lane < NM) {                                   // replay: only the decision is needed
         double logl, newP;
         if (accept(s_part + NW * TILE, s_flag[TILE + lane], logl, newP)) s_flag[TILE + lane] |= 2;
@@ -386,10 +389,8 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;
         locc[e] = keep ? alt_row(rs) : rs;
-        if (keep) {
-            atomicAdd(&A.accepted[gi_m], 1u);
-            s_flag[2 * TILE + lane] |= 2;
-        }
+        s_el[e] = (int32_t)(acc_m + (keep ? 1u : 0u));
+        if (keep) s_flag[2 * TILE + lane] |= 2;
     }
     lds_barrier();
     ITER_TRACE(6);
@@ -465,13 +466,13 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         }
         const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
-        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se]);
+        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]);
         A.locnew[di] = locc[se];
     }
     for (int i = 1 + tid; i < T; i += NT) {
         unsigned n = 0;
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
-        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (SWAP_ACC_ROWS - 1)) * (T - 1) + (i - 1)], n);
+        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n);
     }
     if (walking) store_accepted();
     ITER_TRACE(7);

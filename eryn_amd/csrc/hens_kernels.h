@@ -31,6 +31,13 @@ constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-2
 
 constexpr unsigned FLAG_PIPE_TIMEOUT = 4u; // ladder pipeline: a neighbour's flag did not arrive in time
 
+// A/B knobs of dev builds (tools/devbuild.sh -D...)
+#ifndef HENS_GSTORE
+#define HENS_GSTORE 0
+#endif
+#ifndef HENS_NOACC
+#define HENS_NOACC 0
+#endif
 enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2, LIKE_HOST = 3 };
 // what a stretch-kernel launch does: a red/blue stretch half-step, the evaluation of the resident state, or a
 // full-ensemble Metropolis-Hastings proposal q = x + step (mh.py:56-193; the step rows are read where the
@@ -375,11 +382,16 @@ struct __attribute__((aligned(16))) DrawRec {
 // {log-likelihood, log-prior, pool row} of one walker as ONE 32-byte record (the two-launch iteration of hens_step).
 // k_split1_pt finds its 128 walkers through a random column map: in the by-field arrays every field of every walker
 // costs a cache line of its own, and the phase that gathers them is bound by the number of lines, not by bytes.
+// `acc` is the accept counter of the SLOT the record sits in (move.py:404-421: accepted[t, w]); it does not travel with the
+// walker through the cascade.  In record mode the stepping kernels add to it in the record they hold anyway - one
+// atomicAdd per accepted proposal on a counter array of its own cost 0.7 us per iteration at config 2 (round 3).
 struct __attribute__((aligned(32))) WalkerRec {
     double L, P;
-    int32_t loc, pad0, pad1, pad2;
+    int32_t loc;
+    uint32_t acc;
+    int32_t pad1, pad2;
 };
-__device__ __forceinline__ WalkerRec make_wrec(double L, double P, int32_t loc) { return WalkerRec{L, P, loc, 0, 0, 0}; }
+__device__ __forceinline__ WalkerRec make_wrec(double L, double P, int32_t loc, uint32_t acc) { return WalkerRec{L, P, loc, acc, 0, 0}; }
 
 __device__ __forceinline__ DrawRec draw_values(int own, int cw, double uz, double ua, double a, int D) {
     double zz = (a - 1.0) * uz + 1.0;              // stretch.py:129-132 (mul, add, square, divide)
@@ -420,6 +432,9 @@ struct AdaptArgs {
     double lag, nu;
     int64_t time;               // adaptation steps taken so far (tempering.py:596)
     int32_t T, W, nblocks, moving;   // moving: adaptive and not past stop_adaptation (tempering.py:591)
+    int32_t row_groups;              // rows a wave sums straight out of memory: 8 per group of 64 / row_groups lanes, the groups
+                                     // added with lane exchanges (1: one lane per pair; k_split1_pt accumulates into 8 *
+                                     // row_groups rows, see acc_row_groups)
     // ladder pipeline (k_adapt only): the counts come from every rank - wait for their flags first
     const unsigned* wait_flags;      // my mailbox's PF_CNT0.. words, or nullptr
     unsigned* wait_err;
@@ -541,20 +556,6 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
                 lu = A.dr.lu[(size_t)tl * W + own];
                 Lold = A.L[tl * W + own];
                 Pold = A.P[tl * W + own];
-            } else if (A.ikeys) {
-                // in registers: the Philox call first (it needs no key: the scalar load of the rung's round keys is in
-                // flight), then the walker at this place -> its record, then the logarithms while that load is in flight
-                const uint32_t* kp = A.ikeys + (size_t)(A.rung_begin + tl) * 8;
-                const uint32_t key[8] = {kp[0], kp[1], kp[2], kp[3], kp[4], kp[5], kp[6], kp[7]};
-                const int q = s_off + k;
-                const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)q);
-                own = (int)prp((uint32_t)place_column(A.split, k, A.hb_shift), key, A.idx_bits, (uint32_t)W);
-                const WalkerRec* o = A.wrec + (tl * W + own);
-                const double2 lp = *reinterpret_cast<const double2*>(&o->L);
-                rs = o->loc;
-                const DrawRec dv = draw_values(own, 0, sd.uz, sd.ua, A.ia, A.ndim_active);
-                zz = dv.zz; factors = dv.fac; lu = dv.lu;
-                Lold = lp.x; Pold = lp.y;
             } else {
                 const size_t di = (size_t)tl * W + s_off + k;
                 own = A.dr.own[di];
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
             if (keep) {                                        // move.py:513-532
                 A.L[gi] = logl;
                 A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
-                atomicAdd(&A.accepted[gi], 1u);
+                if (!HENS_NOACC) atomicAdd(&A.accepted[gi], 1u);
                 atomicOr(&s_flag[lane], 2);
             }
             A.loc[gi] = s_dst[lane];
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 
     // The counts are already reduced (one row: a pipeline rank's mailbox): wave 1 of the adapting workgroup
     // adapts right away, while wave 0 fetches the draws, so the new ladder is in the ring long before anyone asks.
-    const bool ad_early = ad_here && A.ad.nblocks <= 8;
+    const bool ad_early = ad_here && A.ad.nblocks <= 8 * A.ad.row_groups;
     // the same workgroup pushes the last sweep's swap counts to every rank (uses the count-reduction machinery below,
     // which a pipeline rank's adaptation - counts already reduced - leaves idle)
     const bool cnt_push = PIPE && !EVAL && NW >= 2 && A.cnt_push && blockIdx.x == 0 && blockIdx.y == 0;
@@ -1123,11 +1124,14 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         unsigned s0 = 0, s1 = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) { s0 += ad_u0[r]; s1 += ad_u1[r]; }
+        const int G = A.ad.row_groups, P2 = 64 / G;
+        for (int m = P2; m < 64; m <<= 1) s0 += __shfl_xor(s0, m);       // (the lane groups' partial sums)
         if (blockIdx.x == 0 && blockIdx.y == 0) {
             if (A.ad.zero_after) {                   // sole reader (mode 2 / a pipeline rank): clear what was read
+                const int p = lane & (P2 - 1), g = lane / P2;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    if (r < NR && lane < T - 1 && ad_u0[r]) A.ad.swap_part[(size_t)r * (T - 1) + lane] = 0u;
+                    if (r * G + g < NR && p < T - 1 && ad_u0[r]) A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] = 0u;
                     if (r < NR && lane + 64 < T - 1 && ad_u1[r]) A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] = 0u;
                 }
             }
@@ -1138,9 +1142,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     };
     if (ad_early && wv == ADW) {
         const int T = A.ad.T, NR = A.ad.nblocks;
+        // (row_groups G > 1 - ladders of at most 64 / G pairs: lane = (group g, pair p), group g sums rows g, g + G, ...)
+        const int G = A.ad.row_groups, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            ad_u0[r] = (r < NR && lane < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane] : 0u;
+            ad_u0[r] = (r * G + g < NR && p < T - 1) ? A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] : 0u;
             ad_u1[r] = (r < NR && lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
         }
         if (lane < T) ad_bi0 = A.ad.betas_in[lane];
@@ -1156,6 +1162,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase A (wave 0): indices and draws -------------------------------------------------------
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
     int own = 0;
+    uint32_t acc_old = 0;                    // record mode, stretch move: the slot's accept counter rides in its record
     bool valid = false;
     if (wv == 0) {
         const int k = k0 + lane;
@@ -1191,7 +1198,14 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 own = (int)prp((uint32_t)place_column(A.split, k, A.hb_shift), key, A.idx_bits, (uint32_t)W);
                 const WalkerRec* o = A.wrec + (tl * W + own);
                 const double2 lp = *reinterpret_cast<const double2*>(&o->L);
+                // ({row, accept counter} as ONE 8-byte load: a third scattered load instruction on this wave cost the
+                //  iteration 0.7 us - the phase is bound by the number of memory instructions, not by bytes)
+#ifdef HENS_X_NOLOAD
                 rs = o->loc;
+#else
+                const int2 la = *reinterpret_cast<const int2*>(&o->loc);
+                rs = la.x; acc_old = (uint32_t)la.y;
+#endif
                 const DrawRec dv = draw_values(own, 0, sd.uz, sd.ua, A.ia, A.ndim_active);
                 zz = dv.zz; factors = dv.fac; lu = dv.lu;
                 Lold = lp.x; Pold = lp.y;
@@ -1209,7 +1223,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 rc = (A.split == 1 && !A.inplace) ? A.home_off + tl * W + cw : A.loc[tl * W + cw];
                 if (A.wrec) {
                     const WalkerRec* o = A.wrec + (tl * W + own);
-                    Lold = o->L; Pold = o->P;
+                    Lold = o->L; Pold = o->P; acc_old = o->acc;
                 } else {
                     Lold = A.L[tl * W + own];
                     Pold = A.P[tl * W + own];
@@ -1440,11 +1454,14 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (keep) {                                        // move.py:513-532
                 if (A.wrec) {
                     *reinterpret_cast<double2*>(&A.wrec[gi].L) = double2{logl, newP};
+#ifndef HENS_X_NOSTORE
+                    if (!MH) A.wrec[gi].acc = acc_old + 1u;
+#endif
                 } else {
                     A.L[gi] = logl;
                     A.P[gi] = newP;
                 }
-                atomicAdd(&A.accepted[gi], 1u);
+                if (MH || !A.wrec) atomicAdd(&A.accepted[gi], 1u);   // (the MH move counts in an array of its own)
                 atomicOr(&s_flag[lane], 2);
             }
             if (PIPE && A.pub_lp && tl == A.Tl - 1) {                  // ladder pipeline: what the hot neighbour's bottom pair needs
@@ -1495,15 +1512,15 @@ __global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __
 }
 
 __global__ void k_pack_state(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
-                             WalkerRec* __restrict__ w, int64_t n) {
+                             const uint32_t* __restrict__ accepted, WalkerRec* __restrict__ w, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        w[i] = make_wrec(L[i], P[i], loc[i]);
+        w[i] = make_wrec(L[i], P[i], loc[i], accepted[i]);
 }
 __global__ void k_unpack_state(const WalkerRec* __restrict__ w, double* __restrict__ L, double* __restrict__ P,
-                               int32_t* __restrict__ loc, int64_t n) {
+                               int32_t* __restrict__ loc, uint32_t* __restrict__ accepted, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const WalkerRec r = w[i];
-        L[i] = r.L; P[i] = r.P; loc[i] = r.loc;
+        L[i] = r.L; P[i] = r.P; loc[i] = r.loc; accepted[i] = r.acc;
     }
 }
 
@@ -1958,7 +1975,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         if (tl < 0 || tl >= A.Tl) continue;
         const size_t di = (size_t)tl * W + dslot;
         if (A.wrecnew) {
-            A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se]);
+            A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], A.wrec[di].acc);   // (the slot keeps its accept counter)
             A.locnew[di] = locc[se];
             continue;
         }
@@ -1994,7 +2011,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
 //   G  thread per slot : permuted L / P / loc into the next buffers; swap counts by atomics into
 //                        SWAP_ACC_ROWS rows (the adapting workgroup of the next launch reduces and clears them)
 // ---------------------------------------------------------------------------------------------
-constexpr int SWAP_ACC_ROWS = 8;       // <= 8: the adapting workgroup sums them straight out of memory (ad_early)
+// Rows the cascade launches accumulate their swap counts into with atomics (workgroup b: row b % rows); the adapting wave
+// of the next launch sums them straight out of memory, 8 loads per lane.  Round 3: 8 rows for every ladder meant 64
+// workgroups x (T - 1) atomics on ONE cache line at config 2 - 0.7 us per iteration, 0.5 of it contention; a ladder of
+// at most 64 / G pairs now spreads over 8 G rows, G lane groups summing 8 rows each (acc_row_groups).
+constexpr int SWAP_ACC_ROWS_MAX = 64;
+__host__ __device__ inline int acc_row_groups(int T) {
+    int p2 = 1;
+    while (p2 < T - 1) p2 <<= 1;
+    const int g = p2 >= 64 ? 1 : 64 / p2;
+    return g > SWAP_ACC_ROWS_MAX / 8 ? SWAP_ACC_ROWS_MAX / 8 : g;
+}
 
 struct FusedArgs {
     double* pool;
@@ -2005,7 +2032,7 @@ struct FusedArgs {
     const double* betas;                                      // [T]
     const uint32_t* keys;                                     // [T][8] round keys of the rungs' column maps (k_plan_keys)
     uint32_t* accepted;                                       // [T][W]
-    uint32_t* swap_acc;                                       // [SWAP_ACC_ROWS][T-1]
+    uint32_t* swap_acc;                                       // [acc_rows][T-1]
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
     const double* period;                                     // [D] periodic parameters (see StretchArgs::period), or nullptr
     unsigned* flags;
@@ -2014,6 +2041,7 @@ struct FusedArgs {
     double a;                                                 // stretch scale (stretch.py:129-132)
     uint64_t iter, seed;
     int32_t T, W, idx_bits, cb, cb_shift, ndim_active;
+    int32_t acc_rows;                                         // rows of swap_acc (a power of two): workgroup b adds to row b % acc_rows
 };
 
 __host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
@@ -2227,7 +2255,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         Pc[e] = keep ? newP : Pold;
         locc[e] = wr_n.loc;                                             // rows are updated in place (see StretchArgs::wrec)
         if (keep) {
-            atomicAdd(&A.accepted[t * W + slot_n], 1u);
+#ifndef HENS_X_NOK2ACC
+            wr_n.acc += 1u;                                             // (phase G writes the slot's record back)
+#endif
             s_flag[m] |= 2;
         }
     }
@@ -2310,13 +2340,40 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         }
         const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
-        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se]);
+#if HENS_GSTORE == 1
+        {   // record + compact row index written through (sc1): nothing of this launch's output waits dirty in L2 for the
+            // write-back at the kernel boundary
+            typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
+            const WalkerRec w = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);
+            const uv4* src = reinterpret_cast<const uv4*>(&w);
+            WalkerRec* dst = A.wrecnew + di;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(dst), "v"(src[0]), "v"(src[1]) : "memory");
+            asm volatile("global_store_dword %0, %1, off sc1" ::"v"(A.locnew + di), "v"(locc[se]) : "memory");
+        }
+#elif HENS_GSTORE == 2
+        {
+            const WalkerRec w = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);
+            typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
+            const uv4* src = reinterpret_cast<const uv4*>(&w);
+            __builtin_nontemporal_store(src[0], reinterpret_cast<uv4*>(A.wrecnew + di));
+            __builtin_nontemporal_store(src[1], reinterpret_cast<uv4*>(A.wrecnew + di) + 1);
+            __builtin_nontemporal_store(locc[se], A.locnew + di);
+        }
+#else
+#ifdef HENS_X_NOK2ACC
+        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], 0u);
+#else
+        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);  // (the slot's own counter: it does not move with a walker)
+#endif
         A.locnew[di] = locc[se];
+#endif
     }
     for (int i = 1 + tid; i < T; i += NT) {                              // pair (i, i-1) -> index i-1
         unsigned n = 0;
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
-        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (SWAP_ACC_ROWS - 1)) * (T - 1) + (i - 1)], n);
+#if !defined(HENS_X_NOSWAP)
+        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n);
+#endif
     }
     // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
     if (walking) store_accepted();

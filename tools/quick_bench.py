@@ -31,11 +31,13 @@ if __name__ == "__main__":
     ap.add_argument("--prof", type=int, default=0)
     ap.add_argument("--stats", type=int, default=0)
     ap.add_argument("--like", default="dense")
+    ap.add_argument("--adaptive", type=int, default=1)
     a = ap.parse_args()
     T, W, D = a.T, a.W, a.D
     mu, invcov, cov = problem(D)
     like = RosenbrockLikelihood(D) if a.like == 'rosen' else GaussianLikelihood(mu, invcov if a.like == 'dense' else np.diag(invcov).copy())
-    eng = HipEnsemble(T, W, D, like, -50.0 if a.like != 'rosen' else -5.0, 50.0 if a.like != 'rosen' else 5.0, seed=2024)
+    eng = HipEnsemble(T, W, D, like, -50.0 if a.like != 'rosen' else -5.0, 50.0 if a.like != 'rosen' else 5.0, seed=2024,
+                      adaptive=bool(a.adaptive))
     x0 = np.random.RandomState(1).randn(T, W, D)
     eng.upload(x0, betas=ladder(D, T))
     eng.eval_state()
