@@ -152,19 +152,20 @@ def timed_blocks(step, sync, steps, dist=None, device=None):
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         try:
             if ok:
                 step(steps)
-                sync()
+                if dist is not None:
+                    sync()                   # (a pipeline rank's flag-wait errors surface in the engine's own synchronize)
         except RuntimeError as exc:
             print(f"[bench] stepping failed: {exc}", file=sys.stderr, flush=True)
             ok = 0
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()             # (device-wide: covers the engine's stream)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt, float(ok)], dtype=torch.float64, device=device)

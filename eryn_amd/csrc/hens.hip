@@ -30,6 +30,7 @@ struct DrawBuf {                     // one batch of planned iterations
     DrawRec* rec3 = nullptr;         //   and the first half-step draws of every second-half walker's complement
     uint32_t* keys = nullptr;        // [NB][T][8] round keys of the cascade's column maps
 };
+constexpr int KEY_WINDOW = 1024;     // iterations of round keys planned at once for the two-launch iteration (hens_ctx_impl::ikeys)
 
 struct hens_ctx_impl {
     hens_config cfg{};
@@ -84,6 +85,11 @@ struct hens_ctx_impl {
     // speculative plan of the NEXT hens_step call (short calls pay ~25 us of plan latency up front otherwise): iterations
     // [spec_iter0, spec_iter0 + spec_nb) planned into db[spec_buf] on plan_stream while the current call steps
     bool spec_valid = false, spec_fused = false, spec_iter1 = false;
+    // the two-launch iteration computes its draws in registers and needs the rungs' round keys only: a window of
+    // KEY_WINDOW iterations, planned on the main stream when the chain leaves it (it survives hens_step calls)
+    uint32_t* ikeys = nullptr;             // [KEY_WINDOW][T][8]
+    uint64_t ikeys_iter0 = 0;
+    int64_t ikeys_n = 0;
     int spec_buf = 0, spec_nb = 0;
     uint64_t spec_iter0 = 0;
     uint64_t win_from = 0; int win_count = 0;   // iterations planned in db[0] for hens_stretch_iter / sharded PT
@@ -901,14 +907,30 @@ void state_to_fields(hens_ctx_impl* c) {
     }
 }
 
-int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
+// round keys of iteration c->iter (planning a new window if the chain has left the current one)
+const uint32_t* iteration_keys(hens_ctx_impl* c) {
+    if (c->iter < c->ikeys_iter0 || c->iter >= c->ikeys_iter0 + (uint64_t)c->ikeys_n) {
+        PlanArgs pa{};
+        pa.iter0 = c->iter; pa.seed = c->cfg.seed;
+        pa.Tl = c->Tl; pa.W = c->W; pa.rung_begin = c->cfg.rung_begin; pa.T = c->T; pa.cb = c->label_cb;
+        pa.keys = c->ikeys;
+        hipLaunchKernelGGL(k_plan_keys, dim3((KEY_WINDOW * c->Tl + 255) / 256), dim3(256), 0, c->stream, pa, KEY_WINDOW);
+        c->ikeys_iter0 = c->iter;
+        c->ikeys_n = KEY_WINDOW;
+        c->timing.n_plan += 1;
+    }
+    return c->ikeys + (size_t)(c->iter - c->ikeys_iter0) * c->T * 8;
+}
+
+int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     const int T = c->T, W = c->W;
     state_to_records(c);
+    const uint32_t* keys = iteration_keys(c);
     {
         StretchArgs a = base_args(c);
         a.wrec = c->wrec[c->cur];
         a.inplace = 1;
-        a.ikeys = c->db[which].keys + (size_t)ib * T * 8;             // draws in registers (stretch_draws_at)
+        a.ikeys = keys;                                                // draws in registers (stretch_draws_at)
         a.iseed = c->cfg.seed; a.iiter = c->iter; a.ia = c->cfg.a;
         a.idx_bits = c->idx_bits; a.hb_shift = c->label_cb_shift - 1; a.ndim_active = dim_active(c);
         a.split = 0;
@@ -929,7 +951,7 @@ int fused_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>
     f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
     f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
-    f.keys = c->db[which].keys + (size_t)ib * T * 8;
+    f.keys = keys;
     f.a = c->cfg.a; f.ndim_active = dim_active(c);
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
@@ -1343,6 +1365,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     }
     for (int b = 0; b < 2; ++b)
         if (c->label_cb) TRY(dalloc(c, &c->wrec[b], TW));
+    if (c->label_cb) TRY(dalloc(c, &c->ikeys, (size_t)KEY_WINDOW * c->T * 8));
     {
         int ncu = 0;
         if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device_id) == hipSuccess && ncu > 0) c->num_cu = ncu;
@@ -1453,6 +1476,7 @@ int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double
     for (int d = 0; d < c->D; ++d)
         if (!(lo[d] < hi[d])) return fail(c, HENS_ERR_INVALID, "prior box needs lo < hi in every dimension (dim %d)", d);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     HIPCHK(c, hipMemcpyAsync(c->lo, lo, c->D * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->hi, hi, c->D * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1474,6 +1498,7 @@ int hens_set_periodic(hens_ctx* ctx, const double* period) {
             any = any || period[d] > 0.0;
         }
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!any) {                       // back to the compile-time-width kernels
@@ -1497,6 +1522,7 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
         return fail(c, HENS_ERR_STATE, "context was not created with a Gaussian likelihood kind");
     const size_t n = c->cfg.likelihood_kind == HENS_LIKE_GAUSS_DENSE ? (size_t)c->D * c->D : (size_t)c->D;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     HIPCHK(c, hipMemcpyAsync(c->mu, mu, c->D * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->prec, prec, n * 8, hipMemcpyHostToDevice, c->stream));
     std::vector<double> sym;
@@ -1554,6 +1580,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     if (c->cfg.tempered && !betas) return fail(c, HENS_ERR_INVALID, "betas required for a tempered context");
     if ((logl == nullptr) != (logp == nullptr)) return fail(c, HENS_ERR_INVALID, "give both logl and logp or neither");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     c->cur = 0;
@@ -1581,6 +1608,7 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     if (!c->have_state) return fail(c, HENS_ERR_STATE, "no state uploaded");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight (call hens_pt_finish_sharded)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     if (x) {
@@ -1600,6 +1628,7 @@ int hens_eval_state(hens_ctx* ctx) {
     int r = ready(c, false);
     if (r) return r;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE) {
         r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
         if (r) return r;
@@ -1687,6 +1716,8 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     hens_ctx_impl* c = CTX(ctx);
     int r = ready(c, true);
     if (r) return r;
+    (void)hipSetDevice(c->cfg.device_id);
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
         return fail(c, HENS_ERR_STATE, "host-likelihood context: use hens_propose_split / hens_accept_split");
     if (!u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -1729,6 +1760,8 @@ int hens_propose_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     hens_ctx_impl* c = CTX(ctx);
     int r = ready(c, true);
     if (r) return r;
+    (void)hipSetDevice(c->cfg.device_id);
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     if (c->cfg.likelihood_kind != HENS_LIKE_HOST)
         return fail(c, HENS_ERR_STATE, "hens_propose_split needs a context created with HENS_LIKE_HOST");
     if (!q_out || !inbox_out) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -1759,6 +1792,7 @@ int hens_accept_split(hens_ctx* ctx, int32_t split, const double* logl, const do
         return fail(c, HENS_ERR_STATE, "hens_accept_split must follow hens_propose_split of the same split");
     if (!logl || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const int Ns = split == 0 ? c->N0 : c->W - c->N0;
     const size_t n = (size_t)c->Tl * Ns;
     const HostLikeArgs h = hostlike_args(c, split);
@@ -1785,6 +1819,7 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "PT sweep between split 0 and split 1");
     if (!iperm || !i1perm || !u_swap) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const int T = c->T, W = c->W;
     if (T < 2) return HENS_OK;
     flush_adapt(c);
@@ -1850,7 +1885,9 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     const bool prof = c->per_kernel_events;
     const bool fused = fused_ok(c);
     const bool iter1 = iter_ok(c);
-    state_to_fields(c);                       // (only after a call that failed half-way)
+    // (the state stays in record mode between hens_step calls of the record paths - every other entry point settles it,
+    //  settle_state - so a short call pays no pack / unpack)
+    if (!fused && !iter1) state_to_fields(c);
     std::vector<hipEvent_t> evs;
     std::vector<char> ev_kind;                // per event pair: 0 stretch launch, 1 cascade launch, 2 fused half-step + cascade
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -1868,7 +1905,8 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // stream costs two cross-stream event waits per batch whatever its size: 31 us per batch of 22 iterations at config 2
     // (1.4 us per iteration) with nothing but the keys kernel on it.  HENS_PLAN_INLINE=0/1 forces either form (A/B knob).
     static const int inline_env = getenv("HENS_PLAN_INLINE") ? atoi(getenv("HENS_PLAN_INLINE")) : -1;
-    const bool plan_inline = !piped && (inline_env >= 0 ? inline_env != 0 : (fused && !iter1));
+    const bool keys_only = fused && !iter1;        // draws in registers: iteration_keys plans the round keys, nothing else
+    const bool plan_inline = keys_only || (!piped && inline_env > 0);
     if (plan_inline && c->spec_valid) {          // (a speculative plan of an earlier call may still be writing a buffer)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0));
         c->spec_valid = false;
@@ -1901,7 +1939,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     }
     for (int64_t b = 0; b < nbatch; ++b) {
         const int which = plan_inline ? 0 : (int)((first_buf + b) & 1), nb = batch_size(b);
-        if (plan_inline) {
+        if (plan_inline && !keys_only) {
             launch_plan(c, c->stream, 0, c->iter, nb, fused, iter1);
             c->timing.n_plan += 1;
         }
@@ -1944,7 +1982,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 c->iter += 1;
                 continue;
             } else if (fused) {
-                r = fused_iteration(c, which, ib, prof ? &evs : nullptr);
+                r = fused_iteration(c, prof ? &evs : nullptr);
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
                 if (r) return r;
                 c->iter += 1;
@@ -1979,7 +2017,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             c->iter += 1;
         }
     }
-    state_to_fields(c);
+    if (piped) state_to_fields(c);
     // The last cascade's ladder adaptation stays pending on one GPU: the next hens_step call folds it into its first
     // launch (no kernel of its own, ~12 us per call with its count-buffer reset), and every entry point that reads the ladder,
     // the swap counters or the state settles it first (flush_adapt at their head) - same bits either way.
@@ -2005,6 +2043,7 @@ int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals, d
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     std::vector<uint32_t> acc;
@@ -2025,6 +2064,7 @@ int hens_reset_counters(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     HIPCHK(c, hipMemsetAsync(c->accepted, 0, (size_t)c->Tl * c->W * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
@@ -2040,6 +2080,7 @@ int hens_set_adapt_time(hens_ctx* ctx, int64_t t) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     c->adapt_time = t;
     return HENS_OK;
@@ -2191,6 +2232,7 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
     if (nbranches < 1 || nbranches > RJ_MAX_BRANCH) return fail(c, HENS_ERR_INVALID, "1..%d branches", RJ_MAX_BRANCH);
     if (ndata < 1 || !(sigma > 0.0)) return fail(c, HENS_ERR_INVALID, "invalid data");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     RjModel M{};
     M.nb = nbranches; M.ndata = ndata; M.sigma = sigma;
     int off = 0;
@@ -2241,6 +2283,7 @@ int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint
     if (r) return r;
     if (!step || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     if ((r = rj_ensure_staging(c))) return r;
     const size_t TW = (size_t)c->Tl * c->W;
@@ -2267,6 +2310,7 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
         if (change[i] != 0 && (leaf[i] < 0 || leaf[i] >= c->rj.nl[branch])) return fail(c, HENS_ERR_INVALID, "leaf slot out of range");
     }
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     if ((r = rj_ensure_staging(c))) return r;
     HIPCHK(c, hipMemcpyAsync(c->rj_change, change, TW, hipMemcpyHostToDevice, c->stream));
@@ -2287,6 +2331,7 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     if (n_iters < 0) return fail(c, HENS_ERR_INVALID, "n_iters < 0");
     if (!c->rj_have_scale) return fail(c, HENS_ERR_STATE, "in-model step scale not set (hens_rj_set_mh_scale)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->timing = hens_timing{};
     for (int64_t i = 0; i < n_iters; ++i) {
@@ -2312,6 +2357,7 @@ int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, in
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || !c->rj_acc_bd) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const size_t TW = (size_t)c->Tl * c->W;
     if (accepted_bd) {
         std::vector<uint32_t> acc(TW);
@@ -2329,6 +2375,7 @@ int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     int r = ensure_shard_buffers(c);
     if (r) return r;
     out->logl = c->L[c->cur];
@@ -2349,6 +2396,7 @@ int hens_stretch_iter(hens_ctx* ctx) {
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST) return fail(c, HENS_ERR_UNSUPPORTED, "hens_stretch_iter needs a device likelihood");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     spec_cancel(c);
     flush_adapt(c);
     c->N0 = (c->W + 1) / 2;
@@ -2386,6 +2434,7 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         if (mine != (rank_of_rung[t] == my_rank)) return fail(c, HENS_ERR_INVALID, "rank_of_rung disagrees with this context's shard");
     }
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     if ((r = ensure_shard_buffers(c))) return r;
     if ((r = ensure_pt_buffers(c))) return r;
@@ -2455,6 +2504,7 @@ int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
     if (!c->pt_pending) return fail(c, HENS_ERR_STATE, "no sharded PT exchange in flight");
     if (n_recv != c->n_recv) return fail(c, HENS_ERR_INVALID, "expected %lld received rows, got %lld", (long long)c->n_recv, (long long)n_recv);
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     if (n_recv > 0)
         hipLaunchKernelGGL(k_unpack_rows, dim3(grid_for(n_recv * (c->D + 2))), dim3(256), 0, c->stream, c->pool,
                            c->loc[c->cur ^ 1], c->P[c->cur ^ 1], c->recv_rows, n_recv, c->D, c->W,
@@ -2476,6 +2526,7 @@ int hens_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_mh_step between split 0 and split 1");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     if ((r = ensure_mh_buffers(c))) return r;
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
@@ -2501,6 +2552,7 @@ int hens_set_mh_proposal(hens_ctx* ctx, int32_t kind, const double* scale, doubl
     if (kind > MH_FULL || !scale) return fail(c, HENS_ERR_INVALID, "kind must be 0 (isotropic), 1 (diagonal) or 2 (full) with its scale");
     if (!(weight >= 0.0 && weight <= 1.0)) return fail(c, HENS_ERR_INVALID, "weight must be a probability");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     int r = ensure_mh_buffers(c);
     if (r) return r;
     const size_t n = kind == MH_ISO ? 1 : (kind == MH_DIAG ? (size_t)c->D : (size_t)c->D * c->D);
@@ -2517,6 +2569,7 @@ int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const size_t TW = (size_t)c->Tl * c->W;
     if (accepted) {
         if (!c->accepted_mh) {
@@ -2544,6 +2597,7 @@ int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_ou
     if ((my_rank == 0) != (c->cfg.rung_begin == 0) || (my_rank == nranks - 1) != (c->cfg.rung_end == c->T))
         return fail(c, HENS_ERR_INVALID, "ranks must hold contiguous rung ranges in rank order (rank 0 = coldest rungs)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const size_t bytes = pipe_box_bytes(c->T, c->W, c->D);
     void* box = nullptr;
     HIPCHK(c, hipExtMallocWithFlags(&box, bytes, hipDeviceMallocUncached));
@@ -2599,6 +2653,7 @@ int hens_pipe_connect(hens_ctx* ctx, const void* blobs) {
     if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
     if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const char* hb = static_cast<const char*>(blobs);
     for (int q = 0; q < c->pipe.nranks; ++q) {
         if (q == c->pipe.rank) continue;
@@ -2629,6 +2684,7 @@ int hens_pipe_connect_staged(hens_ctx* ctx) {
     if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
     if (c->cfg.adaptation_delay != 0) return fail(c, HENS_ERR_UNSUPPORTED, "the staged transport runs the reference's adaptation schedule");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     const size_t bytes = c->pipe.box_bytes;
     int r;
     if ((r = dalloc(c, &c->pipe.out_hot, bytes))) return r;
@@ -2686,6 +2742,7 @@ int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
     if (r) return r;
     if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (hens_step leaves the state in record mode)
     switch (stage) {
         case 0: {           // the iteration's move (stretch halves or the MH proposal); publishes (L, P) of the boundary rung
             spec_cancel(c);
