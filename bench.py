@@ -99,49 +99,80 @@ def cpu_baseline(T, W, D, seconds=12.0):
     return out
 
 
-def kernel_roofline(tm, T_local, T, W, D, f_sw):
-    """Per-kernel durations (HIP events on the engine's own stream, one pair per launch) -> achieved algorithmic GB/s.
+def moved_bytes(kind, tw, D, acc):
+    """Bytes a launch of THIS design moves: rows are updated in place (only accepted proposals are written), a
+    swap permutes a 32-byte walker record and a 4-byte row index, never a row."""
+    row = 8 * D
+    if kind == "stretch":        # tw/2 movers: own row + complement row + {L, P, row, counter} record + complement's row index
+        return tw / 2 * (2 * row + 24 + 4 + acc * (row + 20))
+    if kind == "fused":          # the same gathers + every slot's record read once, record + row index written once
+        return tw / 2 * (2 * row + 4 + acc * row) + tw * (32 + 36)
+    if kind == "iter":           # k_iter: both half-steps + the replayed first half-step of the complements (1.25 x the rows)
+        return tw * (2.5 * row + 8 + acc * row) + tw * (32 + 36)
+    return tw * (32 + 36)        # cascade-only launch
 
-    Algorithmic bytes per launch: a stretch half-step launch moves T_local*W/2 walkers at
-    B_stretch bytes each; the fused launch k_split1_pt does that AND the cascade over all T_local*W walkers
-    (B_pt bytes per walker-step in the reference's accounting); a cascade-only launch just the latter."""
+
+def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25):
+    """Per-kernel durations (HIP events on the engine's own stream, one pair per launch) -> fractions of the HBM peak.
+
+    Three byte counts per launch, each divided by the same measured duration (none may exceed the peak):
+      frac         bytes this design moves (moved_bytes: accepted rows only, 36 bytes per slot of the cascade)
+      frac_8d      SURVEY 8d's accounting, the reference's data movement: B_stretch per proposal (a written row counted
+                   unconditionally) and B_pt per walker-step (moved ROWS per swap) - kept for continuity with rounds 1-2;
+                   it credits the cascade with bytes this design never moves
+      frac_traffic HBM bytes from the rocprofv3 counters (profiles/traffic.json, static), where that shape was profiled"""
     tw = T_local * W
     ks = []
     if tm["n_stretch"]:
         us = tm["stretch_ms"] / tm["n_stretch"] * 1e3
         ks.append({"kernel": "k_stretch_fast (red/blue half-step)", "launches_per_iteration": tm["n_stretch"] / tm["n_iters"],
-                   "avg_launch_us": us, "algorithmic_bytes_per_launch": b_stretch(D) * tw / 2})
+                   "avg_launch_us": us, "bytes_8d": b_stretch(D) * tw / 2, "bytes_moved": moved_bytes("stretch", tw, D, acc)})
     if tm["n_fused"] and not tm["n_stretch"] and tm["n_fused"] == tm["n_iters"]:
         # shapes up to one workgroup per CU: the whole iteration is ONE launch (k_iter, DESIGN 4.3b)
         us = tm["fused_ms"] / tm["n_fused"] * 1e3
         ks.append({"kernel": "k_iter (both half-steps + PT cascade + swap counts in one launch)", "launches_per_iteration": 1.0,
-                   "avg_launch_us": us, "algorithmic_bytes_per_launch": (b_stretch(D) + b_pt(T, D, f_sw)) * tw,
-                   "stretch_bytes_only": b_stretch(D) * tw})
+                   "avg_launch_us": us, "bytes_8d": (b_stretch(D) + b_pt(T, D, f_sw)) * tw,
+                   "bytes_moved": moved_bytes("iter", tw, D, acc)})
     elif tm["n_fused"]:
         us = tm["fused_ms"] / tm["n_fused"] * 1e3
         ks.append({"kernel": "k_split1_pt (second half-step + PT cascade + swap counts)",
                    "launches_per_iteration": tm["n_fused"] / tm["n_iters"], "avg_launch_us": us,
-                   "algorithmic_bytes_per_launch": b_stretch(D) * tw / 2 + b_pt(T, D, f_sw) * tw,
-                   "stretch_bytes_only": b_stretch(D) * tw / 2})
+                   "bytes_8d": b_stretch(D) * tw / 2 + b_pt(T, D, f_sw) * tw, "bytes_moved": moved_bytes("fused", tw, D, acc)})
     if tm["n_pt"]:
         us = tm["pt_ms"] / tm["n_pt"] * 1e3
         ks.append({"kernel": "PT cascade launch(es)", "launches_per_iteration": tm["n_pt"] / tm["n_iters"],
-                   "avg_launch_us": us, "algorithmic_bytes_per_launch": b_pt(T, D, f_sw) * tw})
+                   "avg_launch_us": us, "bytes_8d": b_pt(T, D, f_sw) * tw, "bytes_moved": moved_bytes("pt", tw, D, acc)})
+    traffic = (static_json("traffic.json") or {}).get("shapes", {}).get(f"{T_local}x{W}x{D}", {})
     for k in ks:
-        k["achieved_GBps"] = k["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9
+        sec = k["avg_launch_us"] * 1e-6
+        k["achieved_GBps"] = k["bytes_moved"] / sec / 1e9
         k["frac"] = k["achieved_GBps"] / HBM_PEAK_GBS
+        k["frac_8d"] = k["bytes_8d"] / sec / 1e9 / HBM_PEAK_GBS
+        t = traffic.get(k["kernel"].split(" ")[0])
+        k["traffic"] = t
+        k["frac_traffic"] = None if t is None else t / sec / 1e9 / HBM_PEAK_GBS
+        if k["frac_8d"] > 1.0:               # (the reference's accounting moves ROWS per swap: more bytes than this design's
+            k["frac_8d"] = None              #  launch could move at the peak - not a fraction of anything; bytes_8d stays)
+        assert k["frac"] <= 1.0 and (k["frac_traffic"] is None or k["frac_traffic"] <= 1.0), k
     dom = max(ks, key=lambda k: k["avg_launch_us"] * k["launches_per_iteration"])
-    traffic = static_json("traffic.json") or {}
-    same_shape = list(traffic.get("shape", [])) == [T_local, W, D] and T_local == T       # the PMC passes ran config 2
-    roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["frac"], "traffic": traffic.get(dom["kernel"].split(" ")[0]) if same_shape else None,
-            "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this command, tools/profile_bench.sh; "
-                              "not measured in this run)" if same_shape else None,
-            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_us": dom["avg_launch_us"],
-            "kernels": ks}
-    if "stretch_bytes_only" in dom:
-        roof["frac_stretch_bytes_only"] = dom["stretch_bytes_only"] / (dom["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-    return roof
+    return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["frac"], "frac_8d": dom["frac_8d"], "frac_traffic": dom["frac_traffic"], "traffic": dom["traffic"],
+            "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this shape, tools/profile_bench.sh; "
+                              "not measured in this run)" if dom["traffic"] is not None else None,
+            "bytes": "achieved / frac: bytes this design moves per launch (accepted rows only; a swap permutes a 36-byte "
+                     "record, not a row); frac_8d: SURVEY 8d's reference accounting; frac_traffic: counter bytes",
+            "algorithmic_bytes_per_launch": dom["bytes_moved"], "avg_launch_us": dom["avg_launch_us"], "kernels": ks}
+
+
+def whole_path(roof, T, W, D, f_sw, acc, value):
+    """Whole iteration against the HBM peak: SURVEY 8d's B_alg = B_stretch + B_pt per walker-step (the figure north_star's
+    50 % target is stated in) and the bytes this design moves, both over the driver-timed iteration."""
+    w8 = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
+    per_iter = sum(k["bytes_moved"] * k["launches_per_iteration"] for k in roof["kernels"])
+    wm = per_iter / (T * W) * value / 1e9
+    roof.update(whole_path_GBps=w8, whole_path_frac=w8 / HBM_PEAK_GBS, whole_path_moved_GBps=wm,
+                whole_path_frac_moved=wm / HBM_PEAK_GBS)
+    assert roof["whole_path_frac"] <= 1.0 and roof["whole_path_frac_moved"] <= 1.0
 
 
 def timed_blocks(step, sync, steps, dist=None, device=None):
@@ -205,9 +236,8 @@ def run_single(args):
     eng.set_profiling(False)
     eng.close()
     value = T * W * args.steps / dt
-    whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
-    roof = kernel_roofline(tm, T, T, W, D, f_sw)
-    roof.update(whole_path_GBps=whole, whole_path_frac=whole / HBM_PEAK_GBS)
+    roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
+    whole_path(roof, T, W, D, f_sw, acc, value)
     out = {
         "metric": METRIC, "value": value, "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -250,9 +280,9 @@ def run_cfg5(args):
     tm = eng.timing()
     eng.close()
     value = T * W * args.steps / dt
-    roof = kernel_roofline(tm, T, T, W, D, f_sw)
-    whole = (b_stretch(D) + b_pt(T, D, f_sw)) * value / 1e9
-    roof.update(whole_path_GBps=whole, whole_path_frac=whole / HBM_PEAK_GBS)
+    acc5 = float(c["accepted"].mean() / max(c["num_proposals"], 1))
+    roof = kernel_roofline(tm, T, T, W, D, f_sw, acc5)
+    whole_path(roof, T, W, D, f_sw, acc5, value)
     return {
         "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Rosenbrock logL, move mix", "value": value,
         "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -267,6 +297,31 @@ def run_cfg5(args):
                    "swap_fraction": f_sw},
         "roofline": roof,
     }
+
+
+VALU_PEAK_LANE_INSTS = 256 * 4 * 16 * 2.4e9      # CUs x SIMDs x lanes per clock x peak engine clock = 39.3e12 lane-instructions/s
+                                                 # (the dense FP64 vector peak of MI355X_MICROARCH.md, 78.6 TFLOP/s, is this x 2 for FMA)
+
+
+def rj_roofline(value, evals, alg):
+    """k_rj is bound by FP64 transcendentals (one exp or sin per template point), not by HBM: its roofline is the chip's
+    VALU issue rate.  Lane-instructions per launch come from a rocprofv3 SQ counter pass of this command
+    (profiles/rj_valu.json, tools/profile_rj.sh: SQ_INSTS_VALU x 64); two k_rj launches per step (in-model move, birth /
+    death), their measured share of the step in the same profile."""
+    st = static_json("rj_valu.json")
+    out = {"bound": "valu", "kernel": "k_rj (one wavefront per walker)", "peak": VALU_PEAK_LANE_INSTS / 1e12, "unit": "T lane-instructions/s",
+           "traffic": None, "hbm_algorithmic_GBps": alg * value / 1e9,
+           "note": f"{evals:.3e} template-point evaluations/s (one exp or sin + ~8 flops each); HBM is idle on this path "
+                   f"({alg * value / 1e9 / HBM_PEAK_GBS:.3f} of its peak on the algorithmic bytes)"}
+    if st and st.get("valu_lane_insts_per_launch") and st.get("k_rj_avg_us"):
+        ach = st["valu_lane_insts_per_launch"] / (st["k_rj_avg_us"] * 1e-6)
+        out.update(achieved=ach / 1e12, frac=ach / VALU_PEAK_LANE_INSTS,
+                   source="profiles/rj_valu.json (static: rocprofv3 --pmc SQ_INSTS_VALU of this command; duration from the same profile's kernel trace)",
+                   valu_lane_insts_per_launch=st["valu_lane_insts_per_launch"], profiled_launch_us=st["k_rj_avg_us"])
+        assert out["frac"] <= 1.0
+    else:
+        out.update(achieved=None, frac=None)
+    return out
 
 
 def run_cfg4(args):
@@ -319,10 +374,7 @@ def run_cfg4(args):
                    "ntemps": T, "nwalkers": W, "mean_active_leaves_per_walker": leaves,
                    "accept_in_model": float(c["accepted_mh"].mean() / max(c["num_mh"], 1)),
                    "accept_birth_death": float(c["accepted_bd"].mean() / max(c["num_bd"], 1))},
-        "roofline": {"bound": "hbm", "kernel": "k_rj (one wavefront per walker)", "achieved": alg * value / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg * value / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "note": "this path is bound by FP64 transcendental throughput, not by HBM: "
-                             f"{evals:.3e} template-point evaluations/s (one exp or sin + ~8 flops each)"},
+        "roofline": rj_roofline(value, evals, alg),
     }
 
 
