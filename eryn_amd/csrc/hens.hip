@@ -141,6 +141,12 @@ struct hens_ctx_impl {
         uint32_t due_sweep = 0;            // sweep whose counts the current adapt_pending refers to
         uint32_t sweep = 0;
         long long budget = 0;              // wall-clock ticks a flag wait may take
+        // fused iteration of a pipeline rank (k_stretch_fast + k_split1_pt<PIPE>, rows in place): decided at the first
+        // hens_step call from properties every rank shares (pipe_fused_possible), fixed from then on
+        bool fused = false, fused_decided = false;
+        int cbl = 0, cbl_shift = 0;        // columns per workgroup of the fused launch: 128 / Tl
+        int32_t* ghome = nullptr;          // [2][2][W] home rows of the guests (StretchArgs::ghome)
+        uint32_t* swap_rows = nullptr;     // [W / cbl][Tl] swap counts per workgroup of the fused launch
     } pipe;
     // Metropolis-Hastings (GaussianMove) proposals
     double* mh_step = nullptr;             // [Tl][W][D]
@@ -249,11 +255,12 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     do {                                                                                           \
         const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
-            static bool attr_done = false;                                                         \
-            if (!attr_done) {                                                                      \
+            static uint64_t attr_done = 0;              /* (the attribute is per device) */        \
+            const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
+            if (!(attr_done & dev_bit)) {                                                          \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-                attr_done = true;                                                                  \
+                attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
         if (c->ext_start)                                                                          \
@@ -555,12 +562,15 @@ bool pipe_publish_fused(const hens_ctx_impl* c) {
 
 // adaptation_delay = 1 leaves a whole iteration before a sweep's counts are needed: the adapting workgroup of the
 // next iteration's first launch reduces and publishes them, and the walk kernel needs no collector at all
+// workgroups of the launch that walks the cascade on a pipeline rank (one row of swap counts each)
+int walk_blocks(const hens_ctx_impl* c) { return c->pipe.fused ? c->W / c->pipe.cbl : pt_blocks(c); }
+uint32_t* walk_rows(const hens_ctx_impl* c) { return c->pipe.fused ? c->pipe.swap_rows : c->swap_part; }
 bool pipe_counts_in_stretch(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_PIPE_COUNT_TAIL") != nullptr;       // A/B knob
     if (off || !pipe_active(c) || c->pipe.staged || c->cfg.adaptation_delay != 1 || !fast_path(c)) return false;
     if (fold_mode(c) != 2 || fast_nw(c->D) < 2) return false;
     const int np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
-    return np >= 1 && (int64_t)pt_blocks(c) * np <= (int64_t)8 * fast_nw(c->D) * 64;
+    return np >= 1 && (int64_t)walk_blocks(c) * np <= (int64_t)8 * fast_nw(c->D) * 64;
 }
 
 // one-sided transport: the bottom boundary is the walk kernel's last phase (one launch less on every rank that has a
@@ -745,10 +755,10 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
     }
     if (pipe_counts_in_stretch(c) && c->pipe.sweep > 0) {      // the counts of the sweep that just ended
         a.cnt_push = 1;
-        a.cp_rows = c->swap_part;
+        a.cp_rows = walk_rows(c);
         a.cp_boxes = c->pipe.d_boxes;
         a.cp_sweep = c->pipe.sweep - 1;
-        a.cp_nblocks = pt_blocks(c);
+        a.cp_nblocks = walk_blocks(c);
         a.cp_np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
         a.cp_nranks = c->pipe.nranks;
         a.cp_rank = c->pipe.rank;
@@ -837,34 +847,37 @@ bool fused_ok(const hens_ctx_impl* c) {
 }
 
 template <int LIKE>
-int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1) {
-    const dim3 grid(c->W / c->label_cb);
-#define LAUNCH_FUSED_P(DT, NW, PER, SHORT)                                                         \
+int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1, bool pipe = false) {
+    const dim3 grid(pipe ? c->W / c->pipe.cbl : c->W / c->label_cb);
+    // (the MaxDynamicSharedMemorySize attribute is per device: contexts on several GPUs of one process each set it)
+#define LAUNCH_FUSED_P(DT, NW, PER, SHORT, PIPE)                                                   \
     do {                                                                                           \
-        const size_t lds = fused_lds_bytes(DT, NW);                                                \
+        const size_t lds = fused_lds_bytes(DT, NW, PIPE);                                          \
         if (lds > 60000) {                                                                         \
-            static bool attr_done = false;                                                         \
-            if (!attr_done) {                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT>), \
+            static uint64_t attr_done = 0;                                                         \
+            const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
+            if (!(attr_done & dev_bit)) {                                                          \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-                attr_done = true;                                                                  \
+                attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
         if (e0)                                                                                    \
-            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
-            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT>), grid, dim3(NW * 64), lds, c->stream, f); \
+            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE>), grid, dim3(NW * 64), lds, c->stream, f); \
     } while (0)
 #ifdef HENS_DEV_BUILD
-#define LAUNCH_FUSED(DT, NW) LAUNCH_FUSED_P(DT, NW, false, false)
+#define LAUNCH_FUSED(DT, NW) do { if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true); else LAUNCH_FUSED_P(DT, NW, false, false, false); } while (0)
 #else
 #define LAUNCH_FUSED(DT, NW)                                                                       \
     do {                                                                                           \
         const bool short_tiles = c->T * c->label_cb != 2 * TILE;                                   \
-        if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true);                           \
-        else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false);                                    \
-        else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true);                                 \
-        else LAUNCH_FUSED_P(DT, NW, false, false);                                                 \
+        if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true);                                      \
+        else if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true, false);               \
+        else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false, false);                             \
+        else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true, false);                          \
+        else LAUNCH_FUSED_P(DT, NW, false, false, false);                                          \
     } while (0)
 #endif
     switch (c->D) {
@@ -889,14 +902,14 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
 // the state as one record per walker (k_split1_pt, k_stretch_fast with StretchArgs::wrec) <-> by-field arrays (everything else)
 void state_to_records(hens_ctx_impl* c) {
     if (c->packed) return;
-    const int64_t n = (int64_t)c->T * c->W;
+    const int64_t n = (int64_t)c->Tl * c->W;
     hipLaunchKernelGGL(k_pack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
                        c->accepted, c->wrec[c->cur], n);
     c->packed = true;
 }
 void state_to_fields(hens_ctx_impl* c) {
     if (!c->packed) return;
-    const int64_t n = (int64_t)c->T * c->W;
+    const int64_t n = (int64_t)c->Tl * c->W;
     hipLaunchKernelGGL(k_unpack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], c->L[c->cur], c->P[c->cur],
                        c->loc[c->cur], c->accepted, n);
     c->packed = false;
@@ -912,9 +925,11 @@ const uint32_t* iteration_keys(hens_ctx_impl* c) {
     if (c->iter < c->ikeys_iter0 || c->iter >= c->ikeys_iter0 + (uint64_t)c->ikeys_n) {
         PlanArgs pa{};
         pa.iter0 = c->iter; pa.seed = c->cfg.seed;
-        pa.Tl = c->Tl; pa.W = c->W; pa.rung_begin = c->cfg.rung_begin; pa.T = c->T; pa.cb = c->label_cb;
+        // (a pipeline rank settles the pair across its bottom boundary: the column map of the cold neighbour's hottest rung too)
+        const int below = c->cfg.rung_begin > 0 ? 1 : 0;
+        pa.Tl = c->Tl + below; pa.W = c->W; pa.rung_begin = c->cfg.rung_begin - below; pa.T = c->T; pa.cb = c->label_cb;
         pa.keys = c->ikeys;
-        hipLaunchKernelGGL(k_plan_keys, dim3((KEY_WINDOW * c->Tl + 255) / 256), dim3(256), 0, c->stream, pa, KEY_WINDOW);
+        hipLaunchKernelGGL(k_plan_keys, dim3((KEY_WINDOW * pa.Tl + 255) / 256), dim3(256), 0, c->stream, pa, KEY_WINDOW);
         c->ikeys_iter0 = c->iter;
         c->ikeys_n = KEY_WINDOW;
         c->timing.n_plan += 1;
@@ -995,6 +1010,101 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     return HENS_OK;
 }
 
+// ---- the same two launches on a rank of the ladder pipeline (round 3) -----------------------------------------------------------
+// Round 2's pipeline rank ran round 1's three copying launches (stretch x 2 -> k_pipe_walk): a config-3 shard stepped at 89 us
+// per iteration as a rank against 59 us as a ladder of its own.  Now: k_stretch_fast (first half-step, in place, draws in
+// registers, carries the adaptation and the waits for the previous sweep's arrivals) -> k_split1_pt<PIPE> (second half-step
+// + the rank's segment of the cascade + both boundaries, hand-offs per column block).  What every rank must agree on is a
+// function of (T, W, D, nranks, likelihood kind, move mix) only.
+bool pipe_fused_possible(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_NO_FUSED") != nullptr || getenv("HENS_PIPE_NO_FUSED") != nullptr;   // A/B knob
+    if (off || !pipe_active(c) || c->pipe.staged || c->label_cb <= 0 || !has_pt(c) || !fast_path(c)) return false;
+    if (c->cfg.likelihood_kind == HENS_LIKE_HOST || c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE || c->mh_kind >= 0) return false;
+    const int Tl = c->Tl;
+    if (c->T % c->pipe.nranks != 0 || Tl != c->T / c->pipe.nranks || c->cfg.rung_begin != c->pipe.rank * Tl) return false;   // equal shards
+    if (Tl < 2 || Tl > 64 || (Tl & (Tl - 1)) != 0) return false;                  // 128 / Tl columns x Tl rungs = one full tile
+    const int cbl = 2 * TILE / Tl;
+    return cbl >= c->label_cb && cbl % c->label_cb == 0 && c->W % cbl == 0;
+}
+
+int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
+    const int T = c->T, W = c->W, Tl = c->Tl;
+    state_to_records(c);
+    const uint32_t* keys = iteration_keys(c);
+    {
+        StretchArgs a = base_args(c);
+        a.wrec = c->wrec[c->cur];
+        a.inplace = 1;
+        a.ikeys = keys;
+        a.iseed = c->cfg.seed; a.iiter = c->iter; a.ia = c->cfg.a;
+        a.idx_bits = c->idx_bits; a.hb_shift = c->label_cb_shift - 1; a.ndim_active = dim_active(c);
+        a.split = 0;
+        a.home_off = c->parity * Tl * W;
+        a.ghome = c->pipe.ghome;
+        a.sys_all = pipe_has_top(c) ? 1 : 0;
+        attach_iteration_head(c, a);               // waits for the previous sweep's arrivals, carries the pending adaptation
+        if (evs) {
+            c->ext_start = new_event(c);
+            c->ext_stop = new_event(c);
+            evs->push_back(c->ext_start);
+            evs->push_back(c->ext_stop);
+        }
+        const int r = launch_stretch<MODE_STRETCH>(c, a, (c->N0 + TILE - 1) / TILE);
+        c->ext_start = c->ext_stop = nullptr;
+        if (r) return r;
+    }
+    FusedArgs f{};
+    f.pool = c->pool;
+    f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
+    f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
+    f.betas = c->betas[c->bcur];
+    f.keys = keys;
+    f.a = c->cfg.a; f.ndim_active = dim_active(c);
+    f.accepted = c->accepted;
+    f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
+    f.flags = c->flags;
+    f.trace = (c->tracing && c->trace_fused) ? c->d_trace : nullptr;
+    f.logp_in = c->logp_in; f.fill = c->cfg.fill_value; f.rosen_a = c->rosen_a; f.rosen_b = c->rosen_b;
+    f.iter = c->iter; f.seed = c->cfg.seed;
+    f.T = T; f.W = W; f.idx_bits = c->idx_bits;
+    f.cb = c->label_cb; f.cb_shift = c->label_cb_shift;
+    f.Tl = Tl; f.rung_begin = c->cfg.rung_begin;
+    f.cbl = c->pipe.cbl; f.cbl_shift = c->pipe.cbl_shift;
+    f.guest_delta = guest_delta(c);
+    f.ghome = c->pipe.ghome;
+    f.box = c->pipe.box;
+    f.box_hot = pipe_has_top(c) ? c->pipe.boxes[c->pipe.rank + 1] : nullptr;
+    f.box_cold = pipe_has_bot(c) ? c->pipe.boxes[c->pipe.rank - 1] : nullptr;
+    f.pool_cold = c->pipe.pool_cold;
+    f.boxes = c->pipe.d_boxes;
+    f.swap_part = c->pipe.swap_rows;
+    f.tickets = c->pipe.tickets;
+    f.stats = c->pipe.stats;
+    f.budget = c->pipe.budget;
+    f.sweep = c->pipe.sweep;
+    f.par = (int)(c->pipe.sweep & 1u);
+    f.nranks = c->pipe.nranks; f.rank = c->pipe.rank;
+    f.count_tail = pipe_counts_in_stretch(c) ? 0 : 1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (evs) {
+        e0 = new_event(c); e1 = new_event(c);
+        evs->push_back(e0); evs->push_back(e1);
+    }
+    int r;
+    switch (c->cfg.likelihood_kind) {
+        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1, true); break;
+#ifndef HENS_DEV_BUILD
+        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1, true); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1, true); break;
+#endif
+        default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
+    }
+    if (r) return r;
+    c->num_proposals += 1;
+    pipe_finish_sweep(c);                          // queues this sweep's counts for the adaptation, flips the record buffers
+    return HENS_OK;
+}
+
 // ---- one launch per iteration (k_iter, hens_iter.h) ----------------------------------------------------------------
 // the shapes of fused_ok that leave the chip half empty (latency-bound: see hens_iter.h), row widths with three tiles in
 // half a CU's LDS.  Measured on one box (tools/iter_sweep.sh, us per iteration, one launch vs two):
@@ -1020,11 +1130,12 @@ int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEven
 #define LAUNCH_ITER_P(DT, NW, PER)                                                                 \
     do {                                                                                           \
         const size_t lds = iter_lds_bytes(DT, NW);                                                 \
-        static bool attr_done = false;                                                             \
-        if (!attr_done) {                                                                          \
+        static uint64_t attr_done = 0;                  /* (the attribute is per device) */        \
+        const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                                  \
+        if (!(attr_done & dev_bit)) {                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW, PER>),         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-            attr_done = true;                                                                      \
+            attr_done |= dev_bit;                                                                  \
         }                                                                                          \
         if (e0)                                                                                    \
             hipExtLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
@@ -1885,9 +1996,16 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     const bool prof = c->per_kernel_events;
     const bool fused = fused_ok(c);
     const bool iter1 = iter_ok(c);
+    if (piped && !c->pipe.fused_decided) {         // (every rank reaches the same verdict: pipe_fused_possible)
+        c->pipe.fused = pipe_fused_possible(c);
+        c->pipe.fused_decided = true;
+    }
+    const bool pfused = piped && c->pipe.fused;
+    if (pfused && c->mh_kind >= 0)
+        return fail(c, HENS_ERR_UNSUPPORTED, "ladder pipeline: set the Metropolis-Hastings proposal before the first hens_step call (a rank that steps in place cannot change its path)");
     // (the state stays in record mode between hens_step calls of the record paths - every other entry point settles it,
     //  settle_state - so a short call pays no pack / unpack)
-    if (!fused && !iter1) state_to_fields(c);
+    if (!fused && !iter1 && !pfused) state_to_fields(c);
     std::vector<hipEvent_t> evs;
     std::vector<char> ev_kind;                // per event pair: 0 stretch launch, 1 cascade launch, 2 fused half-step + cascade
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
@@ -1905,7 +2023,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // stream costs two cross-stream event waits per batch whatever its size: 31 us per batch of 22 iterations at config 2
     // (1.4 us per iteration) with nothing but the keys kernel on it.  HENS_PLAN_INLINE=0/1 forces either form (A/B knob).
     static const int inline_env = getenv("HENS_PLAN_INLINE") ? atoi(getenv("HENS_PLAN_INLINE")) : -1;
-    const bool keys_only = fused && !iter1;        // draws in registers: iteration_keys plans the round keys, nothing else
+    const bool keys_only = (fused && !iter1) || pfused;   // draws in registers: iteration_keys plans the round keys, nothing else
     const bool plan_inline = keys_only || (!piped && inline_env > 0);
     if (plan_inline && c->spec_valid) {          // (a speculative plan of an earlier call may still be writing a buffer)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0));
@@ -1969,6 +2087,13 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         for (int ib = 0; ib < nb; ++ib) {
             if (piped) pipe_prewait(c);
             const bool mh = iteration_is_mh(c);
+            if (pfused) {
+                r = pipe_fused_iteration(c, prof ? &evs : nullptr);
+                if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
+                if (r) return r;
+                c->iter += 1;
+                continue;
+            }
             if (mh) {
                 // (the fast kernels and the cascade read the walker records too; other MH launches want the by-field arrays)
                 if (fused && fast_path(c)) state_to_records(c);
@@ -2017,7 +2142,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             c->iter += 1;
         }
     }
-    if (piped) state_to_fields(c);
+    if (piped && !pfused) state_to_fields(c);
     // The last cascade's ladder adaptation stays pending on one GPU: the next hens_step call folds it into its first
     // launch (no kernel of its own, ~12 us per call with its count-buffer reset), and every entry point that reads the ladder,
     // the swap counters or the state settles it first (flush_adapt at their head) - same bits either way.
@@ -2616,6 +2741,16 @@ int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_ou
     if ((r = dalloc(c, &c->pipe.d_boxes, (size_t)nranks))) return r;
     if ((r = dalloc(c, &c->pipe.tickets, (size_t)4))) return r;
     HIPCHK(c, hipMemsetAsync(c->pipe.tickets, 0, 16, c->stream));
+    {   // fused iteration (pipe_fused_possible decides at the first hens_step): guests' home rows, one row of swap counts per workgroup
+        int cbl = 2 * TILE / std::max(1, std::min(c->Tl, 2 * TILE)), sh = 0;
+        while ((1 << sh) < cbl) ++sh;
+        c->pipe.cbl = 1 << sh; c->pipe.cbl_shift = sh;
+        if ((r = dalloc(c, &c->pipe.ghome, (size_t)4 * c->W))) return r;
+        HIPCHK(c, hipMemsetAsync(c->pipe.ghome, 0, (size_t)4 * c->W * 4, c->stream));
+        const size_t rows = (size_t)(c->W / c->pipe.cbl + 1) * (c->Tl + 1);
+        if ((r = dalloc(c, &c->pipe.swap_rows, rows))) return r;
+        HIPCHK(c, hipMemsetAsync(c->pipe.swap_rows, 0, rows * 4, c->stream));
+    }
     if (getenv("HENS_PIPE_STATS")) {
         if ((r = dalloc(c, &c->pipe.stats, (size_t)16))) return r;
         HIPCHK(c, hipMemsetAsync(c->pipe.stats, 0, 128, c->stream));

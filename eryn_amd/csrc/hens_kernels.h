@@ -218,12 +218,18 @@ struct PipeBox {
     double* lp_up;         // [2][2][W] (L, P) carried by each column of the hot neighbour (column order)
     double* lp_dn;         // [2][2][W] (L, P) of the cold neighbour's hottest rung after its stretch move (slot order)
     double* guest;         // [2][2][W][D] arrived rows: side 0 = from the hot neighbour, side 1 = from the cold one
+    // fused pipeline iteration (k_split1_pt<PIPE>, round 3): hand-offs per COLUMN BLOCK of the fused launch (128 / Tl columns)
+    unsigned* blk_lup;     // [W / 2 + 1] sweep counters: block b of the hot neighbour's launch has stored its columns' lp_up
+    unsigned* blk_ldn;     // [W / 2 + 1] block b of the cold neighbour's launch has published its hottest rung (lp_dn, ldn_loc, rows)
+    unsigned* blk_rows;    // [W / 2 + 1] block b of the hot neighbour's launch has pushed its rows into my guest area
+    int32_t* ldn_loc;      // [2][W] pool row of every walker of the cold neighbour's hottest rung (slot order): rows are
+                           // updated in place there, so "where its rows are" is no longer a formula
 };
 __host__ __device__ inline size_t pipe_round(size_t n) { return (n + 255) & ~(size_t)255; }
 __host__ __device__ inline size_t pipe_box_bytes(int T, int W, int D) {
     return pipe_round(PIPE_FLAG_WORDS * 4) + 256 + pipe_round(((size_t)W / 16 + 1) * 4) + pipe_round((size_t)4 * T * 4) +
            2 * pipe_round((size_t)4 * W * 8) +
-           pipe_round((size_t)4 * W * D * 8);
+           pipe_round((size_t)4 * W * D * 8) + 3 * pipe_round(((size_t)W / 2 + 1) * 4) + pipe_round((size_t)2 * W * 4);
 }
 __host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
     PipeBox b;
@@ -234,9 +240,14 @@ __host__ __device__ inline PipeBox pipe_box(char* base, int T, int W, int D) {
     b.counts = reinterpret_cast<unsigned*>(base + off); off += pipe_round((size_t)4 * T * 4);
     b.lp_up = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
     b.lp_dn = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * 8);
-    b.guest = reinterpret_cast<double*>(base + off);
+    b.guest = reinterpret_cast<double*>(base + off); off += pipe_round((size_t)4 * W * D * 8);
+    b.blk_lup = reinterpret_cast<unsigned*>(base + off); off += pipe_round(((size_t)W / 2 + 1) * 4);
+    b.blk_ldn = reinterpret_cast<unsigned*>(base + off); off += pipe_round(((size_t)W / 2 + 1) * 4);
+    b.blk_rows = reinterpret_cast<unsigned*>(base + off); off += pipe_round(((size_t)W / 2 + 1) * 4);
+    b.ldn_loc = reinterpret_cast<int32_t*>(base + off);
     return b;
 }
+constexpr int32_t PIPE_NOSEL = INT32_MIN;      // bottom boundary: the column's pair does not swap
 // guest row index of column c (sweep parity par, side) and its `loc` encoding
 __host__ __device__ inline int32_t pipe_guest_loc(int par, int side, int W, int c) { return ~((par * 2 + side) * W + c); }
 
@@ -491,6 +502,12 @@ struct StretchArgs {
     uint32_t cp_sweep;
     int32_t cnt_push, cp_nblocks, cp_np, cp_nranks, cp_rank, cp_T;
     int32_t sys_rung;          // local rung whose rows a peer will read (written through to memory, system scope), or -1
+    // fused pipeline iteration (in-place rows on a pipeline rank): a walker that arrived through the pipeline sits in a guest
+    // row (loc < 0) until its next half-step, which writes its row - the proposal or the old one - into the pool row the walker
+    // that left in exchange has vacated: ghome[~loc]; sys_all: every row store is system scope (a row is no longer rewritten
+    // every iteration, and any of them may end up in the rung a peer pulls from)
+    const int32_t* ghome;      // [2][2][W] home row of the guest at (sweep parity, side, column), or nullptr
+    int32_t sys_all;
     long long* pub_meta;       // neighbour's meta[par]: receives the pool row of (hottest rung, slot 0) after this move
     // ladder pipeline: before touching the state, wait until the mailbox flags selected by wmask reach wtarget
     const unsigned* wflags;
@@ -1162,6 +1179,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase A (wave 0): indices and draws -------------------------------------------------------
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
     int own = 0;
+    int32_t own_row = 0, ghome_row = 0;      // fused pipeline iteration: the walker's row (< 0: guest) and that guest's home row
     uint32_t acc_old = 0;                    // record mode, stretch move: the slot's accept counter rides in its record
     bool valid = false;
     if (wv == 0) {
@@ -1206,6 +1224,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 const int2 la = *reinterpret_cast<const int2*>(&o->loc);
                 rs = la.x; acc_old = (uint32_t)la.y;
 #endif
+                if (PIPE && A.ghome) ghome_row = A.ghome[rs < 0 ? ~rs : 0];   // (consumed in phase D: no wait in front of the barrier)
                 const DrawRec dv = draw_values(own, 0, sd.uz, sd.ua, A.ia, A.ndim_active);
                 zz = dv.zz; factors = dv.fac; lu = dv.lu;
                 Lold = lp.x; Pold = lp.y;
@@ -1232,6 +1251,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         }
         s_zz[lane] = zz;
         s_rs[lane] = rs;
+        own_row = rs;
         if (!(MODE == MODE_STRETCH && A.ikeys)) s_rc[lane] = rc;
         s_dst[lane] = A.inplace ? rs : A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
@@ -1464,6 +1484,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 if (MH || !A.wrec) atomicAdd(&A.accepted[gi], 1u);   // (the MH move counts in an array of its own)
                 atomicOr(&s_flag[lane], 2);
             }
+            if (PIPE && A.ghome && own_row < 0) {              // a guest: its row - new or old - goes to its home row (phase E)
+                A.wrec[gi].loc = ghome_row;
+                A.loc[gi] = ghome_row;
+                s_dst[lane] = ghome_row;
+                atomicOr(&s_flag[lane], 8);
+            }
             if (PIPE && A.pub_lp && tl == A.Tl - 1) {                  // ladder pipeline: what the hot neighbour's bottom pair needs
                 sys_store(A.pub_lp + own, keep ? logl : Lold);
                 sys_store(A.pub_lp + W + own, keep ? newP : Pold);
@@ -1483,9 +1509,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
         if (!rv[p]) continue;
-        if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
+        const int fl = s_flag[r];
+        if ((fl & 2) == 0) {                              // rejected: the old row is already in place -
+            if (PIPE && (fl & 8)) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, sreg[p]);   // unless it sits in a guest row
+            continue;
+        }
         const double2 qv = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-        if (PIPE && tl == A.sys_rung) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
+        if (PIPE && (tl == A.sys_rung || A.sys_all)) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
         else store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
     }
     if (PIPE && A.pub_lp && A.pub_final && tl == A.Tl - 1)             // every walker of the rung has published: tell the neighbour
@@ -2042,22 +2072,44 @@ struct FusedArgs {
     uint64_t iter, seed;
     int32_t T, W, idx_bits, cb, cb_shift, ndim_active;
     int32_t acc_rows;                                         // rows of swap_acc (a power of two): workgroup b adds to row b % acc_rows
+    // ---- PIPE instantiation: a rank of the ladder pipeline (T, keys, betas stay GLOBAL; the state arrays are the rank's) ----
+    int32_t Tl, rung_begin;                                   // resident rungs [rung_begin, rung_begin + Tl)
+    int32_t cbl, cbl_shift;                                   // columns per workgroup: 128 / Tl (a multiple of cb)
+    int64_t guest_delta;                                      // see row_off
+    int32_t* ghome;                                           // [2][2][W] home row of a guest (see StretchArgs::ghome)
+    char* box; char* box_hot; char* box_cold;                 // my mailbox, the hot / cold neighbour's (or nullptr)
+    const double* pool_cold;                                  // cold neighbour's walker pool (rows that move up are pulled)
+    char* const* boxes;                                       // [nranks] every mailbox (swap counts)
+    uint32_t* swap_part;                                      // [W / cbl][TE - 1] swap counts per workgroup (plain rows)
+    unsigned* tickets;                                        // [4] 0: arrive / collect of the counts, 1: bottom boundary
+    unsigned long long* stats;                                // debug wait statistics or nullptr
+    long long budget;                                         // wall-clock ticks a flag wait may take
+    uint32_t sweep;
+    int32_t par, nranks, rank, count_tail;
 };
 
-__host__ __device__ inline size_t fused_lds_bytes(int D, int NW) {
-    return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64) * 8 + (2 * 2 * TILE + 5 * TILE + 64) * 4;
+// (pipe: the cascade tables hold one more rung - what the hot neighbour's columns carry - and the bottom boundary's lists)
+__host__ __device__ inline size_t fused_lds_bytes(int D, int NW, bool pipe = false) {
+    return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64 + (pipe ? 2 * TILE : 0)) * 8 +
+           (2 * 2 * TILE + 5 * TILE + 64 + (pipe ? 3 * TILE : 0)) * 4;
 }
 
 // SHORT: the ladder length does not divide 128 - cb T < 128 slots and cb T / 2 < 64 moving walkers per workgroup.  An
 // instantiation of its own: with run-time bounds the full-tile launch lost its compile-time-true row guards, 0.2 us at
 // config 2 (tools/ab3.sh: 22.4 / 22.6 / 22.5 us per iteration before / with run-time bounds / with this parameter).
-template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false>
+// PIPE: the context is a rank of the ladder pipeline (round 3) - the workgroup owns 128 / Tl consecutive columns on
+// the rank's Tl rungs (a whole number of label blocks: again 128 slots, 64 of them moving), publishes its share of the
+// hottest rung to the hot neighbour, starts its walk from what that neighbour's columns carry, hands its own columns on to
+// the cold neighbour and settles the bottom boundary - all hand-offs per column block, rows updated in place.
+template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
+    static_assert(!(PIPE && (PER || SHORT)), "pipeline ranks: full tiles, no periodic parameters");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr bool CEN = like_centred(LIKE, DT);
     constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
     constexpr int NE = 2 * TILE;
+    constexpr int NEX = PIPE ? NE + TILE : NE;            // a pipeline rank's tables hold the hot neighbour's columns on top
     static_assert(NT >= 2 * NE, "one thread per slot + one per cascade uniform");
     constexpr bool WIDE = NT >= 2 * NE + 64;              // a further wave for the ladder, else the slot threads fetch it
     double* qtile = reinterpret_cast<double*>(smem_raw);                 // [TILE][RS]
@@ -2067,25 +2119,32 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     double* s_lu = s_fac + TILE;
     double* s_Lold = s_lu + TILE;
     double* s_Pold = s_Lold + TILE;
-    double* Lc = s_Pold + TILE;                                          // [NE] cascade tables, element e = t * cb + cc
-    double* Pc = Lc + NE;
-    double* lupt = Pc + NE;                                              // [NE] log-uniform of pair T-1-t on column cc
+    double* Lc = s_Pold + TILE;                                          // [NEX] cascade tables, element e = t * cb + cc
+    double* Pc = Lc + NEX;
+    double* lupt = Pc + NEX;                                             // [NE] log-uniform of pair T-1-t on column cc
     double* sbeta = lupt + NE;                                           // [64]
-    int32_t* locc = reinterpret_cast<int32_t*>(sbeta + 64);              // [NE]
-    int32_t* scol = locc + NE;                                           // [NE] slot of the element
+    int32_t* locc = reinterpret_cast<int32_t*>(sbeta + 64);              // [NEX]
+    int32_t* scol = locc + NEX;                                          // [NE] slot of the element
     int32_t* s_rs = scol + NE;                                           // [TILE]
     int32_t* s_rc = s_rs + TILE;
-    int32_t* s_dst = s_rc + TILE;
-    int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep
+    int32_t* s_dst = s_rc + TILE;                                        // [TILE] (PIPE: the row an accepted / guest row is written to)
+    int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit3 guest (PIPE)
     int32_t* s_el = s_flag + TILE;                                       // [TILE] element of the moving walker
     uint32_t* smask = reinterpret_cast<uint32_t*>(s_el + TILE);          // [cb][MW] swap bitmask per column
+    int32_t* s_src = reinterpret_cast<int32_t*>(smask + 64);             // PIPE [TILE] bottom boundary: row that moves down
+    int32_t* s_yrow = s_src + TILE;                                      // PIPE [TILE] row (cold neighbour's pool) that moves up
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = A.T, W = A.W, CB = A.cb, CS = A.cb_shift;
+    const int TG = A.T;                                                  // the whole ladder
+    const int T = PIPE ? A.Tl : A.T;                                     // the rungs this workgroup holds
+    const int W = A.W, CB = PIPE ? A.cbl : A.cb, CS = PIPE ? A.cbl_shift : A.cb_shift;
+    const int R0 = PIPE ? A.rung_begin : 0;
+    const bool has_top = PIPE && R0 + T < TG, has_bot = PIPE && R0 > 0;
+    const int TE = T + (has_top ? 1 : 0);                                // the walk's rungs: mine + the hot neighbour's columns
     const int c0 = blockIdx.x * CB;
-    const int MW = (T + 31) >> 5;
+    const int MW = (TE + 31) >> 5;
     // ladders whose length does not divide 128: cb = the largest power of two with cb T <= 128, so a workgroup holds
     // NEr = cb T <= 128 slots and NM = NEr / 2 <= 64 moving walkers; the lanes / rows beyond them idle
     const int NEr = SHORT ? (T << CS) : 2 * TILE, NM = SHORT ? (NEr >> 1) : TILE;
@@ -2110,45 +2169,55 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // Program order matters in the slot threads: the column map is computed BEFORE the record loads are issued (its
     // cycle-walking loop makes the compiler wait for every load in flight), and the records of the walkers that stay
     // (cascade tables) are consumed after the row gathers have been issued.
+    // (PIPE: the workgroup's columns are several label blocks of cb columns: the second half of EACH block moves.)
     WalkerRec wr_n{};                                                    // slot threads: the record of the walker in the slot
     bool stays = false;
     int slot_n = 0;
-    const int HB = CB >> 1;
+    int32_t home_n = 0;                                                  // PIPE: home row of a moving walker that sits in a guest row
+    const int HS = A.cb_shift - 1, HB = 1 << HS;                         // half a label block
+    const int HW = CB >> 1;                                              // moving walkers per rung of this workgroup
     constexpr int CWW = WIDE ? 5 : 2, FLW = WIDE ? 6 : 3;               // the waves of the moving walkers' draws
+    // index of the moving walker met by column cc of rung t among the workgroup's 64
+    auto mover_of = [&](int t, int cc) -> int {
+        if (PIPE) return (t << (CS - 1)) + ((cc >> (HS + 1)) << HS) + (cc & (HB - 1));
+        return (t << (CS - 1)) + cc - HB;
+    };
     if (wv == 0) s_flag[lane] = 0;                                       // (also the idle lanes of a short tile: never in the box)
     if (tid < NEr) {                                                     // (short ladders: the slots beyond cb T do not exist)
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
-        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
+        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
         slot_n = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
-        stays = cc < HB;
+        stays = PIPE ? ((cc >> HS) & 1) == 0 : cc < HB;
         wr_n = A.wrec[(size_t)t * W + slot_n];
         if (!stays) {
-            const int m = (t << (CS - 1)) + cc - HB;
+            const int m = mover_of(t, cc);
             s_rs[m] = wr_n.loc;
-            s_dst[m] = t * W + slot_n;                                   // (walker index: the accept counters)
+            if (PIPE) home_n = A.ghome[wr_n.loc < 0 ? ~wr_n.loc : 0];    // (unconditional; consumed in phase D)
+            else s_dst[m] = t * W + slot_n;                              // (walker index: the accept counters)
         }
         scol[e] = slot_n;
-        if (!WIDE && e < T) sbeta[e] = A.betas[e];
+        if (!WIDE && e < TE) sbeta[e] = A.betas[R0 + e];
     }
     if (tid >= NE && tid < 2 * NE) {
         // the cascade's log-uniforms (a Philox call and a log per element: ~1700 cycles of dependent ALU) on the two
         // waves that would otherwise idle until the barrier, not in the shadow of the slot chain above
         const int e = tid - NE, t = e >> CS, c = c0 + (e & (CB - 1));
-        if (t < T - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, t, W, c));   // tempering.py:535 (row j = t: pair T-1-t)
+        // row t of the table: pair TE-1-t of the walk = global pair R0 + TE-1-t, whose uniform is row TG-1-(R0+TE-1-t)
+        if (t < TE - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, PIPE ? TG - R0 - TE + t : t, W, c));   // tempering.py:535
     }
     if (WIDE && tid >= 2 * NE && tid < 2 * NE + 64) {
-        if (lane < T) sbeta[lane] = A.betas[lane];
+        if (lane < TE) sbeta[lane] = A.betas[R0 + lane];
     }
     if ((wv == CWW || wv == FLW) && lane < NM) {
-        const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HB + (m & (HB - 1));   // split position (second half)
-        const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)t * (uint32_t)W + (uint32_t)q);
+        const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));   // split position (second half)
+        const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q);
         if (wv == CWW) {
-            const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
+            const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
             const uint4 ka = kp[0], kb = kp[1];
             const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-            const int cw = (int)prp((uint32_t)place_column(0, stretch_index(sd.r22, W >> 1), CS - 1), key, A.idx_bits, (uint32_t)W);
+            const int cw = (int)prp((uint32_t)place_column(0, stretch_index(sd.r22, W >> 1), HS), key, A.idx_bits, (uint32_t)W);
             s_rc[m] = A.loc[t * W + cw];
         }
         if (wv == FLW || CWW == FLW) {
@@ -2174,8 +2243,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)s_rs[r] * D + jl * 2);
-            creg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)s_rc[r] * D + jl * 2);
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
+            creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
         }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
@@ -2229,7 +2298,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
 
     // ---- phase D: accept / update into the cascade's tables (the moving walkers' slot threads) ---------------------
     if (tid < NEr && !stays) {
-        const int e = tid, t = e >> CS, m = (t << (CS - 1)) + (e & (CB - 1)) - HB;
+        const int e = tid, t = e >> CS, m = mover_of(t, e & (CB - 1));
         const bool inbox = (s_flag[m] & 1) != 0;
         double acc = 0.0;
 #pragma unroll
@@ -2253,7 +2322,17 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;      // move.py:513-532
         Lc[e] = keep ? logl : Lold;
         Pc[e] = keep ? newP : Pold;
-        locc[e] = wr_n.loc;                                             // rows are updated in place (see StretchArgs::wrec)
+        if (PIPE) {
+            // a walker that arrived through the pipeline sits in a guest row until now: this half-step writes its row - the
+            // proposal or the old one - into the pool row vacated by the walker that left in exchange (phase E)
+            const bool guest = wr_n.loc < 0;
+            const int32_t row = guest ? home_n : wr_n.loc;
+            locc[e] = row;
+            s_dst[m] = row;
+            if (guest) s_flag[m] |= 8;
+        } else {
+            locc[e] = wr_n.loc;                                         // rows are updated in place (see StretchArgs::wrec)
+        }
         if (keep) {
 #ifndef HENS_X_NOK2ACC
             wr_n.acc += 1u;                                             // (phase G writes the slot's record back)
@@ -2270,7 +2349,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // is an immediate and the loop is straight-line code)
     auto walk = [&](auto tt) {
         constexpr int TT = decltype(tt)::value;                          // 0: runtime ladder length
-        const int Tn = TT ? TT : T;
+        const int Tn = TT ? TT : TE;
         const int cc = lane;
         double cL = Lc[((Tn - 1) << CS) + cc];
         uint32_t m = 0;
@@ -2307,24 +2386,69 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         for (int p = 0; p < NPASS; ++p) {
             const int r = p * RPP + rsub;
             if (!rv[p]) continue;
+            if (PIPE) {                          // system scope: a peer may pull the row; guests go home accepted or not
+                const int fl = s_flag[r];
+                if ((fl & (2 | 8)) == 0) continue;
+                store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2,
+                                (fl & 2) ? (CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2)) : sreg[p]);
+                continue;
+            }
             if ((s_flag[r] & 2) == 0) continue;
             store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2,
                         CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
         }
     };
-    if (!walking) store_accepted();
-    if (walking && lane < CB) {
-        if (T == 16) walk(std::integral_constant<int, 16>{});
-        else if (T == 8) walk(std::integral_constant<int, 8>{});
-        else if (T == 32) walk(std::integral_constant<int, 32>{});
-        else walk(std::integral_constant<int, 0>{});
+    if (PIPE) {
+        // The rank's hottest rung after the move goes to the hot neighbour - (L, P, row) of the 128 / Tl slots this
+        // workgroup's columns meet there, slot order - BEFORE the wait for that neighbour's columns: its bottom boundary for
+        // these very columns needs nothing else from this rank.  The rows themselves must be complete first (phase E, system
+        // scope), so on a pipeline rank phase E does not hide in the walk's shadow.
+        store_accepted();
+        const PipeBox me = pipe_box(A.box, TG, W, D);
+        if (has_top) {
+            if (tid >= ((T - 1) << CS) && tid < (T << CS)) {
+                const PipeBox hot = pipe_box(A.box_hot, TG, W, D);
+                const int slot = scol[tid];
+                sys_store(hot.lp_dn + (size_t)(A.par * 2) * W + slot, Lc[tid]);
+                sys_store(hot.lp_dn + (size_t)(A.par * 2 + 1) * W + slot, Pc[tid]);
+                __hip_atomic_store(hot.ldn_loc + (size_t)A.par * W + slot, locc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) pipe_raise(pipe_box(A.box_hot, TG, W, D).blk_ldn + blockIdx.x, A.sweep + 1);
+            // what the hot neighbour's columns carry on leaving its rungs: the walk's top row
+            if (walking) {
+                if (lane == 0) pipe_spin(me.blk_lup + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
+                if (lane < CB) {
+                    const int c = c0 + lane, et = (T << CS) + lane;
+                    Lc[et] = sys_load(me.lp_up + (size_t)(A.par * 2) * W + c);
+                    Pc[et] = sys_load(me.lp_up + (size_t)(A.par * 2 + 1) * W + c);
+                    locc[et] = pipe_guest_loc(A.par, 0, W, c);
+                }
+            }
+        }
+        if (walking && lane < CB) {
+            if (TE == 9) walk(std::integral_constant<int, 9>{});
+            else if (TE == 8) walk(std::integral_constant<int, 8>{});
+            else if (TE == 1) smask[lane * MW] = 0;
+            else walk(std::integral_constant<int, 0>{});
+        }
+    } else {
+        if (!walking) store_accepted();
+        if (walking && lane < CB) {
+            if (T == 16) walk(std::integral_constant<int, 16>{});
+            else if (T == 8) walk(std::integral_constant<int, 8>{});
+            else if (T == 32) walk(std::integral_constant<int, 32>{});
+            else walk(std::integral_constant<int, 0>{});
+        }
     }
     lds_barrier();
     FUSED_TRACE(6);
     if (HENS_CUT_F == 5) return;
 
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
-    auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
+    auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < TE) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
+    int se_n = 0;                                                        // the element that settles in this thread's slot
     if (tid < NEr) {
         const int e = tid, t = e >> CS, cc = e & (CB - 1);
         int st;
@@ -2339,7 +2463,10 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             while (bit(cc, st + 1)) ++st;
         }
         const int se = (st << CS) + cc;
+        se_n = se;
         const size_t di = (size_t)t * W + scol[e];
+        if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
+            A.ghome[(size_t)(A.par * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
 #if HENS_GSTORE == 1
         {   // record + compact row index written through (sc1): nothing of this launch's output waits dirty in L2 for the
             // write-back at the kernel boundary
@@ -2368,19 +2495,147 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         A.locnew[di] = locc[se];
 #endif
     }
-    for (int i = 1 + tid; i < T; i += NT) {                              // pair (i, i-1) -> index i-1
+    for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
         unsigned n = 0;
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
+        if (PIPE) {                              // plain rows, one per workgroup (reduced by the collector / the next launch)
+            __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
 #if !defined(HENS_X_NOSWAP)
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n);
 #endif
     }
     // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
-    if (walking) store_accepted();
+    if (!PIPE && walking) store_accepted();
 
+    if (PIPE) {
+        const PipeBox me = pipe_box(A.box, TG, W, D);
+        // ---- my columns leave for the cold neighbour: its workgroup with the same index may start its walk -----------------
+        if (has_bot) {
+            const PipeBox cold = pipe_box(A.box_cold, TG, W, D);
+            if (tid < CB) {                                              // (slot threads of my coldest rung: t = 0, cc = tid)
+                sys_store(cold.lp_up + (size_t)(A.par * 2) * W + c0 + tid, Lc[se_n]);
+                sys_store(cold.lp_up + (size_t)(A.par * 2 + 1) * W + c0 + tid, Pc[se_n]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) pipe_raise(cold.blk_lup + blockIdx.x, A.sweep + 1);
+            // ---- bottom boundary, hot side: pair (g, g-1) for the same columns (needs the cold neighbour's rung after ITS move,
+            // not its walk); a walker may fall through all my rungs in one sweep, so the rows from above must have landed too
+            if (tid == 0) pipe_spin(me.blk_ldn + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
+            if (tid == 64 && has_top) pipe_spin(me.blk_rows + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
+            __syncthreads();
+            if (tid < CB) {
+                const int cc = tid, c = c0 + cc, g = R0;
+                const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(g - 1) * 2;
+                const uint4 ka = kp[0], kb = kp[1];
+                const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+                const int slot_below = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+                const double La = Lc[se_n];
+                const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
+                const double db = A.betas[g - 1] - A.betas[g];                       // tempering.py:518-522
+                int32_t src = PIPE_NOSEL, yrow = 0;
+                if (db * (La - Lb) > log(pt_uniform(A.seed, A.iter, TG - 1 - g, W, c))) {   // tempering.py:535-541
+                    src = locc[se_n];
+                    yrow = __hip_atomic_load(me.ldn_loc + (size_t)A.par * W + slot_below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const double Pb = sys_load(me.lp_dn + (size_t)(A.par * 2 + 1) * W + slot_below);
+                    const int32_t gl = pipe_guest_loc(A.par, 1, W, c);
+                    const size_t di = (size_t)scol[tid];                             // (rung 0 of the rank)
+                    A.wrecnew[di] = make_wrec(Lb, Pb, gl, wr_n.acc);
+                    A.locnew[di] = gl;
+                    // its home: the row of the walker that goes down - or, if that one only just fell in from above (a guest
+                    // itself), the row of the walker that went up across the top boundary
+                    A.ghome[(size_t)(A.par * 2 + 1) * W + c] = src >= 0 ? src : locc[((T - 1) << CS) + cc];
+                }
+                s_src[cc] = src;
+                s_yrow[cc] = yrow;
+            }
+            __syncthreads();
+            {
+                double* dst = cold.guest + (size_t)(A.par * 2) * W * D;              // rows that move down: push
+                double* mine = me.guest + (size_t)(A.par * 2 + 1) * W * D;           // rows that move up: pull
+                // all of a thread's loads first - the pulls cross xGMI, their latencies must overlap - then the stores
+                for (int base = 0; base < CB * D; base += 4 * NT) {
+                    double push[4], pull[4];
+                    bool on[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = base + q * NT + tid;
+                        on[q] = false;
+                        if (idx < CB * D) {
+                            const int col = idx / D, d = idx - col * D;
+                            const int32_t src = s_src[col];
+                            if (src != PIPE_NOSEL) {
+                                on[q] = true;
+                                push[q] = sys_load(A.pool + row_off(src, D, A.guest_delta) + d);
+                                pull[q] = sys_load(A.pool_cold + (size_t)s_yrow[col] * D + d);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = base + q * NT + tid;
+                        if (on[q]) {
+                            const int col = idx / D, d = idx - col * D;
+                            sys_store(dst + (size_t)(c0 + col) * D + d, push[q]);
+                            mine[(size_t)(c0 + col) * D + d] = pull[q];
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) pipe_raise(cold.blk_rows + blockIdx.x, A.sweep + 1);
+            // the last workgroup to get here tells the cold neighbour that ALL its rows from above have landed (and all of
+            // its own rows that moved up have been read): its next iteration may start
+            if (pipe_last_ticket(A.tickets + 1, gridDim.x * (A.sweep + 1u)) && tid == 0) pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
+        }
+        // ---- workgroup 0 speaks for the launch once everyone has arrived: the swap counts of my pairs ------------------
+        if (A.count_tail) {
+            const long long dbg_t0 = wall_clock64();
+            if (pipe_arrive_collect(A.tickets + 0, gridDim.x, A.sweep, A.budget, A.flags)) {
+                const long long dbg_t1 = wall_clock64();
+                const int NP = TE - 1;
+                unsigned* s_n = reinterpret_cast<unsigned*>(smem_raw);           // [NP] (the tile is dead)
+                for (int i = tid; i < NP; i += NT) s_n[i] = 0;
+                __syncthreads();
+                const int total = (int)gridDim.x * NP;
+                for (int e0 = tid; e0 < total; e0 += 8 * NT) {                   // all of a thread's loads in flight at once
+                    unsigned v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = e0 + q * NT;
+                        v[q] = e < total ? __hip_atomic_load(&A.swap_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = e0 + q * NT;
+                        if (v[q]) atomicAdd(&s_n[e % NP], v[q]);
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < A.nranks * NP; e += NT) {
+                    const int q = e / NP, j = e - q * NP;                        // ext pair j+1 = global pair (R0+j+1, R0+j)
+                    const PipeBox bx = pipe_box(A.boxes[q], TG, W, D);
+                    __hip_atomic_store(bx.counts + (size_t)(A.sweep & 3u) * TG + (R0 + j), s_n[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid < A.nranks) pipe_raise(pipe_box(A.boxes[tid], TG, W, D).flags + PF_CNT0 + A.rank, A.sweep + 1);
+                if (A.stats && tid == 0) {            // debug: collector wait / tail, wall-clock ticks
+                    atomicAdd(A.stats + 10, (unsigned long long)(dbg_t1 - dbg_t0));
+                    atomicAdd(A.stats + 11, 1ull);
+                    atomicAdd(A.stats + 12, (unsigned long long)(wall_clock64() - dbg_t1));
+                    atomicAdd(A.stats + 13, 1ull);
+                }
+            }
+        }
+    }
     FUSED_TRACE(7);
 #undef FUSED_TRACE
 }
+
 
 // Stand-alone ladder adaptation (one workgroup): used where it cannot ride in the next stretch
 // launch (parity API, sharded ladder, generic row widths, T > 64, end of a hens_step call).
@@ -2753,7 +3008,6 @@ __global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
 }
 
 constexpr int PIPE_COLS = 16;       // columns per workgroup of the bottom-boundary kernel (W / 16 workgroups: every CU busy)
-constexpr int32_t PIPE_NOSEL = INT32_MIN;
 
 // bottom boundary, hot side: decide pair (b, b-1), settle my coldest rung, push the rows that move down into
 // the cold neighbour's guest area and pull the rows that move up out of its pool.  One workgroup = PIPE_COLS
