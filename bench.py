@@ -461,18 +461,64 @@ def run_sharded(args):
             return None
         return eng, times
 
-    def fallback_run():
+    STAGED = "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages)"
+
+    def staged_run():
+        """The same protocol and kernels with RCCL point-to-point messages between three host-ordered stages."""
         eng = make_engine(0)
+        try:
+            stepper = StagedPipeline(eng, rank, world, dist, device)
+        except Exception as exc:                      # noqa: BLE001
+            print(f"[rank {rank}] staged pipeline unavailable ({exc})", file=sys.stderr, flush=True)
+            stepper = None
+        flag = torch.tensor([0 if stepper is None else 1], dtype=torch.int32, device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            eng.close()
+            return None
+        times, ok = measure(stepper, eng)
+        if not ok:
+            eng.close()
+            return None
+        return eng, times
+
+    def fallback_run():
         if mode == "rccl_neighbour":
-            stepper, transport = StagedPipeline(eng, rank, world, dist, device), \
-                "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages)"
-        else:
-            stepper, transport = ShardedLadder(HipShardEngine(eng, device), T, dist=dist, rank=rank, nranks=world), \
-                "RCCL all-gather(logL) + all-to-all(rows)"
+            r = staged_run()
+            if r is None:
+                raise SystemExit("bench.py: the RCCL neighbour transport failed")
+            return r[0], r[1], STAGED
+        eng = make_engine(0)
+        stepper, transport = ShardedLadder(HipShardEngine(eng, device), T, dist=dist, rank=rank, nranks=world), \
+            "RCCL all-gather(logL) + all-to-all(rows)"
         times, ok = measure(stepper, eng)
         if not ok:
             raise SystemExit("bench.py: the RCCL fallback failed too")
         return eng, times, transport
+
+    def wait_breakdown(delay):
+        """Where each rank waits (hens_pipe_debug_stats): a separate short pass - with the statistics switched on every flag
+        wait reads the wall clock (~1.5 us), so the timed passes run without them.  Per rank: mean wait per iteration [us]."""
+        os.environ["HENS_PIPE_STATS"] = "1"
+        try:
+            eng = make_engine(delay)
+            stepper = LadderPipeline(eng, rank, world, dist=dist, device_id=local_rank, selftest=False)
+            stepper.step(args.warmup)
+            eng.synchronize()
+            eng.pipe_debug_stats(reset=True)
+            n = max(args.steps, 1)
+            stepper.step(n)
+            eng.synchronize()
+            st = eng.pipe_debug_stats()
+            mine = {k: round(v[0] * 1e6 / n, 3) for k, v in st.items()}     # ticks are seconds here (engine converts)
+            eng.close()
+        except Exception as exc:                      # noqa: BLE001
+            mine = {"error": str(exc)[:200]}
+        finally:
+            os.environ.pop("HENS_PIPE_STATS", None)
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        return {f"rank{q}": g for q, g in enumerate(got)}
 
     # weak-scaling base: ONE shard of the same size alone on this GPU (rank 0's), the N = 1 point of the series
     base = None
@@ -487,19 +533,34 @@ def run_sharded(args):
                 "workload": f"one shard alone on one GPU: ntemps={Tl}, nwalkers={W}, ndim={D} (a {Tl}-rung ladder of its own)"}
     dist.barrier()
 
-    result, delayed, transport = None, None, None
+    def summary(times, **kw):
+        sdt = float(np.median(times))
+        out_ = {"value": T * W * args.steps / sdt, "ms_per_step": sdt / args.steps * 1e3, "block_ms": [t * 1e3 for t in times]}
+        if base:                                   # weak scaling: one shard alone on one GPU / the same shard as a rank
+            out_["efficiency"] = base["ms_per_step"] / out_["ms_per_step"]
+        out_.update(kw)
+        return out_
+
+    result, delayed, transport, staged, waits = None, None, None, None, None
     if mode == "pipeline":
         result = pipeline_run(0)
         if result is not None:
             transport = "xGMI one-sided puts into HIP-IPC mailboxes + device flags (ladder pipeline)"
             d = pipeline_run(1)
             if d is not None:
-                ddt = float(np.median(d[1]))
-                delayed = {"value": T * W * args.steps / ddt, "ms_per_step": ddt / args.steps * 1e3,
-                           "block_ms": [t * 1e3 for t in d[1]],
-                           "schedule": "adaptation_delay=1: the swap ratios of sweep s move the ladder before iteration s+2 "
-                                       "(not the reference's schedule; lets the ranks pipeline)"}
+                delayed = summary(d[1], schedule="adaptation_delay=1: the swap ratios of sweep s move the ladder before iteration "
+                                                 "s+2 (not the reference's schedule; lets the ranks pipeline)")
                 d[0].close()
+            if not args.no_waits:
+                waits = {"adaptation_delay_0": wait_breakdown(0), "adaptation_delay_1": wait_breakdown(1),
+                         "unit": "us per iteration and rank, summed over the waiting workgroups' lead threads (a separate pass "
+                                 "with HENS_PIPE_STATS=1; the timed passes run without the statistics)"}
+        # the transport north_star names, timed in the same run: RCCL point-to-point between ladder neighbours
+        if not args.no_staged and not rosen:
+            sr = staged_run()
+            if sr is not None:
+                staged = summary(sr[1], transport=STAGED, schedule="the reference's (adaptation_delay=0)")
+                sr[0].close()
     if result is None:
         if backend != "nccl":
             raise SystemExit("bench.py: the ladder pipeline did not come up in this dry run (ranks that share ONE GPU can "
@@ -547,8 +608,15 @@ def run_sharded(args):
                        "world_size_seen_by_backend": dist.get_world_size(), "swap_fraction": f_sw},
             "roofline": roof,
         }
+        if base:
+            out["efficiency"] = base["ms_per_step"] / out["ms_per_step"]
+            out["efficiency_definition"] = "weak_base.ms_per_step / ms_per_step: one shard alone on one GPU against the same shard as a rank"
         if delayed:
             out["delayed_adaptation"] = delayed
+        if staged:
+            out["rccl_neighbour"] = staged
+        if waits:
+            out["rank_waits"] = waits
         if base:
             out["weak_base"] = base
         if not args.no_cpu and not rosen:             # (the CPU leg times the Gaussian stretch + PT oracle)
@@ -579,6 +647,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-base", action="store_true")
+    ap.add_argument("--no-staged", action="store_true", help="N > 1: skip the RCCL neighbour-exchange pass")
+    ap.add_argument("--no-waits", action="store_true", help="N > 1: skip the per-rank wait breakdown pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "0"))

@@ -146,7 +146,11 @@ struct hens_ctx_impl {
         bool fused = false, fused_decided = false;
         int cbl = 0, cbl_shift = 0;        // columns per workgroup of the fused launch: 128 / Tl
         int32_t* ghome = nullptr;          // [2][2][W] home rows of the guests (StretchArgs::ghome)
-        uint32_t* swap_rows = nullptr;     // [W / cbl][Tl] swap counts per workgroup of the fused launch
+        // swap counts of the fused launch: [SWAP_ACC_ROWS_MAX][T] accumulated with atomics, buffer = sweep & 1; the head of the
+        // next iteration's first launch (or k_pipe_epilogue at the end of a call) sums, clears and publishes them
+        uint32_t* acc[2] = {nullptr, nullptr};
+        uint32_t pushed = 0;               // sweeps whose counts have been published
+        uint32_t rows_told = 0;            // sweeps whose "all rows have landed" the cold neighbour has been told
     } pipe;
     // Metropolis-Hastings (GaussianMove) proposals
     double* mh_step = nullptr;             // [Tl][W][D]
@@ -562,16 +566,15 @@ bool pipe_publish_fused(const hens_ctx_impl* c) {
 
 // adaptation_delay = 1 leaves a whole iteration before a sweep's counts are needed: the adapting workgroup of the
 // next iteration's first launch reduces and publishes them, and the walk kernel needs no collector at all
-// workgroups of the launch that walks the cascade on a pipeline rank (one row of swap counts each)
-int walk_blocks(const hens_ctx_impl* c) { return c->pipe.fused ? c->W / c->pipe.cbl : pt_blocks(c); }
-uint32_t* walk_rows(const hens_ctx_impl* c) { return c->pipe.fused ? c->pipe.swap_rows : c->swap_part; }
 bool pipe_counts_in_stretch(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_PIPE_COUNT_TAIL") != nullptr;       // A/B knob
+    if (c->pipe.fused) return false;             // (the fused iteration publishes its counts its own way: pipe_fused_counts)
     if (off || !pipe_active(c) || c->pipe.staged || c->cfg.adaptation_delay != 1 || !fast_path(c)) return false;
     if (fold_mode(c) != 2 || fast_nw(c->D) < 2) return false;
     const int np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
-    return np >= 1 && (int64_t)walk_blocks(c) * np <= (int64_t)8 * fast_nw(c->D) * 64;
+    return np >= 1 && (int64_t)pt_blocks(c) * np <= (int64_t)8 * fast_nw(c->D) * 64;
 }
+int pipe_acc_rows(const hens_ctx_impl* c) { return 8 * acc_row_groups(c->Tl + (pipe_has_top(c) ? 1 : 0)); }
 
 // one-sided transport: the bottom boundary is the walk kernel's last phase (one launch less on every rank that has a
 // cold neighbour); the staged transport needs the LUP message to leave between the two, so it keeps them apart
@@ -740,6 +743,31 @@ hipEvent_t new_event(hens_ctx_impl* c) {
     return e;
 }
 
+// fused pipeline iteration: what the head of the next iteration's first launch would say, as a kernel of its own (end of a
+// hens_step call; an adaptation that cannot be folded) - the previous sweep's pushes are complete (cold neighbour's
+// PF_ROWS_TOP) and, on the reference's adaptation schedule, that sweep's swap counts
+void pipe_fused_epilogue(hens_ctx_impl* c) {
+    if (!c->pipe.fused || c->pipe.sweep == 0) return;
+    PipeEpilogueArgs ea{};
+    if (pipe_has_bot(c) && c->pipe.rows_told < c->pipe.sweep) {
+        ea.rt_flag = pipe_box(c->pipe.boxes[c->pipe.rank - 1], c->T, c->W, c->D).flags + PF_ROWS_TOP;
+        ea.rt_value = c->pipe.sweep;
+        c->pipe.rows_told = c->pipe.sweep;
+    }
+    if (c->cfg.adaptation_delay == 0 && c->pipe.pushed < c->pipe.sweep) {
+        ea.push = 1;
+        ea.cp_rows = c->pipe.acc[(c->pipe.sweep - 1) & 1u];
+        ea.cp_boxes = c->pipe.d_boxes;
+        ea.cp_sweep = c->pipe.sweep - 1;
+        ea.cp_nblocks = pipe_acc_rows(c);
+        ea.cp_np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
+        ea.cp_nranks = c->pipe.nranks; ea.cp_rank = c->pipe.rank; ea.cp_T = c->T;
+        ea.rung_begin = c->cfg.rung_begin; ea.W = c->W; ea.D = c->D;
+        c->pipe.pushed = c->pipe.sweep;
+    }
+    if (ea.rt_flag || ea.push) hipLaunchKernelGGL(k_pipe_epilogue, dim3(1), dim3(64), 0, c->stream, ea);
+}
+
 // the first launch of an iteration: wait for the pipeline's arrivals in its prologue and carry the pending
 // ladder adaptation (or run it as a kernel of its own where it cannot be folded)
 void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
@@ -755,14 +783,35 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
     }
     if (pipe_counts_in_stretch(c) && c->pipe.sweep > 0) {      // the counts of the sweep that just ended
         a.cnt_push = 1;
-        a.cp_rows = walk_rows(c);
+        a.cp_rows = c->swap_part;
         a.cp_boxes = c->pipe.d_boxes;
         a.cp_sweep = c->pipe.sweep - 1;
-        a.cp_nblocks = walk_blocks(c);
+        a.cp_nblocks = pt_blocks(c);
         a.cp_np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
         a.cp_nranks = c->pipe.nranks;
         a.cp_rank = c->pipe.rank;
         a.cp_T = c->T;
+    }
+    if (c->pipe.fused && c->adapt_pending && !can_fold_adapt(c)) pipe_fused_epilogue(c);   // (the wait below needs the counts out)
+    if (c->pipe.fused && c->pipe.sweep > 0) {                  // what the previous sweep's fused launch left to its successor
+        if (c->pipe.pushed < c->pipe.sweep) {                  // its swap counts (due NOW on the reference's schedule)
+            a.cnt_push = c->cfg.adaptation_delay == 0 ? 2 : 1;
+            a.cp_rows = c->pipe.acc[(c->pipe.sweep - 1) & 1u];
+            a.cp_zero = 1;
+            a.cp_boxes = c->pipe.d_boxes;
+            a.cp_sweep = c->pipe.sweep - 1;
+            a.cp_nblocks = pipe_acc_rows(c);
+            a.cp_np = c->Tl + (pipe_has_top(c) ? 1 : 0) - 1;
+            a.cp_nranks = c->pipe.nranks;
+            a.cp_rank = c->pipe.rank;
+            a.cp_T = c->T;
+            c->pipe.pushed = c->pipe.sweep;
+        }
+        if (pipe_has_bot(c) && c->pipe.rows_told < c->pipe.sweep) {   // all of its pushes / pulls are complete
+            a.rt_flag = pipe_box(c->pipe.boxes[c->pipe.rank - 1], c->T, c->W, c->D).flags + PF_ROWS_TOP;
+            a.rt_value = c->pipe.sweep;
+            c->pipe.rows_told = c->pipe.sweep;
+        }
     }
     if (!c->adapt_pending) return;
     if (can_fold_adapt(c)) {
@@ -1076,15 +1125,14 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     f.box_hot = pipe_has_top(c) ? c->pipe.boxes[c->pipe.rank + 1] : nullptr;
     f.box_cold = pipe_has_bot(c) ? c->pipe.boxes[c->pipe.rank - 1] : nullptr;
     f.pool_cold = c->pipe.pool_cold;
-    f.boxes = c->pipe.d_boxes;
-    f.swap_part = c->pipe.swap_rows;
-    f.tickets = c->pipe.tickets;
+    f.swap_acc = c->pipe.acc[c->pipe.sweep & 1u];
+    f.acc_rows = pipe_acc_rows(c);
     f.stats = c->pipe.stats;
     f.budget = c->pipe.budget;
     f.sweep = c->pipe.sweep;
     f.par = (int)(c->pipe.sweep & 1u);
     f.nranks = c->pipe.nranks; f.rank = c->pipe.rank;
-    f.count_tail = pipe_counts_in_stretch(c) ? 0 : 1;
+    f.sys_rows = pipe_has_top(c) ? 1 : 0;           // (measured on one GPU: system-scope row stores cost nothing over sc1)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (evs) {
         e0 = new_event(c); e1 = new_event(c);
@@ -2143,6 +2191,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         }
     }
     if (piped && !pfused) state_to_fields(c);
+    if (pfused) pipe_fused_epilogue(c);
     // The last cascade's ladder adaptation stays pending on one GPU: the next hens_step call folds it into its first
     // launch (no kernel of its own, ~12 us per call with its count-buffer reset), and every entry point that reads the ladder,
     // the swap counters or the state settles it first (flush_adapt at their head) - same bits either way.
@@ -2747,9 +2796,10 @@ int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_ou
         c->pipe.cbl = 1 << sh; c->pipe.cbl_shift = sh;
         if ((r = dalloc(c, &c->pipe.ghome, (size_t)4 * c->W))) return r;
         HIPCHK(c, hipMemsetAsync(c->pipe.ghome, 0, (size_t)4 * c->W * 4, c->stream));
-        const size_t rows = (size_t)(c->W / c->pipe.cbl + 1) * (c->Tl + 1);
-        if ((r = dalloc(c, &c->pipe.swap_rows, rows))) return r;
-        HIPCHK(c, hipMemsetAsync(c->pipe.swap_rows, 0, rows * 4, c->stream));
+        const size_t words = (size_t)SWAP_ACC_ROWS_MAX * c->T;
+        if ((r = dalloc(c, &c->pipe.acc[0], 2 * words))) return r;
+        c->pipe.acc[1] = c->pipe.acc[0] + words;
+        HIPCHK(c, hipMemsetAsync(c->pipe.acc[0], 0, 2 * words * 4, c->stream));
     }
     if (getenv("HENS_PIPE_STATS")) {
         if ((r = dalloc(c, &c->pipe.stats, (size_t)16))) return r;

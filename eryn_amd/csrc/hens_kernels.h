@@ -349,6 +349,32 @@ __device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_del
     return loc >= 0 ? (int64_t)loc * D : guest_delta + (int64_t)(~loc) * D;
 }
 
+// One wavefront sums the swap counts a launch of k_split1_pt<PIPE> accumulated (nrows rows of np pairs, atomics), clears
+// them (sole reader) and publishes the sums to every rank's mailbox: counts of sweep `sweep`, flag PF_CNT0 + rank.
+__device__ __forceinline__ void pipe_push_counts(const uint32_t* rows_c, int nrows, int np, char* const* boxes, int nranks, int rank,
+                                                 int T, int rung_begin, int W, int D, uint32_t sweep, int lane) {
+    uint32_t* rows = const_cast<uint32_t*>(rows_c);
+    for (int j = lane; j < np; j += 64) {
+        unsigned sum = 0;
+        for (int r0 = 0; r0 < nrows; r0 += 8) {              // 8 loads in flight
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (r0 + q < nrows) ? rows[(size_t)(r0 + q) * np + j] : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                sum += v[q];
+                if (v[q]) rows[(size_t)(r0 + q) * np + j] = 0u;
+            }
+        }
+        for (int q = 0; q < nranks; ++q)                       // local pair j+1 = global pair (rung_begin+j+1, rung_begin+j)
+            __hip_atomic_store(pipe_box(boxes[q], T, W, D).counts + (size_t)(sweep & 3u) * T + (rung_begin + j), sum, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane < nranks) pipe_raise(pipe_box(boxes[lane], T, W, D).flags + PF_CNT0 + rank, sweep + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Periodic parameters (utils/periodic.py, used by stretch.py:136-154 and gaussian.py:110-115); period <= 0: not periodic.
 // distance(p1 = s, p2 = c): c - s, measured the short way round when it exceeds half a period (periodic.py:80-113: the moving
 // point is shifted by one period towards the complement - new_s = -(period - s) or period + s - and the difference taken
@@ -501,6 +527,12 @@ struct StretchArgs {
     char* const* cp_boxes;     // [cp_nranks]
     uint32_t cp_sweep;
     int32_t cnt_push, cp_nblocks, cp_np, cp_nranks, cp_rank, cp_T;
+    // (cnt_push 2 - fused pipeline iteration on the reference's adaptation schedule: the counts are due in THIS launch, so wave 1
+    //  of workgroup (0,0) sums and publishes them before anything else, in front of the wait for every rank's counts.
+    //  cp_zero: the rows were accumulated with atomics by k_split1_pt<PIPE> - the (sole) reader clears them)
+    int32_t cp_zero;
+    unsigned* rt_flag;         // fused pipeline iteration: the cold neighbour's PF_ROWS_TOP, raised at the head of this launch - the
+    uint32_t rt_value;         //   kernel boundary says that ALL pushes / pulls of the previous sweep's bottom phase are complete
     int32_t sys_rung;          // local rung whose rows a peer will read (written through to memory, system scope), or -1
     // fused pipeline iteration (in-place rows on a pipeline rank): a walker that arrived through the pipeline sits in a guest
     // row (loc < 0) until its next half-step, which writes its row - the proposal or the old one - into the pool row the walker
@@ -1026,6 +1058,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         while (wall_clock64() - t0 < 600) __builtin_amdgcn_s_sleep(4);
         return;
     }
+    if (PIPE && !EVAL && blockIdx.x == 0 && blockIdx.y == 0) {
+        if (A.rt_flag && tid == 0) pipe_raise(A.rt_flag, A.rt_value);
+        if (A.cnt_push == 2 && wv == 1) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T,
+                                                         A.rung_begin, W, DT, A.cp_sweep, lane);
+    }
     if (PIPE && !EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
         if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || ad_here || !ad_lead))
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
@@ -1126,7 +1163,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const bool ad_early = ad_here && A.ad.nblocks <= 8 * A.ad.row_groups;
     // the same workgroup pushes the last sweep's swap counts to every rank (uses the count-reduction machinery below,
     // which a pipeline rank's adaptation - counts already reduced - leaves idle)
-    const bool cnt_push = PIPE && !EVAL && NW >= 2 && A.cnt_push && blockIdx.x == 0 && blockIdx.y == 0;
+    const bool cnt_push = PIPE && !EVAL && NW >= 2 && A.cnt_push == 1 && blockIdx.x == 0 && blockIdx.y == 0;
     const bool red_on = (ad_here && !ad_early) || cnt_push;
     // a handful of rows (one: a pipeline rank's mailbox; SWAP_ACC_ROWS: the fused half-step + cascade launch, which
     // accumulates them with atomics): all loads in flight at once, no LDS, no barrier.  The adaptation itself is a
@@ -1325,6 +1362,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             for (int q = 0; q < 8; ++q) {
                 const int e = tid + q * NT;
                 if (e < total && adv[q]) A.ad.swap_part[e] = 0u;
+            }
+        }
+        if (cnt_push && A.cp_zero) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = tid + q * NT;
+                if (e < total && adv[q]) const_cast<uint32_t*>(A.cp_rows)[e] = 0u;
             }
         }
         if (!cnt_push && wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
@@ -2079,13 +2123,11 @@ struct FusedArgs {
     int32_t* ghome;                                           // [2][2][W] home row of a guest (see StretchArgs::ghome)
     char* box; char* box_hot; char* box_cold;                 // my mailbox, the hot / cold neighbour's (or nullptr)
     const double* pool_cold;                                  // cold neighbour's walker pool (rows that move up are pulled)
-    char* const* boxes;                                       // [nranks] every mailbox (swap counts)
-    uint32_t* swap_part;                                      // [W / cbl][TE - 1] swap counts per workgroup (plain rows)
-    unsigned* tickets;                                        // [4] 0: arrive / collect of the counts, 1: bottom boundary
     unsigned long long* stats;                                // debug wait statistics or nullptr
     long long budget;                                         // wall-clock ticks a flag wait may take
     uint32_t sweep;
-    int32_t par, nranks, rank, count_tail;
+    int32_t par, nranks, rank;
+    int32_t sys_rows;                                         // rows are stored at system scope (a peer pulls rows out of this pool)
 };
 
 // (pipe: the cascade tables hold one more rung - what the hot neighbour's columns carry - and the bottom boundary's lists)
@@ -2389,8 +2431,15 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             if (PIPE) {                          // system scope: a peer may pull the row; guests go home accepted or not
                 const int fl = s_flag[r];
                 if ((fl & (2 | 8)) == 0) continue;
-                store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2,
-                                (fl & 2) ? (CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2)) : sreg[p]);
+                // (no ?: between an LDS read and sreg[p]: a select of ADDRESSES puts the register array into scratch memory, and
+                //  every row gather then waits for itself in front of its scratch store - phase B three times as long)
+                double2 v = sreg[p];
+                if (fl & 2) {
+                    if (CEN) v = qkeep[p];
+                    else v = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+                }
+                if (A.sys_rows) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, v);
+                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, v);
                 continue;
             }
             if ((s_flag[r] & 2) == 0) continue;
@@ -2498,12 +2547,10 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
         unsigned n = 0;
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
-        if (PIPE) {                              // plain rows, one per workgroup (reduced by the collector / the next launch)
-            __hip_atomic_store(&A.swap_part[(size_t)blockIdx.x * (TE - 1) + (i - 1)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
-        }
+        // (a pipeline rank too - round 3: one ticket per workgroup on ONE address, for a collector at the end of the launch, cost
+        //  16 ns per workgroup, serialised: 17 us at 1024 workgroups; the next launch sums these rows and publishes the counts)
 #if !defined(HENS_X_NOSWAP)
-        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n);
+        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (TE - 1) + (i - 1)], n);
 #endif
     }
     // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
@@ -2587,49 +2634,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) pipe_raise(cold.blk_rows + blockIdx.x, A.sweep + 1);
-            // the last workgroup to get here tells the cold neighbour that ALL its rows from above have landed (and all of
-            // its own rows that moved up have been read): its next iteration may start
-            if (pipe_last_ticket(A.tickets + 1, gridDim.x * (A.sweep + 1u)) && tid == 0) pipe_raise(cold.flags + PF_ROWS_TOP, A.sweep + 1);
-        }
-        // ---- workgroup 0 speaks for the launch once everyone has arrived: the swap counts of my pairs ------------------
-        if (A.count_tail) {
-            const long long dbg_t0 = wall_clock64();
-            if (pipe_arrive_collect(A.tickets + 0, gridDim.x, A.sweep, A.budget, A.flags)) {
-                const long long dbg_t1 = wall_clock64();
-                const int NP = TE - 1;
-                unsigned* s_n = reinterpret_cast<unsigned*>(smem_raw);           // [NP] (the tile is dead)
-                for (int i = tid; i < NP; i += NT) s_n[i] = 0;
-                __syncthreads();
-                const int total = (int)gridDim.x * NP;
-                for (int e0 = tid; e0 < total; e0 += 8 * NT) {                   // all of a thread's loads in flight at once
-                    unsigned v[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = e0 + q * NT;
-                        v[q] = e < total ? __hip_atomic_load(&A.swap_part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = e0 + q * NT;
-                        if (v[q]) atomicAdd(&s_n[e % NP], v[q]);
-                    }
-                }
-                __syncthreads();
-                for (int e = tid; e < A.nranks * NP; e += NT) {
-                    const int q = e / NP, j = e - q * NP;                        // ext pair j+1 = global pair (R0+j+1, R0+j)
-                    const PipeBox bx = pipe_box(A.boxes[q], TG, W, D);
-                    __hip_atomic_store(bx.counts + (size_t)(A.sweep & 3u) * TG + (R0 + j), s_n[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid < A.nranks) pipe_raise(pipe_box(A.boxes[tid], TG, W, D).flags + PF_CNT0 + A.rank, A.sweep + 1);
-                if (A.stats && tid == 0) {            // debug: collector wait / tail, wall-clock ticks
-                    atomicAdd(A.stats + 10, (unsigned long long)(dbg_t1 - dbg_t0));
-                    atomicAdd(A.stats + 11, 1ull);
-                    atomicAdd(A.stats + 12, (unsigned long long)(wall_clock64() - dbg_t1));
-                    atomicAdd(A.stats + 13, 1ull);
-                }
-            }
+            // (that ALL rows from above have landed - what the cold neighbour's next iteration waits for - is said by this
+            //  rank's NEXT launch: StretchArgs::rt_flag, k_pipe_epilogue; no grid-wide ticket here)
         }
     }
     FUSED_TRACE(7);
@@ -2989,6 +2995,20 @@ __global__ void k_pipe_wait(const PipeWaitArgs A) {
     if (i < A.n) f = A.p[i];
     else if (A.cnt_flags && i - A.n < A.nranks) f = A.cnt_flags + (i - A.n);
     if (f) pipe_spin(f, A.target, A.budget, A.err);
+}
+// End of a hens_step call on a rank that steps with the fused iteration: what the head of the NEXT iteration's first launch
+// would say - the previous sweep's pushes are complete (cold neighbour's PF_ROWS_TOP), and, on the reference's adaptation
+// schedule, the last sweep's swap counts (the adaptation that closes the call needs every rank's).
+struct PipeEpilogueArgs {
+    unsigned* rt_flag; uint32_t rt_value;
+    const uint32_t* cp_rows; char* const* cp_boxes;
+    uint32_t cp_sweep;
+    int32_t push, cp_nblocks, cp_np, cp_nranks, cp_rank, cp_T, rung_begin, W, D;
+};
+__global__ void k_pipe_epilogue(const PipeEpilogueArgs A) {
+    if (A.rt_flag && threadIdx.x == 0) pipe_raise(A.rt_flag, A.rt_value);
+    if (A.push) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T, A.rung_begin, A.W, A.D,
+                                 A.cp_sweep, (int)threadIdx.x);
 }
 // my hottest rung after the stretch move -> hot neighbour, flag included (one workgroup).  Only for row widths
 // without a fast stretch kernel: those publish from their own accept phase (StretchArgs::pub_lp).

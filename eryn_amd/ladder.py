@@ -199,6 +199,8 @@ class LadderPipeline:
         self.rank, self.nranks = int(rank), int(nranks)
         if self.nranks > 1 and dist is None:
             raise ValueError("nranks > 1 needs torch.distributed to exchange the mailbox handles")
+        if self.nranks > 1:
+            self._refuse_shared_device(dist, group, device_id)
         if self.nranks > 1 and selftest:
             self._selftest(dist, group, device_id)
         if self.nranks == 1:
@@ -223,6 +225,26 @@ class LadderPipeline:
         got2 = [None] * self.nranks
         dist.all_gather_object(got2, (None, err), group=group)     # also the barrier: nobody stores into a mailbox
         self._raise_if_any(got2, "hens_pipe_connect")               # that is not mapped everywhere yet
+
+    def _refuse_shared_device(self, dist, group, device_id):
+        """One rank per GPU.  Ranks that share a device starve each other's flag waits (a resident kernel that spins on a flag
+        whose producer cannot get a compute unit never finishes: tests/test_hip_fullsize.py) - allowed only as a dry run of
+        the code path: the gloo backend (RCCL itself refuses two ranks on one GPU) or HENS_PIPE_SHARED_GPU=1.  Every rank
+        takes part in the collective and all of them raise together."""
+        import os
+        import socket
+        try:
+            import torch
+            props = torch.cuda.get_device_properties(int(device_id))
+            dev = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or device_id)
+        except Exception:                             # noqa: BLE001
+            dev = str(device_id)
+        ids = [None] * self.nranks
+        dist.all_gather_object(ids, (socket.gethostname(), dev), group=group)
+        dry_run = dist.get_backend(group) == "gloo" or os.environ.get("HENS_PIPE_SHARED_GPU") == "1"
+        if len(set(ids)) < self.nranks and not dry_run:
+            raise RuntimeError(f"ladder pipeline: ranks share a GPU ({ids}); one rank per GPU is required outside the dry-run "
+                               f"backend (gloo) / HENS_PIPE_SHARED_GPU=1")
 
     @staticmethod
     def _raise_if_any(results, what):

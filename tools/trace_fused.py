@@ -13,9 +13,15 @@ from eryn_amd import _lib
 T, W, D = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (16, 4096, 32)))
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 3          # 3: fused kernel, 1: first half-step kernel
 mu, invcov, cov = problem(D)
-eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024)
+import os
+PIPE = bool(os.environ.get("TRACE_PIPE"))              # the same shape as a 1-rank ladder pipeline (k_split1_pt<PIPE>)
+eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, rung_range=(0, T) if PIPE else None,
+                  adaptation_delay=int(os.environ.get("PIPE_DELAY", "0")) if PIPE else 0)
 eng.upload(np.random.RandomState(1).randn(T, W, D), betas=ladder(D, T))
 eng.eval_state()
+if PIPE:
+    from eryn_amd.ladder import LadderPipeline
+    LadderPipeline.connect_local([eng])
 eng.step(200)
 eng.synchronize()
 _lib.check(eng.lib.hens_debug_trace(eng.ctx, mode, None, 0, None), eng.ctx)
