@@ -66,7 +66,7 @@ def static_json(name):
         return None
 
 
-def cpu_baseline(T, W, D, seconds=12.0):
+def cpu_baseline(T, W, D, seconds=12.0, max_iters=200):
     """Eryn-faithful NumPy restatement (oracle/, pinned bit-exact to the reference) timed on the host cores on a
     bounded sample of the same workload."""
     from oracle import eryn_oracle as orc
@@ -81,7 +81,7 @@ def cpu_baseline(T, W, D, seconds=12.0):
         o.iteration()
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 200:
+        if dt >= seconds or n >= max_iters:
             break
     threads = 1
     try:
@@ -94,9 +94,19 @@ def cpu_baseline(T, W, D, seconds=12.0):
                      f"(BLAS threads={threads}, os.cpu_count()={os.cpu_count()}), {dt:.1f} s"}
     ratio = static_json("cpu_reference_ratio.json")      # measured where /root/reference can be imported; not in this run
     if ratio:
-        out["reference_over_port"] = {"value": ratio.get("reference_over_port"), "source": "profiles/cpu_reference_ratio.json "
-                                      "(static: tools/measure_reference_ratio.py in the build container)"}
+        shape = (ratio.get("shapes") or {}).get(f"{T}x{W}x{D}")
+        val = shape["reference_over_port"] if shape else (ratio.get("reference_over_port") if (T, W, D) == (16, 4096, 32) else None)
+        if val is not None:
+            out["reference_over_port"] = {"value": val, "source": "profiles/cpu_reference_ratio.json (static: "
+                                          "tools/measure_reference_ratio.py in the build container, this shape)"}
     return out
+
+
+def cpu_baselines_other(seconds):
+    """the CPU path beside the GPU figure for the other shapes too - BASELINE config 1 (the reference's own
+    CPU-runnable case: ntemps=1, nwalkers=32, ndim=5) and one GPU's shard of config 3 (8 x 16384 x 64, >= 3 iterations)."""
+    return {"config_1": cpu_baseline(1, 32, 5, seconds=min(seconds, 3.0), max_iters=2000),
+            "config_3_shard": cpu_baseline(8, 16384, 64, seconds=seconds, max_iters=12)}
 
 
 def moved_bytes(kind, tw, D, acc):
@@ -251,6 +261,8 @@ def run_single(args):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(T, W, D, seconds=args.cpu_seconds)
         out["vs_cpu"] = value / out["cpu_baseline"]["value"]
+        if (T, W, D) == (16, 4096, 32):
+            out["cpu_baseline_other_configs"] = cpu_baselines_other(min(args.cpu_seconds, 8.0))
     return out
 
 

@@ -101,6 +101,7 @@ SIGNATURES = {
     "hens_rj_step": (C.c_int, [_P, C.c_int64]),
     "hens_rj_get_counters": (C.c_int, [_P, _P, _P, _P]),
     "hens_get_iteration": (C.c_int, [_P, _P]),
+    "hens_set_iteration": (C.c_int, [_P, C.c_int64]),
     "hens_debug_draws": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hens_version": (C.c_char_p, []),
     "hens_device_count": (C.c_int, []),

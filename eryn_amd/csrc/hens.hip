@@ -2260,6 +2260,20 @@ int hens_set_adapt_time(hens_ctx* ctx, int64_t t) {
     return HENS_OK;
 }
 
+int hens_set_iteration(hens_ctx* ctx, int64_t iter) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (iter < 0) return fail(c, HENS_ERR_INVALID, "iteration counter < 0");
+    if (pipe_active(c) && c->pipe.sweep > 0)
+        return fail(c, HENS_ERR_STATE, "the iteration counter of a pipeline rank that has stepped cannot be moved");
+    if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    spec_cancel(c);                           // (a speculative plan of the old counter's successors)
+    c->win_count = 0;
+    c->iter = (uint64_t)iter;                 // (the round-key window re-plans itself when the chain has left it)
+    return HENS_OK;
+}
+
 int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");

@@ -208,6 +208,11 @@ class HipEnsemble:
         check(self.lib.hens_debug_permutation(self.ctx, int(which), int(rung), int(it), ptr(out)), self.ctx)
         return out
 
+    def set_iteration(self, it):
+        """Resume: move the Philox iteration counter (hens_set_iteration) - with the same seed, an uploaded state and the
+        adaptation time restored, ``step`` continues a stored chain bit for bit."""
+        check(self.lib.hens_set_iteration(self.ctx, int(it)), self.ctx)
+
     def iteration(self):
         """Index of the next Philox iteration ``step`` will run."""
         n = C.c_int64(0)

@@ -23,7 +23,8 @@ from .state import State
 class EnsembleSampler:
     def __init__(self, nwalkers, ndims, log_like_fn, priors, tempering_kwargs={}, branch_names=None,
                  nleaves_max=1, moves=None, args=None, kwargs=None, backend=None, vectorize=True, periodic=None,
-                 fill_zero_leaves_val=-1e300, rng="numpy", seed=None, device_id=0, info={}, **unused):
+                 fill_zero_leaves_val=-1e300, rng="numpy", seed=None, device_id=0, info={}, num_repeats_in_model=1,
+                 num_repeats_rj=1, **unused):
         # -- shapes: a single branch with one leaf (ensemble.py:265-317 normalises to dicts)
         if isinstance(ndims, dict):
             if len(ndims) != 1:
@@ -51,6 +52,11 @@ class EnsembleSampler:
             log_like_fn = HostLikelihood(log_like_fn, int(ndims), args=args, kwargs=kwargs, vectorize=vectorize,
                                          fill_value=fill_zero_leaves_val)
         self.nwalkers, self.ndim = int(nwalkers), int(ndims)
+        # ensemble.py:243-256: the in-model step runs num_repeats_in_model times per sampler iteration (num_repeats_rj belongs to
+        # the between-model step, which a single fixed-dimension branch does not have: kept for the constructor contract)
+        self.num_repeats_in_model, self.num_repeats_rj = int(num_repeats_in_model), int(num_repeats_rj)
+        if self.num_repeats_in_model < 1 or self.num_repeats_rj < 1:
+            raise ValueError("num_repeats_in_model / num_repeats_rj must be >= 1")
         self.branch_names = ["model_0"] if branch_names is None else list(branch_names)
         self.ndims = {self.branch_names[0]: self.ndim}
         self.nleaves_max = {self.branch_names[0]: 1}
@@ -114,6 +120,7 @@ class EnsembleSampler:
             raise NotImplementedError("all device stretch moves must share one scale a")
         if seed is None:
             seed = int(np.random.randint(0, 2**31 - 1)) if rng == "philox" else 0
+        self.seed = int(seed)
         self.engine = HipEnsemble(self.ntemps, self.nwalkers, self.ndim, log_like_fn, lo, hi, a=a_vals.pop(),
                                   tempered=tc is not None, live_dangerously=live,
                                   fill_value=fill_zero_leaves_val, seed=seed, device_id=device_id, **kw)
@@ -229,28 +236,46 @@ class EnsembleSampler:
         model = self.get_model()
 
         if self.rng == "philox":
-            yield from self._sample_philox(state, iterations, thin_by, store)
+            yield from self._sample_philox(state, iterations, thin_by, store, tune)
             return
 
         for _ in range(iterations):
             for _ in range(thin_by):
                 accepted = np.zeros((self.ntemps, self.nwalkers))
-                move = self._random.choice(self.moves, p=self.weights)          # ensemble.py:971
-                state, accepted_out = move.propose(model, state)
-                accepted += accepted_out
-                swaps = tc.swaps_accepted if self.ntemps > 1 else None
-                state.random_state = self.random_state
+                for _repeat in range(self.num_repeats_in_model):                # ensemble.py:969-984
+                    move = self._random.choice(self.moves, p=self.weights)      # ensemble.py:971
+                    state, accepted_out = move.propose(model, state)
+                    accepted += accepted_out
+                    swaps = tc.swaps_accepted if self.ntemps > 1 else None
+                    state.random_state = self.random_state
+                    if tune:
+                        move.tune(state, accepted_out)
             if store:
                 self.backend.save_step(state, accepted, swaps_accepted=swaps)
             self._previous_state = state
             yield state
 
-    def _sample_philox(self, state, iterations, thin_by, store):
+    def philox_checkpoint(self):
+        """What a stored State carries as ``random_state`` in Philox mode: the device draws are a pure function of (seed,
+        iteration, rung, walker), so (seed, iteration counter, adaptation time) is the whole generator state - the device-side
+        form of the reference's per-step checkpoint of R (backends/backend.py:1014-1091, ensemble.py:605-647)."""
+        tc = self.temperature_control
+        return ("philox", self.seed, int(self.engine.iteration()), 0 if tc is None else int(tc.time))
+
+    def _sample_philox(self, state, iterations, thin_by, store, tune=False):
         eng, tc, name = self.engine, self.temperature_control, self.branch_names[0]
         eng.upload(state.branches[name].coords[:, :, 0, :], state.log_like, state.log_prior,
                    None if tc is None else tc.betas)
+        rs = state.random_state
+        if isinstance(rs, tuple) and len(rs) == 4 and rs[0] == "philox":      # resume a stored chain on its own stream
+            if int(rs[1]) != self.seed:
+                raise ValueError(f"the state was stored by a sampler with seed {rs[1]}, this one has seed {self.seed}")
+            eng.set_iteration(int(rs[2]))
+            if tc is not None:
+                tc.time = int(rs[3])
         if tc is not None:
             eng.set_adapt_time(tc.time)
+        reps = self.num_repeats_in_model
         st_move, mh_move = self._philox_moves
         # one context steps both moves of the mix: they must agree on the periodic parameters
         pers = [period_vector(m.periodic, name, self.ndim) for m in (st_move, mh_move) if m is not None]
@@ -264,12 +289,14 @@ class EnsembleSampler:
         for _ in range(iterations):
             # the reference stores the LAST thinned step's accept mask and swap counts (ensemble.py:968-979,
             # 1013-1024: `accepted` is re-zeroed every sub-iteration); the moves' own counters see every step
+            # (num_repeats_in_model device iterations make one sampler sub-iteration: its accept mask sums over the repeats,
+            #  ensemble.py:968-975)
             mid, mid_mh = prev, prev_mh
             if thin_by > 1:
-                eng.step(thin_by - 1)
+                eng.step((thin_by - 1) * reps)
                 mid = eng.counters()
                 mid_mh = eng.mh_counters() if mh_move is not None else None
-            eng.step(1)
+            eng.step(reps)
             x, L, P, betas = eng.download()
             c = eng.counters()
             accepted = c["accepted"] - mid["accepted"]
@@ -290,7 +317,11 @@ class EnsembleSampler:
                 swaps = c["swaps_last"]
             prev = c
             state = State({name: x[:, :, None, :]}, inds={name: inds}, log_like=L, log_prior=P,
-                          betas=None if tc is None else betas, random_state=None)
+                          betas=None if tc is None else betas, random_state=self.philox_checkpoint())
+            if tune:                               # (once per stored step: the per-repeat masks stay on the device)
+                for m in (st_move, mh_move):
+                    if m is not None:
+                        m.tune(state, accepted)
             if store:
                 self.backend.save_step(state, accepted, swaps_accepted=swaps)
             self._previous_state = state

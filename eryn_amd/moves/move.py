@@ -61,5 +61,10 @@ class Move:
     def compute_log_posterior_basic(self, logl, logp):
         return logl + logp
 
+    def tune(self, state, accepted):
+        """Place holder for tuning, called by the sampler after every proposal when ``tune=True`` (move.py:459-470,
+        ensemble.py:983-984)."""
+        pass
+
     def propose(self, model, state):
         raise NotImplementedError("The proposal must be implemented by subclasses")

@@ -359,6 +359,13 @@ int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, in
  * context so far, by hens_step or by the parity API). */
 int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out);
 
+/* Resume: set the Philox iteration counter.  The device draws are a pure function of (seed, iteration, global rung,
+ * walker), so a chain continues bit-identically from an uploaded State when the counter (and the adaptation time,
+ * hens_set_adapt_time) are restored to the values that State was taken at - the device-side form of the reference's
+ * random_state checkpoint (backends/backend.py:1014-1091 stores R's state with every step, ensemble.py:605-647 restores
+ * it).  Not on a connected pipeline rank (the ranks' sweep counters would have to move together). */
+int hens_set_iteration(hens_ctx* ctx, int64_t iter);
+
 /* Debug / parity: the Philox draws hens_step consumes in iteration `iter` (a pure function of seed, iteration,
  * global rung and walker), exported in a form that maps one-to-one onto the reference's draws so that a
  * production iteration can be replayed through the CPU oracle (tests/test_hip_replay.py):

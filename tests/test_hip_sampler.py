@@ -180,3 +180,68 @@ def test_python_callable_likelihood_reproduces_reference_chain(name, golden_dir)
             np.testing.assert_allclose(state.betas, fx[pre + "betas"], rtol=1e-12, atol=0)
         it += 1
     assert np.array_equal(s.moves[0].accepted, fx["accepted_total"])
+
+
+def test_num_repeats_in_model_and_thinning_reproduce_reference_chain(golden_dir):
+    """ensemble.py:243-256, 963-1045: num_repeats_in_model = 3 proposals per sub-iteration, thin_by = 2 sub-iterations per
+    stored step - the fixture was captured from the reference's own sampler (tests/golden/make_golden_repeats.py)."""
+    fx = np.load(os.path.join(golden_dir, "r1_repeats3_thin2.npz"))
+    T, W, D, n = int(fx["T"]), int(fx["W"]), int(fx["D"]), int(fx["nsteps"])
+    box = float(fx["box"])
+    np.random.seed(int(fx["seed_construct"]))
+    priors = ProbDistContainer({i: uniform_dist(-box, box) for i in range(D)})
+    tuned = []
+
+    s = EnsembleSampler(W, D, GaussianLikelihood(fx["mu"], fx["invcov"]), priors, tempering_kwargs=dict(ntemps=T),
+                        num_repeats_in_model=int(fx["repeats"]))
+    s.moves[0].tune = lambda state, accepted: tuned.append(accepted.copy())       # the reference's hook (ensemble.py:983-984)
+    np.random.seed(int(fx["seed_run"]))
+    it = 0
+    for state in s.sample(fx["x0"], iterations=n, thin_by=int(fx["thin_by"]), store=True, tune=True):
+        pre = f"it{it}_"
+        assert np.array_equal(state.branches["model_0"].coords[:, :, 0, :], fx[pre + "x"]), f"positions differ at stored step {it}"
+        assert np.array_equal(state.log_prior, fx[pre + "P"])
+        np.testing.assert_allclose(state.log_like, fx[pre + "L"], rtol=1e-11, atol=0)
+        np.testing.assert_allclose(state.betas, fx[pre + "betas"], rtol=1e-12, atol=0)
+        assert np.array_equal(s.temperature_control.swaps_accepted, fx[pre + "swaps_accepted"])
+        assert np.array_equal(s.backend.accepted, fx[pre + "backend_accepted"])
+        assert np.array_equal(s.backend.swaps_accepted, fx[pre + "backend_swaps"])
+        it += 1
+    assert np.array_equal(s.moves[0].accepted, fx["move_accepted"]) and s.moves[0].num_proposals == int(fx["num_proposals"])
+    assert len(tuned) == int(fx["num_proposals"]) and np.array_equal(sum(tuned), fx["move_accepted"])
+    assert np.array_equal(s.get_chain()["model_0"][:, :, :, 0, :], fx["chain"])
+
+
+@pytest.mark.parametrize("T,W,D,reps,thin", [(4, 256, 8, 1, 1), (8, 512, 32, 3, 2), (1, 64, 8, 1, 3)])
+def test_philox_chain_resumes_bit_identically_from_a_stored_state(T, W, D, reps, thin):
+    """The device-side form of the reference's random_state checkpoint (backends/backend.py:1014-1091, ensemble.py:605-647):
+    a stored State carries (seed, Philox iteration counter, adaptation time); a NEW sampler object with the same seed continues
+    the chain from it bit for bit (hens_set_iteration)."""
+    rs = np.random.RandomState(3)
+    A = rs.randn(D, D)
+    mu, invcov = 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    x0 = np.random.RandomState(1).randn(T, W, D)
+
+    def sampler():
+        kw = dict(tempering_kwargs=dict(ntemps=T)) if T > 1 else {}
+        return EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=77,
+                               num_repeats_in_model=reps, **kw)
+
+    a = sampler()
+    whole = [State(st, copy=True) for st in a.sample(x0 if T > 1 else x0[0], iterations=9, thin_by=thin, store=True)]
+    b = sampler()
+    first = [State(st, copy=True) for st in b.sample(x0 if T > 1 else x0[0], iterations=4, thin_by=thin, store=True)]
+    assert first[-1].random_state == whole[3].random_state and first[-1].random_state[0] == "philox"
+    assert first[-1].random_state[2] == 4 * thin * reps
+    c = sampler()                                                       # a new context: nothing but the stored State travels
+    rest = [State(st, copy=True) for st in c.sample(first[-1], iterations=5, thin_by=thin, store=True)]
+    for k, (u, v) in enumerate(zip(whole, first + rest)):
+        for f in ("log_like", "log_prior", "betas"):
+            fu, fv = getattr(u, f), getattr(v, f)
+            assert (fu is None and fv is None) or np.array_equal(fu, fv), f"{f} differs at stored step {k}"
+        assert np.array_equal(u.branches["model_0"].coords, v.branches["model_0"].coords), f"positions differ at stored step {k}"
+        assert u.random_state == v.random_state
+    with pytest.raises(ValueError):                                     # another seed is another stream
+        EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=78, num_repeats_in_model=reps,
+                        **(dict(tempering_kwargs=dict(ntemps=T)) if T > 1 else {})).run_mcmc(first[-1], 1)

@@ -192,3 +192,34 @@ def test_periodic_fixtures_take_both_branches_of_the_distance(golden_dir):
     assert np.all(np.abs(d[:, idx]) <= per[idx] / 2.0 + 1e-12) and not np.array_equal(d, c - s)
     q = orc.periodic_wrap(np.array([[-0.25, 7.0, -3.0, 1.0]]), per)
     assert np.array_equal(q, np.array([[-0.25 % per[0], 7.0, -3.0 % 1.5, 1.0]]))
+
+
+def test_oracle_reproduces_reference_sampler_loop_with_repeats_and_thinning(golden_dir):
+    """ensemble.py:963-1045 with num_repeats_in_model = 3 and thin_by = 2 (tests/golden/make_golden_repeats.py): one stored
+    step = thin_by x repeats proposals, each with its own move choice from R; the backend's accept mask is the LAST thinned
+    sub-iteration's, summed over its repeats, the stored swap counts the last repeat's."""
+    fx = np.load(os.path.join(golden_dir, "r1_repeats3_thin2.npz"))
+    T, W, D = int(fx["T"]), int(fx["W"]), int(fx["D"])
+    reps, thin, box = int(fx["repeats"]), int(fx["thin_by"]), float(fx["box"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    o = orc.OracleSampler(fx["x0"], lambda x: orc.gaussian_log_like(x, mu, invcov), np.full(D, -box), np.full(D, box),
+                          np.random.RandomState(int(fx["seed_construct"])), np.random.RandomState(int(fx["seed_run"])),
+                          betas=orc.make_ladder(D, ntemps=T))
+    backend_acc, backend_sw = np.zeros((T, W)), np.zeros(T - 1)
+    for it in range(int(fx["nsteps"])):
+        for _ in range(thin):
+            accepted = np.zeros((T, W))
+            for _ in range(reps):
+                accepted += o.iteration()
+        backend_acc += accepted
+        backend_sw += o.swaps_accepted
+        pre = f"it{it}_"
+        _same(o.x, fx[pre + "x"], pre + "x")
+        _same(o.L, fx[pre + "L"], pre + "L")
+        _same(o.P, fx[pre + "P"], pre + "P")
+        _same(o.betas, fx[pre + "betas"], pre + "betas")
+        _same(o.swaps_accepted, fx[pre + "swaps_accepted"], pre + "swaps")
+        _same(backend_acc, fx[pre + "backend_accepted"], pre + "backend accepted")
+        _same(backend_sw, fx[pre + "backend_swaps"], pre + "backend swaps")
+    _same(o.accepted, fx["move_accepted"], "move.accepted")
+    assert o.num_proposals == int(fx["num_proposals"]) == int(fx["nsteps"]) * thin * reps
