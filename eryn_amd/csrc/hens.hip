@@ -2244,9 +2244,11 @@ int hens_reset_counters(hens_ctx* ctx) {
     HIPCHK(c, hipMemsetAsync(c->swaps_total, 0, (size_t)c->T * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->swaps_last, 0, (size_t)c->T * 8, c->stream));
     if (c->accepted_mh) HIPCHK(c, hipMemsetAsync(c->accepted_mh, 0, (size_t)c->Tl * c->W * 4, c->stream));
+    if (c->rj_acc_bd) HIPCHK(c, hipMemsetAsync(c->rj_acc_bd, 0, (size_t)c->Tl * c->W * 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->num_proposals = 0;
     c->num_proposals_mh = 0;
+    c->rj_num_mh = c->rj_num_bd = 0;
     return HENS_OK;
 }
 
@@ -2512,6 +2514,11 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
     return HENS_OK;
 }
 
+// branch of iteration `it`'s birth / death move (ensemble.py:988-990, "separate_branches"): one counter-based uniform
+static int rj_branch_of(const hens_ctx_impl* c, uint64_t it) {
+    return std::min(c->rj.nb - 1, (int)(move_uniform(c->cfg.seed ^ 0x9E3779B97F4A7C15ull, it) * c->rj.nb));
+}
+
 int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     hens_ctx_impl* c = CTX(ctx);
     int r = rj_ready(c);
@@ -2528,7 +2535,7 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
         c->rj_num_mh += 1;
         rj_cascade(c, 2 * c->iter, true);
         // one branch's birth / death move (ensemble.py:988-990, "separate_branches"), then swaps without adaptation
-        const int branch = std::min(c->rj.nb - 1, (int)(move_uniform(c->cfg.seed ^ 0x9E3779B97F4A7C15ull, c->iter) * c->rj.nb));
+        const int branch = rj_branch_of(c, c->iter);
         if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
         c->rj_num_bd += 1;
         rj_cascade(c, 2 * c->iter + 1, false);
@@ -2537,6 +2544,62 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;
+    // the reference raises "The likelihood function is returning Nan." / on an infinite coordinate at once (ensemble.py:1258-
+    // 1262, 1542); here once per call: the template likelihood's flags are read back with the call's last launch
+    return check_flags(c, true);
+}
+
+int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh, int32_t* branch, int8_t* coin, uint32_t* sel,
+                        double* birth, double* u_bd, int32_t* slot_mh, double* uswap_mh, int32_t* slot_bd, double* uswap_bd) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || iter < 0) return fail(c, HENS_ERR_INVALID, "null context / negative iteration");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || c->rj.nb <= 0) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
+    if (!c->rj_have_scale) return fail(c, HENS_ERR_STATE, "in-model step scale not set (hens_rj_set_mh_scale)");
+    if (!step || !u_mh || !branch || !coin || !sel || !birth || !u_bd) return fail(c, HENS_ERR_INVALID, "null output");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W, IO = (size_t)c->rj.ind_off;
+    struct Scratch {
+        std::vector<void*> p;
+        ~Scratch() { for (void* q : p) (void)hipFree(q); }
+    } sc;
+    auto grab = [&](size_t bytes) -> void* {
+        void* q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(bytes, 8)) != hipSuccess) return nullptr;
+        sc.p.push_back(q);
+        return q;
+    };
+    RjDebugArgs a{};
+    a.M = c->rj;
+    a.step = (double*)grab(TW * IO * 8); a.u_mh = (double*)grab(TW * 8); a.coin = (int8_t*)grab(TW);
+    a.sel = (uint32_t*)grab(TW * 4); a.birth = (double*)grab(TW * RJ_ND * 8); a.u_bd = (double*)grab(TW * 8);
+    if (!a.step || !a.u_mh || !a.coin || !a.sel || !a.birth || !a.u_bd) return fail(c, HENS_ERR_HIP, "hens_rj_debug_draws: out of device memory");
+    a.iter = (uint64_t)iter; a.seed = c->cfg.seed;
+    a.Tl = c->Tl; a.W = c->W; a.rung_begin = c->cfg.rung_begin;
+    a.branch = rj_branch_of(c, (uint64_t)iter);
+    *branch = a.branch;
+    hipLaunchKernelGGL(k_rj_debug_draws, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(step, a.step, TW * IO * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(u_mh, a.u_mh, TW * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(coin, a.coin, TW, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(sel, a.sel, TW * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(birth, a.birth, TW * RJ_ND * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(u_bd, a.u_bd, TW * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (has_pt(c) && slot_mh && uswap_mh && slot_bd && uswap_bd) {       // the two cascades of the iteration (rj_cascade's keys)
+        const size_t n = (size_t)c->T * c->W;
+        int32_t* ds = (int32_t*)grab(n * 4);
+        double* du = (double*)grab(n * 8);
+        if (!ds || !du) return fail(c, HENS_ERR_HIP, "hens_rj_debug_draws: out of device memory");
+        for (int k = 0; k < 2; ++k) {
+            hipLaunchKernelGGL(k_debug_pt, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, ds, du, c->T, c->W, c->idx_bits,
+                               c->cfg.seed, (uint64_t)(2 * iter + k));
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(k ? slot_bd : slot_mh, ds, n * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(k ? uswap_bd : uswap_mh, du, (size_t)(c->T - 1) * c->W * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
     return HENS_OK;
 }
 

@@ -2556,7 +2556,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
     if (!PIPE && walking) store_accepted();
 
-    if (PIPE) {
+    if constexpr (PIPE) {
         const PipeBox me = pipe_box(A.box, TG, W, D);
         // ---- my columns leave for the cold neighbour: its workgroup with the same index may start its walk -----------------
         if (has_bot) {

@@ -80,6 +80,29 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, int k) {
     return __builtin_ctz(m);
 }
 
+// ---- the Philox draws of the production path (hens_rj_step), one definition for k_rj and for hens_rj_debug_draws ------------
+// in-model step of record coordinate i (a unit normal; the caller scales it): gaussian.py:265-268
+__device__ __forceinline__ double rj_unit_normal(uint64_t seed, uint64_t it, uint32_t wid, int i) {
+    return mh_normal_pair(seed, it, wid, (uint32_t)i | 0x10000u).x;        // one Box-Muller pair per coordinate, first value used
+}
+// birth / death: .x bit 0 = the +1 / -1 coin (distgenrj.py:63-66), .y = selector of the leaf among the candidates (:97-112)
+__device__ __forceinline__ u4 rj_bd_raw(uint64_t seed, uint64_t it, uint32_t wid) {
+    return philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BD}, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ int rj_pick(uint32_t sel, int cnt) { return (int)__umulhi(sel, (uint32_t)cnt); }   // uniform on [0, cnt)
+// coordinate d of a leaf born from the (uniform) prior: prior.py:60-66
+__device__ __forceinline__ double rj_birth_coord(uint64_t seed, uint64_t it, uint32_t wid, int d, double lo, double hi) {
+    const u4 e = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BIRTH | ((uint32_t)d << 8)},
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    return u01(e.x, e.y) * (hi - lo) + lo;
+}
+// accept uniform of the in-model (mode 1) / birth-death (mode 2) move: mh.py:157, rj.py:332
+__device__ __forceinline__ double rj_accept_uniform(uint64_t seed, uint64_t it, uint32_t wid, int mode) {
+    const u4 d = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_ACC | ((uint32_t)mode << 8)},
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    return u01(d.x, d.y);
+}
+
 constexpr int RJ_WAVES = 4;        // walkers per workgroup
 
 __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
@@ -120,9 +143,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
                 double st;
                 if (A.step) {
                     st = A.step[(size_t)gw * M.ind_off + i];
-                } else {                                             // one Box-Muller pair per coordinate, first value used
-                    const double2 z = mh_normal_pair(A.seed, A.iter, wid, (uint32_t)i | 0x10000u);
-                    st = M.mh_scale[b][d] * z.x;
+                } else {
+                    st = M.mh_scale[b][d] * rj_unit_normal(A.seed, A.iter, wid, i);
                 }
                 q[i] = cur[i] + st;
             }
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             c = A.change[gw];
             lf = A.leaf[gw];
         } else {
-            const u4 d = philox4x32_10(u4{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), wid, PURPOSE_RJ_BD}, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+            const u4 d = rj_bd_raw(A.seed, A.iter, wid);
             c = (d.x & 1u) ? +1 : -1;                                 // distgenrj.py:63-66
             if (M.nlmin[B] == M.nl[B]) c = 0;
             else if (nold == M.nlmin[B]) c = +1;                      // :69-73
@@ -143,7 +165,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             const uint32_t full = M.nl[B] >= 32 ? 0xffffffffu : ((1u << M.nl[B]) - 1u);
             const uint32_t pool_bits = c > 0 ? (~mask_old[B] & full) : mask_old[B];
             const int cnt = __builtin_popcount(pool_bits);
-            lf = cnt ? nth_set_bit(pool_bits, (int)__umulhi(d.y, (uint32_t)cnt)) : 0;    // uniform over the candidates (:97-112)
+            lf = cnt ? nth_set_bit(pool_bits, rj_pick(d.y, cnt)) : 0;                    // uniform over the candidates (:97-112)
         }
         if (c < 0) {                                                  // death: factor +log q(leaf) (:188-197)
             mask[B] &= ~(1u << lf);
@@ -161,9 +183,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
                 if (A.birth) {
                     v = A.birth[(size_t)gw * RJ_ND + d];
                 } else {
-                    const u4 e = philox4x32_10(u4{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), wid, PURPOSE_RJ_BIRTH | ((uint32_t)d << 8)},
-                                               (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-                    v = u01(e.x, e.y) * (M.hi[B][d] - M.lo[B][d]) + M.lo[B][d];          // prior.py:60-66
+                    v = rj_birth_coord(A.seed, A.iter, wid, d, M.lo[B][d], M.hi[B][d]);
                 }
                 in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
                 if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
@@ -305,9 +325,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     if (A.u_acc) {
         lu = log(A.u_acc[gw]);
     } else {
-        const u4 d = philox4x32_10(u4{(uint32_t)A.iter, (uint32_t)(A.iter >> 32), wid, PURPOSE_RJ_ACC | ((uint32_t)A.mode << 8)},
-                                   (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
-        lu = log(u01(d.x, d.y));
+        lu = log(rj_accept_uniform(A.seed, A.iter, wid, A.mode));
     }
     const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
     if (keep) {                                                        // Move.update (move.py:472-703)
@@ -320,6 +338,39 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     }
     if (lane == 0 && A.keep_out) A.keep_out[gw] = keep ? 1 : 0;
 #undef RJ_LDS_SYNC
+}
+
+// hens_rj_debug_draws: everything hens_rj_step draws per walker in iteration `iter`, as values (one thread per walker)
+struct RjDebugArgs {
+    RjModel M;
+    double* step;        // [Tl][W][ind_off] in-model step of every coordinate slot (scale x unit normal), record layout
+    double* u_mh;        // [Tl][W] accept uniform of the in-model move
+    int8_t* coin;        // [Tl][W] +1 / -1 before the edge rule (distgenrj.py:63-66)
+    uint32_t* sel;       // [Tl][W] leaf selector: the candidate of index (sel * cnt) >> 32 in ascending slot order
+    double* birth;       // [Tl][W][3] coordinates a leaf born in `branch` would get
+    double* u_bd;        // [Tl][W] accept uniform of the birth / death move
+    uint64_t iter, seed;
+    int32_t Tl, W, rung_begin, branch;
+};
+__global__ void k_rj_debug_draws(const RjDebugArgs A) {
+    const int64_t gw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gw >= (int64_t)A.Tl * A.W) return;
+    const RjModel& M = A.M;
+    const int tl = (int)(gw / A.W);
+    const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
+    for (int i = 0; i < M.ind_off; ++i) {
+        int b = 0;
+        while (b + 1 < M.nb && i >= M.off[b + 1]) ++b;
+        const int d = (i - M.off[b]) % RJ_ND;
+        A.step[(size_t)gw * M.ind_off + i] = M.mh_scale[b][d] * rj_unit_normal(A.seed, A.iter, wid, i);
+    }
+    A.u_mh[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_MH);
+    const u4 d = rj_bd_raw(A.seed, A.iter, wid);
+    A.coin[gw] = (d.x & 1u) ? +1 : -1;
+    A.sel[gw] = d.y;
+    for (int k = 0; k < RJ_ND; ++k)
+        A.birth[(size_t)gw * RJ_ND + k] = rj_birth_coord(A.seed, A.iter, wid, k, M.lo[A.branch][k], M.hi[A.branch][k]);
+    A.u_bd[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_BD);
 }
 
 }  // namespace hens

@@ -155,6 +155,23 @@ class RJEngine:
     def step(self, n_iters):
         check(self.lib.hens_rj_step(self.ctx, int(n_iters)), self.ctx)
 
+    def debug_draws(self, it):
+        """Everything ``step`` draws in iteration ``it`` (include/hipensemble.h: hens_rj_debug_draws)."""
+        T, W = self.T, self.W
+        out = dict(step=np.empty((T, W, self.ncoord)), u_mh=np.empty((T, W)), coin=np.empty((T, W), dtype=np.int8),
+                   sel=np.empty((T, W), dtype=np.uint32), birth=np.empty((T, W, 3)), u_bd=np.empty((T, W)),
+                   slot_mh=np.empty((T, W), dtype=np.int32), uswap_mh=np.empty((max(T - 1, 1), W)),
+                   slot_bd=np.empty((T, W), dtype=np.int32), uswap_bd=np.empty((max(T - 1, 1), W)))
+        br = C.c_int32(0)
+        check(self.lib.hens_rj_debug_draws(self.ctx, int(it), ptr(out["step"]), ptr(out["u_mh"]), C.byref(br), ptr(out["coin"]),
+                                           ptr(out["sel"]), ptr(out["birth"]), ptr(out["u_bd"]), ptr(out["slot_mh"]),
+                                           ptr(out["uswap_mh"]), ptr(out["slot_bd"]), ptr(out["uswap_bd"])), self.ctx)
+        out["branch"] = int(br.value)
+        return out
+
+    def iteration(self):
+        return self.eng.iteration()
+
     def synchronize(self):
         self.eng.synchronize()
 
@@ -242,10 +259,18 @@ class RJEnsembleSampler:
                                seed=seed, device_id=device_id, adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag,
                                adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation)
         if rng == "philox":
+            # the device draws axis-aligned steps (hens_rj_set_mh_scale: three standard deviations per branch): a covariance
+            # with off-diagonal terms is another proposal - refused rather than silently reduced to its diagonal
+            for k in self.branch_names:
+                if np.any(moves.cov[k] != np.diag(np.diag(moves.cov[k]))):
+                    raise NotImplementedError("rng='philox' takes diagonal leaf covariances (rng='numpy' runs the reference's "
+                                              "multivariate_normal draws with any covariance)")
             self.engine.set_mh_scale(np.stack([np.sqrt(np.diag(moves.cov[k])) for k in self.branch_names]))
         moves.accepted = np.zeros((self.ntemps, self.nwalkers))
         self.rj_accepted = [np.zeros((self.ntemps, self.nwalkers)) for _ in self.branch_names]
         self.rj_num_proposals = [0 for _ in self.branch_names]
+        # rng="philox": the device counts the birth / death move over all branches together
+        self.rj_accepted_all, self.rj_num_proposals_all = np.zeros((self.ntemps, self.nwalkers)), 0
         self._random = np.random.mtrand.RandomState()
         self._random.set_state(np.random.get_state())          # R := snapshot of the global stream (ensemble.py:604,651-652)
         self.iteration, self.chain = 0, []
@@ -363,6 +388,10 @@ class RJEnsembleSampler:
         if self.rng == "philox":
             c = self.engine.counters()
             tc.time, tc.swaps_accepted = c["adapt_time"], c["swaps_last"]
+            # the moves' own counters (move.py:404-421), cumulative over the context's life like the device's
+            mv = self.moves[0]
+            mv.accepted, mv.num_proposals = c["accepted_mh"].copy(), c["num_mh"]
+            self.rj_accepted_all, self.rj_num_proposals_all = c["accepted_bd"].copy(), c["num_bd"]
         self._previous_state = out
         return out
 

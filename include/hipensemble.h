@@ -355,6 +355,22 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
 int hens_rj_step(hens_ctx* ctx, int64_t n_iters);
 int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, int64_t* num_bd);
 
+/* Debug / parity: everything hens_rj_step draws in iteration `iter` (a pure function of seed, iteration, global rung and
+ * walker), in a form that maps onto the reference's draws so that the production leaf-packing path can be replayed through
+ * the CPU oracle (tests/test_hip_rj.py):
+ *   step [Tl][W][ind_off]   the in-model Gaussian step of every coordinate slot, record layout (gaussian.py:265-268; only the
+ *                           active leaves' entries are consumed)
+ *   u_mh, u_bd [Tl][W]      accept uniforms of the two moves (mh.py:157, rj.py:332)
+ *   branch                  the branch of the birth / death move (ensemble.py:988-990, "separate_branches")
+ *   coin [Tl][W] i8         +1 / -1 before the edge rule (distgenrj.py:63-73)
+ *   sel  [Tl][W] u32        leaf selector: of `cnt` candidate slots in ascending order, the one of index (sel * cnt) >> 32
+ *                           (distgenrj.py:97-112)
+ *   birth [Tl][W][3]        coordinates of a leaf born in `branch` (generate_dist.rvs, prior.py:60-66)
+ *   slot_* [T][W], uswap_* [T-1][W]   column maps and swap uniforms of the cascade after the in-model move and of the one
+ *                           after the birth / death move, as in hens_debug_draws (tempering.py:526-541) */
+int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh, int32_t* branch, int8_t* coin, uint32_t* sel,
+                        double* birth, double* u_bd, int32_t* slot_mh, double* uswap_mh, int32_t* slot_bd, double* uswap_bd);
+
 /* The Philox iteration counter: the index of the NEXT iteration hens_step will run (iterations completed on this
  * context so far, by hens_step or by the parity API). */
 int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out);

@@ -177,6 +177,32 @@ class OracleRJSampler:
         self.rj_num_proposals = [0 for _ in self.branches]
         self.record, self.trace = record, []
 
+    # ---- draw sources: the reference's two streams, call for call in the reference's order.  A replay of the device's
+    # ---- production draws overrides these and nothing else (tests/test_hip_rj.py: hens_rj_step against this oracle) ------
+    def _draw_move_choice(self):
+        self.R.choice(1, p=np.ones(1))                                             # ensemble.py:971 (one move: still a draw)
+
+    def _draw_steps(self, b, n):
+        return self.R.multivariate_normal(np.zeros(b.ndim), b.cov, size=n)         # gaussian.py:265-268 (factor None)
+
+    def _draw_accept(self, which):
+        return self.R.rand(self.T, self.W)                                         # mh.py:157 / rj.py:332
+
+    def _draw_branch(self, nb):
+        return int(self.R.choice(nb, p=np.full(nb, 1.0 / nb)))                     # ensemble.py:988-990, separate_branches
+
+    def _draw_coin(self, shape):
+        return self.R.choice([-1, +1], size=shape)                                 # distgenrj.py:63-66
+
+    def _draw_leaf(self, tt, w, candidates):
+        return self.R.choice(candidates)                                           # distgenrj.py:97-112
+
+    def _draw_birth(self, b, bt, bw):
+        return b.rvs(len(bt), self.G)                                              # generate_dist.rvs (prior.py:60-66), (t, w) order
+
+    def _draw_pair(self, j, W):
+        return self.G.permutation(W), self.G.permutation(W), self.G.uniform(size=W)    # tempering.py:526-535
+
     # ---- shared pieces ------------------------------------------------------------------------------------------
     def _logP(self, logl, logp):
         return base.tempered_log_posterior(logl, logp, self.st.betas)
@@ -201,9 +227,7 @@ class OracleRJSampler:
         arrays = [st.L, st.P] + [st.x[b.name] for b in self.branches] + [st.inds[b.name] for b in self.branches]
         for j, i in enumerate(range(T - 1, 0, -1)):                                # tempering.py:515-559
             dbeta = st.betas[i - 1] - st.betas[i]
-            iperm[j] = self.G.permutation(W)
-            i1perm[j] = self.G.permutation(W)
-            u[j] = self.G.uniform(size=W)
+            iperm[j], i1perm[j], u[j] = self._draw_pair(j, W)
             with np.errstate(divide="ignore"):
                 sel = dbeta * (st.L[i, iperm[j]] - st.L[i - 1, i1perm[j]]) > np.log(u[j])
             sel_all[j] = sel
@@ -230,19 +254,19 @@ class OracleRJSampler:
     # ---- in-model Gaussian move on the packed leaves (mh.py:56-193, gaussian.py:68-115, 260-270) -----------------------
     def mh_move(self, rec=None):
         st = self.st
-        self.R.choice(1, p=np.ones(1))                                             # ensemble.py:971 (one move: still a draw)
+        self._draw_move_choice()
         q, steps = {}, {}
         for b in self.branches:
             inds_here = np.where(st.inds[b.name])
             x0 = st.x[b.name][inds_here]
-            step = self.R.multivariate_normal(np.zeros(b.ndim), b.cov, size=len(x0))   # gaussian.py:265-268 (factor None)
+            step = self._draw_steps(b, len(x0))
             q[b.name] = st.x[b.name].copy()
             q[b.name][inds_here] = x0 + 1.0 * step
             steps[b.name] = step
         logp = compute_log_prior(q, st.inds, self.branches)                        # mh.py:120
         fix_logp_gibbs(logp, st.inds, [b.name for b in self.branches])             # mh.py:122-124 (every branch runs)
         logl = compute_log_like(q, st.inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
-        u_acc = self.R.rand(self.T, self.W)                                        # mh.py:157
+        u_acc = self._draw_accept("mh")
         accepted, lnpdiff = self._accept(np.zeros((self.T, self.W)), logl, logp, u_acc)
         if rec is not None:
             self._snapshot(rec, "pre_")
@@ -260,7 +284,7 @@ class OracleRJSampler:
     def rj_move(self, rec=None):
         st, T, W = self.st, self.T, self.W
         nb = len(self.branches)
-        bi = int(self.R.choice(nb, p=np.full(nb, 1.0 / nb)))                       # ensemble.py:988-990, separate_branches
+        bi = self._draw_branch(nb)
         b = self.branches[bi]
         inds = st.inds[b.name]
         nleaves = inds.sum(axis=-1)
@@ -271,15 +295,15 @@ class OracleRJSampler:
         leaf = np.full((T, W), -1, dtype=np.int64)
         birth = np.zeros((0, b.ndim))
         if b.nleaves_min != b.nleaves_max:
-            change = self.R.choice([-1, +1], size=nleaves.shape)                   # distgenrj.py:63-66
+            change = self._draw_coin(nleaves.shape)
             change = (change * ((nleaves != b.nleaves_min) & (nleaves != b.nleaves_max))
                       + (+1) * (nleaves == b.nleaves_min) + (-1) * (nleaves == b.nleaves_max))   # :69-73
             for tt in range(T):                                                    # :85-121, one draw per walker, in order
                 for w in range(W):
                     if change[tt, w] == +1:
-                        leaf[tt, w] = self.R.choice(np.where(~inds[tt, w])[0])
+                        leaf[tt, w] = self._draw_leaf(tt, w, np.where(~inds[tt, w])[0])
                     elif change[tt, w] == -1:
-                        leaf[tt, w] = self.R.choice(np.where(inds[tt, w])[0])
+                        leaf[tt, w] = self._draw_leaf(tt, w, np.where(inds[tt, w])[0])
             dt, dw = np.where(change == -1)                                        # deaths first (:188-197)
             dl = leaf[dt, dw]
             new_inds[b.name][dt, dw, dl] = False
@@ -287,7 +311,7 @@ class OracleRJSampler:
             bt, bw = np.where(change == +1)                                        # births (:199-214)
             bl = leaf[bt, bw]
             new_inds[b.name][bt, bw, bl] = True
-            birth = b.rvs(len(bt), self.G)
+            birth = self._draw_birth(b, bt, bw)
             q[b.name][bt, bw, bl] = birth
             np.add.at(factors, (bt, bw), -1 * b.leaf_logpdf(q[b.name][bt, bw, bl]))
         # edge factors (rj.py:236-270)
@@ -302,7 +326,7 @@ class OracleRJSampler:
         logp = compute_log_prior(q, new_inds, self.branches)                       # rj.py:300
         fix_logp_gibbs(logp, new_inds, [b.name])                                   # rj.py:302 (this branch only)
         logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
-        u_acc = self.R.rand(T, W)                                                  # rj.py:332
+        u_acc = self._draw_accept("rj")
         accepted, lnpdiff = self._accept(factors, logl, logp, u_acc)
         if rec is not None:
             self._snapshot(rec, "rjpre_")

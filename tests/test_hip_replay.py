@@ -95,6 +95,19 @@ def test_replay_diag_move_mix_axis_aligned():
     assert "mh" in kinds and "stretch" in kinds
 
 
+@pytest.mark.parametrize("T,W,D,like,weight", [(4, 512, 32, "dense", 0.5), (8, 256, 16, "dense", 1.0), (3, 200, 6, "diag", 0.6)])
+def test_replay_full_covariance_move_mix(T, W, D, like, weight):
+    """GaussianMove with a FULL covariance in production (gaussian.py:265-268: multivariate normal steps): k_mh_draw's
+    Box-Muller normals times the Cholesky factor (staged through LDS in the production launch), the step buffer and the MH
+    launch - held to the oracle like the isotropic / axis-aligned forms (a compile-time row width in record mode, a pure MH
+    chain, and a padded generic width)."""
+    rs = np.random.RandomState(21)
+    a = rs.randn(D, D)
+    chol = np.linalg.cholesky(0.02 * (a @ a.T / D + np.eye(D)))
+    kinds = _run_case(T, W, D, like_kind=like, box=20.0, calls=(3, 4), x_scale=0.7, mh=("full", chol, weight))
+    assert "mh" in kinds and (weight >= 1.0 or "stretch" in kinds)
+
+
 @pytest.mark.parametrize("T,W,D", [(3, 257, 8), (3, 33, 4), (5, 100, 5)])
 def test_replay_odd_sizes(T, W, D):
     """odd W (halves of ceil / floor size), W not a multiple of the tile, generic row widths"""

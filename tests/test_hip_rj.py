@@ -223,3 +223,135 @@ def test_rj_sampler_philox_mode():
     assert nl["gauss"].shape == (30, T, W) and nl["gauss"].max() <= 4 and nl["sine"].max() <= 3
     assert np.isfinite(last.log_like).all() and (nl["gauss"][-1] != 1).any()
     s.engine.close()
+
+
+# ---- the PRODUCTION path (hens_rj_step: what bench.py --workload cfg4 times) under the oracle -------------------------------
+def _replay_oracle_class():
+    from oracle import eryn_oracle_rj as orj
+
+    class ReplayRJ(orj.OracleRJSampler):
+        """The pinned RJ oracle with its draw SOURCES replaced by what hens_rj_debug_draws exports for an iteration - the
+        arithmetic, the order of operations and every decision stay the oracle's."""
+
+        def load(self, d, offsets):
+            self.d, self.offsets = d, offsets
+
+        def _draw_move_choice(self):
+            pass                                                     # (one in-model move: the device draws nothing for it)
+
+        def _draw_steps(self, b, n):
+            tt, ww, ll = np.where(self.st.inds[b.name])              # packed active leaves, (t, w, leaf) order
+            assert len(tt) == n
+            idx = self.offsets[b.name] + ll[:, None] * 3 + np.arange(3)
+            return self.d["step"][tt[:, None], ww[:, None], idx]
+
+        def _draw_accept(self, which):
+            return self.d["u_mh" if which == "mh" else "u_bd"]
+
+        def _draw_branch(self, nb):
+            assert 0 <= self.d["branch"] < nb
+            return self.d["branch"]
+
+        def _draw_coin(self, shape):
+            c = self.d["coin"].astype(np.int64)
+            assert c.shape == shape and set(np.unique(c)) <= {-1, 1}
+            return c
+
+        def _draw_leaf(self, tt, w, candidates):                     # uniform over the candidates, ascending slot order
+            return candidates[(int(self.d["sel"][tt, w]) * len(candidates)) >> 32]
+
+        def _draw_birth(self, b, bt, bw):
+            return self.d["birth"][bt, bw]
+
+        def _pt(self, adapt, rec):
+            self._casc = "mh" if adapt else "bd"                     # the cascade after the in-model move adapts (rj.py:381-382)
+            return super()._pt(adapt, rec)
+
+        def _draw_pair(self, j, W):
+            slot, u = self.d["slot_" + self._casc].astype(np.int64), self.d["uswap_" + self._casc]
+            i = self.T - 1 - j                                       # pair (i, i-1): column c meets slot[i][c] and slot[i-1][c]
+            for row in (slot[i], slot[i - 1]):
+                assert np.array_equal(np.sort(row), np.arange(W)), "a rung's column map must be a permutation"
+            return slot[i], slot[i - 1], u[j]
+
+    return ReplayRJ
+
+
+def _replay_rj(T, W, nl_max, nl_min, ndata, iters, seed, start_leaves=(2, 1), calls=None):
+    from oracle import eryn_oracle_rj as orj
+    from eryn_amd.moves.tempering import make_ladder
+    from eryn_amd.rj import RJEngine, TemplateBranch
+    rs = np.random.RandomState(seed)
+    t = np.linspace(-1, 1, ndata)
+    gauss_inj = np.array([[3.3, -0.2, 0.1], [2.6, -0.1, 0.1], [3.4, 0.0, 0.1], [2.9, 0.3, 0.1]])
+    sine_inj = np.array([[1.3, 10.1, 1.0], [0.8, 4.6, 1.2]])
+    sigma = 2.0
+    y = sum(a * np.exp(-((t - b) ** 2) / (2 * c ** 2)) for a, b, c in gauss_inj) + \
+        sum(a * np.sin(2 * np.pi * b * t + c) for a, b, c in sine_inj) + sigma * rs.randn(ndata)
+    boxes = {"gauss": [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)], "sine": [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]}
+    kinds = {"gauss": "pulse", "sine": "sine"}
+    scale = np.array([[1e-2, 1e-2, 1e-3], [1e-2, 1e-2, 1e-2]])
+    names = ["gauss", "sine"]
+    brs = [TemplateBranch(k, kinds[k], boxes[k], nl_max[i], nl_min[i]) for i, k in enumerate(names)]
+    eng = RJEngine(T, W, brs, t, y, sigma, seed=seed)
+    x = {k: np.zeros((T, W, nl_max[i], 3)) for i, k in enumerate(names)}
+    inds = {k: np.zeros((T, W, nl_max[i]), dtype=bool) for i, k in enumerate(names)}
+    inj = {"gauss": gauss_inj, "sine": sine_inj}
+    for i, k in enumerate(names):
+        for n in range(min(start_leaves[i], nl_max[i])):
+            x[k][:, :, n] = inj[k][n % len(inj[k])] + 1e-2 * rs.randn(T, W, 3) * [1, 1, 0.1 if k == "gauss" else 1]
+            inds[k][:, :, n] = True
+    betas0 = make_ladder(3 * sum(start_leaves), ntemps=T)
+    eng.upload(x, inds, betas=betas0)
+    eng.eval_state()
+    eng.set_mh_scale(scale)
+    x0, inds0, L0, P0, _ = eng.download()
+    okind = {"pulse": orj.KIND_PULSE, "sine": orj.KIND_SINE}
+    obr = [orj.Branch(k, okind[kinds[k]], boxes[k], nl_max[i], nl_min[i], cov=np.diag(scale[i] ** 2)) for i, k in enumerate(names)]
+    o = _replay_oracle_class()(obr, x0, inds0, t, y, sigma, None, None, betas0)
+    assert np.array_equal(o.st.P, P0)
+    np.testing.assert_allclose(L0, o.st.L, rtol=RTOL_L, atol=0)
+    offsets = {b.name: eng.off[i] for i, b in enumerate(brs)}
+    mh_acc, bd_acc, swaps_total, nbd, done = np.zeros((T, W)), np.zeros((T, W)), np.zeros(T - 1), [0, 0], 0
+    for n in (calls or (iters,)):
+        it0 = eng.iteration()
+        eng.step(n)
+        eng.synchronize()
+        for it in range(it0, it0 + n):
+            o.load(eng.debug_draws(it), offsets)
+            acc, bi, racc = o.iteration()
+            mh_acc += acc
+            bd_acc += racc
+            nbd[bi] += 1
+        done += n
+        x1, inds1, L1, P1, betas1 = eng.download()
+        what = f"hens_rj_step vs oracle after {done} iterations"
+        for k in names:
+            assert np.array_equal(inds1[k], o.st.inds[k]), f"{what}: leaf masks of {k}"
+            assert np.array_equal(x1[k], o.st.x[k]), f"{what}: coordinates of {k} (dead slots included)"
+        assert np.array_equal(P1, o.st.P), f"{what}: log-prior"
+        np.testing.assert_allclose(L1, o.st.L, rtol=RTOL_L, atol=0, err_msg=what)
+        np.testing.assert_allclose(betas1, o.st.betas, rtol=1e-13, atol=0, err_msg=what)
+        c = eng.counters()
+        assert np.array_equal(c["accepted_mh"], mh_acc) and np.array_equal(c["accepted_bd"], bd_acc), f"{what}: accept counters"
+        assert c["num_mh"] == done and c["num_bd"] == done
+        assert np.array_equal(c["swaps_last"], o.swaps_accepted), f"{what}: swap counts of the last cascade"
+    assert mh_acc.sum() > 0 and bd_acc.sum() > 0 and min(nbd) > 0, "both moves, both branches and both outcomes must occur"
+    eng.close()
+    return o
+
+
+@pytest.mark.parametrize("T,W,nl_max,nl_min,iters", [(4, 10, (3, 4), (0, 0), 8), (4, 10, (3, 4), (1, 0), 8), (3, 12, (10, 10), (0, 0), 6),
+                                                      (2, 64, (2, 2), (0, 1), 6)])
+def test_rj_production_step_replayed_through_the_oracle_small(T, W, nl_max, nl_min, iters):
+    """hens_rj_step - branch choice, in-model steps, birth / death coins, leaf choice, birth draws, accept uniforms, both
+    cascades and the adaptation - on the three rj fixtures' shapes (free leaf counts, a floor under one branch, a 10-leaf
+    budget) and a tight budget whose edge rule fires all the time.  A wrong branch, a mis-keyed birth draw or a leaf picked
+    from the wrong candidate list fails here."""
+    _replay_rj(T, W, nl_max, nl_min, ndata=60, iters=iters, seed=11, start_leaves=(2, 1), calls=(3, iters - 3))
+
+
+def test_rj_production_step_replayed_through_the_oracle_config4():
+    """BASELINE config 4 at full size (8 x 2048 walkers, 2 branches x 10 leaves, 500 data points): three iterations of
+    hens_rj_step replayed."""
+    _replay_rj(8, 2048, (10, 10), (0, 0), ndata=500, iters=3, seed=5, start_leaves=(4, 2))
