@@ -46,6 +46,7 @@ struct hens_ctx_impl {
     double* P[2] = {nullptr, nullptr};
     WalkerRec* wrec[2] = {nullptr, nullptr};   // the same three as one record per walker (two-launch iterations of hens_step)
     bool packed = false;             // wrec[cur] holds the state, L/P/loc[cur] are stale (inside hens_step only)
+    bool colmode = false;            // ... in the column order of iteration `iter` (StretchArgs::col), not by slot
     int cur = 0;                     // which of the double-buffered L/P/loc is current
     int parity = 0;                  // home half the NEXT iteration writes into
     double* betas[2] = {nullptr, nullptr};   // [T]; bcur is current
@@ -257,13 +258,13 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
 #define LAUNCH_FAST_P(DT, NW, PIPE, PER)                                                           \
     do {                                                                                           \
-        const size_t lds = fast_lds_bytes(DT, NW);                                                 \
+        const size_t lds = fast_lds_bytes(DT, NW) + (a.tab_lds ? (size_t)c->W * 4 : 0);            \
         if (lds > 60000) {                                                                         \
             static uint64_t attr_done = 0;              /* (the attribute is per device) */        \
             const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
             if (!(attr_done & dev_bit)) {                                                          \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fast_lds_bytes(DT, NW) + 32768)); \
                 attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
@@ -407,6 +408,7 @@ AdaptArgs adapt_args(hens_ctx_impl* c, bool adaptive, const double* in, double* 
     a.swaps_last = c->swaps_last; a.swaps_total = c->swaps_total;
     a.lag = c->cfg.adaptation_lag; a.nu = c->cfg.adaptation_time;
     a.time = c->adapt_time;
+    a.kappa = (a.lag / ((double)a.time + a.lag)) / a.nu;     // tempering.py:571-572
     a.T = c->T; a.W = c->W; a.nblocks = c->adapt_src ? c->adapt_nblocks : pt_blocks(c);
     a.zero_after = 0;
     a.zero_rows = nullptr;
@@ -896,37 +898,38 @@ bool fused_ok(const hens_ctx_impl* c) {
 }
 
 template <int LIKE>
-int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1, bool pipe = false) {
+int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1, bool pipe = false, bool col = false) {
     const dim3 grid(pipe ? c->W / c->pipe.cbl : c->W / c->label_cb);
     // (the MaxDynamicSharedMemorySize attribute is per device: contexts on several GPUs of one process each set it)
-#define LAUNCH_FUSED_P(DT, NW, PER, SHORT, PIPE)                                                   \
+#define LAUNCH_FUSED_P(DT, NW, PER, SHORT, PIPE, COL)                                              \
     do {                                                                                           \
         const size_t lds = fused_lds_bytes(DT, NW, PIPE);                                          \
         if (lds > 60000) {                                                                         \
             static uint64_t attr_done = 0;                                                         \
             const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
             if (!(attr_done & dev_bit)) {                                                          \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE>), \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
                 attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
         if (e0)                                                                                    \
-            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
+            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
-            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE>), grid, dim3(NW * 64), lds, c->stream, f); \
+            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), lds, c->stream, f); \
     } while (0)
 #ifdef HENS_DEV_BUILD
-#define LAUNCH_FUSED(DT, NW) do { if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true); else LAUNCH_FUSED_P(DT, NW, false, false, false); } while (0)
+#define LAUNCH_FUSED(DT, NW) do { if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false); else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true); else LAUNCH_FUSED_P(DT, NW, false, false, false, false); } while (0)
 #else
 #define LAUNCH_FUSED(DT, NW)                                                                       \
     do {                                                                                           \
         const bool short_tiles = c->T * c->label_cb != 2 * TILE;                                   \
-        if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true);                                      \
-        else if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true, false);               \
-        else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false, false);                             \
-        else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true, false);                          \
-        else LAUNCH_FUSED_P(DT, NW, false, false, false);                                          \
+        if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false);                               \
+        else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true);                           \
+        else if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true, false, false);        \
+        else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false, false, false);                      \
+        else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true, false, false);                   \
+        else LAUNCH_FUSED_P(DT, NW, false, false, false, false);                                   \
     } while (0)
 #endif
     switch (c->D) {
@@ -949,9 +952,20 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
 // one Philox iteration in two launches: first half-step (k_stretch_fast, carrying the pending ladder adaptation), then
 // second half-step + cascade + swap counts (k_split1_pt)
 // the state as one record per walker (k_split1_pt, k_stretch_fast with StretchArgs::wrec) <-> by-field arrays (everything else)
+const uint32_t* iteration_keys(hens_ctx_impl* c);
+bool col_ok(const hens_ctx_impl* c);
 void state_to_records(hens_ctx_impl* c) {
     if (c->packed) return;
     const int64_t n = (int64_t)c->Tl * c->W;
+    if (col_ok(c)) {
+        // column order of iteration c->iter, into the OTHER buffers (the compact row table is permuted too: not in place)
+        const uint32_t* keys = iteration_keys(c);
+        hipLaunchKernelGGL(k_pack_cols, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
+                           c->accepted, keys, c->wrec[c->cur ^ 1], c->loc[c->cur ^ 1], c->T, c->W, c->idx_bits);
+        c->cur ^= 1;
+        c->packed = c->colmode = true;
+        return;
+    }
     hipLaunchKernelGGL(k_pack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
                        c->accepted, c->wrec[c->cur], n);
     c->packed = true;
@@ -959,6 +973,13 @@ void state_to_records(hens_ctx_impl* c) {
 void state_to_fields(hens_ctx_impl* c) {
     if (!c->packed) return;
     const int64_t n = (int64_t)c->Tl * c->W;
+    if (c->colmode) {
+        const uint32_t* keys = iteration_keys(c);            // (the order the last launch wrote: iteration c->iter's)
+        hipLaunchKernelGGL(k_unpack_cols, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], keys, c->L[c->cur],
+                           c->P[c->cur], c->loc[c->cur], c->accepted, c->T, c->W, c->idx_bits);
+        c->packed = c->colmode = false;
+        return;
+    }
     hipLaunchKernelGGL(k_unpack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], c->L[c->cur], c->P[c->cur],
                        c->loc[c->cur], c->accepted, n);
     c->packed = false;
@@ -971,7 +992,8 @@ void state_to_fields(hens_ctx_impl* c) {
 
 // round keys of iteration c->iter (planning a new window if the chain has left the current one)
 const uint32_t* iteration_keys(hens_ctx_impl* c) {
-    if (c->iter < c->ikeys_iter0 || c->iter >= c->ikeys_iter0 + (uint64_t)c->ikeys_n) {
+    // (the window must hold the NEXT iteration's keys too: column-ordered records are written in its order)
+    if (c->iter < c->ikeys_iter0 || c->iter + 1 >= c->ikeys_iter0 + (uint64_t)c->ikeys_n) {
         PlanArgs pa{};
         pa.iter0 = c->iter; pa.seed = c->cfg.seed;
         // (a pipeline rank settles the pair across its bottom boundary: the column map of the cold neighbour's hottest rung too)
@@ -999,6 +1021,14 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         a.idx_bits = c->idx_bits; a.hb_shift = c->label_cb_shift - 1; a.ndim_active = dim_active(c);
         a.split = 0;
         a.home_off = c->parity * T * W;
+        if (c->colmode) {                                              // column-ordered records; the rung's row table in LDS
+            // (the rung's row table staged in LDS by LDS-DMA: built, verified, measured at config 2 on one box - 19.1 us per
+            //  iteration with it, 18.8 without, 19.9 with slot-ordered records: 8 MB of table fills per launch and a wait for
+            //  every load of the wave in front of the first barrier cost more than the L2 hits they replace.  HENS_TAB=1)
+            static const bool tab = getenv("HENS_TAB") != nullptr;               // A/B knob
+            a.col = 1;
+            a.tab_lds = (tab && (size_t)W * 4 <= 32768 && (W & 255) == 0) ? 1 : 0;
+        }
         attach_iteration_head(c, a);
         if (evs) {
             c->ext_start = new_event(c);
@@ -1016,6 +1046,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
     f.keys = keys;
+    f.keys_next = keys + (size_t)T * 8;                                // (inside the window: iteration_keys)
     f.a = c->cfg.a; f.ndim_active = dim_active(c);
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
@@ -1036,10 +1067,10 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     }
     int r;
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1); break;
+        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1, false, c->colmode); break;
 #ifndef HENS_DEV_BUILD
-        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1); break;
-        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1, false, c->colmode); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1, false, c->colmode); break;
 #endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
@@ -1170,6 +1201,17 @@ bool iter_ok(const hens_ctx_impl* c) {
         return false;
     const long nwg = c->W / c->label_cb, allow = per_cu ? per_cu : (c->D == 16 ? 2 : 1);
     return nwg <= allow * (long)c->num_cu;
+}
+
+// Column-ordered records (StretchArgs::col): the two-launch iteration of one GPU on full tiles - every shape of fused_ok that
+// does not take the single launch, has no periodic parameters and no MH move in the mix (those launches address the records
+// by slot).  Round 3, config 2: both launches' index phases were a round key -> permutation -> scattered record load chain
+// (4 600 / 4 700 cycles to the first barrier); in column order the records load coalesced at the head of the launch and the
+// first launch looks rows up in an LDS copy of its rung's table.
+bool col_ok(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_NO_COL") != nullptr;                // A/B knob: records by slot
+    if (off || !fused_ok(c) || iter_ok(c) || c->period || c->mh_kind >= 0) return false;
+    return c->T * c->label_cb == 2 * TILE && (c->W & 3) == 0;
 }
 
 template <int LIKE>
@@ -1744,6 +1786,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     const size_t TW = (size_t)c->Tl * c->W;
     c->cur = 0;
     c->packed = false;
+    c->rows_mixed = false;    // (a failed hens_step call may have left these behind: step_failed)
     c->parity = 1;            // rows live in home 0, the next iteration writes home 1
     c->expect_split = 0;
     c->pt_pending = false;
@@ -2021,6 +2064,22 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     return HENS_OK;
 }
 
+// a launch inside hens_step's loop failed: the walker records / versioned rows / count-buffer rotation may be half-way between
+// two iterations - nothing a later call could read consistently.  The state is declared gone (the caller uploads again)
+// instead of leaving stale by-field arrays behind a `packed` flag.
+static int step_failed(hens_ctx_impl* c, int r) {
+    (void)hipStreamSynchronize(c->stream);
+    c->packed = false;
+    c->rows_mixed = false;
+    c->adapt_pending = false;
+    c->adapt_src = nullptr;
+    c->acc_state[0] = c->acc_state[1] = c->acc_state[2] = 0;
+    if (c->swap_acc[0]) (void)hipMemsetAsync(c->swap_acc[0], 0, (size_t)3 * SWAP_ACC_ROWS_MAX * c->T * 4, c->stream);
+    c->have_state = false;
+    c->have_logs = false;
+    return r;
+}
+
 int hens_step(hens_ctx* ctx, int64_t n_iters) {
     hens_ctx_impl* c = CTX(ctx);
     int r = ready(c, true);
@@ -2138,7 +2197,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             if (pfused) {
                 r = pipe_fused_iteration(c, prof ? &evs : nullptr);
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
-                if (r) return r;
+                if (r) return step_failed(c, r);
                 c->iter += 1;
                 continue;
             }
@@ -2151,20 +2210,20 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             } else if (iter1) {
                 r = iter_iteration(c, which, ib, prof ? &evs : nullptr);
                 if (prof) ev_kind.push_back(3);
-                if (r) return r;
+                if (r) return step_failed(c, r);
                 c->iter += 1;
                 continue;
             } else if (fused) {
                 r = fused_iteration(c, prof ? &evs : nullptr);
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
-                if (r) return r;
+                if (r) return step_failed(c, r);
                 c->iter += 1;
                 continue;
             } else {
                 r = stretch_pair(c, which, ib, prof ? &evs : nullptr, !piped && fast_path(c));
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(0); }
             }
-            if (r) return r;
+            if (r) return step_failed(c, r);
             if (piped) {
                 if (prof) { hipEvent_t e0 = new_event(c); evs.push_back(e0); (void)hipEventRecord(e0, c->stream); }
                 pipe_sweep(c);
@@ -2270,6 +2329,7 @@ int hens_set_iteration(hens_ctx* ctx, int64_t iter) {
         return fail(c, HENS_ERR_STATE, "the iteration counter of a pipeline rank that has stepped cannot be moved");
     if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (column-ordered records are in the OLD counter's order)
     spec_cancel(c);                           // (a speculative plan of the old counter's successors)
     c->win_count = 0;
     c->iter = (uint64_t)iter;                 // (the round-key window re-plans itself when the chain has left it)

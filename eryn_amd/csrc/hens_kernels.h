@@ -435,6 +435,12 @@ __device__ __forceinline__ DrawRec draw_values(int own, int cw, double uz, doubl
     zz = zz * zz / a;
     return DrawRec{zz, ((double)D - 1.0) * log(zz) /* stretch.py:223 */, log(ua) /* red_blue.py:294 */, cw, own};
 }
+// the stretch factor alone - what the proposal needs; (D - 1) log zz and log u are the accept test's (two FP64 logarithms: ~2000
+// cycles of dependent ALU that need not sit in front of the first barrier).  Same expressions as draw_values.
+__device__ __forceinline__ double draw_zz(double uz, double a) {
+    double zz = (a - 1.0) * uz + 1.0;              // stretch.py:129-132 (mul, add, square, divide)
+    return zz * zz / a;
+}
 __device__ __forceinline__ void store_draw(const Draws& d, size_t idx, const DrawRec& r) {
     d.own[idx] = r.own;
     d.cw[idx] = r.cw;
@@ -467,6 +473,8 @@ struct AdaptArgs {
     double* swaps_last;         // [T-1]
     double* swaps_total;        // [T-1]
     double lag, nu;
+    double kappa;               // (lag / (time + lag)) / nu, tempering.py:571-572, formed by the host (the same two IEEE divisions:
+                                // wave-uniform, and two fewer FP64 divides on the folded adaptation's dependent chain)
     int64_t time;               // adaptation steps taken so far (tempering.py:596)
     int32_t T, W, nblocks, moving;   // moving: adaptive and not past stop_adaptation (tempering.py:591)
     int32_t row_groups;              // rows a wave sums straight out of memory: 8 per group of 64 / row_groups lanes, the groups
@@ -553,6 +561,13 @@ struct StretchArgs {
     uint64_t iseed, iiter;
     double ia;                       // stretch scale a
     int32_t idx_bits, hb_shift, ndim_active;
+    // Column-ordered records (round 3, hens_step's two launches on one GPU): wrec / loc hold every rung in the order of THIS
+    // iteration's cascade columns - record c of rung t belongs to the walker column c meets - so the walker at place p of a
+    // half is record place_column(half, p): a coalesced load that waits for no round key and no permutation, and a complement
+    // is a lookup by column in the rung's compact row table, which the workgroup stages in LDS (4 W bytes; tab_lds).
+    // k_split1_pt<COL> writes the next buffers in the NEXT iteration's column order (scattered stores at its tail instead of
+    // scattered loads at both launches' heads).
+    int32_t col, tab_lds;
     AdaptArgs ad;
 };
 
@@ -1035,6 +1050,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     int32_t* s_dst = s_rc + TILE;
     int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [128] swap counts (ad_on)
+    int32_t* s_tab = reinterpret_cast<int32_t*>(s_cnt + 128);            // [W] the rung's row table in column order (tab_lds)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1070,35 +1086,62 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         __syncthreads();
     }
 
+    // column-ordered records: the rung's row table (4 W bytes) -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+    // instruction, no registers), requested HERE, in front of everything else; the wave waits for it in front of the first
+    // barrier (tab_lds implies W a multiple of 256, 4 W <= 32 KiB).
+    const bool tab = MODE == MODE_STRETCH && !PIPE && A.col && A.tab_lds;
+    if (tab) {
+        const char* src = reinterpret_cast<const char*>(A.loc + (size_t)tl * W) + lane * 16;
+        for (int ch = wv; ch < (W >> 8); ch += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ch * 1024),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_tab) + ch * 1024), 16, 0, 0);
+    }
+
     // ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64
     // Two parts, so that a wave can run the first one (ratios, dS, exp, deltaT: ~2500 cycles of dependent FP64 divides
     // that need the counts but not the cumulative sum) while it would otherwise idle before the first barrier, and only
     // the second one (cumsum, reciprocals, update) in the shadow of the row gathers.
-    double ad_c0 = 0.0, ad_c1 = 0.0, ad_dT0 = 0.0, ad_dT1 = 0.0, ad_b0n = 1.0, ad_b1n = 1.0, ad_bb0 = 1.0, ad_bb1 = 1.0;
-    auto adapt_part1 = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1) {
+    double ad_c0 = 0.0, ad_c1 = 0.0, ad_dT0 = 0.0, ad_dT1 = 0.0, ad_b0n = 1.0, ad_b1n = 1.0, ad_bb0 = 1.0, ad_bb1 = 1.0, ad_inv0 = 1.0;
+    auto adapt_part1 = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1, const bool exp_elsewhere = false) {
         const int T = A.ad.T;
         const int e0 = lane, e1 = lane + 64;
         ad_c0 = cnt0; ad_c1 = cnt1; ad_bb0 = ad_b; ad_bb1 = ad_b1;
         if (!A.ad.moving) return;
+        if (exp_elsewhere) {                 // (T <= 64) the ratio chain - cnt / W, dS, exp - runs on wave ADX; here: 1 / beta differences
+            const double inv0v = 1.0 / ad_b;
+            ad_inv0 = inv0v;
+            ad_b0n = __shfl_down(ad_b, 1);
+            const double inv0n = __shfl_down(inv0v, 1);
+            ad_dT0 = (e0 + 2 < T) ? inv0n - inv0v : 0.0;                           // :578; times exp(dS) after the barrier
+            ad_dT1 = 0.0;
+            return;
+        }
         const bool two = T > 64;                                                   // wave-uniform: rungs 64.. exist
         const double r0 = cnt0 / (double)A.ad.W, r1 = two ? cnt1 / (double)A.ad.W : 0.0;   // :587
-        const double decay = A.ad.lag / ((double)A.ad.time + A.ad.lag);            // :571
-        const double kappa = decay / A.ad.nu;                                      // :572
+        const double kappa = A.ad.kappa;                                           // :571-572 (host)
+        // ONE reciprocal per rung: 1 / beta of the next rung is the next lane's (round 3: the chain had 1 / b twice per lane, and
+        // 1 / b[0] once more in the second part - on the path of every launch since the first barrier comes earlier)
+        const double inv0v = 1.0 / ad_b, inv1v = two ? 1.0 / ad_b1 : 1.0;
+        ad_inv0 = inv0v;
         // the value of the NEXT rung (e + 1): lane 63's successor is rung 64 = lane 0's second element
-        const double r0d = __shfl_down(r0, 1), r1first = __shfl(r1, 0);
-        const double b0d = __shfl_down(ad_b, 1), b1first = __shfl(ad_b1, 0);
-        const double r0n = lane < 63 ? r0d : r1first, b0n = lane < 63 ? b0d : b1first;
-        const double r1n = __shfl_down(r1, 1), b1n = __shfl_down(ad_b1, 1);
+        // (lane exchanges are LDS crossbar trips: the second rung set's only for ladders above 64 rungs - wave-uniform)
+        const double r0d = __shfl_down(r0, 1), b0d = __shfl_down(ad_b, 1), i0d = __shfl_down(inv0v, 1);
+        double r0n = r0d, b0n = b0d, inv0n = i0d, r1n = 0.0, b1n = 1.0, inv1n = 1.0;
+        if (two) {
+            const double r1first = __shfl(r1, 0), b1first = __shfl(ad_b1, 0), i1first = __shfl(inv1v, 0);
+            if (lane == 63) { r0n = r1first; b0n = b1first; inv0n = i1first; }
+            r1n = __shfl_down(r1, 1); b1n = __shfl_down(ad_b1, 1); inv1n = __shfl_down(inv1v, 1);
+        }
         ad_b0n = b0n; ad_b1n = b1n;
         double dT0 = 0.0, dT1 = 0.0;
         if (e0 + 2 < T) {
             const double dS = kappa * (r0 - r0n);                                  // :575
-            dT0 = 1.0 / b0n - 1.0 / ad_b;                                          // :578
+            dT0 = inv0n - inv0v;                                                   // :578  1 / b[e+1] - 1 / b[e]
             dT0 *= exp(dS);
         }
         if (two && e1 + 2 < T) {
             const double dS = kappa * (r1 - r1n);
-            dT1 = 1.0 / b1n - 1.0 / ad_b1;
+            dT1 = inv1n - inv1v;
             dT1 *= exp(dS);
         }
         ad_dT0 = dT0; ad_dT1 = dT1;
@@ -1119,12 +1162,15 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     if (i <= e1) cs1 = cs1 + v;
                 }
             }
-            const double inv0 = 1.0 / __shfl(ad_b, 0);
+            const double inv0 = readlane_f64(ad_inv0, 0);                          // 1 / b[0]
             const double bn0 = 1.0 / (cs0 + inv0), bn1 = T > 64 ? 1.0 / (cs1 + inv0) : 0.0;   // :580, belong to rungs e + 1
             const double upd0 = b0n + (bn0 - b0n), upd1 = b1n + (bn1 - b1n);      // :583,:593
-            const double up0 = __shfl_up(upd0, 1), up1 = __shfl_up(upd1, 1), upd0last = __shfl(upd0, 63);
+            const double up0 = __shfl_up(upd0, 1);
             if (e0 >= 1 && e0 + 1 < T) bnew0 = up0;
-            if (e1 + 1 < T) bnew1 = lane >= 1 ? up1 : upd0last;
+            if (T > 64) {                                                          // (wave-uniform: the second rung set)
+                const double up1 = __shfl_up(upd1, 1), upd0last = readlane_f64(upd0, 63);
+                if (e1 + 1 < T) bnew1 = lane >= 1 ? up1 : upd0last;
+            }
         }
         if (e0 < T) s_beta[e0] = bnew0;
         if (e1 < T) s_beta[e1] = bnew1;
@@ -1172,7 +1218,31 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // first and adapts while they are in flight.
     unsigned ad_u0[8], ad_u1[8];
     double ad_bi0 = 1.0, ad_bi1 = 1.0;
+    // (column-ordered records, measured at config 2 in workgroup cycles up to the second barrier: both parts in front of the
+    //  first barrier 13 070, both in the gathers' shadow 11 520, the split as it is 9 900)
     const bool ad_defer = ad_early && !PIPE && !ad_lead;
+    constexpr bool ad_defer_all = false;
+    // Round 3: the first part was the last to reach the first barrier (4 460 cycles after the workgroup's start; the complement
+    // rows' wave 2 830, the rest < 2 000): its two independent chains run on two waves - ratios -> dS -> exp on wave ADX,
+    // reciprocals of the ladder on wave ADW - and meet through LDS after the barrier (ladders of up to 64 rungs).
+    constexpr int ADX = 3;
+    const bool ad_x = ad_defer && NW >= 4 && A.ad.T <= 64 && A.ad.moving;
+    double* s_exp = s_part;                  // [64] exp(dS) per rung (phase C overwrites it after the second barrier)
+    if (ad_x && wv == ADX) {
+        const int T = A.ad.T, NR = A.ad.nblocks;
+        const int G = A.ad.row_groups, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;
+        unsigned u[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r] = (r * G + g < NR && p < T - 1) ? A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] : 0u;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        unsigned s0 = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s0 += u[r];
+        for (int m = P2; m < 64; m <<= 1) s0 += __shfl_xor(s0, m);
+        const double r0 = (double)s0 / (double)A.ad.W;                             // :587
+        const double r0n = __shfl_down(r0, 1);
+        s_exp[lane] = (lane + 2 < T) ? exp(A.ad.kappa * (r0 - r0n)) : 1.0;        // :575
+    }
     auto adapt_early = [&]() {
         const int T = A.ad.T, NR = A.ad.nblocks;
         unsigned s0 = 0, s1 = 0;
@@ -1192,7 +1262,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (A.ad.zero_rows)                      // every workgroup reads the rows: clear the buffer of the NEXT sweep
                 for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
         }
-        adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1);
+        adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1, ad_x);
     };
     if (ad_early && wv == ADW) {
         const int T = A.ad.T, NR = A.ad.nblocks;
@@ -1209,7 +1279,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         // compiler's wait-count pass understands: otherwise it guards the deferred computation with a wait that also
         // covers the row gathers issued in between, and the adaptation no longer overlaps them.
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
-        adapt_early();                           // first part: this wave has nothing else to do before the barrier
+        // first part now: this wave has nothing else to do before the barrier - unless the barrier comes early (column-ordered
+        // records: phase A is one coalesced load), then everything waits for the shadow of the row gathers
+        if (!ad_defer_all) adapt_early();
         if (!ad_defer) adapt_part2();
     }
 
@@ -1217,6 +1289,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0, beta_pre = 1.0;
     int own = 0;
     int32_t own_row = 0, ghome_row = 0;      // fused pipeline iteration: the walker's row (< 0: guest) and that guest's home row
+    double late_ua = -1.0;                   // column-ordered records: >= 0 - (D - 1) log zz is still to be taken (phase B's shadow)
     uint32_t acc_old = 0;                    // record mode, stretch move: the slot's accept counter rides in its record
     bool valid = false;
     if (wv == 0) {
@@ -1243,6 +1316,20 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     Lold = A.L[tl * W + own];
                     Pold = A.P[tl * W + own];
                 }
+            } else if (A.ikeys && A.col) {
+                // column-ordered records: the walker at this place is record place_column(half, place) of its rung - no round
+                // key, no permutation; its row comes out of the rung's table (LDS, phase B) or with the record
+                own = place_column(A.split, k, A.hb_shift);
+                const WalkerRec* o = A.wrec + (tl * W + own);
+                const double2 lp = *reinterpret_cast<const double2*>(&o->L);
+                const int2 la = *reinterpret_cast<const int2*>(&o->loc);
+                const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(s_off + k));
+                zz = draw_zz(sd.uz, A.ia);
+                lu = log(sd.ua);                                 // red_blue.py:294 (this wave is not the last at the barrier)
+                late_ua = 1.0;                                   // ((D - 1) log zz: after the row gathers have been issued)
+                rs = A.tab_lds ? own : la.x;                     // (tab_lds: the column; phase B looks the row up)
+                acc_old = (uint32_t)la.y;                        // (consumed in phase D: the record load gates no barrier then)
+                Lold = lp.x; Pold = lp.y;
             } else if (A.ikeys) {
                 // in registers: the Philox call first (it needs no key: the scalar load of the rung's round keys is in
                 // flight), then the walker at this place -> its record, then the logarithms while that load is in flight
@@ -1292,6 +1379,15 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (!(MODE == MODE_STRETCH && A.ikeys)) s_rc[lane] = rc;
         s_dst[lane] = A.inplace ? rs : A.home_off + tl * W + own;
         s_flag[lane] = valid ? 4 : 0;
+    } else if (MODE == MODE_STRETCH && A.ikeys && A.col && wv == 2) {
+        const int k = k0 + lane;                 // column-ordered records: the complement is a COLUMN of the rung's row table
+        int rc = 0;
+        if (k < Ns) {
+            const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(s_off + k));
+            const int colc = place_column(1 - A.split, stretch_index(sd.r22, W >> 1), A.hb_shift);
+            rc = A.tab_lds ? colc : A.loc[tl * W + colc];
+        }
+        s_rc[lane] = rc;
     } else if (MODE == MODE_STRETCH && A.ikeys && wv == 2) {
         // the complement's row on a wave of its own (same Philox call, the other half of its output): two dependent chains
         // {draw -> walker -> record} side by side instead of one after the other
@@ -1309,6 +1405,15 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_cnt[lane] = 0;
         s_cnt[lane + 64] = 0;
     }
+    if (tab) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row table has landed in LDS (requested at the head)
+#ifdef HENS_TRACE_WAVES      // dev builds: slot w of the trace = arrival of wave w at the first barrier
+    if (A.trace && lane == 0 && wv >= 1 && wv < 8) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv] = trace_stamp();
+    if (A.trace && tid == 0) {           // (thread 0 leaves: no later stamp overwrites these; the launch's results are garbage)
+        A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = trace_stamp();
+        lds_barrier();
+        return;
+    }
+#endif
     HENS_TRACE(1);
     lds_barrier();
     HENS_TRACE(2);
@@ -1326,7 +1431,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
-        if (rv[p]) {
+        if (rv[p] && tab) {                  // column -> row (LDS); the walker's own row kept for phase E
+            const int rsr = s_tab[s_rs[r]], rcr = s_tab[s_rc[r]];
+            if (jl == 0) s_dst[r] = rsr;
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)rsr * D + jl * 2);
+            creg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)rcr * D + jl * 2);
+        } else if (rv[p]) {
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
             if (MH) {
                 if (A.mh_step) {
@@ -1346,7 +1456,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     double2 muv = double2{0.0, 0.0};
     if (CEN) muv = *reinterpret_cast<const double2*>(A.mu + jl * 2);
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
-    if (ad_defer && wv == ADW) adapt_part2();      // second part: the working waves' row gathers are in flight
+    if (MODE == MODE_STRETCH && wv == 0 && late_ua >= 0.0)         // the Hastings factor's logarithm, while the row gathers fly
+        factors = ((double)A.ndim_active - 1.0) * log(s_zz[lane]);                // stretch.py:223
+    if (ad_defer && wv == ADW) {                   // second part: the working waves' row gathers are in flight
+        if (ad_defer_all) adapt_early();
+        if (ad_x && lane + 2 < A.ad.T) ad_dT0 *= s_exp[lane];                      // :578-579 (the other wave's half of the first part)
+        adapt_part2();
+    }
     unsigned adv[8];
     double ad_b = 1.0, ad_b1 = 1.0;       // ladder values of rungs lane and lane + 64
     if (red_on) {                                  // the cascade's per-workgroup swap counts: <= 8 per thread
@@ -1595,6 +1711,35 @@ __global__ void k_unpack_state(const WalkerRec* __restrict__ w, double* __restri
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const WalkerRec r = w[i];
         L[i] = r.L; P[i] = r.P; loc[i] = r.loc; accepted[i] = r.acc;
+    }
+}
+
+// column-ordered records <-> by-field arrays (slot order): record c of rung t is the slot prp_t(c), keys = the round keys of
+// the iteration the order belongs to ([T][8], k_plan_keys).  Pack also writes the compact row table in column order.
+__global__ void k_pack_cols(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
+                            const uint32_t* __restrict__ accepted, const uint32_t* __restrict__ keys, WalkerRec* __restrict__ w,
+                            int32_t* __restrict__ loc_cols, int T, int W, int idx_bits) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * W; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / W), c = (int)(i - (int64_t)t * W);
+        uint32_t key[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) key[r] = keys[(size_t)t * 8 + r];
+        const size_t s = (size_t)t * W + prp((uint32_t)c, key, idx_bits, (uint32_t)W);
+        w[i] = make_wrec(L[s], P[s], loc[s], accepted[s]);
+        loc_cols[i] = loc[s];
+    }
+}
+__global__ void k_unpack_cols(const WalkerRec* __restrict__ w, const uint32_t* __restrict__ keys, double* __restrict__ L,
+                              double* __restrict__ P, int32_t* __restrict__ loc, uint32_t* __restrict__ accepted, int T, int W,
+                              int idx_bits) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * W; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i / W), c = (int)(i - (int64_t)t * W);
+        uint32_t key[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) key[r] = keys[(size_t)t * 8 + r];
+        const size_t s = (size_t)t * W + prp((uint32_t)c, key, idx_bits, (uint32_t)W);
+        const WalkerRec r = w[i];
+        L[s] = r.L; P[s] = r.P; loc[s] = r.loc; accepted[s] = r.acc;
     }
 }
 
@@ -2105,6 +2250,7 @@ struct FusedArgs {
     int32_t* locnew;                                          // 4 W bytes stay in L2): where the complements are looked up
     const double* betas;                                      // [T]
     const uint32_t* keys;                                     // [T][8] round keys of the rungs' column maps (k_plan_keys)
+    const uint32_t* keys_next;                                // COL: the NEXT iteration's round keys (the order the records are written in)
     uint32_t* accepted;                                       // [T][W]
     uint32_t* swap_acc;                                       // [acc_rows][T-1]
     const double* lo; const double* hi; const double* mu; const double* prec; const double* prec_sym;
@@ -2143,10 +2289,15 @@ __host__ __device__ inline size_t fused_lds_bytes(int D, int NW, bool pipe = fal
 // the rank's Tl rungs (a whole number of label blocks: again 128 slots, 64 of them moving), publishes its share of the
 // hottest rung to the hot neighbour, starts its walk from what that neighbour's columns carry, hands its own columns on to
 // the cold neighbour and settles the bottom boundary - all hand-offs per column block, rows updated in place.
-template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false, bool PIPE = false>
+// COL: column-ordered records (StretchArgs::col) - wrec / loc are read in THIS iteration's column order (record c of rung t is
+// the walker column c meets: the slot threads' loads are coalesced and wait for no key), and the next buffers are written in
+// the NEXT iteration's column order: the slot column c meets is prp_t(c), its column next time prp_inv of that under the next
+// iteration's key - a permutation and its inverse in the shadow of the record load, scattered STORES at the tail.
+template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false, bool PIPE = false, bool COL = false>
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     static_assert(!(PIPE && (PER || SHORT)), "pipeline ranks: full tiles, no periodic parameters");
+    static_assert(!(COL && (PER || SHORT || PIPE)), "column-ordered records: full tiles on one GPU");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr bool CEN = like_centred(LIKE, DT);
     constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
@@ -2227,19 +2378,25 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     if (wv == 0) s_flag[lane] = 0;                                       // (also the idle lanes of a short tile: never in the box)
     if (tid < NEr) {                                                     // (short ladders: the slots beyond cb T do not exist)
         const int e = tid, t = e >> CS, cc = e & (CB - 1), c = c0 + cc;
-        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
-        const uint4 ka = kp[0], kb = kp[1];
-        const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        slot_n = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+        if (COL) {
+            // the record of the walker column c meets IS record c: coalesced, waits for no key and no permutation (where the
+            // slot's new record goes - scol, phase G - is worked out by the threads of the cascade uniforms, below)
+            wr_n = A.wrec[(size_t)t * W + c];
+        } else {
+            const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
+            const uint4 ka = kp[0], kb = kp[1];
+            const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+            slot_n = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+            wr_n = A.wrec[(size_t)t * W + slot_n];
+        }
         stays = PIPE ? ((cc >> HS) & 1) == 0 : cc < HB;
-        wr_n = A.wrec[(size_t)t * W + slot_n];
         if (!stays) {
             const int m = mover_of(t, cc);
             s_rs[m] = wr_n.loc;
             if (PIPE) home_n = A.ghome[wr_n.loc < 0 ? ~wr_n.loc : 0];    // (unconditional; consumed in phase D)
             else s_dst[m] = t * W + slot_n;                              // (walker index: the accept counters)
         }
-        scol[e] = slot_n;
+        if (!COL) scol[e] = slot_n;
         if (!WIDE && e < TE) sbeta[e] = A.betas[R0 + e];
     }
     if (tid >= NE && tid < 2 * NE) {
@@ -2249,6 +2406,25 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         // row t of the table: pair TE-1-t of the walk = global pair R0 + TE-1-t, whose uniform is row TG-1-(R0+TE-1-t)
         if (t < TE - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, PIPE ? TG - R0 - TE + t : t, W, c));   // tempering.py:535
     }
+    if (COL && WIDE && wv == 3 && lane < NM) {       // log of the movers' accept uniforms (the same Philox call as FLW's, its other half)
+        const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));
+        s_lu[m] = log(stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q).ua);   // red_blue.py:294
+    }
+    if (COL && (NW >= 8 ? (wv == 4 || wv == 7) : wv < 2)) {
+        // where slot e's record goes (phase G): the slot column c meets is prp_t(c) under this iteration's key, its column in
+        // the next iteration's order the inverse of that under the next key - two Feistel walks, ~1000 cycles of dependent ALU
+        // that nothing in front of the barrier needs: on the two waves with nothing else to do (measured: on the slot threads
+        // the barrier came 1000 cycles later, on the uniform-drawing waves 700)
+        const int e = (NW >= 8 ? (wv == 4 ? 0 : 64) : wv * 64) + lane, t = e >> CS, c = c0 + (e & (CB - 1));
+        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
+        const uint4 ka = kp[0], kb = kp[1];
+        const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+        const uint4* kn = reinterpret_cast<const uint4*>(A.keys_next) + (size_t)t * 2;
+        const uint4 na = kn[0], nb = kn[1];
+        const uint32_t keyn[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+        const uint32_t slot = prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+        scol[e] = (int)prp_inv(slot, keyn, A.idx_bits, (uint32_t)W);
+    }
     if (WIDE && tid >= 2 * NE && tid < 2 * NE + 64) {
         if (lane < TE) sbeta[lane] = A.betas[R0 + lane];
     }
@@ -2256,17 +2432,32 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));   // split position (second half)
         const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q);
         if (wv == CWW) {
-            const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
-            const uint4 ka = kp[0], kb = kp[1];
-            const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-            const int cw = (int)prp((uint32_t)place_column(0, stretch_index(sd.r22, W >> 1), HS), key, A.idx_bits, (uint32_t)W);
+            int cw;
+            if (COL) {                       // the row table is in column order: the complement's column is its index
+                cw = place_column(0, stretch_index(sd.r22, W >> 1), HS);
+            } else {
+                const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
+                const uint4 ka = kp[0], kb = kp[1];
+                const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+                cw = (int)prp((uint32_t)place_column(0, stretch_index(sd.r22, W >> 1), HS), key, A.idx_bits, (uint32_t)W);
+            }
             s_rc[m] = A.loc[t * W + cw];
         }
         if (wv == FLW || CWW == FLW) {
-            const DrawRec dv = draw_values(0, 0, sd.uz, sd.ua, A.a, A.ndim_active);
-            s_zz[m] = dv.zz; s_fac[m] = dv.fac; s_lu[m] = dv.lu;
+            if (COL && WIDE) {               // the two logarithms on two waves (one wave with both was the last at the barrier by
+                const double z = draw_zz(sd.uz, A.a);                             // 600 cycles; behind the barrier they stretched phase B)
+                s_zz[m] = z;
+                s_fac[m] = ((double)A.ndim_active - 1.0) * log(z);                // stretch.py:223
+            } else {
+                const DrawRec dv = draw_values(0, 0, sd.uz, sd.ua, A.a, A.ndim_active);
+                s_zz[m] = dv.zz; s_fac[m] = dv.fac; s_lu[m] = dv.lu;
+            }
         }
     }
+#ifdef HENS_TRACE_WAVES      // dev builds: slot w of the trace = arrival of wave w at the first barrier (slot 0: the workgroup's start)
+    if (A.trace && lane == 0 && wv >= 1 && wv < 8) A.trace[(size_t)blockIdx.x * 8 + wv] = trace_stamp();
+    if (A.trace && tid == 0) { lds_barrier(); return; }
+#endif
     FUSED_TRACE(1);
     lds_barrier();
     FUSED_TRACE(2);
