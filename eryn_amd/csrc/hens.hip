@@ -181,6 +181,7 @@ struct hens_ctx_impl {
     bool per_kernel_events = false;
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool step_events = false;        // the last hens_step call recorded ev0 / ev1 (hens_timing::total_ms)
     hipEvent_t ext_start = nullptr, ext_stop = nullptr;   // armed: the next stretch launch records its own begin/end
     std::vector<hipEvent_t> evpool;
     std::vector<void*> allocs;
@@ -2118,7 +2119,12 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
     c->evpool.clear();
     c->timing = hens_timing{};
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    // (an event pair around the call - total_ms of hens_get_timing - only when timing is asked for: per-kernel profiling or
+    //  HENS_STEP_EVENTS=1.  A record is a barrier packet in front of the first launch and one more behind the last: a short
+    //  call - the driver times blocks of 20 iterations - pays for both.)
+    static const bool ev_env = getenv("HENS_STEP_EVENTS") != nullptr;
+    c->step_events = prof || ev_env;
+    if (c->step_events) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // the plan of batch b+1 runs on plan_stream while batch b steps on the main stream
     const int64_t nbatch = (n_iters + c->NB - 1) / c->NB;
     auto batch_size = [&](int64_t b) { return (int)std::min<int64_t>(c->NB, n_iters - b * c->NB); };
@@ -2256,7 +2262,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // the swap counters or the state settles it first (flush_adapt at their head) - same bits either way.
     if (piped) pipe_flush_adapt(c);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    if (c->step_events) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;
     if (prof) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2349,7 +2355,7 @@ int hens_get_timing(hens_ctx* ctx, hens_timing* out) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0;
-    if (c->timing.n_iters > 0) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (c->timing.n_iters > 0 && c->step_events) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->timing.total_ms = ms;
     *out = c->timing;
     return HENS_OK;
@@ -2588,6 +2594,7 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    c->step_events = true;
     c->timing = hens_timing{};
     for (int64_t i = 0; i < n_iters; ++i) {
         // in-model Gaussian move on the packed leaves, then swaps + adaptation (mh.py:190-191)

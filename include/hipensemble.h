@@ -175,7 +175,8 @@ int hens_reset_counters(hens_ctx* ctx);
 int hens_set_adapt_time(hens_ctx* ctx, int64_t t);
 
 /* Timing of the most recent hens_step call, from hipEvents on the context's stream.
- *   total_ms      wall time of the whole call on the device
+ *   total_ms      wall time of the whole call on the device (0 unless per-kernel profiling is on or HENS_STEP_EVENTS=1: the
+ *                 event pair costs a short call two barrier packets)
  *   stretch_ms    summed duration of the stretch kernels, n_stretch = their count
  *   pt_ms         summed duration of the PT cascade kernels, n_pt = their count
  * Per-kernel figures are only filled when per-kernel events were enabled with

@@ -1,6 +1,9 @@
 """Exploratory timing of hens_step on one GPU (not the contract bench; see bench.py)."""
 import argparse
+import os
 import time
+
+os.environ.setdefault("HENS_STEP_EVENTS", "1")     # the "device" figure below: an event pair around the hens_step call
 
 import numpy as np
 
