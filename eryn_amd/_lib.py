@@ -101,6 +101,7 @@ SIGNATURES = {
     "hens_rj_step": (C.c_int, [_P, C.c_int64]),
     "hens_rj_get_counters": (C.c_int, [_P, _P, _P, _P]),
     "hens_rj_debug_draws": (C.c_int, [_P, C.c_int64] + [_P] * 11),
+    "hens_rj_set_schedule": (C.c_int, [_P, C.c_int32]),
     "hens_get_iteration": (C.c_int, [_P, _P]),
     "hens_set_iteration": (C.c_int, [_P, C.c_int64]),
     "hens_debug_draws": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

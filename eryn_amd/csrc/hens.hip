@@ -171,6 +171,7 @@ struct hens_ctx_impl {
     uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
     int64_t rj_num_mh = 0, rj_num_bd = 0;
     bool rj_have_scale = false;
+    int rj_schedule = 0;                    // hens_rj_set_schedule: 0 "separate_branches", 1 "iterate_branches" (ensemble.py:434-480)
     const uint32_t* adapt_src = nullptr;   // pending swap counts: swap_part (nullptr) or the mailbox's reduced counts
     int adapt_nblocks = 0;
 
@@ -1052,6 +1053,11 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
     f.acc_rows = 8 * acc_row_groups(c->T);
+    {   // A/B knob: rows the swap counts spread over (8 x groups; fewer rows = fewer hot lines for every workgroup's adaptation
+        // wave to read in the next launch, more atomics per line in this one)
+        static const int g_env = getenv("HENS_ACC_GROUPS") ? atoi(getenv("HENS_ACC_GROUPS")) : 0;
+        if (g_env > 0) f.acc_rows = 8 * std::min(g_env, acc_row_groups(c->T));
+    }
     acc_commit(c);
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
     f.period = c->period;
@@ -1402,6 +1408,7 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     a.pool = c->pool; a.loc = c->loc[c->cur]; a.L = c->L[c->cur]; a.P = c->P[c->cur];
     a.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
     a.accepted = mode == RJ_MODE_BD ? c->rj_acc_bd : c->accepted;
+    if (mode == RJ_MODE_BD && c->rj_schedule == 1 && !change && branch != c->rj.nb - 1) a.accepted = nullptr;   // (production, not the last branch)
     a.keep_out = keep;
     a.tdata = c->rj_t; a.ydata = c->rj_y;
     a.step = step; a.change = change; a.leaf = leaf; a.birth = birth; a.u_acc = u_acc;
@@ -2601,9 +2608,16 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
         if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
         c->rj_num_mh += 1;
         rj_cascade(c, 2 * c->iter, true);
-        // one branch's birth / death move (ensemble.py:988-990, "separate_branches"), then swaps without adaptation
-        const int branch = rj_branch_of(c, c->iter);
-        if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        if (c->rj_schedule == 1) {
+            // "iterate_branches" (ensemble.py:434-451, rj.py:169-388): ONE move walks through every branch - birth / death,
+            // accept, update per branch - then one sweep of swaps without adaptation; its accept mask is the last branch's
+            for (int b = 0; b < c->rj.nb; ++b)
+                if ((r = rj_launch(c, RJ_MODE_BD, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        } else {
+            // one branch's birth / death move (ensemble.py:988-990, "separate_branches"), then swaps without adaptation
+            const int branch = rj_branch_of(c, c->iter);
+            if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        }
         c->rj_num_bd += 1;
         rj_cascade(c, 2 * c->iter + 1, false);
         c->iter += 1;
@@ -2614,6 +2628,15 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     // the reference raises "The likelihood function is returning Nan." / on an infinite coordinate at once (ensemble.py:1258-
     // 1262, 1542); here once per call: the template likelihood's flags are read back with the call's last launch
     return check_flags(c, true);
+}
+
+int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
+    if (schedule != 0 && schedule != 1) return fail(c, HENS_ERR_UNSUPPORTED, "rj schedule must be 0 (separate_branches) or 1 (iterate_branches)");
+    c->rj_schedule = schedule;
+    return HENS_OK;
 }
 
 int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh, int32_t* branch, int8_t* coin, uint32_t* sel,
@@ -2642,17 +2665,23 @@ int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh,
     if (!a.step || !a.u_mh || !a.coin || !a.sel || !a.birth || !a.u_bd) return fail(c, HENS_ERR_HIP, "hens_rj_debug_draws: out of device memory");
     a.iter = (uint64_t)iter; a.seed = c->cfg.seed;
     a.Tl = c->Tl; a.W = c->W; a.rung_begin = c->cfg.rung_begin;
-    a.branch = rj_branch_of(c, (uint64_t)iter);
-    *branch = a.branch;
-    hipLaunchKernelGGL(k_rj_debug_draws, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(step, a.step, TW * IO * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(u_mh, a.u_mh, TW * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(coin, a.coin, TW, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(sel, a.sel, TW * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(birth, a.birth, TW * RJ_ND * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(u_bd, a.u_bd, TW * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // "separate_branches": the chosen branch's draws; "iterate_branches": every branch's, in order (outputs [nbranches][...])
+    const int nsub = c->rj_schedule == 1 ? c->rj.nb : 1;
+    *branch = c->rj_schedule == 1 ? -1 : rj_branch_of(c, (uint64_t)iter);
+    for (int k = 0; k < nsub; ++k) {
+        a.branch = c->rj_schedule == 1 ? k : *branch;
+        hipLaunchKernelGGL(k_rj_debug_draws, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        if (k == 0) {
+            HIPCHK(c, hipMemcpyAsync(step, a.step, TW * IO * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(u_mh, a.u_mh, TW * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(coin + (size_t)k * TW, a.coin, TW, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(sel + (size_t)k * TW, a.sel, TW * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(birth + (size_t)k * TW * RJ_ND, a.birth, TW * RJ_ND * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(u_bd + (size_t)k * TW, a.u_bd, TW * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (has_pt(c) && slot_mh && uswap_mh && slot_bd && uswap_bd) {       // the two cascades of the iteration (rj_cascade's keys)
         const size_t n = (size_t)c->T * c->W;
         int32_t* ds = (int32_t*)grab(n * 4);

@@ -86,19 +86,21 @@ __device__ __forceinline__ double rj_unit_normal(uint64_t seed, uint64_t it, uin
     return mh_normal_pair(seed, it, wid, (uint32_t)i | 0x10000u).x;        // one Box-Muller pair per coordinate, first value used
 }
 // birth / death: .x bit 0 = the +1 / -1 coin (distgenrj.py:63-66), .y = selector of the leaf among the candidates (:97-112)
-__device__ __forceinline__ u4 rj_bd_raw(uint64_t seed, uint64_t it, uint32_t wid) {
-    return philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BD}, (uint32_t)seed, (uint32_t)(seed >> 32));
+// (the branch is part of every birth / death key: "iterate_branches" runs the move on every branch within one iteration)
+__device__ __forceinline__ u4 rj_bd_raw(uint64_t seed, uint64_t it, uint32_t wid, int branch) {
+    return philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BD | ((uint32_t)branch << 16)}, (uint32_t)seed,
+                         (uint32_t)(seed >> 32));
 }
 __device__ __forceinline__ int rj_pick(uint32_t sel, int cnt) { return (int)__umulhi(sel, (uint32_t)cnt); }   // uniform on [0, cnt)
 // coordinate d of a leaf born from the (uniform) prior: prior.py:60-66
-__device__ __forceinline__ double rj_birth_coord(uint64_t seed, uint64_t it, uint32_t wid, int d, double lo, double hi) {
-    const u4 e = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BIRTH | ((uint32_t)d << 8)},
+__device__ __forceinline__ double rj_birth_coord(uint64_t seed, uint64_t it, uint32_t wid, int branch, int d, double lo, double hi) {
+    const u4 e = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BIRTH | ((uint32_t)d << 8) | ((uint32_t)branch << 16)},
                                (uint32_t)seed, (uint32_t)(seed >> 32));
     return u01(e.x, e.y) * (hi - lo) + lo;
 }
 // accept uniform of the in-model (mode 1) / birth-death (mode 2) move: mh.py:157, rj.py:332
-__device__ __forceinline__ double rj_accept_uniform(uint64_t seed, uint64_t it, uint32_t wid, int mode) {
-    const u4 d = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_ACC | ((uint32_t)mode << 8)},
+__device__ __forceinline__ double rj_accept_uniform(uint64_t seed, uint64_t it, uint32_t wid, int mode, int branch) {
+    const u4 d = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_ACC | ((uint32_t)mode << 8) | ((uint32_t)branch << 16)},
                                (uint32_t)seed, (uint32_t)(seed >> 32));
     return u01(d.x, d.y);
 }
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             c = A.change[gw];
             lf = A.leaf[gw];
         } else {
-            const u4 d = rj_bd_raw(A.seed, A.iter, wid);
+            const u4 d = rj_bd_raw(A.seed, A.iter, wid, B);
             c = (d.x & 1u) ? +1 : -1;                                 // distgenrj.py:63-66
             if (M.nlmin[B] == M.nl[B]) c = 0;
             else if (nold == M.nlmin[B]) c = +1;                      // :69-73
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
                 if (A.birth) {
                     v = A.birth[(size_t)gw * RJ_ND + d];
                 } else {
-                    v = rj_birth_coord(A.seed, A.iter, wid, d, M.lo[B][d], M.hi[B][d]);
+                    v = rj_birth_coord(A.seed, A.iter, wid, B, d, M.lo[B][d], M.hi[B][d]);
                 }
                 in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
                 if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     if (A.u_acc) {
         lu = log(A.u_acc[gw]);
     } else {
-        lu = log(rj_accept_uniform(A.seed, A.iter, wid, A.mode));
+        lu = log(rj_accept_uniform(A.seed, A.iter, wid, A.mode, A.mode == RJ_MODE_BD ? A.branch : 0));
     }
     const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
     if (keep) {                                                        // Move.update (move.py:472-703)
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
         if (lane == 0) {
             A.L[gw] = logl;
             A.P[gw] = (fabs(logp) == INFINITY) ? 0.0 : logp;
-            A.accepted[gw] += 1u;
+            if (A.accepted) A.accepted[gw] += 1u;     // ("iterate_branches": the move's mask is its LAST branch's, rj.py:385-386)
         }
     }
     if (lane == 0 && A.keep_out) A.keep_out[gw] = keep ? 1 : 0;
@@ -364,13 +366,13 @@ __global__ void k_rj_debug_draws(const RjDebugArgs A) {
         const int d = (i - M.off[b]) % RJ_ND;
         A.step[(size_t)gw * M.ind_off + i] = M.mh_scale[b][d] * rj_unit_normal(A.seed, A.iter, wid, i);
     }
-    A.u_mh[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_MH);
-    const u4 d = rj_bd_raw(A.seed, A.iter, wid);
+    A.u_mh[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_MH, 0);
+    const u4 d = rj_bd_raw(A.seed, A.iter, wid, A.branch);
     A.coin[gw] = (d.x & 1u) ? +1 : -1;
     A.sel[gw] = d.y;
     for (int k = 0; k < RJ_ND; ++k)
-        A.birth[(size_t)gw * RJ_ND + k] = rj_birth_coord(A.seed, A.iter, wid, k, M.lo[A.branch][k], M.hi[A.branch][k]);
-    A.u_bd[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_BD);
+        A.birth[(size_t)gw * RJ_ND + k] = rj_birth_coord(A.seed, A.iter, wid, A.branch, k, M.lo[A.branch][k], M.hi[A.branch][k]);
+    A.u_bd[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_BD, A.branch);
 }
 
 }  // namespace hens

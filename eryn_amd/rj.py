@@ -63,6 +63,7 @@ class RJEngine:
                                stop_adaptation=stop_adaptation, live_dangerously=True, fill_value=fill_value, seed=seed,
                                device_id=device_id)
         self.lib, self.ctx = self.eng.lib, self.eng.ctx
+        self.schedule = "separate_branches"
         nb = len(self.branches)
         kinds = np.array([b.kind for b in self.branches], dtype=np.int32)
         nlmax = np.array([b.nleaves_max for b in self.branches], dtype=np.int32)
@@ -155,11 +156,21 @@ class RJEngine:
     def step(self, n_iters):
         check(self.lib.hens_rj_step(self.ctx, int(n_iters)), self.ctx)
 
+    def set_schedule(self, rj_moves):
+        """The sampler's ``rj_moves`` string for ``step`` (ensemble.py:434-480): "separate_branches" | "iterate_branches"."""
+        code = {"separate_branches": 0, "iterate_branches": 1}.get(rj_moves)
+        if code is None:
+            raise NotImplementedError('rj_moves must be "separate_branches" or "iterate_branches"')
+        check(self.lib.hens_rj_set_schedule(self.ctx, code), self.ctx)
+        self.schedule = rj_moves
+
     def debug_draws(self, it):
-        """Everything ``step`` draws in iteration ``it`` (include/hipensemble.h: hens_rj_debug_draws)."""
+        """Everything ``step`` draws in iteration ``it`` (include/hipensemble.h: hens_rj_debug_draws).  The birth / death
+        arrays carry a leading branch axis: one entry ("separate_branches": the chosen branch) or one per branch in order."""
         T, W = self.T, self.W
-        out = dict(step=np.empty((T, W, self.ncoord)), u_mh=np.empty((T, W)), coin=np.empty((T, W), dtype=np.int8),
-                   sel=np.empty((T, W), dtype=np.uint32), birth=np.empty((T, W, 3)), u_bd=np.empty((T, W)),
+        ns = len(self.branches)
+        out = dict(step=np.empty((T, W, self.ncoord)), u_mh=np.empty((T, W)), coin=np.empty((ns, T, W), dtype=np.int8),
+                   sel=np.empty((ns, T, W), dtype=np.uint32), birth=np.empty((ns, T, W, 3)), u_bd=np.empty((ns, T, W)),
                    slot_mh=np.empty((T, W), dtype=np.int32), uswap_mh=np.empty((max(T - 1, 1), W)),
                    slot_bd=np.empty((T, W), dtype=np.int32), uswap_bd=np.empty((max(T - 1, 1), W)))
         br = C.c_int32(0)
@@ -167,6 +178,9 @@ class RJEngine:
                                            ptr(out["sel"]), ptr(out["birth"]), ptr(out["u_bd"]), ptr(out["slot_mh"]),
                                            ptr(out["uswap_mh"]), ptr(out["slot_bd"]), ptr(out["uswap_bd"])), self.ctx)
         out["branch"] = int(br.value)
+        if out["branch"] >= 0:                          # one move on the chosen branch
+            for k in ("coin", "sel", "birth", "u_bd"):
+                out[k] = out[k][:1]
         return out
 
     def iteration(self):
@@ -225,8 +239,10 @@ class RJEnsembleSampler:
         from .moves.tempering import TemperatureControl
         if not isinstance(log_like_fn, TemplateLikelihood):
             raise NotImplementedError("the device RJ path runs the template model: pass an eryn_amd.rj.TemplateLikelihood")
-        if rj_moves != "separate_branches":
-            raise NotImplementedError('rj_moves must be "separate_branches" (one DistributionGenerateRJ per branch)')
+        if rj_moves not in ("separate_branches", "iterate_branches"):
+            raise NotImplementedError('rj_moves must be "separate_branches" (one DistributionGenerateRJ per branch, one chosen per '
+                                      'iteration) or "iterate_branches" (one move that walks through every branch)')
+        self.rj_schedule = rj_moves
         if not isinstance(moves, GaussianLeafMove):
             raise NotImplementedError("the in-model move must be an eryn_amd.rj.GaussianLeafMove")
         if rng not in ("numpy", "philox"):
@@ -258,6 +274,7 @@ class RJEnsembleSampler:
         self.engine = RJEngine(self.ntemps, self.nwalkers, self.branches, log_like_fn.t, log_like_fn.y, log_like_fn.sigma,
                                seed=seed, device_id=device_id, adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag,
                                adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation)
+        self.engine.set_schedule(rj_moves)
         if rng == "philox":
             # the device draws axis-aligned steps (hens_rj_set_mh_scale: three standard deviations per branch): a covariance
             # with off-diagonal terms is another proposal - refused rather than silently reduced to its diagonal
@@ -267,8 +284,9 @@ class RJEnsembleSampler:
                                               "multivariate_normal draws with any covariance)")
             self.engine.set_mh_scale(np.stack([np.sqrt(np.diag(moves.cov[k])) for k in self.branch_names]))
         moves.accepted = np.zeros((self.ntemps, self.nwalkers))
-        self.rj_accepted = [np.zeros((self.ntemps, self.nwalkers)) for _ in self.branch_names]
-        self.rj_num_proposals = [0 for _ in self.branch_names]
+        nmoves = 1 if rj_moves == "iterate_branches" else len(self.branch_names)     # (rj move objects, ensemble.py:434-471)
+        self.rj_accepted = [np.zeros((self.ntemps, self.nwalkers)) for _ in range(nmoves)]
+        self.rj_num_proposals = [0 for _ in range(nmoves)]
         # rng="philox": the device counts the birth / death move over all branches together
         self.rj_accepted_all, self.rj_num_proposals_all = np.zeros((self.ntemps, self.nwalkers)), 0
         self._random = np.random.mtrand.RandomState()
@@ -311,11 +329,29 @@ class RJEnsembleSampler:
         tc.swaps_accepted = swaps
         if tc.adaptive:
             tc.time += 1
-        # reversible jump on one branch (ensemble.py:988-990; distgenrj.py:35-222)
+        # reversible jump (ensemble.py:988-990; distgenrj.py:35-222): on one branch chosen from R, or - "iterate_branches" - one
+        # move (the choice among ONE move still draws) that takes the branches in turn, its accept mask the last branch's
+        nb = len(self.branches)
+        if self.rj_schedule == "iterate_branches":
+            R.choice(1, p=np.ones(1))
+            for bi in range(nb):
+                racc = self._bd_numpy(bi)
+            self.rj_accepted[0] += racc
+            self.rj_num_proposals[0] += 1
+        else:
+            bi = int(R.choice(nb, p=np.full(nb, 1.0 / nb)))
+            racc = self._bd_numpy(bi)
+            self.rj_accepted[bi] += racc
+            self.rj_num_proposals[bi] += 1
+        iperm, i1perm, u = tc.draw_swap_randoms()
+        eng.pt_sweep(iperm, i1perm, u, adapt=False)                             # rj.py:381-382
+        return acc, racc
+
+    def _bd_numpy(self, bi):
+        """Birth / death on branch ``bi`` with the reference's draws (distgenrj.py:35-222, rj.py:169-352)."""
+        eng, tc, R, T, W = self.engine, self.temperature_control, self._random, self.ntemps, self.nwalkers
         x, inds, _, _, betas = eng.download()
         tc.betas = betas
-        nb = len(self.branches)
-        bi = int(R.choice(nb, p=np.full(nb, 1.0 / nb)))
         b = self.branches[bi]
         ib = inds[b.name]
         nleaves = ib.sum(axis=-1)
@@ -337,12 +373,7 @@ class RJEnsembleSampler:
             for d in range(3):                                                  # ProbDistContainer.rvs: GLOBAL stream, per parameter
                 draws[:, d] = np.random.rand(nbirth) * (b.hi[d] - b.lo[d]) + b.lo[d]      # prior.py:60-66, 432-497
             birth[change == +1] = draws
-        racc = eng.bd_step(bi, change, leaf, birth, R.rand(T, W))               # rj.py:332
-        self.rj_accepted[bi] += racc
-        self.rj_num_proposals[bi] += 1
-        iperm, i1perm, u = tc.draw_swap_randoms()
-        eng.pt_sweep(iperm, i1perm, u, adapt=False)                             # rj.py:381-382
-        return acc, racc
+        return eng.bd_step(bi, change, leaf, birth, R.rand(T, W))               # rj.py:332
 
     def _state(self, nan_fill=False):
         from .state import State

@@ -372,6 +372,14 @@ int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, in
 int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh, int32_t* branch, int8_t* coin, uint32_t* sel,
                         double* birth, double* u_bd, int32_t* slot_mh, double* uswap_mh, int32_t* slot_bd, double* uswap_bd);
 
+/* The between-model schedule of hens_rj_step (the sampler's rj_moves string, ensemble.py:434-480):
+ *   0  "separate_branches" (default): one DistributionGenerateRJ per branch, one of them chosen per iteration
+ *   1  "iterate_branches": ONE move that walks through every branch in turn (birth / death, accept, update per branch), then
+ *      one sweep of swaps without adaptation; its accept counts are the last branch's (rj.py:169-388).
+ * With schedule 1 hens_rj_debug_draws returns branch = -1 and coin / sel / birth / u_bd for every branch in order
+ * ([nbranches][Tl][W]...; the caller sizes them for nbranches either way).  "together" is not built. */
+int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule);
+
 /* The Philox iteration counter: the index of the NEXT iteration hens_step will run (iterations completed on this
  * context so far, by hens_step or by the parity API). */
 int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out);

@@ -160,7 +160,12 @@ class OracleRJSampler:
     """One in-model GaussianMove + one RJ move per iteration, driven by the two reference streams."""
 
     def __init__(self, branches, x0, inds0, t, y, sigma, R, G, betas, adaptive=True, adaptation_lag=10000,
-                 adaptation_time=100, stop_adaptation=-1, fill=-1e300, record=False):
+                 adaptation_time=100, stop_adaptation=-1, fill=-1e300, record=False, schedule="separate_branches"):
+        # schedule: the sampler's ``rj_moves`` string (ensemble.py:434-480) - "separate_branches": one DistributionGenerateRJ per
+        # branch, one of them chosen per iteration; "iterate_branches": ONE move that walks through every branch in turn
+        if schedule not in ("separate_branches", "iterate_branches"):
+            raise NotImplementedError('rj schedule "together" is not restated')
+        self.schedule = schedule
         self.branches = list(branches)
         self.t, self.y, self.sigma = np.asarray(t, dtype=np.float64), np.asarray(y, dtype=np.float64), float(sigma)
         self.R, self.G = R, G
@@ -282,9 +287,38 @@ class OracleRJSampler:
 
     # ---- reversible jump: one leaf born or killed per walker in ONE branch (distgenrj.py:35-222, rj.py:145-388) ------
     def rj_move(self, rec=None):
-        st, T, W = self.st, self.T, self.W
         nb = len(self.branches)
+        if self.schedule == "iterate_branches":
+            # one move object (ensemble.py:434-451: the choice among ONE move still draws), the Gibbs iterator hands it the
+            # branches one at a time (rj.py:169-171): propose / accept / update per branch, `accepted` overwritten each time,
+            # then ONE sweep of swaps without adaptation (rj.py:381-382)
+            self._draw_branch(1)
+            accepted, sub = None, []
+            for bi in range(nb):
+                r = {} if rec is not None else None
+                accepted = self._rj_branch(bi, r)
+                sub.append(r)
+            rec2 = {} if rec is not None else None
+            self._pt(False, rec2)
+            if rec is not None:
+                rec.update(rj_sub=sub, rj_accepted=accepted)
+                rec.update({f"rj_{k}": v for k, v in rec2.items()})
+            self.rj_accepted[0] += accepted                                        # rj.py:385-386: the LAST branch's mask
+            self.rj_num_proposals[0] += 1
+            return 0, accepted
         bi = self._draw_branch(nb)
+        accepted = self._rj_branch(bi, rec)
+        rec2 = {} if rec is not None else None
+        self._pt(False, rec2)                                                      # rj.py:381-382
+        if rec is not None:
+            rec.update({f"rj_{k}": v for k, v in rec2.items()})
+        self.rj_accepted[bi] += accepted
+        self.rj_num_proposals[bi] += 1
+        return bi, accepted
+
+    def _rj_branch(self, bi, rec=None):
+        """Birth / death on ONE branch: proposal, factors, prior + likelihood, accept, update (rj.py:169-352)."""
+        st, T, W = self.st, self.T, self.W
         b = self.branches[bi]
         inds = st.inds[b.name]
         nleaves = inds.sum(axis=-1)
@@ -337,13 +371,7 @@ class OracleRJSampler:
         update(st, q, new_inds, logl, logp, accepted)
         if rec is not None:
             self._snapshot(rec, "rjupd_")
-        rec2 = {} if rec is not None else None
-        self._pt(False, rec2)                                                      # rj.py:381-382
-        if rec is not None:
-            rec.update({f"rj_{k}": v for k, v in rec2.items()})
-        self.rj_accepted[bi] += accepted
-        self.rj_num_proposals[bi] += 1
-        return bi, accepted
+        return accepted
 
     def iteration(self):
         rec = {} if self.record else None

@@ -67,7 +67,7 @@ SINE_BOX = [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]
 
 
 def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=1e-4, n_init=(2, 1),
-            seed_data=42, seed_construct=135, seed_run=246):
+            seed_data=42, seed_construct=135, seed_run=246, rj_moves="separate_branches"):
     branch_names = ["gauss", "sine"]
     ndims = {"gauss": 3, "sine": 3}
     nleaves_max = dict(zip(branch_names, nl_max))
@@ -93,7 +93,7 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
     s = EnsembleSampler(W, ndims, log_like_fn_gauss_and_sine, priors, args=[t, y, sigma],
                         tempering_kwargs=dict(ntemps=T), nbranches=2, branch_names=branch_names,
                         nleaves_max=nleaves_max, nleaves_min=nleaves_min, moves=GaussianMove(cov),
-                        rj_moves="separate_branches")
+                        rj_moves=rj_moves)
     logp0 = s.compute_log_prior(coords, inds=inds)
     logl0 = s.compute_log_like(coords, inds=inds, logp=logp0)[0]
     state = State(coords, log_like=logl0, log_prior=logp0, inds=inds)
@@ -101,7 +101,7 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
     out = dict(T=T, W=W, ndata=ndata, sigma=float(sigma), nsteps=nsteps, t=t, y=y, nl_max=np.array(nl_max),
                nl_min=np.array(nl_min), cov_factor=float(cov_factor), seed_construct=seed_construct, seed_run=seed_run,
                gauss_box=np.array(GAUSS_BOX), sine_box=np.array(SINE_BOX), betas0=np.array(s.temperature_control.betas),
-               L0=logl0, P0=logp0)
+               L0=logl0, P0=logp0, rj_moves=rj_moves)
     for k in branch_names:
         out[f"x0_{k}"], out[f"inds0_{k}"] = coords[k].copy(), inds[k].copy()
 
@@ -159,3 +159,8 @@ if __name__ == "__main__":
     capture("rj2_min_leaves", T=4, W=6, nl_max=(5, 2), nl_min=(1, 0), nsteps=16, cov_factor=4e-3, sigma=1.0, seed_run=99)
     # config-4-like leaf budget (nleaves_max = 10: numpy's 8-way pairwise reduction over the leaf axis of the prior)
     capture("rj3_ten_leaves", T=2, W=6, nl_max=(10, 10), nl_min=(0, 0), nsteps=12, n_init=(4, 2), ndata=60)
+    # "iterate_branches" (ensemble.py:434-451; the schedule the reference's own two-branch test runs first, tests/test_eryn.py:
+    # 341-507): ONE RJ move per iteration walks through every branch - birth / death, accept, update per branch - then one
+    # sweep of swaps without adaptation; its accept mask is the LAST branch's (rj.py:163-388)
+    capture("rj4_iterate_branches", T=3, W=8, nl_max=(4, 3), nl_min=(0, 1), nsteps=16, cov_factor=1e-3, seed_run=77,
+            rj_moves="iterate_branches")

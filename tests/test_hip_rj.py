@@ -8,7 +8,7 @@ exactly; log-likelihood to rtol 1e-12 (device exp / sin / summation order); beta
 import numpy as np
 import pytest
 
-from tests.test_oracle_golden_rj import NAMES, load_rj, make_rj_oracle
+from tests.test_oracle_golden_rj import NAMES, NAMES_ALL, load_rj, make_rj_oracle
 
 pytestmark = pytest.mark.gpu
 RTOL_L = 1e-12
@@ -45,7 +45,7 @@ def knife(lnpdiff, u):
         return np.abs(lnpdiff - np.log(u)) < 1e-12 * np.maximum(1.0, np.abs(lnpdiff))
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES_ALL)
 def test_rj_moves_match_the_oracle(golden_dir, name):
     fx = load_rj(golden_dir, name)
     o = make_rj_oracle(fx, record=True)
@@ -82,16 +82,17 @@ def test_rj_moves_match_the_oracle(golden_dir, name):
         assert np.array_equal(sel, rec["sel"]) and np.array_equal(swaps, rec["swaps"]), f"{what}: swaps"
         betas = assert_state(eng, rec, "mh_", o, exact_L=True, what=what + " after the swaps")
         np.testing.assert_allclose(betas, rec["betas_after"], rtol=1e-13, atol=0)
-        # ---- birth / death ---------------------------------------------------------------------------------------
-        x, inds, L, P = state_of(rec, "rjpre_", o)
-        eng.upload(x, inds, L, P, rec["betas_after"])
-        birth = np.zeros((o.T, o.W, 3))
-        birth[rec["rj_change"] == +1] = rec["rj_birth"]          # births are listed in (t, w) order (distgenrj.py:85-121)
-        keep = eng.bd_step(rec["rj_branch"], rec["rj_change"], rec["rj_leaf"], birth, rec["rj_u_acc"])
-        assert not knife(rec["rj_lnpdiff"], rec["rj_u_acc"]).any()
-        assert np.array_equal(keep, rec["rj_accepted"]), f"{what}: birth/death accept mask"
-        assert_state(eng, rec, "rjupd_", o, what=what + " after birth/death")
-        eng.upload(*state_of(rec, "rjupd_", o), rec["betas_after"])
+        # ---- birth / death: on one branch, or ("iterate_branches") on every branch in turn ------------------------------
+        for sub in rec.get("rj_sub", [rec]):
+            x, inds, L, P = state_of(sub, "rjpre_", o)
+            eng.upload(x, inds, L, P, rec["betas_after"])
+            birth = np.zeros((o.T, o.W, 3))
+            birth[sub["rj_change"] == +1] = sub["rj_birth"]      # births are listed in (t, w) order (distgenrj.py:85-121)
+            keep = eng.bd_step(sub["rj_branch"], sub["rj_change"], sub["rj_leaf"], birth, sub["rj_u_acc"])
+            assert not knife(sub["rj_lnpdiff"], sub["rj_u_acc"]).any()
+            assert np.array_equal(keep, sub["rj_accepted"]), f"{what}: birth/death accept mask (branch {sub['rj_branch']})"
+            assert_state(eng, sub, "rjupd_", o, what=what + f" after birth/death on branch {sub['rj_branch']}")
+        eng.upload(*state_of(sub, "rjupd_", o), rec["betas_after"])
         sel, swaps = eng.pt_sweep(rec["rj_iperm"], rec["rj_i1perm"], rec["rj_u_swap"], adapt=False)   # rj.py:381-382
         assert np.array_equal(sel, rec["rj_sel"]) and np.array_equal(swaps, rec["rj_swaps"])
         betas = assert_state(eng, rec, "rj_", o, exact_L=True, what=what + " after the RJ swaps")
@@ -150,7 +151,7 @@ def test_rj_philox_run_config4_shape():
     eng.close()
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES_ALL)
 def test_rj_sampler_reproduces_the_reference_chain(golden_dir, name):
     """The sampler-level mirror (eryn_amd.rj.RJEnsembleSampler, the reference's constructor contract for this path)
     free-running with the reference's seeds lands on the reference's chain: every leaf slot (dead ones included) and
@@ -169,7 +170,7 @@ def test_rj_sampler_reproduces_the_reference_chain(golden_dir, name):
                           fx["t"], fx["y"], float(fx["sigma"])), priors, tempering_kwargs=dict(ntemps=int(fx["T"])),
                           nbranches=2, branch_names=names, nleaves_max=dict(zip(names, map(int, fx["nl_max"]))),
                           nleaves_min=dict(zip(names, map(int, fx["nl_min"]))), moves=GaussianLeafMove(cov),
-                          rj_moves="separate_branches")
+                          rj_moves=str(fx["rj_moves"]))
     assert np.array_equal(s.temperature_control.betas, fx["betas0"])
     coords = {k: fx[f"x0_{k}"] for k in names}
     inds = {k: fx[f"inds0_{k}"] for k in names}
@@ -245,23 +246,33 @@ def _replay_oracle_class():
             idx = self.offsets[b.name] + ll[:, None] * 3 + np.arange(3)
             return self.d["step"][tt[:, None], ww[:, None], idx]
 
+        def _k(self):                                                # entry of the birth / death arrays' branch axis
+            return self._bi if self.schedule == "iterate_branches" else 0
+
+        def _rj_branch(self, bi, rec=None):
+            self._bi = bi
+            return super()._rj_branch(bi, rec)
+
         def _draw_accept(self, which):
-            return self.d["u_mh" if which == "mh" else "u_bd"]
+            return self.d["u_mh"] if which == "mh" else self.d["u_bd"][self._k()]
 
         def _draw_branch(self, nb):
-            assert 0 <= self.d["branch"] < nb
+            if self.schedule == "iterate_branches":                  # (the choice among ONE move: nothing to draw on the device)
+                assert nb == 1 and self.d["branch"] == -1 and self.d["coin"].shape[0] == len(self.branches)
+                return 0
+            assert 0 <= self.d["branch"] < nb and self.d["coin"].shape[0] == 1
             return self.d["branch"]
 
         def _draw_coin(self, shape):
-            c = self.d["coin"].astype(np.int64)
+            c = self.d["coin"][self._k()].astype(np.int64)
             assert c.shape == shape and set(np.unique(c)) <= {-1, 1}
             return c
 
         def _draw_leaf(self, tt, w, candidates):                     # uniform over the candidates, ascending slot order
-            return candidates[(int(self.d["sel"][tt, w]) * len(candidates)) >> 32]
+            return candidates[(int(self.d["sel"][self._k()][tt, w]) * len(candidates)) >> 32]
 
         def _draw_birth(self, b, bt, bw):
-            return self.d["birth"][bt, bw]
+            return self.d["birth"][self._k()][bt, bw]
 
         def _pt(self, adapt, rec):
             self._casc = "mh" if adapt else "bd"                     # the cascade after the in-model move adapts (rj.py:381-382)
@@ -277,7 +288,7 @@ def _replay_oracle_class():
     return ReplayRJ
 
 
-def _replay_rj(T, W, nl_max, nl_min, ndata, iters, seed, start_leaves=(2, 1), calls=None):
+def _replay_rj(T, W, nl_max, nl_min, ndata, iters, seed, start_leaves=(2, 1), calls=None, schedule="separate_branches"):
     from oracle import eryn_oracle_rj as orj
     from eryn_amd.moves.tempering import make_ladder
     from eryn_amd.rj import RJEngine, TemplateBranch
@@ -305,10 +316,11 @@ def _replay_rj(T, W, nl_max, nl_min, ndata, iters, seed, start_leaves=(2, 1), ca
     eng.upload(x, inds, betas=betas0)
     eng.eval_state()
     eng.set_mh_scale(scale)
+    eng.set_schedule(schedule)
     x0, inds0, L0, P0, _ = eng.download()
     okind = {"pulse": orj.KIND_PULSE, "sine": orj.KIND_SINE}
     obr = [orj.Branch(k, okind[kinds[k]], boxes[k], nl_max[i], nl_min[i], cov=np.diag(scale[i] ** 2)) for i, k in enumerate(names)]
-    o = _replay_oracle_class()(obr, x0, inds0, t, y, sigma, None, None, betas0)
+    o = _replay_oracle_class()(obr, x0, inds0, t, y, sigma, None, None, betas0, schedule=schedule)
     assert np.array_equal(o.st.P, P0)
     np.testing.assert_allclose(L0, o.st.L, rtol=RTOL_L, atol=0)
     offsets = {b.name: eng.off[i] for i, b in enumerate(brs)}
@@ -321,8 +333,11 @@ def _replay_rj(T, W, nl_max, nl_min, ndata, iters, seed, start_leaves=(2, 1), ca
             o.load(eng.debug_draws(it), offsets)
             acc, bi, racc = o.iteration()
             mh_acc += acc
-            bd_acc += racc
-            nbd[bi] += 1
+            bd_acc += racc                                           # ("iterate_branches": the last branch's mask, like the device)
+            if schedule == "iterate_branches":
+                nbd = [n_ + 1 for n_ in nbd]
+            else:
+                nbd[bi] += 1
         done += n
         x1, inds1, L1, P1, betas1 = eng.download()
         what = f"hens_rj_step vs oracle after {done} iterations"
@@ -349,6 +364,15 @@ def test_rj_production_step_replayed_through_the_oracle_small(T, W, nl_max, nl_m
     budget) and a tight budget whose edge rule fires all the time.  A wrong branch, a mis-keyed birth draw or a leaf picked
     from the wrong candidate list fails here."""
     _replay_rj(T, W, nl_max, nl_min, ndata=60, iters=iters, seed=11, start_leaves=(2, 1), calls=(3, iters - 3))
+
+
+@pytest.mark.parametrize("T,W,nl_max,nl_min,iters", [(3, 8, (4, 3), (0, 1), 8), (2, 64, (2, 2), (0, 0), 6)])
+def test_rj_production_step_iterate_branches_replayed_through_the_oracle(T, W, nl_max, nl_min, iters):
+    """rj_moves="iterate_branches" (hens_rj_set_schedule 1): every branch's birth / death move in turn within one iteration, each
+    with its own draws (the branch is part of the Philox key), one sweep of swaps after the last, accept counts the last
+    branch's - on the rj4 fixture's shape and on a tight budget."""
+    _replay_rj(T, W, nl_max, nl_min, ndata=60, iters=iters, seed=13, start_leaves=(2, 1), calls=(3, iters - 3),
+               schedule="iterate_branches")
 
 
 def test_rj_production_step_replayed_through_the_oracle_config4():
