@@ -32,6 +32,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "iter":
         same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
         print(f"({T},{Wk},{D}) {n} iterations mh={mh}: one launch per iteration == two launches:", same)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "col":
+    # column-ordered records (round 3: coalesced record loads, next buffers written in the NEXT iteration's column order by
+    # scattered stores) against slot-ordered records (HENS_NO_COL=1) from the same seed; chunks of 7777 iterations also cross
+    # the 1024-iteration key windows at every offset
+    for (T, Wk, D, n) in ((16, 4096, 32, 200000), (64, 2048, 64, 30000), (32, 8192, 32, 40000), (2, 16384, 8, 60000)):
+        outs = []
+        for tag, env in (("col", {}), ("slot", {"HENS_NO_COL": "1"})):
+            out = f"/tmp/soak_{tag}.npz"
+            r = subprocess.run([sys.executable, "-c", W, root, str(T), str(Wk), str(D), str(n), "0", out], env=dict(os.environ, **env), capture_output=True, text=True)
+            print(tag, r.stdout.strip()[-200:], r.stderr.strip()[-300:])
+            outs.append(dict(np.load(out)))
+        same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+        print(f"({T},{Wk},{D}) {n} iterations: column-ordered records == slot-ordered records:", same)
+    sys.exit(0)
 for (T, Wk, D, n, mh) in ((16, 4096, 32, 200000, 0), (8, 2048, 64, 60000, 1), (32, 1024, 16, 100000, 1)):
     outs = []
     for tag, env in (("fused", {}), ("three", {"HENS_NO_FUSED": "1"})):
