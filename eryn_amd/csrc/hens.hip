@@ -104,6 +104,8 @@ struct hens_ctx_impl {
     double* xtmp = nullptr;          // [Tl*W][D] download staging
     int expect_split = 0;
     bool propose_pending = false;
+    int nsplits = 2;                 // hens_set_nsplits: sets of the parity API's red-blue move (red_blue.py:41-47)
+    std::vector<int> seg_off;        // [nsplits + 1] position range of every set in `order` (this iteration's labels)
     int32_t* hl_rs = nullptr; uint8_t* hl_keep = nullptr;   // host-likelihood path scratch
     std::vector<uint8_t> labels_host;
     std::vector<int32_t> rank_of_host;
@@ -1862,9 +1864,10 @@ int hens_eval_state(hens_ctx* ctx) {
 static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels, const int64_t* rint,
                          const double* u_zz, const double* u_acc, int* Ns_out) {
     if (!labels || !rint || !u_zz) return fail(c, HENS_ERR_INVALID, "null argument");
-    if (split != 0 && split != 1) return fail(c, HENS_ERR_INVALID, "split must be 0 or 1 (nsplits = 2)");
+    const int NSP = c->nsplits;
+    if (split < 0 || split >= NSP) return fail(c, HENS_ERR_INVALID, "split must be in [0, %d) (hens_set_nsplits)", NSP);
     if (split != c->expect_split)
-        return fail(c, HENS_ERR_STATE, "half-step calls must alternate split 0, 1 (expected %d)", c->expect_split);
+        return fail(c, HENS_ERR_STATE, "split calls must run 0 .. %d in order (expected %d)", NSP - 1, c->expect_split);
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     if (c->propose_pending) return fail(c, HENS_ERR_STATE, "hens_propose_split without its hens_accept_split");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1872,21 +1875,20 @@ static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels,
     flush_adapt(c);
     const int Tl = c->Tl, W = c->W;
     if (split == 0) {
-        // ascending index lists per label (red_blue.py:150-154): order = [label 0 ... | label 1 ...]
+        // ascending index lists per label (red_blue.py:150-154): order = [label 0 ... | label 1 ... | ...]
         std::vector<int32_t> order((size_t)Tl * W);
+        // arange(W) % nsplits shuffled: set k always has ceil((W - k) / nsplits) walkers (red_blue.py:120-124)
+        c->seg_off.assign((size_t)NSP + 1, 0);
+        for (int k = 0; k < NSP; ++k) c->seg_off[k + 1] = c->seg_off[k] + (W - k + NSP - 1) / NSP;
+        std::vector<int> fill((size_t)NSP);
         for (int t = 0; t < Tl; ++t) {
-            int n0 = 0;
+            for (int k = 0; k < NSP; ++k) fill[k] = c->seg_off[k];
             for (int w = 0; w < W; ++w) {
                 const uint8_t l = labels[(size_t)t * W + w];
-                if (l > 1) return fail(c, HENS_ERR_INVALID, "labels must be 0 or 1");
-                n0 += (l == 0);
-            }
-            if (n0 != (W + 1) / 2)   // arange(W) % 2 shuffled always has ceil(W/2) zeros (red_blue.py:120-124)
-                return fail(c, HENS_ERR_INVALID, "labels must hold ceil(W/2) zeros per rung (got %d)", n0);
-            int a0 = 0, a1 = n0;
-            for (int w = 0; w < W; ++w) {
-                if (labels[(size_t)t * W + w] == 0) order[(size_t)t * W + a0++] = w;
-                else order[(size_t)t * W + a1++] = w;
+                if (l >= NSP) return fail(c, HENS_ERR_INVALID, "labels must be in [0, %d)", NSP);
+                if (fill[l] >= c->seg_off[l + 1])
+                    return fail(c, HENS_ERR_INVALID, "labels must hold ceil((W - k) / nsplits) walkers of set k per rung (set %d too large)", (int)l);
+                order[(size_t)t * W + fill[l]++] = w;
             }
         }
         c->N0 = (W + 1) / 2;
@@ -1897,7 +1899,8 @@ static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels,
         if (c->labels_host.size() != (size_t)Tl * W || memcmp(c->labels_host.data(), labels, (size_t)Tl * W) != 0)
             return fail(c, HENS_ERR_INVALID, "labels differ between split 0 and split 1 of the same iteration");
     }
-    const int Ns = split == 0 ? c->N0 : W - c->N0;
+    if ((int)c->seg_off.size() != NSP + 1) return fail(c, HENS_ERR_STATE, "split %d without its split 0", split);
+    const int Ns = c->seg_off[split + 1] - c->seg_off[split];
     const int Nc = W - Ns;
     for (size_t i = 0; i < (size_t)Tl * Ns; ++i)
         if (rint[i] < 0 || rint[i] >= Nc) return fail(c, HENS_ERR_INVALID, "rint out of range [0, %d)", Nc);
@@ -1907,19 +1910,21 @@ static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels,
     if (u_acc) HIPCHK(c, hipMemcpyAsync(c->d_uacc, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
     c->win_count = 0;
     hipLaunchKernelGGL(k_prep_draws, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, c->order, c->d_rint, c->d_uzz,
-                       u_acc ? c->d_uacc : c->d_uzz, c->db[0].d, Tl, W, c->N0, (int)split, c->cfg.a, dim_active(c));
+                       u_acc ? c->d_uacc : c->d_uzz, c->db[0].d, Tl, W, c->seg_off[split], Ns, c->cfg.a, dim_active(c));
     *Ns_out = Ns;
     return HENS_OK;
 }
 
 static void finish_split(hens_ctx_impl* c, int32_t split) {
-    if (split == 1) {
+    if (split == c->nsplits - 1) {
         c->parity ^= 1;
         c->num_proposals += 1;
         if (!has_pt(c)) c->iter += 1;
     }
-    c->expect_split = split ^ 1;
+    c->expect_split = (split + 1) % c->nsplits;
 }
+// how a launch of the parity API sees set `split` of nsplits (StretchArgs::ns_x): 0 first, 1 last, 2 between
+static int kernel_split(const hens_ctx_impl* c, int32_t split) { return split == 0 ? 0 : (split == c->nsplits - 1 ? 1 : 2); }
 
 int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
                        const double* u_acc, uint8_t* keep_out) {
@@ -1935,7 +1940,8 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
     if ((r = prepare_split(c, split, labels, rint, u_zz, u_acc, &Ns))) return r;
     const size_t n = (size_t)c->Tl * Ns;
     StretchArgs a = base_args(c);
-    a.split = split;
+    a.split = kernel_split(c, split);
+    a.ns_x = Ns; a.soff_x = c->seg_off[split];
     a.home_off = c->parity * c->Tl * c->W;
     a.keep_out = c->d_keep;
     r = launch_stretch<MODE_STRETCH>(c, a, (Ns + TILE - 1) / TILE);
@@ -1960,9 +1966,21 @@ static HostLikeArgs hostlike_args(hens_ctx_impl* c, int32_t split) {
     h.u_acc = c->d_uacc;
     h.accepted = c->accepted; h.flags = c->flags;
     h.logp_in = c->logp_in;
-    h.Tl = c->Tl; h.W = c->W; h.D = c->D; h.split = split; h.N0 = c->N0;
+    h.Tl = c->Tl; h.W = c->W; h.D = c->D; h.split = kernel_split(c, split); h.N0 = c->N0;
+    if ((int)c->seg_off.size() == c->nsplits + 1) { h.ns_x = c->seg_off[split + 1] - c->seg_off[split]; h.soff_x = c->seg_off[split]; }
     h.rung_begin = c->cfg.rung_begin; h.home_off = c->parity * c->Tl * c->W; h.tempered = c->cfg.tempered;
     return h;
+}
+
+int hens_set_nsplits(hens_ctx* ctx, int32_t nsplits) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (nsplits < 2 || nsplits > 8) return fail(c, HENS_ERR_INVALID, "nsplits must be in [2, 8]");
+    if (nsplits > c->W) return fail(c, HENS_ERR_INVALID, "more sets than walkers");
+    if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a red-blue move is under way");
+    c->nsplits = nsplits;
+    c->seg_off.clear();
+    return HENS_OK;
 }
 
 int hens_propose_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
@@ -2003,7 +2021,7 @@ int hens_accept_split(hens_ctx* ctx, int32_t split, const double* logl, const do
     if (!logl || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
-    const int Ns = split == 0 ? c->N0 : c->W - c->N0;
+    const int Ns = c->seg_off[split + 1] - c->seg_off[split];
     const size_t n = (size_t)c->Tl * Ns;
     const HostLikeArgs h = hostlike_args(c, split);
     HIPCHK(c, hipMemcpyAsync(c->d_uzz, logl, n * 8, hipMemcpyHostToDevice, c->stream));
@@ -2101,6 +2119,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (!piped && c->cfg.adaptation_delay != 0)
         return fail(c, HENS_ERR_UNSUPPORTED, "adaptation_delay is an option of the ladder pipeline (hens_pipe_*)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
+    if (c->nsplits != 2) return fail(c, HENS_ERR_UNSUPPORTED, "hens_step's stretch move has two sets (hens_set_nsplits(2)); more sets run through the parity API");
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
         return fail(c, HENS_ERR_UNSUPPORTED, "hens_step needs a device likelihood (host-callable likelihoods step through hens_propose_split / hens_accept_split)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));

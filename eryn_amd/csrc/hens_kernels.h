@@ -568,6 +568,10 @@ struct StretchArgs {
     // k_split1_pt<COL> writes the next buffers in the NEXT iteration's column order (scattered stores at its tail instead of
     // scattered loads at both launches' heads).
     int32_t col, tab_lds;
+    // parity API with nsplits > 2 (red_blue.py:41-47,148): the moving set's position range, given explicitly (0: the two-half
+    // rule from N0 / split); `split` is then 0 for the first set, 1 for the last (every complement already sits in its home
+    // row) and 2 for the ones between
+    int32_t ns_x, soff_x;
     AdaptArgs ad;
 };
 
@@ -596,8 +600,8 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tl = blockIdx.y;
     const int W = A.W;
-    const int Ns = (EVAL || MH) ? W : (A.split == 0 ? A.N0 : W - A.N0);
-    const int s_off = (EVAL || MH) ? 0 : (A.split == 0 ? 0 : A.N0);
+    const int Ns = (EVAL || MH) ? W : (A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : W - A.N0));
+    const int s_off = (EVAL || MH) ? 0 : (A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0));
     const int k0 = blockIdx.x * TILE;
 
     double factors = 0.0, lu = 0.0, Lold = 0.0, Pold = 0.0;
@@ -1059,8 +1063,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                                                 // wave was measured: two 9-wave workgroups do not pack onto one CU)
     const int tl = blockIdx.y;
     const int W = A.W;
-    const int Ns = (EVAL || MH) ? W : (A.split == 0 ? A.N0 : W - A.N0);
-    const int s_off = (EVAL || MH) ? 0 : (A.split == 0 ? 0 : A.N0);
+    const int Ns = (EVAL || MH) ? W : (A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : W - A.N0));
+    const int s_off = (EVAL || MH) ? 0 : (A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0));
     const int k0 = blockIdx.x * TILE;
     const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
     // mode 2: only workgroup (0,0) reduces the counts and adapts; everyone else reads its rung's beta from the ring
@@ -1749,16 +1753,18 @@ __global__ void k_iota(int32_t* p, int64_t n) {
 }
 
 // parity mode: the caller's NumPy draws (stretch.py:93-99,129-132; red_blue.py:294) -> Draws
+// order = [set 0 ascending | set 1 ascending | ...]: the moving set is positions [s_off, s_off + Ns), the complement list the
+// reference indexes with rint is the other sets concatenated in set order (stretch.py:199: c = concatenate(c, axis=1)) = `order`
+// with that range cut out
 __global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* __restrict__ rint,
                              const double* __restrict__ u_zz, const double* __restrict__ u_acc, Draws d,
-                             int Tl, int W, int N0, int split, double a, int D) {
-    const int Ns = split == 0 ? N0 : W - N0;
-    const int s_off = split == 0 ? 0 : N0, c_off = split == 0 ? N0 : 0;
+                             int Tl, int W, int s_off, int Ns, double a, int D) {
     const int64_t n = (int64_t)Tl * Ns;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int tl = (int)(i / Ns), k = (int)(i - (int64_t)tl * Ns);
         const int own = order[(size_t)tl * W + s_off + k];
-        const int cw = order[(size_t)tl * W + c_off + (int)rint[i]];
+        const int r = (int)rint[i];
+        const int cw = order[(size_t)tl * W + (r < s_off ? r : r + Ns)];
         make_draw(d, (size_t)tl * W + s_off + k, own, cw, u_zz[i], u_acc[i], a, D);
     }
 }
@@ -2952,10 +2958,11 @@ struct HostLikeArgs {
     unsigned* flags;
     double logp_in;
     int32_t Tl, W, D, split, N0, rung_begin, home_off, tempered;
+    int32_t ns_x, soff_x;    // see StretchArgs::ns_x
 };
 
 __global__ void k_propose(const HostLikeArgs A) {
-    const int Ns = A.split == 0 ? A.N0 : A.W - A.N0, s_off = A.split == 0 ? 0 : A.N0;
+    const int Ns = A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : A.W - A.N0), s_off = A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0);
     const int64_t total = (int64_t)A.Tl * Ns * A.D;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t wk = i / A.D;
@@ -2975,7 +2982,7 @@ __global__ void k_propose(const HostLikeArgs A) {
 }
 
 __global__ void k_accept_decide(const HostLikeArgs A) {
-    const int Ns = A.split == 0 ? A.N0 : A.W - A.N0, s_off = A.split == 0 ? 0 : A.N0;
+    const int Ns = A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : A.W - A.N0), s_off = A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0);
     const int64_t total = (int64_t)A.Tl * Ns;
     for (int64_t wk = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; wk < total; wk += (int64_t)gridDim.x * blockDim.x) {
         const int tl = (int)(wk / Ns), k = (int)(wk - (int64_t)tl * Ns);
@@ -3017,7 +3024,7 @@ __global__ void k_accept_decide(const HostLikeArgs A) {
 }
 
 __global__ void k_accept_rows(const HostLikeArgs A) {
-    const int Ns = A.split == 0 ? A.N0 : A.W - A.N0, s_off = A.split == 0 ? 0 : A.N0;
+    const int Ns = A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : A.W - A.N0), s_off = A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0);
     const int64_t total = (int64_t)A.Tl * Ns * A.D;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t wk = i / A.D;

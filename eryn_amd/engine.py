@@ -132,11 +132,23 @@ class HipEnsemble:
         check(self.lib.hens_eval_state(self.ctx), self.ctx)
 
     # -- parity-mode steps -----------------------------------------------------------------------
+    nsplits = 2
+
+    def set_nsplits(self, nsplits):
+        """Sets of the parity API's red-blue move (``RedBlueMove(nsplits=...)``, red_blue.py:41-47): include/hipensemble.h,
+        hens_set_nsplits."""
+        check(self.lib.hens_set_nsplits(self.ctx, int(nsplits)), self.ctx)
+        self.nsplits = int(nsplits)
+
+    def set_size(self, split):
+        """Walkers of set ``split``: arange(W) % nsplits, shuffled (red_blue.py:119-124)."""
+        return (self.W - int(split) + self.nsplits - 1) // self.nsplits
+
     def stretch_split(self, split, labels, rint, u_zz, u_acc):
         labels = np.ascontiguousarray(labels, dtype=np.uint8)
         if labels.shape != (self.Tl, self.W):
             raise ValueError("labels must have shape (ntemps, nwalkers)")
-        Ns = self.N0 if split == 0 else self.W - self.N0
+        Ns = self.set_size(split)
         rint = np.ascontiguousarray(rint, dtype=np.int64)
         u_zz, u_acc = f64(u_zz, (self.Tl, Ns)), f64(u_acc, (self.Tl, Ns))
         if rint.shape != (self.Tl, Ns):
@@ -149,7 +161,7 @@ class HipEnsemble:
     def propose_split(self, split, labels, rint, u_zz):
         """Host-likelihood contexts: proposed points q[Tl, Ns, D] and the in-prior mask [Tl, Ns]."""
         labels = np.ascontiguousarray(labels, dtype=np.uint8)
-        Ns = self.N0 if split == 0 else self.W - self.N0
+        Ns = self.set_size(split)
         rint = np.ascontiguousarray(rint, dtype=np.int64)
         u_zz = f64(u_zz, (self.Tl, Ns))
         if labels.shape != (self.Tl, self.W) or rint.shape != (self.Tl, Ns):
@@ -161,7 +173,7 @@ class HipEnsemble:
         return q, inbox.astype(bool)
 
     def accept_split(self, split, logl, u_acc):
-        Ns = self.N0 if split == 0 else self.W - self.N0
+        Ns = self.set_size(split)
         logl, u_acc = f64(logl, (self.Tl, Ns)), f64(u_acc, (self.Tl, Ns))
         keep = np.empty((self.Tl, Ns), dtype=np.uint8)
         check(self.lib.hens_accept_split(self.ctx, int(split), ptr(logl), ptr(u_acc), ptr(keep)), self.ctx)

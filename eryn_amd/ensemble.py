@@ -140,6 +140,8 @@ class EnsembleSampler:
             st = [(m, w) for m, w in zip(self.moves, self.weights) if isinstance(m, StretchMove)]
             if len(mh) > 1 or len(st) > 1 or any(not isinstance(m, GaussianMove) for m, _ in mh):
                 raise NotImplementedError("rng='philox' mixes at most one StretchMove with one GaussianMove")
+            if st and st[0][0].nsplits != 2:
+                raise NotImplementedError("rng='philox' steps a two-set stretch move (nsplits > 2 runs with rng='numpy')")
             if mh:
                 kind, scale = mh[0][0].device_proposal()
                 self.engine.set_mh_proposal(kind, scale, float(mh[0][1]))

@@ -34,8 +34,8 @@ class StretchMove(DeviceMove):
     def __init__(self, a=2.0, nsplits=2, randomize_split=True, live_dangerously=False, likelihood=None,
                  prior_box=None, device_id=0, fill_value=-1e300, trust_resident=False, return_gpu=False,
                  **kwargs):
-        if nsplits != 2:
-            raise NotImplementedError("the device path implements nsplits = 2")
+        if not 2 <= int(nsplits) <= 8:
+            raise NotImplementedError("the device path runs red-blue moves of 2 to 8 sets")
         self.a = a
         self.nsplits = nsplits
         self.randomize_split = randomize_split
@@ -50,6 +50,8 @@ class StretchMove(DeviceMove):
         eng = self._ensure_engine(T, W, D)
         self._apply_periodic(eng, name, D)
         self._upload_if_needed(eng, state, br)
+        if getattr(eng, "nsplits", 2) != self.nsplits:                 # (the context's parity API defaults to two sets)
+            eng.set_nsplits(self.nsplits)
 
         accepted = np.zeros((T, W), dtype=bool)
         labels = np.tile(np.arange(W), (T, 1)) % self.nsplits         # red_blue.py:119-124

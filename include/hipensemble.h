@@ -137,6 +137,12 @@ int hens_eval_state(hens_ctx* ctx);
 int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint,
                        const double* u_zz, const double* u_acc, uint8_t* keep_out);
 
+/* Number of sets of the red-blue move the parity API runs (`RedBlueMove(nsplits=...)`, red_blue.py:41-47,148: walker w of a rung
+ * starts in set w % nsplits, shuffled per rung; set k moves against the other sets concatenated in set order, stretch.py:199).
+ * Default 2.  With nsplits = n the split calls of one move run 0 .. n-1 in order, labels take values in [0, n), set k holds
+ * ceil((W - k) / n) walkers and rint indexes the W - that many others.  hens_step (device draws) stays a two-set move. */
+int hens_set_nsplits(hens_ctx* ctx, int32_t nsplits);
+
 /* Host-callable likelihood (contexts created with HENS_LIKE_HOST).  The half-step of
  * hens_stretch_split is cut in two around the caller's log_like_fn (ensemble.py:1219-1545,
  * 1623-1667): hens_propose_split returns the proposed points q[Tl][Ns][D] and inbox[Tl][Ns]

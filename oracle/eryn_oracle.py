@@ -177,12 +177,13 @@ def split_labels(T, W, G, nsplits=2, randomize=True):
     return labels
 
 
-def split_index_lists(labels, split):
-    """Ascending walker indices of the moving set S and its complement C
-    (moves/red_blue.py:150-154,183-197; boolean masks enumerate ascending)."""
+def split_index_lists(labels, split, nsplits=2):
+    """Walker indices of the moving set S (ascending: a boolean mask enumerates it, moves/red_blue.py:150-154) and of its
+    complement C: the OTHER sets, each ascending, concatenated in set order (red_blue.py:183-197 builds the list
+    ``sets[:split] + sets[split+1:]``, stretch.py:199 concatenates it) - for two sets simply the other set."""
     T, W = labels.shape
     S = np.stack([np.flatnonzero(labels[t] == split) for t in range(T)])
-    C = np.stack([np.flatnonzero(labels[t] != split) for t in range(T)])
+    C = np.stack([np.concatenate([np.flatnonzero(labels[t] == j) for j in range(nsplits) if j != split]) for t in range(T)])
     return S, C
 
 
@@ -214,14 +215,14 @@ def periodic_wrap(q, period):
 
 
 def stretch_split(x, L, P, betas, labels, split, rint, u_zz, u_acc, a, lo, hi,
-                  loglike, fill=-1e300, period=None):
+                  loglike, fill=-1e300, period=None, nsplits=2):
     """One red/blue half-step, all rungs; mutates x, L, P in place.
 
     Returns a dict of intermediates (q, logp, logl, factors, lnpdiff, keep).
     SURVEY 3.2 step 3 a-j.  ``period``: periodic parameters (stretch.py:136-154), see ``periodic_distance``.
     """
     T, W, D = x.shape
-    S, C = split_index_lists(labels, split)
+    S, C = split_index_lists(labels, split, nsplits)
     Ns, Nc = S.shape[1], C.shape[1]
     tt = np.arange(T)[:, None]
 
@@ -398,8 +399,9 @@ class OracleSampler:
     def __init__(self, x0, loglike, lo, hi, R, G, betas=None, a=2.0,
                  adaptive=True, permute=True, adaptation_lag=10000,
                  adaptation_time=100, stop_adaptation=-1, randomize_split=True,
-                 live_dangerously=False, fill=-1e300, record=False, moves=None, period=None):
+                 live_dangerously=False, fill=-1e300, record=False, moves=None, period=None, nsplits=2):
         # moves: [("stretch" | GaussianProposal, weight), ...]; default the reference's single StretchMove
+        self.nsplits = int(nsplits)                                   # RedBlueMove(nsplits=...), red_blue.py:41-47
         self.moves = [("stretch", 1.0)] if moves is None else list(moves)
         w = np.atleast_1d([m[1] for m in self.moves]).astype(float)
         self.weights = w / np.sum(w)                                  # ensemble.py:377-378
@@ -503,11 +505,11 @@ class OracleSampler:
         if W < 2 * D and not self.live_dangerously:                   # red_blue.py:108-114
             raise RuntimeError("It is unadvisable to use a red-blue move with fewer "
                                "walkers than twice the number of dimensions.")
-        labels = split_labels(T, W, self.G, randomize=self.randomize_split)
+        labels = split_labels(T, W, self.G, nsplits=self.nsplits, randomize=self.randomize_split)
         rec["labels"] = labels
         accepted = np.zeros((T, W), dtype=bool)
         tt = np.arange(T)[:, None]
-        for split in (0, 1):
+        for split in range(self.nsplits):                             # red_blue.py:148
             Ns = int(np.sum(labels[0] == split))
             Nc = W - Ns
             rint, u_zz = self.draw_stretch(Ns, Nc)
@@ -516,7 +518,7 @@ class OracleSampler:
             u_acc = self.R.rand(T, Ns)
             out = stretch_split(self.x, self.L, self.P, self.betas, labels, split, rint,
                                 u_zz, u_acc, self.a, self.lo, self.hi, self.loglike,
-                                fill=self.fill, period=self.period)
+                                fill=self.fill, period=self.period, nsplits=self.nsplits)
             accepted[tt, out["S"]] = out["keep"]
             if self.record:
                 rec[f"rint{split}"], rec[f"u_zz{split}"], rec[f"u_acc{split}"] = rint, u_zz, u_acc

@@ -88,7 +88,7 @@ class RProxy:
 
 
 def capture(name, T, W, D, nsteps, box, dense=True, vectorize=True, seed_construct=123,
-            seed_run=456, tempering_kwargs=None, x0_scale=1.0, x0_uniform=False, keep_q=True):
+            seed_run=456, tempering_kwargs=None, x0_scale=1.0, x0_uniform=False, keep_q=True, nsplits=2):
     mu, invcov = gaussian_problem(D, dense=dense)
     np.random.seed(seed_construct)          # R := snapshot of G at construction (ensemble.py:604,651-652)
     priors = ProbDistContainer({i: uniform_dist(-box, box) for i in range(D)})
@@ -98,6 +98,9 @@ def capture(name, T, W, D, nsteps, box, dense=True, vectorize=True, seed_constru
         tk = dict(ntemps=T)
         tk.update(tempering_kwargs or {})
         kw["tempering_kwargs"] = tk
+    if nsplits != 2:                        # RedBlueMove(nsplits=...): more than two sets (red_blue.py:41-47,148)
+        from eryn.moves import StretchMove
+        kw["moves"] = StretchMove(nsplits=nsplits)
     s = EnsembleSampler(W, D, log_like_vec if vectorize else log_like_single, priors,
                         args=[mu, invcov], vectorize=vectorize, **kw)
     if x0_uniform:
@@ -169,7 +172,7 @@ def capture(name, T, W, D, nsteps, box, dense=True, vectorize=True, seed_constru
 
         tc.temper_comps, tc.do_swaps_indexing = temper_comps, do_swaps_indexing
 
-    out = dict(T=T, W=W, D=D, nsteps=nsteps, box=float(box), dense=dense, vectorize=vectorize,
+    out = dict(T=T, W=W, D=D, nsteps=nsteps, box=float(box), dense=dense, vectorize=vectorize, nsplits=nsplits,
                seed_construct=seed_construct, seed_run=seed_run, x0_scale=float(x0_scale),
                x0_uniform=bool(x0_uniform),
                mu=mu, invcov=invcov, x0=x0, a=float(move.a))
@@ -185,8 +188,8 @@ def capture(name, T, W, D, nsteps, box, dense=True, vectorize=True, seed_constru
         for state in s.sample(x0, iterations=nsteps, store=False):
             pre = f"it{it}_"
             # ---- R log: choice, then per split randint, rand(zz), rand(acc)
-            assert [k for k, _ in rlog] == ["choice"] + ["randint", "rand", "rand"] * 2, rlog
-            for sp in (0, 1):
+            assert [k for k, _ in rlog] == ["choice"] + ["randint", "rand", "rand"] * nsplits, rlog
+            for sp in range(nsplits):
                 out[pre + f"rint{sp}"] = rlog[1 + 3 * sp][1]
                 out[pre + f"u_zz{sp}"] = rlog[2 + 3 * sp][1]
                 out[pre + f"u_acc{sp}"] = rlog[3 + 3 * sp][1]
@@ -217,9 +220,9 @@ def capture(name, T, W, D, nsteps, box, dense=True, vectorize=True, seed_constru
                 pl = pl[2:]
             names = [k for k, _ in pl]
             per_split = ["q", "factors", "logp", "logl", "keep", "subset", "x_after_split"]
-            expect = per_split * 2 + (["pre_pt"] if tc is not None else [])
+            expect = per_split * nsplits + (["pre_pt"] if tc is not None else [])
             assert names[:len(expect)] == expect, names
-            for sp in (0, 1):
+            for sp in range(nsplits):
                 blk = dict(pl[7 * sp:7 * sp + 7])
                 if keep_q:
                     out[pre + f"q{sp}"] = blk["q"]
@@ -229,11 +232,11 @@ def capture(name, T, W, D, nsteps, box, dense=True, vectorize=True, seed_constru
                 out[pre + f"keep{sp}"] = blk["keep"]
                 out[pre + f"S{sp}"] = blk["subset"]
             if tc is not None:
-                xs, Ls, Ps = pl[14][1]
+                xs, Ls, Ps = pl[7 * nsplits][1]
                 out[pre + "L_stretch"], out[pre + "P_stretch"] = Ls, Ps
                 if keep_q:
                     out[pre + "x_stretch"] = xs
-                swaps = pl[15:]
+                swaps = pl[7 * nsplits + 1:]
                 assert all(k == "swap_idx" for k, _ in swaps) and len(swaps) == T - 1
                 sel = np.zeros((T - 1, W), dtype=bool)
                 for j, (_, (i, a_, b_)) in enumerate(swaps):
@@ -290,3 +293,5 @@ if __name__ == "__main__":
     # F7 Tmax=inf ladder (beta = 0 rung: 0 * -1e300 and friends)
     capture("f7_tmaxinf", T=4, W=24, D=5, nsteps=12, box=2.0, x0_scale=0.9, x0_uniform=True,
             tempering_kwargs=dict(Tmax=np.inf))
+    # F8 three sets (RedBlueMove(nsplits=3)): uneven sets 6 / 6 / 5, the complement list = the other sets in set order
+    capture("f8_nsplits3", T=3, W=17, D=4, nsteps=12, box=50.0, nsplits=3)

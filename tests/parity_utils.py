@@ -60,7 +60,10 @@ def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=1e-12, stats=
             eng.set_adapt_time(prev[4])
     labels = rec["labels"]
     tt = np.arange(T)[:, None]
-    for sp in (0, 1):
+    nsp = getattr(o, "nsplits", 2)
+    if eng.nsplits != nsp:
+        eng.set_nsplits(nsp)
+    for sp in range(nsp):
         keep = eng.stretch_split(sp, labels, rec[f"rint{sp}"], rec[f"u_zz{sp}"], rec[f"u_acc{sp}"])
         ref = rec[f"keep{sp}"]
         bad = keep != ref
@@ -72,7 +75,7 @@ def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=1e-12, stats=
     x, L, P, _ = eng.download()
     if tolerated == 0:
         # positions: accepted rows are q = c - (c - s) zz computed without FMA -> bit-exact
-        xs = rec["x_after1"]
+        xs = rec[f"x_after{nsp - 1}"]
         assert np.array_equal(x, xs), f"x after stretch: max abs diff {np.abs(x - xs).max()}"
         assert np.array_equal(P, rec["P_stretch"]), "log-prior after stretch"
         np.testing.assert_allclose(L, rec["L_stretch"], rtol=rtol_l, atol=0)
@@ -83,7 +86,7 @@ def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=1e-12, stats=
     if o.tempered and T > 1:
         if teacher_forced and tolerated == 0:
             # swap decisions depend on L to the last bit: teacher-force the oracle's L
-            eng.upload(rec["x_after1"], rec["L_stretch"], rec["P_stretch"], prev[3])
+            eng.upload(rec[f"x_after{nsp - 1}"], rec["L_stretch"], rec["P_stretch"], prev[3])
             eng.set_adapt_time(prev[4])
         sel, swaps = eng.pt_sweep(rec["iperm"], rec["i1perm"], rec["u_swap"], adapt=True)
         bad = sel != rec["sel"]

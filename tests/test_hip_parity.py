@@ -29,13 +29,15 @@ def _fixture_oracle(fx):
     kw = {}
     if "betas0" in fx.files:
         kw.update(betas=fx["betas0"], adaptive=bool(fx["adaptive"]), permute=bool(fx["permute"]))
+    if "nsplits" in fx.files:
+        kw["nsplits"] = int(fx["nsplits"])
     o = orc.OracleSampler(fx["x0"], lambda x: orc.gaussian_log_like(x, mu, invcov), np.full(D, -box),
                           np.full(D, box), R, G, a=float(fx["a"]), record=True, **kw)
     return o, mu, invcov
 
 
 @pytest.mark.parametrize("name", ["f1_plumbing", "f2_pt", "f3_oddW", "f4_narrowbox", "f5_noadapt",
-                                  "f5_nopermute", "f6_medium", "f7_tmaxinf"])
+                                  "f5_nopermute", "f6_medium", "f7_tmaxinf", "f8_nsplits3"])
 def test_golden_fixture_teacher_forced(name, golden_dir):
     """Replay the reference's own recorded draws (committed fixtures) through the HIP path."""
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -49,7 +51,7 @@ def test_golden_fixture_teacher_forced(name, golden_dir):
         o.iteration()
         rec = o.trace[-1]
         # the oracle trace is pinned to the fixture on CPU; cross-check the masks against the file here too
-        for sp in (0, 1):
+        for sp in range(o.nsplits):
             assert np.array_equal(rec[f"keep{sp}"], fx[f"it{it}_keep{sp}"])
         tolerated += pu.check_iteration(eng, o, rec, prev, teacher_forced=True)
         o.trace.clear()

@@ -15,7 +15,7 @@ from eryn_amd.state import State
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["f2_pt", "f3_oddW", "f4_narrowbox", "f5_noadapt", "f5_nopermute", "f1_plumbing"])
+@pytest.mark.parametrize("name", ["f2_pt", "f3_oddW", "f4_narrowbox", "f5_noadapt", "f5_nopermute", "f1_plumbing", "f8_nsplits3"])
 def test_dropin_sampler_reproduces_reference_chain(name, golden_dir):
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
     T, W, D, n = int(fx["T"]), int(fx["W"]), int(fx["D"]), int(fx["nsteps"])
@@ -25,6 +25,9 @@ def test_dropin_sampler_reproduces_reference_chain(name, golden_dir):
     kw = {}
     if "betas0" in fx.files:
         kw["tempering_kwargs"] = dict(ntemps=T, adaptive=bool(fx["adaptive"]), permute=bool(fx["permute"]))
+    if "nsplits" in fx.files and int(fx["nsplits"]) != 2:     # RedBlueMove(nsplits=...): three sets (red_blue.py:41-47,148)
+        from eryn_amd.moves import StretchMove
+        kw["moves"] = StretchMove(nsplits=int(fx["nsplits"]))
     s = EnsembleSampler(W, D, GaussianLikelihood(fx["mu"], fx["invcov"]), priors, **kw)
     np.random.seed(int(fx["seed_run"]))                       # G for the run
     it = 0

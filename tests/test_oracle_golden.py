@@ -13,7 +13,7 @@ import pytest
 from oracle import eryn_oracle as orc
 
 FIXTURES = ["f1_plumbing", "f2_pt", "f3_oddW", "f4_narrowbox", "f5_noadapt",
-            "f5_nopermute", "f6_medium", "f7_tmaxinf"]
+            "f5_nopermute", "f6_medium", "f7_tmaxinf", "f8_nsplits3"]
 
 
 def _loglike(fx):
@@ -32,6 +32,8 @@ def build_oracle(fx, record=True):
     kw = {}
     if "betas0" in fx.files:
         kw.update(betas=fx["betas0"], adaptive=bool(fx["adaptive"]), permute=bool(fx["permute"]))
+    if "nsplits" in fx.files:
+        kw["nsplits"] = int(fx["nsplits"])
     return orc.OracleSampler(fx["x0"], _loglike(fx), np.full(D, -box), np.full(D, box), R, G,
                              a=float(fx["a"]), record=record, **kw)
 
@@ -59,12 +61,12 @@ def test_oracle_reproduces_reference(name, golden_dir):
         o.iteration()
         rec, pre = o.trace[-1], f"it{it}_"
         _same(rec["labels"], fx[pre + "labels"], "labels")
-        for sp in (0, 1):
+        for sp in range(o.nsplits):
             for k in ("rint", "u_zz", "u_acc", "factors", "logp", "logl", "keep"):
                 _same(rec[f"{k}{sp}"], fx[pre + f"{k}{sp}"], f"{pre}{k}{sp}")
             if pre + f"q{sp}" in fx.files:
                 _same(rec[f"q{sp}"], fx[pre + f"q{sp}"], f"{pre}q{sp}")
-            S, _ = orc.split_index_lists(rec["labels"], sp)
+            S, _ = orc.split_index_lists(rec["labels"], sp, o.nsplits)
             _same(S, fx[pre + f"S{sp}"], f"{pre}S{sp}")
         if pre + "sel" in fx.files:
             _same(rec["L_stretch"], fx[pre + "L_stretch"], "L_stretch")
