@@ -173,7 +173,7 @@ struct hens_ctx_impl {
     uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
     int64_t rj_num_mh = 0, rj_num_bd = 0;
     bool rj_have_scale = false;
-    int rj_schedule = 0;                    // hens_rj_set_schedule: 0 "separate_branches", 1 "iterate_branches" (ensemble.py:434-480)
+    int rj_schedule = 0;                    // hens_rj_set_schedule: 0 "separate_branches", 1 "iterate_branches", 2 "together" (ensemble.py:414-480)
     const uint32_t* adapt_src = nullptr;   // pending swap counts: swap_part (nullptr) or the mailbox's reduced counts
     int adapt_nblocks = 0;
 
@@ -1441,9 +1441,9 @@ int rj_ensure_staging(hens_ctx_impl* c) {
     int r;
     if ((r = dalloc(c, &c->rj_step, TW * c->D))) return r;
     if ((r = dalloc(c, &c->rj_u, TW))) return r;
-    if ((r = dalloc(c, &c->rj_birth, TW * RJ_ND))) return r;
-    if ((r = dalloc(c, &c->rj_change, TW))) return r;
-    if ((r = dalloc(c, &c->rj_leaf, TW))) return r;
+    if ((r = dalloc(c, &c->rj_birth, TW * RJ_ND * RJ_MAX_BRANCH))) return r;      // ([nbranches][Tl][W]: hens_rj_bd_all_step)
+    if ((r = dalloc(c, &c->rj_change, TW * RJ_MAX_BRANCH))) return r;
+    if ((r = dalloc(c, &c->rj_leaf, TW * RJ_MAX_BRANCH))) return r;
     if ((r = dalloc(c, &c->rj_keep, TW))) return r;
     return HENS_OK;
 }
@@ -2606,6 +2606,35 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
     return HENS_OK;
 }
 
+// "together" with the caller's draws: change / leaf [nbranches][Tl][W], birth [nbranches][Tl][W][3], one u_acc [Tl][W]
+int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf, const double* birth, const double* u_acc,
+                        uint8_t* keep_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    int r = rj_ready(c);
+    if (r) return r;
+    if (!change || !leaf || !birth || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    const size_t TW = (size_t)c->Tl * c->W, NB = (size_t)c->rj.nb;
+    for (size_t b = 0; b < NB; ++b)
+        for (size_t i = 0; i < TW; ++i) {
+            const int8_t ch = change[b * TW + i];
+            if (ch < -1 || ch > 1) return fail(c, HENS_ERR_INVALID, "change must be -1, 0 or +1");
+            if (ch != 0 && (leaf[b * TW + i] < 0 || leaf[b * TW + i] >= c->rj.nl[b])) return fail(c, HENS_ERR_INVALID, "leaf slot out of range");
+        }
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);
+    flush_adapt(c);
+    if ((r = rj_ensure_staging(c))) return r;
+    HIPCHK(c, hipMemcpyAsync(c->rj_change, change, NB * TW, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_leaf, leaf, NB * TW * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, NB * TW * RJ_ND * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    if ((r = rj_launch(c, RJ_MODE_BD, -1, nullptr, c->rj_change, c->rj_leaf, c->rj_birth, c->rj_u, c->rj_keep))) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
+    if ((r = check_flags(c, false))) return r;
+    c->rj_num_bd += 1;
+    return HENS_OK;
+}
+
 // branch of iteration `it`'s birth / death move (ensemble.py:988-990, "separate_branches"): one counter-based uniform
 static int rj_branch_of(const hens_ctx_impl* c, uint64_t it) {
     return std::min(c->rj.nb - 1, (int)(move_uniform(c->cfg.seed ^ 0x9E3779B97F4A7C15ull, it) * c->rj.nb));
@@ -2627,7 +2656,10 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
         if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
         c->rj_num_mh += 1;
         rj_cascade(c, 2 * c->iter, true);
-        if (c->rj_schedule == 1) {
+        if (c->rj_schedule == 2) {
+            // "together" (ensemble.py:414-432): ONE proposal changes a leaf in every branch of the walker; one accept test
+            if ((r = rj_launch(c, RJ_MODE_BD, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        } else if (c->rj_schedule == 1) {
             // "iterate_branches" (ensemble.py:434-451, rj.py:169-388): ONE move walks through every branch - birth / death,
             // accept, update per branch - then one sweep of swaps without adaptation; its accept mask is the last branch's
             for (int b = 0; b < c->rj.nb; ++b)
@@ -2653,7 +2685,7 @@ int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
-    if (schedule != 0 && schedule != 1) return fail(c, HENS_ERR_UNSUPPORTED, "rj schedule must be 0 (separate_branches) or 1 (iterate_branches)");
+    if (schedule < 0 || schedule > 2) return fail(c, HENS_ERR_UNSUPPORTED, "rj schedule must be 0 (separate_branches), 1 (iterate_branches) or 2 (together)");
     c->rj_schedule = schedule;
     return HENS_OK;
 }
@@ -2685,10 +2717,11 @@ int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh,
     a.iter = (uint64_t)iter; a.seed = c->cfg.seed;
     a.Tl = c->Tl; a.W = c->W; a.rung_begin = c->cfg.rung_begin;
     // "separate_branches": the chosen branch's draws; "iterate_branches": every branch's, in order (outputs [nbranches][...])
-    const int nsub = c->rj_schedule == 1 ? c->rj.nb : 1;
-    *branch = c->rj_schedule == 1 ? -1 : rj_branch_of(c, (uint64_t)iter);
+    const int nsub = c->rj_schedule >= 1 ? c->rj.nb : 1;
+    *branch = c->rj_schedule >= 1 ? -1 : rj_branch_of(c, (uint64_t)iter);
     for (int k = 0; k < nsub; ++k) {
-        a.branch = c->rj_schedule == 1 ? k : *branch;
+        a.branch = c->rj_schedule >= 1 ? k : *branch;
+        a.acc_branch = c->rj_schedule == 2 ? c->rj.nb : a.branch;      // ("together": ONE accept uniform, in every row of u_bd)
         hipLaunchKernelGGL(k_rj_debug_draws, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, a);
         HIPCHK(c, hipGetLastError());
         if (k == 0) {

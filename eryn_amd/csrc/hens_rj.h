@@ -152,12 +152,18 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             }
         }
     } else if (A.mode == RJ_MODE_BD) {
-        const int B = A.branch;
+      // one branch, or - branch < 0, the "together" schedule (ensemble.py:414-432, distgenrj.py:150-222) - every branch of the
+      // walker in one proposal: the factors add up in branch order, then the edge factors (one sum over the branches, rj.py:236-270)
+      const int b_lo = A.branch >= 0 ? A.branch : 0, b_hi = A.branch >= 0 ? A.branch + 1 : M.nb;
+      const size_t TW = (size_t)A.Tl * A.W;
+      double edge = 0.0;
+      for (int B = b_lo; B < b_hi; ++B) {
+        const size_t bo = A.branch >= 0 ? 0 : (size_t)B * TW;        // teacher-forced arrays: [nbranches][Tl][W] when all branches move
         const int nold = __builtin_popcount(mask_old[B]);
         int c, lf;
         if (A.change) {
-            c = A.change[gw];
-            lf = A.leaf[gw];
+            c = A.change[bo + gw];
+            lf = A.leaf[bo + gw];
         } else {
             const u4 d = rj_bd_raw(A.seed, A.iter, wid, B);
             c = (d.x & 1u) ? +1 : -1;                                 // distgenrj.py:63-66
@@ -176,33 +182,33 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
                 const double v = cur[M.off[B] + lf * RJ_ND + d];
                 in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
             }
-            factors = 0.0 + (in ? M.leaf_logp[B] : -INFINITY);
+            factors = factors + (in ? M.leaf_logp[B] : -INFINITY);
         } else if (c > 0) {                                           // birth from the prior: factor -log q(leaf) (:199-214)
             mask[B] |= (1u << lf);
             bool in = true;
             for (int d = 0; d < RJ_ND; ++d) {
                 double v;
                 if (A.birth) {
-                    v = A.birth[(size_t)gw * RJ_ND + d];
+                    v = A.birth[(bo + (size_t)gw) * RJ_ND + d];
                 } else {
                     v = rj_birth_coord(A.seed, A.iter, wid, B, d, M.lo[B][d], M.hi[B][d]);
                 }
                 in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
                 if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
             }
-            factors = 0.0 - (in ? M.leaf_logp[B] : -INFINITY);
+            factors = factors - (in ? M.leaf_logp[B] : -INFINITY);
         }
         if (!(M.nlmin[B] == M.nl[B] || M.nlmin[B] + 1 == M.nl[B])) {  // edge factors (rj.py:236-270)
             const int nnew = __builtin_popcount(mask[B]);
             const double lh = log(1 / 2.0);
-            double edge = 0.0;
             if (nold == M.nlmin[B]) edge += lh;
             if (nold == M.nl[B]) edge += lh;
             if (nnew == M.nlmin[B]) edge -= lh;
             if (nnew == M.nl[B]) edge -= lh;
-            factors += edge;
         }
         if (lane == 0) q[M.ind_off + B] = (double)mask[B];
+      }
+      factors += edge;
     }
     RJ_LDS_SYNC();
 
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
         total_leaves += __builtin_popcount(mask[b]);
     }
     {   // Move.fix_logp_gibbs (move.py:368-402): the branches under proposal are all of them (in-model) or one (RJ)
-        const int here = A.mode == RJ_MODE_BD ? __builtin_popcount(mask[A.branch]) : total_leaves;
+        const int here = (A.mode == RJ_MODE_BD && A.branch >= 0) ? __builtin_popcount(mask[A.branch]) : total_leaves;
         if (A.mode != RJ_MODE_EVAL) {
             if (total_leaves != 0 && here == 0) logp = -INFINITY;
             if (total_leaves == 0 && here == 0) logp = 0.0;
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     if (A.u_acc) {
         lu = log(A.u_acc[gw]);
     } else {
-        lu = log(rj_accept_uniform(A.seed, A.iter, wid, A.mode, A.mode == RJ_MODE_BD ? A.branch : 0));
+        lu = log(rj_accept_uniform(A.seed, A.iter, wid, A.mode, A.mode == RJ_MODE_BD ? (A.branch >= 0 ? A.branch : M.nb) : 0));
     }
     const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
     if (keep) {                                                        // Move.update (move.py:472-703)
@@ -353,6 +359,7 @@ struct RjDebugArgs {
     double* u_bd;        // [Tl][W] accept uniform of the birth / death move
     uint64_t iter, seed;
     int32_t Tl, W, rung_begin, branch;
+    int32_t acc_branch;  // branch field of the accept uniform's key: the branch, or nbranches ("together": one test for all)
 };
 __global__ void k_rj_debug_draws(const RjDebugArgs A) {
     const int64_t gw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -372,7 +379,7 @@ __global__ void k_rj_debug_draws(const RjDebugArgs A) {
     A.sel[gw] = d.y;
     for (int k = 0; k < RJ_ND; ++k)
         A.birth[(size_t)gw * RJ_ND + k] = rj_birth_coord(A.seed, A.iter, wid, A.branch, k, M.lo[A.branch][k], M.hi[A.branch][k]);
-    A.u_bd[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_BD, A.branch);
+    A.u_bd[gw] = rj_accept_uniform(A.seed, A.iter, wid, RJ_MODE_BD, A.acc_branch);
 }
 
 }  // namespace hens

@@ -144,6 +144,19 @@ class RJEngine:
         check(self.lib.hens_rj_bd_step(self.ctx, int(branch), ptr(ch), ptr(lf), ptr(bt), ptr(u), ptr(keep)), self.ctx)
         return keep.astype(bool)
 
+    def bd_all_step(self, change, leaf, birth, u_acc):
+        """"together": one proposal over every branch - change / leaf [nbranches, T, W], birth [nbranches, T, W, 3], u_acc [T, W]."""
+        nb = len(self.branches)
+        ch = np.ascontiguousarray(change, dtype=np.int8)
+        lf = np.ascontiguousarray(np.where(np.asarray(change) == 0, 0, leaf), dtype=np.int32)
+        bt = f64(birth, (nb, self.T, self.W, 3))
+        u = f64(u_acc, (self.T, self.W))
+        if ch.shape != (nb, self.T, self.W) or lf.shape != ch.shape:
+            raise ValueError("change / leaf must have shape (nbranches, ntemps, nwalkers)")
+        keep = np.empty((self.T, self.W), dtype=np.uint8)
+        check(self.lib.hens_rj_bd_all_step(self.ctx, ptr(ch), ptr(lf), ptr(bt), ptr(u), ptr(keep)), self.ctx)
+        return keep.astype(bool)
+
     def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
         return self.eng.pt_sweep(iperm, i1perm, u_swap, adapt=adapt)
 
@@ -158,9 +171,9 @@ class RJEngine:
 
     def set_schedule(self, rj_moves):
         """The sampler's ``rj_moves`` string for ``step`` (ensemble.py:434-480): "separate_branches" | "iterate_branches"."""
-        code = {"separate_branches": 0, "iterate_branches": 1}.get(rj_moves)
+        code = {"separate_branches": 0, "iterate_branches": 1, "together": 2}.get(rj_moves)
         if code is None:
-            raise NotImplementedError('rj_moves must be "separate_branches" or "iterate_branches"')
+            raise ValueError("rj_moves must be 'together', 'iterate_branches', or 'separate_branches'")
         check(self.lib.hens_rj_set_schedule(self.ctx, code), self.ctx)
         self.schedule = rj_moves
 
@@ -239,9 +252,9 @@ class RJEnsembleSampler:
         from .moves.tempering import TemperatureControl
         if not isinstance(log_like_fn, TemplateLikelihood):
             raise NotImplementedError("the device RJ path runs the template model: pass an eryn_amd.rj.TemplateLikelihood")
-        if rj_moves not in ("separate_branches", "iterate_branches"):
-            raise NotImplementedError('rj_moves must be "separate_branches" (one DistributionGenerateRJ per branch, one chosen per '
-                                      'iteration) or "iterate_branches" (one move that walks through every branch)')
+        if rj_moves not in ("separate_branches", "iterate_branches", "together"):
+            raise ValueError("When providing a str for rj_moves, must be 'together', 'iterate_branches', or "
+                             f"'separate_branches'. Input is {rj_moves}")                # ensemble.py:473-476
         self.rj_schedule = rj_moves
         if not isinstance(moves, GaussianLeafMove):
             raise NotImplementedError("the in-model move must be an eryn_amd.rj.GaussianLeafMove")
@@ -284,7 +297,7 @@ class RJEnsembleSampler:
                                               "multivariate_normal draws with any covariance)")
             self.engine.set_mh_scale(np.stack([np.sqrt(np.diag(moves.cov[k])) for k in self.branch_names]))
         moves.accepted = np.zeros((self.ntemps, self.nwalkers))
-        nmoves = 1 if rj_moves == "iterate_branches" else len(self.branch_names)     # (rj move objects, ensemble.py:434-471)
+        nmoves = len(self.branch_names) if rj_moves == "separate_branches" else 1    # (rj move objects, ensemble.py:414-471)
         self.rj_accepted = [np.zeros((self.ntemps, self.nwalkers)) for _ in range(nmoves)]
         self.rj_num_proposals = [0 for _ in range(nmoves)]
         # rng="philox": the device counts the birth / death move over all branches together
@@ -332,7 +345,12 @@ class RJEnsembleSampler:
         # reversible jump (ensemble.py:988-990; distgenrj.py:35-222): on one branch chosen from R, or - "iterate_branches" - one
         # move (the choice among ONE move still draws) that takes the branches in turn, its accept mask the last branch's
         nb = len(self.branches)
-        if self.rj_schedule == "iterate_branches":
+        if self.rj_schedule == "together":
+            R.choice(1, p=np.ones(1))
+            racc = self._bd_numpy_all()
+            self.rj_accepted[0] += racc
+            self.rj_num_proposals[0] += 1
+        elif self.rj_schedule == "iterate_branches":
             R.choice(1, p=np.ones(1))
             for bi in range(nb):
                 racc = self._bd_numpy(bi)
@@ -347,32 +365,54 @@ class RJEnsembleSampler:
         eng.pt_sweep(iperm, i1perm, u, adapt=False)                             # rj.py:381-382
         return acc, racc
 
+    def _bd_numpy_all(self):
+        """"together": every branch in one proposal - all branches' coins and leaf choices from R first, then the births from
+        the global stream branch by branch (distgenrj.py:166-220)."""
+        eng, tc, R, T, W = self.engine, self.temperature_control, self._random, self.ntemps, self.nwalkers
+        _, inds, _, _, betas = eng.download()
+        tc.betas = betas
+        nb = len(self.branches)
+        change, leaf, birth = np.zeros((nb, T, W), dtype=np.int64), np.zeros((nb, T, W), dtype=np.int64), np.zeros((nb, T, W, 3))
+        for bi, b in enumerate(self.branches):
+            if b.nleaves_min != b.nleaves_max:
+                change[bi], leaf[bi] = self._draw_change_leaf(b, inds[b.name])
+        for bi, b in enumerate(self.branches):
+            if b.nleaves_min != b.nleaves_max:
+                birth[bi][change[bi] == +1] = self._draw_births(b, int((change[bi] == +1).sum()))
+        return eng.bd_all_step(change, leaf, birth, R.rand(T, W))               # rj.py:332
+
+    def _draw_change_leaf(self, b, ib):
+        R, T, W = self._random, self.ntemps, self.nwalkers
+        nleaves = ib.sum(axis=-1)
+        leaf = np.zeros((T, W), dtype=np.int64)
+        change = R.choice([-1, +1], size=nleaves.shape)                         # distgenrj.py:63-66
+        change = (change * ((nleaves != b.nleaves_min) & (nleaves != b.nleaves_max))
+                  + (+1) * (nleaves == b.nleaves_min) + (-1) * (nleaves == b.nleaves_max))       # :69-73
+        for t in range(T):                                                      # one draw per walker, in order (:85-121)
+            for w in range(W):
+                if change[t, w] == +1:
+                    leaf[t, w] = R.choice(np.where(~ib[t, w])[0])
+                elif change[t, w] == -1:
+                    leaf[t, w] = R.choice(np.where(ib[t, w])[0])
+        return change, leaf
+
+    @staticmethod
+    def _draw_births(b, nbirth):
+        draws = np.zeros((nbirth, 3))
+        for d in range(3):                                                      # ProbDistContainer.rvs: GLOBAL stream, per parameter
+            draws[:, d] = np.random.rand(nbirth) * (b.hi[d] - b.lo[d]) + b.lo[d]          # prior.py:60-66, 432-497
+        return draws
+
     def _bd_numpy(self, bi):
         """Birth / death on branch ``bi`` with the reference's draws (distgenrj.py:35-222, rj.py:169-352)."""
         eng, tc, R, T, W = self.engine, self.temperature_control, self._random, self.ntemps, self.nwalkers
-        x, inds, _, _, betas = eng.download()
+        _, inds, _, _, betas = eng.download()
         tc.betas = betas
         b = self.branches[bi]
-        ib = inds[b.name]
-        nleaves = ib.sum(axis=-1)
-        change = np.zeros((T, W), dtype=np.int64)
-        leaf = np.zeros((T, W), dtype=np.int64)
-        birth = np.zeros((T, W, 3))
+        change, leaf, birth = np.zeros((T, W), dtype=np.int64), np.zeros((T, W), dtype=np.int64), np.zeros((T, W, 3))
         if b.nleaves_min != b.nleaves_max:
-            change = R.choice([-1, +1], size=nleaves.shape)                     # distgenrj.py:63-66
-            change = (change * ((nleaves != b.nleaves_min) & (nleaves != b.nleaves_max))
-                      + (+1) * (nleaves == b.nleaves_min) + (-1) * (nleaves == b.nleaves_max))       # :69-73
-            for t in range(T):                                                  # one draw per walker, in order (:85-121)
-                for w in range(W):
-                    if change[t, w] == +1:
-                        leaf[t, w] = R.choice(np.where(~ib[t, w])[0])
-                    elif change[t, w] == -1:
-                        leaf[t, w] = R.choice(np.where(ib[t, w])[0])
-            nbirth = int((change == +1).sum())
-            draws = np.zeros((nbirth, 3))
-            for d in range(3):                                                  # ProbDistContainer.rvs: GLOBAL stream, per parameter
-                draws[:, d] = np.random.rand(nbirth) * (b.hi[d] - b.lo[d]) + b.lo[d]      # prior.py:60-66, 432-497
-            birth[change == +1] = draws
+            change, leaf = self._draw_change_leaf(b, inds[b.name])
+            birth[change == +1] = self._draw_births(b, int((change == +1).sum()))
         return eng.bd_step(bi, change, leaf, birth, R.rand(T, W))               # rj.py:332
 
     def _state(self, nan_fill=False):

@@ -382,9 +382,16 @@ int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh,
  *   0  "separate_branches" (default): one DistributionGenerateRJ per branch, one of them chosen per iteration
  *   1  "iterate_branches": ONE move that walks through every branch in turn (birth / death, accept, update per branch), then
  *      one sweep of swaps without adaptation; its accept counts are the last branch's (rj.py:169-388).
- * With schedule 1 hens_rj_debug_draws returns branch = -1 and coin / sel / birth / u_bd for every branch in order
- * ([nbranches][Tl][W]...; the caller sizes them for nbranches either way).  "together" is not built. */
+ *   2  "together" (ensemble.py:414-432): ONE proposal changes a leaf in EVERY branch of the walker - all coins and leaf choices,
+ *      then the births branch by branch, the factors summed, one accept test (distgenrj.py:150-222).
+ * With schedules 1 and 2 hens_rj_debug_draws returns branch = -1 and coin / sel / birth / u_bd for every branch in order
+ * ([nbranches][Tl][W]...; the caller sizes them for nbranches either way; schedule 2: every row of u_bd is the one uniform). */
 int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule);
+
+/* Parity-mode birth / death over ALL branches in one proposal ("together"): change / leaf [nbranches][Tl][W],
+ * birth [nbranches][Tl][W][3], ONE u_acc [Tl][W] (rj.py:145-388 with gibbs_sampling_setup = None). */
+int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf, const double* birth, const double* u_acc,
+                        uint8_t* keep_out);
 
 /* The Philox iteration counter: the index of the NEXT iteration hens_step will run (iterations completed on this
  * context so far, by hens_step or by the parity API). */

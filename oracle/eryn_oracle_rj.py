@@ -162,9 +162,10 @@ class OracleRJSampler:
     def __init__(self, branches, x0, inds0, t, y, sigma, R, G, betas, adaptive=True, adaptation_lag=10000,
                  adaptation_time=100, stop_adaptation=-1, fill=-1e300, record=False, schedule="separate_branches"):
         # schedule: the sampler's ``rj_moves`` string (ensemble.py:434-480) - "separate_branches": one DistributionGenerateRJ per
-        # branch, one of them chosen per iteration; "iterate_branches": ONE move that walks through every branch in turn
-        if schedule not in ("separate_branches", "iterate_branches"):
-            raise NotImplementedError('rj schedule "together" is not restated')
+        # branch, one of them chosen per iteration; "iterate_branches": ONE move that walks through every branch in turn;
+        # "together": ONE move that proposes a birth or death in every branch of a walker at once (ensemble.py:414-432)
+        if schedule not in ("separate_branches", "iterate_branches", "together"):
+            raise ValueError("rj_moves must be 'together', 'iterate_branches', or 'separate_branches'")
         self.schedule = schedule
         self.branches = list(branches)
         self.t, self.y, self.sigma = np.asarray(t, dtype=np.float64), np.asarray(y, dtype=np.float64), float(sigma)
@@ -306,6 +307,16 @@ class OracleRJSampler:
             self.rj_accepted[0] += accepted                                        # rj.py:385-386: the LAST branch's mask
             self.rj_num_proposals[0] += 1
             return 0, accepted
+        if self.schedule == "together":
+            self._draw_branch(1)                                                   # (the choice among ONE move still draws)
+            accepted = self._rj_propose(list(range(nb)), rec)
+            rec2 = {} if rec is not None else None
+            self._pt(False, rec2)
+            if rec is not None:
+                rec.update({f"rj_{k}": v for k, v in rec2.items()})
+            self.rj_accepted[0] += accepted
+            self.rj_num_proposals[0] += 1
+            return 0, accepted
         bi = self._draw_branch(nb)
         accepted = self._rj_branch(bi, rec)
         rec2 = {} if rec is not None else None
@@ -318,54 +329,79 @@ class OracleRJSampler:
 
     def _rj_branch(self, bi, rec=None):
         """Birth / death on ONE branch: proposal, factors, prior + likelihood, accept, update (rj.py:169-352)."""
+        return self._rj_propose([bi], rec)
+
+    def _rj_propose(self, bis, rec=None):
+        """One birth / death proposal over the branches ``bis`` (one: "separate_branches" / "iterate_branches"; all of them:
+        "together") - DistributionGenerateRJ.get_proposal (distgenrj.py:150-222) inside ReversibleJumpMove.propose
+        (rj.py:169-352): every branch's coin and leaf choices first, then deaths / births and their factors branch by branch,
+        edge factors, prior + likelihood, ONE accept test, update."""
         st, T, W = self.st, self.T, self.W
-        b = self.branches[bi]
-        inds = st.inds[b.name]
-        nleaves = inds.sum(axis=-1)
         q = {k: v.copy() for k, v in st.x.items()}
         new_inds = {k: v.copy() for k, v in st.inds.items()}
         factors = np.zeros((T, W))
-        change = np.zeros((T, W), dtype=np.int64)
-        leaf = np.full((T, W), -1, dtype=np.int64)
-        birth = np.zeros((0, b.ndim))
-        if b.nleaves_min != b.nleaves_max:
-            change = self._draw_coin(nleaves.shape)
-            change = (change * ((nleaves != b.nleaves_min) & (nleaves != b.nleaves_max))
-                      + (+1) * (nleaves == b.nleaves_min) + (-1) * (nleaves == b.nleaves_max))   # :69-73
-            for tt in range(T):                                                    # :85-121, one draw per walker, in order
-                for w in range(W):
-                    if change[tt, w] == +1:
-                        leaf[tt, w] = self._draw_leaf(tt, w, np.where(~inds[tt, w])[0])
-                    elif change[tt, w] == -1:
-                        leaf[tt, w] = self._draw_leaf(tt, w, np.where(inds[tt, w])[0])
-            dt, dw = np.where(change == -1)                                        # deaths first (:188-197)
-            dl = leaf[dt, dw]
-            new_inds[b.name][dt, dw, dl] = False
-            np.add.at(factors, (dt, dw), +1 * b.leaf_logpdf(q[b.name][dt, dw, dl]))
-            bt, bw = np.where(change == +1)                                        # births (:199-214)
-            bl = leaf[bt, bw]
-            new_inds[b.name][bt, bw, bl] = True
-            birth = self._draw_birth(b, bt, bw)
-            q[b.name][bt, bw, bl] = birth
-            np.add.at(factors, (bt, bw), -1 * b.leaf_logpdf(q[b.name][bt, bw, bl]))
-        # edge factors (rj.py:236-270)
+        changes, leaves, births = {}, {}, {}
+        for bi in bis:                                                             # distgenrj.py:166-180 (first loop: R only)
+            b = self.branches[bi]
+            self._bi = bi
+            inds = st.inds[b.name]
+            nleaves = inds.sum(axis=-1)
+            change = np.zeros((T, W), dtype=np.int64)
+            leaf = np.full((T, W), -1, dtype=np.int64)
+            if b.nleaves_min != b.nleaves_max:
+                change = self._draw_coin(nleaves.shape)
+                change = (change * ((nleaves != b.nleaves_min) & (nleaves != b.nleaves_max))
+                          + (+1) * (nleaves == b.nleaves_min) + (-1) * (nleaves == b.nleaves_max))   # :69-73
+                for tt in range(T):                                                # :85-121, one draw per walker, in order
+                    for w in range(W):
+                        if change[tt, w] == +1:
+                            leaf[tt, w] = self._draw_leaf(tt, w, np.where(~inds[tt, w])[0])
+                        elif change[tt, w] == -1:
+                            leaf[tt, w] = self._draw_leaf(tt, w, np.where(inds[tt, w])[0])
+            changes[bi], leaves[bi] = change, leaf
+        for bi in bis:                                                             # :183-220 (second loop: G for the births)
+            b = self.branches[bi]
+            self._bi = bi
+            change, leaf = changes[bi], leaves[bi]
+            births[bi] = np.zeros((0, b.ndim))
+            if b.nleaves_min != b.nleaves_max:
+                dt, dw = np.where(change == -1)                                    # deaths first (:188-197)
+                dl = leaf[dt, dw]
+                new_inds[b.name][dt, dw, dl] = False
+                np.add.at(factors, (dt, dw), +1 * b.leaf_logpdf(q[b.name][dt, dw, dl]))
+                bt, bw = np.where(change == +1)                                    # births (:199-214)
+                bl = leaf[bt, bw]
+                new_inds[b.name][bt, bw, bl] = True
+                births[bi] = self._draw_birth(b, bt, bw)
+                q[b.name][bt, bw, bl] = births[bi]
+                np.add.at(factors, (bt, bw), -1 * b.leaf_logpdf(q[b.name][bt, bw, bl]))
+        # edge factors (rj.py:236-270): one array, every branch under proposal adds to it in branch order
         edge = np.zeros((T, W))
-        if not (b.nleaves_min == b.nleaves_max or b.nleaves_min + 1 == b.nleaves_max):
-            new_nl = new_inds[b.name].sum(axis=-1)
-            edge[nleaves == b.nleaves_min] += np.log(1 / 2.0)
-            edge[nleaves == b.nleaves_max] += np.log(1 / 2.0)
-            edge[new_nl == b.nleaves_min] -= np.log(1 / 2.0)
-            edge[new_nl == b.nleaves_max] -= np.log(1 / 2.0)
+        for bi in bis:
+            b = self.branches[bi]
+            if not (b.nleaves_min == b.nleaves_max or b.nleaves_min + 1 == b.nleaves_max):
+                nleaves = st.inds[b.name].sum(axis=-1)
+                new_nl = new_inds[b.name].sum(axis=-1)
+                edge[nleaves == b.nleaves_min] += np.log(1 / 2.0)
+                edge[nleaves == b.nleaves_max] += np.log(1 / 2.0)
+                edge[new_nl == b.nleaves_min] -= np.log(1 / 2.0)
+                edge[new_nl == b.nleaves_max] -= np.log(1 / 2.0)
         factors += edge
         logp = compute_log_prior(q, new_inds, self.branches)                       # rj.py:300
-        fix_logp_gibbs(logp, new_inds, [b.name])                                   # rj.py:302 (this branch only)
+        fix_logp_gibbs(logp, new_inds, [self.branches[bi].name for bi in bis])     # rj.py:302 (the branches under proposal)
         logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
+        self._bi = bis[0] if len(bis) == 1 else len(self.branches)
         u_acc = self._draw_accept("rj")
         accepted, lnpdiff = self._accept(factors, logl, logp, u_acc)
         if rec is not None:
             self._snapshot(rec, "rjpre_")
-            rec.update(rj_branch=bi, rj_change=change.copy(), rj_leaf=leaf.copy(), rj_birth=birth.copy(),
-                       rj_factors=factors.copy(), rj_logp=logp, rj_logl=logl, rj_u_acc=u_acc, rj_lnpdiff=lnpdiff,
+            if len(bis) == 1:
+                rec.update(rj_branch=bis[0], rj_change=changes[bis[0]].copy(), rj_leaf=leaves[bis[0]].copy(),
+                           rj_birth=births[bis[0]].copy())
+            else:
+                rec.update(rj_branches=list(bis), rj_change_all=[changes[bi].copy() for bi in bis],
+                           rj_leaf_all=[leaves[bi].copy() for bi in bis], rj_birth_all=[births[bi].copy() for bi in bis])
+            rec.update(rj_factors=factors.copy(), rj_logp=logp, rj_logl=logl, rj_u_acc=u_acc, rj_lnpdiff=lnpdiff,
                        rj_accepted=accepted, rj_q={k: v.copy() for k, v in q.items()},
                        rj_new_inds={k: v.copy() for k, v in new_inds.items()})
         update(st, q, new_inds, logl, logp, accepted)

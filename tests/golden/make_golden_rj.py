@@ -164,3 +164,7 @@ if __name__ == "__main__":
     # sweep of swaps without adaptation; its accept mask is the LAST branch's (rj.py:163-388)
     capture("rj4_iterate_branches", T=3, W=8, nl_max=(4, 3), nl_min=(0, 1), nsteps=16, cov_factor=1e-3, seed_run=77,
             rj_moves="iterate_branches")
+    # "together" (ensemble.py:414-432): ONE move proposes a birth or death in EVERY branch of a walker at once - all branches'
+    # coins and leaf choices first, then the births branch by branch, the factors summed, one accept test (distgenrj.py:150-222)
+    capture("rj5_together", T=3, W=8, nl_max=(4, 3), nl_min=(0, 0), nsteps=16, cov_factor=1e-3, seed_run=31,
+            rj_moves="together")

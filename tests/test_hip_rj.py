@@ -86,6 +86,16 @@ def test_rj_moves_match_the_oracle(golden_dir, name):
         for sub in rec.get("rj_sub", [rec]):
             x, inds, L, P = state_of(sub, "rjpre_", o)
             eng.upload(x, inds, L, P, rec["betas_after"])
+            if "rj_branches" in sub:                             # "together": every branch in one proposal
+                nb = len(o.branches)
+                birth = np.zeros((nb, o.T, o.W, 3))
+                for bi in range(nb):
+                    birth[bi][sub["rj_change_all"][bi] == +1] = sub["rj_birth_all"][bi]
+                keep = eng.bd_all_step(np.stack(sub["rj_change_all"]), np.stack(sub["rj_leaf_all"]), birth, sub["rj_u_acc"])
+                assert not knife(sub["rj_lnpdiff"], sub["rj_u_acc"]).any()
+                assert np.array_equal(keep, sub["rj_accepted"]), f"{what}: birth/death accept mask (all branches)"
+                assert_state(eng, sub, "rjupd_", o, what=what + " after birth/death on all branches")
+                continue
             birth = np.zeros((o.T, o.W, 3))
             birth[sub["rj_change"] == +1] = sub["rj_birth"]      # births are listed in (t, w) order (distgenrj.py:85-121)
             keep = eng.bd_step(sub["rj_branch"], sub["rj_change"], sub["rj_leaf"], birth, sub["rj_u_acc"])
@@ -247,7 +257,9 @@ def _replay_oracle_class():
             return self.d["step"][tt[:, None], ww[:, None], idx]
 
         def _k(self):                                                # entry of the birth / death arrays' branch axis
-            return self._bi if self.schedule == "iterate_branches" else 0
+            if self.schedule == "separate_branches":
+                return 0
+            return min(self._bi, len(self.branches) - 1)             # ("together": _bi = nbranches while the ONE accept uniform is drawn)
 
         def _rj_branch(self, bi, rec=None):
             self._bi = bi
@@ -257,7 +269,7 @@ def _replay_oracle_class():
             return self.d["u_mh"] if which == "mh" else self.d["u_bd"][self._k()]
 
         def _draw_branch(self, nb):
-            if self.schedule == "iterate_branches":                  # (the choice among ONE move: nothing to draw on the device)
+            if self.schedule != "separate_branches":                 # (the choice among ONE move: nothing to draw on the device)
                 assert nb == 1 and self.d["branch"] == -1 and self.d["coin"].shape[0] == len(self.branches)
                 return 0
             assert 0 <= self.d["branch"] < nb and self.d["coin"].shape[0] == 1
@@ -334,7 +346,7 @@ def _replay_rj(T, W, nl_max, nl_min, ndata, iters, seed, start_leaves=(2, 1), ca
             acc, bi, racc = o.iteration()
             mh_acc += acc
             bd_acc += racc                                           # ("iterate_branches": the last branch's mask, like the device)
-            if schedule == "iterate_branches":
+            if schedule != "separate_branches":
                 nbd = [n_ + 1 for n_ in nbd]
             else:
                 nbd[bi] += 1
@@ -373,6 +385,13 @@ def test_rj_production_step_iterate_branches_replayed_through_the_oracle(T, W, n
     branch's - on the rj4 fixture's shape and on a tight budget."""
     _replay_rj(T, W, nl_max, nl_min, ndata=60, iters=iters, seed=13, start_leaves=(2, 1), calls=(3, iters - 3),
                schedule="iterate_branches")
+
+
+@pytest.mark.parametrize("T,W,nl_max,nl_min,iters", [(3, 8, (4, 3), (0, 0), 8), (2, 64, (2, 3), (0, 1), 6)])
+def test_rj_production_step_together_replayed_through_the_oracle(T, W, nl_max, nl_min, iters):
+    """rj_moves="together" (hens_rj_set_schedule 2): one proposal changes a leaf in every branch of a walker - per-branch coins,
+    leaf choices and births, the factors summed, one accept uniform."""
+    _replay_rj(T, W, nl_max, nl_min, ndata=60, iters=iters, seed=17, start_leaves=(2, 2), calls=(3, iters - 3), schedule="together")
 
 
 def test_rj_production_step_replayed_through_the_oracle_config4():

@@ -12,7 +12,8 @@ import pytest
 from oracle import eryn_oracle_rj as orj
 
 NAMES = ["rj1_two_branches", "rj2_min_leaves", "rj3_ten_leaves"]
-NAMES_ALL = NAMES + ["rj4_iterate_branches"]          # rj_moves="iterate_branches": one RJ move walks through every branch
+# rj_moves="iterate_branches": one RJ move walks through every branch; "together": one proposal changes every branch at once
+NAMES_ALL = NAMES + ["rj4_iterate_branches", "rj5_together"]
 
 
 def load_rj(golden_dir, name):
