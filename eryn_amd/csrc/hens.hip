@@ -850,7 +850,7 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
 // ladder pipeline: this launch (one of the iteration's move launches; `final` = the last one) publishes the
 // hottest resident rung's (L, P) to the hot neighbour; ntiles = workgroups per rung of this launch
 void attach_publish(hens_ctx_impl* c, StretchArgs& a, bool final, int ntiles) {
-    if (!pipe_active(c) || !pipe_has_top(c) || !pipe_publish_fused(c)) return;
+    if (!pipe_active(c) || !pipe_has_top(c) || !pipe_publish_fused(c) || c->pipe.fused) return;   // (fused: the cascade launch publishes)
     const PipeBox hot = pipe_box(c->pipe.boxes[c->pipe.rank + 1], c->T, c->W, c->D);
     a.pub_lp = hot.lp_dn + (size_t)(c->pipe.sweep & 1u) * 2 * c->W;
     a.pub_flag = hot.flags + PF_LDN;
@@ -1108,7 +1108,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
 bool pipe_fused_possible(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FUSED") != nullptr || getenv("HENS_PIPE_NO_FUSED") != nullptr;   // A/B knob
     if (off || !pipe_active(c) || c->pipe.staged || c->label_cb <= 0 || !has_pt(c) || !fast_path(c)) return false;
-    if (c->cfg.likelihood_kind == HENS_LIKE_HOST || c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE || c->mh_kind >= 0) return false;
+    if (c->cfg.likelihood_kind == HENS_LIKE_HOST || c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE) return false;
     const int Tl = c->Tl;
     if (c->T % c->pipe.nranks != 0 || Tl != c->T / c->pipe.nranks || c->cfg.rung_begin != c->pipe.rank * Tl) return false;   // equal shards
     if (Tl < 2 || Tl > 64 || (Tl & (Tl - 1)) != 0) return false;                  // 128 / Tl columns x Tl rungs = one full tile
@@ -1116,11 +1116,17 @@ bool pipe_fused_possible(const hens_ctx_impl* c) {
     return cbl >= c->label_cb && cbl % c->label_cb == 0 && c->W % cbl == 0;
 }
 
-int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
+// mh: the iteration's move is the full-ensemble Metropolis-Hastings launch (in place, in the records; every guest goes home
+// in it), and the second launch is the cascade alone (FusedArgs::no_move)
+int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool inplace = false);
+int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh = false) {
     const int T = c->T, W = c->W, Tl = c->Tl;
     state_to_records(c);
     const uint32_t* keys = iteration_keys(c);
-    {
+    if (mh) {
+        const int r = mh_iteration(c, evs, true);
+        if (r) return r;
+    } else {
         StretchArgs a = base_args(c);
         a.wrec = c->wrec[c->cur];
         a.inplace = 1;
@@ -1173,6 +1179,7 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     f.par = (int)(c->pipe.sweep & 1u);
     f.nranks = c->pipe.nranks; f.rank = c->pipe.rank;
     f.sys_rows = pipe_has_top(c) ? 1 : 0;           // (measured on one GPU: system-scope row stores cost nothing over sc1)
+    f.no_move = mh ? 1 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (evs) {
         e0 = new_event(c); e1 = new_event(c);
@@ -1188,7 +1195,7 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
     if (r) return r;
-    c->num_proposals += 1;
+    if (!mh) c->num_proposals += 1;
     pipe_finish_sweep(c);                          // queues this sweep's counts for the adaptation, flips the record buffers
     return HENS_OK;
 }
@@ -1349,6 +1356,10 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
     a.dr.lu = c->mh_lu;
     a.accepted = c->accepted_mh;
     a.keep_out = want_keep ? c->mh_keep : nullptr;
+    if (c->pipe.fused) {                           // fused pipeline iteration: every guest goes home in this launch
+        a.ghome = c->pipe.ghome;
+        a.sys_all = pipe_has_top(c) ? 1 : 0;
+    }
     attach_iteration_head(c, a);
     attach_publish(c, a, true, (c->W + TILE - 1) / TILE);
     if (evs) {
@@ -1368,7 +1379,7 @@ int mh_launch(hens_ctx_impl* c, bool want_keep, std::vector<hipEvent_t>* evs, bo
 // Philox mode: draw the iteration's steps and accept uniforms on the device, then propose.  Isotropic and
 // axis-aligned proposals on the fast row widths are drawn inside the MH launch itself (one Box-Muller pair per
 // lane); a full covariance (Cholesky product) and the generic row widths go through k_mh_draw + the step buffer.
-int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool inplace = false) {
+int mh_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool inplace) {
     const bool inline_draws = c->mh_kind != MH_FULL && fast_path(c);
     if (!inline_draws) {
         MhDrawArgs d{};
@@ -2135,8 +2146,6 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         c->pipe.fused_decided = true;
     }
     const bool pfused = piped && c->pipe.fused;
-    if (pfused && c->mh_kind >= 0)
-        return fail(c, HENS_ERR_UNSUPPORTED, "ladder pipeline: set the Metropolis-Hastings proposal before the first hens_step call (a rank that steps in place cannot change its path)");
     // (the state stays in record mode between hens_step calls of the record paths - every other entry point settles it,
     //  settle_state - so a short call pays no pack / unpack)
     if (!fused && !iter1 && !pfused) state_to_fields(c);
@@ -2227,7 +2236,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             if (piped) pipe_prewait(c);
             const bool mh = iteration_is_mh(c);
             if (pfused) {
-                r = pipe_fused_iteration(c, prof ? &evs : nullptr);
+                r = pipe_fused_iteration(c, prof ? &evs : nullptr, mh);
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
                 if (r) return step_failed(c, r);
                 c->iter += 1;

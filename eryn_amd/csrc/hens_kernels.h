@@ -1313,6 +1313,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 rc = rs;
                 lu = A.mh_step ? A.dr.lu[(size_t)tl * W + own]
                                : mh_log_uniform(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)own);
+                if (PIPE && A.ghome) ghome_row = A.ghome[rs < 0 ? ~rs : 0];   // (fused pipeline iteration: every guest goes home here)
                 if (A.wrec) {
                     const double2 lp = *reinterpret_cast<const double2*>(&A.wrec[tl * W + own].L);
                     Lold = lp.x; Pold = lp.y;
@@ -2280,6 +2281,7 @@ struct FusedArgs {
     uint32_t sweep;
     int32_t par, nranks, rank;
     int32_t sys_rows;                                         // rows are stored at system scope (a peer pulls rows out of this pool)
+    int32_t no_move;                                          // PIPE: the cascade alone (the iteration's move was a full-ensemble MH launch)
 };
 
 // (pipe: the cascade tables hold one more rung - what the hot neighbour's columns carry - and the bottom boundary's lists)
@@ -2375,6 +2377,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     int32_t home_n = 0;                                                  // PIPE: home row of a moving walker that sits in a guest row
     const int HS = A.cb_shift - 1, HB = 1 << HS;                         // half a label block
     const int HW = CB >> 1;                                              // moving walkers per rung of this workgroup
+    const bool nomove = PIPE && A.no_move != 0;                          // every slot stays: the records go straight into the tables
     constexpr int CWW = WIDE ? 5 : 2, FLW = WIDE ? 6 : 3;               // the waves of the moving walkers' draws
     // index of the moving walker met by column cc of rung t among the workgroup's 64
     auto mover_of = [&](int t, int cc) -> int {
@@ -2395,7 +2398,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             slot_n = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
             wr_n = A.wrec[(size_t)t * W + slot_n];
         }
-        stays = PIPE ? ((cc >> HS) & 1) == 0 : cc < HB;
+        stays = PIPE ? (nomove || ((cc >> HS) & 1) == 0) : cc < HB;
         if (!stays) {
             const int m = mover_of(t, cc);
             s_rs[m] = wr_n.loc;
@@ -2434,7 +2437,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     if (WIDE && tid >= 2 * NE && tid < 2 * NE + 64) {
         if (lane < TE) sbeta[lane] = A.betas[R0 + lane];
     }
-    if ((wv == CWW || wv == FLW) && lane < NM) {
+    if ((wv == CWW || wv == FLW) && lane < NM && !nomove) {
         const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));   // split position (second half)
         const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q);
         if (wv == CWW) {
@@ -2478,7 +2481,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
-        rv[p] = r < NM;
+        rv[p] = r < NM && !nomove;
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
@@ -2527,7 +2530,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     if (HENS_CUT_F == 2) return;
 
     // ---- phase C: likelihood ------------------------------------------------------------------------------
-    {
+    if (!nomove) {
         const bool inbox = (s_flag[lane] & 1) != 0;
         s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW, CEN>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }

@@ -77,7 +77,7 @@ def test_pipeline_delayed_adaptation_is_rank_count_invariant(tmp_path, nranks, T
     np.testing.assert_allclose(exact["betas"], ref["betas"], rtol=0.05)
 
 
-@pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 256, 128, 10), (4, 4, 64, 16, 10)])
+@pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 256, 128, 10), (4, 4, 64, 16, 10), (2, 8, 512, 32, 24), (4, 8, 256, 16, 16)])
 def test_pipeline_rosenbrock_move_mix(tmp_path, nranks, T, W, D, iters):
     """BASELINE config 4 in small: Rosenbrock likelihood (ndim = 128: the generic-row-width kernels, wait and
     publish kernels instead of the fused prologues), StretchMove + GaussianMove mixed by weight, sharded."""
