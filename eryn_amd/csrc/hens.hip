@@ -260,6 +260,16 @@ size_t fast_lds_bytes(int D, int NW) {
 template <int LIKE, int MODE>
 int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
+    {
+        // Consecutive workgroups go round-robin to the 8 XCDs, each with an L2 of its own that keeps its lines from launch to
+        // launch: renumbered, an XCD works on WHOLE rungs (T = 16: two of them), so the rows a rung's half-step gathers - every
+        // row of the rung, as own row or as complement - are the rows the same XCD gathered an iteration ago, minus what the
+        // second launch (column blocks over all rungs: no such order possible) pushed out in between.  Config 2, same box:
+        // 8.45 -> 8.0 us per first launch (7.65 with the second launch's row traffic removed: the ceiling of the idea);
+        // 16 x 16384 x 32 27.7 -> 27.3; HENS_NO_XCD=1 is the A/B knob.
+        static const bool xcd = getenv("HENS_NO_XCD") == nullptr;
+        if (xcd && (ntiles & (ntiles - 1)) == 0 && ((long)ntiles * c->Tl) % 8 == 0) { int sh = 0; while ((1 << sh) < ntiles) ++sh; a.xcd_shift = sh + 1; }
+    }
 #define LAUNCH_FAST_P(DT, NW, PIPE, PER)                                                           \
     do {                                                                                           \
         const size_t lds = fast_lds_bytes(DT, NW) + (a.tab_lds ? (size_t)c->W * 4 : 0);            \

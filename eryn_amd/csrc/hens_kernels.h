@@ -572,6 +572,7 @@ struct StretchArgs {
     // rule from N0 / split); `split` is then 0 for the first set, 1 for the last (every complement already sits in its home
     // row) and 2 for the ones between
     int32_t ns_x, soff_x;
+    int32_t xcd_shift;         // > 0: log2(tiles per rung) + 1 - workgroups are renumbered so that an XCD (linear id mod 8) works on whole rungs
     AdaptArgs ad;
 };
 
@@ -1061,11 +1062,15 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int ADW = 1;                      // the wave that runs the early ladder adaptation (a 9th, adaptation-only
                                                 // wave was measured: two 9-wave workgroups do not pack onto one CU)
-    const int tl = blockIdx.y;
+    int bx = blockIdx.x, tl = blockIdx.y;
+    if (A.xcd_shift > 0) {                      // dispatch order deals consecutive workgroups round-robin to the 8 XCDs
+        const int sh = A.xcd_shift - 1, L = bx + (tl << sh), g = (L & 7) * ((int)(gridDim.x * gridDim.y) >> 3) + (L >> 3);
+        tl = g >> sh; bx = g & ((1 << sh) - 1);
+    }
     const int W = A.W;
     const int Ns = (EVAL || MH) ? W : (A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : W - A.N0));
     const int s_off = (EVAL || MH) ? 0 : (A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0));
-    const int k0 = blockIdx.x * TILE;
+    const int k0 = bx * TILE;
     const bool ad_on = !EVAL && NW >= 2 && A.ad_on;
     // mode 2: only workgroup (0,0) reduces the counts and adapts; everyone else reads its rung's beta from the ring
     const bool ad_lead = ad_on && A.ad_on == 2;
