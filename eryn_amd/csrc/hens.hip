@@ -933,12 +933,13 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
             hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), lds, c->stream, f); \
     } while (0)
 #ifdef HENS_DEV_BUILD
-#define LAUNCH_FUSED(DT, NW) do { if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false); else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true); else LAUNCH_FUSED_P(DT, NW, false, false, false, false); } while (0)
+#define LAUNCH_FUSED(DT, NW) do { if (pipe && col) LAUNCH_FUSED_P(DT, NW, false, false, true, true); else if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false); else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true); else LAUNCH_FUSED_P(DT, NW, false, false, false, false); } while (0)
 #else
 #define LAUNCH_FUSED(DT, NW)                                                                       \
     do {                                                                                           \
         const bool short_tiles = c->T * c->label_cb != 2 * TILE;                                   \
-        if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false);                               \
+        if (pipe && col) LAUNCH_FUSED_P(DT, NW, false, false, true, true);                         \
+        else if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false);                          \
         else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true);                           \
         else if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true, false, false);        \
         else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false, false, false);                      \
@@ -968,14 +969,16 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
 // the state as one record per walker (k_split1_pt, k_stretch_fast with StretchArgs::wrec) <-> by-field arrays (everything else)
 const uint32_t* iteration_keys(hens_ctx_impl* c);
 bool col_ok(const hens_ctx_impl* c);
+bool pipe_col_ok(const hens_ctx_impl* c);
 void state_to_records(hens_ctx_impl* c) {
     if (c->packed) return;
     const int64_t n = (int64_t)c->Tl * c->W;
-    if (col_ok(c)) {
+    if (col_ok(c) || pipe_col_ok(c)) {
         // column order of iteration c->iter, into the OTHER buffers (the compact row table is permuted too: not in place)
-        const uint32_t* keys = iteration_keys(c);
+        // (a pipeline rank: its Tl rungs, whose round keys start at rung_begin)
+        const uint32_t* keys = iteration_keys(c) + (size_t)c->cfg.rung_begin * 8;
         hipLaunchKernelGGL(k_pack_cols, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
-                           c->accepted, keys, c->wrec[c->cur ^ 1], c->loc[c->cur ^ 1], c->T, c->W, c->idx_bits);
+                           c->accepted, keys, c->wrec[c->cur ^ 1], c->loc[c->cur ^ 1], c->Tl, c->W, c->idx_bits);
         c->cur ^= 1;
         c->packed = c->colmode = true;
         return;
@@ -988,9 +991,9 @@ void state_to_fields(hens_ctx_impl* c) {
     if (!c->packed) return;
     const int64_t n = (int64_t)c->Tl * c->W;
     if (c->colmode) {
-        const uint32_t* keys = iteration_keys(c);            // (the order the last launch wrote: iteration c->iter's)
+        const uint32_t* keys = iteration_keys(c) + (size_t)c->cfg.rung_begin * 8;   // (the order the last launch wrote: iteration c->iter's)
         hipLaunchKernelGGL(k_unpack_cols, dim3(grid_for(n)), dim3(256), 0, c->stream, c->wrec[c->cur], keys, c->L[c->cur],
-                           c->P[c->cur], c->loc[c->cur], c->accepted, c->T, c->W, c->idx_bits);
+                           c->P[c->cur], c->loc[c->cur], c->accepted, c->Tl, c->W, c->idx_bits);
         c->packed = c->colmode = false;
         return;
     }
@@ -1144,6 +1147,7 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh
         a.iseed = c->cfg.seed; a.iiter = c->iter; a.ia = c->cfg.a;
         a.idx_bits = c->idx_bits; a.hb_shift = c->label_cb_shift - 1; a.ndim_active = dim_active(c);
         a.split = 0;
+        a.col = c->colmode ? 1 : 0;                // column-ordered records (pipe_col_ok)
         a.home_off = c->parity * Tl * W;
         a.ghome = c->pipe.ghome;
         a.sys_all = pipe_has_top(c) ? 1 : 0;
@@ -1164,6 +1168,7 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh
     f.loc = c->loc[c->cur]; f.locnew = c->loc[c->cur ^ 1];
     f.betas = c->betas[c->bcur];
     f.keys = keys;
+    f.keys_next = keys + (size_t)T * 8;             // (inside the window: iteration_keys)
     f.a = c->cfg.a; f.ndim_active = dim_active(c);
     f.accepted = c->accepted;
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
@@ -1197,10 +1202,10 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh
     }
     int r;
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1, true); break;
+        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1, true, c->colmode); break;
 #ifndef HENS_DEV_BUILD
-        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1, true); break;
-        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1, true); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1, true, c->colmode); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1, true, c->colmode); break;
 #endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
@@ -1234,6 +1239,11 @@ bool iter_ok(const hens_ctx_impl* c) {
 // by slot).  Round 3, config 2: both launches' index phases were a round key -> permutation -> scattered record load chain
 // (4 600 / 4 700 cycles to the first barrier); in column order the records load coalesced at the head of the launch and the
 // first launch looks rows up in an LDS copy of its rung's table.
+// the same on a rank of the ladder pipeline that steps with the two in-place launches (every rank reaches the same verdict)
+bool pipe_col_ok(const hens_ctx_impl* c) {
+    static const bool off = getenv("HENS_NO_COL") != nullptr || getenv("HENS_PIPE_NO_COL") != nullptr;   // A/B knobs
+    return !off && pipe_active(c) && c->pipe.fused && !c->period && c->mh_kind < 0 && (c->W & 3) == 0;
+}
 bool col_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_COL") != nullptr;                // A/B knob: records by slot
     if (off || !fused_ok(c) || iter_ok(c) || c->period || c->mh_kind >= 0) return false;

@@ -1339,6 +1339,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 late_ua = 1.0;                                   // ((D - 1) log zz: after the row gathers have been issued)
                 rs = A.tab_lds ? own : la.x;                     // (tab_lds: the column; phase B looks the row up)
                 acc_old = (uint32_t)la.y;                        // (consumed in phase D: the record load gates no barrier then)
+                if (PIPE && A.ghome) ghome_row = A.ghome[la.x < 0 ? ~la.x : 0];
                 Lold = lp.x; Pold = lp.y;
             } else if (A.ikeys) {
                 // in registers: the Philox call first (it needs no key: the scalar load of the rung's round keys is in
@@ -2310,7 +2311,7 @@ template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false, bool P
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
     static_assert(!(PIPE && (PER || SHORT)), "pipeline ranks: full tiles, no periodic parameters");
-    static_assert(!(COL && (PER || SHORT || PIPE)), "column-ordered records: full tiles on one GPU");
+    static_assert(!(COL && (PER || SHORT)), "column-ordered records: full tiles");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr bool CEN = like_centred(LIKE, DT);
     constexpr int D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP;
@@ -2430,10 +2431,10 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         // that nothing in front of the barrier needs: on the two waves with nothing else to do (measured: on the slot threads
         // the barrier came 1000 cycles later, on the uniform-drawing waves 700)
         const int e = (NW >= 8 ? (wv == 4 ? 0 : 64) : wv * 64) + lane, t = e >> CS, c = c0 + (e & (CB - 1));
-        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)t * 2;
+        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
         const uint4 ka = kp[0], kb = kp[1];
         const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        const uint4* kn = reinterpret_cast<const uint4*>(A.keys_next) + (size_t)t * 2;
+        const uint4* kn = reinterpret_cast<const uint4*>(A.keys_next) + (size_t)(R0 + t) * 2;
         const uint4 na = kn[0], nb = kn[1];
         const uint32_t keyn[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
         const uint32_t slot = prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
@@ -2662,7 +2663,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         if (has_top) {
             if (tid >= ((T - 1) << CS) && tid < (T << CS)) {
                 const PipeBox hot = pipe_box(A.box_hot, TG, W, D);
-                const int slot = scol[tid];
+                // (column-ordered records: the hot neighbour's column c meets the walker at index c - no permutation on its side)
+                const int slot = COL ? c0 + (tid & (CB - 1)) : scol[tid];
                 sys_store(hot.lp_dn + (size_t)(A.par * 2) * W + slot, Lc[tid]);
                 sys_store(hot.lp_dn + (size_t)(A.par * 2 + 1) * W + slot, Pc[tid]);
                 __hip_atomic_store(hot.ldn_loc + (size_t)A.par * W + slot, locc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2780,10 +2782,13 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             __syncthreads();
             if (tid < CB) {
                 const int cc = tid, c = c0 + cc, g = R0;
-                const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(g - 1) * 2;
-                const uint4 ka = kp[0], kb = kp[1];
-                const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-                const int slot_below = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+                int slot_below = c;                                                  // (column-ordered records: published by column)
+                if (!COL) {
+                    const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(g - 1) * 2;
+                    const uint4 ka = kp[0], kb = kp[1];
+                    const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+                    slot_below = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
+                }
                 const double La = Lc[se_n];
                 const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
                 const double db = A.betas[g - 1] - A.betas[g];                       // tempering.py:518-522
