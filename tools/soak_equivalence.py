@@ -32,6 +32,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "iter":
         same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
         print(f"({T},{Wk},{D}) {n} iterations mh={mh}: one launch per iteration == two launches:", same)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "xcd":
+    # first launch with workgroups renumbered so that an XCD works on whole rungs (its L2 keeps rows from launch to launch)
+    # against the plain numbering (HENS_NO_XCD=1): a stale line in one XCD's L2 would show up as a different chain
+    for (T, Wk, D, n, mh) in ((16, 4096, 32, 200000, 0), (8, 16384, 64, 20000, 0), (16, 4096, 32, 60000, 1), (4, 2048, 16, 100000, 0)):
+        outs = []
+        for tag, env in (("xcd", {}), ("plain", {"HENS_NO_XCD": "1"})):
+            out = f"/tmp/soak_{tag}.npz"
+            r = subprocess.run([sys.executable, "-c", W, root, str(T), str(Wk), str(D), str(n), str(mh), out], env=dict(os.environ, **env), capture_output=True, text=True)
+            print(tag, r.stdout.strip()[-200:], r.stderr.strip()[-300:])
+            outs.append(dict(np.load(out)))
+        same = all(np.array_equal(outs[0][k], outs[1][k]) for k in outs[0])
+        print(f"({T},{Wk},{D}) {n} iterations mh={mh}: XCD-affine first launch == plain numbering:", same)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "col":
     # column-ordered records (round 3: coalesced record loads, next buffers written in the NEXT iteration's column order by
     # scattered stores) against slot-ordered records (HENS_NO_COL=1) from the same seed; chunks of 7777 iterations also cross
