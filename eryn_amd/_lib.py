@@ -84,6 +84,8 @@ SIGNATURES = {
     "hens_mh_step": (C.c_int, [_P, _P, _P, _P]),
     "hens_set_mh_proposal": (C.c_int, [_P, C.c_int32, _P, C.c_double]),
     "hens_get_mh_counters": (C.c_int, [_P, _P, _P]),
+    "hens_step_marked": (C.c_int, [_P, C.c_int64, C.c_int64]),
+    "hens_get_marked_counters": (C.c_int, [_P, _P, _P]),
     "hens_pipe_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "hens_pipe_connect": (C.c_int, [_P, _P]),
     "hens_pipe_connect_local": (C.c_int, [_P, _P]),

@@ -162,6 +162,8 @@ struct hens_ctx_impl {
     uint8_t* mh_keep = nullptr;            // [Tl][W]
     double* mh_scale = nullptr;            // [D*D] proposal scale (see MhDrawArgs)
     uint32_t* accepted_mh = nullptr;       // [Tl][W] accept counts of the MH move
+    uint32_t* accepted_mark = nullptr;     // [2][Tl][W] hens_step_marked: stretch / MH accept counts in front of the call's last iterations
+    bool mark_valid = false, mark_mh = false;
     int mh_kind = -1;                      // -1: hens_step runs the stretch move only
     double mh_weight = 0.0;                // probability that an iteration of hens_step is an MH proposal
     int64_t num_proposals_mh = 0;
@@ -2329,6 +2331,42 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             else { c->timing.fused_ms += ms; c->timing.n_fused += 1; }
         }
     }
+    return HENS_OK;
+}
+
+// hens_step(n_before), then the accept counters as they stand are kept on the device, then hens_step(n_last): what the
+// reference stores per thinned step is the accept mask of the LAST sub-iteration only (ensemble.py:968-979), and the host
+// loop no longer has to split the call and read the counters in between (a settled ladder adaptation, two device-to-host
+// copies and their synchronisations per stored sample).
+int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (n_before < 0 || n_last < 0) return fail(c, HENS_ERR_INVALID, "negative iteration count");
+    int r;
+    if (n_before > 0 && (r = hens_step(ctx, n_before))) return r;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    if (!c->accepted_mark && (r = dalloc(c, &c->accepted_mark, 2 * TW))) return r;
+    state_to_fields(c);                       // (the counters ride in the walker records during a hens_step call)
+    HIPCHK(c, hipMemcpyAsync(c->accepted_mark, c->accepted, TW * 4, hipMemcpyDeviceToDevice, c->stream));
+    c->mark_mh = c->accepted_mh != nullptr;
+    if (c->mark_mh) HIPCHK(c, hipMemcpyAsync(c->accepted_mark + TW, c->accepted_mh, TW * 4, hipMemcpyDeviceToDevice, c->stream));
+    c->mark_valid = true;
+    return n_last > 0 ? hens_step(ctx, n_last) : HENS_OK;
+}
+
+// the counters kept by the last hens_step_marked call ([Tl][W] each; accepted_mh may be null; zeros if there is no MH move)
+int hens_get_marked_counters(hens_ctx* ctx, double* accepted, double* accepted_mh) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (!c->mark_valid) return fail(c, HENS_ERR_STATE, "hens_get_marked_counters without hens_step_marked");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    std::vector<uint32_t> h(2 * TW, 0u);
+    HIPCHK(c, hipMemcpyAsync(h.data(), c->accepted_mark, (c->mark_mh ? 2 : 1) * TW * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (accepted) for (size_t i = 0; i < TW; ++i) accepted[i] = (double)h[i];
+    if (accepted_mh) for (size_t i = 0; i < TW; ++i) accepted_mh[i] = (double)h[TW + i];
     return HENS_OK;
 }
 

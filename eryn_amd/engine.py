@@ -196,6 +196,18 @@ class HipEnsemble:
     def step(self, n_iters):
         check(self.lib.hens_step(self.ctx, int(n_iters)), self.ctx)
 
+    def step_marked(self, n_before, n_last):
+        """n_before iterations, the accept counters kept on the device, n_last iterations (thin_by > 1: the reference stores
+        the accept mask of the last sub-iteration only, ensemble.py:968-979); see marked_counters."""
+        check(self.lib.hens_step_marked(self.ctx, int(n_before), int(n_last)), self.ctx)
+
+    def marked_counters(self):
+        """The accept counts (stretch move, MH move) in front of the last step_marked call's final iterations."""
+        acc = np.zeros((self.Tl, self.W))
+        acc_mh = np.zeros((self.Tl, self.W))
+        check(self.lib.hens_get_marked_counters(self.ctx, ptr(acc), ptr(acc_mh)), self.ctx)
+        return acc, acc_mh
+
     def synchronize(self):
         check(self.lib.hens_synchronize(self.ctx), self.ctx)
 

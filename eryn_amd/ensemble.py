@@ -293,15 +293,22 @@ class EnsembleSampler:
             # 1013-1024: `accepted` is re-zeroed every sub-iteration); the moves' own counters see every step
             # (num_repeats_in_model device iterations make one sampler sub-iteration: its accept mask sums over the repeats,
             #  ensemble.py:968-975)
-            mid, mid_mh = prev, prev_mh
-            if thin_by > 1:
-                eng.step((thin_by - 1) * reps)
-                mid = eng.counters()
-                mid_mh = eng.mh_counters() if mh_move is not None else None
-            eng.step(reps)
+            # (thin_by > 1: ONE device call; the counters in front of the last sub-iteration stay on the device until the
+            #  download below - no split call, no counter read in between)
+            mid_acc, mid_mh_acc = prev["accepted"], None if prev_mh is None else prev_mh["accepted"]
+            if thin_by > 1 and hasattr(eng, "step_marked"):
+                eng.step_marked((thin_by - 1) * reps, reps)
+            else:
+                if thin_by > 1:
+                    eng.step((thin_by - 1) * reps)
+                    mid_acc = eng.counters()["accepted"]
+                    mid_mh_acc = eng.mh_counters()["accepted"] if mh_move is not None else None
+                eng.step(reps)
             x, L, P, betas = eng.download()
             c = eng.counters()
-            accepted = c["accepted"] - mid["accepted"]
+            if thin_by > 1 and hasattr(eng, "step_marked"):
+                mid_acc, mid_mh_acc = eng.marked_counters()
+            accepted = c["accepted"] - mid_acc
             if st_move is not None:
                 st_move.accepted += c["accepted"] - prev["accepted"]
                 st_move.num_proposals += c["num_proposals"] - prev["num_proposals"]
@@ -309,7 +316,7 @@ class EnsembleSampler:
                 cm = eng.mh_counters()
                 mh_move.accepted += cm["accepted"] - prev_mh["accepted"]
                 mh_move.num_proposals += cm["num_proposals"] - prev_mh["num_proposals"]
-                accepted = accepted + (cm["accepted"] - mid_mh["accepted"])
+                accepted = accepted + (cm["accepted"] - mid_mh_acc)
                 prev_mh = cm
             swaps = None
             if tc is not None:

@@ -172,6 +172,13 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
  * Asynchronous on the context's stream; hens_synchronize / any download waits. */
 int hens_step(hens_ctx* ctx, int64_t n_iters);
 
+/* hens_step(n_before), keep the accept counters as they stand on the device, hens_step(n_last): the reference stores the
+ * accept mask of the LAST thinned sub-iteration only (ensemble.py:968-979: `accepted` is re-zeroed per sub-iteration), and
+ * a host loop with thin_by > 1 needs no call split and no counter read in between.  hens_get_marked_counters downloads the
+ * kept counts ([rungs][nwalkers] f64 each: stretch move, MH move - zeros without one; either pointer may be null). */
+int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last);
+int hens_get_marked_counters(hens_ctx* ctx, double* accepted, double* accepted_mh);
+
 /* Counters.  Replaces Move.accepted / num_proposals (move.py:404-421, red_blue.py:326-327),
  * TemperatureControl.swaps_accepted / time (tempering.py:542,596).  Any pointer may be NULL.
  *   accepted[Tl][W] f64 cumulative, swaps_last[T-1], swaps_total[T-1] f64. */

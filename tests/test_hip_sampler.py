@@ -248,3 +248,37 @@ def test_philox_chain_resumes_bit_identically_from_a_stored_state(T, W, D, reps,
     with pytest.raises(ValueError):                                     # another seed is another stream
         EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=78, num_repeats_in_model=reps,
                         **(dict(tempering_kwargs=dict(ntemps=T)) if T > 1 else {})).run_mcmc(first[-1], 1)
+
+
+@pytest.mark.parametrize("mix", [False, True])
+def test_philox_thinned_accept_mask_is_the_last_sub_iterations(mix):
+    """ensemble.py:968-979: with thin_by > 1 the stored accept mask is the LAST sub-iteration's.  The thinned run keeps the
+    counters in front of that sub-iteration on the device (hens_step_marked); an unthinned run of the same chain gives the
+    per-iteration masks to compare with."""
+    from eryn_amd.moves import GaussianMove, StretchMove
+    T, W, D, thin, reps, n = 4, 256, 8, 3, 2, 5
+    rs = np.random.RandomState(5)
+    A = rs.randn(D, D)
+    mu, invcov = 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    x0 = np.random.RandomState(2).randn(T, W, D)
+
+    def sampler():
+        moves = [(StretchMove(), 0.5), (GaussianMove({"model_0": 0.05 * np.eye(D)}), 0.5)] if mix else None
+        return EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=11, moves=moves,
+                               num_repeats_in_model=reps, tempering_kwargs=dict(ntemps=T))
+
+    a, masks, last = sampler(), [], None
+    for _ in a.sample(x0, iterations=n * thin, thin_by=1, store=True):
+        cur = a.backend.accepted.copy()
+        masks.append(cur if last is None else cur - last)
+        last = cur
+    b, got, last = sampler(), [], None
+    for _ in b.sample(x0, iterations=n, thin_by=thin, store=True):
+        cur = b.backend.accepted.copy()
+        got.append(cur if last is None else cur - last)
+        last = cur
+    for k in range(n):
+        assert np.array_equal(got[k], masks[k * thin + thin - 1]), f"stored step {k}"
+    assert any(m.any() for m in got)
+    assert np.array_equal(a.get_chain()["model_0"][thin - 1::thin], b.get_chain()["model_0"])
