@@ -181,8 +181,31 @@ def whole_path(roof, T, W, D, f_sw, acc, value):
     per_iter = sum(k["bytes_moved"] * k["launches_per_iteration"] for k in roof["kernels"])
     wm = per_iter / (T * W) * value / 1e9
     roof.update(whole_path_GBps=w8, whole_path_frac=w8 / HBM_PEAK_GBS, whole_path_moved_GBps=wm,
-                whole_path_frac_moved=wm / HBM_PEAK_GBS)
+                whole_path_frac_moved=wm / HBM_PEAK_GBS,
+                # SURVEY 8d's conservative figure: B_stretch alone (no credit for the cascade's bytes)
+                stretch_only_frac=b_stretch(D) * value / 1e9 / HBM_PEAK_GBS)
     assert roof["whole_path_frac"] <= 1.0 and roof["whole_path_frac_moved"] <= 1.0
+
+
+def measured_copy_bandwidth():
+    """the box's own HBM rate beside the spec peak - a device-to-device copy of 1 GiB (read + write), GB/s."""
+    try:
+        n = 1 << 27
+        a = torch.empty(n, dtype=torch.float64, device="cuda").normal_()
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            b.copy_(a)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        del a, b
+        torch.cuda.empty_cache()
+        return 2 * n * 8 / dt / 1e9
+    except Exception:                      # (a figure beside the line, never a reason to lose the line)
+        return None
 
 
 def timed_blocks(step, sync, steps, dist=None, device=None):
@@ -248,6 +271,10 @@ def run_single(args):
     value = T * W * args.steps / dt
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
     whole_path(roof, T, W, D, f_sw, acc, value)
+    if not args.no_cpu:                      # (the secondary figures of the default run; --no-cpu = the bare line)
+        bw = measured_copy_bandwidth()
+        roof["measured_copy_GBps"] = bw       # this box's device-to-device copy rate, beside the 8 TB/s spec peak
+        roof["whole_path_frac_of_measured_copy"] = None if not bw else roof["whole_path_GBps"] / bw
     out = {
         "metric": METRIC, "value": value, "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
