@@ -1110,6 +1110,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // Two parts, so that a wave can run the first one (ratios, dS, exp, deltaT: ~2500 cycles of dependent FP64 divides
     // that need the counts but not the cumulative sum) while it would otherwise idle before the first barrier, and only
     // the second one (cumsum, reciprocals, update) in the shadow of the row gathers.
+    const bool ad_early = ad_here && A.ad.nblocks <= 8 * A.ad.row_groups;
+    const bool ad_defer = ad_early && !PIPE && !ad_lead;
+    const bool ad_x = ad_defer && NW >= 4 && A.ad.T <= 64 && A.ad.moving;    // (see ADX below)
     double ad_c0 = 0.0, ad_c1 = 0.0, ad_dT0 = 0.0, ad_dT1 = 0.0, ad_b0n = 1.0, ad_b1n = 1.0, ad_bb0 = 1.0, ad_bb1 = 1.0, ad_inv0 = 1.0;
     auto adapt_part1 = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1, const bool exp_elsewhere = false) {
         const int T = A.ad.T;
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (blockIdx.x == 0 && blockIdx.y == 0) {
             if (e0 < T) A.ad.betas_out[e0] = bnew0;
             if (e1 < T) A.ad.betas_out[e1] = bnew1;
-            if (e0 < T - 1) {
+            if (e0 < T - 1 && !ad_x) {             // (ad_x: wave ADX, the only reader of the counts then, keeps these books)
                 A.ad.swaps_last[e0] = cnt0;
                 A.ad.swaps_total[e0] += cnt0;
             }
@@ -1215,7 +1218,6 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 
     // The counts are already reduced (one row: a pipeline rank's mailbox): wave 1 of the adapting workgroup
     // adapts right away, while wave 0 fetches the draws, so the new ladder is in the ring long before anyone asks.
-    const bool ad_early = ad_here && A.ad.nblocks <= 8 * A.ad.row_groups;
     // the same workgroup pushes the last sweep's swap counts to every rank (uses the count-reduction machinery below,
     // which a pipeline rank's adaptation - counts already reduced - leaves idle)
     const bool cnt_push = PIPE && !EVAL && NW >= 2 && A.cnt_push == 1 && blockIdx.x == 0 && blockIdx.y == 0;
@@ -1229,13 +1231,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     double ad_bi0 = 1.0, ad_bi1 = 1.0;
     // (column-ordered records, measured at config 2 in workgroup cycles up to the second barrier: both parts in front of the
     //  first barrier 13 070, both in the gathers' shadow 11 520, the split as it is 9 900)
-    const bool ad_defer = ad_early && !PIPE && !ad_lead;
     constexpr bool ad_defer_all = false;
     // Round 3: the first part was the last to reach the first barrier (4 460 cycles after the workgroup's start; the complement
     // rows' wave 2 830, the rest < 2 000): its two independent chains run on two waves - ratios -> dS -> exp on wave ADX,
     // reciprocals of the ladder on wave ADW - and meet through LDS after the barrier (ladders of up to 64 rungs).
     constexpr int ADX = 3;
-    const bool ad_x = ad_defer && NW >= 4 && A.ad.T <= 64 && A.ad.moving;
     double* s_exp = s_part;                  // [64] exp(dS) per rung (phase C overwrites it after the second barrier)
     if (ad_x && wv == ADX) {
         const int T = A.ad.T, NR = A.ad.nblocks;
@@ -1251,6 +1251,22 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const double r0 = (double)s0 / (double)A.ad.W;                             // :587
         const double r0n = __shfl_down(r0, 1);
         s_exp[lane] = (lane + 2 < T) ? exp(A.ad.kappa * (r0 - r0n)) : 1.0;        // :575
+        // This wave is the ONLY reader of the count rows (the reciprocal chain on wave ADW needs none of them: every workgroup
+        // reading the same 15 cache lines twice made those loads ~3 000 cycles long and wave ADW the last at the first
+        // barrier, 4 150 cycles after the start against the complement wave's 3 000), so workgroup (0,0)'s books are kept here.
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            if (g == 0 && p < T - 1) {
+                A.ad.swaps_last[p] = (double)s0;
+                A.ad.swaps_total[p] += (double)s0;
+            }
+            if (A.ad.zero_after) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r * G + g < NR && p < T - 1 && u[r]) A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] = 0u;
+            }
+            if (A.ad.zero_rows)
+                for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
+        }
     }
     auto adapt_early = [&]() {
         const int T = A.ad.T, NR = A.ad.nblocks;
@@ -1259,7 +1275,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         for (int r = 0; r < 8; ++r) { s0 += ad_u0[r]; s1 += ad_u1[r]; }
         const int G = A.ad.row_groups, P2 = 64 / G;
         for (int m = P2; m < 64; m <<= 1) s0 += __shfl_xor(s0, m);       // (the lane groups' partial sums)
-        if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && !ad_x) {
             if (A.ad.zero_after) {                   // sole reader (mode 2 / a pipeline rank): clear what was read
                 const int p = lane & (P2 - 1), g = lane / P2;
 #pragma unroll
@@ -1279,8 +1295,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const int G = A.ad.row_groups, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            ad_u0[r] = (r * G + g < NR && p < T - 1) ? A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] : 0u;
-            ad_u1[r] = (r < NR && lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
+            ad_u0[r] = (!ad_x && r * G + g < NR && p < T - 1) ? A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] : 0u;
+            ad_u1[r] = (!ad_x && r < NR && lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
         }
         if (lane < T) ad_bi0 = A.ad.betas_in[lane];
         if (lane + 64 < T) ad_bi1 = A.ad.betas_in[lane + 64];
