@@ -2194,7 +2194,12 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // (1.4 us per iteration) with nothing but the keys kernel on it.  HENS_PLAN_INLINE=0/1 forces either form (A/B knob).
     static const int inline_env = getenv("HENS_PLAN_INLINE") ? atoi(getenv("HENS_PLAN_INLINE")) : -1;
     const bool keys_only = (fused && !iter1) || pfused;   // draws in registers: iteration_keys plans the round keys, nothing else
-    const bool plan_inline = keys_only || (!piped && inline_env > 0);
+    // Every path plans on the main stream now (HENS_PLAN_INLINE=0 restores the side stream): beside being slower (two cross-stream
+    // event waits per batch: 15.8 -> 15.4 us per iteration at 8 x 4096 x 32, 28.3 -> 26.1 for the three copying launches at config
+    // 2), the side-stream plan made about one chain in five of 10^5 iterations at 32 x 1024 x 16 part ways with its repeats
+    // (tools/soak_flaky.py: 9 of 39 runs; 0 of 32 with the plan inline or serialised) - a plan that overlaps the previous batch's
+    // readers once in ~10^5 batch boundaries, whatever lets it through.
+    const bool plan_inline = keys_only || inline_env != 0;
     if (plan_inline && c->spec_valid) {          // (a speculative plan of an earlier call may still be writing a buffer)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0));
         c->spec_valid = false;
