@@ -32,9 +32,6 @@ constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-2
 constexpr unsigned FLAG_PIPE_TIMEOUT = 4u; // ladder pipeline: a neighbour's flag did not arrive in time
 
 // A/B knobs of dev builds (tools/devbuild.sh -D...)
-#ifndef HENS_GSTORE
-#define HENS_GSTORE 0
-#endif
 #ifndef HENS_NOACC
 #define HENS_NOACC 0
 #endif
@@ -2739,33 +2736,12 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const size_t di = (size_t)t * W + scol[e];
         if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
             A.ghome[(size_t)(A.par * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
-#if HENS_GSTORE == 1
-        {   // record + compact row index written through (sc1): nothing of this launch's output waits dirty in L2 for the
-            // write-back at the kernel boundary
-            typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
-            const WalkerRec w = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);
-            const uv4* src = reinterpret_cast<const uv4*>(&w);
-            WalkerRec* dst = A.wrecnew + di;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(dst), "v"(src[0]), "v"(src[1]) : "memory");
-            asm volatile("global_store_dword %0, %1, off sc1" ::"v"(A.locnew + di), "v"(locc[se]) : "memory");
-        }
-#elif HENS_GSTORE == 2
-        {
-            const WalkerRec w = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);
-            typedef uint32_t uv4 __attribute__((ext_vector_type(4)));
-            const uv4* src = reinterpret_cast<const uv4*>(&w);
-            __builtin_nontemporal_store(src[0], reinterpret_cast<uv4*>(A.wrecnew + di));
-            __builtin_nontemporal_store(src[1], reinterpret_cast<uv4*>(A.wrecnew + di) + 1);
-            __builtin_nontemporal_store(locc[se], A.locnew + di);
-        }
-#else
 #ifdef HENS_X_NOK2ACC
         A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], 0u);
 #else
         A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);  // (the slot's own counter: it does not move with a walker)
 #endif
         A.locnew[di] = locc[se];
-#endif
     }
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
         unsigned n = 0;
