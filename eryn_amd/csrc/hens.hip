@@ -2236,19 +2236,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             launch_plan(c, c->stream, 0, c->iter, nb, fused, iter1);
             c->timing.n_plan += 1;
         }
-#ifdef HENS_DEV_BUILD
-        static const bool plan_once = getenv("HENS_DEBUG_PLAN_ONCE") != nullptr;   // timing only: both buffers planned once, reused
-        static const int fake_slots = getenv("HENS_DEBUG_FAKE_PLAN") ? atoi(getenv("HENS_DEBUG_FAKE_PLAN")) : 0;
-        static const int fake_threads = getenv("HENS_DEBUG_FAKE_THREADS") ? atoi(getenv("HENS_DEBUG_FAKE_THREADS")) : 256;
-        if (plan_once && b >= 1 && fake_slots > 0 && b + 1 < nbatch) {            // a stand-in of known ALU work, small workgroups
-            const int64_t n = (int64_t)c->T * c->W * batch_size(b + 1);
-            hipLaunchKernelGGL(k_fake_plan, dim3((unsigned)((n + fake_threads - 1) / fake_threads)), dim3(fake_threads), 0, c->plan_stream,
-                               reinterpret_cast<uint32_t*>(c->xtmp), fake_slots, n);
-        }
-        if (b + 1 < nbatch && !(plan_once && b >= 1) && !plan_inline) {
-#else
         if (b + 1 < nbatch && !plan_inline) {
-#endif
             const int nxt = which ^ 1;
             HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
             HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));

@@ -32,9 +32,6 @@ constexpr unsigned FLAG_NAN_LOGL = 2u;      // NaN likelihood (red_blue.py:279-2
 constexpr unsigned FLAG_PIPE_TIMEOUT = 4u; // ladder pipeline: a neighbour's flag did not arrive in time
 
 // A/B knobs of dev builds (tools/devbuild.sh -D...)
-#ifndef HENS_NOACC
-#define HENS_NOACC 0
-#endif
 enum { LIKE_DENSE = 0, LIKE_DIAG = 1, LIKE_ROSEN = 2, LIKE_HOST = 3 };
 // what a stretch-kernel launch does: a red/blue stretch half-step, the evaluation of the resident state, or a
 // full-ensemble Metropolis-Hastings proposal q = x + step (mh.py:56-193; the step rows are read where the
@@ -795,7 +792,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
             if (keep) {                                        // move.py:513-532
                 A.L[gi] = logl;
                 A.P[gi] = (fabs(logp) == INFINITY) ? 0.0 : logp;
-                if (!HENS_NOACC) atomicAdd(&A.accepted[gi], 1u);
+                atomicAdd(&A.accepted[gi], 1u);
                 atomicOr(&s_flag[lane], 2);
             }
             A.loc[gi] = s_dst[lane];
@@ -1366,12 +1363,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 const double2 lp = *reinterpret_cast<const double2*>(&o->L);
                 // ({row, accept counter} as ONE 8-byte load: a third scattered load instruction on this wave cost the
                 //  iteration 0.7 us - the phase is bound by the number of memory instructions, not by bytes)
-#ifdef HENS_X_NOLOAD
-                rs = o->loc;
-#else
                 const int2 la = *reinterpret_cast<const int2*>(&o->loc);
                 rs = la.x; acc_old = (uint32_t)la.y;
-#endif
                 if (PIPE && A.ghome) ghome_row = A.ghome[rs < 0 ? ~rs : 0];   // (consumed in phase D: no wait in front of the barrier)
                 const DrawRec dv = draw_values(own, 0, sd.uz, sd.ua, A.ia, A.ndim_active);
                 zz = dv.zz; factors = dv.fac; lu = dv.lu;
@@ -1658,9 +1651,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (keep) {                                        // move.py:513-532
                 if (A.wrec) {
                     *reinterpret_cast<double2*>(&A.wrec[gi].L) = double2{logl, newP};
-#ifndef HENS_X_NOSTORE
                     if (!MH) A.wrec[gi].acc = acc_old + 1u;
-#endif
                 } else {
                     A.L[gi] = logl;
                     A.P[gi] = newP;
@@ -2013,19 +2004,6 @@ __global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
         A.dbg_uacc[base + q] = pd.ua;
     }
 }
-
-#ifdef HENS_DEV_BUILD
-// timing experiment: a side-stream kernel of known ALU work per walker (full-rate integer ops), small short workgroups
-__global__ void k_fake_plan(uint32_t* out, int slots, int64_t n) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t x = (uint32_t)g * 2654435761u + 1u, y = (uint32_t)(g >> 3) ^ 0x9E3779B9u;
-    for (int i = 0; i < slots; i += 4) {
-        x = (x ^ (y >> 7)) + 0x85EBCA6Bu;
-        y = (y + (x << 3)) ^ 0xC2B2AE35u;
-    }
-    if (g < n && (x ^ y) == 0x12345u) out[g & 1023] = x;
-}
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // PT cascade in column form.
@@ -2595,9 +2573,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             locc[e] = wr_n.loc;                                         // rows are updated in place (see StretchArgs::wrec)
         }
         if (keep) {
-#ifndef HENS_X_NOK2ACC
             wr_n.acc += 1u;                                             // (phase G writes the slot's record back)
-#endif
             s_flag[m] |= 2;
         }
     }
@@ -2736,11 +2712,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const size_t di = (size_t)t * W + scol[e];
         if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
             A.ghome[(size_t)(A.par * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
-#ifdef HENS_X_NOK2ACC
-        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], 0u);
-#else
         A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);  // (the slot's own counter: it does not move with a walker)
-#endif
         A.locnew[di] = locc[se];
     }
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
@@ -2748,9 +2720,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
         // (a pipeline rank too - round 3: one ticket per workgroup on ONE address, for a collector at the end of the launch, cost
         //  16 ns per workgroup, serialised: 17 us at 1024 workgroups; the next launch sums these rows and publishes the counts)
-#if !defined(HENS_X_NOSWAP)
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (TE - 1) + (i - 1)], n);
-#endif
     }
     // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
     if (!PIPE && walking) store_accepted();
