@@ -221,8 +221,9 @@ def timed_blocks(step, sync, steps, dist=None, device=None):
         try:
             if ok:
                 step(steps)
-                if dist is not None:
-                    sync()                   # (a pipeline rank's flag-wait errors surface in the engine's own synchronize)
+                # the engine's own stream first (a pipeline rank's flag-wait errors surface here; and hipStreamSynchronize on
+                # the one stream with work returns ~10 us sooner than the device-wide synchronisation that follows finds out)
+                sync()
         except RuntimeError as exc:
             print(f"[bench] stepping failed: {exc}", file=sys.stderr, flush=True)
             ok = 0
