@@ -1680,18 +1680,49 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 
     // ---- phase E: accepted rows only (the old rows went out right after phase B) ------------------------
     double* __restrict__ pool_w = A.pool;
+    if constexpr (PIPE) {
+        // A pipeline rank: a guest goes home accepted or not, and rows a peer may pull are written at system scope (a property of
+        // the launch).  Values and addresses of ALL passes first, then the stores back to back: the stores are inline asm, and the
+        // compiler drains the memory pipeline (s_waitcnt vmcnt(0)) before it redefines a register an asm statement has read - with
+        // one pass after the other every pass waited for the store of the pass before (1 200 cycles per workgroup at D = 64).
+        // The proposal is read from the tile unconditionally and selected against sreg[p] as a VALUE (a conditional read merged
+        // with sreg[p] becomes a select of addresses and puts the row registers into scratch memory).
+        const bool sysw = tl == A.sys_rung || A.sys_all;
+        double2 val[NPASS];
+        double* dstp[NPASS];
+        bool on[NPASS];
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        if (!rv[p]) continue;
-        const int fl = s_flag[r];
-        if ((fl & 2) == 0) {                              // rejected: the old row is already in place -
-            if (PIPE && (fl & 8)) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, sreg[p]);   // unless it sits in a guest row
-            continue;
+        for (int p = 0; p < NPASS; ++p) {
+            const int r = p * RPP + rsub;
+            on[p] = false;
+            val[p] = double2{0.0, 0.0};
+            dstp[p] = pool_w;
+            if (!rv[p]) continue;
+            const int fl = s_flag[r];
+            const double2 ql = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+            const double2 o = sreg[p];
+            const bool acc = (fl & 2) != 0;
+            val[p].x = acc ? ql.x : o.x;
+            val[p].y = acc ? ql.y : o.y;
+            on[p] = (fl & (2 | 8)) != 0;                       // accepted, or a guest's old row going home
+            dstp[p] = pool_w + (size_t)s_dst[r] * D + jl * 2;
         }
-        const double2 qv = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-        if (PIPE && (tl == A.sys_rung || A.sys_all)) store_row16_sys(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
-        else store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
+        if (sysw) {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) if (on[p]) store_row16_sys(dstp[p], val[p]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) if (on[p]) store_row16(dstp[p], val[p]);
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const int r = p * RPP + rsub;
+            if (!rv[p]) continue;
+            if ((s_flag[r] & 2) == 0) continue;               // rejected: the old row is already in place
+            const double2 qv = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+            store_row16(pool_w + (size_t)s_dst[r] * D + jl * 2, qv);
+        }
     }
     if (PIPE && A.pub_lp && A.pub_final && tl == A.Tl - 1)             // every walker of the rung has published: tell the neighbour
         if (pipe_last_ticket(A.pub_ticket, A.pub_target) && tid == 0) {
@@ -2619,27 +2650,44 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // (the accepted rows - phase E - go out in the walk's shadow from every wave but the walking one)
     const bool walking = wv == (NW > 1 ? 1 : 0);
     auto store_accepted = [&]() {
+        if constexpr (PIPE) {
+            // system scope where a peer may pull the row; guests go home accepted or not.  Values and addresses of all passes
+            // first, then the (inline asm) stores back to back: see phase E of k_stretch_fast.
+            double2 val[NPASS];
+            double* dstp[NPASS];
+            bool on[NPASS];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int r = p * RPP + rsub;
-            if (!rv[p]) continue;
-            if (PIPE) {                          // system scope: a peer may pull the row; guests go home accepted or not
+            for (int p = 0; p < NPASS; ++p) {
+                const int r = p * RPP + rsub;
+                on[p] = false;
+                val[p] = double2{0.0, 0.0};
+                dstp[p] = A.pool;
+                if (!rv[p]) continue;
                 const int fl = s_flag[r];
-                if ((fl & (2 | 8)) == 0) continue;
-                // (no ?: between an LDS read and sreg[p]: a select of ADDRESSES puts the register array into scratch memory, and
-                //  every row gather then waits for itself in front of its scratch store - phase B three times as long)
-                double2 v = sreg[p];
-                if (fl & 2) {
-                    if (CEN) v = qkeep[p];
-                    else v = *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-                }
-                if (A.sys_rows) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, v);
-                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, v);
-                continue;
+                const double2 ql = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
+                const double2 o = sreg[p];
+                const bool acc = (fl & 2) != 0;
+                val[p].x = acc ? ql.x : o.x;
+                val[p].y = acc ? ql.y : o.y;
+                on[p] = (fl & (2 | 8)) != 0;
+                dstp[p] = A.pool + (size_t)s_dst[r] * D + jl * 2;
             }
-            if ((s_flag[r] & 2) == 0) continue;
-            store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2,
-                        CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
+            if (A.sys_rows) {
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) if (on[p]) store_row16_sys(dstp[p], val[p]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) if (on[p]) store_row16(dstp[p], val[p]);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int r = p * RPP + rsub;
+                if (!rv[p]) continue;
+                if ((s_flag[r] & 2) == 0) continue;
+                store_row16(A.pool + (size_t)s_rs[r] * D + jl * 2,
+                            CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2));
+            }
         }
     };
     if (PIPE) {
