@@ -420,9 +420,12 @@ struct __attribute__((aligned(32))) WalkerRec {
     double L, P;
     int32_t loc;
     uint32_t acc;
-    int32_t pad1, pad2;
+    int32_t slot;      // column-ordered records: the slot (walker index within the rung) the record belongs to - like `acc` a property
+                       // of the place, written once by k_pack_cols and carried along: the slot's next column is ONE inverse
+                       // permutation away (k_split1_pt), not a permutation and an inverse
+    int32_t pad2;
 };
-__device__ __forceinline__ WalkerRec make_wrec(double L, double P, int32_t loc, uint32_t acc) { return WalkerRec{L, P, loc, acc, 0, 0}; }
+__device__ __forceinline__ WalkerRec make_wrec(double L, double P, int32_t loc, uint32_t acc, int32_t slot = 0) { return WalkerRec{L, P, loc, acc, slot, 0}; }
 
 __device__ __forceinline__ DrawRec draw_values(int own, int cw, double uz, double ua, double a, int D) {
     double zz = (a - 1.0) * uz + 1.0;              // stretch.py:129-132 (mul, add, square, divide)
@@ -1770,8 +1773,9 @@ __global__ void k_pack_cols(const double* __restrict__ L, const double* __restri
         uint32_t key[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) key[r] = keys[(size_t)t * 8 + r];
-        const size_t s = (size_t)t * W + prp((uint32_t)c, key, idx_bits, (uint32_t)W);
-        w[i] = make_wrec(L[s], P[s], loc[s], accepted[s]);
+        const uint32_t sl = prp((uint32_t)c, key, idx_bits, (uint32_t)W);
+        const size_t s = (size_t)t * W + sl;
+        w[i] = make_wrec(L[s], P[s], loc[s], accepted[s], (int32_t)sl);
         loc_cols[i] = loc[s];
     }
 }
@@ -2443,29 +2447,48 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         // row t of the table: pair TE-1-t of the walk = global pair R0 + TE-1-t, whose uniform is row TG-1-(R0+TE-1-t)
         if (t < TE - 1) lupt[e] = log(pt_uniform(A.seed, A.iter, PIPE ? TG - R0 - TE + t : t, W, c));   // tempering.py:535
     }
-    if (COL && WIDE && wv == 3 && lane < NM) {       // log of the movers' accept uniforms (the same Philox call as FLW's, its other half)
+    // Two Philox calls per mover instead of three (column order, 8 waves): complement row + zz + (D - 1) log zz on one wave, the
+    // accept uniform's logarithm on a second.  What stands in front of the first barrier is ALU issue - two 8-wave workgroups per CU
+    // all drawing at once - as much as the length of any one chain: a timing-only build without the draws runs this launch in 7.4
+    // instead of 9.0 us; with the slot index carried in the records (one Feistel walk per slot instead of two) the last wave
+    // reaches the barrier at 2 900 cycles instead of 3 400 and the launch takes 8.8 us.  (Slot order keeps the three-wave split:
+    // its chains wait for round keys.)
+    constexpr bool ONEDRAW = COL && WIDE;
+    if (COL && WIDE && !ONEDRAW && wv == 3 && lane < NM) {       // log of the movers' accept uniforms (the same Philox call as FLW's, its other half)
         const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));
         s_lu[m] = log(stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q).ua);   // red_blue.py:294
     }
     if (COL && (NW >= 8 ? (wv == 4 || wv == 7) : wv < 2)) {
-        // where slot e's record goes (phase G): the slot column c meets is prp_t(c) under this iteration's key, its column in
-        // the next iteration's order the inverse of that under the next key - two Feistel walks, ~1000 cycles of dependent ALU
-        // that nothing in front of the barrier needs: on the two waves with nothing else to do (measured: on the slot threads
-        // the barrier came 1000 cycles later, on the uniform-drawing waves 700)
+        // where slot e's record goes (phase G): the slot column c meets is prp_t(c) under this iteration's key - carried in the
+        // record since k_pack_cols computed it (WalkerRec::slot) - its column in the next iteration's order the inverse of that
+        // under the next key: one Feistel walk that nothing in front of the barrier needs, on two waves with nothing else to do
+        // (measured, when it was two walks: on the slot threads the barrier came 1000 cycles later, on the uniform-drawing waves
+        // 700)
         const int e = (NW >= 8 ? (wv == 4 ? 0 : 64) : wv * 64) + lane, t = e >> CS, c = c0 + (e & (CB - 1));
-        const uint4* kp = reinterpret_cast<const uint4*>(A.keys) + (size_t)(R0 + t) * 2;
-        const uint4 ka = kp[0], kb = kp[1];
-        const uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+        const uint32_t slot = (uint32_t)A.wrec[(size_t)t * W + c].slot;      // (= prp_t(c) under this iteration's key: carried in the record)
         const uint4* kn = reinterpret_cast<const uint4*>(A.keys_next) + (size_t)(R0 + t) * 2;
         const uint4 na = kn[0], nb = kn[1];
         const uint32_t keyn[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
-        const uint32_t slot = prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
         scol[e] = (int)prp_inv(slot, keyn, A.idx_bits, (uint32_t)W);
     }
-    if (WIDE && tid >= 2 * NE && tid < 2 * NE + 64) {
+    if (WIDE && wv == (ONEDRAW ? FLW : 4)) {         // (one draw wave: the wave that drew zz has nothing else to do)
         if (lane < TE) sbeta[lane] = A.betas[R0 + lane];
     }
-    if ((wv == CWW || wv == FLW) && lane < NM && !nomove) {
+    if (ONEDRAW && wv == CWW && lane < NM && !nomove) {
+        const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));
+        const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q);
+        const int cw = place_column(0, stretch_index(sd.r22, W >> 1), HS);
+        const int32_t rcv = A.loc[t * W + cw];                             // (in flight under the logarithms)
+        const double z = draw_zz(sd.uz, A.a);
+        s_zz[m] = z;
+        s_fac[m] = ((double)A.ndim_active - 1.0) * log(z);                // stretch.py:223
+        s_rc[m] = rcv;
+    }
+    if (ONEDRAW && wv == FLW && lane < NM && !nomove) {   // (the accept uniform's logarithm: the same call's other half, on a wave of its own)
+        const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));
+        s_lu[m] = log(stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q).ua);   // red_blue.py:294
+    }
+    if (!ONEDRAW && (wv == CWW || wv == FLW) && lane < NM && !nomove) {
         const int m = lane, t = m >> (CS - 1), q = (W >> 1) + blockIdx.x * HW + (m & (HW - 1));   // split position (second half)
         const StretchDraw sd = stretch_draw(A.seed, A.iter, (uint32_t)(R0 + t) * (uint32_t)W + (uint32_t)q);
         if (wv == CWW) {
@@ -2760,7 +2783,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const size_t di = (size_t)t * W + scol[e];
         if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
             A.ghome[(size_t)(A.par * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
-        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc);  // (the slot's own counter: it does not move with a walker)
+        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);  // (the slot's own counter and index: they do not move with a walker)
         A.locnew[di] = locc[se];
     }
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
@@ -2809,7 +2832,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
                     const double Pb = sys_load(me.lp_dn + (size_t)(A.par * 2 + 1) * W + slot_below);
                     const int32_t gl = pipe_guest_loc(A.par, 1, W, c);
                     const size_t di = (size_t)scol[tid];                             // (rung 0 of the rank)
-                    A.wrecnew[di] = make_wrec(Lb, Pb, gl, wr_n.acc);
+                    A.wrecnew[di] = make_wrec(Lb, Pb, gl, wr_n.acc, wr_n.slot);
                     A.locnew[di] = gl;
                     // its home: the row of the walker that goes down - or, if that one only just fell in from above (a guest
                     // itself), the row of the walker that went up across the top boundary
