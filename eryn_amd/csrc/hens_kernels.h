@@ -1008,6 +1008,43 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
     return part;
 }
 
+// Phase C of the two production kernels: every wave's partial sum into s_part[wave][walker].  Dense Gaussian at D = 32 (8 waves):
+// the phase is bound by LDS bandwidth, not by FP64 issue - every wave reads its walker's whole centred row (64 lanes x 256 B per
+// wave, 16 waves per CU: 2 048 clocks of the CU's 128 B / clock) to use it for 2 of the 16 row pairs.  Half the waves now read
+// the row and each computes TWO of the eight partial sums, the very sums (same pairs, same order) the eight waves computed:
+// same bits, half the LDS traffic.
+template <int DT, int LIKE, int NW, bool CEN>
+__device__ __forceinline__ void like_partials(const double* qtile, double* s_part, int lane, int wv, bool inbox, const double* mu_p,
+                                              const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b) {
+#ifndef HENS_NO_LIKE_PAIR
+    if constexpr (LIKE == LIKE_DENSE && DT == 32 && NW == 8 && CEN) {
+        if (wv >= NW / 2) return;
+        double pa = 0.0, pb = 0.0;
+        if (inbox) {
+            typedef const __attribute__((address_space(4))) double* cptr_t;
+            const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
+            const double* qrow = qtile + lane * (DT + 2);
+            double qreg[DT];
+#pragma unroll
+            for (int k = 0; k < DT; k += 2) {
+                const double2 v = *reinterpret_cast<const double2*>(qrow + k);
+                qreg[k] = v.x; qreg[k + 1] = v.y;
+            }
+            switch (wv) {
+#define HENS_SYM_PAIR(WI) case WI: pa = sym_quad<DT, NW, WI>(qreg, psym); pb = sym_quad<DT, NW, WI + NW / 2>(qreg, psym); break;
+                HENS_SYM_PAIR(0) HENS_SYM_PAIR(1) HENS_SYM_PAIR(2) HENS_SYM_PAIR(3)
+#undef HENS_SYM_PAIR
+                default: break;
+            }
+        }
+        s_part[wv * TILE + lane] = pa;
+        s_part[(wv + NW / 2) * TILE + lane] = pb;
+        return;
+    }
+#endif
+    s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW, CEN>(qtile, lane, wv, inbox, mu_p, prec_p, prec_sym_p, rosen_a, rosen_b);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fast path for power-of-two row widths (D = 8, 16, 32, 64): same five phases, but
 //   * every row chunk a thread will touch is loaded up front (NPASS x 2 x 16 B per thread in
@@ -1598,8 +1635,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        const double part = like_partial<DT, LIKE, NW, CEN>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
-        s_part[wv * TILE + lane] = part;
+        like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }
     HENS_TRACE(5);
     lds_barrier();
@@ -2583,7 +2619,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // ---- phase C: likelihood ------------------------------------------------------------------------------
     if (!nomove) {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        s_part[wv * TILE + lane] = like_partial<DT, LIKE, NW, CEN>(qtile, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }
     FUSED_TRACE(4);
     lds_barrier();
