@@ -35,7 +35,7 @@ constexpr int KEY_WINDOW = 1024;     // iterations of round keys planned at once
 struct hens_ctx_impl {
     hens_config cfg{};
     int T = 0, W = 0, D = 0, Tl = 0, N0 = 0;
-    hipStream_t stream = nullptr, plan_stream = nullptr;
+    hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
 
@@ -79,20 +79,14 @@ struct hens_ctx_impl {
     double logp_in = 0.0, rosen_a = 1.0, rosen_b = 100.0;
     bool have_prior = false, have_like = false, have_state = false, have_logs = false;
 
-    // draws: two batch buffers (plan of batch b+1 overlaps the stepping of batch b)
-    DrawBuf db[2];
+    // draws: ONE batch buffer, planned on the main stream in front of the batch that reads it
+    DrawBuf db[1];
     int NB = 0, NP2 = 1, idx_bits = 0;
-    hipEvent_t ev_plan[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
-    // speculative plan of the NEXT hens_step call (short calls pay ~25 us of plan latency up front otherwise): iterations
-    // [spec_iter0, spec_iter0 + spec_nb) planned into db[spec_buf] on plan_stream while the current call steps
-    bool spec_valid = false, spec_fused = false, spec_iter1 = false;
     // the two-launch iteration computes its draws in registers and needs the rungs' round keys only: a window of
     // KEY_WINDOW iterations, planned on the main stream when the chain leaves it (it survives hens_step calls)
     uint32_t* ikeys = nullptr;             // [KEY_WINDOW][T][8]
     uint64_t ikeys_iter0 = 0;
     int64_t ikeys_n = 0;
-    int spec_buf = 0, spec_nb = 0;
-    uint64_t spec_iter0 = 0;
     uint64_t win_from = 0; int win_count = 0;   // iterations planned in db[0] for hens_stretch_iter / sharded PT
 
     // parity staging
@@ -189,6 +183,7 @@ struct hens_ctx_impl {
     bool step_events = false;        // the last hens_step call recorded ev0 / ev1 (hens_timing::total_ms)
     hipEvent_t ext_start = nullptr, ext_stop = nullptr;   // armed: the next stretch launch records its own begin/end
     std::vector<hipEvent_t> evpool;
+    std::vector<double> launch_us;   // per-kernel profiling: begin / end of every launch of the last hens_step call (us after the first begin)
     std::vector<void*> allocs;
 };
 
@@ -274,13 +269,14 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     }
 #define LAUNCH_FAST_P(DT, NW, PIPE, PER)                                                           \
     do {                                                                                           \
-        const size_t lds = fast_lds_bytes(DT, NW) + (a.tab_lds ? (size_t)c->W * 4 : 0);            \
+        const size_t lds = fast_lds_bytes(DT, NW);                                                 \
         if (lds > 60000) {                                                                         \
             static uint64_t attr_done = 0;              /* (the attribute is per device) */        \
             const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
             if (!(attr_done & dev_bit)) {                                                          \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(fast_lds_bytes(DT, NW) + 32768)); \
+                const hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_stretch_fast, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
                 attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
@@ -325,9 +321,8 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         int RS;
         const size_t lds = generic_lds_bytes(c->D, &RS);
         if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
-        if (lds > 60000)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE, MODE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 60000) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE, MODE>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         a.RS = RS;
         a.ad_on = 0;
         if (c->ext_start)
@@ -347,9 +342,8 @@ int launch_hostlike_eval(hens_ctx_impl* c, StretchArgs a, int ntiles) {
     int RS;
     const size_t lds = generic_lds_bytes(c->D, &RS);
     if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
-    if (lds > 60000)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE_HOST, MODE_EVAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 60000) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE_HOST, MODE_EVAL>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     a.RS = RS;
     a.ad_on = 0;
     hipLaunchKernelGGL((k_stretch<LIKE_HOST, MODE_EVAL>), dim3(ntiles, c->Tl), dim3(256), lds, c->stream, a);
@@ -720,15 +714,7 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
     }
 }
 
-// plan nb iterations starting at iteration `iter0` into draw buffer `which`
-// another user of the plan buffers (parity API, sharded stepping) is about to write them on the main stream: order it
-// behind a speculative plan that may still be in flight, and forget that plan
-void spec_cancel(hens_ctx_impl* c) {
-    if (!c->spec_valid) return;
-    (void)hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0);
-    c->spec_valid = false;
-}
-
+// plan nb iterations starting at iteration `iter0` into draw buffer `which` (on stream s: always the context's main stream)
 // block-balanced labels: keys -> places -> draws (small short workgroups, see k_plan_cols); other shapes: k_plan
 void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, int nb, bool keys_only = false) {
     if (!pa.cb) {
@@ -924,8 +910,9 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
             static uint64_t attr_done = 0;                                                         \
             const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
             if (!(attr_done & dev_bit)) {                                                          \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), \
+                const hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+                if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_split1_pt, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
                 attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
@@ -988,6 +975,7 @@ void state_to_records(hens_ctx_impl* c) {
     hipLaunchKernelGGL(k_pack_state, dim3(grid_for(n)), dim3(256), 0, c->stream, c->L[c->cur], c->P[c->cur], c->loc[c->cur],
                        c->accepted, c->wrec[c->cur], n);
     c->packed = true;
+    c->colmode = false;           // (slot order: a stale flag would send the COL kernels over slot-ordered records)
 }
 void state_to_fields(hens_ctx_impl* c) {
     if (!c->packed) return;
@@ -1040,14 +1028,10 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         a.idx_bits = c->idx_bits; a.hb_shift = c->label_cb_shift - 1; a.ndim_active = dim_active(c);
         a.split = 0;
         a.home_off = c->parity * T * W;
-        if (c->colmode) {                                              // column-ordered records; the rung's row table in LDS
-            // (the rung's row table staged in LDS by LDS-DMA: built, verified, measured at config 2 on one box - 19.1 us per
-            //  iteration with it, 18.8 without, 19.9 with slot-ordered records: 8 MB of table fills per launch and a wait for
-            //  every load of the wave in front of the first barrier cost more than the L2 hits they replace.  HENS_TAB=1)
-            static const bool tab = getenv("HENS_TAB") != nullptr;               // A/B knob
-            a.col = 1;
-            a.tab_lds = (tab && (size_t)W * 4 <= 32768 && (W & 255) == 0) ? 1 : 0;
-        }
+        // (column-ordered records.  Round 3 also built the rung's row table staged in LDS by LDS-DMA: verified, measured at config 2
+        //  on one box at 19.1 us per iteration against 18.8 without - 8 MB of table fills per launch and a wait for every load of
+        //  the wave in front of the first barrier cost more than the L2 hits they replace - and removed in round 4.)
+        if (c->colmode) a.col = 1;
         attach_iteration_head(c, a);
         if (evs) {
             c->ext_start = new_event(c);
@@ -1261,8 +1245,9 @@ int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEven
         static uint64_t attr_done = 0;                  /* (the attribute is per device) */        \
         const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                                  \
         if (!(attr_done & dev_bit)) {                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW, PER>),         \
+            const hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW, PER>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_iter, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
             attr_done |= dev_bit;                                                                  \
         }                                                                                          \
         if (e0)                                                                                    \
@@ -1555,11 +1540,10 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
 #define TRY(x) do { int r_ = (x); if (r_) { g_last_error = c->err; hens_destroy(h); return r_; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fail(c, HENS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); g_last_error = c->err; hens_destroy(h); return HENS_ERR_HIP; } } while (0)
     TRYHIP(hipSetDevice(cfg->device_id));
-    {   // the stepping stream outranks the plan stream: plans run ahead in the gaps
+    {   // ONE stream per context (round 4: the side stream of the draw plan is gone)
         int prio_lo = 0, prio_hi = 0;
         TRYHIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         TRYHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi));
-        TRYHIP(hipStreamCreateWithPriority(&c->plan_stream, hipStreamNonBlocking, prio_lo));
     }
     c->own_stream = true;
     const size_t TW = (size_t)c->Tl * c->W;
@@ -1625,7 +1609,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         nb &= ~(size_t)1;
         c->NB = (int)nb;
     }
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 1; ++b) {
         const size_t n = (size_t)c->NB * TW;
         TRY(dalloc(c, &c->db[b].d.own, n));
         TRY(dalloc(c, &c->db[b].d.cw, n));
@@ -1639,8 +1623,6 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
             TRY(dalloc(c, &c->db[b].rec3, nrec));
         }
         TRY(dalloc(c, &c->db[b].keys, (size_t)c->NB * c->T * 8));
-        TRYHIP(hipEventCreateWithFlags(&c->ev_plan[b], hipEventDisableTiming));
-        TRYHIP(hipEventCreateWithFlags(&c->ev_used[b], hipEventDisableTiming));
     }
     TRYHIP(hipMemsetAsync(c->accepted, 0, TW * 4, c->stream));
     TRYHIP(hipMemsetAsync(c->flags, 0, 4, c->stream));
@@ -1675,7 +1657,6 @@ void hens_destroy(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
-    if (c->plan_stream) (void)hipStreamSynchronize(c->plan_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t q = 0; q < c->pipe.boxes.size(); ++q)
         if (c->pipe.opened[q] && c->pipe.boxes[q]) (void)hipIpcCloseMemHandle(c->pipe.boxes[q]);
@@ -1684,13 +1665,8 @@ void hens_destroy(hens_ctx* ctx) {
     for (void* p : c->allocs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->evpool) (void)hipEventDestroy(e);
-    for (int b = 0; b < 2; ++b) {
-        if (c->ev_plan[b]) (void)hipEventDestroy(c->ev_plan[b]);
-        if (c->ev_used[b]) (void)hipEventDestroy(c->ev_used[b]);
-    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->plan_stream) (void)hipStreamDestroy(c->plan_stream);
     if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1829,6 +1805,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     const size_t TW = (size_t)c->Tl * c->W;
     c->cur = 0;
     c->packed = false;
+    c->colmode = false;
     c->rows_mixed = false;    // (a failed hens_step call may have left these behind: step_failed)
     c->parity = 1;            // rows live in home 0, the next iteration writes home 1
     c->expect_split = 0;
@@ -1904,7 +1881,6 @@ static int prepare_split(hens_ctx_impl* c, int32_t split, const uint8_t* labels,
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     if (c->propose_pending) return fail(c, HENS_ERR_STATE, "hens_propose_split without its hens_accept_split");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    spec_cancel(c);               // (the draws of this half-step go into plan buffer 0)
     flush_adapt(c);
     const int Tl = c->Tl, W = c->W;
     if (split == 0) {
@@ -2129,6 +2105,7 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
 static int step_failed(hens_ctx_impl* c, int r) {
     (void)hipStreamSynchronize(c->stream);
     c->packed = false;
+    c->colmode = false;
     c->rows_mixed = false;
     c->adapt_pending = false;
     c->adapt_src = nullptr;
@@ -2182,71 +2159,21 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     static const bool ev_env = getenv("HENS_STEP_EVENTS") != nullptr;
     c->step_events = prof || ev_env;
     if (c->step_events) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    // the plan of batch b+1 runs on plan_stream while batch b steps on the main stream
+    // Draws are planned ON THE MAIN STREAM, right in front of the batch that consumes them (one buffer, ordered by the stream).  The
+    // two-launch iteration computes its draws in registers and needs the round keys only (iteration_keys).  Rounds 1-3 planned batch
+    // b + 1 on a low-priority side stream while batch b stepped; that form cost two cross-stream event waits per batch (15.8 -> 15.4
+    // us per iteration at 8 x 4096 x 32 without it) and, in a soak of 10^5 iterations at 32 x 1024 x 16, one chain in five parted
+    // ways with its own repeats (a plan overlapping the previous batch's readers; never with the plan on the main stream: 0 of 76
+    // runs).  Round 4 removed it: no code path can reach that configuration any more (tests/test_hip_repeat.py is the soak).
     const int64_t nbatch = (n_iters + c->NB - 1) / c->NB;
     auto batch_size = [&](int64_t b) { return (int)std::min<int64_t>(c->NB, n_iters - b * c->NB); };
-    // A call of at most one batch may find its plan ready: the previous call planned it speculatively (a pure function of
-    // seed, iteration and path) while it stepped.  And it plans the iterations that follow its own for the next call.
-    static const bool spec_on = getenv("HENS_NO_SPEC") == nullptr;
-    // Round 3: the plan of a batch ON THE MAIN STREAM, right in front of the batch - always for the two-launch iteration, which
-    // computes its draws in registers and needs the round keys only (a few hundred threads per batch).  A plan on the side
-    // stream costs two cross-stream event waits per batch whatever its size: 31 us per batch of 22 iterations at config 2
-    // (1.4 us per iteration) with nothing but the keys kernel on it.  HENS_PLAN_INLINE=0/1 forces either form (A/B knob).
-    static const int inline_env = getenv("HENS_PLAN_INLINE") ? atoi(getenv("HENS_PLAN_INLINE")) : -1;
     const bool keys_only = (fused && !iter1) || pfused;   // draws in registers: iteration_keys plans the round keys, nothing else
-    // Every path plans on the main stream now (HENS_PLAN_INLINE=0 restores the side stream): beside being slower (two cross-stream
-    // event waits per batch: 15.8 -> 15.4 us per iteration at 8 x 4096 x 32, 28.3 -> 26.1 for the three copying launches at config
-    // 2), the side-stream plan made about one chain in five of 10^5 iterations at 32 x 1024 x 16 part ways with its repeats
-    // (tools/soak_flaky.py: 9 of 39 runs; 0 of 32 with the plan inline or serialised) - a plan that overlaps the previous batch's
-    // readers once in ~10^5 batch boundaries, whatever lets it through.
-    const bool plan_inline = keys_only || inline_env != 0;
-    if (plan_inline && c->spec_valid) {          // (a speculative plan of an earlier call may still be writing a buffer)
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[c->spec_buf], 0));
-        c->spec_valid = false;
-    }
-    int first_buf = 0;
-    bool spec_hit = false;
-    if (plan_inline) spec_hit = true;            // (no plan ahead of the loop, no speculation)
-    else if (nbatch == 1 && c->spec_valid && c->spec_iter0 == c->iter && c->spec_nb >= n_iters && c->spec_fused == fused &&
-        c->spec_iter1 == iter1) {
-        first_buf = c->spec_buf;
-        spec_hit = true;
-    }
-    c->spec_valid = false;      // (a speculative plan that does not fit stays ordered in front of the new one on plan_stream)
-    if (nbatch > 0 && !spec_hit) {
-        HIPCHK(c, hipEventRecord(c->ev_used[first_buf], c->stream));      // earlier work may still read the buffer
-        HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[first_buf], 0));
-        launch_plan(c, c->plan_stream, first_buf, c->iter, batch_size(0), fused, iter1);
-        HIPCHK(c, hipEventRecord(c->ev_plan[first_buf], c->plan_stream));
-        c->timing.n_plan += 1;
-    }
-    if (spec_on && nbatch == 1 && !piped && !plan_inline) {
-        const int sb = first_buf ^ 1;
-        HIPCHK(c, hipEventRecord(c->ev_used[sb], c->stream));             // its last readers: the previous call's launches
-        HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[sb], 0));
-        launch_plan(c, c->plan_stream, sb, c->iter + (uint64_t)n_iters, (int)n_iters, fused, iter1);
-        HIPCHK(c, hipEventRecord(c->ev_plan[sb], c->plan_stream));
-        c->timing.n_plan += 1;
-        c->spec_valid = true; c->spec_buf = sb; c->spec_iter0 = c->iter + (uint64_t)n_iters; c->spec_nb = (int)n_iters;
-        c->spec_fused = fused; c->spec_iter1 = iter1;
-    }
     for (int64_t b = 0; b < nbatch; ++b) {
-        const int which = plan_inline ? 0 : (int)((first_buf + b) & 1), nb = batch_size(b);
-        if (plan_inline && !keys_only) {
+        const int which = 0, nb = batch_size(b);
+        if (!keys_only) {
             launch_plan(c, c->stream, 0, c->iter, nb, fused, iter1);
             c->timing.n_plan += 1;
         }
-        if (b + 1 < nbatch && !plan_inline) {
-            const int nxt = which ^ 1;
-            HIPCHK(c, hipEventRecord(c->ev_used[nxt], c->stream));   // batch b-1 (queued above) was `nxt`'s last reader
-            HIPCHK(c, hipStreamWaitEvent(c->plan_stream, c->ev_used[nxt], 0));
-            launch_plan(c, c->plan_stream, nxt, c->iter + (uint64_t)nb, batch_size(b + 1), fused, iter1);
-            HIPCHK(c, hipEventRecord(c->ev_plan[nxt], c->plan_stream));
-            c->timing.n_plan += 1;
-            static const bool plan_serial = getenv("HENS_PLAN_SERIAL") != nullptr;     // A/B knob: the plan runs alone
-            if (plan_serial) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[nxt], 0));
-        }
-        if (!plan_inline) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan[which], 0));
         for (int ib = 0; ib < nb; ++ib) {
             if (piped) pipe_prewait(c);
             const bool mh = iteration_is_mh(c);
@@ -2317,7 +2244,13 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (prof) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0;
+        c->launch_us.clear();
         for (size_t k = 0; k < ev_kind.size() && 2 * k + 1 < evs.size(); ++k) {
+            float b = 0, e = 0;
+            (void)hipEventElapsedTime(&b, evs[0], evs[2 * k]);
+            (void)hipEventElapsedTime(&e, evs[0], evs[2 * k + 1]);
+            c->launch_us.push_back(b * 1e3);
+            c->launch_us.push_back(e * 1e3);
             (void)hipEventElapsedTime(&ms, evs[2 * k], evs[2 * k + 1]);
             if (ev_kind[k] == 0) { c->timing.stretch_ms += ms; c->timing.n_stretch += 1; }
             else if (ev_kind[k] == 1) { c->timing.pt_ms += ms; c->timing.n_pt += 1; }
@@ -2422,7 +2355,6 @@ int hens_set_iteration(hens_ctx* ctx, int64_t iter) {
     if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (column-ordered records are in the OLD counter's order)
-    spec_cancel(c);                           // (a speculative plan of the old counter's successors)
     c->win_count = 0;
     c->iter = (uint64_t)iter;                 // (the round-key window re-plans itself when the chain has left it)
     return HENS_OK;
@@ -2444,6 +2376,16 @@ int hens_get_timing(hens_ctx* ctx, hens_timing* out) {
     if (c->timing.n_iters > 0 && c->step_events) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->timing.total_ms = ms;
     *out = c->timing;
+    return HENS_OK;
+}
+
+// begin / end of every launch of the last hens_step call made with per-kernel events (us after the first launch's begin)
+int hens_debug_launch_times(hens_ctx* ctx, double* out_us, int64_t capacity, int64_t* n_out) {
+    hens_ctx_impl* c = CTX(ctx);
+    if (!c || !n_out) return fail(c, HENS_ERR_INVALID, "null argument");
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)c->launch_us.size());
+    for (int64_t i = 0; i < n && out_us; ++i) out_us[i] = c->launch_us[(size_t)i];
+    *n_out = (int64_t)c->launch_us.size();
     return HENS_OK;
 }
 
@@ -2856,7 +2798,6 @@ int hens_stretch_iter(hens_ctx* ctx) {
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
-    spec_cancel(c);
     flush_adapt(c);
     c->N0 = (c->W + 1) / 2;
     if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
@@ -3215,7 +3156,6 @@ int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
     switch (stage) {
         case 0: {           // the iteration's move (stretch halves or the MH proposal); publishes (L, P) of the boundary rung
-            spec_cancel(c);
             c->N0 = (c->W + 1) / 2;
             if (!(c->iter >= c->win_from && c->iter < c->win_from + (uint64_t)c->win_count)) {
                 launch_plan(c, c->stream, 0, c->iter, c->NB);

@@ -561,10 +561,10 @@ struct StretchArgs {
     // Column-ordered records (round 3, hens_step's two launches on one GPU): wrec / loc hold every rung in the order of THIS
     // iteration's cascade columns - record c of rung t belongs to the walker column c meets - so the walker at place p of a
     // half is record place_column(half, p): a coalesced load that waits for no round key and no permutation, and a complement
-    // is a lookup by column in the rung's compact row table, which the workgroup stages in LDS (4 W bytes; tab_lds).
+    // is a lookup by column in the rung's compact row table (`loc`, 4 W bytes per rung: L2-resident).
     // k_split1_pt<COL> writes the next buffers in the NEXT iteration's column order (scattered stores at its tail instead of
     // scattered loads at both launches' heads).
-    int32_t col, tab_lds;
+    int32_t col, col_pad_;
     // parity API with nsplits > 2 (red_blue.py:41-47,148): the moving set's position range, given explicitly (0: the two-half
     // rule from N0 / split); `split` is then 0 for the first set, 1 for the last (every complement already sits in its home
     // row) and 2 for the ones between
@@ -1089,7 +1089,6 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     int32_t* s_dst = s_rc + TILE;
     int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [128] swap counts (ad_on)
-    int32_t* s_tab = reinterpret_cast<int32_t*>(s_cnt + 128);            // [W] the rung's row table in column order (tab_lds)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1127,17 +1126,6 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
                       A.wstats ? A.wstats + (lane >= PF_CNT0 ? 2 : 0) : nullptr);
         __syncthreads();
-    }
-
-    // column-ordered records: the rung's row table (4 W bytes) -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
-    // instruction, no registers), requested HERE, in front of everything else; the wave waits for it in front of the first
-    // barrier (tab_lds implies W a multiple of 256, 4 W <= 32 KiB).
-    const bool tab = MODE == MODE_STRETCH && !PIPE && A.col && A.tab_lds;
-    if (tab) {
-        const char* src = reinterpret_cast<const char*>(A.loc + (size_t)tl * W) + lane * 16;
-        for (int ch = wv; ch < (W >> 8); ch += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ch * 1024),
-                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(s_tab) + ch * 1024), 16, 0, 0);
     }
 
     // ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64
@@ -1387,7 +1375,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 zz = draw_zz(sd.uz, A.ia);
                 lu = log(sd.ua);                                 // red_blue.py:294 (this wave is not the last at the barrier)
                 late_ua = 1.0;                                   // ((D - 1) log zz: after the row gathers have been issued)
-                rs = A.tab_lds ? own : la.x;                     // (tab_lds: the column; phase B looks the row up)
+                rs = la.x;
                 acc_old = (uint32_t)la.y;                        // (consumed in phase D: the record load gates no barrier then)
                 if (PIPE && A.ghome) ghome_row = A.ghome[la.x < 0 ? ~la.x : 0];
                 Lold = lp.x; Pold = lp.y;
@@ -1442,7 +1430,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (k < Ns) {
             const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(s_off + k));
             const int colc = place_column(1 - A.split, stretch_index(sd.r22, W >> 1), A.hb_shift);
-            rc = A.tab_lds ? colc : A.loc[tl * W + colc];
+            rc = A.loc[tl * W + colc];
         }
         s_rc[lane] = rc;
     } else if (MODE == MODE_STRETCH && A.ikeys && wv == 2) {
@@ -1462,7 +1450,6 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         s_cnt[lane] = 0;
         s_cnt[lane + 64] = 0;
     }
-    if (tab) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row table has landed in LDS (requested at the head)
 #ifdef HENS_TRACE_WAVES      // dev builds: slot w of the trace = arrival of wave w at the first barrier
     if (A.trace && lane == 0 && wv >= 1 && wv < 8) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv] = trace_stamp();
     if (A.trace && tid == 0) {           // (thread 0 leaves: no later stamp overwrites these; the launch's results are garbage)
@@ -1488,12 +1475,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
-        if (rv[p] && tab) {                  // column -> row (LDS); the walker's own row kept for phase E
-            const int rsr = s_tab[s_rs[r]], rcr = s_tab[s_rc[r]];
-            if (jl == 0) s_dst[r] = rsr;
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)rsr * D + jl * 2);
-            creg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)rcr * D + jl * 2);
-        } else if (rv[p]) {
+        if (rv[p]) {
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
             if (MH) {
                 if (A.mh_step) {

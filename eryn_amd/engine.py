@@ -270,6 +270,15 @@ class HipEnsemble:
         check(self.lib.hens_get_timing(self.ctx, C.byref(t)), self.ctx)
         return {k: getattr(t, k) for k, _ in HensTiming._fields_}
 
+    def launch_times(self):
+        """(n_launches, 2) begin / end in us after the first launch's begin, of the last step() made with set_profiling(True)."""
+        n = C.c_int64(0)
+        check(self.lib.hens_debug_launch_times(self.ctx, None, 0, C.byref(n)), self.ctx)
+        out = np.zeros(max(n.value, 0))
+        if n.value:
+            check(self.lib.hens_debug_launch_times(self.ctx, ptr(out), n.value, C.byref(n)), self.ctx)
+        return out.reshape(-1, 2)
+
     # -- ladder sharding (eryn_amd/ladder.py) ----------------------------------------------------------
     def stretch_iter(self):
         """One Philox iteration of both halves on the resident rungs (asynchronous, no PT)."""

@@ -208,6 +208,9 @@ typedef struct hens_timing {
 } hens_timing;
 int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events);
 int hens_get_timing(hens_ctx* ctx, hens_timing* out);
+/* Dev aid: begin / end (us after the first launch's begin, from the dispatch packets' own timestamps) of every launch of the
+ * last hens_step call that ran with per-kernel events; *n_out = values available (2 per launch). */
+int hens_debug_launch_times(hens_ctx* ctx, double* out_us, int64_t capacity, int64_t* n_out);
 
 /* Ladder sharding (one context per GPU, rungs [rung_begin, rung_end)).  The stretch
  * step needs no communication (complement walkers are drawn within a rung,
