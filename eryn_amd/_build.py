@@ -8,9 +8,10 @@ SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.environ.get("HENS_LIB") or os.path.join(LIB_DIR, "libhipensemble.so")
 SOURCES = [os.path.join(SRC_DIR, "hens.hip")]
-DEPS = SOURCES + [os.path.join(SRC_DIR, "hens_kernels.h"), os.path.join(SRC_DIR, "hens_rj.h"), os.path.join(SRC_DIR, "hens_iter.h"),
+DEPS = SOURCES + [os.path.join(SRC_DIR, "hens_kernels.h"), os.path.join(SRC_DIR, "hens_rj.h"), os.path.join(SRC_DIR, "hens_iter.h"), os.path.join(SRC_DIR, "hens_aql.h"),
                   os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+LINK = ["-L/opt/rocm/lib", "-lhsa-runtime64"]      # (direct AQL dispatch of the stepping launches: csrc/hens_aql.h)
 
 
 def hipcc_path():
@@ -32,7 +33,7 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + SOURCES + ["-o", LIB_PATH]
+    cmd = [hipcc_path()] + FLAGS + SOURCES + ["-o", LIB_PATH] + LINK
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

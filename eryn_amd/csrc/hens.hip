@@ -4,6 +4,7 @@
 #include "hens_kernels.h"
 #include "hens_rj.h"
 #include "hens_iter.h"
+#include "hens_aql.h"
 #include <hip/hip_ext.h>
 
 #include <algorithm>
@@ -183,6 +184,14 @@ struct hens_ctx_impl {
     bool step_events = false;        // the last hens_step call recorded ev0 / ev1 (hens_timing::total_ms)
     hipEvent_t ext_start = nullptr, ext_stop = nullptr;   // armed: the next stretch launch records its own begin/end
     std::vector<hipEvent_t> evpool;
+    // direct AQL dispatch of the stepping launches (hens_aql.h): a user-mode HSA queue of the context's own
+    hens_aql::Queue aql;
+    bool aql_on = false;             // the queue exists (hens_create); HENS_NO_AQL=1 keeps every launch on the HIP stream
+    bool aql_now = false;            // inside a hens_step call whose launches go to the AQL queue
+    bool aql_last = false;           // ... and the iteration being queued is the call's last (its last packet carries the signal)
+    bool hip_dirty = true;           // the HIP stream may hold work the AQL queue has not been ordered behind
+    bool aql_failed = false;         // a dispatch inside a void helper failed (checked by fused_iteration)
+    int aql_ring_every = 8;
     std::vector<double> launch_us;   // per-kernel profiling: begin / end of every launch of the last hens_step call (us after the first begin)
     std::vector<void*> allocs;
 };
@@ -212,6 +221,67 @@ template <typename Tp>
 int dalloc(hens_ctx_impl* c, Tp** p, size_t n) {
     HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(n, 1) * sizeof(Tp)));
     c->allocs.push_back(*p);
+    return HENS_OK;
+}
+
+// ---- the two queues of a context ------------------------------------------------------------------------------------------
+// Stepping launches of hens_step go to the context's AQL queue (hens_aql.h) where they can; everything else uses the HIP stream.
+// The host orders the two: aql_settle before any HIP work (every entry point: enter()), hipStreamSynchronize before the first
+// packet of a call if the stream may be busy (hens_step).
+int aql_settle(hens_ctx_impl* c) {
+    if (!c || !c->aql_on) return HENS_OK;
+    c->hip_dirty = true;                       // (the caller is about to use the HIP stream)
+    if (!c->aql.pending) return HENS_OK;
+    static const double tmo = getenv("HENS_PIPE_TIMEOUT_S") ? atof(getenv("HENS_PIPE_TIMEOUT_S")) + 10.0 : 30.0;
+    if (!c->aql.drain(tmo)) {
+        c->have_state = false;                 // nothing a later call could read consistently
+        return fail(c, HENS_ERR_HIP, "%s", c->aql.err.c_str());
+    }
+    return HENS_OK;
+}
+hens_ctx_impl* enter(hens_ctx* h) {            // head of every entry point that may touch the device through HIP
+    hens_ctx_impl* c = CTX(h);
+    (void)aql_settle(c);
+    return c;
+}
+
+// kernel arguments as the AMDGPU kernarg segment lays them out: by value, in order, each at its natural alignment
+template <class... Ts>
+size_t pack_kernargs(char* buf, const Ts&... a) {
+    size_t off = 0;
+    ((off = (off + alignof(Ts) - 1) & ~(alignof(Ts) - 1), memcpy(buf + off, &a, sizeof(Ts)), off += sizeof(Ts)), ...);
+    return off;
+}
+// one launch on the AQL queue; `cache` = the call site's per-device kernel handles
+template <class F, class... Ts>
+int aql_launch(hens_ctx_impl* c, const hens_aql::Kernel** cache, F fn, dim3 grid, unsigned block, size_t lds, bool signal, const Ts&... args) {
+    const hens_aql::Kernel*& k = cache[c->cfg.device_id & 63];
+    if (!k) {
+        k = hens_aql::kernel_for(*c->aql.dev, reinterpret_cast<const void*>(fn));
+        if (!k) return fail(c, HENS_ERR_HIP, "AQL dispatch: kernel not found in the library's code object");
+    }
+    alignas(16) char buf[hens_aql::SLOT_BYTES];
+    static_assert((sizeof(Ts) + ... + 0) + 8 * sizeof...(Ts) <= hens_aql::SLOT_BYTES - 256, "kernel arguments exceed the kernarg slot");
+    const size_t n = pack_kernargs(buf, args...);
+    if (!c->aql.dispatch(*k, grid.x, grid.y, grid.z, block, (uint32_t)lds, buf, n, signal)) return fail(c, HENS_ERR_HIP, "AQL dispatch: %s", c->aql.err.c_str());
+    // doorbell: right behind a call's first packet (the GPU starts while the host writes the rest), then every few packets
+    if (c->aql.windex == c->aql.call_first + 1 || c->aql.windex - c->aql.rung >= (uint64_t)c->aql_ring_every) c->aql.ring();
+    return HENS_OK;
+}
+
+// a piece of HIP-stream work in the middle of a call that steps on the AQL queue (packing the state at the head of the first call
+// after another entry point, an adaptation that cannot be folded): the queue drains, the work runs, the stream drains
+template <class Fn>
+int hip_interlude(hens_ctx_impl* c, Fn&& work) {
+    if (!c->aql_now) { work(); return HENS_OK; }
+    int r = aql_settle(c);
+    if (r) return r;
+    c->aql_now = false;
+    work();
+    c->aql_now = true;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hip_dirty = false;
+    c->aql.own_only = false;
     return HENS_OK;
 }
 
@@ -280,7 +350,11 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
                 attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
-        if (c->ext_start)                                                                          \
+        if (c->aql_now) {                                                                          \
+            static const hens_aql::Kernel* ak_[64] = {};                                           \
+            const int ar_ = aql_launch(c, ak_, k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>, grid, NW * 64, lds, false, a); \
+            if (ar_) return ar_;                                                                   \
+        } else if (c->ext_start)                                                                   \
             hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
                                   c->ext_start, c->ext_stop, 0, a);                                \
         else                                                                                       \
@@ -717,6 +791,17 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
 // plan nb iterations starting at iteration `iter0` into draw buffer `which` (on stream s: always the context's main stream)
 // block-balanced labels: keys -> places -> draws (small short workgroups, see k_plan_cols); other shapes: k_plan
 void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, int nb, bool keys_only = false) {
+    if (c->aql_now) {                // (the queue of the launches that read the plan: ordered by the packets' barrier bits)
+        static const hens_aql::Kernel *ak0_[64] = {}, *ak1_[64] = {}, *ak2_[64] = {};
+        int r;
+        if (!pa.cb) r = aql_launch(c, ak0_, k_plan, dim3(nb * c->Tl), (unsigned)plan_threads(c), plan_lds_bytes(c), false, pa);
+        else {
+            r = aql_launch(c, ak1_, k_plan_keys, dim3((nb * c->Tl + 63) / 64), 64, 0, false, pa, nb);
+            if (!r && !keys_only) r = aql_launch(c, ak2_, k_plan_draws, dim3((c->W + 255) / 256, nb * c->Tl), 256, 0, false, pa);
+        }
+        if (r) c->aql_failed = true;
+        return;
+    }
     if (!pa.cb) {
         hipLaunchKernelGGL(k_plan, dim3(nb * c->Tl), dim3(plan_threads(c)), plan_lds_bytes(c), s, pa);
         return;
@@ -916,7 +1001,11 @@ int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEv
                 attr_done |= dev_bit;                                                              \
             }                                                                                      \
         }                                                                                          \
-        if (e0)                                                                                    \
+        if (c->aql_now) {      /* (the iteration's last launch: the call's last one carries the completion signal) */ \
+            static const hens_aql::Kernel* ak_[64] = {};                                           \
+            const int ar_ = aql_launch(c, ak_, k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>, grid, NW * 64, lds, c->aql_last, f); \
+            if (ar_) return ar_;                                                                   \
+        } else if (e0)                                                                             \
             hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
             hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), lds, c->stream, f); \
@@ -1007,7 +1096,12 @@ const uint32_t* iteration_keys(hens_ctx_impl* c) {
         const int below = c->cfg.rung_begin > 0 ? 1 : 0;
         pa.Tl = c->Tl + below; pa.W = c->W; pa.rung_begin = c->cfg.rung_begin - below; pa.T = c->T; pa.cb = c->label_cb;
         pa.keys = c->ikeys;
-        hipLaunchKernelGGL(k_plan_keys, dim3((KEY_WINDOW * pa.Tl + 255) / 256), dim3(256), 0, c->stream, pa, KEY_WINDOW);
+        if (c->aql_now) {       // (same queue as the launches that read the window: ordered by the packets' barrier bits)
+            static const hens_aql::Kernel* ak_[64] = {};
+            const int nbk = KEY_WINDOW;
+            if (aql_launch(c, ak_, k_plan_keys, dim3((KEY_WINDOW * pa.Tl + 255) / 256), 256, 0, false, pa, nbk)) c->aql_failed = true;
+        } else
+            hipLaunchKernelGGL(k_plan_keys, dim3((KEY_WINDOW * pa.Tl + 255) / 256), dim3(256), 0, c->stream, pa, KEY_WINDOW);
         c->ikeys_iter0 = c->iter;
         c->ikeys_n = KEY_WINDOW;
         c->timing.n_plan += 1;
@@ -1017,8 +1111,12 @@ const uint32_t* iteration_keys(hens_ctx_impl* c) {
 
 int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     const int T = c->T, W = c->W;
-    state_to_records(c);
+    if (!c->packed) {                        // (the pack kernel - first call after another entry point - runs on the HIP stream)
+        const int r = hip_interlude(c, [&] { state_to_records(c); });
+        if (r) return r;
+    }
     const uint32_t* keys = iteration_keys(c);
+    if (c->aql_failed) { c->aql_failed = false; return HENS_ERR_HIP; }
     {
         StretchArgs a = base_args(c);
         a.wrec = c->wrec[c->cur];
@@ -1250,7 +1348,11 @@ int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEven
             if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_iter, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
             attr_done |= dev_bit;                                                                  \
         }                                                                                          \
-        if (e0)                                                                                    \
+        if (c->aql_now) {                                                                          \
+            static const hens_aql::Kernel* ak_[64] = {};                                           \
+            const int ar_ = aql_launch(c, ak_, k_iter<DT, LIKE, NW, PER>, grid, NW * 64, lds, c->aql_last, f); \
+            if (ar_) return ar_;                                                                   \
+        } else if (e0)                                                                             \
             hipExtLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
         else                                                                                       \
             hipLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), lds, c->stream, f);    \
@@ -1280,8 +1382,14 @@ int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEven
 
 int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
     const int T = c->T, W = c->W;
-    state_to_records(c);
-    if (c->adapt_pending && !(is_acc_buffer(c, c->adapt_src) && c->T <= 128)) flush_adapt(c);   // (counts of an MH iteration's cascade)
+    if (!c->packed) {
+        const int r = hip_interlude(c, [&] { state_to_records(c); });
+        if (r) return r;
+    }
+    if (c->adapt_pending && !(is_acc_buffer(c, c->adapt_src) && c->T <= 128)) {   // (counts of an MH iteration's cascade)
+        const int r = hip_interlude(c, [&] { flush_adapt(c); });
+        if (r) return r;
+    }
     IterArgs f{};
     f.pool = c->pool;
     f.wrec = c->wrec[c->cur]; f.wrecnew = c->wrec[c->cur ^ 1];
@@ -1546,6 +1654,22 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRYHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi));
     }
     c->own_stream = true;
+    {   // the context's AQL queue for the stepping launches (hens_aql.h); HENS_NO_AQL=1: everything on the HIP stream
+        static const bool aql_off = getenv("HENS_NO_AQL") != nullptr;
+        static const int ring_env = getenv("HENS_AQL_RING") ? atoi(getenv("HENS_AQL_RING")) : 0;
+        if (ring_env > 0) c->aql_ring_every = ring_env;
+        if (!aql_off) {
+            hens_aql::Device& ad = hens_aql::device(cfg->device_id);
+            if (ad.ok && c->aql.create(ad)) c->aql_on = true;
+            else {
+                static bool warned = false;
+                if (!warned) fprintf(stderr, "[hipensemble] direct AQL dispatch unavailable (%s): stepping launches use the HIP stream\n",
+                                     ad.ok ? c->aql.err.c_str() : ad.err.c_str());
+                warned = true;
+                if (ad.ok) c->aql.destroy();
+            }
+        }
+    }
     const size_t TW = (size_t)c->Tl * c->W;
     TRY(dalloc(c, &c->pool, 2 * TW * c->D));
     for (int b = 0; b < 2; ++b) {
@@ -1657,6 +1781,13 @@ void hens_destroy(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
+    if (c->aql_on) {
+        if (getenv("HENS_AQL_STATS")) fprintf(stderr, "[hipensemble] AQL queue: %llu packets written, %llu doorbells; kernarg ring in %s memory%s, HDP flush register %s\n",
+                                              (unsigned long long)c->aql.packets, (unsigned long long)c->aql.doorbells, c->aql.kernarg_dev ? "device" : "host",
+                                              c->aql.kernarg_uncached ? " (uncached)" : (c->aql.kernarg_fine ? " (fine-grained pool)" : " (coarse-grained pool)"), c->aql.dev->hdp.HDP_MEM_FLUSH_CNTL ? "present" : "absent");
+        c->aql.destroy();
+        c->aql_on = false;
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t q = 0; q < c->pipe.boxes.size(); ++q)
         if (c->pipe.opened[q] && c->pipe.boxes[q]) (void)hipIpcCloseMemHandle(c->pipe.boxes[q]);
@@ -1674,14 +1805,22 @@ void hens_destroy(hens_ctx* ctx) {
 int hens_synchronize(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(nullptr, HENS_ERR_INVALID, "null context");
+    if (c->aql_on) {              // the AQL queue first (a spin on its completion signal); the HIP stream only if it may hold work
+        const bool dirty = c->hip_dirty;
+        const int r = aql_settle(c);
+        if (r) return r;
+        c->hip_dirty = dirty;
+        if (!dirty) return HENS_OK;
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hip_dirty = false;
     if (pipe_active(c)) return check_flags(c, false);     // a neighbour that never answered surfaces here
     return HENS_OK;
 }
 
 int hens_set_stream(hens_ctx* ctx, void* s) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(nullptr, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1691,7 +1830,7 @@ int hens_set_stream(hens_ctx* ctx, void* s) {
 }
 
 int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double logp_inside) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !lo || !hi) return fail(c, HENS_ERR_INVALID, "null argument");
     for (int d = 0; d < c->D; ++d)
         if (!(lo[d] < hi[d])) return fail(c, HENS_ERR_INVALID, "prior box needs lo < hi in every dimension (dim %d)", d);
@@ -1706,7 +1845,7 @@ int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double
 }
 
 int hens_set_periodic(hens_ctx* ctx, const double* period) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE)
         return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters are not defined on leaf-packing records");
@@ -1736,7 +1875,7 @@ int hens_set_periodic(hens_ctx* ctx, const double* period) {
 }
 
 int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !mu || !prec) return fail(c, HENS_ERR_INVALID, "null argument");
     if (c->cfg.likelihood_kind != HENS_LIKE_GAUSS_DENSE && c->cfg.likelihood_kind != HENS_LIKE_GAUSS_DIAG)
         return fail(c, HENS_ERR_STATE, "context was not created with a Gaussian likelihood kind");
@@ -1785,7 +1924,7 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
 }
 
 int hens_set_rosenbrock(hens_ctx* ctx, double a, double b) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind != HENS_LIKE_ROSENBROCK)
         return fail(c, HENS_ERR_STATE, "context was not created with HENS_LIKE_ROSENBROCK");
@@ -1795,7 +1934,7 @@ int hens_set_rosenbrock(hens_ctx* ctx, double a, double b) {
 }
 
 int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const double* logp, const double* betas) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !x) return fail(c, HENS_ERR_INVALID, "null argument");
     if (c->cfg.tempered && !betas) return fail(c, HENS_ERR_INVALID, "betas required for a tempered context");
     if ((logl == nullptr) != (logp == nullptr)) return fail(c, HENS_ERR_INVALID, "give both logl and logp or neither");
@@ -1825,7 +1964,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
 }
 
 int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, double* betas) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (!c->have_state) return fail(c, HENS_ERR_STATE, "no state uploaded");
     if (c->pt_pending) return fail(c, HENS_ERR_STATE, "sharded PT exchange in flight (call hens_pt_finish_sharded)");
@@ -1846,7 +1985,7 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
 }
 
 int hens_eval_state(hens_ctx* ctx) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, false);
     if (r) return r;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -1937,7 +2076,7 @@ static int kernel_split(const hens_ctx_impl* c, int32_t split) { return split ==
 
 int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
                        const double* u_acc, uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     (void)hipSetDevice(c->cfg.device_id);
@@ -1982,7 +2121,7 @@ static HostLikeArgs hostlike_args(hens_ctx_impl* c, int32_t split) {
 }
 
 int hens_set_nsplits(hens_ctx* ctx, int32_t nsplits) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (nsplits < 2 || nsplits > 8) return fail(c, HENS_ERR_INVALID, "nsplits must be in [2, 8]");
     if (nsplits > c->W) return fail(c, HENS_ERR_INVALID, "more sets than walkers");
@@ -1994,7 +2133,7 @@ int hens_set_nsplits(hens_ctx* ctx, int32_t nsplits) {
 
 int hens_propose_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
                        double* q_out, uint8_t* inbox_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     (void)hipSetDevice(c->cfg.device_id);
@@ -2022,7 +2161,7 @@ int hens_propose_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
 }
 
 int hens_accept_split(hens_ctx* ctx, int32_t split, const double* logl, const double* u_acc, uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     if (!c->propose_pending || split != c->expect_split)
@@ -2048,7 +2187,7 @@ int hens_accept_split(hens_ctx* ctx, int32_t split, const double* logl, const do
 
 int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, const double* u_swap, int32_t adapt,
                   uint8_t* sel_out, double* swaps_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     if (!c->cfg.tempered) return fail(c, HENS_ERR_STATE, "context is not tempered");
@@ -2103,6 +2242,8 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
 // two iterations - nothing a later call could read consistently.  The state is declared gone (the caller uploads again)
 // instead of leaving stale by-field arrays behind a `packed` flag.
 static int step_failed(hens_ctx_impl* c, int r) {
+    c->aql_now = c->aql_last = false;
+    (void)aql_settle(c);
     (void)hipStreamSynchronize(c->stream);
     c->packed = false;
     c->colmode = false;
@@ -2158,6 +2299,18 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     //  call - the driver times blocks of 20 iterations - pays for both.)
     static const bool ev_env = getenv("HENS_STEP_EVENTS") != nullptr;
     c->step_events = prof || ev_env;
+    // Which queue: the two-launch iteration of one GPU goes to the context's AQL queue (hens_aql.h) unless something in this call
+    // needs the HIP stream between its launches (per-kernel events, traces, the MH move of a mix).
+    const bool use_aql = c->aql_on && fused && !piped && !c->step_events && !c->tracing && c->mh_kind < 0 && n_iters > 0;
+    if (use_aql) {
+        c->aql.own_only = !c->hip_dirty;
+        if (c->hip_dirty) {                      // the HIP stream may still be working on the state (upload, evaluation, ...)
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->hip_dirty = false;
+        }
+        c->aql.call_first = c->aql.windex;
+        c->aql_now = true;
+    } else if ((r = aql_settle(c))) return r;
     if (c->step_events) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // Draws are planned ON THE MAIN STREAM, right in front of the batch that consumes them (one buffer, ordered by the stream).  The
     // two-launch iteration computes its draws in registers and needs the round keys only (iteration_keys).  Rounds 1-3 planned batch
@@ -2173,6 +2326,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
         if (!keys_only) {
             launch_plan(c, c->stream, 0, c->iter, nb, fused, iter1);
             c->timing.n_plan += 1;
+            if (c->aql_failed) { c->aql_failed = false; return step_failed(c, fail(c, HENS_ERR_HIP, "AQL dispatch of the draw plan: %s", c->aql.err.c_str())); }
         }
         for (int ib = 0; ib < nb; ++ib) {
             if (piped) pipe_prewait(c);
@@ -2191,12 +2345,14 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 r = mh_iteration(c, prof ? &evs : nullptr, !piped && fast_path(c));
                 if (prof) ev_kind.push_back(0);
             } else if (iter1) {
+                c->aql_last = c->aql_now && b + 1 == nbatch && ib + 1 == nb;
                 r = iter_iteration(c, which, ib, prof ? &evs : nullptr);
                 if (prof) ev_kind.push_back(3);
                 if (r) return step_failed(c, r);
                 c->iter += 1;
                 continue;
             } else if (fused) {
+                c->aql_last = c->aql_now && b + 1 == nbatch && ib + 1 == nb;
                 r = fused_iteration(c, prof ? &evs : nullptr);
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(2); }
                 if (r) return step_failed(c, r);
@@ -2232,6 +2388,10 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
             c->iter += 1;
         }
     }
+    if (c->aql_now) {                 // (every packet of the call is written: the doorbell for the rest)
+        c->aql.ring();
+        c->aql_now = c->aql_last = false;
+    }
     if (piped && !pfused) state_to_fields(c);
     if (pfused) pipe_fused_epilogue(c);
     // The last cascade's ladder adaptation stays pending on one GPU: the next hens_step call folds it into its first
@@ -2265,11 +2425,12 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
 // loop no longer has to split the call and read the counters in between (a settled ladder adaptation, two device-to-host
 // copies and their synchronisations per stored sample).
 int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (n_before < 0 || n_last < 0) return fail(c, HENS_ERR_INVALID, "negative iteration count");
     int r;
     if (n_before > 0 && (r = hens_step(ctx, n_before))) return r;
+    if ((r = aql_settle(c))) return r;        // (what follows uses the HIP stream)
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t TW = (size_t)c->Tl * c->W;
     if (!c->accepted_mark && (r = dalloc(c, &c->accepted_mark, 2 * TW))) return r;
@@ -2283,7 +2444,7 @@ int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last) {
 
 // the counters kept by the last hens_step_marked call ([Tl][W] each; accepted_mh may be null; zeros if there is no MH move)
 int hens_get_marked_counters(hens_ctx* ctx, double* accepted, double* accepted_mh) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (!c->mark_valid) return fail(c, HENS_ERR_STATE, "hens_get_marked_counters without hens_step_marked");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -2298,7 +2459,7 @@ int hens_get_marked_counters(hens_ctx* ctx, double* accepted, double* accepted_m
 
 int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals, double* swaps_last, double* swaps_total,
                       int64_t* adapt_time) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
@@ -2319,7 +2480,7 @@ int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals, d
 }
 
 int hens_reset_counters(hens_ctx* ctx) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
@@ -2337,7 +2498,7 @@ int hens_reset_counters(hens_ctx* ctx) {
 }
 
 int hens_set_adapt_time(hens_ctx* ctx, int64_t t) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
@@ -2347,7 +2508,7 @@ int hens_set_adapt_time(hens_ctx* ctx, int64_t t) {
 }
 
 int hens_set_iteration(hens_ctx* ctx, int64_t iter) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (iter < 0) return fail(c, HENS_ERR_INVALID, "iteration counter < 0");
     if (pipe_active(c) && c->pipe.sweep > 0)
@@ -2390,7 +2551,7 @@ int hens_debug_launch_times(hens_ctx* ctx, double* out_us, int64_t capacity, int
 }
 
 int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capacity, int64_t* n_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const int64_t words = std::max<int64_t>((int64_t)c->Tl * ((c->W + TILE - 1) / TILE), pt_blocks(c)) * 8;
@@ -2416,7 +2577,7 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
 }
 
 int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t iter, int32_t* out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     int32_t* d = reinterpret_cast<int32_t*>(c->xtmp);          // scratch: at least W * 4 bytes
@@ -2436,7 +2597,7 @@ int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out) {
 
 int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, double* u_zz, double* u_acc,
                      int32_t* pt_slot, double* u_swap, int32_t* is_mh, double* mh_step, double* mh_u) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || iter < 0) return fail(c, HENS_ERR_INVALID, "null context / negative iteration");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     const size_t TW = (size_t)c->Tl * c->W;
@@ -2509,7 +2670,7 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
 int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, const int32_t* nleaves_max,
                       const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp,
                       int32_t ndata, const double* t, const double* y, double sigma) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !kinds || !nleaves_max || !nleaves_min || !lo || !hi || !leaf_logp || !t || !y)
         return fail(c, HENS_ERR_INVALID, "null argument");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_set_model needs HENS_LIKE_TEMPLATE");
@@ -2552,7 +2713,7 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
 }
 
 int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !scale) return fail(c, HENS_ERR_INVALID, "null argument");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || !c->have_like) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
     for (int b = 0; b < c->rj.nb; ++b)
@@ -2562,7 +2723,7 @@ int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale) {
 }
 
 int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = rj_ready(c);
     if (r) return r;
     if (!step || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -2583,7 +2744,7 @@ int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint
 
 int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const int32_t* leaf, const double* birth,
                     const double* u_acc, uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = rj_ready(c);
     if (r) return r;
     if (!change || !leaf || !birth || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -2611,7 +2772,7 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
 // "together" with the caller's draws: change / leaf [nbranches][Tl][W], birth [nbranches][Tl][W][3], one u_acc [Tl][W]
 int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf, const double* birth, const double* u_acc,
                         uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = rj_ready(c);
     if (r) return r;
     if (!change || !leaf || !birth || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -2643,7 +2804,7 @@ static int rj_branch_of(const hens_ctx_impl* c, uint64_t it) {
 }
 
 int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = rj_ready(c);
     if (r) return r;
     if (n_iters < 0) return fail(c, HENS_ERR_INVALID, "n_iters < 0");
@@ -2684,7 +2845,7 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
 }
 
 int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
     if (schedule < 0 || schedule > 2) return fail(c, HENS_ERR_UNSUPPORTED, "rj schedule must be 0 (separate_branches), 1 (iterate_branches) or 2 (together)");
@@ -2694,7 +2855,7 @@ int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule) {
 
 int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh, int32_t* branch, int8_t* coin, uint32_t* sel,
                         double* birth, double* u_bd, int32_t* slot_mh, double* uswap_mh, int32_t* slot_bd, double* uswap_bd) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || iter < 0) return fail(c, HENS_ERR_INVALID, "null context / negative iteration");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || c->rj.nb <= 0) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
     if (!c->rj_have_scale) return fail(c, HENS_ERR_STATE, "in-model step scale not set (hens_rj_set_mh_scale)");
@@ -2754,7 +2915,7 @@ int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh,
 }
 
 int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, int64_t* num_bd) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || !c->rj_acc_bd) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -2773,7 +2934,7 @@ int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, in
 
 // ---- ladder sharding ---------------------------------------------------------------------------------
 int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
@@ -2790,7 +2951,7 @@ int hens_get_device_buffers(hens_ctx* ctx, hens_device_buffers* out) {
 }
 
 int hens_stretch_iter(hens_ctx* ctx) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_stretch_iter between split 0 and split 1");
@@ -2816,7 +2977,7 @@ int hens_stretch_iter(hens_ctx* ctx) {
 int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, const double* u_swap,
                          int32_t adapt, const int32_t* rank_of_rung, int32_t nranks, int32_t my_rank,
                          int64_t* send_counts, int64_t* recv_counts, uint8_t* sel_out, double* swaps_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     if (!c->cfg.tempered || c->T < 2) return fail(c, HENS_ERR_STATE, "context is not tempered");
@@ -2899,7 +3060,7 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
 }
 
 int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (!c->pt_pending) return fail(c, HENS_ERR_STATE, "no sharded PT exchange in flight");
     if (n_recv != c->n_recv) return fail(c, HENS_ERR_INVALID, "expected %lld received rows, got %lld", (long long)c->n_recv, (long long)n_recv);
@@ -2918,7 +3079,7 @@ int hens_pt_finish_sharded(hens_ctx* ctx, int64_t n_recv) {
 
 // ---- Metropolis-Hastings proposals ----------------------------------------------------------
 int hens_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     if (!step || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
@@ -2942,7 +3103,7 @@ int hens_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t
 }
 
 int hens_set_mh_proposal(hens_ctx* ctx, int32_t kind, const double* scale, double weight) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (kind < 0) {                                   // back to the stretch move only
         c->mh_kind = -1;
@@ -2966,7 +3127,7 @@ int hens_set_mh_proposal(hens_ctx* ctx, int32_t kind, const double* scale, doubl
 }
 
 int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
@@ -2987,7 +3148,7 @@ int hens_get_mh_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals
 
 // ---- ladder pipeline set-up -------------------------------------------------------------------------
 int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_out, int64_t* box_bytes_out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->pipe.on) return fail(c, HENS_ERR_STATE, "pipeline already initialised");
     if (!c->cfg.tempered || c->T < 2) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
@@ -3059,7 +3220,7 @@ static int pipe_finish_connect(hens_ctx_impl* c) {
 }
 
 int hens_pipe_connect(hens_ctx* ctx, const void* blobs) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !blobs) return fail(c, HENS_ERR_INVALID, "null argument");
     if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
     if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
@@ -3089,7 +3250,7 @@ int hens_pipe_connect(hens_ctx* ctx, const void* blobs) {
 // (eryn_amd.ladder.StagedPipeline: torch.distributed point-to-point = grouped ncclSend/ncclRecv on ROCm) moves
 // the message regions between the stages.  RCCL cannot pull, so the LDN message carries the boundary rung's rows.
 int hens_pipe_connect_staged(hens_ctx* ctx) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
     if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");
@@ -3122,7 +3283,7 @@ int hens_pipe_connect_staged(hens_ctx* ctx) {
 }
 
 int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
     if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
     const int W = c->W, D = c->D, T = c->T, par = (int)(c->pipe.sweep & 1u);
@@ -3148,7 +3309,7 @@ int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out) {
 }
 
 int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     int r = ready(c, true);
     if (r) return r;
     if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
@@ -3274,7 +3435,7 @@ int hens_pipe_selftest(int32_t device_id, int32_t rank, int32_t nranks, const ch
 }
 
 int hens_pipe_debug_stats(hens_ctx* ctx, uint64_t* out16, int32_t reset) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !out16) return fail(c, HENS_ERR_INVALID, "null argument");
     if (!c->pipe.stats) return fail(c, HENS_ERR_STATE, "set HENS_PIPE_STATS=1 before hens_pipe_init");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -3285,7 +3446,7 @@ int hens_pipe_debug_stats(hens_ctx* ctx, uint64_t* out16, int32_t reset) {
 }
 
 int hens_pipe_connect_local(hens_ctx* ctx, hens_ctx* const* peers) {
-    hens_ctx_impl* c = CTX(ctx);
+    hens_ctx_impl* c = enter(ctx);
     if (!c || !peers) return fail(c, HENS_ERR_INVALID, "null argument");
     if (!c->pipe.on) return fail(c, HENS_ERR_STATE, "hens_pipe_init first");
     if (c->pipe.connected) return fail(c, HENS_ERR_STATE, "pipeline already connected");

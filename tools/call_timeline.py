@@ -6,6 +6,7 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 from tools.quick_bench import problem, ladder
+import os; os.environ.pop("HENS_STEP_EVENTS", None)      # (quick_bench sets it on import: an event pair per call, and the HIP stream)
 from eryn_amd.engine import HipEnsemble
 from eryn_amd.likelihood import GaussianLikelihood
 

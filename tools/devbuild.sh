@@ -4,4 +4,4 @@
 R=$(git rev-parse --show-toplevel); N=${1:-dev}; shift
 mkdir -p $R/build_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DHENS_DEV_BUILD "$@" -I$R/include \
-    $R/eryn_amd/csrc/hens.hip -o $R/build_ab/libhens_$N.so 2>&1 | grep -E "error|Error" ; ls -la $R/build_ab/libhens_$N.so
+    $R/eryn_amd/csrc/hens.hip -o $R/build_ab/libhens_$N.so -L/opt/rocm/lib -lhsa-runtime64 2>&1 | grep -E "error|Error" ; ls -la $R/build_ab/libhens_$N.so
