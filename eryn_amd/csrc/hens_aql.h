@@ -231,6 +231,7 @@ struct Queue {
     Device* dev = nullptr;
     hsa_queue_t* q = nullptr;
     hsa_signal_t done{};
+    uint32_t qsize = 0;              // packets the queue REALLY holds (a profiler's intercept queue need not honour the request)
     char* kernarg = nullptr;
     bool kernarg_dev = false;        // the ring is device memory mapped into the host (writes cross the BAR: flush before the doorbell)
     bool kernarg_uncached = false, kernarg_fine = false;
@@ -252,6 +253,8 @@ struct Queue {
         dev = &d;
         hsa_status_t st = hsa_queue_create(d.agent, QUEUE_PACKETS, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q);
         if (st != HSA_STATUS_SUCCESS) { err = "hsa_queue_create failed"; q = nullptr; return false; }
+        qsize = q->size;
+        if (qsize < 8 || (qsize & (qsize - 1)) != 0) { err = "AQL queue size is not a power of two >= 8"; return false; }
         st = hsa_signal_create(0, 0, nullptr, &done);
         if (st != HSA_STATUS_SUCCESS) { err = "hsa_signal_create failed"; return false; }
         done_target = 0;
@@ -264,7 +267,7 @@ struct Queue {
         if (d.have_vram && !host_ka) {
             const bool fine = d.have_vram_fine && ka_pool != "coarse" && ka_pool != "uncached";
             const bool unc = ka_pool == "uncached";
-            st = hsa_amd_memory_pool_allocate(fine ? d.vram_fine_pool : d.vram_pool, (size_t)QUEUE_PACKETS * SLOT_BYTES,
+            st = hsa_amd_memory_pool_allocate(fine ? d.vram_fine_pool : d.vram_pool, (size_t)qsize * SLOT_BYTES,
                                               unc ? HSA_AMD_MEMORY_POOL_UNCACHED_FLAG : 0, reinterpret_cast<void**>(&kernarg));
             kernarg_uncached = unc; kernarg_fine = fine;
             if (st == HSA_STATUS_SUCCESS) {
@@ -274,7 +277,7 @@ struct Queue {
             } else kernarg = nullptr;
         }
         if (!kernarg) {
-            st = hsa_amd_memory_pool_allocate(d.kernarg_pool, (size_t)QUEUE_PACKETS * SLOT_BYTES, 0, reinterpret_cast<void**>(&kernarg));
+            st = hsa_amd_memory_pool_allocate(d.kernarg_pool, (size_t)qsize * SLOT_BYTES, 0, reinterpret_cast<void**>(&kernarg));
             if (st != HSA_STATUS_SUCCESS) { err = "kernarg ring allocation failed"; kernarg = nullptr; return false; }
             st = hsa_amd_agents_allow_access(1, &d.agent, nullptr, kernarg);
             if (st != HSA_STATUS_SUCCESS) { err = "hsa_amd_agents_allow_access(kernarg ring) failed"; return false; }
@@ -298,13 +301,13 @@ struct Queue {
         const bool implicit = k.kernarg_size > impl_off;
         if (impl_off + (implicit ? sizeof(ImplicitArgs) : 0) > SLOT_BYTES || k.kernarg_size > SLOT_BYTES) { err = "kernel arguments exceed the kernarg slot"; return false; }
         // a slot is free once the packet AFTER its old tenant has been consumed (barrier bit: the old tenant has completed then)
-        if (windex + 2 > hsa_queue_load_read_index_relaxed(q) + QUEUE_PACKETS) {
+        if (windex + 2 > hsa_queue_load_read_index_relaxed(q) + qsize) {
             ring();
             const auto t0 = std::chrono::steady_clock::now();
-            while (windex + 2 > hsa_queue_load_read_index_scacquire(q) + QUEUE_PACKETS)
+            while (windex + 2 > hsa_queue_load_read_index_scacquire(q) + qsize)
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) { err = "AQL queue stalled for 30 s"; return false; }
         }
-        const uint32_t slot = (uint32_t)(windex & (QUEUE_PACKETS - 1));
+        const uint32_t slot = (uint32_t)(windex & (qsize - 1));
         char* ka = kernarg + (size_t)slot * SLOT_BYTES;
         memcpy(ka, args, args_size);
         if (implicit) {
@@ -339,6 +342,9 @@ struct Queue {
         hsa_queue_store_write_index_relaxed(q, windex);
         fresh = false;
         pending = true;
+        // (never let one doorbell cover packets on both sides of the ring's end: rocprofv3's intercept queue copies the range a
+        //  doorbell announces in one piece and ran off the end of the ring - SIGSEGV at the first wrap-around under --kernel-trace)
+        if ((windex & (qsize - 1)) == 0) ring();
         return true;
     }
     void ring() {
@@ -362,8 +368,8 @@ struct Queue {
     }
     // a barrier packet that carries the completion signal (a call that ended without a signalled dispatch: error paths)
     void barrier_signal() {
-        const uint32_t slot = (uint32_t)(windex & (QUEUE_PACKETS - 1));
-        while (windex + 2 > hsa_queue_load_read_index_scacquire(q) + QUEUE_PACKETS) {}
+        const uint32_t slot = (uint32_t)(windex & (qsize - 1));
+        while (windex + 2 > hsa_queue_load_read_index_scacquire(q) + qsize) {}
         hsa_barrier_and_packet_t* p = reinterpret_cast<hsa_barrier_and_packet_t*>(q->base_address) + slot;
         memset(reinterpret_cast<char*>(p) + 4, 0, sizeof(*p) - 4);
         p->completion_signal = done;

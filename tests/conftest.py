@@ -40,3 +40,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """what the log-likelihood comparisons of this session actually observed (tests/tolerance_log.py)."""
+    from tests import tolerance_log as tol
+    rep = tol.report()
+    if not rep:
+        return
+    out = tol.write(os.path.join(ROOT, "gpurun_out", "tolerance_report.json"))
+    tr = terminalreporter
+    tr.write_sep("-", f"log-likelihood vs oracle: worst relative difference {out['worst']:.2e} (bar {tol.RTOL_L:.0e}; per test in gpurun_out/tolerance_report.json)")
+    worst = sorted(rep.items(), key=lambda kv: -kv[1]["max_rel_L"])[:8]
+    for name, v in worst:
+        tr.write_line(f"  {v['max_rel_L']:.2e}  (bar {v['rtol']:.0e}, {v['values']} values)  {name}")

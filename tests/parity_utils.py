@@ -38,6 +38,8 @@ def make_engine(o, mu, invcov, dense=True, **kw):
                        adaptation_lag=o.lag, adaptation_time=o.nu, stop_adaptation=o.stop_adaptation, **kw)
 
 
+from tests import tolerance_log as tol
+
 KNIFE = 1e-12
 
 
@@ -46,7 +48,7 @@ def knife_edge(lnpdiff, logu):
         return np.abs(lnpdiff - logu) < KNIFE * np.maximum(1.0, np.abs(lnpdiff))
 
 
-def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=1e-12, stats=None):
+def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=None, stats=None):
     """Replay one recorded oracle iteration on the HIP engine and compare everything.
 
     prev = (x, L, P, betas, time) before the iteration (uploaded when teacher_forced).
@@ -78,11 +80,9 @@ def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=1e-12, stats=
         xs = rec[f"x_after{nsp - 1}"]
         assert np.array_equal(x, xs), f"x after stretch: max abs diff {np.abs(x - xs).max()}"
         assert np.array_equal(P, rec["P_stretch"]), "log-prior after stretch"
-        np.testing.assert_allclose(L, rec["L_stretch"], rtol=rtol_l, atol=0)
+        rel = tol.check_logl(L, rec["L_stretch"], tol.RTOL_L if rtol_l is None else rtol_l, "log-like after stretch")
         if stats is not None:
-            with np.errstate(invalid="ignore", divide="ignore"):
-                stats["max_rel_L"] = max(stats.get("max_rel_L", 0.0),
-                                         float(np.nanmax(np.abs(L - rec["L_stretch"]) / np.abs(rec["L_stretch"]))))
+            stats["max_rel_L"] = max(stats.get("max_rel_L", 0.0), rel)
     if o.tempered and T > 1:
         if teacher_forced and tolerated == 0:
             # swap decisions depend on L to the last bit: teacher-force the oracle's L
@@ -101,7 +101,7 @@ def check_iteration(eng, o, rec, prev, teacher_forced=True, rtol_l=1e-12, stats=
             if teacher_forced:
                 assert np.array_equal(L, rec["L"]), "log-like after PT (teacher-forced: pure permutation)"
             else:
-                np.testing.assert_allclose(L, rec["L"], rtol=rtol_l, atol=0)
+                tol.check_logl(L, rec["L"], tol.RTOL_L if rtol_l is None else rtol_l, "log-like after PT")
         np.testing.assert_allclose(betas, rec["betas_after"], rtol=1e-13, atol=0)
     return tolerated
 

@@ -18,6 +18,7 @@ ascending order in which the reference's boolean masks enumerate a half.
 import numpy as np
 
 from oracle import eryn_oracle as orc
+from tests import tolerance_log as tol
 
 
 def is_permutation_rows(a, W):
@@ -130,12 +131,12 @@ def replay(eng_draws, st, it0, n, loglike, lo, hi, mh=False, **kw):
     return kinds
 
 
-def assert_state_equal(st, x, L, P, betas, counters=None, mh_counters=None, rtol_l=1e-12, what=""):
-    """Bars of SURVEY 8c: positions / log-prior / counters exact, log-likelihood rtol 1e-12, betas rtol 1e-13."""
+def assert_state_equal(st, x, L, P, betas, counters=None, mh_counters=None, rtol_l=None, what=""):
+    """Bars of SURVEY 8c: positions / log-prior / counters exact, log-likelihood rtol 1e-13 (tests/tolerance_log.py records what was observed), betas rtol 1e-13."""
     assert np.array_equal(x, st.x), f"{what}: x differs from the oracle in {int((x != st.x).any(axis=-1).sum())} walkers " \
                                     f"(closest decision margin {st.min_margin:.2e})"
     assert np.array_equal(P, st.P), f"{what}: log-prior differs"
-    np.testing.assert_allclose(L, st.L, rtol=rtol_l, atol=0, err_msg=f"{what}: log-likelihood")
+    tol.check_logl(L, st.L, tol.RTOL_L if rtol_l is None else rtol_l, what)
     if st.betas is not None:
         np.testing.assert_allclose(betas, st.betas, rtol=1e-13, atol=0, err_msg=f"{what}: betas")
     if counters is not None:

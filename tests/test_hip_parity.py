@@ -6,7 +6,7 @@ cannot snowball.  Tolerances:
   accept / swap masks, swap counts, indices ... exact (knife-edge allowance 1e-12 relative,
                                                counted and expected to be 0)
   walker positions, log-prior ............... exact (proposal arithmetic is compiled without FMA)
-  log-likelihood ............................ rtol 1e-12 (summation order of the quadratic form)
+  log-likelihood ............................ rtol 1e-13 (summation order of the quadratic form; observed: tolerance_log)
   betas after adaptation .................... rtol 1e-13 (device exp vs libm exp)
 """
 import os
@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 from tests import parity_utils as pu
+from tests import tolerance_log as tol
 from oracle import eryn_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +76,7 @@ def test_seeded_teacher_forced(T, W, D, box, n):
     stats = {}
     tolerated = pu.run_parity(o, eng, n, teacher_forced=True, stats=stats)
     assert tolerated == 0
-    assert stats.get("max_rel_L", 0.0) < 1e-12
+    assert stats.get("max_rel_L", 0.0) <= tol.RTOL_L
     eng.close()
 
 
@@ -97,7 +98,7 @@ def test_eval_state_matches_oracle():
     _, L, P, _ = eng.download()
     assert np.array_equal(P, o.P)
     assert np.array_equal(L == -1e300, o.L == -1e300)
-    np.testing.assert_allclose(L, o.L, rtol=1e-12)
+    tol.check_logl(L, o.L, what="hens_eval_state")
     eng.close()
 
 
