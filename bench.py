@@ -481,7 +481,7 @@ def run_sharded(args):
     import torch.distributed as dist
 
     from eryn_amd.engine import HipEnsemble
-    from eryn_amd.ladder import HipShardEngine, LadderPipeline, ShardedLadder, StagedPipeline, rung_partition
+    from eryn_amd.ladder import HipShardEngine, LadderPipeline, RcclPipeline, ShardedLadder, StagedPipeline, rung_partition
     from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
     from eryn_amd.moves.tempering import make_ladder
 
@@ -559,13 +559,15 @@ def run_sharded(args):
             return None
         return eng, times
 
-    STAGED = "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages)"
+    STAGED = "RCCL neighbour exchange (ncclSend/ncclRecv between the pipeline's stages, enqueued by the library: hens_comm_init)"
 
     def staged_run():
         """The same protocol and kernels with RCCL point-to-point messages between three host-ordered stages."""
         eng = make_engine(0)
         try:
-            stepper = StagedPipeline(eng, rank, world, dist, device)
+            # RCCL ranks: the library sends the messages itself (hens_comm_init: one C call per block of iterations); the gloo
+            # dry run keeps the host-ordered form of the same protocol (torch.distributed carries the regions)
+            stepper = RcclPipeline(eng, rank, world, dist) if backend == "nccl" else StagedPipeline(eng, rank, world, dist, device)
         except Exception as exc:                      # noqa: BLE001
             print(f"[rank {rank}] staged pipeline unavailable ({exc})", file=sys.stderr, flush=True)
             stepper = None
@@ -654,7 +656,7 @@ def run_sharded(args):
                          "unit": "us per iteration and rank, summed over the waiting workgroups' lead threads (a separate pass "
                                  "with HENS_PIPE_STATS=1; the timed passes run without the statistics)"}
         # the transport north_star names, timed in the same run: RCCL point-to-point between ladder neighbours
-        if not args.no_staged and not rosen:
+        if not args.no_staged:
             sr = staged_run()
             if sr is not None:
                 staged = summary(sr[1], transport=STAGED, schedule="the reference's (adaptation_delay=0)")

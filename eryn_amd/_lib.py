@@ -96,6 +96,10 @@ SIGNATURES = {
     "hens_pipe_debug_stats": (C.c_int, [_P, _P, C.c_int32]),
     "hens_debug_trace": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P]),
     "hens_debug_launch_times": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "hens_comm_unique_id": (C.c_int, [_P]),
+    "hens_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "hens_comm_destroy": (C.c_int, [_P]),
+    "hens_comm_selfsend": (C.c_int, [_P, C.c_int64, _P, _P]),
     "hens_debug_permutation": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int64, _P]),
     "hens_rj_set_model": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_double]),
     "hens_rj_set_mh_scale": (C.c_int, [_P, _P]),

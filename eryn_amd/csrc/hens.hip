@@ -6,6 +6,7 @@
 #include "hens_iter.h"
 #include "hens_aql.h"
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>          // (types and prototypes only: the library is dlopen()ed, see rccl_api)
 
 #include <algorithm>
 #include <chrono>
@@ -168,6 +169,12 @@ struct hens_ctx_impl {
     double* rj_step = nullptr; double* rj_u = nullptr; double* rj_birth = nullptr;   // parity staging
     int8_t* rj_change = nullptr; int32_t* rj_leaf = nullptr; uint8_t* rj_keep = nullptr;
     uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
+    double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
+    int64_t rj_tm_ndata = 0;
+    bool rj_tm_valid = false;
+    // ladder sharding over RCCL point-to-point messages inside the library (hens_comm_init): the staged transport's exchanges
+    void* comm = nullptr;                   // ncclComm_t
+    bool comm_on = false;               // ... and they belong to the rows as they are (false after an upload / a parity-API move)
     int64_t rj_num_mh = 0, rj_num_bd = 0;
     bool rj_have_scale = false;
     int rj_schedule = 0;                    // hens_rj_set_schedule: 0 "separate_branches", 1 "iterate_branches", 2 "together" (ensemble.py:414-480)
@@ -178,6 +185,7 @@ struct hens_ctx_impl {
     unsigned long long* d_trace = nullptr;
     int64_t trace_words = 0;
     bool tracing = false, trace_pt = false, trace_fused = false;
+    int trace_rj = -1;               // k_rj launches of this mode stamp their phases (hens_debug_trace 4: in-model move, 5: birth / death)
     bool per_kernel_events = false;
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1530,13 +1538,19 @@ bool iteration_is_mh(const hens_ctx_impl* c) {
 }
 
 // ---- reversible-jump leaf packing ---------------------------------------------------------------------------------------
+// tm_mode: -1 no resident templates (parity API), else RjArgs::tm_mode
 int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const int8_t* change, const int32_t* leaf,
-              const double* birth, const double* u_acc, uint8_t* keep) {
+              const double* birth, const double* u_acc, uint8_t* keep, int tm_mode = -1) {
     RjArgs a{};
+    if (c->tracing && c->trace_rj == mode) { a.trace = c->d_trace; a.trace_n = (int32_t)(c->trace_words / 8); }
+    a.tm = (tm_mode >= 0) ? c->rj_tm : nullptr;
+    a.tm_mode = tm_mode >= 0 ? tm_mode : 0;
     a.pool = c->pool; a.loc = c->loc[c->cur]; a.L = c->L[c->cur]; a.P = c->P[c->cur];
     a.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
     a.accepted = mode == RJ_MODE_BD ? c->rj_acc_bd : c->accepted;
-    if (mode == RJ_MODE_BD && c->rj_schedule == 1 && !change && branch != c->rj.nb - 1) a.accepted = nullptr;   // (production, not the last branch)
+    // "iterate_branches": the move's accept mask is the LAST branch's (rj.py:385-386) - in both modes, so the counters of
+    // hens_rj_step and of the parity API (one hens_rj_bd_step per branch) mean the same thing
+    if (mode == RJ_MODE_BD && c->rj_schedule == 1 && branch != c->rj.nb - 1) a.accepted = nullptr;
     a.keep_out = keep;
     a.tdata = c->rj_t; a.ydata = c->rj_y;
     a.step = step; a.change = change; a.leaf = leaf; a.birth = birth; a.u_acc = u_acc;
@@ -1591,6 +1605,84 @@ void rj_cascade(hens_ctx_impl* c, uint64_t key, bool adapt) {
 }  // namespace
 
 // ================================================================================================
+// ---- RCCL neighbour exchange inside the library (hens_comm_init / hens_comm_destroy) ------------------------------
+// The staged transport's protocol (include/hipensemble.h, "Staged transport") with the messages sent by the library itself:
+// ncclSend / ncclRecv between ladder neighbours and one all-reduce of the swap counts per sweep, all enqueued on the context's
+// stream between the three stage launches - hens_step(n) on such a context is ONE call for n iterations, no host in the loop.
+// librccl is dlopen()ed by its soname: in a process that holds PyTorch-ROCm that is torch's own copy (already loaded), so both
+// speak to one RCCL; a process without torch gets the system library.
+struct RcclApi {
+    bool tried = false, ok = false;
+    std::string err;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi& rccl_api() {
+    static RcclApi a;
+    if (a.tried) return a;
+    a.tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { a.err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return a; }
+#define HENS_RCCL_SYM(field, sym) do { *reinterpret_cast<void**>(&a.field) = dlsym(h, sym); if (!a.field) { a.err = std::string("librccl lacks ") + sym; return a; } } while (0)
+    HENS_RCCL_SYM(GetUniqueId, "ncclGetUniqueId"); HENS_RCCL_SYM(CommInitRank, "ncclCommInitRank"); HENS_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    HENS_RCCL_SYM(Send, "ncclSend"); HENS_RCCL_SYM(Recv, "ncclRecv"); HENS_RCCL_SYM(AllReduce, "ncclAllReduce");
+    HENS_RCCL_SYM(GroupStart, "ncclGroupStart"); HENS_RCCL_SYM(GroupEnd, "ncclGroupEnd"); HENS_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef HENS_RCCL_SYM
+    a.ok = true;
+    return a;
+}
+#define RCCLCHK(c, expr)                                                                           \
+    do {                                                                                           \
+        const ncclResult_t n_ = (expr);                                                            \
+        if (n_ != ncclSuccess) return fail(c, HENS_ERR_HIP, "%s failed: %s", #expr, rccl_api().GetErrorString(n_)); \
+    } while (0)
+
+static int pipe_regions_impl(hens_ctx_impl* c, hens_pipe_region_table* out);
+static int pipe_stage_impl(hens_ctx_impl* c, int32_t stage);
+
+// n iterations of a ladder shard whose neighbours are reached through the context's communicator
+static int comm_step(hens_ctx_impl* c, int64_t n_iters) {
+    RcclApi& R = rccl_api();
+    ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
+    const int up = c->pipe.rank + 1, dn = c->pipe.rank - 1;
+    const bool top = pipe_has_top(c), bot = pipe_has_bot(c);
+    int r = aql_settle(c);
+    if (r) return r;
+    for (int64_t it = 0; it < n_iters; ++it) {
+        hens_pipe_region_table g{};
+        if ((r = pipe_regions_impl(c, &g))) return r;
+        const size_t lp = (size_t)g.lp_doubles, rows = (size_t)g.row_doubles, nc = (size_t)g.cnt_words;
+        if ((r = pipe_stage_impl(c, 0))) return r;                       // the move; publishes the boundary rung
+        if (top || bot) {                                                // LDN: cold -> hot (RCCL cannot pull: the rung's rows travel along)
+            RCCLCHK(c, R.GroupStart());
+            if (top) { RCCLCHK(c, R.Send(g.ldn_out, lp, ncclDouble, up, comm, c->stream)); RCCLCHK(c, R.Send(g.ldn_rows_out, rows, ncclDouble, up, comm, c->stream)); }
+            if (bot) { RCCLCHK(c, R.Recv(g.ldn_in, lp, ncclDouble, dn, comm, c->stream)); RCCLCHK(c, R.Recv(g.ldn_rows_in, rows, ncclDouble, dn, comm, c->stream)); }
+            RCCLCHK(c, R.GroupEnd());
+        }
+        if (top) RCCLCHK(c, R.Recv(g.lup_in, lp, ncclDouble, up, comm, c->stream));       // LUP: hot -> cold
+        if ((r = pipe_stage_impl(c, 1))) return r;                       // the walk
+        if (bot) RCCLCHK(c, R.Send(g.lup_out, lp, ncclDouble, dn, comm, c->stream));
+        if (top) RCCLCHK(c, R.Recv(g.rows_in, rows, ncclDouble, up, comm, c->stream));    // ROWS: hot -> cold, before my bottom pair
+        if ((r = pipe_stage_impl(c, 2))) return r;                       // bottom pair; fills the rows that go down
+        if (bot) RCCLCHK(c, R.Send(g.rows_out, rows, ncclDouble, dn, comm, c->stream));
+        if (c->pipe.nranks > 1) RCCLCHK(c, R.AllReduce(g.cnt_out, g.cnt_out, nc, ncclUint32, ncclSum, comm, c->stream));   // CNT: every pair's owner -> all
+        HIPCHK(c, hipMemcpyAsync(g.cnt_in, g.cnt_out, nc * 4, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    return HENS_OK;
+}
+
 extern "C" {
 
 const char* hens_version(void) { return "hipensemble 0.2 (gfx950)"; }
@@ -1781,6 +1873,7 @@ void hens_destroy(hens_ctx* ctx) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return;
     (void)hipSetDevice(c->cfg.device_id);
+    if (c->comm_on) { RcclApi& R = rccl_api(); if (c->stream) (void)hipStreamSynchronize(c->stream); if (R.ok) (void)R.CommDestroy(static_cast<ncclComm_t>(c->comm)); c->comm_on = false; }
     if (c->aql_on) {
         if (getenv("HENS_AQL_STATS")) fprintf(stderr, "[hipensemble] AQL queue: %llu packets written, %llu doorbells; kernarg ring in %s memory%s, HDP flush register %s\n",
                                               (unsigned long long)c->aql.packets, (unsigned long long)c->aql.doorbells, c->aql.kernarg_dev ? "device" : "host",
@@ -1943,6 +2036,7 @@ int hens_upload_state(hens_ctx* ctx, const double* x, const double* logl, const 
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
     c->cur = 0;
+    c->rj_tm_valid = false;
     c->packed = false;
     c->colmode = false;
     c->rows_mixed = false;    // (a failed hens_step call may have left these behind: step_failed)
@@ -1991,8 +2085,9 @@ int hens_eval_state(hens_ctx* ctx) {
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
     if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE) {
-        r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         if (r) return r;
+        c->rj_tm_valid = c->rj_tm != nullptr;
         r = check_flags(c, true);
         if (r) return r;
         c->have_logs = true;
@@ -2266,7 +2361,10 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (c->Tl != c->T && !piped)
         return fail(c, HENS_ERR_STATE, "hens_step on a ladder shard needs the pipeline connected (hens_pipe_init / hens_pipe_connect)");
     if (piped && !has_pt(c)) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
-    if (piped && c->pipe.staged) return fail(c, HENS_ERR_STATE, "staged pipeline: step with hens_pipe_stage (the messages travel between the stages)");
+    if (piped && c->pipe.staged) {
+        if (c->comm_on) return comm_step(c, n_iters);      // (RCCL neighbour exchange inside the library: hens_comm_init)
+        return fail(c, HENS_ERR_STATE, "staged pipeline: step with hens_pipe_stage (the messages travel between the stages), or give the context a communicator (hens_comm_init)");
+    }
     if (!piped && c->cfg.adaptation_delay != 0)
         return fail(c, HENS_ERR_UNSUPPORTED, "adaptation_delay is an option of the ladder pipeline (hens_pipe_*)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
@@ -2565,6 +2663,8 @@ int hens_debug_trace(hens_ctx* ctx, int32_t enable, uint64_t* out, int64_t capac
         c->tracing = true;
         c->trace_pt = enable == 2;           // 1: stretch kernel, 2: PT cascade, 3: fused half-step + cascade
         c->trace_fused = enable == 3;
+        c->trace_rj = enable == 4 ? RJ_MODE_MH : (enable == 5 ? RJ_MODE_BD : -1);
+        if (c->trace_rj >= 0) c->trace_pt = true;        // (keeps the stretch / fused kernels' own stamps out)
         return HENS_OK;
     }
     c->tracing = false;
@@ -2704,6 +2804,14 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
         if ((r = dalloc(c, &c->rj_acc_bd, (size_t)c->Tl * c->W))) return r;
         HIPCHK(c, hipMemsetAsync(c->rj_acc_bd, 0, (size_t)c->Tl * c->W * 4, c->stream));
     }
+    // every pool row's template, resident (birth / death by difference in hens_rj_step): 2 Tl W rows of ndata doubles
+    // (config 4: 131 MB); a lane keeps 8 points, so models of up to 512 data points
+    static const bool tm_off = getenv("HENS_RJ_NO_TEMPLATES") != nullptr;         // A/B knob
+    if (!tm_off && ndata <= 512 && (!c->rj_tm || c->rj_tm_ndata != ndata)) {
+        if ((r = dalloc(c, &c->rj_tm, (size_t)2 * c->Tl * c->W * (size_t)ndata))) return r;
+        c->rj_tm_ndata = ndata;
+    }
+    c->rj_tm_valid = false;
     HIPCHK(c, hipMemcpyAsync(c->rj_t, t, (size_t)ndata * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_y, y, (size_t)ndata * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2734,6 +2842,7 @@ int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint
     const size_t TW = (size_t)c->Tl * c->W;
     HIPCHK(c, hipMemcpyAsync(c->rj_step, step, TW * c->rj.ind_off * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    c->rj_tm_valid = false;                   // (teacher-forced move: the reference's full evaluation, no resident templates)
     if ((r = rj_launch(c, RJ_MODE_MH, 0, c->rj_step, nullptr, nullptr, nullptr, c->rj_u, c->rj_keep))) return r;
     if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
     if ((r = check_flags(c, false))) return r;
@@ -2762,10 +2871,11 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
     HIPCHK(c, hipMemcpyAsync(c->rj_leaf, leaf, TW * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, TW * RJ_ND * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    c->rj_tm_valid = false;                   // (teacher-forced move: the reference's full evaluation, no resident templates)
     if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, c->rj_change, c->rj_leaf, c->rj_birth, c->rj_u, c->rj_keep))) return r;
     if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
     if ((r = check_flags(c, false))) return r;
-    c->rj_num_bd += 1;
+    if (!(c->rj_schedule == 1 && branch != c->rj.nb - 1)) c->rj_num_bd += 1;    // (one MOVE per walk through the branches)
     return HENS_OK;
 }
 
@@ -2791,6 +2901,7 @@ int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf
     HIPCHK(c, hipMemcpyAsync(c->rj_leaf, leaf, NB * TW * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, NB * TW * RJ_ND * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
+    c->rj_tm_valid = false;                   // (teacher-forced move: the reference's full evaluation, no resident templates)
     if ((r = rj_launch(c, RJ_MODE_BD, -1, nullptr, c->rj_change, c->rj_leaf, c->rj_birth, c->rj_u, c->rj_keep))) return r;
     if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
     if ((r = check_flags(c, false))) return r;
@@ -2814,23 +2925,33 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->step_events = true;
     c->timing = hens_timing{};
+    // resident templates (RjArgs::tm): made true once (after an upload / a parity-API move), kept true by every accepting launch,
+    // and re-evaluated from scratch every RJ_REFRESH iterations so that the rounding of a chain of +- leaf updates cannot pile up
+    constexpr int64_t RJ_REFRESH = 64;
+    const int tmode = c->rj_tm ? 0 : -1;
+    if (c->rj_tm && !c->rj_tm_valid && n_iters > 0) {
+        if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2))) return r;
+        c->rj_tm_valid = true;
+    }
     for (int64_t i = 0; i < n_iters; ++i) {
+        if (c->rj_tm && c->iter % RJ_REFRESH == RJ_REFRESH - 1)
+            if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0))) return r;
         // in-model Gaussian move on the packed leaves, then swaps + adaptation (mh.py:190-191)
-        if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+        if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tmode))) return r;
         c->rj_num_mh += 1;
         rj_cascade(c, 2 * c->iter, true);
         if (c->rj_schedule == 2) {
             // "together" (ensemble.py:414-432): ONE proposal changes a leaf in every branch of the walker; one accept test
-            if ((r = rj_launch(c, RJ_MODE_BD, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+            if ((r = rj_launch(c, RJ_MODE_BD, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->rj_tm ? 1 : -1))) return r;
         } else if (c->rj_schedule == 1) {
             // "iterate_branches" (ensemble.py:434-451, rj.py:169-388): ONE move walks through every branch - birth / death,
             // accept, update per branch - then one sweep of swaps without adaptation; its accept mask is the last branch's
             for (int b = 0; b < c->rj.nb; ++b)
-                if ((r = rj_launch(c, RJ_MODE_BD, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+                if ((r = rj_launch(c, RJ_MODE_BD, b, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->rj_tm ? 1 : -1))) return r;
         } else {
             // one branch's birth / death move (ensemble.py:988-990, "separate_branches"), then swaps without adaptation
             const int branch = rj_branch_of(c, c->iter);
-            if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))) return r;
+            if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c->rj_tm ? 1 : -1))) return r;
         }
         c->rj_num_bd += 1;
         rj_cascade(c, 2 * c->iter + 1, false);
@@ -3284,6 +3405,9 @@ int hens_pipe_connect_staged(hens_ctx* ctx) {
 
 int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out) {
     hens_ctx_impl* c = enter(ctx);
+    return pipe_regions_impl(c, out);
+}
+static int pipe_regions_impl(hens_ctx_impl* c, hens_pipe_region_table* out) {
     if (!c || !out) return fail(c, HENS_ERR_INVALID, "null argument");
     if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
     const int W = c->W, D = c->D, T = c->T, par = (int)(c->pipe.sweep & 1u);
@@ -3310,6 +3434,9 @@ int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out) {
 
 int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
     hens_ctx_impl* c = enter(ctx);
+    return pipe_stage_impl(c, stage);
+}
+static int pipe_stage_impl(hens_ctx_impl* c, int32_t stage) {
     int r = ready(c, true);
     if (r) return r;
     if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "hens_pipe_connect_staged first");
@@ -3345,6 +3472,77 @@ int hens_pipe_stage(hens_ctx* ctx, int32_t stage) {
     }
     HIPCHK(c, hipGetLastError());
     return HENS_OK;
+}
+
+// Communicator of a ladder shard.  unique_id: NCCL_UNIQUE_ID_BYTES (128) from hens_comm_unique_id on ONE rank,
+// handed to the others by the caller (torch.distributed broadcast, MPI, a file ...); every rank calls hens_comm_init with the same
+// id - the call is collective.  The context becomes a rank of the staged pipeline whose messages the library sends itself.
+int hens_comm_unique_id(void* out) {
+    RcclApi& R = rccl_api();
+    if (!R.ok) return fail(nullptr, HENS_ERR_UNSUPPORTED, "RCCL is not available: %s", R.err.c_str());
+    if (!out) return fail(nullptr, HENS_ERR_INVALID, "null argument");
+    ncclUniqueId id;
+    const ncclResult_t n = R.GetUniqueId(&id);
+    if (n != ncclSuccess) return fail(nullptr, HENS_ERR_HIP, "ncclGetUniqueId failed: %s", R.GetErrorString(n));
+    memcpy(out, &id, sizeof id);
+    return HENS_OK;
+}
+int hens_comm_init(hens_ctx* ctx, int32_t nranks, int32_t rank, const void* unique_id) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c || !unique_id) return fail(c, HENS_ERR_INVALID, "null argument");
+    RcclApi& R = rccl_api();
+    if (!R.ok) return fail(c, HENS_ERR_UNSUPPORTED, "RCCL is not available: %s", R.err.c_str());
+    if (c->comm_on) return fail(c, HENS_ERR_STATE, "the context already has a communicator");
+    int r;
+    int64_t nbytes = 0;
+    if (!c->pipe.on && (r = hens_pipe_init(ctx, nranks, rank, nullptr, &nbytes))) return r;
+    if (!c->pipe.connected && (r = hens_pipe_connect_staged(ctx))) return r;
+    if (!c->pipe.staged) return fail(c, HENS_ERR_STATE, "the context is connected to the one-sided pipeline already");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    RCCLCHK(c, R.CommInitRank(&comm, nranks, id, rank));
+    c->comm = comm;
+    c->comm_on = true;
+    return HENS_OK;
+}
+int hens_comm_destroy(hens_ctx* ctx) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (!c->comm_on) return HENS_OK;
+    (void)hipStreamSynchronize(c->stream);
+    RcclApi& R = rccl_api();
+    RCCLCHK(c, R.CommDestroy(static_cast<ncclComm_t>(c->comm)));
+    c->comm = nullptr;
+    c->comm_on = false;
+    return HENS_OK;
+}
+// dev aid / one-GPU test of the transport: `n` doubles from src to dst through ncclSend / ncclRecv to MYSELF (one grouped call on
+// the context's stream; RCCL allows a rank to send to itself inside a group)
+int hens_comm_selfsend(hens_ctx* ctx, int64_t n, const double* src_host, double* dst_host) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c || !src_host || !dst_host || n <= 0) return fail(c, HENS_ERR_INVALID, "bad argument");
+    if (!c->comm_on) return fail(c, HENS_ERR_STATE, "hens_comm_init first");
+    RcclApi& R = rccl_api();
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    double *a = nullptr, *b = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&a), (size_t)n * 8));
+    HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&b), (size_t)n * 8));
+    int rc = HENS_OK;
+    do {
+        if (hipMemcpyAsync(a, src_host, (size_t)n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail(c, HENS_ERR_HIP, "copy in"); break; }
+        (void)hipMemsetAsync(b, 0, (size_t)n * 8, c->stream);
+        ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
+        ncclResult_t e1 = R.GroupStart(), e2 = R.Send(a, (size_t)n, ncclDouble, c->pipe.rank, comm, c->stream),
+                     e3 = R.Recv(b, (size_t)n, ncclDouble, c->pipe.rank, comm, c->stream), e4 = R.GroupEnd();
+        for (ncclResult_t e : {e1, e2, e3, e4}) if (e != ncclSuccess) { rc = fail(c, HENS_ERR_HIP, "RCCL self send / recv: %s", R.GetErrorString(e)); break; }
+        if (rc) break;
+        if (hipMemcpyAsync(dst_host, b, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail(c, HENS_ERR_HIP, "copy out"); break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail(c, HENS_ERR_HIP, "stream synchronisation after the self send"); break; }
+    } while (0);
+    (void)hipFree(a); (void)hipFree(b);
+    return rc;
 }
 
 // ---- pipeline self-test --------------------------------------------------------------------------------

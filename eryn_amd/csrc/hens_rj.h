@@ -52,6 +52,17 @@ struct RjArgs {
     double fill;
     uint64_t iter, seed;
     int32_t Tl, W, rung_begin, tempered, mode, branch;
+    // Round 4: every pool row's TEMPLATE (the model's value at the ndata points, the sum over branches of the sums over leaves)
+    // stays resident in HBM, [pool rows][ndata].  A launch that accepts a proposal writes the proposal's template; the birth /
+    // death launch of hens_rj_step then needs only the ONE leaf (per branch under proposal) that is born or dies:
+    // template' = template +- leaf instead of the whole sum (~6 leaves x 500 FP64 exp / sin per walker at config 4).
+    //   tm == nullptr  no resident templates (parity API: the reference's order of operations, bit for bit)
+    //   tm_mode 0      full evaluation; the accepted proposal's template is stored (in-model move; evaluation: every row's)
+    //   tm_mode 1      birth / death by difference (production); the accepted template is stored
+    //   tm_mode 2      evaluation mode only: store every row's template, leave L / P alone (refresh after parity calls)
+    double* tm;
+    int32_t tm_mode, trace_n;               // (trace_n: waves that stamp their phases into `trace`, dev aid)
+    unsigned long long* trace;
 };
 
 // ndarray.sum(axis=-1) of v[0..n): NumPy's pairwise order (n < 8: a plain loop from 0.0; 8 <= n <= 128: eight partial
@@ -118,6 +129,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     const RjModel& M = A.M;
     const int tl = (int)(gw / A.W);
     const int RW = M.RW;
+#define RJ_TRACE(i) do { if (A.trace && gw < A.trace_n && lane == 0) A.trace[gw * 8 + (i)] = trace_stamp(); } while (0)
+    RJ_TRACE(0);
     double* cur = s_cur[wv];
     double* q = s_q[wv];
     double* leafv = s_leafv[wv];
@@ -133,8 +146,11 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     for (int b = 0; b < M.nb; ++b) mask[b] = mask_old[b] = (uint32_t)cur[M.ind_off + b];
     const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
 
+    RJ_TRACE(1);
     // ---- proposal -----------------------------------------------------------------------------------------------------
     double factors = 0.0;
+    int ch_sign[RJ_MAX_BRANCH], ch_leaf[RJ_MAX_BRANCH];      // birth / death: what changes in every branch (+1 born, -1 dies, 0 nothing)
+    for (int B = 0; B < RJ_MAX_BRANCH; ++B) { ch_sign[B] = 0; ch_leaf[B] = 0; }
     if (A.mode == RJ_MODE_MH) {
         // every active leaf of every branch moves: q = x + step (gaussian.py:96-104, 265-268; factors = 0)
         for (int i = lane; i < M.ind_off; i += 64) {
@@ -157,6 +173,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
       const int b_lo = A.branch >= 0 ? A.branch : 0, b_hi = A.branch >= 0 ? A.branch + 1 : M.nb;
       const size_t TW = (size_t)A.Tl * A.W;
       double edge = 0.0;
+      for (int B = 0; B < RJ_MAX_BRANCH; ++B) { ch_sign[B] = 0; ch_leaf[B] = 0; }
       for (int B = b_lo; B < b_hi; ++B) {
         const size_t bo = A.branch >= 0 ? 0 : (size_t)B * TW;        // teacher-forced arrays: [nbranches][Tl][W] when all branches move
         const int nold = __builtin_popcount(mask_old[B]);
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             const int cnt = __builtin_popcount(pool_bits);
             lf = cnt ? nth_set_bit(pool_bits, rj_pick(d.y, cnt)) : 0;                    // uniform over the candidates (:97-112)
         }
+        ch_sign[B] = c; ch_leaf[B] = lf;
         if (c < 0) {                                                  // death: factor +log q(leaf) (:188-197)
             mask[B] &= ~(1u << lf);
             bool in = true;
@@ -212,6 +230,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     }
     RJ_LDS_SYNC();
 
+    RJ_TRACE(2);
     // ---- log-prior over the leaf slots (ensemble.py:1189-1210): dead slots count 0.0, NumPy's sum order per branch ------
     double logp = 0.0;
     int total_leaves = 0;
@@ -242,16 +261,80 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
         }
     }
 
+    RJ_TRACE(3);
     // ---- template likelihood: lanes over the data points ------------------------------------------------------------------
     double logl;
     const bool evaluated = total_leaves > 0 && !(fabs(logp) == INFINITY);   // ensemble.py:1278-1306, 1486-1513
-    if (evaluated) {
+    // (residual / sigma as the reference divides it, tests/test_eryn.py:52-54 - unless sigma is a power of two: then the product with
+    //  its reciprocal is the same double, and eight FP64 divisions per lane and likelihood are a tenth of the launch's VALU time)
+    int sig_e = 0;
+    const bool sig_pow2 = frexp(M.sigma, &sig_e) == 0.5 && sig_e > -1000 && sig_e < 1000;
+    const double sig_inv = 1.0 / M.sigma;
+    constexpr int NPT = 4, MAXCH = 2;                        // (template points per lane and chunk; chunks a lane keeps: ndata <= 512)
+    double* tmrow = A.tm ? A.tm + (size_t)A.loc[gw] * M.ndata : nullptr;
+    const bool by_diff = A.tm && A.tm_mode == 1 && A.mode == RJ_MODE_BD && M.ndata <= 64 * NPT * MAXCH;
+    double tmk[MAXCH][NPT];                                  // the proposal's template at this lane's points (stored on acceptance)
+#pragma unroll
+    for (int ch = 0; ch < MAXCH; ++ch)
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) tmk[ch][k] = 0.0;
+    if (evaluated && by_diff) {
+        // template' = template + (born leaf) - (dead leaf) per branch under proposal: one leaf's values instead of every leaf's
+        double acc = 0.0;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch) {
+            const int i0 = ch * 64 * NPT;
+            if (i0 < M.ndata) {
+                double ti[NPT];
+#pragma unroll
+                for (int k = 0; k < NPT; ++k) {
+                    const int i = i0 + k * 64 + lane;
+                    ti[k] = i < M.ndata ? A.tdata[i] : 0.0;
+                    tmk[ch][k] = i < M.ndata ? tmrow[i] : 0.0;
+                }
+                for (int b = 0; b < M.nb; ++b) {
+                    if (ch_sign[b] == 0) continue;
+                    const int n = ch_leaf[b];
+                    const double* src = ch_sign[b] > 0 ? q : cur;             // (a dead leaf's coordinates stay in the record)
+                    const double a = src[M.off[b] + n * RJ_ND], bb = src[M.off[b] + n * RJ_ND + 1], c = src[M.off[b] + n * RJ_ND + 2];
+                    const double sg = ch_sign[b] > 0 ? 1.0 : -1.0;
+                    if (M.kind[b] == RJ_KIND_PULSE) {
+                        const double inv = 1.0 / (2 * (c * c));
+#pragma unroll
+                        for (int k = 0; k < NPT; ++k) {
+                            const double dx = ti[k] - bb;
+                            tmk[ch][k] += sg * (a * exp(-(dx * dx) * inv));
+                        }
+                    } else {
+                        const double w = 2 * M_PI * bb;
+#pragma unroll
+                        for (int k = 0; k < NPT; ++k) tmk[ch][k] += sg * (a * sin(w * ti[k] + c));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NPT; ++k) {
+                    const int i = i0 + k * 64 + lane;
+                    if (i < M.ndata) {
+                        const double d0 = tmk[ch][k] - A.ydata[i];
+                        const double r = sig_pow2 ? d0 * sig_inv : d0 / M.sigma;
+                        acc += r * r;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        logl = -0.5 * acc;
+        if (logl != logl) {
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+    } else if (evaluated || (A.tm && A.mode == RJ_MODE_EVAL && total_leaves > 0)) {     // (an evaluation always leaves a true template behind)
         double acc = 0.0;
         // Leaves outside, NPT data points per lane inside: a leaf's three parameters are read (LDS) and its 1 / (2 c^2)
         // formed once per chunk instead of once per point (the FP64 division was a third of the work per template
         // point).  Per point the leaves are still summed branch by branch in ascending slot order, and the lane's points in
         // ascending order, like the reference's NumPy sums over the leaf and the data axes.
-        constexpr int NPT = 4;
         for (int i0 = 0; i0 < M.ndata; i0 += 64 * NPT) {
             double ti[NPT], tm[NPT];
 #pragma unroll
@@ -290,9 +373,19 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             for (int k = 0; k < NPT; ++k) {
                 const int i = i0 + k * 64 + lane;
                 if (i < M.ndata) {
-                    const double r = (tm[k] - A.ydata[i]) / M.sigma;
+                    const double d0 = tm[k] - A.ydata[i];
+                    const double r = sig_pow2 ? d0 * sig_inv : d0 / M.sigma;
                     acc += r * r;
                 }
+            }
+            if (A.tm) {                          // (kept for the store below; chunk index is uniform: static register indices)
+                const int ch = i0 / (64 * NPT);
+#pragma unroll
+                for (int c2 = 0; c2 < MAXCH; ++c2)
+                    if (c2 == ch) {
+#pragma unroll
+                        for (int k = 0; k < NPT; ++k) tmk[c2][k] = tm[k];
+                    }
             }
         }
 #pragma unroll
@@ -302,13 +395,26 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
             logl = -1e300;
             atomicOr(A.flags, FLAG_NAN_LOGL);
         }
+        if (!evaluated) logl = A.fill;
     } else {
-        logl = A.fill;
+        logl = A.fill;                           // (no leaves: the template that goes with it is all zeros)
     }
+    auto store_template = [&]() {
+        if (!tmrow || M.ndata > 64 * NPT * MAXCH) return;
+#pragma unroll
+        for (int ch = 0; ch < MAXCH; ++ch)
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) {
+                const int i = ch * 64 * NPT + k * 64 + lane;
+                if (i < M.ndata) tmrow[i] = total_leaves > 0 ? tmk[ch][k] : 0.0;
+            }
+    };
 
+    RJ_TRACE(4);
     // ---- evaluation / accept + update ----------------------------------------------------------------------------------------
     if (A.mode == RJ_MODE_EVAL) {
-        if (lane == 0) {
+        store_template();
+        if (lane == 0 && A.tm_mode != 2) {
             A.L[gw] = logl;
             A.P[gw] = logp;
         }
@@ -337,6 +443,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     }
     const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
     if (keep) {                                                        // Move.update (move.py:472-703)
+        store_template();
         for (int i = lane; i < RW; i += 64) row[i] = q[i];
         if (lane == 0) {
             A.L[gw] = logl;
@@ -345,6 +452,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
         }
     }
     if (lane == 0 && A.keep_out) A.keep_out[gw] = keep ? 1 : 0;
+    RJ_TRACE(5);
+#undef RJ_TRACE
 #undef RJ_LDS_SYNC
 }
 

@@ -351,6 +351,29 @@ class HipEnsemble:
         check(self.lib.hens_get_mh_counters(self.ctx, ptr(acc), C.byref(n)), self.ctx)
         return dict(accepted=acc, num_proposals=int(n.value))
 
+    # -- RCCL neighbour exchange inside the library (include/hipensemble.h: hens_comm_*) ----------------
+    def comm_unique_id(self):
+        """128 bytes from ncclGetUniqueId (call on ONE rank, hand the bytes to the others)."""
+        buf = (C.c_ubyte * 128)()
+        check(self.lib.hens_comm_unique_id(C.cast(buf, C.c_void_p)), None)
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        """Collective: this shard becomes rank `rank` of `nranks`; ``step(n)`` then sends the neighbour messages itself."""
+        if len(unique_id) != 128:
+            raise ValueError("unique_id: 128 bytes from comm_unique_id()")
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        check(self.lib.hens_comm_init(self.ctx, int(nranks), int(rank), C.cast(buf, C.c_void_p)), self.ctx)
+
+    def comm_destroy(self):
+        check(self.lib.hens_comm_destroy(self.ctx), self.ctx)
+
+    def comm_selfsend(self, values):
+        src = np.ascontiguousarray(values, dtype=np.float64)
+        dst = np.empty_like(src)
+        check(self.lib.hens_comm_selfsend(self.ctx, src.size, ptr(src), ptr(dst)), self.ctx)
+        return dst
+
     # -- ladder pipeline (include/hipensemble.h: hens_pipe_*) ------------------------------------------
     def pipe_init(self, nranks, rank):
         """Allocate this shard's mailbox; returns the 128-byte blob of HIP IPC handles (mailbox, walker pool)."""

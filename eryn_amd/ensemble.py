@@ -296,7 +296,30 @@ class EnsembleSampler:
             # (thin_by > 1: ONE device call; the counters in front of the last sub-iteration stay on the device until the
             #  download below - no split call, no counter read in between)
             mid_acc, mid_mh_acc = prev["accepted"], None if prev_mh is None else prev_mh["accepted"]
-            if thin_by > 1 and hasattr(eng, "step_marked"):
+            tuned_accepted = None
+            if tune:
+                # the reference calls move.tune(state, accepted_out) after EVERY proposal with that proposal's own mask
+                # (ensemble.py:969-984): a host hook per proposal, so the device steps one iteration at a time here and the
+                # move that ran is read off the counters
+                last, last_mh = prev, prev_mh
+                for _sub in range(thin_by):
+                    tuned_accepted = np.zeros_like(prev["accepted"])   # (re-zeroed every sub-iteration, ensemble.py:968)
+                    if _sub == thin_by - 1:
+                        mid_acc = last["accepted"]
+                        mid_mh_acc = None if last_mh is None else last_mh["accepted"]
+                    for _rep in range(reps):
+                        eng.step(1)
+                        c1 = eng.counters()
+                        cm1 = eng.mh_counters() if mh_move is not None else None
+                        ran_stretch = c1["num_proposals"] > last["num_proposals"]
+                        out = c1["accepted"] - last["accepted"] if ran_stretch else cm1["accepted"] - last_mh["accepted"]
+                        xi, Li, Pi, bi = eng.download()
+                        st_i = State({name: xi[:, :, None, :]}, inds={name: inds}, log_like=Li, log_prior=Pi,
+                                     betas=None if tc is None else bi, random_state=self.philox_checkpoint())
+                        (st_move if ran_stretch else mh_move).tune(st_i, out)
+                        tuned_accepted += out
+                        last, last_mh = c1, cm1
+            elif thin_by > 1 and hasattr(eng, "step_marked"):
                 eng.step_marked((thin_by - 1) * reps, reps)
             else:
                 if thin_by > 1:
@@ -306,7 +329,7 @@ class EnsembleSampler:
                 eng.step(reps)
             x, L, P, betas = eng.download()
             c = eng.counters()
-            if thin_by > 1 and hasattr(eng, "step_marked"):
+            if not tune and thin_by > 1 and hasattr(eng, "step_marked"):
                 mid_acc, mid_mh_acc = eng.marked_counters()
             accepted = c["accepted"] - mid_acc
             if st_move is not None:
@@ -327,10 +350,6 @@ class EnsembleSampler:
             prev = c
             state = State({name: x[:, :, None, :]}, inds={name: inds}, log_like=L, log_prior=P,
                           betas=None if tc is None else betas, random_state=self.philox_checkpoint())
-            if tune:                               # (once per stored step: the per-repeat masks stay on the device)
-                for m in (st_move, mh_move):
-                    if m is not None:
-                        m.tune(state, accepted)
             if store:
                 self.backend.save_step(state, accepted, swaps_accepted=swaps)
             self._previous_state = state

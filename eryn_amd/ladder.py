@@ -233,16 +233,25 @@ class LadderPipeline:
         takes part in the collective and all of them raise together."""
         import os
         import socket
+        unique = True                 # does `dev` identify the physical GPU?
         try:
             import torch
             props = torch.cuda.get_device_properties(int(device_id))
-            dev = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or device_id)
+            dev = getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None)
         except Exception:                             # noqa: BLE001
-            dev = str(device_id)
+            dev = None
+        if dev is None:
+            # no physical id from this torch build: the ordinal under the visibility masks (one-rank-per-GPU launchers mask
+            # every rank down to "its" GPU, which is then ordinal 0 everywhere) - good enough to warn, not to refuse
+            unique = False
+            dev = (device_id, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"), os.environ.get("CUDA_VISIBLE_DEVICES"))
         ids = [None] * self.nranks
-        dist.all_gather_object(ids, (socket.gethostname(), dev), group=group)
+        dist.all_gather_object(ids, (socket.gethostname(), str(dev), unique), group=group)
         dry_run = dist.get_backend(group) == "gloo" or os.environ.get("HENS_PIPE_SHARED_GPU") == "1"
-        if len(set(ids)) < self.nranks and not dry_run:
+        if len(set(ids)) < self.nranks and not dry_run and not all(u for _, _, u in ids):
+            import warnings
+            warnings.warn(f"ladder pipeline: cannot tell whether ranks share a GPU (no device uuid / PCI id from torch): {ids}")
+        elif len(set(ids)) < self.nranks and not dry_run:
             raise RuntimeError(f"ladder pipeline: ranks share a GPU ({ids}); one rank per GPU is required outside the dry-run "
                                f"backend (gloo) / HENS_PIPE_SHARED_GPU=1")
 
@@ -364,3 +373,29 @@ class StagedPipeline:
                 else:
                     self.dist.all_reduce(cnt, group=self.group)
             self._t(r.cnt_in, nc, "<i4").copy_(cnt)
+
+
+class RcclPipeline:
+    """The staged protocol with the messages sent by the LIBRARY (``hens_comm_init``): grouped ncclSend / ncclRecv between ladder
+    neighbours and one all-reduce of the swap counts per sweep, enqueued between the stage launches on the context's stream -
+    ``step(n)`` is one C call for n iterations, no Python in the loop (:class:`StagedPipeline` orders the same messages from the
+    host through ``torch.distributed`` and stays for the CPU tests' gloo backend).  ``dist`` is used once: to hand rank 0's
+    ncclUniqueId to the other ranks."""
+
+    def __init__(self, engine, rank, nranks, dist=None, group=None):
+        self.e, self.rank, self.nranks = engine, int(rank), int(nranks)
+        uid = [engine.comm_unique_id() if self.rank == 0 else None]
+        if self.nranks > 1:
+            if dist is None:
+                raise ValueError("nranks > 1 needs a torch.distributed group to share the communicator's id")
+            dist.broadcast_object_list(uid, src=0, group=group)
+        engine.comm_init(self.nranks, self.rank, uid[0])
+
+    def step(self, n_iters=1):
+        self.e.step(int(n_iters))
+
+    def synchronize(self):
+        self.e.synchronize()
+
+    def close(self):
+        self.e.comm_destroy()

@@ -312,6 +312,18 @@ typedef struct hens_pipe_region_table {
     void* stream;
 } hens_pipe_region_table;
 int hens_pipe_connect_staged(hens_ctx* ctx);
+/* ---- The same with the messages sent by the LIBRARY over RCCL (hens_comm_init / hens_comm_destroy) -------------
+ * hens_comm_unique_id: ncclGetUniqueId on ONE rank (128 bytes out); the caller hands the id to the other ranks.
+ * hens_comm_init: collective; every rank of the ladder calls it with the same id.  The context becomes a rank of the staged
+ *   pipeline (hens_pipe_init + hens_pipe_connect_staged if not done yet) whose neighbour exchanges - grouped ncclSend / ncclRecv
+ *   with the ladder neighbours, one all-reduce of the swap counts per sweep - the library enqueues itself on the context's stream:
+ *   hens_step(ctx, n) is then ONE call for n iterations (the reference has no distributed path: tempering.py:484-561 is the
+ *   cascade being sharded).  librccl.so.1 is dlopen()ed (in a PyTorch-ROCm process: torch's own copy).
+ * hens_comm_selfsend: dev aid - n doubles through ncclSend / ncclRecv to the calling rank itself (a one-GPU test of the transport). */
+int hens_comm_unique_id(void* unique_id_out /* 128 bytes */);
+int hens_comm_init(hens_ctx* ctx, int32_t nranks, int32_t rank, const void* unique_id /* 128 bytes */);
+int hens_comm_destroy(hens_ctx* ctx);
+int hens_comm_selfsend(hens_ctx* ctx, int64_t n, const double* src_host, double* dst_host);
 int hens_pipe_regions(hens_ctx* ctx, hens_pipe_region_table* out);
 int hens_pipe_stage(hens_ctx* ctx, int32_t stage);
 

@@ -124,6 +124,22 @@ def main():
         dist.barrier()
         e.close()
         dist.destroy_process_group()
+    elif mode == "rccl1":
+        # the library's own RCCL transport (hens_comm_init) with ONE rank - what a one-GPU box can run of it: the communicator, a
+        # ncclSend / ncclRecv round trip to myself, and hens_step(n) as one call through the staged protocol's three stages
+        T, W, D, iters = map(int, sys.argv[2:6])
+        from eryn_amd.ladder import RcclPipeline
+        e = make(T, W, D, delay=0)
+        pipe = RcclPipeline(e, 0, 1)
+        v = np.random.RandomState(1).randn(100003)
+        back = e.comm_selfsend(v)
+        assert np.array_equal(back, v), "ncclSend / ncclRecv to myself did not return the data"
+        for n in (iters // 2, iters - iters // 2):
+            pipe.step(n)
+            e.synchronize()
+        np.savez(sys.argv[6], **snapshot(e))
+        pipe.close()
+        e.close()
     elif mode == "replay":
         # the sharded production path held to the oracle: the draws are a pure function of (seed, iteration, global
         # rung, walker), so a whole-ladder context exports them and the oracle replays the pipeline's iterations

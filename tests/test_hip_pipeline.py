@@ -151,6 +151,19 @@ def test_staged_transport_matches_single_context(tmp_path, world, T, W, D, iters
     _compare(ref, got)
 
 
+@pytest.mark.parametrize("T,W,D,iters,model", [(4, 256, 32, 8, "gauss"), (4, 256, 128, 8, "rosen_mix")])
+def test_rccl_transport_inside_the_library_world_size_one(tmp_path, T, W, D, iters, model):
+    """hens_comm_init / hens_step on a staged context: librccl loaded by the library, a communicator of one rank, a
+    ncclSend / ncclRecv round trip to itself, and n iterations as ONE library call through the staged protocol - bit-identical to
+    the unsharded ladder.  (Two RCCL ranks cannot share one GPU; the protocol between ranks is pinned by the gloo-backed
+    StagedPipeline tests above, which drive the same three stages.)"""
+    ref = _single(tmp_path, T, W, D, iters, model=model)
+    out = tmp_path / "rccl1.npz"
+    r = _run(["rccl1", T, W, D, iters, out], model=model)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _compare(ref, np.load(out))
+
+
 def test_pipe_selftest_helper_processes(tmp_path):
     """hens_pipe_selftest (what LadderPipeline runs in throw-away processes before connecting): three ranks put into
     and pull from their neighbours through HIP IPC; a rank whose neighbour never shows up fails instead of hanging."""

@@ -282,3 +282,35 @@ def test_philox_thinned_accept_mask_is_the_last_sub_iterations(mix):
         assert np.array_equal(got[k], masks[k * thin + thin - 1]), f"stored step {k}"
     assert any(m.any() for m in got)
     assert np.array_equal(a.get_chain()["model_0"][thin - 1::thin], b.get_chain()["model_0"])
+
+
+def test_philox_tune_hook_is_called_per_proposal_with_that_moves_own_mask():
+    """ensemble.py:969-984: `move.tune(state, accepted_out)` after EVERY proposal, with that proposal's mask - also with
+    rng="philox", thin_by > 1, num_repeats_in_model > 1 and two moves in the mix; tuning changes nothing about the chain."""
+    from eryn_amd.moves import GaussianMove, StretchMove
+    T, W, D, thin, reps, n = 4, 256, 8, 2, 3, 4
+    rs = np.random.RandomState(5)
+    A = rs.randn(D, D)
+    mu, invcov = 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    x0 = np.random.RandomState(2).randn(T, W, D)
+
+    def sampler():
+        moves = [(StretchMove(), 0.5), (GaussianMove({"model_0": 0.05 * np.eye(D)}), 0.5)]
+        return EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=11, moves=moves,
+                               num_repeats_in_model=reps, tempering_kwargs=dict(ntemps=T))
+
+    a = sampler()
+    plain = [State(st, copy=True) for st in a.sample(x0, iterations=n, thin_by=thin, store=True)]
+    b = sampler()
+    calls = {0: [], 1: []}
+    for k, m in enumerate(b.moves):
+        m.tune = (lambda kk: (lambda state, accepted: calls[kk].append((accepted.copy(), state.log_like.copy()))))(k)
+    tuned = [State(st, copy=True) for st in b.sample(x0, iterations=n, thin_by=thin, store=True, tune=True)]
+    assert len(calls[0]) + len(calls[1]) == n * thin * reps and len(calls[0]) > 0 and len(calls[1]) > 0
+    for k, m in enumerate(b.moves):                      # every move saw exactly its own proposals' masks
+        assert len(calls[k]) == m.num_proposals
+        assert np.array_equal(sum(c[0] for c in calls[k]), m.accepted)
+    for u, v in zip(plain, tuned):                       # the hook is an observer: same chain, same stored masks
+        assert np.array_equal(u.branches["model_0"].coords, v.branches["model_0"].coords) and np.array_equal(u.log_like, v.log_like)
+    assert np.array_equal(a.backend.accepted, b.backend.accepted)
