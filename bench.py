@@ -14,9 +14,13 @@ N > 1: one process per GPU over RCCL (the driver starts them with torch.distribu
        adaptation schedules are timed: the reference's (``value``) and the pipeline's one-sweep-late schedule
        (``delayed_adaptation``); ``weak_base`` is one such shard alone on one GPU, the N = 1 point of the same series.
 
-W untimed warm-up steps, then BLOCKS (5) timed blocks of exactly K steps each, every block bracketed by a barrier +
+W untimed warm-up steps, then BLOCKS timed blocks of exactly K steps each, every block bracketed by a barrier +
 synchronize on both sides and reduced with MAX over ranks; ``ms_per_step`` / ``value`` come from the MEDIAN block
-(``block_ms`` lists all of them).  Prints ONE JSON line (rank 0).
+(``block_ms`` lists all of them).  BLOCKS = max(5, ceil(2000 / K)), at most 120: SURVEY 8d's protocol times >= 2000 iterations
+(median of 5 at the default K = 2000); with short blocks - the driver runs K = 20, W = 5 - five blocks would all fall into the
+first 2 ms after the GPU leaves its idle clocks, where an iteration runs ~3 % slower than 10 ms later (tools/block_series.py,
+profiles/r04b_block_series.txt: 368 -> 357 us per block over the first 25 blocks).  ``cold_blocks`` reports the median of
+the FIRST five blocks beside the headline.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -34,7 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BLOCKS = 5
+BLOCKS = 5                     # set per run: blocks_for(K)
+TIMED_ITERATIONS = 2000        # time >= 2000 iterations
 METRIC = "walker-steps/sec (ntemps x nwalkers x iters/s), Gaussian logL"
 
 
@@ -218,6 +223,16 @@ def measured_copy_bandwidth():
         return None
 
 
+def blocks_for(steps):
+    return int(max(5, min(120, -(-TIMED_ITERATIONS // max(int(steps), 1)))))
+
+
+def cold_blocks(times, steps, units):
+    """The first five blocks of the run (a GPU that has just left its idle clocks) beside the median of all blocks."""
+    dt = float(np.median(times[:5]))
+    return {"ms_per_step": dt / steps * 1e3, "value": units * steps / dt, "blocks": 5}
+
+
 def timed_blocks(step, sync, steps, dist=None, device=None):
     """BLOCKS blocks of exactly `steps` steps; per block MAX over ranks.  Every rank runs the same collectives
     whether or not its own stepping raised (a flag wait that timed out), and learns whether ALL ranks are fine."""
@@ -289,7 +304,8 @@ def time_other_shape(T, W, D, steps, warmup, rosen_mix=False):
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
     whole_path(roof, T, W, D, f_sw, acc, value)
     return {"shape": f"ntemps={T}, nwalkers={W}, ndim={D}, " + ("Rosenbrock, StretchMove + GaussianMove 50/50" if rosen_mix else "dense Gaussian, StretchMove") + " + adaptive PT",
-            "ms_per_step": dt / steps * 1e3, "value": value, "block_ms": [t * 1e3 for t in times], "stretch_acceptance": acc,
+            "ms_per_step": dt / steps * 1e3, "value": value, "block_ms": [t * 1e3 for t in times],
+            "cold_blocks": cold_blocks(times, steps, T * W), "stretch_acceptance": acc,
             "swap_fraction": f_sw, "whole_path_frac": roof["whole_path_frac"], "whole_path_frac_moved": roof["whole_path_frac_moved"],
             "kernels": [{k: v for k, v in kk.items() if k in ("kernel", "launches_per_iteration", "avg_launch_us", "frac", "frac_moved", "frac_traffic")}
                         for kk in roof["kernels"]]}
@@ -334,6 +350,7 @@ def run_single(args):
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "block_ms": [t * 1e3 for t in times], "timing": f"median of {BLOCKS} blocks of {args.steps} steps",
+        "cold_blocks": cold_blocks(times, args.steps, T * W),
         "config": {"workload": f"{'config 2' if (T, W, D) == (16, 4096, 32) else 'custom shape'}: ntemps={T}, nwalkers={W}, ndim={D} dense-covariance Gaussian, box prior +-50, "
                                f"StretchMove(a=2)+adaptive PT, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
                    "parallelism": "single GPU", "stretch_acceptance": acc, "swap_fraction": f_sw},
@@ -635,7 +652,8 @@ def run_sharded(args):
 
     def summary(times, **kw):
         sdt = float(np.median(times))
-        out_ = {"value": T * W * args.steps / sdt, "ms_per_step": sdt / args.steps * 1e3, "block_ms": [t * 1e3 for t in times]}
+        out_ = {"value": T * W * args.steps / sdt, "ms_per_step": sdt / args.steps * 1e3, "block_ms": [t * 1e3 for t in times],
+                "cold_blocks": cold_blocks(times, args.steps, T * W)}
         if base:                                   # weak scaling: one shard alone on one GPU / the same shard as a rank
             out_["efficiency"] = base["ms_per_step"] / out_["ms_per_step"]
         out_.update(kw)
@@ -655,12 +673,6 @@ def run_sharded(args):
                 waits = {"adaptation_delay_0": wait_breakdown(0), "adaptation_delay_1": wait_breakdown(1),
                          "unit": "us per iteration and rank, summed over the waiting workgroups' lead threads (a separate pass "
                                  "with HENS_PIPE_STATS=1; the timed passes run without the statistics)"}
-        # the transport north_star names, timed in the same run: RCCL point-to-point between ladder neighbours
-        if not args.no_staged:
-            sr = staged_run()
-            if sr is not None:
-                staged = summary(sr[1], transport=STAGED, schedule="the reference's (adaptation_delay=0)")
-                sr[0].close()
     if result is None:
         if backend != "nccl":
             raise SystemExit("bench.py: the ladder pipeline did not come up in this dry run (ranks that share ONE GPU can "
@@ -713,8 +725,6 @@ def run_sharded(args):
             out["efficiency_definition"] = "weak_base.ms_per_step / ms_per_step: one shard alone on one GPU against the same shard as a rank"
         if delayed:
             out["delayed_adaptation"] = delayed
-        if staged:
-            out["rccl_neighbour"] = staged
         if waits:
             out["rank_waits"] = waits
         if base:
@@ -724,6 +734,30 @@ def run_sharded(args):
             out["cpu_baseline"]["sample"] += " = one GPU's shard as a ladder of its own"
     eng.close()
     dist.barrier()
+    # The transport north_star names, timed in the same run as the LAST leg: RCCL point-to-point between ladder neighbours,
+    # enqueued by the library (hens_comm_init).  It has never run between physical GPUs (a one-GPU box cannot host two RCCL ranks),
+    # so a watchdog stands behind it: if the leg does not finish, rank 0 prints the line measured so far and every rank leaves.
+    if mode == "pipeline" and result is not None and not args.no_staged:
+        import threading
+        limit = float(os.environ.get("BENCH_STAGED_TIMEOUT_S", "120"))
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out["rccl_neighbour"] = {"error": f"the RCCL neighbour-exchange leg did not finish within {limit:.0f} s; the line above it is complete"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        dog.start()
+        sr = staged_run()
+        dog.cancel()
+        if sr is not None:
+            staged = summary(sr[1], transport=STAGED, schedule="the reference's (adaptation_delay=0)")
+            sr[0].close()
+            if out is not None:
+                out["rccl_neighbour"] = staged
+        dist.barrier()
     dist.destroy_process_group()
     return out
 
@@ -752,16 +786,19 @@ def main():
     ap.add_argument("--no-waits", action="store_true", help="N > 1: skip the per-rank wait breakdown pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
+    global BLOCKS
     world = int(os.environ.get("WORLD_SIZE", "0"))
     n = max(args.gpus, world, 1)
     if args.workload == "cfg4":
         if n > 1:
             raise SystemExit("bench.py --workload cfg4 is a single-GPU workload")
         args.steps = args.steps or 200
+        BLOCKS = blocks_for(args.steps)
         print(json.dumps(run_cfg4(args)), flush=True)
         return
     if args.workload == "cfg5" and n == 1:
         args.steps = args.steps or 500
+        BLOCKS = blocks_for(args.steps)
         print(json.dumps(run_cfg5(args)), flush=True)
         return
     if n > 1 and world == 0:
@@ -783,12 +820,14 @@ def main():
         else:
             args.ntemps, args.nwalkers, args.ndim = args.ntemps or 16 * n, args.nwalkers or 4096, args.ndim or 32
             args.steps = args.steps or 2000
+        BLOCKS = blocks_for(args.steps)
         out = run_sharded(args)
     else:
         args.ntemps = args.ntemps or 16
         args.nwalkers = args.nwalkers or 4096
         args.ndim = args.ndim or 32
         args.steps = args.steps or 2000
+        BLOCKS = blocks_for(args.steps)
         out = run_single(args)
     if out is not None:
         print(json.dumps(out), flush=True)

@@ -113,6 +113,7 @@ SIGNATURES = {
     "hens_get_iteration": (C.c_int, [_P, _P]),
     "hens_set_iteration": (C.c_int, [_P, C.c_int64]),
     "hens_set_nsplits": (C.c_int, [_P, C.c_int32]),
+    "hens_set_stretch_scale": (C.c_int, [_P, C.c_double]),
     "hens_debug_draws": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hens_version": (C.c_char_p, []),
     "hens_device_count": (C.c_int, []),

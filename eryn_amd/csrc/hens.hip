@@ -2215,6 +2215,18 @@ static HostLikeArgs hostlike_args(hens_ctx_impl* c, int32_t split) {
     return h;
 }
 
+// Move.a of the reference's StretchMove is a plain attribute that a tuning hook may change between proposals
+// (utils/updates.py:130-175 mutates move.a; stretch.py:37,129-132 reads it per proposal): the scale of every LATER proposal.
+int hens_set_stretch_scale(hens_ctx* ctx, double a) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (!(a > 1.0) || !(a < INFINITY)) return fail(c, HENS_ERR_INVALID, "stretch scale a must be finite and > 1");
+    if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
+    c->cfg.a = a;                              // (every launch reads it from the context when it is built)
+    c->win_count = 0;                          // (planned draws of the sharded / staged paths were made with the old scale)
+    return HENS_OK;
+}
+
 int hens_set_nsplits(hens_ctx* ctx, int32_t nsplits) {
     hens_ctx_impl* c = enter(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");

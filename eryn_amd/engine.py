@@ -64,6 +64,7 @@ class HipEnsemble:
                          fill_value=float(fill_value), adaptation_lag=float(adaptation_lag),
                          adaptation_time=float(adaptation_time), seed=int(seed) & (2**64 - 1))
         self.tempered = bool(tempered)
+        self.a = float(a)
         self.ctx = C.c_void_p()
         code = self.lib.hens_create(C.byref(cfg), C.byref(self.ctx))
         if code != _lib.HENS_OK:
@@ -88,6 +89,11 @@ class HipEnsemble:
         out = np.full(a.shape[:-1] + (self.RW,), fill, dtype=np.float64)
         out[..., :self.D] = a
         return out
+
+    def set_stretch_scale(self, a):
+        """``StretchMove.a`` for every later proposal (the reference's tuning hook mutates it, utils/updates.py:130-175)."""
+        check(self.lib.hens_set_stretch_scale(self.ctx, float(a)), self.ctx)
+        self.a = float(a)
 
     def set_periodic(self, period):
         """Periods of the periodic parameters, ``[ndim]`` (0 = not periodic), or None for none: the ``periodic``

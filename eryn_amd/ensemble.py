@@ -285,6 +285,8 @@ class EnsembleSampler:
                                    (pers[0] is not None and pers[1] is not None and np.array_equal(pers[0], pers[1]))):
             raise NotImplementedError("rng='philox': the moves of a mix must share their periodic parameters")
         eng.set_periodic(pers[0] if pers else None)
+        if st_move is not None and eng.a != float(st_move.a):
+            eng.set_stretch_scale(st_move.a)
         prev = eng.counters()
         prev_mh = eng.mh_counters() if mh_move is not None else None
         inds = state.branches[name].inds
@@ -317,6 +319,8 @@ class EnsembleSampler:
                         st_i = State({name: xi[:, :, None, :]}, inds={name: inds}, log_like=Li, log_prior=Pi,
                                      betas=None if tc is None else bi, random_state=self.philox_checkpoint())
                         (st_move if ran_stretch else mh_move).tune(st_i, out)
+                        if st_move is not None and eng.a != float(st_move.a):      # (the hook may retune the stretch scale)
+                            eng.set_stretch_scale(st_move.a)
                         tuned_accepted += out
                         last, last_mh = c1, cm1
             elif thin_by > 1 and hasattr(eng, "step_marked"):

@@ -50,6 +50,8 @@ class StretchMove(DeviceMove):
         eng = self._ensure_engine(T, W, D)
         self._apply_periodic(eng, name, D)
         self._upload_if_needed(eng, state, br)
+        if getattr(eng, "a", self.a) != float(self.a):                  # (a tuning hook changed move.a: stretch.py:37 reads it per proposal)
+            eng.set_stretch_scale(self.a)
         if getattr(eng, "nsplits", 2) != self.nsplits:                 # (the context's parity API defaults to two sets)
             eng.set_nsplits(self.nsplits)
 

@@ -172,3 +172,30 @@ def test_rosenbrock_likelihood(T, W, D):
     assert pu.run_parity(o, eng, 5, teacher_forced=True, stats=stats) == 0
     assert 0.0 < o.accepted.mean() / o.num_proposals < 0.6
     eng.close()
+
+
+def test_stretch_scale_can_change_between_proposals():
+    """StretchMove.a is a plain attribute in the reference (stretch.py:37, read per proposal at :129-132) and its tuning hook
+    mutates it (utils/updates.py:130-175): hens_set_stretch_scale.  Teacher-forced against the oracle with a = 2, then 3, then
+    1.5; and hens_step's Philox iterations replayed through the oracle with the scale they ran at."""
+    from tests import replay_utils as ru
+    T, W, D = 4, 512, 32
+    o, mu, invcov = pu.make_oracle(T, W, D, box=50.0)
+    eng = pu.make_engine(o, mu, invcov)
+    for a in (2.0, 3.0, 1.5):
+        o.a = a
+        eng.set_stretch_scale(a)
+        assert pu.run_parity(o, eng, 2, teacher_forced=True) == 0
+    eng.upload(o.x, o.L, o.P, o.betas)
+    st = ru.OracleState(o.x, o.L, o.P, o.betas, time=o.time)
+    eng.set_adapt_time(o.time)
+    for a in (2.5, 1.7):
+        eng.set_stretch_scale(a)
+        it0 = eng.iteration()
+        eng.step(2)
+        ru.replay(eng, st, it0, 2, lambda q: orc.gaussian_log_like(q, mu, invcov), o.lo, o.hi, a=a)
+    x, L, P, betas = eng.download()
+    ru.assert_state_equal(st, x, L, P, betas, what="hens_step after hens_set_stretch_scale")
+    with pytest.raises(ValueError):
+        eng.set_stretch_scale(1.0)
+    eng.close()
