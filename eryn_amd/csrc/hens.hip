@@ -309,7 +309,7 @@ int dim_active(const hens_ctx_impl* c) { return c->cfg.ndim_active ? c->cfg.ndim
 size_t rec_per_iter(const hens_ctx_impl* c) { return c->label_cb ? (size_t)(c->W / c->label_cb) * TILE : 0; }
 
 int plan_threads(const hens_ctx_impl* c) {
-    static const int cap = getenv("HENS_PLAN_THREADS") ? atoi(getenv("HENS_PLAN_THREADS")) : 1024;
+    constexpr int cap = 1024;
     return std::min(cap, std::max(64, c->NP2 / 4));
 }
 size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)6 * c->W + 16; }
@@ -561,8 +561,7 @@ void flush_adapt(hens_ctx_impl* c) {
 // it.  Measured at cfg 2: 31.2 vs 32.4 us per iteration; on a pipeline rank (the counts live in uncached mailbox
 // memory, one reader instead of hundreds) 108 vs 126 us at 64 rungs, 213 vs 288 us at 128 rungs.
 int fold_mode(const hens_ctx_impl*) {
-    static const int forced = getenv("HENS_FOLD_MODE") ? atoi(getenv("HENS_FOLD_MODE")) : 0;
-    return forced == 1 ? 1 : 2;
+    return 2;
 }
 
 // can the pending adaptation ride in the next split-0 stretch launch?
@@ -654,14 +653,13 @@ PtArgs pt_args(hens_ctx_impl* c, const int32_t* colslot, bool sharded) {
 // ---- ladder pipeline ------------------------------------------------------------------------------
 
 bool pipe_publish_fused(const hens_ctx_impl* c) {
-    static const bool off = getenv("HENS_PIPE_SEPARATE_PUB") != nullptr;     // A/B knob
-    return !off && fast_path(c);
+    return fast_path(c);
 }
 
 // adaptation_delay = 1 leaves a whole iteration before a sweep's counts are needed: the adapting workgroup of the
 // next iteration's first launch reduces and publishes them, and the walk kernel needs no collector at all
 bool pipe_counts_in_stretch(const hens_ctx_impl* c) {
-    static const bool off = getenv("HENS_PIPE_COUNT_TAIL") != nullptr;       // A/B knob
+    constexpr bool off = false;
     if (c->pipe.fused) return false;             // (the fused iteration publishes its counts its own way: pipe_fused_counts)
     if (off || !pipe_active(c) || c->pipe.staged || c->cfg.adaptation_delay != 1 || !fast_path(c)) return false;
     if (fold_mode(c) != 2 || fast_nw(c->D) < 2) return false;
@@ -673,8 +671,7 @@ int pipe_acc_rows(const hens_ctx_impl* c) { return 8 * acc_row_groups(c->Tl + (p
 // one-sided transport: the bottom boundary is the walk kernel's last phase (one launch less on every rank that has a
 // cold neighbour); the staged transport needs the LUP message to leave between the two, so it keeps them apart
 bool pipe_fuse_bottom(const hens_ctx_impl* c) {
-    static const bool off = getenv("HENS_PIPE_SEPARATE_BOTTOM") != nullptr;      // A/B knob
-    return !off && pipe_active(c) && !c->pipe.staged && pipe_has_bot(c);
+    return pipe_active(c) && !c->pipe.staged && pipe_has_bot(c);
 }
 
 PipeArgs pipe_args(hens_ctx_impl* c) {
@@ -1160,11 +1157,6 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     f.accepted = c->accepted;
     f.swap_acc = acc_take(c);
     f.acc_rows = 8 * acc_row_groups(c->T);
-    {   // A/B knob: rows the swap counts spread over (8 x groups; fewer rows = fewer hot lines for every workgroup's adaptation
-        // wave to read in the next launch, more atomics per line in this one)
-        static const int g_env = getenv("HENS_ACC_GROUPS") ? atoi(getenv("HENS_ACC_GROUPS")) : 0;
-        if (g_env > 0) f.acc_rows = 8 * std::min(g_env, acc_row_groups(c->T));
-    }
     acc_commit(c);
     f.lo = c->lo; f.hi = c->hi; f.mu = c->mu; f.prec = c->prec; f.prec_sym = c->prec_sym;
     f.period = c->period;
@@ -1333,7 +1325,7 @@ bool iter_ok(const hens_ctx_impl* c) {
 // first launch looks rows up in an LDS copy of its rung's table.
 // the same on a rank of the ladder pipeline that steps with the two in-place launches (every rank reaches the same verdict)
 bool pipe_col_ok(const hens_ctx_impl* c) {
-    static const bool off = getenv("HENS_NO_COL") != nullptr || getenv("HENS_PIPE_NO_COL") != nullptr;   // A/B knobs
+    static const bool off = getenv("HENS_NO_COL") != nullptr;                // A/B knob: records by slot
     return !off && pipe_active(c) && c->pipe.fused && !c->period && c->mh_kind < 0 && (c->W & 3) == 0;
 }
 bool col_ok(const hens_ctx_impl* c) {
@@ -1748,8 +1740,6 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     c->own_stream = true;
     {   // the context's AQL queue for the stepping launches (hens_aql.h); HENS_NO_AQL=1: everything on the HIP stream
         static const bool aql_off = getenv("HENS_NO_AQL") != nullptr;
-        static const int ring_env = getenv("HENS_AQL_RING") ? atoi(getenv("HENS_AQL_RING")) : 0;
-        if (ring_env > 0) c->aql_ring_every = ring_env;
         if (!aql_off) {
             hens_aql::Device& ad = hens_aql::device(cfg->device_id);
             if (ad.ok && c->aql.create(ad)) c->aql_on = true;
@@ -1799,7 +1789,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     // that are a multiple of the block.  A property of (T, W) only, so every rank of a sharded ladder agrees.
     // (round 2, end: ladders whose length does not divide 128 too - cb = the largest power of two with cb T <= 128, the
     //  workgroups of k_split1_pt / k_iter then hold cb T <= 128 slots and cb T / 2 <= 64 moving walkers)
-    if (cfg->tempered && c->T >= 2 && c->T <= 64 && !getenv("HENS_LEGACY_LABELS")) {
+    if (cfg->tempered && c->T >= 2 && c->T <= 64) {
         int cb = 1;
         while (cb * 2 * c->T <= 2 * TILE) cb *= 2;
         if (cb >= 2 && c->W % cb == 0) {
@@ -1877,7 +1867,7 @@ void hens_destroy(hens_ctx* ctx) {
     if (c->aql_on) {
         if (getenv("HENS_AQL_STATS")) fprintf(stderr, "[hipensemble] AQL queue: %llu packets written, %llu doorbells; kernarg ring in %s memory%s, HDP flush register %s\n",
                                               (unsigned long long)c->aql.packets, (unsigned long long)c->aql.doorbells, c->aql.kernarg_dev ? "device" : "host",
-                                              c->aql.kernarg_uncached ? " (uncached)" : (c->aql.kernarg_fine ? " (fine-grained pool)" : " (coarse-grained pool)"), c->aql.dev->hdp.HDP_MEM_FLUSH_CNTL ? "present" : "absent");
+                                              c->aql.kernarg_fine ? " (fine-grained pool)" : " (coarse-grained pool)", c->aql.dev->hdp.HDP_MEM_FLUSH_CNTL ? "present" : "absent");
         c->aql.destroy();
         c->aql_on = false;
     }

@@ -234,10 +234,10 @@ struct Queue {
     uint32_t qsize = 0;              // packets the queue REALLY holds (a profiler's intercept queue need not honour the request)
     char* kernarg = nullptr;
     bool kernarg_dev = false;        // the ring is device memory mapped into the host (writes cross the BAR: flush before the doorbell)
-    bool kernarg_uncached = false, kernarg_fine = false;
+    bool kernarg_fine = false;
     volatile char* last_ka = nullptr;
-    int flush_mode = 2;              // A/B (HENS_AQL_FLUSH): 0 sfence only, 1 + HDP flush register write, 2 + read back except at a call's first doorbell
-    bool acq_agent_ok = true;        // the first packet of a call acquires at agent scope when only this queue touched the state (HENS_AQL_ACQ_SYSTEM=1: always system)
+    int flush_mode = 2;              // 0 sfence only, 1 + HDP flush register write, 2 + read back except at a call's first doorbell (measured: 5.0 vs 6.7 us per call)
+    bool acq_agent_ok = true;        // the first packet of a call acquires at agent scope when only this queue touched the state
     uint64_t windex = 0;             // next packet index (single producer: the context's host thread)
     uint64_t rung = 0;               // packets below this index have been handed to the doorbell
     uint64_t call_first = 0;         // index of the current hens_step call's first packet
@@ -261,15 +261,12 @@ struct Queue {
         // The kernarg ring lives in DEVICE memory, written by the host through the PCIe BAR (what HIP does on this platform, its
         // HIP_FORCE_DEV_KERNARG): every wave of a launch reads its arguments with scalar loads, and from fine-grained host memory
         // those loads cross PCIe - measured here: 41 us per launch of 4 096 waves instead of 8.  HENS_AQL_HOST_KERNARG=1 = host pool.
-        static const bool host_ka = getenv("HENS_AQL_HOST_KERNARG") != nullptr;
-        // A/B: HENS_AQL_KA_POOL = fine | coarse | uncached (which device pool / flag the ring is allocated with)
-        static const std::string ka_pool = getenv("HENS_AQL_KA_POOL") ? getenv("HENS_AQL_KA_POOL") : "";
-        if (d.have_vram && !host_ka) {
-            const bool fine = d.have_vram_fine && ka_pool != "coarse" && ka_pool != "uncached";
-            const bool unc = ka_pool == "uncached";
-            st = hsa_amd_memory_pool_allocate(fine ? d.vram_fine_pool : d.vram_pool, (size_t)qsize * SLOT_BYTES,
-                                              unc ? HSA_AMD_MEMORY_POOL_UNCACHED_FLAG : 0, reinterpret_cast<void**>(&kernarg));
-            kernarg_uncached = unc; kernarg_fine = fine;
+        // (measured, round 4: the fine-grained device pool and the coarse-grained one run the kernels alike; HSA's UNCACHED flag
+        //  costs 3 us per launch - every wave's argument loads go to memory)
+        if (d.have_vram) {
+            const bool fine = d.have_vram_fine;
+            st = hsa_amd_memory_pool_allocate(fine ? d.vram_fine_pool : d.vram_pool, (size_t)qsize * SLOT_BYTES, 0, reinterpret_cast<void**>(&kernarg));
+            kernarg_fine = fine;
             if (st == HSA_STATUS_SUCCESS) {
                 st = hsa_amd_agents_allow_access(1, &d.cpu_agent, nullptr, kernarg);
                 if (st == HSA_STATUS_SUCCESS) kernarg_dev = true;
@@ -289,8 +286,6 @@ struct Queue {
         __builtin_ia32_sfence();
         windex = hsa_queue_load_write_index_relaxed(q);
         rung = windex;
-        if (getenv("HENS_AQL_FLUSH")) flush_mode = atoi(getenv("HENS_AQL_FLUSH"));
-        acq_agent_ok = getenv("HENS_AQL_ACQ_SYSTEM") == nullptr;
         return true;
     }
     void destroy() {

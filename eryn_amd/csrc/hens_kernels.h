@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void k_stretch(const StretchArgs A) {
 // every outstanding global STORE (CDNA4 counts stores in vmcnt); the stretch kernel deliberately leaves
 // row stores in flight across its phases.  Global loads are still waited for where their values are used.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// dev builds (tools/devbuild.sh -DHENS_CUT_S=n / -DHENS_CUT_F=n): the first / second launch returns after phase n - cumulative
+// DEV BUILDS ONLY (tools/devbuild.sh -DHENS_CUT_S=n / -DHENS_CUT_F=n; compiled out of the product): the first / second launch returns after phase n - cumulative
 // phase timings without trace stamps (results are wrong; run with HENS_DEBUG_NOFLIP=1 so the state stays addressable)
 #ifndef HENS_CUT_S
 #define HENS_CUT_S 0
@@ -1110,12 +1110,16 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const bool ad_here = ad_on && (!ad_lead || (blockIdx.x == 0 && blockIdx.y == 0));
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = trace_stamp(); } while (0)
     HENS_TRACE(0);
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 9 && !EVAL && !PIPE && A.inplace) return;
+#endif
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 8 && !EVAL && !PIPE && A.inplace) {          // a launch of known length: every workgroup spins 6 us
         const long long t0 = wall_clock64();
         while (wall_clock64() - t0 < 600) __builtin_amdgcn_s_sleep(4);
         return;
     }
+#endif
     if (PIPE && !EVAL && blockIdx.x == 0 && blockIdx.y == 0) {
         if (A.rt_flag && tid == 0) pipe_raise(A.rt_flag, A.rt_value);
         if (A.cnt_push == 2 && wv == 1) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T,
@@ -1461,7 +1465,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(1);
     lds_barrier();
     HENS_TRACE(2);
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 1 && !EVAL && !PIPE && A.inplace) return;
+#endif
 
     // ---- phase B: lanes over d, all loads first -------------------------------------------------
     const int jl = tid & (LPR - 1);
@@ -1585,7 +1591,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(3);
     lds_barrier();
     HENS_TRACE(4);
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 2 && !EVAL && !PIPE && A.inplace) return;
+#endif
 
     // ---- ladder adaptation (unless the adapting workgroup already did it up front) ------------------------------
     if (ad_here && !ad_early && wv == 1) {
@@ -1621,7 +1629,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     HENS_TRACE(5);
     lds_barrier();
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 3 && !EVAL && !PIPE && A.inplace) return;
+#endif
 
     // ---- phase D: accept / update (wave 0) -------------------------------------------------------
     if (wv == 0 && valid) {
@@ -1697,7 +1707,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     if (EVAL) return;
     HENS_TRACE(6);
     lds_barrier();
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 4 && !PIPE && A.inplace) return;
+#endif
 
     // ---- phase E: accepted rows only (the old rows went out right after phase B) ------------------------
     double* __restrict__ pool_w = A.pool;
@@ -2401,12 +2413,16 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const int NEr = SHORT ? (T << CS) : 2 * TILE, NM = SHORT ? (NEr >> 1) : TILE;
 #define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     FUSED_TRACE(0);
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 9) return;
+#endif
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 8) {
         const long long t0 = wall_clock64();
         while (wall_clock64() - t0 < 600) __builtin_amdgcn_s_sleep(4);
         return;
     }
+#endif
 
     // ---- phase A: one thread per slot, the moving walkers' draws on waves of their own -----------------------------------
     // One memory round trip of round keys (a 32-byte load per rung that hits L2, k_plan_keys) and one of walker records in
@@ -2539,7 +2555,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     FUSED_TRACE(1);
     lds_barrier();
     FUSED_TRACE(2);
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 1) return;
+#endif
 
     // ---- phase B: lanes over d, all loads first ----------------------------------------------------------
     const int jl = tid & (LPR - 1);
@@ -2596,7 +2614,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     FUSED_TRACE(3);
     lds_barrier();
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 2) return;
+#endif
 
     // ---- phase C: likelihood ------------------------------------------------------------------------------
     if (!nomove) {
@@ -2605,7 +2625,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     FUSED_TRACE(4);
     lds_barrier();
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 3) return;
+#endif
 
     // ---- phase D: accept / update into the cascade's tables (the moving walkers' slot threads) ---------------------
     if (tid < NEr && !stays) {
@@ -2651,7 +2673,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     FUSED_TRACE(5);
     lds_barrier();
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 4) return;
+#endif
 
     // ---- phase F: one lane per column walks hot -> cold (tempering.py:515-541) ---------------------------------
     // (a serial chain of T-1 compare / select steps; with the ladder length a compile-time constant every LDS address
@@ -2778,7 +2802,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     }
     lds_barrier();
     FUSED_TRACE(6);
+#ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 5) return;
+#endif
 
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < TE) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };

@@ -177,3 +177,23 @@ def test_config2_keeps_the_two_launch_path():
     eng, *_ = _engine(16, 4096, 32)
     assert not _one_launch(eng)
     eng.close()
+
+
+@pytest.mark.parametrize("knob,T,W,D", [("HENS_NO_COL", 16, 4096, 32), ("HENS_NO_COL", 8, 2048, 64), ("HENS_NO_XCD", 16, 4096, 32),
+                                        ("HENS_NO_XCD", 8, 2048, 64), ("HENS_NO_AQL", 16, 4096, 32), ("HENS_NO_AQL", 8, 4096, 32),
+                                        ("HENS_NO_AQL", 10, 512, 64)])
+def test_every_kept_switch_reaches_the_default_paths_state(knob, T, W, D, tmp_path):
+    """The A/B switches the library still reads select another ORDER of the same arithmetic - walker records by slot instead of by
+    cascade column, plain instead of XCD-affine workgroup numbering, the HIP stream instead of the context's AQL queue - so the
+    chain must be the default path's bit for bit (round 4: every kept switch is in the suite, the others are gone)."""
+    outs = []
+    for env in ({}, {knob: "1"}):
+        out = str(tmp_path / f"{len(outs)}.npz")
+        e = dict(os.environ, **env)
+        if not env:
+            e.pop(knob, None)
+        r = subprocess.run([sys.executable, "-c", _WORKER, ROOT, str(T), str(W), str(D), "0", "dense", out],
+                           env=e, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(dict(np.load(out)))
+    _assert_same(outs[0], outs[1], f"({T},{W},{D}) default vs {knob}=1")
