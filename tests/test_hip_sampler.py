@@ -314,3 +314,19 @@ def test_philox_tune_hook_is_called_per_proposal_with_that_moves_own_mask():
     for u, v in zip(plain, tuned):                       # the hook is an observer: same chain, same stored masks
         assert np.array_equal(u.branches["model_0"].coords, v.branches["model_0"].coords) and np.array_equal(u.log_like, v.log_like)
     assert np.array_equal(a.backend.accepted, b.backend.accepted)
+
+
+def test_philox_sampler_steps_a_three_set_stretch_move():
+    """EnsembleSampler(rng="philox") with StretchMove(nsplits=3) (red_blue.py:41-47): the device draws the three sets itself
+    (tests/test_hip_replay.py holds that path to the oracle); here the sampler plumbing - counters, stored chain, thinning."""
+    from eryn_amd.moves import StretchMove
+    T, W, D = 4, 300, 8
+    rs = np.random.RandomState(5)
+    A = rs.randn(D, D)
+    mu, invcov = 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    s = EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=3, moves=StretchMove(nsplits=3),
+                        tempering_kwargs=dict(ntemps=T))
+    last = s.run_mcmc(np.random.RandomState(2).randn(T, W, D), 6, thin_by=2)
+    assert s.moves[0].num_proposals == 12 and 0.05 < s.moves[0].accepted.mean() / 12 < 0.9
+    assert np.isfinite(last.log_like).all() and s.get_chain()["model_0"].shape[0] == 6
