@@ -7,10 +7,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.environ.get("HENS_LIB") or os.path.join(LIB_DIR, "libhipensemble.so")
-SOURCES = [os.path.join(SRC_DIR, "hens.hip")]
-DEPS = SOURCES + [os.path.join(SRC_DIR, "hens_kernels.h"), os.path.join(SRC_DIR, "hens_rj.h"), os.path.join(SRC_DIR, "hens_iter.h"), os.path.join(SRC_DIR, "hens_aql.h"),
-                  os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+OBJ_DIR = os.path.join(os.path.dirname(HERE), "build", "hens_obj")
+# hens.hip: the C ABI, the host logic and the small kernels; hens_k_<likelihood>.hip (x 2 parts): the stepping kernels' instantiations
+# (csrc/hens_ktable.h) - one translation unit per (likelihood, part), compiled side by side, then linked.
+UNITS = [("hens", "hens.hip", [])] + [(f"hens_k_{k}_{part}", f"hens_k_{k}.hip", [f"-DHENS_KT_PART={part}"])
+                                      for k in ("dense", "diag", "rosen") for part in (0, 1)]
+SOURCES = sorted({os.path.join(SRC_DIR, u[1]) for u in UNITS})
+DEPS = SOURCES + [os.path.join(SRC_DIR, h) for h in ("hens_kernels.h", "hens_rj.h", "hens_iter.h", "hens_aql.h", "hens_ktable.h", "hens_ktable.inc")] + [
+    os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-cuda-compat"]   # (inline __global__: see hens_kernels.h)
 LINK = ["-L/opt/rocm/lib", "-lhsa-runtime64"]      # (direct AQL dispatch of the stepping launches: csrc/hens_aql.h)
 
 
@@ -32,13 +37,30 @@ def build(force=False, verbose=False):
     """Compile the HIP extension if missing or older than its sources.  Returns the .so path."""
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + SOURCES + ["-o", LIB_PATH] + LINK
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = hipcc_path()
+    include = ["-I" + os.path.join(os.path.dirname(HERE), "include")]
+    jobs = []
+    for name, src, defs in UNITS:
+        obj = os.path.join(OBJ_DIR, name + ".o")
+        cmd = [hipcc] + FLAGS + defs + include + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for obj, cmd, proc in jobs:            # (7 compilers side by side: about 1.5 GB each at their peak)
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            failed.append(" ".join(cmd) + "\n" + out)
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[0] for j in jobs] + ["-o", LIB_PATH] + LINK
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("hipcc (link) failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 

@@ -5,6 +5,8 @@
 #include "hens_rj.h"
 #include "hens_iter.h"
 #include "hens_aql.h"
+#include "hens_ktable.h"
+#include <unordered_map>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>          // (types and prototypes only: the library is dlopen()ed, see rccl_api)
 
@@ -200,6 +202,9 @@ struct hens_ctx_impl {
     bool hip_dirty = true;           // the HIP stream may hold work the AQL queue has not been ordered behind
     bool aql_failed = false;         // a dispatch inside a void helper failed (checked by fused_iteration)
     int aql_ring_every = 8;
+    // kernels launched by host function pointer (launch_by_ptr): dynamic-LDS attribute set on this context's device, AQL handle
+    struct KernelSlot { bool attr_done = false; const hens_aql::Kernel* ak = nullptr; };
+    std::unordered_map<const void*, KernelSlot> kslots;
     std::vector<double> launch_us;   // per-kernel profiling: begin / end of every launch of the last hens_step call (us after the first begin)
     std::vector<void*> allocs;
 };
@@ -260,14 +265,9 @@ size_t pack_kernargs(char* buf, const Ts&... a) {
     ((off = (off + alignof(Ts) - 1) & ~(alignof(Ts) - 1), memcpy(buf + off, &a, sizeof(Ts)), off += sizeof(Ts)), ...);
     return off;
 }
-// one launch on the AQL queue; `cache` = the call site's per-device kernel handles
-template <class F, class... Ts>
-int aql_launch(hens_ctx_impl* c, const hens_aql::Kernel** cache, F fn, dim3 grid, unsigned block, size_t lds, bool signal, const Ts&... args) {
-    const hens_aql::Kernel*& k = cache[c->cfg.device_id & 63];
-    if (!k) {
-        k = hens_aql::kernel_for(*c->aql.dev, reinterpret_cast<const void*>(fn));
-        if (!k) return fail(c, HENS_ERR_HIP, "AQL dispatch: kernel not found in the library's code object");
-    }
+// one launch on the AQL queue of a kernel already resolved in the library's code objects
+template <class... Ts>
+int aql_launch_k(hens_ctx_impl* c, const hens_aql::Kernel* k, dim3 grid, unsigned block, size_t lds, bool signal, const Ts&... args) {
     alignas(16) char buf[hens_aql::SLOT_BYTES];
     static_assert((sizeof(Ts) + ... + 0) + 8 * sizeof...(Ts) <= hens_aql::SLOT_BYTES - 256, "kernel arguments exceed the kernarg slot");
     const size_t n = pack_kernargs(buf, args...);
@@ -275,6 +275,86 @@ int aql_launch(hens_ctx_impl* c, const hens_aql::Kernel** cache, F fn, dim3 grid
     // doorbell: right behind a call's first packet (the GPU starts while the host writes the rest), then every few packets
     if (c->aql.windex == c->aql.call_first + 1 || c->aql.windex - c->aql.rung >= (uint64_t)c->aql_ring_every) c->aql.ring();
     return HENS_OK;
+}
+// ... of a kernel of this translation unit; `cache` = the call site's per-device kernel handles
+template <class F, class... Ts>
+int aql_launch(hens_ctx_impl* c, const hens_aql::Kernel** cache, F fn, dim3 grid, unsigned block, size_t lds, bool signal, const Ts&... args) {
+    const hens_aql::Kernel*& k = cache[c->cfg.device_id & 63];
+    if (!k) {
+        k = hens_aql::kernel_for(*c->aql.dev, reinterpret_cast<const void*>(fn));
+        if (!k) return fail(c, HENS_ERR_HIP, "AQL dispatch: kernel not found in the library's code object");
+    }
+    return aql_launch_k(c, k, grid, block, lds, signal, args...);
+}
+
+// One launch of a stepping kernel instantiated in another translation unit (hens_ktable.h), by its host function: on the
+// context's AQL queue while a call steps there, else on the HIP stream (between two timing events when asked).  `what` names the
+// kernel in errors.  The context remembers per function that the dynamic-LDS attribute is set (it is per device, a context has one
+// device) and the function's AQL handle.
+template <class Args>
+int launch_by_ptr(hens_ctx_impl* c, const void* fn, const char* what, dim3 grid, unsigned block, size_t lds, bool signal,
+                  hipEvent_t e0, hipEvent_t e1, const Args& a) {
+    if (!fn) return fail(c, HENS_ERR_UNSUPPORTED, "%s: no such instantiation in this build (ndim %d)", what, c->D);
+    hens_ctx_impl::KernelSlot& ks = c->kslots[fn];
+    if (lds > 60000 && !ks.attr_done) {
+        const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ae != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(%s, %zu B of LDS): %s", what, lds, hipGetErrorString(ae));
+        ks.attr_done = true;
+    }
+    if (c->aql_now) {
+        if (!ks.ak) {
+            ks.ak = hens_aql::kernel_for(*c->aql.dev, fn);
+            if (!ks.ak) return fail(c, HENS_ERR_HIP, "AQL dispatch: %s not found in the library's code objects", what);
+        }
+        return aql_launch_k(c, ks.ak, grid, block, lds, signal, a);
+    }
+    void* args[] = {const_cast<Args*>(&a)};
+    const hipError_t e = e0 ? hipExtLaunchKernel(fn, grid, dim3(block), args, lds, c->stream, e0, e1, 0)
+                            : hipLaunchKernel(fn, grid, dim3(block), args, lds, c->stream);
+    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return HENS_OK;
+}
+
+// the kernel tables of the per-likelihood translation units, by LIKE_*
+const void* ktab_stretch_fast(int like, int mode, int D, bool pipe, bool per) {
+    switch (like) {
+        case LIKE_DENSE: return ktab_stretch_fast_dense(mode, D, pipe, per);
+#ifndef HENS_DEV_BUILD       // (dev build, tools/devbuild.sh: the dense-Gaussian D = 32 kernels only - seconds instead of minutes)
+        case LIKE_DIAG: return ktab_stretch_fast_diag(mode, D, pipe, per);
+        case LIKE_ROSEN: return ktab_stretch_fast_rosen(mode, D, pipe, per);
+#endif
+    }
+    return nullptr;
+}
+const void* ktab_stretch(int like, int mode) {
+    switch (like) {
+        case LIKE_DENSE: return ktab_stretch_dense(mode);
+#ifndef HENS_DEV_BUILD
+        case LIKE_DIAG: return ktab_stretch_diag(mode);
+        case LIKE_ROSEN: return ktab_stretch_rosen(mode);
+#endif
+    }
+    return nullptr;
+}
+const void* ktab_split1_pt(int like, int D, bool per, bool shrt, bool pipe, bool col) {
+    switch (like) {
+        case LIKE_DENSE: return ktab_split1_pt_dense(D, per, shrt, pipe, col);
+#ifndef HENS_DEV_BUILD
+        case LIKE_DIAG: return ktab_split1_pt_diag(D, per, shrt, pipe, col);
+        case LIKE_ROSEN: return ktab_split1_pt_rosen(D, per, shrt, pipe, col);
+#endif
+    }
+    return nullptr;
+}
+const void* ktab_iter(int like, int D, bool per) {
+    switch (like) {
+        case LIKE_DENSE: return ktab_iter_dense(D, per);
+#ifndef HENS_DEV_BUILD
+        case LIKE_DIAG: return ktab_iter_diag(D, per);
+        case LIKE_ROSEN: return ktab_iter_rosen(D, per);
+#endif
+    }
+    return nullptr;
 }
 
 // a piece of HIP-stream work in the middle of a call that steps on the AQL queue (packing the state at the head of the first call
@@ -332,8 +412,7 @@ size_t fast_lds_bytes(int D, int NW) {
     return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 128) * 8 + (4 * (size_t)TILE + 128) * 4;
 }
 
-template <int LIKE, int MODE>
-int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
+int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int ntiles) {
     const dim3 grid(ntiles, c->Tl);
     {
         // Consecutive workgroups go round-robin to the 8 XCDs, each with an L2 of its own that keeps its lines from launch to
@@ -345,79 +424,24 @@ int launch_stretch_like(hens_ctx_impl* c, StretchArgs a, int ntiles) {
         static const bool xcd = getenv("HENS_NO_XCD") == nullptr;
         if (xcd && (ntiles & (ntiles - 1)) == 0 && ((long)ntiles * c->Tl) % 8 == 0) { int sh = 0; while ((1 << sh) < ntiles) ++sh; a.xcd_shift = sh + 1; }
     }
-#define LAUNCH_FAST_P(DT, NW, PIPE, PER)                                                           \
-    do {                                                                                           \
-        const size_t lds = fast_lds_bytes(DT, NW);                                                 \
-        if (lds > 60000) {                                                                         \
-            static uint64_t attr_done = 0;              /* (the attribute is per device) */        \
-            const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
-            if (!(attr_done & dev_bit)) {                                                          \
-                const hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-                if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_stretch_fast, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
-                attr_done |= dev_bit;                                                              \
-            }                                                                                      \
-        }                                                                                          \
-        if (c->aql_now) {                                                                          \
-            static const hens_aql::Kernel* ak_[64] = {};                                           \
-            const int ar_ = aql_launch(c, ak_, k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>, grid, NW * 64, lds, false, a); \
-            if (ar_) return ar_;                                                                   \
-        } else if (c->ext_start)                                                                   \
-            hipExtLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, \
-                                  c->ext_start, c->ext_stop, 0, a);                                \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_stretch_fast<DT, LIKE, MODE, NW, PIPE, PER>), grid, dim3(NW * 64), lds, c->stream, a); \
-    } while (0)
-    // (periodic parameters: an instantiation of their own, never on a pipeline rank - hens_set_periodic / hens_pipe_init
-    //  refuse the combination - and not for the evaluation launch, which proposes nothing)
-#ifdef HENS_DEV_BUILD
-#define LAUNCH_FAST(DT, NW) LAUNCH_FAST_P(DT, NW, false, false)
-#else
-#define LAUNCH_FAST(DT, NW)                                                                        \
-    do {                                                                                           \
-        if (c->pipe.on) LAUNCH_FAST_P(DT, NW, true, false);                                        \
-        else if (MODE != MODE_EVAL && c->period) {                                                 \
-            if constexpr (MODE != MODE_EVAL) LAUNCH_FAST_P(DT, NW, false, true);                   \
-        } else LAUNCH_FAST_P(DT, NW, false, false);                                                \
-    } while (0)
-#endif
-    bool launched = true;
-    if (!fast_path(c)) {
-        launched = false;
-    } else if (c->D == 32) {
-        LAUNCH_FAST(32, FAST_NW_32);
-#ifndef HENS_DEV_BUILD
-    } else if (c->D == 64) {
-        LAUNCH_FAST(64, 8);
-    } else if (c->D == 16) {
-        LAUNCH_FAST(16, 4);
-    } else if (c->D == 8) {
-        LAUNCH_FAST(8, 4);
-    } else if (c->D == 128) {
-        LAUNCH_FAST(128, 8);
-#endif
-    } else {
-        launched = false;
+    if (fast_path(c)) {
+        // (periodic parameters: an instantiation of their own, never on a pipeline rank - hens_set_periodic / hens_pipe_init
+        //  refuse the combination - and not for the evaluation launch, which proposes nothing)
+        const bool pipe = c->pipe.on, per = !pipe && mode != MODE_EVAL && c->period;
+        const int NW = fast_nw(c->D);
+        return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW), false,
+                             c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
     }
-    if (!launched) {
-        int RS;
-        const size_t lds = generic_lds_bytes(c->D, &RS);
-        if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
-        if (lds > 60000) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_stretch<LIKE, MODE>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        a.RS = RS;
-        a.ad_on = 0;
-        if (c->ext_start)
-            hipExtLaunchKernelGGL((k_stretch<LIKE, MODE>), grid, dim3(256), (uint32_t)lds, c->stream, c->ext_start,
-                                  c->ext_stop, 0, a);
-        else
-            hipLaunchKernelGGL((k_stretch<LIKE, MODE>), grid, dim3(256), lds, c->stream, a);
-    }
-#undef LAUNCH_FAST
-#undef LAUNCH_FAST_P
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_stretch launch failed: %s", hipGetErrorString(e));
-    return HENS_OK;
+    int RS;
+    const size_t lds = generic_lds_bytes(c->D, &RS);
+    if (lds > 160 * 1024) return fail(c, HENS_ERR_UNSUPPORTED, "ndim %d exceeds the LDS row tile", c->D);
+    a.RS = RS;
+    a.ad_on = 0;
+    const bool was_aql = c->aql_now;           // (the generic-width kernel always goes through the HIP stream, as it did)
+    c->aql_now = false;
+    const int r = launch_by_ptr(c, ktab_stretch(like, mode), "k_stretch", grid, 256, lds, false, c->ext_start, c->ext_stop, a);
+    c->aql_now = was_aql;
+    return r;
 }
 
 int launch_hostlike_eval(hens_ctx_impl* c, StretchArgs a, int ntiles) {
@@ -437,11 +461,9 @@ int launch_hostlike_eval(hens_ctx_impl* c, StretchArgs a, int ntiles) {
 template <int MODE>
 int launch_stretch(hens_ctx_impl* c, const StretchArgs& a, int ntiles) {
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like<LIKE_DENSE, MODE>(c, a, ntiles);
-#ifndef HENS_DEV_BUILD       // (dev build, tools/devbuild.sh: the dense-Gaussian D = 32 kernels only - seconds instead of minutes)
-        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like<LIKE_DIAG, MODE>(c, a, ntiles);
-        case HENS_LIKE_ROSENBROCK: return launch_stretch_like<LIKE_ROSEN, MODE>(c, a, ntiles);
-#endif
+        case HENS_LIKE_GAUSS_DENSE: return launch_stretch_like(c, LIKE_DENSE, MODE, a, ntiles);
+        case HENS_LIKE_GAUSS_DIAG: return launch_stretch_like(c, LIKE_DIAG, MODE, a, ntiles);
+        case HENS_LIKE_ROSENBROCK: return launch_stretch_like(c, LIKE_ROSEN, MODE, a, ntiles);
         case HENS_LIKE_TEMPLATE:
             return fail(c, HENS_ERR_STATE, "leaf-packing context: step with hens_rj_* (the stretch move is not defined on variable-dimension records)");
         case HENS_LIKE_HOST:
@@ -1027,62 +1049,14 @@ bool fused_ok(const hens_ctx_impl* c) {
            c->cfg.likelihood_kind != HENS_LIKE_HOST;
 }
 
-template <int LIKE>
-int launch_fused_like(hens_ctx_impl* c, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1, bool pipe = false, bool col = false) {
+int launch_fused_like(hens_ctx_impl* c, int like, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1, bool pipe = false, bool col = false) {
     const dim3 grid(pipe ? c->W / c->pipe.cbl : c->W / c->label_cb);
-    // (the MaxDynamicSharedMemorySize attribute is per device: contexts on several GPUs of one process each set it)
-#define LAUNCH_FUSED_P(DT, NW, PER, SHORT, PIPE, COL)                                              \
-    do {                                                                                           \
-        const size_t lds = fused_lds_bytes(DT, NW, PIPE);                                          \
-        if (lds > 60000) {                                                                         \
-            static uint64_t attr_done = 0;                                                         \
-            const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                              \
-            if (!(attr_done & dev_bit)) {                                                          \
-                const hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-                if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_split1_pt, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
-                attr_done |= dev_bit;                                                              \
-            }                                                                                      \
-        }                                                                                          \
-        if (c->aql_now) {      /* (the iteration's last launch: the call's last one carries the completion signal) */ \
-            static const hens_aql::Kernel* ak_[64] = {};                                           \
-            const int ar_ = aql_launch(c, ak_, k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>, grid, NW * 64, lds, c->aql_last, f); \
-            if (ar_) return ar_;                                                                   \
-        } else if (e0)                                                                             \
-            hipExtLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_split1_pt<DT, LIKE, NW, PER, SHORT, PIPE, COL>), grid, dim3(NW * 64), lds, c->stream, f); \
-    } while (0)
-#ifdef HENS_DEV_BUILD
-#define LAUNCH_FUSED(DT, NW) do { if (pipe && col) LAUNCH_FUSED_P(DT, NW, false, false, true, true); else if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false); else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true); else LAUNCH_FUSED_P(DT, NW, false, false, false, false); } while (0)
-#else
-#define LAUNCH_FUSED(DT, NW)                                                                       \
-    do {                                                                                           \
-        const bool short_tiles = c->T * c->label_cb != 2 * TILE;                                   \
-        if (pipe && col) LAUNCH_FUSED_P(DT, NW, false, false, true, true);                         \
-        else if (pipe) LAUNCH_FUSED_P(DT, NW, false, false, true, false);                          \
-        else if (col) LAUNCH_FUSED_P(DT, NW, false, false, false, true);                           \
-        else if (f.period && short_tiles) LAUNCH_FUSED_P(DT, NW, true, true, false, false);        \
-        else if (f.period) LAUNCH_FUSED_P(DT, NW, true, false, false, false);                      \
-        else if (short_tiles) LAUNCH_FUSED_P(DT, NW, false, true, false, false);                   \
-        else LAUNCH_FUSED_P(DT, NW, false, false, false, false);                                   \
-    } while (0)
-#endif
-    switch (c->D) {
-        case 32: LAUNCH_FUSED(32, FAST_NW_32); break;
-#ifndef HENS_DEV_BUILD
-        case 8: LAUNCH_FUSED(8, 4); break;
-        case 16: LAUNCH_FUSED(16, 4); break;
-        case 64: LAUNCH_FUSED(64, 8); break;
-        case 128: LAUNCH_FUSED(128, 8); break;
-#endif
-        default: return fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for ndim %d", c->D);
-    }
-#undef LAUNCH_FUSED
-#undef LAUNCH_FUSED_P
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_split1_pt launch failed: %s", hipGetErrorString(e));
-    return HENS_OK;
+    const int NW = fast_nw(c->D);
+    // the instantiation: pipeline rank and column order know neither periodic parameters nor short tiles (their callers refuse)
+    const bool plain = !pipe && !col, per = plain && f.period, shrt = plain && c->T * c->label_cb != 2 * TILE;
+    // (the iteration's last launch: the call's last one carries the completion signal)
+    return launch_by_ptr(c, ktab_split1_pt(like, c->D, per, shrt, pipe, col), "k_split1_pt", grid, NW * 64, fused_lds_bytes(c->D, NW, pipe),
+                         c->aql_last, e0, e1, f);
 }
 
 // one Philox iteration in two launches: first half-step (k_stretch_fast, carrying the pending ladder adaptation), then
@@ -1211,10 +1185,10 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     }
     int r;
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1, false, c->colmode); break;
+        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like(c, LIKE_DENSE, f, e0, e1, false, c->colmode); break;
 #ifndef HENS_DEV_BUILD
-        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1, false, c->colmode); break;
-        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1, false, c->colmode); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like(c, LIKE_DIAG, f, e0, e1, false, c->colmode); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_fused_like(c, LIKE_ROSEN, f, e0, e1, false, c->colmode); break;
 #endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
@@ -1324,10 +1298,10 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh
     }
     int r;
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like<LIKE_DENSE>(c, f, e0, e1, true, c->colmode); break;
+        case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like(c, LIKE_DENSE, f, e0, e1, true, c->colmode); break;
 #ifndef HENS_DEV_BUILD
-        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like<LIKE_DIAG>(c, f, e0, e1, true, c->colmode); break;
-        case HENS_LIKE_ROSENBROCK: r = launch_fused_like<LIKE_ROSEN>(c, f, e0, e1, true, c->colmode); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_fused_like(c, LIKE_DIAG, f, e0, e1, true, c->colmode); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_fused_like(c, LIKE_ROSEN, f, e0, e1, true, c->colmode); break;
 #endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no fused kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }
@@ -1372,50 +1346,10 @@ bool col_ok(const hens_ctx_impl* c) {
     return c->T * c->label_cb == 2 * TILE && (c->W & 3) == 0;
 }
 
-template <int LIKE>
-int launch_iter_like(hens_ctx_impl* c, const IterArgs& f, hipEvent_t e0, hipEvent_t e1) {
+int launch_iter_like(hens_ctx_impl* c, int like, const IterArgs& f, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(c->W / c->label_cb);
-#define LAUNCH_ITER_P(DT, NW, PER)                                                                 \
-    do {                                                                                           \
-        const size_t lds = iter_lds_bytes(DT, NW);                                                 \
-        static uint64_t attr_done = 0;                  /* (the attribute is per device) */        \
-        const uint64_t dev_bit = 1ull << (c->cfg.device_id & 63);                                  \
-        if (!(attr_done & dev_bit)) {                                                              \
-            const hipError_t ae_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_iter<DT, LIKE, NW, PER>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-            if (ae_ != hipSuccess) return fail(c, HENS_ERR_HIP, "hipFuncSetAttribute(k_iter, %zu B of LDS): %s", lds, hipGetErrorString(ae_)); \
-            attr_done |= dev_bit;                                                                  \
-        }                                                                                          \
-        if (c->aql_now) {                                                                          \
-            static const hens_aql::Kernel* ak_[64] = {};                                           \
-            const int ar_ = aql_launch(c, ak_, k_iter<DT, LIKE, NW, PER>, grid, NW * 64, lds, c->aql_last, f); \
-            if (ar_) return ar_;                                                                   \
-        } else if (e0)                                                                             \
-            hipExtLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), (uint32_t)lds, c->stream, e0, e1, 0, f); \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_iter<DT, LIKE, NW, PER>), grid, dim3(NW * 64), lds, c->stream, f);    \
-    } while (0)
-#ifdef HENS_DEV_BUILD
-#define LAUNCH_ITER(DT, NW) LAUNCH_ITER_P(DT, NW, false)
-#else
-#define LAUNCH_ITER(DT, NW)                                                                        \
-    do {                                                                                           \
-        if (f.period) LAUNCH_ITER_P(DT, NW, true);                                                 \
-        else LAUNCH_ITER_P(DT, NW, false);                                                         \
-    } while (0)
-#endif
-    switch (c->D) {
-        case 32: LAUNCH_ITER(32, 8); break;
-#ifndef HENS_DEV_BUILD
-        case 16: LAUNCH_ITER(16, 8); break;
-#endif
-        default: return fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for ndim %d", c->D);
-    }
-#undef LAUNCH_ITER
-#undef LAUNCH_ITER_P
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_iter launch failed: %s", hipGetErrorString(e));
-    return HENS_OK;
+    constexpr int NW = 8;
+    return launch_by_ptr(c, ktab_iter(like, c->D, f.period != nullptr), "k_iter", grid, NW * 64, iter_lds_bytes(c->D, NW), c->aql_last, e0, e1, f);
 }
 
 int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {
@@ -1465,10 +1399,10 @@ int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>*
     }
     int r;
     switch (c->cfg.likelihood_kind) {
-        case HENS_LIKE_GAUSS_DENSE: r = launch_iter_like<LIKE_DENSE>(c, f, e0, e1); break;
+        case HENS_LIKE_GAUSS_DENSE: r = launch_iter_like(c, LIKE_DENSE, f, e0, e1); break;
 #ifndef HENS_DEV_BUILD
-        case HENS_LIKE_GAUSS_DIAG: r = launch_iter_like<LIKE_DIAG>(c, f, e0, e1); break;
-        case HENS_LIKE_ROSENBROCK: r = launch_iter_like<LIKE_ROSEN>(c, f, e0, e1); break;
+        case HENS_LIKE_GAUSS_DIAG: r = launch_iter_like(c, LIKE_DIAG, f, e0, e1); break;
+        case HENS_LIKE_ROSENBROCK: r = launch_iter_like(c, LIKE_ROSEN, f, e0, e1); break;
 #endif
         default: r = fail(c, HENS_ERR_UNSUPPORTED, "no one-launch kernel for likelihood kind %d", c->cfg.likelihood_kind);
     }

@@ -50,9 +50,11 @@ struct Device {
     hsa_amd_memory_pool_t vram_fine_pool{};     // ... its fine-grained pool, if it has one
     bool have_pool = false, have_vram = false, have_vram_fine = false;
     hsa_amd_hdp_flush_t hdp{nullptr, nullptr};
-    hsa_executable_t exe{};
-    hsa_code_object_reader_t reader{};
-    std::vector<char> image;                    // the code object's bytes (the reader refers to them)
+    // one loaded executable per code object: the library is built from several translation units (hens_ktable.h), each with a
+    // fat binary of its own in .hip_fatbin
+    std::vector<hsa_executable_t> exes;
+    std::vector<hsa_code_object_reader_t> readers;
+    std::vector<std::vector<char>> images;      // the code objects' bytes (the readers refer to them)
     std::unordered_map<std::string, Kernel> kernels;
     std::mutex mu;
 };
@@ -82,23 +84,30 @@ inline bool read_code_object(Device& d) {
     for (int i = 0; i < eh->e_shnum; ++i)
         if (strcmp(names + sh[i].sh_name, ".hip_fatbin") == 0) { fat = so.data() + sh[i].sh_offset; fat_size = sh[i].sh_size; }
     static const char MAGIC[] = "__CLANG_OFFLOAD_BUNDLE__";
-    if (!fat || fat_size < 32 || memcmp(fat, MAGIC, 24) != 0) return fail(d, "no uncompressed clang offload bundle in .hip_fatbin");
-    uint64_t n;
-    memcpy(&n, fat + 24, 8);
-    size_t off = 32;
-    for (uint64_t i = 0; i < n && off + 24 <= fat_size; ++i) {
-        uint64_t eo, es, ts;
-        memcpy(&eo, fat + off, 8); memcpy(&es, fat + off + 8, 8); memcpy(&ts, fat + off + 16, 8);
-        off += 24;
-        if (off + ts > fat_size) break;
-        const std::string triple(fat + off, ts);
-        off += ts;
-        if (triple.find("amdgcn") != std::string::npos && triple.find("gfx950") != std::string::npos && es > 0 && eo + es <= fat_size) {
-            d.image.assign(fat + eo, fat + eo + es);
-            return true;
+    if (!fat || fat_size < 32) return fail(d, "no .hip_fatbin section");
+    // every translation unit's bundle, one after the other (each aligned; found by its magic)
+    for (const char* b = fat; b + 32 <= fat + fat_size;) {
+        b = static_cast<const char*>(memmem(b, (size_t)(fat + fat_size - b), MAGIC, 24));
+        if (!b) break;
+        const size_t left = (size_t)(fat + fat_size - b);
+        uint64_t n;
+        memcpy(&n, b + 24, 8);
+        size_t off = 32, end = 32;
+        for (uint64_t i = 0; i < n && off + 24 <= left; ++i) {
+            uint64_t eo, es, ts;
+            memcpy(&eo, b + off, 8); memcpy(&es, b + off + 8, 8); memcpy(&ts, b + off + 16, 8);
+            off += 24;
+            if (off + ts > left) break;
+            const std::string triple(b + off, ts);
+            off += ts;
+            if (eo + es <= left) end = std::max<size_t>(end, eo + es);
+            if (triple.find("amdgcn") != std::string::npos && triple.find("gfx950") != std::string::npos && es > 0 && eo + es <= left)
+                d.images.emplace_back(b + eo, b + eo + es);
         }
+        b += std::max<size_t>(end, off);
     }
-    return fail(d, "no gfx950 code object in the fat binary");
+    if (d.images.empty()) return fail(d, "no uncompressed gfx950 code object in the library's fat binaries");
+    return true;
 }
 
 struct FindAgent { uint32_t bdf, domain; hsa_agent_t out; bool found; };
@@ -175,14 +184,20 @@ inline Device& device(int hip_device) {
     if (ff.found) { d.vram_fine_pool = ff.out; d.have_vram_fine = true; }
     (void)hsa_agent_get_info(d.agent, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_HDP_FLUSH, &d.hdp);
     if (!read_code_object(d)) return d;
-    st = hsa_code_object_reader_create_from_memory(d.image.data(), d.image.size(), &d.reader);
-    if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_code_object_reader_create_from_memory", st); return d; }
-    st = hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &d.exe);
-    if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_executable_create_alt", st); return d; }
-    st = hsa_executable_load_agent_code_object(d.exe, d.agent, d.reader, nullptr, nullptr);
-    if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_executable_load_agent_code_object", st); return d; }
-    st = hsa_executable_freeze(d.exe, nullptr);
-    if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_executable_freeze", st); return d; }
+    for (const std::vector<char>& image : d.images) {
+        hsa_code_object_reader_t reader{};
+        hsa_executable_t exe{};
+        st = hsa_code_object_reader_create_from_memory(image.data(), image.size(), &reader);
+        if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_code_object_reader_create_from_memory", st); return d; }
+        d.readers.push_back(reader);
+        st = hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &exe);
+        if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_executable_create_alt", st); return d; }
+        d.exes.push_back(exe);
+        st = hsa_executable_load_agent_code_object(exe, d.agent, reader, nullptr, nullptr);
+        if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_executable_load_agent_code_object", st); return d; }
+        st = hsa_executable_freeze(exe, nullptr);
+        if (st != HSA_STATUS_SUCCESS) { fail(d, "hsa_executable_freeze", st); return d; }
+    }
     d.ok = true;
     return d;
 }
@@ -197,7 +212,10 @@ inline const Kernel* kernel_for(Device& d, const void* host_fn) {
     k.resolved = true;
     const std::string sym = std::string(nm) + ".kd";
     hsa_executable_symbol_t s{};
-    if (hsa_executable_get_symbol_by_name(d.exe, sym.c_str(), &d.agent, &s) != HSA_STATUS_SUCCESS) return nullptr;
+    bool found = false;
+    for (hsa_executable_t exe : d.exes)
+        if (hsa_executable_get_symbol_by_name(exe, sym.c_str(), &d.agent, &s) == HSA_STATUS_SUCCESS && s.handle) { found = true; break; }
+    if (!found) return nullptr;
     uint64_t obj = 0;
     uint32_t ka = 0, gs = 0, ps = 0;
     if (hsa_executable_symbol_get_info(s, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &obj) != HSA_STATUS_SUCCESS) return nullptr;
@@ -274,10 +292,10 @@ struct Queue {
             } else kernarg = nullptr;
         }
         if (!kernarg) {
-            st = hsa_amd_memory_pool_allocate(d.kernarg_pool, (size_t)qsize * SLOT_BYTES, 0, reinterpret_cast<void**>(&kernarg));
-            if (st != HSA_STATUS_SUCCESS) { err = "kernarg ring allocation failed"; kernarg = nullptr; return false; }
-            st = hsa_amd_agents_allow_access(1, &d.agent, nullptr, kernarg);
-            if (st != HSA_STATUS_SUCCESS) { err = "hsa_amd_agents_allow_access(kernarg ring) failed"; return false; }
+            // (no host mapping of device memory - no large BAR: a ring in HOST memory would run every launch at 41 us instead of 8;
+            //  the context then keeps its launches on the HIP stream, whose runtime places kernel arguments itself)
+            err = "the kernarg ring cannot live in host-mapped device memory on this system";
+            return false;
         }
         // first touch of every page of the ring NOW: the host's mapping of device memory is populated by page faults (a fresh 4 KiB
         // page every four packets until the ring has wrapped once - 2 048 iterations; measured: blocks of 20 iterations 10 us

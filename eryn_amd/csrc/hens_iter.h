@@ -481,7 +481,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
 
 // Leaving record mode after k_iter launches: walkers whose current row sits in the half the copying launches write next
 // (`free_lo` .. `free_lo + half`) move back to their other row, so that all rows live in one half again.
-__global__ void k_fold_rows(double* __restrict__ pool, int32_t* __restrict__ loc, int64_t n, int D, int32_t half, int32_t free_lo) {
+inline __global__ void k_fold_rows(double* __restrict__ pool, int32_t* __restrict__ loc, int64_t n, int D, int32_t half, int32_t free_lo) {
     const int lpr = D / 2;
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = g / lpr;

@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 // ---------------------------------------------------------------------------------------------
 // Small utilities
 // ---------------------------------------------------------------------------------------------
-__global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
+inline __global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
                               double* __restrict__ dst, int64_t nrows, int D, int64_t guest_delta) {
     const int64_t total = nrows * D;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -1780,12 +1780,12 @@ __global__ void k_gather_rows(const double* __restrict__ pool, const int32_t* __
     }
 }
 
-__global__ void k_pack_state(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
+inline __global__ void k_pack_state(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
                              const uint32_t* __restrict__ accepted, WalkerRec* __restrict__ w, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         w[i] = make_wrec(L[i], P[i], loc[i], accepted[i]);
 }
-__global__ void k_unpack_state(const WalkerRec* __restrict__ w, double* __restrict__ L, double* __restrict__ P,
+inline __global__ void k_unpack_state(const WalkerRec* __restrict__ w, double* __restrict__ L, double* __restrict__ P,
                                int32_t* __restrict__ loc, uint32_t* __restrict__ accepted, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const WalkerRec r = w[i];
@@ -1795,7 +1795,7 @@ __global__ void k_unpack_state(const WalkerRec* __restrict__ w, double* __restri
 
 // column-ordered records <-> by-field arrays (slot order): record c of rung t is the slot prp_t(c), keys = the round keys of
 // the iteration the order belongs to ([T][8], k_plan_keys).  Pack also writes the compact row table in column order.
-__global__ void k_pack_cols(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
+inline __global__ void k_pack_cols(const double* __restrict__ L, const double* __restrict__ P, const int32_t* __restrict__ loc,
                             const uint32_t* __restrict__ accepted, const uint32_t* __restrict__ keys, WalkerRec* __restrict__ w,
                             int32_t* __restrict__ loc_cols, int T, int W, int idx_bits) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * W; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1809,7 +1809,7 @@ __global__ void k_pack_cols(const double* __restrict__ L, const double* __restri
         loc_cols[i] = loc[s];
     }
 }
-__global__ void k_unpack_cols(const WalkerRec* __restrict__ w, const uint32_t* __restrict__ keys, double* __restrict__ L,
+inline __global__ void k_unpack_cols(const WalkerRec* __restrict__ w, const uint32_t* __restrict__ keys, double* __restrict__ L,
                               double* __restrict__ P, int32_t* __restrict__ loc, uint32_t* __restrict__ accepted, int T, int W,
                               int idx_bits) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * W; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1823,7 +1823,7 @@ __global__ void k_unpack_cols(const WalkerRec* __restrict__ w, const uint32_t* _
     }
 }
 
-__global__ void k_iota(int32_t* p, int64_t n) {
+inline __global__ void k_iota(int32_t* p, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = (int32_t)i;
 }
@@ -1832,7 +1832,7 @@ __global__ void k_iota(int32_t* p, int64_t n) {
 // order = [set 0 ascending | set 1 ascending | ...]: the moving set is positions [s_off, s_off + Ns), the complement list the
 // reference indexes with rint is the other sets concatenated in set order (stretch.py:199: c = concatenate(c, axis=1)) = `order`
 // with that range cut out
-__global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* __restrict__ rint,
+inline __global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* __restrict__ rint,
                              const double* __restrict__ u_zz, const double* __restrict__ u_acc, Draws d,
                              int Tl, int W, int s_off, int Ns, double a, int D) {
     const int64_t n = (int64_t)Tl * Ns;
@@ -1849,7 +1849,7 @@ __global__ void k_prep_draws(const int32_t* __restrict__ order, const int64_t* _
 // Metropolis-Hastings proposals: the draws of a GaussianMove (gaussian.py:68-270).
 // ---------------------------------------------------------------------------------------------
 // parity mode: the caller's accept uniforms (mh.py:157) -> log
-__global__ void k_mh_prep(const double* __restrict__ u_acc, double* __restrict__ lu, int64_t n) {
+inline __global__ void k_mh_prep(const double* __restrict__ u_acc, double* __restrict__ lu, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         lu[i] = log(u_acc[i]);
 }
@@ -1865,7 +1865,7 @@ struct MhDrawArgs {
 // Philox mode: step = scale * z (isotropic / diagonal) or chol * z (full covariance), z ~ N(0, 1) by
 // Box-Muller from Philox counters keyed (iteration, global rung, walker, coordinate pair); the accept
 // uniform likewise.  One workgroup = 64 walkers of one rung; z goes through LDS for the triangular product.
-__global__ __launch_bounds__(256) void k_mh_draw(const MhDrawArgs A) {
+inline __global__ __launch_bounds__(256) void k_mh_draw(const MhDrawArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* z = reinterpret_cast<double*>(smem_raw);                  // [64][D + 1]
     const int D = A.D, W = A.W, ZS = D + 1;
@@ -1959,7 +1959,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t x, uint32_t* wtot, 
     return inc - x + (wave > 0 ? wtot[wave - 1] : 0u);
 }
 
-__global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
+inline __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
     // shapes WITHOUT block-balanced labels (untempered ensembles, ladders above 64 rungs, walker counts that are not a
     // multiple of the block): label = prp(w) >= ceil(W/2), both halves listed in ascending walker order through a scan
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2018,7 +2018,7 @@ __global__ __launch_bounds__(1024) void k_plan(const PlanArgs A) {
 // 183-197's `sets`): order with the moving range cut out.  One workgroup per rung, one iteration per launch; the copying launches
 // then run set after set exactly as the parity API's (StretchArgs::ns_x / soff_x).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_plan_sets(const PlanArgs A) {
+inline __global__ __launch_bounds__(256) void k_plan_sets(const PlanArgs A) {
     __shared__ uint32_t cnt[8][256];
     __shared__ uint32_t skey[8];
     __shared__ int s_off[9];
@@ -2088,7 +2088,7 @@ __global__ __launch_bounds__(256) void k_plan_sets(const PlanArgs A) {
 // cost them 2.8 us per iteration at config 2 (a stepping workgroup that cannot start until a plan workgroup leaves its CU
 // doubles its launch), run alone 4 us.  Now one thread per (iteration, rung, place), nothing ordered, nothing shared.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_plan_keys(const PlanArgs A, int nb) {
+inline __global__ void k_plan_keys(const PlanArgs A, int nb) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nb * A.Tl) return;
     const int ib = g / A.Tl, job = g - ib * A.Tl;
@@ -2099,7 +2099,7 @@ __global__ void k_plan_keys(const PlanArgs A, int nb) {
     for (int r = 0; r < 8; ++r) dst[r] = K.k[r];
 }
 
-__global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
+inline __global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
     const int ib = blockIdx.y / A.Tl, job = blockIdx.y - ib * A.Tl;
     const uint32_t rung = (uint32_t)(A.rung_begin + job);
     const uint64_t it = A.iter0 + (uint64_t)ib;
@@ -2156,7 +2156,7 @@ __global__ __launch_bounds__(256) void k_plan_draws(const PlanArgs A) {
 // meets slot prp_t(c) of rung t (a keyed pseudo-random matching per pair, computed inline - one
 // permutation per pair has the same distribution as the reference's two).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pt_invert(const int64_t* __restrict__ iperm, int32_t* __restrict__ inv, int npairs, int W) {
+inline __global__ void k_pt_invert(const int64_t* __restrict__ iperm, int32_t* __restrict__ inv, int npairs, int W) {
     const int64_t n = (int64_t)npairs * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(i / W);
@@ -2165,7 +2165,7 @@ __global__ void k_pt_invert(const int64_t* __restrict__ iperm, int32_t* __restri
 }
 
 // thread c follows column c: rows j = 0..T-2 of iperm/i1perm are the pairs i = T-1-j.
-__global__ void k_pt_chain(const int64_t* __restrict__ iperm, const int64_t* __restrict__ i1perm,
+inline __global__ void k_pt_chain(const int64_t* __restrict__ iperm, const int64_t* __restrict__ i1perm,
                            const int32_t* __restrict__ inv, const double* __restrict__ u_swap,
                            int32_t* __restrict__ colslot, int32_t* __restrict__ colk,
                            double* __restrict__ colu, int T, int W) {
@@ -3005,7 +3005,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
 // launch (parity API, sharded ladder, generic row widths, T > 64, end of a hens_step call).
 // Lane-parallel where the reference's arithmetic allows: ratios, dS, deltaT per lane; the cumsum
 // stays a sequential left-to-right sum like np.cumsum; reciprocal and update per lane again.
-__global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
+inline __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NTHREADS = 256;
     const int T = A.T, tid = threadIdx.x;
@@ -3078,7 +3078,7 @@ __global__ __launch_bounds__(256) void k_adapt(const AdaptArgs A) {
 
 // debug (hens_debug_draws): the Philox-mode PT draws of iteration `it` in the form the cascade consumes them -
 // slot[t][c] = slot of rung t that column c visits, u[j][c] = the swap uniform of pair (T-1-j, T-2-j) on column c
-__global__ void k_debug_pt(int32_t* slot, double* u, int T, int W, int idx_bits, uint64_t seed, uint64_t it) {
+inline __global__ void k_debug_pt(int32_t* slot, double* u, int T, int W, int idx_bits, uint64_t seed, uint64_t it) {
     const int64_t n = (int64_t)T * W;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(e / W), c = (int)(e - (int64_t)t * W);
@@ -3088,7 +3088,7 @@ __global__ void k_debug_pt(int32_t* slot, double* u, int T, int W, int idx_bits,
 }
 
 // debug: materialise one PRP permutation (tests/test_hip_parity.py checks bijectivity and uniformity)
-__global__ void k_debug_prp(int32_t* out, int W, int idx_bits, uint64_t seed, uint64_t it, uint32_t purpose, uint32_t rung) {
+inline __global__ void k_debug_prp(int32_t* out, int W, int idx_bits, uint64_t seed, uint64_t it, uint32_t purpose, uint32_t rung) {
     const PrpKey K = prp_key(seed, it, purpose, rung);
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < W; c += gridDim.x * blockDim.x)
         out[c] = (int32_t)prp((uint32_t)c, K.k, idx_bits, (uint32_t)W);
@@ -3122,7 +3122,7 @@ struct HostLikeArgs {
     int32_t ns_x, soff_x;    // see StretchArgs::ns_x
 };
 
-__global__ void k_propose(const HostLikeArgs A) {
+inline __global__ void k_propose(const HostLikeArgs A) {
     const int Ns = A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : A.W - A.N0), s_off = A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0);
     const int64_t total = (int64_t)A.Tl * Ns * A.D;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -3142,7 +3142,7 @@ __global__ void k_propose(const HostLikeArgs A) {
     }
 }
 
-__global__ void k_accept_decide(const HostLikeArgs A) {
+inline __global__ void k_accept_decide(const HostLikeArgs A) {
     const int Ns = A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : A.W - A.N0), s_off = A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0);
     const int64_t total = (int64_t)A.Tl * Ns;
     for (int64_t wk = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; wk < total; wk += (int64_t)gridDim.x * blockDim.x) {
@@ -3184,7 +3184,7 @@ __global__ void k_accept_decide(const HostLikeArgs A) {
     }
 }
 
-__global__ void k_accept_rows(const HostLikeArgs A) {
+inline __global__ void k_accept_rows(const HostLikeArgs A) {
     const int Ns = A.ns_x ? A.ns_x : (A.split == 0 ? A.N0 : A.W - A.N0), s_off = A.ns_x ? A.soff_x : (A.split == 0 ? 0 : A.N0);
     const int64_t total = (int64_t)A.Tl * Ns * A.D;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -3198,7 +3198,7 @@ __global__ void k_accept_rows(const HostLikeArgs A) {
 }
 
 // column-order decisions -> the reference's k order (row j, element colk[j][c])
-__global__ void k_pt_sel_to_korder(const uint8_t* __restrict__ selcol, const int32_t* __restrict__ colk,
+inline __global__ void k_pt_sel_to_korder(const uint8_t* __restrict__ selcol, const int32_t* __restrict__ colk,
                                    uint8_t* __restrict__ selk, int npairs, int W) {
     const int64_t n = (int64_t)npairs * W;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -3216,7 +3216,7 @@ __global__ void k_pt_sel_to_korder(const uint8_t* __restrict__ selcol, const int
 constexpr int MAX_RANKS = 16;
 
 // counts[0..nranks) = rows this rank sends to each peer, counts[MAX_RANKS..) = rows it receives
-__global__ void k_xchg_count(const int32_t* __restrict__ srcfull, const int32_t* __restrict__ rank_of_rung,
+inline __global__ void k_xchg_count(const int32_t* __restrict__ srcfull, const int32_t* __restrict__ rank_of_rung,
                              int T, int W, int me, unsigned* __restrict__ counts) {
     __shared__ unsigned s_cnt[2 * MAX_RANKS];
     if (threadIdx.x < 2 * MAX_RANKS) s_cnt[threadIdx.x] = 0;
@@ -3235,7 +3235,7 @@ __global__ void k_xchg_count(const int32_t* __restrict__ srcfull, const int32_t*
 }
 
 // cursors[p] starts at the offset of peer p's segment in the send buffer
-__global__ void k_xchg_fill(const int32_t* __restrict__ srcfull, const int32_t* __restrict__ rank_of_rung,
+inline __global__ void k_xchg_fill(const int32_t* __restrict__ srcfull, const int32_t* __restrict__ rank_of_rung,
                             int T, int W, int me, int rung_begin, unsigned* __restrict__ cursors,
                             int32_t* __restrict__ send_slot, int32_t* __restrict__ send_dest) {
     const int64_t n = (int64_t)T * W;
@@ -3250,7 +3250,7 @@ __global__ void k_xchg_fill(const int32_t* __restrict__ srcfull, const int32_t* 
     }
 }
 
-__global__ void k_pack_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
+inline __global__ void k_pack_rows(const double* __restrict__ pool, const int32_t* __restrict__ loc,
                             const double* __restrict__ P, const int32_t* __restrict__ send_slot,
                             const int32_t* __restrict__ send_dest, double* __restrict__ out, int64_t nsend, int D) {
     const int64_t total = nsend * (D + 2);
@@ -3266,7 +3266,7 @@ __global__ void k_pack_rows(const double* __restrict__ pool, const int32_t* __re
     }
 }
 
-__global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ locnew, double* __restrict__ Pnew,
+inline __global__ void k_unpack_rows(double* __restrict__ pool, int32_t* __restrict__ locnew, double* __restrict__ Pnew,
                               const double* __restrict__ in, int64_t nrecv, int D, int W, int rung_begin,
                               int32_t free_off) {
     const int64_t total = nrecv * (D + 2);
@@ -3348,7 +3348,7 @@ struct PipeWaitArgs {
     uint32_t target;
     int32_t n, nranks;
 };
-__global__ void k_pipe_wait(const PipeWaitArgs A) {
+inline __global__ void k_pipe_wait(const PipeWaitArgs A) {
     const int i = threadIdx.x;
     const unsigned* f = nullptr;
     if (i < A.n) f = A.p[i];
@@ -3364,14 +3364,14 @@ struct PipeEpilogueArgs {
     uint32_t cp_sweep;
     int32_t push, cp_nblocks, cp_np, cp_nranks, cp_rank, cp_T, rung_begin, W, D;
 };
-__global__ void k_pipe_epilogue(const PipeEpilogueArgs A) {
+inline __global__ void k_pipe_epilogue(const PipeEpilogueArgs A) {
     if (A.rt_flag && threadIdx.x == 0) pipe_raise(A.rt_flag, A.rt_value);
     if (A.push) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T, A.rung_begin, A.W, A.D,
                                  A.cp_sweep, (int)threadIdx.x);
 }
 // my hottest rung after the stretch move -> hot neighbour, flag included (one workgroup).  Only for row widths
 // without a fast stretch kernel: those publish from their own accept phase (StretchArgs::pub_lp).
-__global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
+inline __global__ __launch_bounds__(1024) void k_pipe_pub(const PipeArgs A) {
     const PipeBox hot = pipe_box(A.box_hot, A.T, A.W, A.D);
     const int W = A.W;
     const size_t base = (size_t)(A.Tl - 1) * W;
@@ -3461,7 +3461,7 @@ __device__ __forceinline__ void pipe_bottom_block(const PipeArgs& A, const int c
 
 // The walk over my rungs (+ the virtual rung of the hot neighbour on top): k_pt_cascade on the extended
 // ladder; the pair across my top boundary is the first step of every column.
-__global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
+inline __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int T = A.T, W = A.W, Tl = A.Tl, D = A.D;
     const bool has_top = A.rung_begin + Tl < T, has_bot = A.rung_begin > 0;
@@ -3628,23 +3628,23 @@ __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs A) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
+inline __global__ __launch_bounds__(256) void k_pipe_bottom(const PipeArgs A) {
     __shared__ int32_t s_src[PIPE_COLS];
     __shared__ int32_t s_below[PIPE_COLS];
     pipe_bottom_block(A, blockIdx.x * PIPE_COLS, s_src, s_below, nullptr, nullptr);
 }
 
 // ---- hens_pipe_selftest: the three access patterns the pipeline relies on, between two processes ----------
-__global__ void k_probe_put(double* peer_buf, unsigned* peer_flag, int n, double tag) {
+inline __global__ void k_probe_put(double* peer_buf, unsigned* peer_flag, int n, double tag) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) sys_store(peer_buf + i, tag + i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) pipe_raise(peer_flag, 1u);
 }
-__global__ void k_probe_fill(double* buf, int n, double tag) {     // system-scope stores into my own cached memory
+inline __global__ void k_probe_fill(double* buf, int n, double tag) {     // system-scope stores into my own cached memory
     for (int i = threadIdx.x; i < n; i += blockDim.x) sys_store(buf + i, tag + i);
 }
-__global__ void k_probe_check(const unsigned* my_flag, const double* my_buf, const double* peer_cached, int n,
+inline __global__ void k_probe_check(const unsigned* my_flag, const double* my_buf, const double* peer_cached, int n,
                               double tag_in, double tag_pull, int check_put, int check_pull, long long budget,
                               unsigned* result) {
     __shared__ unsigned bad;

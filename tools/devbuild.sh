@@ -3,5 +3,5 @@
 #   -> build_ab/libhens_<name>.so ; run with HENS_LIB=$PWD/build_ab/libhens_<name>.so
 R=$(git rev-parse --show-toplevel); N=${1:-dev}; shift
 mkdir -p $R/build_ab
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -DHENS_DEV_BUILD "$@" -I$R/include \
-    $R/eryn_amd/csrc/hens.hip -o $R/build_ab/libhens_$N.so -L/opt/rocm/lib -lhsa-runtime64 2>&1 | grep -E "error|Error" ; ls -la $R/build_ab/libhens_$N.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -Wno-cuda-compat -DHENS_DEV_BUILD "$@" -I$R/include \
+    $R/eryn_amd/csrc/hens.hip $R/eryn_amd/csrc/hens_k_dense.hip -o $R/build_ab/libhens_$N.so -L/opt/rocm/lib -lhsa-runtime64 2>&1 | grep -E "error|Error" ; ls -la $R/build_ab/libhens_$N.so
