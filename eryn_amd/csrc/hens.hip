@@ -409,7 +409,7 @@ size_t generic_lds_bytes(int D, int* RS_out) {
     return (size_t)TILE * RS * 8 + (size_t)TILE * 8 + (size_t)4 * TILE * 8 + 4 * (size_t)TILE * 4;
 }
 size_t fast_lds_bytes(int D, int NW) {
-    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 128) * 8 + (4 * (size_t)TILE + 128) * 4;
+    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 128) * 8 + (4 * (size_t)TILE + 128) * 4 + mf_lds_extra(D);
 }
 
 int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int ntiles) {
@@ -1741,7 +1741,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRY(dalloc(c, &c->hi, (size_t)c->D));
     TRY(dalloc(c, &c->mu, (size_t)c->D));
     TRY(dalloc(c, &c->prec, (size_t)c->D * c->D));
-    TRY(dalloc(c, &c->prec_sym, (size_t)(c->D / 2 + 1) * (c->D + 2)));
+    TRY(dalloc(c, &c->prec_sym, std::max<size_t>((size_t)(c->D / 2 + 1) * (c->D + 2), (size_t)MF64_END)));
     TRY(dalloc(c, &c->ad_ring, (size_t)4 * c->T));
     {
         std::vector<double> neg((size_t)4 * c->T, -1.0);
@@ -1959,7 +1959,19 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
             // blocked form (see like_partial): four H = D / 4 blocks: [4 diagonal blocks][6 cross blocks (0,1) (0,2) (0,3)
             // (1,2) (1,3) (2,3)]
             const int H = D / 4, BLK = (H / 2) * (H + 2);
-            sym.assign((size_t)4 * BLK + (size_t)6 * H * H, 0.0);
+            sym.assign((size_t)4 * BLK + (size_t)6 * H * H + (D == 64 ? (size_t)MF64_STEPS * 64 : 0), 0.0);
+            if (D == 64) {
+                // the matrix-pipe operands (like_tile_mf64): step c = (I, J >= I, s) in order, mf[c][lane] = M_IJ[lane % 16][4 s +
+                // lane / 16], M_II = A_II, M_IJ = A_IJ + A_JI^T
+                static_assert(MF64_OFF == 4 * 144 + 6 * 256, "prec_sym layout at D = 64");
+                for (int cidx = 0; cidx < MF64_STEPS; ++cidx) {
+                    const int I = mf64_I(cidx), J = mf64_J(cidx), st = mf64_S(cidx);
+                    for (int l = 0; l < 64; ++l) {
+                        const int r = 16 * I + l % 16, k = 16 * J + 4 * st + l / 16;
+                        sym[(size_t)MF64_OFF + (size_t)cidx * 64 + l] = I == J ? prec[(size_t)r * D + k] : prec[(size_t)r * D + k] + prec[(size_t)k * D + r];
+                    }
+                }
+            }
             for (int b = 0; b < 4; ++b) pack_block(b * H, H, sym.data() + (size_t)b * BLK);
             int x = 0;
             for (int bi = 0; bi < 4; ++bi)

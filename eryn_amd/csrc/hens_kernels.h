@@ -1008,6 +1008,116 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
     return part;
 }
 
+// ---- dense Gaussian at D = 64, round 4: the quadratic form on the FP64 MATRIX pipe ------------------------------------------------
+// Measured on gfx950 (tools/probe/mfma_f64_rate.hip): a wave issues v_fma_f64 once per 8.5 cycles (7.5 multiply-adds per clock and
+// SIMD), v_mfma_f64_16x16x4_f64 once per 64 cycles (16 per clock and SIMD).  Phase C at D = 64 is bound by exactly that issue rate:
+// cut builds at 8 x 16384 x 64 give 8.1 us of a 27.0 us first launch (7.2 of 24.7 in the second) for the blocked symmetric VALU form
+// - 8 waves x ~290 FMAs per tile, 19 700 SIMD-cycles, the launch's 1 024 tiles on 1 024 SIMDs.  (At D = 32 the same phase is bound
+// by LDS reads and the matrix pipe bought nothing: tools/probe/mfma_like_d32_*.)  With the centred proposal q cut into four blocks
+// of 16 coordinates,
+//     q^T A q = sum_I q_I . y_I,     y_I = sum_{J >= I} M_IJ q_J,     M_II = A_II,  M_IJ = A_IJ + A_JI^T  (J > I)
+// is 10 block products of 16 x 16, each 4 MFMA steps of 16 x 16 x 4 per 16 walkers: A operand M_IJ[r][4 s + k] (the same for every
+// workgroup: prec_sym's last part, mf[step][lane] = M[lane % 16][4 s + lane / 16], requested before the barrier), B operand
+// q[16 J + 4 s + k][walker] out of the LDS tile (the tile holds q itself - phase E stores accepted rows from it; centring it would
+// cost 16 registers for the proposal across phase C, one workgroup per CU - so mu is subtracted on the way, out of a 512-byte LDS
+// copy of its own: MF_LDS_EXTRA behind each kernel's arrays).  The 40 (I, J, s) steps are dealt to the eight waves five each, in order - a wave
+// meets at most two row blocks I - and every wave runs its steps for all four 16-walker blocks (20 MFMAs: 1 280 cycles of its SIMD's
+// matrix pipe, two waves per SIMD; the VALU form took 4 900 per SIMD), then dots its partial y with q_I: the result tile holds rows
+// g, g + 4, g + 8, g + 12 of walker l % 16 in lane l = 16 g + l % 16 (tools/probe/mfma_f64_layout.cpp), so 4 FMAs per row block
+// and one sum over the four 16-lane rows (gfx950's row swaps, VALU only).  Eight partial sums per walker, added in wave order in
+// phase D as before.  Same value as the VALU form to ~1e-15 relative (another summation order; the oracle comparison has 1e-13).
+// EVERY dense D = 64 path goes through here (k_stretch_fast in all its modes and k_split1_pt, single GPU and pipeline rank), so they
+// stay bit-identical to one another.
+constexpr int MF64_OFF = 4 * ((16 / 2) * (16 + 2)) + 6 * 16 * 16;        // behind the blocked sym_quad form in prec_sym (D = 64)
+constexpr int MF64_STEPS = 40;
+constexpr int MF64_END = MF64_OFF + MF64_STEPS * 64;
+__host__ __device__ constexpr size_t mf_lds_extra(int D) { return D == 64 ? 64 * 8 : 0; }   // mu in LDS (all likelihood kinds: one size per width)
+typedef double d4_t __attribute__((ext_vector_type(4)));
+struct MfRegs { double m[5]; };
+template <int DT, int LIKE, int NW>
+constexpr bool like_mf() { return LIKE == LIKE_DENSE && DT == 64 && NW == 8; }
+// step c = 0..39 in the order (I, J >= I, s)
+constexpr int mf64_I(int c) { return c < 16 ? 0 : (c < 28 ? 1 : (c < 36 ? 2 : 3)); }
+constexpr int mf64_base(int I) { return I == 0 ? 0 : (I == 1 ? 16 : (I == 2 ? 28 : 36)); }
+constexpr int mf64_J(int c) { return mf64_I(c) + (c - mf64_base(mf64_I(c))) / 4; }
+constexpr int mf64_S(int c) { return (c - mf64_base(mf64_I(c))) % 4; }
+// the matrix operand of the wave's five steps, requested before the barrier in front of phase C (a no-op elsewhere)
+template <int DT, int LIKE, int NW>
+__device__ __forceinline__ MfRegs like_prefetch(int lane, int wv, const double* prec_sym_p) {
+    MfRegs r;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) r.m[t] = 0.0;
+    if constexpr (like_mf<DT, LIKE, NW>()) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) r.m[t] = prec_sym_p[MF64_OFF + (5 * wv + t) * 64 + lane];
+    }
+    return r;
+}
+// sum over the four 16-lane rows of a wave, in every lane (lanes l, l ^ 16, l ^ 32, l ^ 48): gfx950's row swaps - VALU only, no LDS
+// round trip
+__device__ __forceinline__ double sum_rows_f64(double p) {
+    unsigned lo = (unsigned)__double2loint(p), hi = (unsigned)__double2hiint(p);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double x = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = (unsigned)__double2loint(x); hi = (unsigned)__double2hiint(x);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+// wave WI's share for the tile's 64 walkers: lane l returns walker l's partial sum.  CEN: the tile holds q - mu.
+template <int WI, bool CEN>
+__device__ __forceinline__ double mf64_wave(const double* qtile, int lane, const double* mu_p, const MfRegs& mf) {
+    constexpr int RS = 66, C0 = 5 * WI;
+    constexpr int IA = mf64_I(C0), IB = mf64_I(C0 + 4);          // the (at most two) row blocks of this wave's steps
+    const int j = lane & 15, g = lane >> 4;
+    double mk[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, mra[4] = {0.0, 0.0, 0.0, 0.0}, mrb[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!CEN) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) mk[t] = mu_p[16 * mf64_J(C0 + t) + 4 * mf64_S(C0 + t) + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mra[r] = mu_p[16 * IA + g + 4 * r]; mrb[r] = mu_p[16 * IB + g + 4 * r]; }
+    }
+    double psel = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {                                // (one accumulator chain per block: the pipe issues a dependent MFMA
+        const double* qw = qtile + (16 * b + j) * RS;            //  as fast as an independent one, and four chains cost 64 VGPRs)
+        d4_t accA = d4_t{0.0, 0.0, 0.0, 0.0}, accB = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const double bq = qw[16 * mf64_J(C0 + t) + 4 * mf64_S(C0 + t) + g] - mk[t];      // this lane's coordinate of the step
+            if (mf64_I(C0 + t) == IA) accA = __builtin_amdgcn_mfma_f64_16x16x4f64(mf.m[t], bq, accA, 0, 0, 0);
+            else accB = __builtin_amdgcn_mfma_f64_16x16x4f64(mf.m[t], bq, accB, 0, 0, 0);
+        }
+        double p = (qw[16 * IA + g] - mra[0]) * accA[0];         // rows g, g + 4, g + 8, g + 12 of walker 16 b + j
+        p = fma(qw[16 * IA + g + 4] - mra[1], accA[1], p);
+        p = fma(qw[16 * IA + g + 8] - mra[2], accA[2], p);
+        p = fma(qw[16 * IA + g + 12] - mra[3], accA[3], p);
+        if (IB != IA) {
+            p = fma(qw[16 * IB + g] - mrb[0], accB[0], p);
+            p = fma(qw[16 * IB + g + 4] - mrb[1], accB[1], p);
+            p = fma(qw[16 * IB + g + 8] - mrb[2], accB[2], p);
+            p = fma(qw[16 * IB + g + 12] - mrb[3], accB[3], p);
+        }
+        p = sum_rows_f64(p);
+        psel = (g == b) ? p : psel;                              // (lane group g keeps block g's walkers: lane l = walker l)
+    }
+    return psel;
+}
+// one 64-walker tile: the eight partial sums of every walker into srow[wave * TILE + walker]
+template <bool CEN>
+__device__ __forceinline__ void like_tile_mf64(const double* qtile, double* srow, int lane, int wv, const double* mu_p, const MfRegs& mf) {
+    double part = 0.0;
+    switch (wv) {
+#define HENS_MF_CASE(WI) case WI: part = mf64_wave<WI, CEN>(qtile, lane, mu_p, mf); break;
+        HENS_MF_CASE(0) HENS_MF_CASE(1) HENS_MF_CASE(2) HENS_MF_CASE(3)
+        HENS_MF_CASE(4) HENS_MF_CASE(5) HENS_MF_CASE(6) HENS_MF_CASE(7)
+#undef HENS_MF_CASE
+        default: break;
+    }
+    srow[wv * TILE + lane] = part;
+}
+
 // Phase C of the two production kernels: every wave's partial sum into s_part[wave][walker].  Dense Gaussian at D = 32 (8 waves):
 // the phase is bound by LDS bandwidth, not by FP64 issue - every wave reads its walker's whole centred row (64 lanes x 256 B per
 // wave, 16 waves per CU: 2 048 clocks of the CU's 128 B / clock) to use it for 2 of the 16 row pairs.  Half the waves now read
@@ -1015,7 +1125,11 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 // same bits, half the LDS traffic.
 template <int DT, int LIKE, int NW, bool CEN>
 __device__ __forceinline__ void like_partials(const double* qtile, double* s_part, int lane, int wv, bool inbox, const double* mu_p,
-                                              const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b) {
+                                              const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b, const MfRegs& mf) {
+    if constexpr (like_mf<DT, LIKE, NW>()) {          // (walkers outside the prior box ride along: a walker is a column of the product)
+        like_tile_mf64<CEN>(qtile, s_part, lane, wv, mu_p, mf);
+        return;
+    }
 #ifndef HENS_NO_LIKE_PAIR
     if constexpr (LIKE == LIKE_DENSE && DT == 32 && NW == 8 && CEN) {
         if (wv >= NW / 2) return;
@@ -1089,10 +1203,14 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     int32_t* s_dst = s_rc + TILE;
     int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [128] swap counts (ad_on)
+    double* s_mu = reinterpret_cast<double*>(s_cnt + 128);               // [64] D = 64: mu for the matrix-pipe phase C (mf_lds_extra)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (like_mf<DT, LIKE, NW>()) {
+        if (tid >= NW * 64 - 32) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - 32))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - 32)));
+    }
     constexpr int ADW = 1;                      // the wave that runs the early ladder adaptation (a 9th, adaptation-only
                                                 // wave was measured: two 9-wave workgroups do not pack onto one CU)
     int bx = blockIdx.x, tl = blockIdx.y;
@@ -1588,6 +1706,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         for (int q = 0; q < 8; ++q)
             if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
     }
+    const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);   // (the matrix operand of phase C: in flight across the barrier)
     HENS_TRACE(3);
     lds_barrier();
     HENS_TRACE(4);
@@ -1625,7 +1744,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // ---- phase C: likelihood, lane per walker, precision rows split over the waves ----------------
     {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, like_mf<DT, LIKE, NW>() ? s_mu : A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b, mfr);
     }
     HENS_TRACE(5);
     lds_barrier();
@@ -2418,10 +2537,11 @@ struct FusedArgs {
 };
 
 // (pipe: the cascade tables hold one more rung - what the hot neighbour's columns carry - and the bottom boundary's lists)
-__host__ __device__ inline size_t fused_lds_bytes(int D, int NW, bool pipe = false) {
+__host__ __device__ constexpr size_t fused_lds_base(int D, int NW, bool pipe = false) {
     return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64 + (pipe ? 2 * TILE : 0)) * 8 +
            (2 * 2 * TILE + 5 * TILE + 64 + (pipe ? 3 * TILE : 0)) * 4;
 }
+__host__ __device__ inline size_t fused_lds_bytes(int D, int NW, bool pipe = false) { return fused_lds_base(D, NW, pipe) + mf_lds_extra(D); }
 
 // SHORT: the ladder length does not divide 128 - cb T < 128 slots and cb T / 2 < 64 moving walkers per workgroup.  An
 // instantiation of its own: with run-time bounds the full-tile launch lost its compile-time-true row guards, 0.2 us at
@@ -2467,10 +2587,14 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     uint32_t* smask = reinterpret_cast<uint32_t*>(s_el + TILE);          // [cb][MW] swap bitmask per column
     int32_t* s_src = reinterpret_cast<int32_t*>(smask + 64);             // PIPE [TILE] bottom boundary: row that moves down
     int32_t* s_yrow = s_src + TILE;                                      // PIPE [TILE] row (cold neighbour's pool) that moves up
+    double* s_mu = reinterpret_cast<double*>(smem_raw + fused_lds_base(DT, NW, PIPE));   // [64] D = 64: mu for the matrix-pipe phase C
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (like_mf<DT, LIKE, NW>()) {
+        if (tid >= NW * 64 - 32) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - 32))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - 32)));
+    }
     const int TG = A.T;                                                  // the whole ladder
     const int T = PIPE ? A.Tl : A.T;                                     // the rungs this workgroup holds
     const int W = A.W, CB = PIPE ? A.cbl : A.cb, CS = PIPE ? A.cbl_shift : A.cb_shift;
@@ -2692,7 +2816,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // ---- phase C: likelihood ------------------------------------------------------------------------------
     if (!nomove) {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
+        // (the matrix operand is requested here, not in front of the barrier as in k_stretch_fast)
+        const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);
+        like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, like_mf<DT, LIKE, NW>() ? s_mu : A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b, mfr);
     }
     FUSED_TRACE(4);
     lds_barrier();
