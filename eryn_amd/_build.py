@@ -15,7 +15,7 @@ UNITS = [("hens", "hens.hip", [])] + [(f"hens_k_{k}_{part}", f"hens_k_{k}.hip", 
 SOURCES = sorted({os.path.join(SRC_DIR, u[1]) for u in UNITS})
 DEPS = SOURCES + [os.path.join(SRC_DIR, h) for h in ("hens_kernels.h", "hens_rj.h", "hens_iter.h", "hens_aql.h", "hens_ktable.h", "hens_ktable.inc")] + [
     os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-cuda-compat"]   # (inline __global__: see hens_kernels.h)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-cuda-compat"] + os.environ.get("HENS_BUILD_DEFS", "").split()   # (inline __global__: see hens_kernels.h)
 LINK = ["-L/opt/rocm/lib", "-lhsa-runtime64"]      # (direct AQL dispatch of the stepping launches: csrc/hens_aql.h)
 
 
@@ -45,14 +45,32 @@ def build(force=False, verbose=False):
     for name, src, defs in UNITS:
         obj = os.path.join(OBJ_DIR, name + ".o")
         cmd = [hipcc] + FLAGS + defs + include + ["-c", os.path.join(SRC_DIR, src), "-o", obj]
+        # an object is kept if it is newer than everything its unit includes (the kernel units see neither hens.hip nor the RJ / AQL
+        # headers) and was made by the same command
+        deps = [os.path.join(SRC_DIR, src), os.path.join(os.path.dirname(HERE), "include", "hipensemble.h"), os.path.abspath(__file__)] + [
+            os.path.join(SRC_DIR, h) for h in (("hens_kernels.h", "hens_iter.h", "hens_ktable.h") +
+                                               (("hens_rj.h", "hens_aql.h") if name == "hens" else ("hens_ktable.inc",)))]
+        stamp = obj + ".cmd"
+        fresh = (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd) and
+                 all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps))
+        if fresh and not os.environ.get("HENS_BUILD_ALL"):
+            jobs.append((obj, cmd, None, stamp))
+            continue
         if verbose:
             print(" ".join(cmd), flush=True)
-        jobs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        jobs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), stamp))
     failed = []
-    for obj, cmd, proc in jobs:            # (7 compilers side by side: about 1.5 GB each at their peak)
+    for obj, cmd, proc, stamp in jobs:     # (7 compilers side by side: about 1.5 GB each at their peak)
+        if proc is None:
+            continue
         out, _ = proc.communicate()
         if proc.returncode != 0:
             failed.append(" ".join(cmd) + "\n" + out)
+            if os.path.exists(stamp):
+                os.remove(stamp)
+        else:
+            with open(stamp, "w") as f:
+                f.write(" ".join(cmd))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[0] for j in jobs] + ["-o", LIB_PATH] + LINK

@@ -2787,6 +2787,12 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
         }
         M.leaf_logp[b] = leaf_logp[b];
     }
+    {   // data points on a uniform grid (np.linspace): the sine leaves' rotation scheme of k_rj applies
+        const double dt = ndata > 1 ? (t[ndata - 1] - t[0]) / (double)(ndata - 1) : 0.0;
+        double tmax = 0.0, dev = 0.0;
+        for (int i = 0; i < ndata; ++i) { tmax = std::max(tmax, std::fabs(t[i])); dev = std::max(dev, std::fabs(t[i] - (t[0] + (double)i * dt))); }
+        M.t_step64 = (ndata > 64 && dt > 0.0 && dev <= 4.0 * 2.220446049250313e-16 * std::max(tmax, std::fabs(dt))) ? 64.0 * dt : 0.0;
+    }
     M.ind_off = off;
     M.RW = c->D;
     if (off + nbranches > c->D) return fail(c, HENS_ERR_INVALID, "record width ndim = %d cannot hold %d coordinates + %d masks", c->D, off, nbranches);

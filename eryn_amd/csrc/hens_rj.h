@@ -35,6 +35,7 @@ struct RjModel {
     double leaf_logp[RJ_MAX_BRANCH];                // sum_d log(1 / (hi_d - lo_d)) accumulated by the host in the reference's order
     double mh_scale[RJ_MAX_BRANCH][RJ_ND];          // Philox mode: standard deviations of the in-model Gaussian step
     double sigma;
+    double t_step64;                                // the data points lie on a uniform grid: 64 grid steps (else 0), see k_rj
 };
 
 struct RjArgs {
@@ -64,6 +65,44 @@ struct RjArgs {
     int32_t tm_mode, trace_n;               // (trace_n: waves that stamp their phases into `trace`, dev aid)
     unsigned long long* trace;
 };
+
+// exp(x) for the pulses' arguments x = -(t - b)^2 / (2 c^2) <= 0 (Tang's table method: x = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128,
+// exp(x) = 2^m T[j] (1 + r + r^2 (1/2 + r (1/6 + r (1/24 + r / 120)))), T[j] = 2^(j/64) out of LDS): 14 FP64-rate operations where
+// the library routine's |r| <= ln2 / 2 needs a degree-11 polynomial and, with its range checks, ~25.  The pulses' exps were half of
+// k_rj's VALU instructions.  Error <= 1.01 * 2^-52 relative (200 000 random arguments in [-700, 0] against 60-digit arithmetic,
+// tools/probe/exp_tang_check.py) - the library's and NumPy's are each within 1 ulp of the true value as well; underflow is gradual
+// (v_ldexp_f64), x < -745.2 gives 0, NaN stays NaN.
+__device__ const double RJ_EXP_TAB[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+__device__ __forceinline__ double rj_exp_neg(double x, const double* tab) {
+    x = x < -800.0 ? -800.0 : x;
+    const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);           // 64 / ln 2
+    const int k = (int)kd;
+    double r = fma(-kd, 0x1.62e42fee00000p-7, x);                           // ln 2 / 64 in two parts: the first product is exact
+    r = fma(-kd, 0x1.a39ef35793c76p-39, r);
+    const double r2 = r * r;
+    double t = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    t = fma(r, t, 1.0 / 6.0);
+    t = fma(r, t, 0.5);
+    const double q = fma(r2, t, r);
+    const double tj = tab[k & 63];
+    return ldexp(fma(tj, q, tj), k >> 6);
+}
 
 // ndarray.sum(axis=-1) of v[0..n): NumPy's pairwise order (n < 8: a plain loop from 0.0; 8 <= n <= 128: eight partial
 // sums, the tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail).  Checked against NumPy for n = 1..20.
@@ -118,10 +157,15 @@ __device__ __forceinline__ double rj_accept_uniform(uint64_t seed, uint64_t it, 
 
 constexpr int RJ_WAVES = 4;        // walkers per workgroup
 
-__global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
+// (four waves per SIMD: the kernel is bound by FP64 issue and hides its latencies with waves; with the sine rotation scheme the
+//  allocator would take 132 VGPRs - three waves - if it were not held to 128)
+__global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_rj(const RjArgs A) {
     __shared__ double s_cur[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_q[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_leafv[RJ_WAVES][32];
+    __shared__ double s_rot[RJ_WAVES][2][32];
+    __shared__ double s_tab[64];                            // rj_exp_neg's table (every wave writes the same 64 values, then reads)
+    s_tab[threadIdx.x & 63] = RJ_EXP_TAB[threadIdx.x & 63];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t gw = (int64_t)blockIdx.x * RJ_WAVES + wv;
@@ -270,7 +314,26 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
     int sig_e = 0;
     const bool sig_pow2 = frexp(M.sigma, &sig_e) == 0.5 && sig_e > -1000 && sig_e < 1000;
     const double sig_inv = 1.0 / M.sigma;
+    // Sine leaves on a uniform grid (production path, resident templates): a lane's points lane, lane + 64, ... are 64 grid steps
+    // apart, so a * sin(w t + c) at the later points of a chunk is a rotation of (sin, cos) at its first by the leaf's angle w * 64 dt
+    // - one sincos per chunk of four points and 4 FMA-rate operations per further point instead of a sin each (the library's FP64
+    // sin is ~100 VALU operations: argument reduction in double-double + polynomial, five times an exp).  Against the direct
+    // formula the ARGUMENT differs by the rounding of w t_k (<= 130 eps ~ 1.5e-14, what the reference's own products carry) and each
+    // rotation adds ~1 eps: the log-likelihood moves by ~1e-15 relative (bar 1e-13; the replay tests run this path).  The parity API
+    // (tm == nullptr) keeps the reference's sin per point.
+    const bool rot = A.tm != nullptr && M.t_step64 != 0.0;
     constexpr int NPT = 4, MAXCH = 2;                        // (template points per lane and chunk; chunks a lane keeps: ndata <= 512)
+    auto sine_points = [&](const double a, const double w, const double c, const double sd, const double cd, const double (&ti)[NPT], double (&out)[NPT], const double sg) {
+        double sk, ck;
+        sincos(w * ti[0] + c, &sk, &ck);
+        out[0] += sg * (a * sk);
+#pragma unroll
+        for (int k = 1; k < NPT; ++k) {
+            const double sn = fma(sk, cd, ck * sd), cn = fma(ck, cd, -(sk * sd));
+            sk = sn; ck = cn;
+            out[k] += sg * (a * sk);
+        }
+    };
     double* tmrow = A.tm ? A.tm + (size_t)A.loc[gw] * M.ndata : nullptr;
     const bool by_diff = A.tm && A.tm_mode == 1 && A.mode == RJ_MODE_BD && M.ndata <= 64 * NPT * MAXCH;
     double tmk[MAXCH][NPT];                                  // the proposal's template at this lane's points (stored on acceptance)
@@ -303,12 +366,18 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
 #pragma unroll
                         for (int k = 0; k < NPT; ++k) {
                             const double dx = ti[k] - bb;
-                            tmk[ch][k] += sg * (a * exp(-(dx * dx) * inv));
+                            tmk[ch][k] += sg * (a * rj_exp_neg(-(dx * dx) * inv, s_tab));
                         }
                     } else {
                         const double w = 2 * M_PI * bb;
+                        if (rot) {
+                            double sd, cd;
+                            sincos(w * M.t_step64, &sd, &cd);
+                            sine_points(a, w, c, sd, cd, ti, tmk[ch], sg);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < NPT; ++k) tmk[ch][k] += sg * (a * sin(w * ti[k] + c));
+                            for (int k = 0; k < NPT; ++k) tmk[ch][k] += sg * (a * sin(w * ti[k] + c));
+                        }
                     }
                 }
 #pragma unroll
@@ -349,6 +418,14 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
                 for (int k = 0; k < NPT; ++k) sub[k] = 0.0;
                 uint32_t m = mask[b];
                 const bool pulse = M.kind[b] == RJ_KIND_PULSE;
+                if (!pulse && rot) {                 // every leaf's rotation by 64 grid steps, a lane per leaf
+                    if (lane < M.nl[b]) {
+                        double sd, cd;
+                        sincos((2 * M_PI * q[M.off[b] + lane * RJ_ND + 1]) * M.t_step64, &sd, &cd);
+                        s_rot[wv][0][lane] = sd; s_rot[wv][1][lane] = cd;
+                    }
+                    RJ_LDS_SYNC();
+                }
                 while (m) {
                     const int n = __builtin_ctz(m);
                     m &= m - 1u;
@@ -358,12 +435,16 @@ __global__ __launch_bounds__(RJ_WAVES * 64) void k_rj(const RjArgs A) {
 #pragma unroll
                         for (int k = 0; k < NPT; ++k) {
                             const double dx = ti[k] - bb;
-                            sub[k] += a * exp(-(dx * dx) * inv);                               // tests/test_eryn.py:38-40
+                            sub[k] += a * rj_exp_neg(-(dx * dx) * inv, s_tab);                               // tests/test_eryn.py:38-40
                         }
                     } else {
                         const double w = 2 * M_PI * bb;
+                        if (rot) {
+                            sine_points(a, w, c, s_rot[wv][0][n], s_rot[wv][1][n], ti, sub, 1.0);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < NPT; ++k) sub[k] += a * sin(w * ti[k] + c);          // tests/test_eryn.py:67-69
+                            for (int k = 0; k < NPT; ++k) sub[k] += a * sin(w * ti[k] + c);      // tests/test_eryn.py:67-69
+                        }
                     }
                 }
 #pragma unroll
