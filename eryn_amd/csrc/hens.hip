@@ -174,6 +174,9 @@ struct hens_ctx_impl {
     double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
     int64_t rj_tm_ndata = 0;
     bool rj_tm_valid = false;
+    unsigned* rj_ad_flag = nullptr;  // the folded adaptation's "ladder published" word (RjArgs::ad_flag), serial of the last folding launch
+    uint32_t rj_ad_serial = 0;
+    bool rj_defer_adapt = false;     // hens_rj_step: the adaptation behind a cascade rides in the next k_rj launch
     // ladder sharding over RCCL point-to-point messages inside the library (hens_comm_init): the staged transport's exchanges
     void* comm = nullptr;                   // ncclComm_t
     bool comm_on = false;               // ... and they belong to the rows as they are (false after an upload / a parity-API move)
@@ -1523,8 +1526,29 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     a.fill = c->cfg.fill_value;
     a.iter = c->iter; a.seed = c->cfg.seed;
     a.Tl = c->Tl; a.W = c->W; a.rung_begin = c->cfg.rung_begin; a.tempered = c->cfg.tempered; a.mode = mode; a.branch = branch;
+    if (c->adapt_pending) {
+        // the adaptation behind the last cascade: inside this launch (production launches that test against the ladder, up to 64
+        // rungs: RjArgs::ad), else as a launch of its own in front of it
+        if (c->rj_defer_adapt && a.tm && mode != RJ_MODE_EVAL && c->T <= 64 && c->Tl == c->T && c->rj_ad_flag && !c->adapt_src) {
+            a.ad = adapt_args(c, c->adapt_pending_adaptive, c->betas[c->bcur], c->betas[c->bcur]);
+            a.ad_fold = 1;
+            a.ad_serial = ++c->rj_ad_serial;
+            a.ad_flag = c->rj_ad_flag;
+            if (c->adapt_pending_adaptive) c->adapt_time += 1;               // tempering.py:596
+            c->adapt_pending = false;
+        } else {
+            flush_adapt(c);
+        }
+    }
     const int64_t n = (int64_t)c->Tl * c->W;
-    hipLaunchKernelGGL(k_rj, dim3((unsigned)((n + RJ_WAVES - 1) / RJ_WAVES)), dim3(RJ_WAVES * 64), 0, c->stream, a);
+    const dim3 grid((unsigned)((n + RJ_WAVES - 1) / RJ_WAVES)), block(RJ_WAVES * 64);
+    const int tmm = a.tm ? a.tm_mode : -1;            // the instantiation: (mode, template scheme), see k_rj
+#define RJ_CASE(MODE_, TMM_) if (mode == MODE_ && tmm == TMM_) hipLaunchKernelGGL((k_rj<MODE_, TMM_>), grid, block, 0, c->stream, a); else
+    RJ_CASE(RJ_MODE_EVAL, -1) RJ_CASE(RJ_MODE_EVAL, 0) RJ_CASE(RJ_MODE_EVAL, 2)
+    RJ_CASE(RJ_MODE_MH, -1) RJ_CASE(RJ_MODE_MH, 0)
+    RJ_CASE(RJ_MODE_BD, -1) RJ_CASE(RJ_MODE_BD, 1)
+        return fail(c, HENS_ERR_INVALID, "k_rj: no instantiation for mode %d with template scheme %d", mode, tmm);
+#undef RJ_CASE
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(c, HENS_ERR_HIP, "k_rj launch failed: %s", hipGetErrorString(e));
     return HENS_OK;
@@ -1563,7 +1587,7 @@ void rj_cascade(hens_ctx_impl* c, uint64_t key, bool adapt) {
     c->adapt_pending = true;
     c->adapt_pending_adaptive = adapt && c->cfg.adaptive != 0;      // rj.py:381-382: swaps without adaptation after the RJ move
     c->adapt_src = nullptr;
-    flush_adapt(c);
+    if (!c->rj_defer_adapt) flush_adapt(c);      // (hens_rj_step: the next k_rj launch adapts, see rj_launch)
 }
 
 }  // namespace
@@ -2933,6 +2957,16 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
         if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2))) return r;
         c->rj_tm_valid = true;
     }
+    static const bool fold_off = getenv("HENS_NO_FOLD") != nullptr;           // A/B knob: k_adapt behind every cascade
+    if (!c->rj_ad_flag && !fold_off) {
+        if ((r = dalloc(c, &c->rj_ad_flag, 2))) return r;
+        HIPCHK(c, hipMemsetAsync(c->rj_ad_flag, 0, 8, c->stream));
+    }
+    struct Defer {                             // (every way out of the loop leaves no adaptation pending and the switch off)
+        hens_ctx_impl* c;
+        ~Defer() { c->rj_defer_adapt = false; flush_adapt(c); }
+    } defer{c};
+    c->rj_defer_adapt = !fold_off && c->rj_tm != nullptr;
     for (int64_t i = 0; i < n_iters; ++i) {
         if (c->rj_tm && c->iter % RJ_REFRESH == RJ_REFRESH - 1)
             if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0))) return r;
@@ -2957,6 +2991,8 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
         rj_cascade(c, 2 * c->iter + 1, false);
         c->iter += 1;
     }
+    c->rj_defer_adapt = false;
+    flush_adapt(c);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;

@@ -64,7 +64,63 @@ struct RjArgs {
     double* tm;
     int32_t tm_mode, trace_n;               // (trace_n: waves that stamp their phases into `trace`, dev aid)
     unsigned long long* trace;
+    // The ladder adaptation that follows the previous cascade, folded into this launch (hens_rj_step, ladders of up to 64 rungs):
+    // wave 0 adapts while every other wave proposes and evaluates, publishes the ladder and raises *ad_flag to ad_serial; a
+    // wave reads its rung's beta - at its accept test, the end of its life - after it has seen the flag.  Removes a dependent
+    // single-workgroup launch (k_adapt: 5.2 us + boundary) behind both cascades of an iteration.
+    AdaptArgs ad;
+    unsigned* ad_flag;
+    uint32_t ad_serial;
+    int32_t ad_fold;
 };
+
+// k_adapt's arithmetic (tempering.py:563-596) in one wavefront, T <= 64: lane j owns rung j; same operations in the same order
+// per element (the cumulative sum stays a left-to-right loop like np.cumsum), so the ladder comes out bit for bit as k_adapt's
+__device__ __forceinline__ void rj_adapt_wave(const AdaptArgs& A, int lane, double* sd, unsigned* sc) {
+    const int T = A.T, total = A.nblocks * (T - 1);
+    sc[lane] = 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int e = lane; e < total; e += 64) {
+        const unsigned v = A.swap_part[e];
+        if (v) {
+            atomicAdd(&sc[e % (T - 1)], v);
+            if (A.zero_after) A.swap_part[e] = 0u;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned cnt = lane < T - 1 ? sc[lane] : 0u;
+    const double b = lane < T ? A.betas_in[lane] : 1.0;
+    const double r = (double)cnt / (double)A.W;                                   // :587
+    double upd = 0.0;                                                            // lane j: the new beta of rung j + 1
+    if (A.moving) {
+        const double rn = __shfl_down(r, 1), bn = __shfl_down(b, 1);
+        double d = 0.0;
+        if (lane + 2 < T) {
+            const double dS = A.kappa * (r - rn);                                // :575
+            d = 1.0 / bn - 1.0 / b;                                              // :578
+            d *= exp(dS);
+        }
+        sd[lane] = d;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0)
+            for (int j = 1; j + 2 < T; ++j) sd[j] = sd[j - 1] + sd[j];           // np.cumsum order
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double inv0 = 1.0 / __shfl(b, 0);
+        if (lane + 2 < T) {
+            const double bnn = 1.0 / (sd[lane] + inv0);                          // :580
+            upd = bn + (bnn - bn);                                               // :583,:593
+        }
+    }
+    const double from_below = __shfl_up(upd, 1);
+    if (lane < T)            // (written through to memory: other XCDs read it with agent-scope loads while this launch runs)
+        __hip_atomic_store(A.betas_out + lane, (A.moving && lane >= 1 && lane + 1 < T) ? from_below : b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (A.zero_rows)
+        for (int e = lane; e < total; e += 64) A.zero_rows[e] = 0u;
+    if (lane < T - 1) {
+        A.swaps_last[lane] = (double)cnt;
+        A.swaps_total[lane] += (double)cnt;
+    }
+}
 
 // exp(x) for the pulses' arguments x = -(t - b)^2 / (2 c^2) <= 0 (Tang's table method: x = (64 m + j) ln2 / 64 + r, |r| <= ln2 / 128,
 // exp(x) = 2^m T[j] (1 + r + r^2 (1/2 + r (1/6 + r (1/24 + r / 120)))), T[j] = 2^(j/64) out of LDS): 14 FP64-rate operations where
@@ -104,6 +160,10 @@ __device__ __forceinline__ double rj_exp_neg(double x, const double* tab) {
     return ldexp(fma(tj, q, tj), k >> 6);
 }
 
+// (Measured and rejected, round 4: a sincos of our own for the rotation scheme's base points - two FMAs against pi / 2 = hi + lo and
+//  fdlibm's kernel polynomials, 1.02 * 2^-53 absolute, tools/probe/sincos_check.py.  With its 15 constants as literals the allocator
+//  spilled 34 VGPRs; with the constants out of LDS it fitted, and config 4 ran at 161.2 us per iteration against the library
+//  routine's 157.0: the library's small-argument path is cheaper than its instruction count suggests.)
 // ndarray.sum(axis=-1) of v[0..n): NumPy's pairwise order (n < 8: a plain loop from 0.0; 8 <= n <= 128: eight partial
 // sums, the tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail).  Checked against NumPy for n = 1..20.
 __device__ __forceinline__ double numpy_sum(const double* v, int n) {
@@ -159,7 +219,15 @@ constexpr int RJ_WAVES = 4;        // walkers per workgroup
 
 // (four waves per SIMD: the kernel is bound by FP64 issue and hides its latencies with waves; with the sine rotation scheme the
 //  allocator would take 132 VGPRs - three waves - if it were not held to 128)
-__global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4))) void k_rj(const RjArgs A) {
+// waves per SIMD the allocator is held to (measured at config 4: the in-model launch at three waves 165.8 us per iteration against
+// 157.0 at four; the birth / death launch by difference - 99 VGPRs - held to five 174.7)
+constexpr int RJ_WPE(int, int) { return 4; }
+// MODE, TMM: RjArgs::mode and the resident-template scheme (-1: RjArgs::tm == nullptr, else RjArgs::tm_mode) as compile-time
+// parameters - one instantiation per launch kind (hens.hip: rj_launch), so that the birth / death launch by difference does not
+// carry the registers of the full evaluation's leaf loops, nor the in-model launch those of the birth / death proposal.
+template <int MODE, int TMM>
+__global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(RJ_WPE(MODE, TMM)))) void k_rj(const RjArgs A) {
+    constexpr bool HAVE_TM = TMM >= 0;
     __shared__ double s_cur[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_q[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_leafv[RJ_WAVES][32];
@@ -190,12 +258,21 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     for (int b = 0; b < M.nb; ++b) mask[b] = mask_old[b] = (uint32_t)cur[M.ind_off + b];
     const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
 
+    constexpr bool FOLD = HAVE_TM && MODE != RJ_MODE_EVAL;     // (production launches of hens_rj_step)
+    if (FOLD && A.ad_fold && gw == 0) {
+        __shared__ double s_ad[64];
+        __shared__ unsigned s_adc[64];
+        rj_adapt_wave(A.ad, lane, s_ad, s_adc);
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(A.ad_flag, A.ad_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     RJ_TRACE(1);
     // ---- proposal -----------------------------------------------------------------------------------------------------
     double factors = 0.0;
     int ch_sign[RJ_MAX_BRANCH], ch_leaf[RJ_MAX_BRANCH];      // birth / death: what changes in every branch (+1 born, -1 dies, 0 nothing)
     for (int B = 0; B < RJ_MAX_BRANCH; ++B) { ch_sign[B] = 0; ch_leaf[B] = 0; }
-    if (A.mode == RJ_MODE_MH) {
+    if (MODE == RJ_MODE_MH) {
         // every active leaf of every branch moves: q = x + step (gaussian.py:96-104, 265-268; factors = 0)
         for (int i = lane; i < M.ind_off; i += 64) {
             int b = 0;
@@ -211,7 +288,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
                 q[i] = cur[i] + st;
             }
         }
-    } else if (A.mode == RJ_MODE_BD) {
+    } else if (MODE == RJ_MODE_BD) {
       // one branch, or - branch < 0, the "together" schedule (ensemble.py:414-432, distgenrj.py:150-222) - every branch of the
       // walker in one proposal: the factors add up in branch order, then the edge factors (one sum over the branches, rj.py:236-270)
       const int b_lo = A.branch >= 0 ? A.branch : 0, b_hi = A.branch >= 0 ? A.branch + 1 : M.nb;
@@ -298,8 +375,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
         total_leaves += __builtin_popcount(mask[b]);
     }
     {   // Move.fix_logp_gibbs (move.py:368-402): the branches under proposal are all of them (in-model) or one (RJ)
-        const int here = (A.mode == RJ_MODE_BD && A.branch >= 0) ? __builtin_popcount(mask[A.branch]) : total_leaves;
-        if (A.mode != RJ_MODE_EVAL) {
+        const int here = (MODE == RJ_MODE_BD && A.branch >= 0) ? __builtin_popcount(mask[A.branch]) : total_leaves;
+        if (MODE != RJ_MODE_EVAL) {
             if (total_leaves != 0 && here == 0) logp = -INFINITY;
             if (total_leaves == 0 && here == 0) logp = 0.0;
         }
@@ -321,7 +398,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     // formula the ARGUMENT differs by the rounding of w t_k (<= 130 eps ~ 1.5e-14, what the reference's own products carry) and each
     // rotation adds ~1 eps: the log-likelihood moves by ~1e-15 relative (bar 1e-13; the replay tests run this path).  The parity API
     // (tm == nullptr) keeps the reference's sin per point.
-    const bool rot = A.tm != nullptr && M.t_step64 != 0.0;
+    const bool rot = HAVE_TM && M.t_step64 != 0.0;
     constexpr int NPT = 4, MAXCH = 2;                        // (template points per lane and chunk; chunks a lane keeps: ndata <= 512)
     auto sine_points = [&](const double a, const double w, const double c, const double sd, const double cd, const double (&ti)[NPT], double (&out)[NPT], const double sg) {
         double sk, ck;
@@ -334,8 +411,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
             out[k] += sg * (a * sk);
         }
     };
-    double* tmrow = A.tm ? A.tm + (size_t)A.loc[gw] * M.ndata : nullptr;
-    const bool by_diff = A.tm && A.tm_mode == 1 && A.mode == RJ_MODE_BD && M.ndata <= 64 * NPT * MAXCH;
+    double* tmrow = HAVE_TM ? A.tm + (size_t)A.loc[gw] * M.ndata : nullptr;
+    constexpr bool by_diff = TMM == 1 && MODE == RJ_MODE_BD;      // (resident templates exist for ndata <= 64 NPT MAXCH only: hens_rj_set_model)
     double tmk[MAXCH][NPT];                                  // the proposal's template at this lane's points (stored on acceptance)
 #pragma unroll
     for (int ch = 0; ch < MAXCH; ++ch)
@@ -398,7 +475,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
             logl = -1e300;
             atomicOr(A.flags, FLAG_NAN_LOGL);
         }
-    } else if (evaluated || (A.tm && A.mode == RJ_MODE_EVAL && total_leaves > 0)) {     // (an evaluation always leaves a true template behind)
+    } else if (evaluated || (HAVE_TM && MODE == RJ_MODE_EVAL && total_leaves > 0)) {     // (an evaluation always leaves a true template behind)
         double acc = 0.0;
         // Leaves outside, NPT data points per lane inside: a leaf's three parameters are read (LDS) and its 1 / (2 c^2)
         // formed once per chunk instead of once per point (the FP64 division was a third of the work per template
@@ -459,7 +536,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
                     acc += r * r;
                 }
             }
-            if (A.tm) {                          // (kept for the store below; chunk index is uniform: static register indices)
+            if (HAVE_TM) {                       // (kept for the store below; chunk index is uniform: static register indices)
                 const int ch = i0 / (64 * NPT);
 #pragma unroll
                 for (int c2 = 0; c2 < MAXCH; ++c2)
@@ -493,18 +570,29 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
 
     RJ_TRACE(4);
     // ---- evaluation / accept + update ----------------------------------------------------------------------------------------
-    if (A.mode == RJ_MODE_EVAL) {
+    if (MODE == RJ_MODE_EVAL) {
         store_template();
-        if (lane == 0 && A.tm_mode != 2) {
+        if (lane == 0 && TMM != 2) {
             A.L[gw] = logl;
             A.P[gw] = logp;
         }
         return;
     }
+    // (measured: requested at the head of the kernel, with the record, these two cost the in-model launch four more spilled
+    //  registers and config 4 3 us per iteration)
     const double Lold = A.L[gw], Pold = A.P[gw];
     double logP, prevP;
     if (A.tempered) {                                                  // tempering.py:304-306,343-349
-        const double beta = A.betas[A.rung_begin + tl];
+        double beta;
+        if (FOLD && A.ad_fold) {                 // the ladder of this launch: published by wave 0 (long ago, as a rule)
+            // (relaxed agent-scope loads - they read past the caches that are not coherent across XCDs; an ACQUIRE here invalidates
+            //  the XCD's L2 once per wave: measured, the launch took twice as long)
+            while (__hip_atomic_load(A.ad_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.ad_serial) __builtin_amdgcn_s_sleep(4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            beta = __hip_atomic_load(A.betas + (A.rung_begin + tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            beta = A.betas[A.rung_begin + tl];
+        }
         double lt = logl * beta;
         if (lt != lt) lt = -INFINITY;
         logP = lt + logp;
@@ -520,7 +608,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(4
     if (A.u_acc) {
         lu = log(A.u_acc[gw]);
     } else {
-        lu = log(rj_accept_uniform(A.seed, A.iter, wid, A.mode, A.mode == RJ_MODE_BD ? (A.branch >= 0 ? A.branch : M.nb) : 0));
+        lu = log(rj_accept_uniform(A.seed, A.iter, wid, MODE, MODE == RJ_MODE_BD ? (A.branch >= 0 ? A.branch : M.nb) : 0));
     }
     const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
     if (keep) {                                                        // Move.update (move.py:472-703)

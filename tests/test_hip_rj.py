@@ -401,3 +401,55 @@ def test_rj_production_step_replayed_through_the_oracle_config4():
     """BASELINE config 4 at full size (8 x 2048 walkers, 2 branches x 10 leaves, 500 data points): three iterations of
     hens_rj_step replayed."""
     _replay_rj(8, 2048, (10, 10), (0, 0), ndata=500, iters=3, seed=5, start_leaves=(4, 2))
+
+
+_FOLD_WORKER = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from eryn_amd.moves.tempering import make_ladder
+from eryn_amd.rj import RJEngine, TemplateBranch
+T, W, N, NL = 6, 256, 200, 5
+t = np.linspace(-1, 1, N); rs = np.random.RandomState(3)
+y = 3.0 * np.exp(-((t + 0.2) ** 2) / 0.02) + 1.2 * np.sin(2 * np.pi * 7.3 * t + 1.0) + 2.0 * rs.randn(N)
+brs = [TemplateBranch("gauss", "pulse", [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)], NL, 0),
+       TemplateBranch("sine", "sine", [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)], NL, 0)]
+eng = RJEngine(T, W, brs, t, y, 2.0, seed=9)
+x = {"gauss": np.zeros((T, W, NL, 3)), "sine": np.zeros((T, W, NL, 3))}
+inds = {k: np.zeros((T, W, NL), dtype=bool) for k in x}
+x["gauss"][:, :, 0] = [3.0, -0.2, 0.1] + 1e-2 * rs.randn(T, W, 3) * [1, 1, 0.1]; inds["gauss"][:, :, 0] = True
+x["sine"][:, :, 0] = [1.2, 7.3, 1.0] + 1e-2 * rs.randn(T, W, 3); inds["sine"][:, :, 0] = True
+eng.upload(x, inds, betas=make_ladder(6, ntemps=T)); eng.eval_state()
+eng.set_mh_scale(np.full((2, 3), 1e-2) * [[1, 1, 0.1], [1, 1, 1]])
+for n in (1, 70, 130):                       # (calls that end on, before and after a template refresh)
+    eng.step(n)
+eng.synchronize()
+x1, inds1, L1, P1, betas1 = eng.download()
+c = eng.counters()
+np.savez(sys.argv[2], xg=x1["gauss"], xs=x1["sine"], ig=inds1["gauss"], js=inds1["sine"], L=L1, P=P1, betas=betas1,
+         acc_mh=c["accepted_mh"], acc_bd=c["accepted_bd"], swaps_total=c["swaps_total"], swaps_last=c["swaps_last"])
+eng.close()
+"""
+
+
+def test_rj_adaptation_folded_into_the_next_launch_changes_nothing(tmp_path):
+    """hens_rj_step runs the ladder adaptation behind a cascade INSIDE the next k_rj launch (wave 0 adapts and publishes, the others
+    pick up their rung's beta at their accept test); HENS_NO_FOLD=1 keeps k_adapt as a launch of its own.  Same arithmetic, same
+    order: 201 iterations of both must agree in every bit - coordinates, masks, log-probabilities, the ladder and every counter."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"HENS_NO_FOLD": "1"}):
+        out = str(tmp_path / f"{len(outs)}.npz")
+        e = dict(os.environ, **env)
+        if not env:
+            e.pop("HENS_NO_FOLD", None)
+        r = subprocess.run([sys.executable, "-c", _FOLD_WORKER, root, out], env=e, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(dict(np.load(out)))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), f"folded adaptation vs k_adapt: `{k}` differs"
+    assert outs[0]["acc_mh"].sum() > 0 and outs[0]["acc_bd"].sum() > 0 and outs[0]["swaps_total"].sum() > 0
+    assert not np.array_equal(outs[0]["betas"], __import__("eryn_amd.moves.tempering", fromlist=["make_ladder"]).make_ladder(6, ntemps=6)), "the ladder must have moved"
