@@ -19,7 +19,8 @@ with open('$OUT/kernel_summary.txt', 'w') as f:
     f.write("command: rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg4 --steps 100 --warmup 20 --no-cpu\n")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         f.write(f"{k[:80]:80s} calls {len(v):6d} avg_us {sum(v)/len(v)/1e3:9.2f} min_us {min(v)/1e3:9.2f} total_ms {sum(v)/1e6:9.2f} pct {100*sum(v)/tot:5.1f}\n")
-rj_us = [sum(v) / len(v) / 1e3 for k, v in agg.items() if 'k_rj' in k]
+rj_all = [d for k, v in agg.items() if 'k_rj' in k for d in v]      # (every instantiation of k_rj: the counters below average over the same launches)
+rj_us = [sum(rj_all) / len(rj_all) / 1e3] if rj_all else []
 rows = list(csv.DictReader(open(glob.glob('/tmp/r2/**/*counter_collection.csv', recursive=True)[0])))
 c = collections.defaultdict(list)
 for r in rows:
