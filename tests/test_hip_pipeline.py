@@ -52,7 +52,8 @@ def _compare(ref, got):
 
 
 @pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 128, 8, 6), (4, 8, 256, 32, 8), (2, 6, 70, 5, 7),
-                                                 (4, 4, 64, 16, 6), (1, 4, 128, 8, 5)])
+                                                 (4, 4, 64, 16, 6), (1, 4, 128, 8, 5),
+                                                 (2, 8, 256, 64, 8)])      # (D = 64 dense: the matrix-pipe likelihood on pipeline ranks)
 def test_pipeline_local_matches_single_context(tmp_path, nranks, T, W, D, iters):
     ref = _single(tmp_path, T, W, D, iters)
     out = tmp_path / "local.npz"
