@@ -1593,26 +1593,34 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const double* __restrict__ pool_r = A.pool;
     double2 sreg[NPASS], creg[NPASS];
     bool rv[NPASS];
+    // D = 128 (8 passes: 64 VGPRs of rows in flight per thread, 145 in all - ONE workgroup per CU): the gathers go in two halves of
+    // four passes, each consumed (proposal -> LDS tile) before the next is requested, so the rows of one half reuse the registers
+    // of the other: 106 VGPRs, two workgroups per CU, and a CU has as many bytes in flight as before (config 5's shard 28.4 -> 26.1
+    // us per iteration).  Not on a pipeline rank (phase E stores the old rows from these registers there).  The pass bodies are
+    // macros so that the other widths keep their one loop each, token for token: as lambdas the D = 32 launch was 0.2 us slower.
+    constexpr int HP = (DT == 128 && !PIPE) ? NPASS / 2 : NPASS;
+#define HENS_GATHER_PASS(p) \
+        const int r = p * RPP + rsub;                                                                                                                          \
+        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;                                                                                             \
+        sreg[p] = double2{0.0, 0.0};                                                                                                                           \
+        creg[p] = double2{0.0, 0.0};                                                                                                                           \
+        if (rv[p]) {                                                                                                                                           \
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);                 \
+            if (MH) {                                                                                                                                          \
+                if (A.mh_step) {                                                                                                                               \
+                    creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);                                           \
+                } else { /* one Box-Muller pair per lane: exactly the two coordinates it owns */                                                               \
+                    const double2 z = mh_normal_pair(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(k0 + r), (uint32_t)jl);    \
+                    const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];                                                                \
+                    const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];                                                                       \
+                    creg[p] = double2{s0 * z.x, s1 * z.y};                                                                                                     \
+                }                                                                                                                                              \
+            }                                                                                                                                                  \
+            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2); \
+        }                                                                                                                                                     
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;
-        sreg[p] = double2{0.0, 0.0};
-        creg[p] = double2{0.0, 0.0};
-        if (rv[p]) {
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
-            if (MH) {
-                if (A.mh_step) {
-                    creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);
-                } else {                         // one Box-Muller pair per lane: exactly the two coordinates it owns
-                    const double2 z = mh_normal_pair(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(k0 + r), (uint32_t)jl);
-                    const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];
-                    const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];
-                    creg[p] = double2{s0 * z.x, s1 * z.y};
-                }
-            }
-            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
-        }
+    for (int p = 0; p < HP; ++p) {
+        HENS_GATHER_PASS(p)
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
@@ -1653,53 +1661,67 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (!cnt_push && wv == 1 && lane < A.ad.T) ad_b = A.ad.betas_in[lane];
         if (!cnt_push && wv == 1 && lane + 64 < A.ad.T) ad_b1 = A.ad.betas_in[lane + 64];
     }
+#define HENS_PROPOSE_PASS(p) \
+        const int r = p * RPP + rsub;                                                                           \
+        bool ok = true, finite = true;                                                                          \
+        if (rv[p]) {                                                                                            \
+            double2 qv;                                                                                         \
+            if (EVAL) {                                                                                         \
+                qv = sreg[p];                                                                                   \
+            } else {                                                                                            \
+                const double zz = s_zz[r];                                                                      \
+                if (MH) {                                                                                       \
+                    qv.x = sreg[p].x + creg[p].x; /* gaussian.py:166-167 */                                     \
+                    qv.y = sreg[p].y + creg[p].y;                                                               \
+                } else {                                                                                        \
+                    qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; /* stretch.py:143,145 */                   \
+                    qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;                                            \
+                }                                                                                               \
+                if (PER) { /* periodic parameters (see periodic_diff) */                                        \
+                    const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);                    \
+                    if (!MH) { /* stretch.py:136-145 */                                                         \
+                        qv.x = creg[p].x - periodic_diff(sreg[p].x, creg[p].x, pv.x) * zz;                      \
+                        qv.y = creg[p].y - periodic_diff(sreg[p].y, creg[p].y, pv.y) * zz;                      \
+                    }                                                                                           \
+                    qv.x = periodic_wrap(qv.x, pv.x); /* stretch.py:149-154, gaussian.py:110-115 */             \
+                    qv.y = periodic_wrap(qv.y, pv.y);                                                           \
+                }                                                                                               \
+            }                                                                                                   \
+            ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);                      \
+            finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);                                        \
+            if (CEN) qkeep[p] = qv;                                                                             \
+            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};         \
+        /* write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E */         \
+        /* overwrites only accepted rows, so the store tail after the accept test is short */                   \
+            if (!EVAL && !A.inplace) {                                                                          \
+                if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]); \
+                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);                              \
+            }                                                                                                   \
+        }                                                                                                       \
+        const unsigned long long bad = __ballot(!ok); /* prior.py:80-88, row-wide AND */                        \
+        const unsigned long long nonfin = __ballot(!finite);                                                    \
+        const int gshift = lane & ~(LPR - 1);                                                                   \
+        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << (LPR & 63)) - 1ull) << gshift);       \
+        if (jl == 0 && rv[p]) {                                                                                 \
+            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);                                                 \
+            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);                                  \
+        }                                                                                                      
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const int r = p * RPP + rsub;
-        bool ok = true, finite = true;
-        if (rv[p]) {
-            double2 qv;
-            if (EVAL) {
-                qv = sreg[p];
-            } else {
-                const double zz = s_zz[r];
-                if (MH) {
-                    qv.x = sreg[p].x + creg[p].x;                    // gaussian.py:166-167
-                    qv.y = sreg[p].y + creg[p].y;
-                } else {
-                    qv.x = creg[p].x - (creg[p].x - sreg[p].x) * zz; // stretch.py:143,145
-                    qv.y = creg[p].y - (creg[p].y - sreg[p].y) * zz;
-                }
-                if (PER) {                                           // periodic parameters (see periodic_diff)
-                    const double2 pv = *reinterpret_cast<const double2*>(A.period + jl * 2);
-                    if (!MH) {                                       // stretch.py:136-145
-                        qv.x = creg[p].x - periodic_diff(sreg[p].x, creg[p].x, pv.x) * zz;
-                        qv.y = creg[p].y - periodic_diff(sreg[p].y, creg[p].y, pv.y) * zz;
-                    }
-                    qv.x = periodic_wrap(qv.x, pv.x);                // stretch.py:149-154, gaussian.py:110-115
-                    qv.y = periodic_wrap(qv.y, pv.y);
-                }
-            }
-            ok = (qv.x >= lov.x) && (qv.x <= hiv.x) && (qv.y >= lov.y) && (qv.y <= hiv.y);
-            finite = (fabs(qv.x) < INFINITY) && (fabs(qv.y) < INFINITY);
-            if (CEN) qkeep[p] = qv;
-            *reinterpret_cast<double2*>(qtile + r * RS + jl * 2) = double2{qv.x - muv.x, qv.y - muv.y};
-            // write the OLD row to its new home now (78 % of proposals are rejected at D = 32); phase E
-            // overwrites only accepted rows, so the store tail after the accept test is short
-            if (!EVAL && !A.inplace) {
-                if (PIPE && tl == A.sys_rung) store_row16_sys(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
-                else store_row16(A.pool + (size_t)s_dst[r] * D + jl * 2, sreg[p]);
-            }
+    for (int p = 0; p < HP; ++p) {
+        HENS_PROPOSE_PASS(p)
+    }
+    if constexpr (HP < NPASS) {
+#pragma unroll
+        for (int p = HP; p < NPASS; ++p) {
+            HENS_GATHER_PASS(p)
         }
-        const unsigned long long bad = __ballot(!ok);               // prior.py:80-88, row-wide AND
-        const unsigned long long nonfin = __ballot(!finite);
-        const int gshift = lane & ~(LPR - 1);
-        const unsigned long long gmask = (LPR == 64) ? ~0ull : (((1ull << (LPR & 63)) - 1ull) << gshift);
-        if (jl == 0 && rv[p]) {
-            if ((bad & gmask) == 0ull) atomicOr(&s_flag[r], 1);
-            if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
+#pragma unroll
+        for (int p = HP; p < NPASS; ++p) {
+            HENS_PROPOSE_PASS(p)
         }
     }
+#undef HENS_GATHER_PASS
+#undef HENS_PROPOSE_PASS
     if (red_on) {
         const int Tm1 = cnt_push ? A.cp_np : A.ad.T - 1;
 #pragma unroll
