@@ -1765,7 +1765,7 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     TRY(dalloc(c, &c->hi, (size_t)c->D));
     TRY(dalloc(c, &c->mu, (size_t)c->D));
     TRY(dalloc(c, &c->prec, (size_t)c->D * c->D));
-    TRY(dalloc(c, &c->prec_sym, std::max<size_t>((size_t)(c->D / 2 + 1) * (c->D + 2), (size_t)MF64_END)));
+    TRY(dalloc(c, &c->prec_sym, std::max<size_t>((size_t)(c->D / 2 + 1) * (c->D + 2), (size_t)(c->D == 128 ? MF128_END : MF64_END))));
     TRY(dalloc(c, &c->ad_ring, (size_t)4 * c->T));
     {
         std::vector<double> neg((size_t)4 * c->T, -1.0);
@@ -1983,7 +1983,17 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
             // blocked form (see like_partial): four H = D / 4 blocks: [4 diagonal blocks][6 cross blocks (0,1) (0,2) (0,3)
             // (1,2) (1,3) (2,3)]
             const int H = D / 4, BLK = (H / 2) * (H + 2);
-            sym.assign((size_t)4 * BLK + (size_t)6 * H * H + (D == 64 ? (size_t)MF64_STEPS * 64 : 0), 0.0);
+            sym.assign((size_t)4 * BLK + (size_t)6 * H * H + (size_t)(D == 64 ? MF64_STEPS : MF128_STEPS) * 64, 0.0);
+            if (D == 128) {             // the same for like_tile_mf128: eight blocks of 16, 144 steps
+                static_assert(MF128_OFF == 4 * 544 + 6 * 1024, "prec_sym layout at D = 128");
+                for (int cidx = 0; cidx < MF128_STEPS; ++cidx) {
+                    const int I = mf128_I(cidx), J = mf128_J(cidx), st = mf128_S(cidx);
+                    for (int l = 0; l < 64; ++l) {
+                        const int r = 16 * I + l % 16, k = 16 * J + 4 * st + l / 16;
+                        sym[(size_t)MF128_OFF + (size_t)cidx * 64 + l] = I == J ? prec[(size_t)r * D + k] : prec[(size_t)r * D + k] + prec[(size_t)k * D + r];
+                    }
+                }
+            }
             if (D == 64) {
                 // the matrix-pipe operands (like_tile_mf64): step c = (I, J >= I, s) in order, mf[c][lane] = M_IJ[lane % 16][4 s +
                 // lane / 16], M_II = A_II, M_IJ = A_IJ + A_JI^T

@@ -1031,11 +1031,19 @@ __device__ __forceinline__ double like_partial(const double* qtile, int lane, in
 constexpr int MF64_OFF = 4 * ((16 / 2) * (16 + 2)) + 6 * 16 * 16;        // behind the blocked sym_quad form in prec_sym (D = 64)
 constexpr int MF64_STEPS = 40;
 constexpr int MF64_END = MF64_OFF + MF64_STEPS * 64;
-__host__ __device__ constexpr size_t mf_lds_extra(int D) { return D == 64 ? 64 * 8 : 0; }   // mu in LDS (all likelihood kinds: one size per width)
+// D = 128: eight blocks of 16 coordinates, 36 block products, 144 steps - 18 per wave (like_tile_mf128)
+constexpr int MF128_OFF = 4 * ((32 / 2) * (32 + 2)) + 6 * 32 * 32;       // behind the blocked sym_quad form in prec_sym (D = 128)
+constexpr int MF128_STEPS = 144;
+constexpr int MF128_END = MF128_OFF + MF128_STEPS * 64;
+constexpr int mf128_base(int I) { return 4 * (I * 8 - I * (I - 1) / 2); }                 // steps in front of row block I
+constexpr int mf128_I(int c) { int I = 0; while (I < 7 && c >= mf128_base(I + 1)) ++I; return I; }
+constexpr int mf128_J(int c) { return mf128_I(c) + (c - mf128_base(mf128_I(c))) / 4; }
+constexpr int mf128_S(int c) { return (c - mf128_base(mf128_I(c))) % 4; }
+__host__ __device__ constexpr size_t mf_lds_extra(int D) { return D == 64 ? 64 * 8 : (D == 128 ? 128 * 8 : 0); }   // mu in LDS (all likelihood kinds: one size per width)
 typedef double d4_t __attribute__((ext_vector_type(4)));
 struct MfRegs { double m[5]; };
 template <int DT, int LIKE, int NW>
-constexpr bool like_mf() { return LIKE == LIKE_DENSE && DT == 64 && NW == 8; }
+constexpr bool like_mf() { return LIKE == LIKE_DENSE && (DT == 64 || DT == 128) && NW == 8; }
 // step c = 0..39 in the order (I, J >= I, s)
 constexpr int mf64_I(int c) { return c < 16 ? 0 : (c < 28 ? 1 : (c < 36 ? 2 : 3)); }
 constexpr int mf64_base(int I) { return I == 0 ? 0 : (I == 1 ? 16 : (I == 2 ? 28 : 36)); }
@@ -1047,7 +1055,7 @@ __device__ __forceinline__ MfRegs like_prefetch(int lane, int wv, const double* 
     MfRegs r;
 #pragma unroll
     for (int t = 0; t < 5; ++t) r.m[t] = 0.0;
-    if constexpr (like_mf<DT, LIKE, NW>()) {
+    if constexpr (like_mf<DT, LIKE, NW>() && DT == 64) {          // (D = 128: 18 operands per wave, requested where they are used)
 #pragma unroll
         for (int t = 0; t < 5; ++t) r.m[t] = prec_sym_p[MF64_OFF + (5 * wv + t) * 64 + lane];
     }
@@ -1118,6 +1126,95 @@ __device__ __forceinline__ void like_tile_mf64(const double* qtile, double* srow
     srow[wv * TILE + lane] = part;
 }
 
+// D = 128, the same scheme: 36 block products = 144 steps, 18 per wave in the order (I, J >= I, s); a wave meets up to three row
+// blocks (one accumulator chain each per 16-walker block), its matrix operands come straight from prec_sym's last part (L2), mu
+// from the LDS copy.  72 MFMAs per wave - 4 608 cycles of its SIMD's matrix pipe - where the blocked VALU form issued ~1 040 FMAs
+// per lane (8 900 cycles) and held 32 coordinates in registers (156 - 197 VGPRs: one workgroup per CU).
+// one row block I's steps [T0, T1) of the wave for the four 16-walker blocks of the tile: the matrix operand is requested once per
+// step and used four times (four independent accumulator chains), then the partial y_I is dotted with q_I into p[block]
+template <int C0, int T0, int T1, int I>
+__device__ __forceinline__ void mf128_segment(const double* qtile, int lane, const double* mu_s, const double* mf_tab, double (&p)[4]) {
+    if constexpr (T1 > T0) {
+        constexpr int RS = 130;
+        const int j = lane & 15, g = lane >> 4;
+        d4_t acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = d4_t{0.0, 0.0, 0.0, 0.0};
+        // (within a row block the steps' coordinates 16 J + 4 s run on in fours - (J, 3) -> (J + 1, 0) included.  The operands of step
+        //  t + 1 are requested in front of step t's four MFMAs and nothing moves across the fence behind them: left to itself the
+        //  scheduler requested all 18 matrix operands and 72 LDS values of the unrolled loop up front - 170 to 247 VGPRs, one
+        //  workgroup per CU)
+        constexpr int K0 = 16 * mf128_J(C0 + T0) + 4 * mf128_S(C0 + T0);
+        const double* tp = mf_tab + (C0 + T0) * 64 + lane;
+        const double* qk = qtile + j * RS + K0 + g;
+        const double* mp = mu_s + K0 + g;
+        double am = *tp, bq[4];
+        {
+            const double mk = *mp;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bq[b] = qk[16 * b * RS] - mk;
+        }
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+            double am_n = 0.0, bq_n[4] = {0.0, 0.0, 0.0, 0.0};
+            if (t + 1 < T1) {
+                tp += 64; qk += 4; mp += 4;
+                am_n = *tp;
+                const double mk = *mp;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bq_n[b] = qk[16 * b * RS] - mk;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bq[b], acc[b], 0, 0, 0);
+            asm volatile("" ::: "memory");
+            am = am_n;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bq[b] = bq_n[b];
+        }
+        double mr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mr[r] = mu_s[16 * I + g + 4 * r];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double* qw = qtile + (16 * b + j) * RS + 16 * I + g;            // rows g, g + 4, g + 8, g + 12 of walker 16 b + j
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[b] = fma(qw[4 * r] - mr[r], acc[b][r], p[b]);
+        }
+    }
+}
+template <int WI>
+__device__ __forceinline__ double mf128_wave(const double* qtile, int lane, const double* mu_s, const double* mf_tab) {
+    constexpr int SPW = 18, C0 = SPW * WI;
+    constexpr int IA = mf128_I(C0), IC = mf128_I(C0 + SPW - 1), IB = (IA + 1 < IC) ? IA + 1 : IC;     // this wave's row blocks, ascending
+    static_assert(IC - IA <= 2, "a wave's 18 steps span at most three row blocks");
+    constexpr int EA = (mf128_base(IA + 1) - C0 < SPW) ? mf128_base(IA + 1) - C0 : SPW;              // steps [0, EA) belong to IA
+    constexpr int EB = (IB == IA) ? EA : ((mf128_base(IB + 1) - C0 < SPW) ? mf128_base(IB + 1) - C0 : SPW);
+    double p[4] = {0.0, 0.0, 0.0, 0.0};
+    mf128_segment<C0, 0, EA, IA>(qtile, lane, mu_s, mf_tab, p);
+    mf128_segment<C0, EA, EB, IB>(qtile, lane, mu_s, mf_tab, p);
+    mf128_segment<C0, EB, SPW, IC>(qtile, lane, mu_s, mf_tab, p);
+    const int g = lane >> 4;
+    double psel = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const double v = sum_rows_f64(p[b]);
+        psel = (g == b) ? v : psel;                                      // (lane group g keeps block g's walkers: lane l = walker l)
+    }
+    return psel;
+}
+__device__ __forceinline__ void like_tile_mf128(const double* qtile, double* srow, int lane, int wv, const double* mu_s, const double* prec_sym_p) {
+    double part = 0.0;
+    const double* tab = prec_sym_p + MF128_OFF;
+    switch (wv) {
+#define HENS_MF_CASE(WI) case WI: part = mf128_wave<WI>(qtile, lane, mu_s, tab); break;
+        HENS_MF_CASE(0) HENS_MF_CASE(1) HENS_MF_CASE(2) HENS_MF_CASE(3)
+        HENS_MF_CASE(4) HENS_MF_CASE(5) HENS_MF_CASE(6) HENS_MF_CASE(7)
+#undef HENS_MF_CASE
+        default: break;
+    }
+    srow[wv * TILE + lane] = part;
+}
+
 // Phase C of the two production kernels: every wave's partial sum into s_part[wave][walker].  Dense Gaussian at D = 32 (8 waves):
 // the phase is bound by LDS bandwidth, not by FP64 issue - every wave reads its walker's whole centred row (64 lanes x 256 B per
 // wave, 16 waves per CU: 2 048 clocks of the CU's 128 B / clock) to use it for 2 of the 16 row pairs.  Half the waves now read
@@ -1127,7 +1224,8 @@ template <int DT, int LIKE, int NW, bool CEN>
 __device__ __forceinline__ void like_partials(const double* qtile, double* s_part, int lane, int wv, bool inbox, const double* mu_p,
                                               const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b, const MfRegs& mf) {
     if constexpr (like_mf<DT, LIKE, NW>()) {          // (walkers outside the prior box ride along: a walker is a column of the product)
-        like_tile_mf64<CEN>(qtile, s_part, lane, wv, mu_p, mf);
+        if constexpr (DT == 64) like_tile_mf64<CEN>(qtile, s_part, lane, wv, mu_p, mf);
+        else like_tile_mf128(qtile, s_part, lane, wv, mu_p, prec_sym_p);
         return;
     }
 #ifndef HENS_NO_LIKE_PAIR
@@ -1203,13 +1301,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     int32_t* s_dst = s_rc + TILE;
     int32_t* s_flag = s_dst + TILE;                                      // bit0 inbox, bit1 keep, bit2 valid
     unsigned* s_cnt = reinterpret_cast<unsigned*>(s_flag + TILE);        // [128] swap counts (ad_on)
-    double* s_mu = reinterpret_cast<double*>(s_cnt + 128);               // [64] D = 64: mu for the matrix-pipe phase C (mf_lds_extra)
+    double* s_mu = reinterpret_cast<double*>(s_cnt + 128);               // [D] D = 64 / 128 dense: mu for the matrix-pipe phase C (mf_lds_extra)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (like_mf<DT, LIKE, NW>()) {
-        if (tid >= NW * 64 - 32) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - 32))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - 32)));
+        if (tid >= NW * 64 - DT / 2) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - DT / 2))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - DT / 2)));
     }
     constexpr int ADW = 1;                      // the wave that runs the early ladder adaptation (a 9th, adaptation-only
                                                 // wave was measured: two 9-wave workgroups do not pack onto one CU)
@@ -2609,13 +2707,13 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     uint32_t* smask = reinterpret_cast<uint32_t*>(s_el + TILE);          // [cb][MW] swap bitmask per column
     int32_t* s_src = reinterpret_cast<int32_t*>(smask + 64);             // PIPE [TILE] bottom boundary: row that moves down
     int32_t* s_yrow = s_src + TILE;                                      // PIPE [TILE] row (cold neighbour's pool) that moves up
-    double* s_mu = reinterpret_cast<double*>(smem_raw + fused_lds_base(DT, NW, PIPE));   // [64] D = 64: mu for the matrix-pipe phase C
+    double* s_mu = reinterpret_cast<double*>(smem_raw + fused_lds_base(DT, NW, PIPE));   // [D] D = 64 / 128 dense: mu for the matrix-pipe phase C
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (like_mf<DT, LIKE, NW>()) {
-        if (tid >= NW * 64 - 32) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - 32))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - 32)));
+        if (tid >= NW * 64 - DT / 2) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - DT / 2))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - DT / 2)));
     }
     const int TG = A.T;                                                  // the whole ladder
     const int T = PIPE ? A.Tl : A.T;                                     // the rungs this workgroup holds
