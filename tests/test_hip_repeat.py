@@ -59,6 +59,8 @@ def _same(a, b, what):
     (5, 100, 5, 20000, 7777, None, "generic width (padded rows), calls crossing batches and key windows"),
     (32, 1024, 16, 20000, 20000, None, "the shape whose side-stream plan diverged in round 3"),
     (32, 1024, 16, 20000, 333, ("iso", 0.05, 0.3), "the same with the MH move in the mix, short calls"),
+    (8, 2048, 64, 6000, 1500, None, "D = 64: the likelihood on the matrix pipe"),
+    (4, 1024, 128, 4000, 777, ("iso", 0.02, 0.4), "D = 128: matrix pipe, gathers in two halves, MH move in the mix"),
 ], ids=lambda s: f"{s[0]}x{s[1]}x{s[2]}-{s[4]}{'-mh' if s[5] else ''}")
 def test_same_seed_same_chain(shape):
     T, W, D, n, call, mh, what = shape
