@@ -428,9 +428,9 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
         if (xcd && (ntiles & (ntiles - 1)) == 0 && ((long)ntiles * c->Tl) % 8 == 0) { int sh = 0; while ((1 << sh) < ntiles) ++sh; a.xcd_shift = sh + 1; }
     }
     if (fast_path(c)) {
-        // (periodic parameters: an instantiation of their own, never on a pipeline rank - hens_set_periodic / hens_pipe_init
-        //  refuse the combination - and not for the evaluation launch, which proposes nothing)
-        const bool pipe = c->pipe.on, per = !pipe && mode != MODE_EVAL && c->period;
+        // (periodic parameters: an instantiation of their own - on a pipeline rank too - but not for the evaluation launch, which
+        //  proposes nothing)
+        const bool pipe = c->pipe.on, per = mode != MODE_EVAL && c->period;
         const int NW = fast_nw(c->D);
         return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW), false,
                              c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
@@ -1055,8 +1055,9 @@ bool fused_ok(const hens_ctx_impl* c) {
 int launch_fused_like(hens_ctx_impl* c, int like, const FusedArgs& f, hipEvent_t e0, hipEvent_t e1, bool pipe = false, bool col = false) {
     const dim3 grid(pipe ? c->W / c->pipe.cbl : c->W / c->label_cb);
     const int NW = fast_nw(c->D);
-    // the instantiation: pipeline rank and column order know neither periodic parameters nor short tiles (their callers refuse)
-    const bool plain = !pipe && !col, per = plain && f.period, shrt = plain && c->T * c->label_cb != 2 * TILE;
+    // the instantiation: column order knows neither periodic parameters nor short tiles, a pipeline rank no short tiles (their
+    // callers refuse)
+    const bool plain = !pipe && !col, per = !col && f.period, shrt = plain && c->T * c->label_cb != 2 * TILE;
     // (the iteration's last launch: the call's last one carries the completion signal)
     return launch_by_ptr(c, ktab_split1_pt(like, c->D, per, shrt, pipe, col), "k_split1_pt", grid, NW * 64, fused_lds_bytes(c->D, NW, pipe),
                          c->aql_last, e0, e1, f);
@@ -1280,6 +1281,7 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh
     f.Tl = Tl; f.rung_begin = c->cfg.rung_begin;
     f.cbl = c->pipe.cbl; f.cbl_shift = c->pipe.cbl_shift;
     f.guest_delta = guest_delta(c);
+    f.period = c->period;                           // (periodic parameters: set before hens_pipe_init, the same on every rank)
     f.ghome = c->pipe.ghome;
     f.box = c->pipe.box;
     f.box_hot = pipe_has_top(c) ? c->pipe.boxes[c->pipe.rank + 1] : nullptr;
@@ -1928,13 +1930,16 @@ int hens_set_periodic(hens_ctx* ctx, const double* period) {
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE)
         return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters are not defined on leaf-packing records");
-    if (c->pipe.on) return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters on a rank of the ladder pipeline");
     bool any = false;
     if (period)
         for (int d = 0; d < c->D; ++d) {
             if (!(period[d] >= 0.0) || !(period[d] < INFINITY)) return fail(c, HENS_ERR_INVALID, "period of dimension %d must be finite and >= 0", d);
             any = any || period[d] > 0.0;
         }
+    if (c->pipe.on) {                 // a rank of the ladder pipeline keeps what it had at hens_pipe_init (the same on every rank)
+        if (!any && !c->period) return HENS_OK;
+        return fail(c, HENS_ERR_STATE, "set the periodic parameters before hens_pipe_init");
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
@@ -3319,7 +3324,6 @@ int hens_pipe_init(hens_ctx* ctx, int32_t nranks, int32_t my_rank, void* blob_ou
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (c->pipe.on) return fail(c, HENS_ERR_STATE, "pipeline already initialised");
     if (!c->cfg.tempered || c->T < 2) return fail(c, HENS_ERR_STATE, "the ladder pipeline needs a tempered ladder");
-    if (c->period) return fail(c, HENS_ERR_UNSUPPORTED, "periodic parameters on a rank of the ladder pipeline");
     if (nranks < 1 || nranks > PIPE_MAX_RANKS || my_rank < 0 || my_rank >= nranks)
         return fail(c, HENS_ERR_INVALID, "nranks must be in [1, %d] and my_rank inside it", PIPE_MAX_RANKS);
     if ((my_rank == 0) != (c->cfg.rung_begin == 0) || (my_rank == nranks - 1) != (c->cfg.rung_end == c->T))

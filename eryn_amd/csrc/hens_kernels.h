@@ -2677,7 +2677,7 @@ __host__ __device__ inline size_t fused_lds_bytes(int D, int NW, bool pipe = fal
 template <int DT, int LIKE, int NW, bool PER = false, bool SHORT = false, bool PIPE = false, bool COL = false>
 __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     static_assert(DT == 8 || DT == 16 || DT == 32 || DT == 64 || DT == 128, "power-of-two row width");
-    static_assert(!(PIPE && (PER || SHORT)), "pipeline ranks: full tiles, no periodic parameters");
+    static_assert(!(PIPE && SHORT), "pipeline ranks: full tiles");
     static_assert(!(COL && (PER || SHORT)), "column-ordered records: full tiles");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr bool CEN = like_centred(LIKE, DT);

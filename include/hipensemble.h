@@ -104,8 +104,8 @@ int hens_set_prior_box(hens_ctx* ctx, const double* lo, const double* hi, double
  *   stretch move measures c - s the short way round (stretch.py:136-141 -> periodic.py:49-116) and every proposal is
  *   wrapped into [0, period) with NumPy's remainder (stretch.py:149-154, gaussian.py:110-115 -> periodic.py:118-151);
  *   0 = not periodic; NULL or all zeros = no periodic parameters.  Every entry point honours it (the one- and two-launch
- *   iterations' compile-time-width kernels and the generic-width kernel alike); not available on a rank of the ladder
- *   pipeline or a leaf-packing context. */
+ *   iterations' compile-time-width kernels and the generic-width kernel alike, and the ranks of a ladder pipeline - set it
+ *   on every rank BEFORE hens_pipe_init); not available on a leaf-packing context. */
 int hens_set_periodic(hens_ctx* ctx, const double* period);
 int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec);
 int hens_set_rosenbrock(hens_ctx* ctx, double a, double b);

@@ -34,7 +34,7 @@ def problem(T, W, D):
 
 
 DELAY = int(os.environ.get("PIPE_TEST_DELAY", "0"))      # hens_config.adaptation_delay of every context
-MODEL = os.environ.get("PIPE_TEST_MODEL", "gauss")       # "rosen_mix": BASELINE config 4 in small - Rosenbrock + Stretch/Gaussian mix
+MODEL = os.environ.get("PIPE_TEST_MODEL", "gauss")       # "rosen_mix": BASELINE config 4 in small - Rosenbrock + Stretch/Gaussian mix; "gauss_periodic"
 
 
 def make(T, W, D, rng_range=None, delay=None):
@@ -47,6 +47,12 @@ def make(T, W, D, rng_range=None, delay=None):
     e = HipEnsemble(T, W, D, like, -6.0, 6.0, seed=SEED, rung_range=rng_range,
                     adaptation_delay=DELAY if delay is None else delay)
     r0, r1 = rng_range if rng_range else (0, T)
+    if MODEL == "gauss_periodic":                        # periodic parameters on every rank - before the pipeline is initialised
+        period = np.zeros(D)
+        period[1::3] = 5.0
+        e.set_periodic(period)
+        x0 = x0.copy()
+        x0[..., 1::3] = np.mod(x0[..., 1::3], 5.0)
     e.upload(x0[r0:r1], betas=betas)
     e.eval_state()
     if MODEL == "rosen_mix":
