@@ -231,7 +231,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     __shared__ double s_cur[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_q[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_leafv[RJ_WAVES][32];
-    __shared__ double s_rot[RJ_WAVES][2][32];
+    __shared__ double s_rot[RJ_WAVES][RJ_MAX_BRANCH][2][32];   // sine leaves: (sin, cos) of the rotation by 64 grid steps, per branch and leaf
     __shared__ double s_tab[64];                            // rj_exp_neg's table (every wave writes the same 64 values, then reads)
     s_tab[threadIdx.x & 63] = RJ_EXP_TAB[threadIdx.x & 63];
     const int lane = threadIdx.x & 63;
@@ -421,6 +421,16 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     if (evaluated && by_diff) {
         // template' = template + (born leaf) - (dead leaf) per branch under proposal: one leaf's values instead of every leaf's
         double acc = 0.0;
+        if (rot) {                             // the changing sine leaf's rotation, once for both chunks
+            for (int b = 0; b < M.nb; ++b) {
+                if (ch_sign[b] == 0 || M.kind[b] == RJ_KIND_PULSE) continue;
+                const double* src = ch_sign[b] > 0 ? q : cur;
+                double sd, cd;
+                sincos((2 * M_PI * src[M.off[b] + ch_leaf[b] * RJ_ND + 1]) * M.t_step64, &sd, &cd);
+                if (lane == 0) { s_rot[wv][b][0][0] = sd; s_rot[wv][b][1][0] = cd; }
+            }
+            RJ_LDS_SYNC();
+        }
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
             const int i0 = ch * 64 * NPT;
@@ -448,9 +458,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                     } else {
                         const double w = 2 * M_PI * bb;
                         if (rot) {
-                            double sd, cd;
-                            sincos(w * M.t_step64, &sd, &cd);
-                            sine_points(a, w, c, sd, cd, ti, tmk[ch], sg);
+                            sine_points(a, w, c, s_rot[wv][b][0][0], s_rot[wv][b][1][0], ti, tmk[ch], sg);
                         } else {
 #pragma unroll
                             for (int k = 0; k < NPT; ++k) tmk[ch][k] += sg * (a * sin(w * ti[k] + c));
@@ -481,6 +489,17 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         // formed once per chunk instead of once per point (the FP64 division was a third of the work per template
         // point).  Per point the leaves are still summed branch by branch in ascending slot order, and the lane's points in
         // ascending order, like the reference's NumPy sums over the leaf and the data axes.
+        if (rot) {                             // every sine leaf's rotation by 64 grid steps, a lane per leaf, once for all chunks
+            for (int b = 0; b < M.nb; ++b) {
+                if (M.kind[b] == RJ_KIND_PULSE) continue;
+                if (lane < M.nl[b]) {
+                    double sd, cd;
+                    sincos((2 * M_PI * q[M.off[b] + lane * RJ_ND + 1]) * M.t_step64, &sd, &cd);
+                    s_rot[wv][b][0][lane] = sd; s_rot[wv][b][1][lane] = cd;
+                }
+            }
+            RJ_LDS_SYNC();
+        }
         for (int i0 = 0; i0 < M.ndata; i0 += 64 * NPT) {
             double ti[NPT], tm[NPT];
 #pragma unroll
@@ -495,14 +514,6 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 for (int k = 0; k < NPT; ++k) sub[k] = 0.0;
                 uint32_t m = mask[b];
                 const bool pulse = M.kind[b] == RJ_KIND_PULSE;
-                if (!pulse && rot) {                 // every leaf's rotation by 64 grid steps, a lane per leaf
-                    if (lane < M.nl[b]) {
-                        double sd, cd;
-                        sincos((2 * M_PI * q[M.off[b] + lane * RJ_ND + 1]) * M.t_step64, &sd, &cd);
-                        s_rot[wv][0][lane] = sd; s_rot[wv][1][lane] = cd;
-                    }
-                    RJ_LDS_SYNC();
-                }
                 while (m) {
                     const int n = __builtin_ctz(m);
                     m &= m - 1u;
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                     } else {
                         const double w = 2 * M_PI * bb;
                         if (rot) {
-                            sine_points(a, w, c, s_rot[wv][0][n], s_rot[wv][1][n], ti, sub, 1.0);
+                            sine_points(a, w, c, s_rot[wv][b][0][n], s_rot[wv][b][1][n], ti, sub, 1.0);
                         } else {
 #pragma unroll
                             for (int k = 0; k < NPT; ++k) sub[k] += a * sin(w * ti[k] + c);      // tests/test_eryn.py:67-69
