@@ -29,6 +29,7 @@ def make(T, W, D, rr=None):
     invcov = a @ a.T / D + np.eye(D)
     r0, r1 = rr if rr else (0, T)
     e = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=3, rung_range=rr,
+                    adaptive=os.environ.get("PIPE_ADAPTIVE", "1") != "0",
                     adaptation_delay=int(os.environ.get("PIPE_DELAY", "0")) if rr is not None else 0)
     e.upload(np.random.RandomState(1).randn(T, W, D)[r0:r1], betas=make_ladder(D, ntemps=T))
     e.eval_state()
