@@ -411,8 +411,8 @@ size_t generic_lds_bytes(int D, int* RS_out) {
     *RS_out = RS;
     return (size_t)TILE * RS * 8 + (size_t)TILE * 8 + (size_t)4 * TILE * 8 + 4 * (size_t)TILE * 4;
 }
-size_t fast_lds_bytes(int D, int NW) {
-    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 128) * 8 + (4 * (size_t)TILE + 128) * 4 + mf_lds_extra(D);
+size_t fast_lds_bytes(int D, int NW, int like) {
+    return ((size_t)TILE * (D + 2) + TILE + (size_t)NW * TILE + 128) * 8 + (4 * (size_t)TILE + 128) * 4 + mf_lds_extra(D, like);
 }
 
 int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int ntiles) {
@@ -432,7 +432,7 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
         //  proposes nothing)
         const bool pipe = c->pipe.on, per = mode != MODE_EVAL && c->period;
         const int NW = fast_nw(c->D);
-        return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW), false,
+        return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW, like), false,
                              c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
     }
     int RS;
@@ -1059,7 +1059,7 @@ int launch_fused_like(hens_ctx_impl* c, int like, const FusedArgs& f, hipEvent_t
     // callers refuse)
     const bool plain = !pipe && !col, per = !col && f.period, shrt = plain && c->T * c->label_cb != 2 * TILE;
     // (the iteration's last launch: the call's last one carries the completion signal)
-    return launch_by_ptr(c, ktab_split1_pt(like, c->D, per, shrt, pipe, col), "k_split1_pt", grid, NW * 64, fused_lds_bytes(c->D, NW, pipe),
+    return launch_by_ptr(c, ktab_split1_pt(like, c->D, per, shrt, pipe, col), "k_split1_pt", grid, NW * 64, fused_lds_bytes(c->D, NW, like, pipe),
                          c->aql_last, e0, e1, f);
 }
 

@@ -1039,7 +1039,9 @@ constexpr int mf128_base(int I) { return 4 * (I * 8 - I * (I - 1) / 2); }       
 constexpr int mf128_I(int c) { int I = 0; while (I < 7 && c >= mf128_base(I + 1)) ++I; return I; }
 constexpr int mf128_J(int c) { return mf128_I(c) + (c - mf128_base(mf128_I(c))) / 4; }
 constexpr int mf128_S(int c) { return (c - mf128_base(mf128_I(c))) % 4; }
-__host__ __device__ constexpr size_t mf_lds_extra(int D) { return D == 64 ? 64 * 8 : (D == 128 ? 128 * 8 : 0); }   // mu in LDS (all likelihood kinds: one size per width)
+// mu in LDS, dense likelihood only (D = 128 on a pipeline rank: with it for every kind the diagonal likelihood's 127-VGPR launch would
+// lose its second workgroup per CU to 512 bytes of LDS)
+__host__ __device__ constexpr size_t mf_lds_extra(int D, int like) { return like != LIKE_DENSE ? 0 : (D == 64 ? 64 * 8 : (D == 128 ? 128 * 8 : 0)); }
 typedef double d4_t __attribute__((ext_vector_type(4)));
 struct MfRegs { double m[5]; };
 template <int DT, int LIKE, int NW>
@@ -2661,7 +2663,7 @@ __host__ __device__ constexpr size_t fused_lds_base(int D, int NW, bool pipe = f
     return ((size_t)TILE * (D + 2) + (size_t)NW * TILE + 5 * TILE + 3 * 2 * TILE + 64 + (pipe ? 2 * TILE : 0)) * 8 +
            (2 * 2 * TILE + 5 * TILE + 64 + (pipe ? 3 * TILE : 0)) * 4;
 }
-__host__ __device__ inline size_t fused_lds_bytes(int D, int NW, bool pipe = false) { return fused_lds_base(D, NW, pipe) + mf_lds_extra(D); }
+__host__ __device__ inline size_t fused_lds_bytes(int D, int NW, int like, bool pipe = false) { return fused_lds_base(D, NW, pipe) + mf_lds_extra(D, like); }
 
 // SHORT: the ladder length does not divide 128 - cb T < 128 slots and cb T / 2 < 64 moving walkers per workgroup.  An
 // instantiation of its own: with run-time bounds the full-tile launch lost its compile-time-true row guards, 0.2 us at
@@ -3047,8 +3049,15 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
                 if (!rv[p]) continue;
                 const int fl = s_flag[r];
                 const double2 ql = CEN ? qkeep[p] : *reinterpret_cast<const double2*>(qtile + r * RS + jl * 2);
-                const double2 o = sreg[p];
                 const bool acc = (fl & 2) != 0;
+                // (D = 128: a rejected guest's old row is read again here - a handful of rows per launch - instead of every row's
+                //  registers staying live from the gathers to this point: 32 VGPRs, the second workgroup per CU.  Narrower rows
+                //  keep the registers: at D = 64 the reload made the launch 1 us slower, 27.5 against 26.5)
+                double2 o = sreg[p];
+                if constexpr (DT == 128) {
+                    o = double2{0.0, 0.0};
+                    if (!acc && (fl & 8)) o = *reinterpret_cast<const double2*>(A.pool + row_off(s_rs[r], D, A.guest_delta) + jl * 2);
+                }
                 val[p].x = acc ? ql.x : o.x;
                 val[p].y = acc ? ql.y : o.y;
                 on[p] = (fl & (2 | 8)) != 0;
