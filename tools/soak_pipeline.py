@@ -8,7 +8,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16"); os.environ.setdefault("HENS_PI
 import numpy as np
 KEYS = ("x", "L", "P", "betas", "accepted", "swaps_total", "swaps_last")
 cases = ((2, 8, 512, 32, 20000, 0, "gauss"), (4, 8, 256, 16, 20000, 1, "gauss"), (2, 4, 256, 128, 5000, 0, "rosen_mix"),
-         (2, 16, 1024, 32, 10000, 0, "gauss"), (4, 8, 256, 16, 10000, 0, "rosen_mix"))
+         (2, 16, 1024, 32, 10000, 0, "gauss"), (4, 8, 256, 16, 10000, 0, "rosen_mix"),
+         (2, 8, 512, 64, 10000, 0, "gauss"), (2, 8, 256, 32, 10000, 1, "gauss_periodic"), (2, 8, 256, 64, 5000, 0, "gauss_periodic"))
 if len(sys.argv) > 1:
     import importlib
     nr, T, W, D, iters, delay = (int(v) for v in sys.argv[1:7]); model = sys.argv[7]
