@@ -1698,7 +1698,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // of the other: 106 VGPRs, two workgroups per CU, and a CU has as many bytes in flight as before (config 5's shard 28.4 -> 26.1
     // us per iteration).  Not on a pipeline rank (phase E stores the old rows from these registers there).  The pass bodies are
     // macros so that the other widths keep their one loop each, token for token: as lambdas the D = 32 launch was 0.2 us slower.
-    constexpr int HP = (DT == 128 && !PIPE) ? NPASS / 2 : NPASS;
+    // (D = 64 too - four passes, two halves: nothing for the dense likelihood, 110 -> 94 VGPRs either way two workgroups per CU, but
+    //  the diagonal and Rosenbrock launches get under 80 and a third workgroup: 8 x 16384 x 64 diagonal, first launch 16.3 -> 15.4 us)
+    constexpr int HP = (DT >= 64 && !PIPE) ? NPASS / 2 : NPASS;
 #define HENS_GATHER_PASS(p) \
         const int r = p * RPP + rsub;                                                                                                                          \
         rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;                                                                                             \
