@@ -1698,8 +1698,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // of the other: 106 VGPRs, two workgroups per CU, and a CU has as many bytes in flight as before (config 5's shard 28.4 -> 26.1
     // us per iteration).  Not on a pipeline rank (phase E stores the old rows from these registers there).  The pass bodies are
     // macros so that the other widths keep their one loop each, token for token: as lambdas the D = 32 launch was 0.2 us slower.
-    // (D = 64 too - four passes, two halves: nothing for the dense likelihood, 110 -> 94 VGPRs either way two workgroups per CU, but
-    //  the diagonal and Rosenbrock launches get under 80 and a third workgroup: 8 x 16384 x 64 diagonal, first launch 16.3 -> 15.4 us)
+    // (D = 64 too - four passes, two halves.  Measured: 8 x 16384 x 64 with the DIAGONAL likelihood, first launch 16.27 -> 15.40 us
+    //  (one box, one event-timed run of each build); the dense launch unchanged (21.9 / 21.75 us).  Registers of the diagonal
+    //  launch 100 -> 84, compiler-reported room 4 -> 5 waves per SIMD - which is still TWO eight-wave workgroups per CU, so
+    //  occupancy is not the explanation; the cause of the 0.9 us has not been isolated.  Rosenbrock was not measured with this
+    //  change alone.)
     constexpr int HP = (DT >= 64 && !PIPE) ? NPASS / 2 : NPASS;
 #define HENS_GATHER_PASS(p) \
         const int r = p * RPP + rsub;                                                                                                                          \
