@@ -163,7 +163,7 @@ __device__ __forceinline__ double rj_exp_neg(double x, const double* tab) {
 // (Measured and rejected, round 4: a sincos of our own for the rotation scheme's base points - two FMAs against pi / 2 = hi + lo and
 //  fdlibm's kernel polynomials, 1.02 * 2^-53 absolute, tools/probe/sincos_check.py.  With its 15 constants as literals the allocator
 //  spilled 34 VGPRs; with the constants out of LDS it fitted, and config 4 ran at 161.2 us per iteration against the library
-//  routine's 157.0: the library's small-argument path is cheaper than its instruction count suggests.)
+//  routine's 157.0 (presumably the library's small-argument path executes far fewer instructions than its static count: not examined).)
 // ndarray.sum(axis=-1) of v[0..n): NumPy's pairwise order (n < 8: a plain loop from 0.0; 8 <= n <= 128: eight partial
 // sums, the tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail).  Checked against NumPy for n = 1..20.
 __device__ __forceinline__ double numpy_sum(const double* v, int n) {
