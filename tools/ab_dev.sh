@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box timing of dev builds at config 2: tools/ab_dev.sh [-e "ENV=1 ..."] [-a "quick_bench args"] name1 name2 ...   (build_ab/libhens_<name>.so)
+# same-box timing of dev builds at config 2: tools/ab_dev.sh [-e "ENV=1 ..."] [-a "quick_bench args"] name1 name2 ...   (ab_live/libhens_<name>.so)
 export PYTHONPATH=$GRAFT_REPO_ROOT
 cd $GRAFT_REPO_ROOT
 EXTRA=""; ARGS=""
@@ -9,6 +9,6 @@ while [ "$1" == "-e" ] || [ "$1" == "-a" ]; do
 done
 for rep in 1 2; do
   for n in "$@"; do
-    echo -n "$n: "; env $EXTRA HENS_LIB=$GRAFT_REPO_ROOT/build_ab/libhens_$n.so timeout 120 python tools/quick_bench.py --steps 4000 $ARGS 2>&1 | grep -o "[0-9.]* us/iter" || echo failed
+    echo -n "$n: "; env $EXTRA HENS_LIB=$GRAFT_REPO_ROOT/ab_live/libhens_$n.so timeout 120 python tools/quick_bench.py --steps 4000 $ARGS 2>&1 | grep -o "[0-9.]* us/iter" || echo failed
   done
 done

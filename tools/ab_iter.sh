@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the one-launch iteration: base library (tools/mkbase.sh) vs current, config 2 (+ replay test of the current one)
 export PYTHONPATH=$GRAFT_REPO_ROOT
-B=$GRAFT_REPO_ROOT/build_ab/libhens_base.so
+B=$GRAFT_REPO_ROOT/ab_live/libhens_base.so
 timeout 300 python -m pytest tests/test_hip_replay.py -x -q -m gpu -k "config2 or small_two or diag" 2>&1 | tail -2
 for i in 1 2; do
   echo -n "base: "; HENS_LIB=$B timeout 120 python tools/quick_bench.py --prof 0 2>&1 | head -1 | cut -c60-

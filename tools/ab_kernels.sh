@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B (see ab_lib.sh): per-kernel durations and the gaps in front of them from a rocprofv3 kernel trace
 R=$GRAFT_REPO_ROOT; export PYTHONPATH=$R
-B=$R/build_ab/libhens_base.so
+B=$R/ab_live/libhens_base.so
 cd /tmp && export TMPDIR=/tmp
 for which in base new base new; do
   rm -rf /tmp/p3
