@@ -357,9 +357,26 @@ def run_single(args):
         "roofline": roof,
     }
     if (T, W, D) == (16, 4096, 32) and not args.no_other:
-        # the shapes whose state does not fit the caches, timed by the same clock in the same run (a few ms of GPU time each)
+        # the shapes whose state does not fit the caches, timed by the same clock in the same run (a few ms of GPU time each),
+        # and BASELINE configs 4 and 5 whole on this one GPU (0.3 s of GPU time each): every config's single-GPU figure in one line
         out["other_shapes"] = {"config_3_shard": time_other_shape(8, 16384, 64, args.steps, args.warmup),
                                "config_5_shard": time_other_shape(4, 8192, 128, args.steps, args.warmup, rosen_mix=True)}
+        sub = argparse.Namespace(**vars(args))
+        sub.ntemps = sub.nwalkers = sub.ndim = None
+        for name, fn in (("config_4", run_cfg4), ("config_5_one_gpu", run_cfg5)):
+            try:
+                r = fn(sub)
+                out["other_shapes"][name] = {"shape": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "value": r["value"],
+                                             "cold_blocks": cold_blocks([t_ / 1e3 for t_ in r["block_ms"]], args.steps, r["config"]["ntemps"] * r["config"]["nwalkers"]),
+                                             "config": {k: v for k, v in r["config"].items() if k != "workload"},
+                                             "roofline": {k: v for k, v in r["roofline"].items() if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_path_frac", "whole_path_frac_moved", "kernel")} |
+                                                         ({"kernels": [{k: v for k, v in kk.items() if k in ("kernel", "launches_per_iteration", "avg_launch_us", "frac", "frac_moved", "frac_traffic")}
+                                                                        for kk in r["roofline"]["kernels"]]} if "kernels" in r["roofline"] else {})}
+            except Exception as exc:                  # noqa: BLE001  (a secondary figure must not cost the headline line)
+                out["other_shapes"][name] = {"error": f"{type(exc).__name__}: {exc}"}
+        for v in out["other_shapes"].values():        # (the line is long enough: the other shapes keep their first five blocks only)
+            if "block_ms" in v:
+                v["block_ms"] = v["block_ms"][:5]
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(T, W, D, seconds=args.cpu_seconds)
         out["vs_cpu"] = value / out["cpu_baseline"]["value"]

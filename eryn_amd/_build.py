@@ -16,7 +16,13 @@ SOURCES = sorted({os.path.join(SRC_DIR, u[1]) for u in UNITS})
 DEPS = SOURCES + [os.path.join(SRC_DIR, h) for h in ("hens_kernels.h", "hens_rj.h", "hens_iter.h", "hens_aql.h", "hens_ktable.h", "hens_ktable.inc")] + [
     os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-cuda-compat"] + os.environ.get("HENS_BUILD_DEFS", "").split()   # (inline __global__: see hens_kernels.h)
-LINK = ["-L/opt/rocm/lib", "-lhsa-runtime64"]      # (direct AQL dispatch of the stepping launches: csrc/hens_aql.h)
+
+
+def link_flags(hipcc):
+    """-lhsa-runtime64 (direct AQL dispatch of the stepping launches: csrc/hens_aql.h) from the ROCm tree hipcc itself lives in."""
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    dirs = [d for d in (os.path.join(root, "lib"), "/opt/rocm/lib") if os.path.isdir(d)]
+    return ["-L" + d for d in dict.fromkeys(dirs)] + ["-lhsa-runtime64"]
 
 
 def hipcc_path():
@@ -73,7 +79,7 @@ def build(force=False, verbose=False):
                 f.write(" ".join(cmd))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[0] for j in jobs] + ["-o", LIB_PATH] + LINK
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[0] for j in jobs] + ["-o", LIB_PATH] + link_flags(hipcc)
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -117,6 +117,7 @@ SIGNATURES = {
     "hens_debug_draws": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hens_version": (C.c_char_p, []),
     "hens_device_count": (C.c_int, []),
+    "hens_device_pci_bus_id": (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
 }
 
 _lib = None
@@ -136,8 +137,14 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m eryn_amd._build` "
             "(hipcc --offload-arch=gfx950); eryn_amd has no CPU fallback")
     lib = C.CDLL(LIB_PATH)
+    other_build = bool(os.environ.get("HENS_LIB"))   # a same-box A/B against another revision's build (tools/mkbase.sh)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        try:
+            fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        except AttributeError:
+            if other_build:           # (an older build may lack entry points added since; calling one still fails loudly)
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib

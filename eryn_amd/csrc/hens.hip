@@ -8,7 +8,19 @@
 #include "hens_ktable.h"
 #include <unordered_map>
 #include <hip/hip_ext.h>
-#include <rccl/rccl.h>          // (types and prototypes only: the library is dlopen()ed, see rccl_api)
+// RCCL: types only - the library is dlopen()ed (rccl_api), nothing of it is linked.  A ROCm without the RCCL development headers
+// still builds: the few types the dlsym'ed entry points use, as rccl.h (NCCL 2.x API) declares them.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+typedef enum { ncclUint32 = 3, ncclDouble = 8 } ncclDataType_t;
+}
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -745,11 +757,19 @@ void pipe_wait(hens_ctx_impl* c, std::initializer_list<int> which, bool counts, 
 // before the stretch move of sweep s > 0: the rows that arrived in sweep s-1 and (if a ladder adaptation is
 // pending) every rank's swap counts must be here.  The fast stretch kernel waits in its own prologue
 // (wmask); other row widths get a wait kernel.
+// dev hook: HENS_PIPE_INJECT_CYCLES=n - the previous sweep's swap-count flags count as raised only n shader cycles after the adapting
+// workgroup of the first launch has started (StretchArgs::inject_c64; tools/pipe_slack.sh measures the slack with it)
+int32_t pipe_inject_c64() {
+    static const long n = getenv("HENS_PIPE_INJECT_CYCLES") ? atol(getenv("HENS_PIPE_INJECT_CYCLES")) : 0;
+    return n > 0 ? (int32_t)((n + 63) / 64) : 0;
+}
 unsigned long long pipe_prewait_mask(const hens_ctx_impl* c) {
     if (!pipe_active(c) || c->pipe.sweep == 0 || c->pipe.staged) return 0ull;
     unsigned long long m = 0;
     if (pipe_has_top(c)) m |= 1ull << PF_ROWS_TOP;
-    if (c->adapt_pending && c->adapt_src != nullptr && c->pipe.nranks > 1)
+    // (a lone rank reads the counts it pushed itself: no flag needed - unless the latency-injection hook is on, which delays
+    //  exactly that flag: pipe_inject_c64)
+    if (c->adapt_pending && c->adapt_src != nullptr && (c->pipe.nranks > 1 || pipe_inject_c64() > 0))
         for (int q = 0; q < c->pipe.nranks; ++q) m |= 1ull << (PF_CNT0 + q);
     return m;
 }
@@ -902,6 +922,7 @@ void attach_iteration_head(hens_ctx_impl* c, StretchArgs& a) {
             a.wtarget_cnt = c->pipe.due_sweep + 1;
             a.wbudget = c->pipe.budget;
             a.wstats = c->pipe.stats;
+            a.inject_c64 = pipe_inject_c64();
         }
     }
     if (pipe_counts_in_stretch(c) && c->pipe.sweep > 0) {      // the counts of the sweep that just ended
@@ -1134,6 +1155,13 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     const int T = c->T, W = c->W;
     if (!c->packed) {                        // (the pack kernel - first call after another entry point - runs on the HIP stream)
         const int r = hip_interlude(c, [&] { state_to_records(c); });
+        if (r) return r;
+    }
+    if (c->adapt_pending && !can_fold_adapt(c)) {
+        // an adaptation that cannot ride in the first launch (HENS_NO_FOLD=1; counts in more rows than a wave sums) is a kernel of
+        // its own on the HIP stream: the AQL queue drains first - its last packets are the previous cascade, which wrote the counts,
+        // and nothing orders the two queues but the host (round 4 launched it from attach_iteration_head beside the queued packets)
+        const int r = hip_interlude(c, [&] { flush_adapt(c); });
         if (r) return r;
     }
     const uint32_t* keys = iteration_keys(c);
@@ -1683,6 +1711,13 @@ int hens_device_count(void) {
     return n;
 }
 
+int hens_device_pci_bus_id(int32_t device_id, char* out, int32_t capacity) {
+    if (!out || capacity < 16) return fail(nullptr, HENS_ERR_INVALID, "hens_device_pci_bus_id: buffer of at least 16 bytes");
+    const hipError_t e = hipDeviceGetPCIBusId(out, capacity, device_id);
+    if (e != hipSuccess) return fail(nullptr, HENS_ERR_HIP, "hipDeviceGetPCIBusId(%d): %s", (int)device_id, hipGetErrorString(e));
+    return HENS_OK;
+}
+
 const char* hens_last_error(const hens_ctx* ctx) {
     const hens_ctx_impl* c = reinterpret_cast<const hens_ctx_impl*>(ctx);
     return c ? c->err.c_str() : g_last_error.c_str();
@@ -1740,8 +1775,11 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         static const bool aql_off = getenv("HENS_NO_AQL") != nullptr;
         if (!aql_off) {
             hens_aql::Device& ad = hens_aql::device(cfg->device_id);
-            if (ad.ok && c->aql.create(ad)) c->aql_on = true;
-            else {
+            if (ad.ok && c->aql.create(ad)) {
+                c->aql_on = true;
+                static const int fm = getenv("HENS_AQL_FLUSH") ? atoi(getenv("HENS_AQL_FLUSH")) : -1;   // (see hens_aql::Queue::flush_mode)
+                if (fm >= 0 && fm <= 3) c->aql.flush_mode = fm;
+            } else {
                 static bool warned = false;
                 if (!warned) fprintf(stderr, "[hipensemble] direct AQL dispatch unavailable (%s): stepping launches use the HIP stream\n",
                                      ad.ok ? c->aql.err.c_str() : ad.err.c_str());
@@ -2088,6 +2126,9 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     if (logp) HIPCHK(c, hipMemcpyAsync(logp, c->P[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
     if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas[c->bcur], (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    // leaf-packing contexts: what the caller now holds is what a resumed chain would start from - the next hens_rj_step call
+    // re-evaluates the resident templates and log-likelihoods from the coordinates, as it does after an upload (see hens_rj_step)
+    if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE && (x || logl)) c->rj_tm_valid = false;
     return HENS_OK;
 }
 
@@ -2964,13 +3005,21 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->step_events = true;
     c->timing = hens_timing{};
-    // resident templates (RjArgs::tm): made true once (after an upload / a parity-API move), kept true by every accepting launch,
-    // and re-evaluated from scratch every RJ_REFRESH iterations so that the rounding of a chain of +- leaf updates cannot pile up
+    // resident templates (RjArgs::tm): kept true by every accepting launch, and re-evaluated from scratch - templates AND log-
+    // likelihoods - whenever the state has crossed the C ABI since the last call (upload, parity-API move, DOWNLOAD) and every
+    // RJ_REFRESH iterations (by the iteration counter), so that the rounding of a chain of +- leaf updates cannot pile up beyond 64
+    // iterations.  Round 5: the evaluation after an upload used to rebuild the templates only, and a download did not count; a
+    // chain resumed from a stored State (exact templates) then parted from the uninterrupted one (templates with up to 63
+    // iterations of +- updates behind them) in the last bits of its birth / death likelihoods.  Now the resident state behind a
+    // download is a function of what the download returned, so a chain is a function of (State, seed, iteration counter,
+    // adaptation time): resumed in a new context it is the uninterrupted chain bit for bit (tests/test_hip_rj.py).
     constexpr int64_t RJ_REFRESH = 64;
     const int tmode = c->rj_tm ? 0 : -1;
+    bool fresh = false;
     if (c->rj_tm && !c->rj_tm_valid && n_iters > 0) {
-        if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2))) return r;
+        if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0))) return r;
         c->rj_tm_valid = true;
+        fresh = true;
     }
     static const bool fold_off = getenv("HENS_NO_FOLD") != nullptr;           // A/B knob: k_adapt behind every cascade
     if (!c->rj_ad_flag && !fold_off) {
@@ -2983,8 +3032,9 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     } defer{c};
     c->rj_defer_adapt = !fold_off && c->rj_tm != nullptr;
     for (int64_t i = 0; i < n_iters; ++i) {
-        if (c->rj_tm && c->iter % RJ_REFRESH == RJ_REFRESH - 1)
+        if (c->rj_tm && c->iter % RJ_REFRESH == RJ_REFRESH - 1 && !fresh)
             if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0))) return r;
+        fresh = false;
         // in-model Gaussian move on the packed leaves, then swaps + adaptation (mh.py:190-191)
         if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tmode))) return r;
         c->rj_num_mh += 1;

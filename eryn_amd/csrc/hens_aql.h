@@ -254,7 +254,11 @@ struct Queue {
     bool kernarg_dev = false;        // the ring is device memory mapped into the host (writes cross the BAR: flush before the doorbell)
     bool kernarg_fine = false;
     volatile char* last_ka = nullptr;
-    int flush_mode = 2;              // 0 sfence only, 1 + HDP flush register write, 2 + read back except at a call's first doorbell (measured: 5.0 vs 6.7 us per call)
+    // how argument writes are made visible before a doorbell: 0 sfence only, 1 + HDP flush register write, 2 + read back except at a
+    // call's first doorbell (measured: 5.0 vs 6.7 us per call), 3 + read back before EVERY doorbell - the ordered form, what HIP's
+    // own runtime does for device-resident kernel arguments, and the default since round 5 (HENS_AQL_FLUSH=2 opts into the shortcut:
+    // it relies on the packet fetch over PCIe taking longer than the flush, which holds on this machine and is no guarantee)
+    int flush_mode = 3;
     bool acq_agent_ok = true;        // the first packet of a call acquires at agent scope when only this queue touched the state
     uint64_t windex = 0;             // next packet index (single producer: the context's host thread)
     uint64_t rung = 0;               // packets below this index have been handed to the doorbell
@@ -373,7 +377,7 @@ struct Queue {
             // and ahead of the doorbell (posted writes to one device stay in order).  With the queue backlogged the read-back that
             // waits for the flush costs host time nobody misses; in front of a call's FIRST doorbell - the GPU is idle, and the
             // packet processor still has to fetch the packet over PCIe (>= 1 us) before any wave starts - it is skipped: 1.8 us per call.
-            const int mode = (rung == call_first && flush_mode == 2) ? 1 : flush_mode;
+            const int mode = flush_mode == 2 ? (rung == call_first ? 1 : 2) : (flush_mode >= 3 ? 2 : flush_mode);
             __builtin_ia32_sfence();
             if (mode >= 1 && dev->hdp.HDP_MEM_FLUSH_CNTL) {
                 *reinterpret_cast<volatile uint32_t*>(dev->hdp.HDP_MEM_FLUSH_CNTL) = 1u;

@@ -285,25 +285,36 @@ __device__ __forceinline__ bool pipe_last_ticket(unsigned* ticket, uint32_t targ
     return s_last_t != 0;
 }
 
+// A flag wait's budget is given in ticks of the 100 MHz wall clock but measured on the shader clock (s_memtime, a scalar load's
+// worth of cycles): reading the wall clock (s_memrealtime) takes ~1.5 us on this chip, and rounds 2-4 read it once in front of
+// every spin that had to wait at all and once per poll - a wait for a value one memory round trip away cost 3 us and more,
+// every wait was quantised to 1.5 us.  The shader clock runs at <= 2.4 GHz: a budget of b ticks is at least b * 10 ns.
+__device__ __forceinline__ bool spin_expired(unsigned long long t0, long long budget_ticks) {
+    return (long long)(__builtin_amdgcn_s_memtime() - t0) > budget_ticks * 24;
+}
+
 // a workgroup's thread 0 spins until flag >= target (or the budget runs out: a peer died - fail the run
 // instead of hanging the GPU); callers follow with __syncthreads()
+// inject (dev hook, HENS_PIPE_INJECT_CYCLES): the flag counts as raised only once the shader clock has passed `inject_until` - a
+// neighbour whose message arrives that late (see StretchArgs::inject_cycles)
 __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, long long budget, unsigned* err,
-                                          unsigned long long* stats = nullptr) {
-    // the wall clock (s_memrealtime) takes ~1.5 us to read: start it only if the flag is not there yet
-    if (!stats && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= target) {
+                                          unsigned long long* stats = nullptr, unsigned long long inject_until = 0) {
+    if (!stats && !inject_until && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= target) {
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         return;
     }
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+    const long long w0 = stats ? wall_clock64() : 0;      // (debug statistics only: ~1.5 us per reading)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target ||
+           (inject_until && (long long)(__builtin_amdgcn_s_memtime() - inject_until) < 0)) {
         __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - t0 > budget) {
+        if (spin_expired(t0, budget)) {
             atomicOr(err, FLAG_PIPE_TIMEOUT);
             return;
         }
     }
     if (stats) {                       // debug (HENS_PIPE_STATS): ticks spent waiting and number of waits at this site
-        atomicAdd(stats, (unsigned long long)(wall_clock64() - t0));
+        atomicAdd(stats, (unsigned long long)(wall_clock64() - w0));
         atomicAdd(stats + 1, 1ull);
     }
     // Acquire side of the hand-off.  Hardware: the wave has waited for the flag's value (the branch depends on it), and
@@ -324,10 +335,10 @@ __device__ __forceinline__ bool pipe_arrive_collect(unsigned* ticket, unsigned n
     if (blockIdx.x != 0) return false;
     if (threadIdx.x == 0 && __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nblocks * (sweep + 1u)) {
         const unsigned target = nblocks * (sweep + 1u);              // cumulative over the sweeps (mod 2^32)
-        const long long t0 = wall_clock64();
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > budget) {
+            if (spin_expired(t0, budget)) {
                 atomicOr(err, FLAG_PIPE_TIMEOUT);
                 break;
             }
@@ -564,7 +575,10 @@ struct StretchArgs {
     // is a lookup by column in the rung's compact row table (`loc`, 4 W bytes per rung: L2-resident).
     // k_split1_pt<COL> writes the next buffers in the NEXT iteration's column order (scattered stores at its tail instead of
     // scattered loads at both launches' heads).
-    int32_t col, col_pad_;
+    int32_t col;
+    int32_t inject_c64;        // dev hook (HENS_PIPE_INJECT_CYCLES, pipeline ranks): the swap-count flags of the previous sweep count as raised
+                               // only that many x 64 shader cycles after the adapting workgroup's start - a neighbour whose counts
+                               // arrive that late; 0: off.  Measures the slack the first launch absorbs (tools/pipe_slack.sh)
     // parity API with nsplits > 2 (red_blue.py:41-47,148): the moving set's position range, given explicitly (0: the two-half
     // rule from N0 / split); `split` is then 0 for the first set, 1 for the last (every complement already sits in its home
     // row) and 2 for the ones between
@@ -1343,8 +1357,19 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (A.cnt_push == 2 && wv == 1) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T,
                                                          A.rung_begin, W, DT, A.cp_sweep, lane);
     }
-    if (PIPE && !EVAL && A.wmask) {          // rows and swap counts of the previous sweep (ladder pipeline)
-        if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || ad_here || !ad_lead))
+    // Round 5: the swap counts are waited for by the ONE wave that needs them - the adapting wave of workgroup (0,0), below - and no
+    // longer by the whole workgroup at the head of the launch (rounds 3-4: wave 0 spun for every rank's counts, then a
+    // __syncthreads(), then the ~4 000-cycle adaptation chain in front of the first barrier; the workgroup started its own tile
+    // 4-5 us late and the launch ended with it).  The rows' flag (PF_ROWS_TOP) is everybody's: nobody gathers before it.
+    const bool cnt_wait = PIPE && !EVAL && ad_here && ad_lead && (A.wmask >> PF_CNT0) != 0ull;
+#ifdef HENS_DEV_BUILD      // (latency injection: dev builds only - two more live scalars cost the production kernel SGPR spills)
+    unsigned long long inject_until = 0;
+    if (PIPE && !EVAL && A.inject_c64 > 0 && cnt_wait) inject_until = __builtin_amdgcn_s_memtime() + (unsigned long long)A.inject_c64 * 64ull;
+#else
+    constexpr unsigned long long inject_until = 0;
+#endif
+    if (PIPE && !EVAL && A.wmask) {          // rows of the previous sweep (ladder pipeline)
+        if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || (!ad_lead && ad_here)))
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
                       A.wstats ? A.wstats + (lane >= PF_CNT0 ? 2 : 0) : nullptr);
         __syncthreads();
@@ -1355,6 +1380,10 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // that need the counts but not the cumulative sum) while it would otherwise idle before the first barrier, and only
     // the second one (cumsum, reciprocals, update) in the shadow of the row gathers.
     const bool ad_early = ad_here && A.ad.nblocks <= 8 * A.ad.row_groups;
+    // (a pipeline rank's adapting workgroup runs the whole chain in one piece - in front of the first barrier if every rank's counts
+    //  are there by then, else behind its row gathers, cnt_late below: the other workgroups wait for the ring it publishes, and split
+    //  around the barrier the second part's state stayed live across the gathers - measured, round 5: SGPR spills 4 -> 21 at D = 64,
+    //  every workgroup's phase A 0.4 us longer)
     const bool ad_defer = ad_early && !PIPE && !ad_lead;
     const bool ad_x = ad_defer && NW >= 4 && A.ad.T <= 64 && A.ad.moving;    // (see ADX below)
     double ad_c0 = 0.0, ad_c1 = 0.0, ad_dT0 = 0.0, ad_dT1 = 0.0, ad_b0n = 1.0, ad_b1n = 1.0, ad_bb0 = 1.0, ad_bb1 = 1.0, ad_inv0 = 1.0;
@@ -1533,7 +1562,22 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         }
         adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1, ad_x);
     };
-    if (ad_early && wv == ADW) {
+    // A pipeline rank on the reference's schedule: every rank's swap counts of the sweep that just ended are due in THIS launch
+    // (tempering.py:563-649 adapts after the sweep), but beta is first consumed in the accept phase (red_blue.py:285-308).  The
+    // adapting wave looks for the count flags ONCE here; if a rank's counts are still on their way it does not wait - the
+    // workgroup's other waves would wait for it at the first barrier - but comes back for them behind its row gathers (cnt_late).
+    bool cnt_late = false;                       // (wave-uniform)
+    if constexpr (PIPE) {
+        if (cnt_wait && wv == ADW) {
+            bool here = true;
+            if (lane >= PF_CNT0 && ((A.wmask >> lane) & 1ull))
+                here = __hip_atomic_load(A.wflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= A.wtarget_cnt;
+            if (inject_until && (long long)(__builtin_amdgcn_s_memtime() - inject_until) < 0) here = false;
+            cnt_late = __ballot(!here) != 0ull;
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);          // (acquire side: see pipe_spin)
+        }
+    }
+    if (ad_early && wv == ADW && !cnt_late) {
         const int T = A.ad.T, NR = A.ad.nblocks;
         // (row_groups G > 1 - ladders of at most 64 / G pairs: lane = (group g, pair p), group g sums rows g, g + G, ...)
         const int G = A.ad.row_groups, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;
@@ -1734,6 +1778,21 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     double2 qkeep[NPASS];                          // the proposal itself stays here for phase E (the tile holds q - mu)
     if (MODE == MODE_STRETCH && wv == 0 && late_ua >= 0.0)         // the Hastings factor's logarithm, while the row gathers fly
         factors = ((double)A.ndim_active - 1.0) * log(s_zz[lane]);                // stretch.py:223
+    if constexpr (PIPE) {
+        if (cnt_late && wv == ADW) {
+            // the counts were not there at the first look: wait for them now (the polls queue up behind this wave's own gathers -
+            // loads return in order - so the chain below overlaps the OTHER waves' gathers only), then the whole chain and the ring
+            if (lane >= PF_CNT0 && ((A.wmask >> lane) & 1ull))
+                pipe_spin(A.wflags + lane, A.wtarget_cnt, A.wbudget, A.flags, A.wstats ? A.wstats + 2 : nullptr, inject_until);
+            const int T = A.ad.T, NR = A.ad.nblocks;
+            unsigned s0 = 0, s1 = 0;                          // (the mailbox's reduced counts: one row; row_groups = 1)
+            for (int r = 0; r < NR; ++r) {
+                s0 += (lane < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane] : 0u;
+                s1 += (lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
+            }
+            adapt_publish((double)s0, (double)s1, (lane < T) ? A.ad.betas_in[lane] : 1.0, (lane + 64 < T) ? A.ad.betas_in[lane + 64] : 1.0);
+        }
+    }
     if (ad_defer && wv == ADW) {                   // second part: the working waves' row gathers are in flight
         if (ad_defer_all) adapt_early();
         if (ad_x && lane + 2 < A.ad.T) ad_dT0 *= s_exp[lane];                      // :578-579 (the other wave's half of the first part)
@@ -1863,7 +1922,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     // mode 2: the rung's new beta, requested now and consumed after the likelihood (phase D)
     double beta_ring = -1.0;
     const double* ring_slot = nullptr;
-    if (ad_lead && wv == 0) {
+    // (a pipeline rank's adapting workgroup may publish late - cnt_late - and reads its own LDS copy; elsewhere it asks the ring like
+    //  everybody: the condition stays the round-4 one there, token for token - one more live scalar pair cost the single-GPU
+    //  instantiations SGPR spills and, at D = 128, 20 bytes of scratch)
+    const bool ring_me = ad_lead && !(PIPE && ad_here);
+    if (ring_me && wv == 0) {
         ring_slot = A.ad_ring + (size_t)(A.ad_serial & 3u) * A.ad.T + (A.rung_begin + tl);
         beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1899,13 +1962,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             double logP, prevP;
             if (A.tempered) {                                  // tempering.py:304-306,343-349
                 double beta = beta_pre;
-                if (ad_lead) {                                 // workgroup (0,0) may still be adapting: wait for the value
-                    if (beta_ring < 0.0) {                     // (rare; reading the wall clock costs ~1.5 us: only when waiting)
-                        const long long t0 = wall_clock64();
+                if (ring_me) {                                 // workgroup (0,0) may still be adapting: wait for the value
+                    if (beta_ring < 0.0) {                     // (the budget runs on the shader clock: see spin_expired)
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
                         while (beta_ring < 0.0) {
                             __builtin_amdgcn_s_sleep(1);
                             beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (wall_clock64() - t0 > 200000000LL) { atomicOr(A.flags, FLAG_PIPE_TIMEOUT); break; }
+                            if (spin_expired(t0, 200000000LL)) { atomicOr(A.flags, FLAG_PIPE_TIMEOUT); break; }
                         }
                     }
                     beta = beta_ring;
@@ -3850,9 +3913,9 @@ inline __global__ __launch_bounds__(PT_THREADS) void k_pipe_walk(const PipeArgs 
     if (!A.count_tail) return;
 
     // ---- workgroup 0 speaks for the launch once everyone has arrived: the swap counts of my pairs ------
-    const long long dbg_t0 = wall_clock64();
+    const long long dbg_t0 = A.stats ? wall_clock64() : 0;         // (debug statistics only: ~1.5 us per reading)
     if (!pipe_arrive_collect(A.tickets + 0, gridDim.x, A.sweep, A.budget, A.flags)) return;
-    const long long dbg_t1 = wall_clock64();
+    const long long dbg_t1 = A.stats ? wall_clock64() : 0;
     const int NP = TE - 1;
     unsigned* s_n = reinterpret_cast<unsigned*>(smem_raw);           // [NP] (the column tables are dead)
     for (int i = tid; i < NP; i += PT_THREADS) s_n[i] = 0;

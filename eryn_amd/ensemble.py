@@ -140,9 +140,10 @@ class EnsembleSampler:
             st = [(m, w) for m, w in zip(self.moves, self.weights) if isinstance(m, StretchMove)]
             if len(mh) > 1 or len(st) > 1 or any(not isinstance(m, GaussianMove) for m, _ in mh):
                 raise NotImplementedError("rng='philox' mixes at most one StretchMove with one GaussianMove")
+            self._mh_weight = float(mh[0][1]) if mh else 0.0
+            self._mh_pushed = None
             if mh:
-                kind, scale = mh[0][0].device_proposal()
-                self.engine.set_mh_proposal(kind, scale, float(mh[0][1]))
+                self._push_mh_proposal(mh[0][0])
             self._philox_moves = (st[0][0] if st else None, mh[0][0] if mh else None)
 
         # -- backend + RNG (ensemble.py:593-652)
@@ -255,6 +256,15 @@ class EnsembleSampler:
             self._previous_state = state
             yield state
 
+    def _push_mh_proposal(self, mh_move):
+        """Hand the Gaussian move's proposal to the device if it differs from what the device holds (construction; a ``tune`` hook
+        that rescales the move, ensemble.py:983-984 - the reference's hook mutates the move object the next proposal reads)."""
+        kind, scale = mh_move.device_proposal()
+        key = (kind, np.asarray(scale, dtype=np.float64).tobytes())
+        if key != self._mh_pushed:
+            self.engine.set_mh_proposal(kind, scale, self._mh_weight)
+            self._mh_pushed = key
+
     def philox_checkpoint(self):
         """What a stored State carries as ``random_state`` in Philox mode: the device draws are a pure function of (seed,
         iteration, rung, walker), so (seed, iteration counter, adaptation time) is the whole generator state - the device-side
@@ -298,14 +308,12 @@ class EnsembleSampler:
             # (thin_by > 1: ONE device call; the counters in front of the last sub-iteration stay on the device until the
             #  download below - no split call, no counter read in between)
             mid_acc, mid_mh_acc = prev["accepted"], None if prev_mh is None else prev_mh["accepted"]
-            tuned_accepted = None
             if tune:
                 # the reference calls move.tune(state, accepted_out) after EVERY proposal with that proposal's own mask
                 # (ensemble.py:969-984): a host hook per proposal, so the device steps one iteration at a time here and the
                 # move that ran is read off the counters
                 last, last_mh = prev, prev_mh
                 for _sub in range(thin_by):
-                    tuned_accepted = np.zeros_like(prev["accepted"])   # (re-zeroed every sub-iteration, ensemble.py:968)
                     if _sub == thin_by - 1:
                         mid_acc = last["accepted"]
                         mid_mh_acc = None if last_mh is None else last_mh["accepted"]
@@ -316,12 +324,15 @@ class EnsembleSampler:
                         ran_stretch = c1["num_proposals"] > last["num_proposals"]
                         out = c1["accepted"] - last["accepted"] if ran_stretch else cm1["accepted"] - last_mh["accepted"]
                         xi, Li, Pi, bi = eng.download()
+                        if tc is not None:
+                            tc.time = c1["adapt_time"]             # (the checkpoint in the State the hook sees: this proposal's)
                         st_i = State({name: xi[:, :, None, :]}, inds={name: inds}, log_like=Li, log_prior=Pi,
                                      betas=None if tc is None else bi, random_state=self.philox_checkpoint())
                         (st_move if ran_stretch else mh_move).tune(st_i, out)
                         if st_move is not None and eng.a != float(st_move.a):      # (the hook may retune the stretch scale)
                             eng.set_stretch_scale(st_move.a)
-                        tuned_accepted += out
+                        if mh_move is not None:                                    # (... or the Gaussian move's scale / covariance)
+                            self._push_mh_proposal(mh_move)
                         last, last_mh = c1, cm1
             elif thin_by > 1 and hasattr(eng, "step_marked"):
                 eng.step_marked((thin_by - 1) * reps, reps)

@@ -240,8 +240,17 @@ class LadderPipeline:
             dev = getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None)
         except Exception:                             # noqa: BLE001
             dev = None
+        if dev is None:                               # ... then from the HIP runtime itself, through the library
+            try:
+                import ctypes
+                from . import _lib
+                buf = ctypes.create_string_buffer(64)
+                if _lib.load().hens_device_pci_bus_id(int(device_id), buf, 64) == 0 and buf.value:
+                    dev = buf.value.decode()
+            except Exception:                         # noqa: BLE001
+                dev = None
         if dev is None:
-            # no physical id from this torch build: the ordinal under the visibility masks (one-rank-per-GPU launchers mask
+            # no physical id at all: the ordinal under the visibility masks (one-rank-per-GPU launchers mask
             # every rank down to "its" GPU, which is then ordinal 0 everywhere) - good enough to warn, not to refuse
             unique = False
             dev = (device_id, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"), os.environ.get("CUDA_VISIBLE_DEVICES"))

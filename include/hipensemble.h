@@ -376,7 +376,13 @@ int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t i
  *   prior draw of a born leaf, u_acc[Tl][W].  The library adds the proposal factors -/+ log q(leaf), the edge factors
  *   (rj.py:236-270) and the fix_logp_gibbs rule (move.py:368-402).  Follow it with hens_pt_sweep(adapt = 0) (rj.py:381-382).
  * hens_rj_set_mh_scale + hens_rj_step: production: n iterations of (in-model move, swaps + adaptation, birth / death on
- *   a uniformly chosen branch, swaps) with device-side Philox draws of the same distributions.
+ *   a uniformly chosen branch, swaps) with device-side Philox draws of the same distributions.  Every walker's model at the
+ *   data points stays resident and birth / death evaluates `model +- one leaf`; the resident models AND the log-likelihoods
+ *   are re-evaluated from the coordinates whenever the state has crossed this interface since the last call (hens_upload_state,
+ *   a parity-API move, hens_download_state) and whenever iteration % 64 == 63, so a log-likelihood carries the rounding of at
+ *   most 63 iterations of +- updates (observed <= 6e-16 relative against the oracle, bar 1e-12) and a chain is a function of
+ *   (State, seed, iteration counter, adaptation time): resumed from a downloaded State in a new context it is the uninterrupted
+ *   chain bit for bit.
  * hens_rj_get_counters: accept counts of the birth / death move (hens_get_counters has the in-model move's). */
 int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, const int32_t* nleaves_max,
                       const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp,
@@ -451,6 +457,10 @@ int hens_debug_draws(hens_ctx* ctx, int64_t iter, int32_t* own, int32_t* cw, dou
 /* Static description of the build. */
 const char* hens_version(void);
 int hens_device_count(void);
+/* PCI address ("0000:c1:00.0") of HIP device `device_id` - the physical GPU behind an ordinal, whatever the visibility masks say.
+ * Host-side helper of the ladder pipeline's one-rank-per-GPU check (eryn_amd/ladder.py; no reference counterpart: the reference is
+ * single-process).  Returns HENS_OK and a NUL-terminated string in out[capacity], or a negative error code. */
+int hens_device_pci_bus_id(int32_t device_id, char* out, int32_t capacity);
 
 #ifdef __cplusplus
 }

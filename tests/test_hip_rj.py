@@ -117,6 +117,64 @@ def test_rj_moves_match_the_oracle(golden_dir, name):
     eng.close()
 
 
+def test_rj_chain_resumed_from_a_downloaded_state_is_the_uninterrupted_chain():
+    """The production path keeps every walker's model resident and evaluates birth / death as `model +- one leaf`; templates and
+    log-likelihoods are re-evaluated from the coordinates whenever the state has crossed the C ABI since the last call - upload,
+    parity move, DOWNLOAD - (and when iteration % 64 == 63), so the state behind a download is a function of what the download
+    returned: the chain continues the same way in the same context or in a NEW one after an upload (round 4 rebuilt the
+    templates only, and only after an upload: the resumed chain's last bits then differed)."""
+    from eryn_amd.moves.tempering import make_ladder
+    from eryn_amd.rj import RJEngine, TemplateBranch
+    T, W, N = 4, 256, 500
+    t = np.linspace(-1, 1, N)
+    rs = np.random.RandomState(42)
+    gauss_inj = np.array([[3.3, -0.2, 0.1], [2.6, -0.1, 0.1], [3.4, 0.0, 0.1]])
+    sine_inj = np.array([[1.3, 10.1, 1.0], [0.8, 4.6, 1.2]])
+    y = sum(a * np.exp(-((t - b) ** 2) / (2 * c ** 2)) for a, b, c in gauss_inj) + \
+        sum(a * np.sin(2 * np.pi * b * t + c) for a, b, c in sine_inj) + 2.0 * rs.randn(N)
+    brs = [TemplateBranch("gauss", "pulse", [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)], 6, 0),
+           TemplateBranch("sine", "sine", [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)], 6, 0)]
+    x = {"gauss": np.zeros((T, W, 6, 3)), "sine": np.zeros((T, W, 6, 3))}
+    inds = {k: np.zeros((T, W, 6), dtype=bool) for k in x}
+    for n in range(3):
+        x["gauss"][:, :, n] = gauss_inj[n] + 1e-2 * rs.randn(T, W, 3) * [1, 1, 0.1]
+        inds["gauss"][:, :, n] = True
+    for n in range(2):
+        x["sine"][:, :, n] = sine_inj[n] + 1e-2 * rs.randn(T, W, 3)
+        inds["sine"][:, :, n] = True
+    scale = np.full((2, 3), 1e-2) * [[1, 1, 0.1], [1, 1, 1]]
+    calls = (70, 5, 90)                                # (the calls cross iteration % 64 == 63 at different offsets)
+
+    def fresh():
+        e = RJEngine(T, W, brs, t, y, 2.0, seed=5)
+        e.set_mh_scale(scale)
+        return e
+
+    a = fresh()
+    a.upload(x, inds, betas=make_ladder(3 * 5, ntemps=T))
+    a.eval_state()
+    snaps = []
+    for n in calls:
+        a.step(n)
+        snaps.append((a.download(), a.iteration(), a.counters()["adapt_time"]))
+    a.close()
+    (x1, i1, L1, P1, b1), it1, at1 = snaps[0]
+    b = fresh()                                        # a NEW context continues from the first download
+    b.upload(x1, i1, L1, P1, b1)
+    b.eng.set_iteration(it1)
+    b.set_adapt_time(at1)
+    for k, n in enumerate(calls[1:], start=1):
+        b.step(n)
+        xb, ib, Lb, Pb, bb = b.download()
+        (xa, ia, La, Pa, ba), ita, _ = snaps[k]
+        assert b.iteration() == ita
+        for name in xa:
+            assert np.array_equal(ia[name], ib[name]), f"leaf masks differ after call {k}"
+            assert np.array_equal(xa[name], xb[name]), f"coordinates differ after call {k}"
+        assert np.array_equal(La, Lb) and np.array_equal(Pa, Pb) and np.array_equal(ba, bb), f"log-probabilities / ladder differ after call {k}"
+    b.close()
+
+
 def test_rj_philox_run_config4_shape():
     """BASELINE config 4 at full size - 2 branches x 10 leaves, ntemps = 8, nwalkers = 2048 - with device-side draws:
     leaf budgets respected, the stored log-like / log-prior are those of the stored leaves (re-evaluation), births and

@@ -316,6 +316,43 @@ def test_philox_tune_hook_is_called_per_proposal_with_that_moves_own_mask():
     assert np.array_equal(a.backend.accepted, b.backend.accepted)
 
 
+def test_philox_tune_hook_that_rescales_the_gaussian_move_reaches_the_device():
+    """A `tune` hook mutates the move object and the NEXT proposal reads it (ensemble.py:983-984; the reference's shipped tuner does
+    so with `move.a`).  For a GaussianMove that means the retuned scale must be handed to the device: a chain whose hook shrinks
+    the scale after the second proposal equals, from there on, a chain resumed from that state by a sampler built with the small
+    scale (same seed: the Philox checkpoint in the stored State carries the stream across)."""
+    from eryn_amd.moves import GaussianMove
+    T, W, D, n = 4, 256, 8, 5
+    rs = np.random.RandomState(5)
+    A = rs.randn(D, D)
+    mu, invcov = 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    x0 = np.random.RandomState(2).randn(T, W, D)
+
+    def sampler(cov):
+        return EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, rng="philox", seed=11, moves=GaussianMove({"model_0": cov}),
+                               tempering_kwargs=dict(ntemps=T))
+
+    a = sampler(0.3)
+    ncall = [0]
+
+    def hook(state, accepted):
+        ncall[0] += 1
+        if ncall[0] == 2:
+            a.moves[0].scale = np.sqrt(0.01)                 # (what GaussianMove({"model_0": 0.01}) holds: gaussian.py:44-46)
+    a.moves[0].tune = hook
+    tuned = [State(st, copy=True) for st in a.sample(x0, iterations=n, store=True, tune=True)]
+    b = sampler(0.01)
+    rest = [State(st, copy=True) for st in b.sample(tuned[1], iterations=n - 2, store=True)]
+    for k, (u, v) in enumerate(zip(tuned[2:], rest)):
+        assert np.array_equal(u.branches["model_0"].coords, v.branches["model_0"].coords), f"positions differ {k + 1} steps after the retune"
+        assert np.array_equal(u.log_like, v.log_like) and u.random_state == v.random_state
+    c = sampler(0.3)                                         # and the retune did change the chain
+    plain = [State(st, copy=True) for st in c.sample(x0, iterations=n, store=True)]
+    assert np.array_equal(plain[1].branches["model_0"].coords, tuned[1].branches["model_0"].coords)
+    assert not np.array_equal(plain[2].branches["model_0"].coords, tuned[2].branches["model_0"].coords)
+
+
 def test_philox_sampler_steps_a_three_set_stretch_move():
     """EnsembleSampler(rng="philox") with StretchMove(nsplits=3) (red_blue.py:41-47): the device draws the three sets itself
     (tests/test_hip_replay.py holds that path to the oracle); here the sampler plumbing - counters, stored chain, thinning."""

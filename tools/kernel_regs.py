@@ -8,8 +8,9 @@ with tempfile.TemporaryDirectory() as d:
     so = os.path.join(d, "lib.so")
     os.symlink(LIB, so)
     subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", so], cwd=d, capture_output=True)
-    co = [f for f in os.listdir(d) if "gfx950" in f][0]
-    txt = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", os.path.join(d, co)], capture_output=True, text=True).stdout
+    # (one code object per translation unit since round 4: all of them)
+    txt = "".join(subprocess.run([f"{LLVM}/llvm-readelf", "--notes", os.path.join(d, co)], capture_output=True, text=True).stdout
+                  for co in sorted(f for f in os.listdir(d) if "gfx950" in f))
 rows = []
 for b in re.split(r"\n\s+- \.agpr_count", txt)[1:]:
     g = lambda k: (re.search(rf"\.{k}:\s+(\S+)", b) or [None, "0"])[1]

@@ -1,11 +1,10 @@
 #!/bin/bash
-# Build ab_live/libhens_base.so from the sources of a git revision (default HEAD) for a same-box A/B (tools/ab_lib.sh).
-REV=${1:-HEAD}
+# Build ab_live/libhens_<name>.so (default: base) from the sources of a git revision (default HEAD) for a same-box A/B:
+#   tools/mkbase.sh [rev] [name]      run with HENS_LIB=$GRAFT_REPO_ROOT/ab_live/libhens_<name>.so
+REV=${1:-HEAD}; NAME=${2:-base}
 R=$(git rev-parse --show-toplevel)
 T=$(mktemp -d)
-mkdir -p $T/eryn_amd/csrc $T/include
-for f in hens.hip hens_kernels.h hens_rj.h hens_iter.h; do git show $REV:eryn_amd/csrc/$f > $T/eryn_amd/csrc/$f 2>/dev/null; done
-git show $REV:include/hipensemble.h > $T/include/hipensemble.h
+git -C $R worktree add -f --detach $T $REV > /dev/null 2>&1 || { echo "worktree failed"; exit 1; }
 mkdir -p $R/ab_live
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $T/eryn_amd/csrc/hens.hip -o $R/ab_live/libhens_base.so 2>/dev/null && echo built libhens_base.so from $REV
-rm -rf $T
+(cd $T && HENS_LIB=$R/ab_live/libhens_$NAME.so python -m eryn_amd._build > /dev/null) && echo "built ab_live/libhens_$NAME.so from $REV"
+git -C $R worktree remove --force $T
