@@ -269,6 +269,7 @@ struct Queue {
     bool pending = false;            // packets submitted since the last drain
     bool own_only = false;           // since the last drain only this queue has touched the state (no HIP work, no host upload)
     bool fresh = true;               // the next packet is the first since the host (or the HIP stream) touched the state
+    bool nobar_next = false;         // DEV PROBE (timing only, results wrong): the next packet goes out without the barrier bit
     std::string err;
 
     bool create(Device& d) {
@@ -353,7 +354,9 @@ struct Queue {
         p->completion_signal.handle = signal ? done.handle : 0;
         const uint16_t acq = (fresh && !(acq_agent_ok && own_only)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
         const uint16_t rel = signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
-        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1u << HSA_PACKET_HEADER_BARRIER) |
+        const uint16_t barrier = nobar_next ? 0u : 1u;
+        nobar_next = false;
+        const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (barrier << HSA_PACKET_HEADER_BARRIER) |
                                            (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         const uint16_t setup = (uint16_t)(3u << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
         if (signal) hsa_signal_add_relaxed(done, 1);                  // (the packet's completion takes the 1 back off)

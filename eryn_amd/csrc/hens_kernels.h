@@ -354,30 +354,41 @@ __device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_del
     return loc >= 0 ? (int64_t)loc * D : guest_delta + (int64_t)(~loc) * D;
 }
 
-// One wavefront sums the swap counts a launch of k_split1_pt<PIPE> accumulated (nrows rows of np pairs, atomics), clears
-// them (sole reader) and publishes the sums to every rank's mailbox: counts of sweep `sweep`, flag PF_CNT0 + rank.
+// All rows of one swap-count accumulation buffer of k_split1_pt<PIPE> (nrows = 8 G rows of np pairs, G in {1, 2, 4, 8}, np <= 64 / G:
+// pipe_acc_rows / acc_row_groups) summed by ONE wavefront in ONE memory round trip: lane = (row group g, pair p), 8 loads in flight
+// per lane, the groups added with lane exchanges.  Every lane returns the total of pair lane % (64 / G) (pairs >= np: 0).
+// (Round 5: rounds 3-4 summed the rows in nrows / 8 dependent batches of 8 loads on np lanes - under the row gathers of a launch in
+//  full swing every batch is a 1.5-2 us round trip, and the adapting wave of a pipeline rank reached its first barrier 12.7 us into a
+//  22 us launch: tools/pipe_trace.py, LABNOTES 10.)
+__device__ __forceinline__ unsigned acc_rows_sum(const uint32_t* rows, int nrows, int np, int lane) {
+    const int G = nrows >> 3, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;
+    unsigned u[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) u[r] = (p < np) ? rows[(size_t)(r * G + g) * np + p] : 0u;
+    unsigned sum = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sum += u[r];
+    for (int m = P2; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+    return sum;
+}
+__device__ __forceinline__ void acc_rows_clear(uint32_t* rows, int nrows, int np, int lane) {
+    for (int e = lane; e < nrows * np; e += 64) rows[e] = 0u;
+}
+
+// One wavefront sums the swap counts a launch of k_split1_pt<PIPE> accumulated (acc_rows_sum), clears them if asked (sole reader;
+// a caller with a second reader clears later: k_stretch_fast) and publishes the sums to every rank's mailbox: counts of sweep
+// `sweep`, flag PF_CNT0 + rank.
 __device__ __forceinline__ void pipe_push_counts(const uint32_t* rows_c, int nrows, int np, char* const* boxes, int nranks, int rank,
-                                                 int T, int rung_begin, int W, int D, uint32_t sweep, int lane) {
-    uint32_t* rows = const_cast<uint32_t*>(rows_c);
-    for (int j = lane; j < np; j += 64) {
-        unsigned sum = 0;
-        for (int r0 = 0; r0 < nrows; r0 += 8) {              // 8 loads in flight
-            unsigned v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (r0 + q < nrows) ? rows[(size_t)(r0 + q) * np + j] : 0u;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                sum += v[q];
-                if (v[q]) rows[(size_t)(r0 + q) * np + j] = 0u;
-            }
-        }
-        for (int q = 0; q < nranks; ++q)                       // local pair j+1 = global pair (rung_begin+j+1, rung_begin+j)
-            __hip_atomic_store(pipe_box(boxes[q], T, W, D).counts + (size_t)(sweep & 3u) * T + (rung_begin + j), sum, __ATOMIC_RELAXED,
+                                                 int T, int rung_begin, int W, int D, uint32_t sweep, int lane, bool clear_now = true) {
+    const unsigned sum = acc_rows_sum(rows_c, nrows, np, lane);
+    if (clear_now) acc_rows_clear(const_cast<uint32_t*>(rows_c), nrows, np, lane);
+    if (lane < np)                                             // (group 0: lane = pair; local pair j+1 = global pair (rung_begin+j+1, rung_begin+j))
+        for (int q = 0; q < nranks; ++q)
+            __hip_atomic_store(pipe_box(boxes[q], T, W, D).counts + (size_t)(sweep & 3u) * T + (rung_begin + lane), sum, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane < nranks) pipe_raise(pipe_box(boxes[lane], T, W, D).flags + PF_CNT0 + rank, sweep + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the flag stores are left in flight: nothing here depends on them, and the launch does not end before they have landed)
 }
 
 // Periodic parameters (utils/periodic.py, used by stretch.py:136-154 and gaussian.py:110-115); period <= 0: not periodic.
@@ -578,7 +589,8 @@ struct StretchArgs {
     int32_t col;
     int32_t inject_c64;        // dev hook (HENS_PIPE_INJECT_CYCLES, pipeline ranks): the swap-count flags of the previous sweep count as raised
                                // only that many x 64 shader cycles after the adapting workgroup's start - a neighbour whose counts
-                               // arrive that late; 0: off.  Measures the slack the first launch absorbs (tools/pipe_slack.sh)
+                               // arrive that late; 0: off.  Measures the slack the first launch absorbs (tools/pipe_slack.sh).
+                               // -1 (HENS_PIPE_FORCE_LATE=1, any build): the adapting wave always comes back for the counts (tests)
     // parity API with nsplits > 2 (red_blue.py:41-47,148): the moving set's position range, given explicitly (0: the two-half
     // rule from N0 / split); `split` is then 0 for the first set, 1 for the last (every complement already sits in its home
     // row) and 2 for the ones between
@@ -1327,6 +1339,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     }
     constexpr int ADW = 1;                      // the wave that runs the early ladder adaptation (a 9th, adaptation-only
                                                 // wave was measured: two 9-wave workgroups do not pack onto one CU)
+    constexpr int PUSHW = 3;                    // pipeline rank, workgroup (0,0): the wave that publishes the last sweep's swap counts
     int bx = blockIdx.x, tl = blockIdx.y;
     if (A.xcd_shift > 0) {                      // dispatch order deals consecutive workgroups round-robin to the 8 XCDs
         const int sh = A.xcd_shift - 1, L = bx + (tl << sh), g = (L & 7) * ((int)(gridDim.x * gridDim.y) >> 3) + (L >> 3);
@@ -1344,6 +1357,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     HENS_TRACE(0);
 #ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 9 && !EVAL && !PIPE && A.inplace) return;
+    // HENS_CUT_S 10..13 (round 5, tools/cut_phase_a.sh): ONE wave's chain in front of the first barrier, the others leave at once -
+    // 10: wave 0 up to its record load landed; 11: wave 0's whole phase A (record, Philox call, zz, log u); 12: wave 2 (Philox call,
+    // complement's column, its row out of the compact table); 13: the two adaptation waves (count rows, ratios -> exp / reciprocals)
+    if (HENS_CUT_S >= 10 && HENS_CUT_S <= 13 && !EVAL && !PIPE && A.inplace) {
+        const bool mine = HENS_CUT_S <= 11 ? wv == 0 : (HENS_CUT_S == 12 ? wv == 2 : (wv == 1 || wv == 3));
+        if (!mine) return;
+    }
 #endif
 #ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 8 && !EVAL && !PIPE && A.inplace) {          // a launch of known length: every workgroup spins 6 us
@@ -1354,8 +1374,11 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 #endif
     if (PIPE && !EVAL && blockIdx.x == 0 && blockIdx.y == 0) {
         if (A.rt_flag && tid == 0) pipe_raise(A.rt_flag, A.rt_value);
-        if (A.cnt_push == 2 && wv == 1) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T,
-                                                         A.rung_begin, W, DT, A.cp_sweep, lane);
+        // The last sweep's swap counts (reference's schedule: due in THIS launch) go to every rank's mailbox on a wave of their own -
+        // PUSHW, idle until the first barrier on a pipeline rank: its store round trip is not the adapting wave's business, which
+        // sums the same rows for itself; the rows are cleared behind the first barrier, when both have read them.
+        if (A.cnt_push == 2 && wv == PUSHW) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T,
+                                                             A.rung_begin, W, DT, A.cp_sweep, lane, false);
     }
     // Round 5: the swap counts are waited for by the ONE wave that needs them - the adapting wave of workgroup (0,0), below - and no
     // longer by the whole workgroup at the head of the launch (rounds 3-4: wave 0 spun for every rank's counts, then a
@@ -1372,7 +1395,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (wv == 0 && ((A.wmask >> lane) & 1ull) && (lane < PF_CNT0 || (!ad_lead && ad_here)))
             pipe_spin(A.wflags + lane, lane >= PF_CNT0 ? A.wtarget_cnt : A.wtarget, A.wbudget, A.flags,
                       A.wstats ? A.wstats + (lane >= PF_CNT0 ? 2 : 0) : nullptr);
-        __syncthreads();
+        // Wave 0 waits; the others meet it at the first barrier: nothing in front of that barrier touches a row (records, the
+        // compact row table and the guests' home rows are this rank's own previous launch's).  Rounds 3-4 had a __syncthreads()
+        // here - with its wait for EVERY outstanding load, the kernel arguments' included, at the head of every workgroup of
+        // every launch whose rank has a neighbour: measured with the injection hook (which sets the count bits on a lone rank) at
+        // 0.9 us per round of workgroups, 1.9 us per launch at 8 x 16384 x 64.  (D = 32 keeps it: without it that instantiation
+        // spilled to scratch memory.)
+        if constexpr (DT == 32) __syncthreads();
     }
 
     // ladder adaptation in one wavefront (tempering.py:563-596), T <= 128: lane l owns rungs l and l + 64
@@ -1562,22 +1591,87 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         }
         adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1, ad_x);
     };
+    unsigned* s_late = reinterpret_cast<unsigned*>(s_part);      // [l] late, [64 + l] own sums, [128 + l] / [192 + l] counts of rungs l / l + 64
+    double* s_lateb = s_part + 128;                              // [l] / [64 + l] the ladder
+    // the chain of a pipeline rank's adapting wave (below): ONE instance per kernel - behind the first barrier, in the shadow of the
+    // wave's row gathers, at D = 128 (one workgroup per CU there anyway: registers to spare; eight passes of gathers hide the chain;
+    // and config 5's shard is ONE round of workgroups - the launch ends with its slowest); right behind the loads, in front of the
+    // first barrier, otherwise.  Measured (round 5, LABNOTES 10.1): at D = 64 the kernel sits at 128 VGPRs and behind the barrier
+    // wave 0's phase-A values are live across the chain's temporaries - 129, one workgroup per CU; at D = 32 the gathers (2 us) are
+    // shorter than loads + chain (3 us) and the ring came later for everybody's accept phase: 22.4 against 21.4 us per iteration
+    // at 16 x 4096 x 32.  In front of the barrier the workgroup's tile starts ~2 us late - or when the counts arrive.
+    constexpr bool PIPE_CHAIN_IN_SHADOW = DT == 128;
+    auto pipe_chain = [&]() {
+        const int T = A.ad.T, rb = A.rung_begin, np = A.cp_np;
+        const bool own_acc = A.cnt_push == 2;
+        unsigned m0 = s_late[128 + lane], m1 = s_late[192 + lane];
+        const unsigned own = s_late[64 + lane];
+        const double b0 = s_lateb[lane], b1 = s_lateb[64 + lane];
+        if (s_late[lane] != 0u) {
+            // a rank's counts were not there at the first look: wait for them now (the polls queue up behind this wave's own
+            // gathers - loads return in order - so the chain overlaps the OTHER waves' gathers only)
+            if (lane >= PF_CNT0 && lane != PF_CNT0 + A.cp_rank && ((A.wmask >> lane) & 1ull))
+                pipe_spin(A.wflags + lane, A.wtarget_cnt, A.wbudget, A.flags, A.wstats ? A.wstats + 2 : nullptr, inject_until);
+#ifdef HENS_DEV_BUILD
+            if (inject_until)                    // (a lone rank has no flag to wait for: the injected delay alone)
+                while ((long long)(__builtin_amdgcn_s_memtime() - inject_until) < 0) __builtin_amdgcn_s_sleep(2);
+#endif
+            if (!(own_acc && A.cp_nranks == 1)) {
+                if (lane < T - 1) m0 = A.ad.swap_part[lane];
+                if (lane + 64 < T - 1) m1 = A.ad.swap_part[lane + 64];
+            }
+        }
+        if (own_acc) {                           // my pairs out of my own sums: global pair e = rung_begin + local pair
+            const int j0 = lane - rb, j1 = lane + 64 - rb;
+            const unsigned o0 = (unsigned)__shfl((int)own, (j0 >= 0 && j0 < np) ? j0 : 0);
+            const unsigned o1 = (unsigned)__shfl((int)own, (j1 >= 0 && j1 < np) ? j1 : 0);
+            if (j0 >= 0 && j0 < np) m0 = o0;
+            if (j1 >= 0 && j1 < np) m1 = o1;
+        }
+        adapt_publish((double)m0, (double)m1, b0, b1);
+    };
     // A pipeline rank on the reference's schedule: every rank's swap counts of the sweep that just ended are due in THIS launch
     // (tempering.py:563-649 adapts after the sweep), but beta is first consumed in the accept phase (red_blue.py:285-308).  The
-    // adapting wave looks for the count flags ONCE here; if a rank's counts are still on their way it does not wait - the
-    // workgroup's other waves would wait for it at the first barrier - but comes back for them behind its row gathers (cnt_late).
-    bool cnt_late = false;                       // (wave-uniform)
+    // adapting wave (workgroup (0,0)) only LOADS in front of the first barrier - one round trip in the shadow of wave 0's phase A:
+    // its OWN rank's counts summed straight out of the accumulation rows (the same loads as the publishing wave's: it does not wait
+    // for its own push to come back through the mailbox), the ladder, ONE look at the other ranks' count flags and, if they are up,
+    // their counts - and runs the ~4 000-cycle chain behind the barrier, in the shadow of its row gathers: the workgroup's tile is
+    // not held up by it (rounds 3-4: everything in front of the barrier; the launch ended with this workgroup, 2.3 us after the
+    // others at 16 x 4096 x 32).  If a rank's counts are still on their way it comes back for them there (late).  What crosses the
+    // barrier waits in LDS (s_part: nobody touches it before the second barrier) - as live registers across the gathers it cost
+    // every workgroup of the launch spilled SGPRs.
     if constexpr (PIPE) {
-        if (cnt_wait && wv == ADW) {
-            bool here = true;
-            if (lane >= PF_CNT0 && ((A.wmask >> lane) & 1ull))
-                here = __hip_atomic_load(A.wflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= A.wtarget_cnt;
-            if (inject_until && (long long)(__builtin_amdgcn_s_memtime() - inject_until) < 0) here = false;
-            cnt_late = __ballot(!here) != 0ull;
-            __atomic_signal_fence(__ATOMIC_SEQ_CST);          // (acquire side: see pipe_spin)
+        if (ad_early && ad_lead && wv == ADW) {
+            const int T = A.ad.T;
+            // (one round trip: ladder and flags are requested first, the accumulation rows last - loads return in order, the wait for
+            //  the rows' sum covers all of them)
+            const double b0 = (lane < T) ? A.ad.betas_in[lane] : 1.0, b1 = (lane + 64 < T) ? A.ad.betas_in[lane + 64] : 1.0;
+            uint32_t fl = 0xFFFFFFFFu;
+            if (cnt_wait && lane >= PF_CNT0 && lane != PF_CNT0 + A.cp_rank && ((A.wmask >> lane) & 1ull))
+                fl = __hip_atomic_load(A.wflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned own = 0;                        // lane p: this rank's count of local pair p (cnt_push == 2)
+            if (A.cnt_push == 2) own = acc_rows_sum(A.cp_rows, A.cp_nblocks, A.cp_np, lane);
+            bool late = false;
+            if (cnt_wait) {
+                bool here = fl >= A.wtarget_cnt;
+                if (inject_until && (long long)(__builtin_amdgcn_s_memtime() - inject_until) < 0) here = false;
+                late = __ballot(!here) != 0ull;
+                if (A.inject_c64 < 0) late = true;       // (HENS_PIPE_FORCE_LATE=1, tests: every adaptation takes the late path)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);          // (acquire side: see pipe_spin)
+            }
+            unsigned m0 = 0, m1 = 0;                 // (row_groups = 1: the mailbox's reduced counts, one row)
+            if (!late && !(A.cnt_push == 2 && A.cp_nranks == 1)) {
+                if (lane < T - 1) m0 = A.ad.swap_part[lane];
+                if (lane + 64 < T - 1) m1 = A.ad.swap_part[lane + 64];
+            }
+            s_late[lane] = late ? 1u : 0u;           // (every lane its own word: a value one lane stores for the others needs a barrier -
+                                                     //  without one the compiler may read before the store, and did)
+            s_late[64 + lane] = own; s_late[128 + lane] = m0; s_late[192 + lane] = m1;
+            s_lateb[lane] = b0; s_lateb[64 + lane] = b1;
+            if constexpr (!PIPE_CHAIN_IN_SHADOW) pipe_chain();
         }
     }
-    if (ad_early && wv == ADW && !cnt_late) {
+    if (ad_early && wv == ADW && !(PIPE && ad_lead)) {
         const int T = A.ad.T, NR = A.ad.nblocks;
         // (row_groups G > 1 - ladders of at most 64 / G pairs: lane = (group g, pair p), group g sums rows g, g + G, ...)
         const int G = A.ad.row_groups, P2 = 64 / G, p = lane & (P2 - 1), g = lane / P2;
@@ -1637,6 +1731,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 const WalkerRec* o = A.wrec + (tl * W + own);
                 const double2 lp = *reinterpret_cast<const double2*>(&o->L);
                 const int2 la = *reinterpret_cast<const int2*>(&o->loc);
+#ifdef HENS_DEV_BUILD
+                if (HENS_CUT_S == 10 && !PIPE && A.inplace) { s_rs[lane] = la.x; s_zz[lane] = lp.x + lp.y; return; }
+#endif
                 const StretchDraw sd = stretch_draw(A.iseed, A.iiter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(s_off + k));
                 zz = draw_zz(sd.uz, A.ia);
                 lu = log(sd.ua);                                 // red_blue.py:294 (this wave is not the last at the barrier)
@@ -1724,6 +1821,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         return;
     }
 #endif
+#ifdef HENS_DEV_BUILD
+    if (HENS_CUT_S >= 11 && HENS_CUT_S <= 13 && !EVAL && !PIPE && A.inplace) {     // (the selected wave's chain ends here: its values are used)
+        asm volatile("" ::"v"(ad_dT0), "v"(ad_inv0), "v"(lu), "v"(Lold));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return;
+    }
+#endif
     HENS_TRACE(1);
     lds_barrier();
     HENS_TRACE(2);
@@ -1779,19 +1883,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     if (MODE == MODE_STRETCH && wv == 0 && late_ua >= 0.0)         // the Hastings factor's logarithm, while the row gathers fly
         factors = ((double)A.ndim_active - 1.0) * log(s_zz[lane]);                // stretch.py:223
     if constexpr (PIPE) {
-        if (cnt_late && wv == ADW) {
-            // the counts were not there at the first look: wait for them now (the polls queue up behind this wave's own gathers -
-            // loads return in order - so the chain below overlaps the OTHER waves' gathers only), then the whole chain and the ring
-            if (lane >= PF_CNT0 && ((A.wmask >> lane) & 1ull))
-                pipe_spin(A.wflags + lane, A.wtarget_cnt, A.wbudget, A.flags, A.wstats ? A.wstats + 2 : nullptr, inject_until);
-            const int T = A.ad.T, NR = A.ad.nblocks;
-            unsigned s0 = 0, s1 = 0;                          // (the mailbox's reduced counts: one row; row_groups = 1)
-            for (int r = 0; r < NR; ++r) {
-                s0 += (lane < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane] : 0u;
-                s1 += (lane + 64 < T - 1) ? A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] : 0u;
-            }
-            adapt_publish((double)s0, (double)s1, (lane < T) ? A.ad.betas_in[lane] : 1.0, (lane + 64 < T) ? A.ad.betas_in[lane + 64] : 1.0);
+        if constexpr (PIPE_CHAIN_IN_SHADOW) {
+            if (ad_early && ad_lead && wv == ADW) pipe_chain();
         }
+        // (the accumulation rows the publishing and the adapting wave have read: cleared behind the first barrier)
+        if (!EVAL && A.cnt_push == 2 && A.cp_zero && wv == PUSHW && blockIdx.x == 0 && blockIdx.y == 0)
+            acc_rows_clear(const_cast<uint32_t*>(A.cp_rows), A.cp_nblocks, A.cp_np, lane);
     }
     if (ad_defer && wv == ADW) {                   // second part: the working waves' row gathers are in flight
         if (ad_defer_all) adapt_early();

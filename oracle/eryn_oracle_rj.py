@@ -4,6 +4,8 @@ TEST INFRASTRUCTURE ONLY - the checker the HIP path is compared against, never s
 (see oracle/eryn_oracle.py).  A flat NumPy restatement of, per sampler iteration (ensemble.py:963-1024):
 
   * the in-model ``GaussianMove`` on the packed active leaves of every branch   moves/mh.py:56-193, gaussian.py:68-270
+  * or, as the in-model move, the red / blue ``StretchMove`` over EVERY branch and leaf slot of a walker (SURVEY 8 row a4's loop
+    over branches: one complement walker per branch, one stretch factor per walker)   moves/stretch.py:55-231, red_blue.py:103-330
   * ``EnsembleSampler.compute_log_prior`` / ``compute_log_like`` with ``inds``    ensemble.py:1127-1217, 1219-1545
   * ``Move.update`` incl. ``inds``                                               moves/move.py:472-703
   * ``TemperatureControl.temper_comps`` (swaps carry every branch's leaves)       moves/tempering.py:351-649
@@ -160,13 +162,17 @@ class OracleRJSampler:
     """One in-model GaussianMove + one RJ move per iteration, driven by the two reference streams."""
 
     def __init__(self, branches, x0, inds0, t, y, sigma, R, G, betas, adaptive=True, adaptation_lag=10000,
-                 adaptation_time=100, stop_adaptation=-1, fill=-1e300, record=False, schedule="separate_branches"):
+                 adaptation_time=100, stop_adaptation=-1, fill=-1e300, record=False, schedule="separate_branches",
+                 in_model="gaussian", a=2.0):
         # schedule: the sampler's ``rj_moves`` string (ensemble.py:434-480) - "separate_branches": one DistributionGenerateRJ per
         # branch, one of them chosen per iteration; "iterate_branches": ONE move that walks through every branch in turn;
         # "together": ONE move that proposes a birth or death in every branch of a walker at once (ensemble.py:414-432)
-        if schedule not in ("separate_branches", "iterate_branches", "together"):
+        # "none": no reversible-jump move at all (EnsembleSampler without rj_moves: the leaf masks never change)
+        if schedule not in ("separate_branches", "iterate_branches", "together", "none"):
             raise ValueError("rj_moves must be 'together', 'iterate_branches', or 'separate_branches'")
-        self.schedule = schedule
+        if in_model not in ("gaussian", "stretch"):
+            raise ValueError("in_model must be 'gaussian' or 'stretch'")
+        self.schedule, self.in_model, self.a = schedule, in_model, float(a)
         self.branches = list(branches)
         self.t, self.y, self.sigma = np.asarray(t, dtype=np.float64), np.asarray(y, dtype=np.float64), float(sigma)
         self.R, self.G = R, G
@@ -193,6 +199,18 @@ class OracleRJSampler:
 
     def _draw_accept(self, which):
         return self.R.rand(self.T, self.W)                                         # mh.py:157 / rj.py:332
+
+    def _draw_split_labels(self):
+        return base.split_labels(self.T, self.W, self.G)                           # red_blue.py:119-124 (shuffles of the GLOBAL stream)
+
+    def _draw_rint(self, bi, split, Ns, Nc):
+        return self.R.randint(Nc, size=(self.T, Ns))                               # stretch.py:93-99, once per branch
+
+    def _draw_zz(self, split, Ns):
+        return self.R.rand(self.T, Ns)                                             # stretch.py:129-132, first branch only
+
+    def _draw_accept_split(self, split, Ns):
+        return self.R.rand(self.T, Ns)                                             # red_blue.py:294
 
     def _draw_branch(self, nb):
         return int(self.R.choice(nb, p=np.full(nb, 1.0 / nb)))                     # ensemble.py:988-990, separate_branches
@@ -282,6 +300,76 @@ class OracleRJSampler:
         update(st, q, st.inds, logl, logp, accepted)
         self.mh_accepted += accepted
         if rec is not None:
+            self._snapshot(rec, "mhupd_")
+        self._pt(True, rec)
+        return accepted
+
+    # ---- in-model red / blue stretch move over every branch and leaf slot (red_blue.py:103-330, stretch.py:55-231) -------------
+    def stretch_move(self, rec=None):
+        """``RedBlueMove.propose`` with ``StretchMove.get_proposal`` on a state of several branches and leaves, no Gibbs sampling
+        (``inds_run`` None everywhere: ``gibbs_ndim`` equals the full dimension, ``adjust_factors`` changes nothing, stretch.py:
+        225-229).  Per half: for every branch IN ORDER one ``randint`` of R picks each moving walker's complement walker - a
+        different one per branch (``choose_c_vals``, stretch.py:205) - and right behind the first branch's one ``rand`` of R gives
+        the walker's stretch factor, shared by all branches (stretch.py:128-132: ``branch_i == 0``); every leaf slot moves, active
+        or not (the masks enter the prior and the likelihood only); factors = (sum over branches of nleaves_max * ndim - 1) log zz
+        (stretch.py:222-223); the masks of the moving walkers stay (red_blue.py:158-165); all slots of an accepted walker are
+        replaced (move.py:659-682)."""
+        st, T, W = self.st, self.T, self.W
+        self._draw_move_choice()
+        ndim_total = sum(b.nleaves_max * b.ndim for b in self.branches)
+        if W < 2 * ndim_total:                                                     # red_blue.py:103-114
+            raise RuntimeError("It is unadvisable to use a red-blue move with fewer walkers than twice the number of dimensions.")
+        labels = self._draw_split_labels()
+        accepted = np.zeros((T, W), dtype=bool)
+        tt = np.arange(T)[:, None]
+        names = [b.name for b in self.branches]
+        if rec is not None:
+            self._snapshot(rec, "pre_")
+            rec.update(st_labels=labels.copy(), betas_before=st.betas.copy(), time_before=self.time)
+        for split in range(2):                                                     # red_blue.py:148
+            S, C = base.split_index_lists(labels, split, 2)
+            Ns, Nc = S.shape[1], C.shape[1]
+            q, rints, zz, u_zz = {}, [], None, None
+            for bi, b in enumerate(self.branches):                                 # stretch.py:187-218
+                rint = self._draw_rint(bi, split, Ns, Nc)
+                if bi == 0:
+                    u_zz = self._draw_zz(split, Ns)
+                    zz = ((self.a - 1.0) * u_zz + 1) ** 2.0 / self.a
+                s = st.x[b.name][tt, S]                                            # [T, Ns, nleaves_max, ndim]
+                c = st.x[b.name][tt, C[tt, rint]]
+                q[b.name] = c - (c - s) * zz[:, :, None, None]                     # stretch.py:141-145
+                rints.append(rint)
+            factors = (ndim_total - 1.0) * np.log(zz)                              # stretch.py:223
+            new_inds = {n: st.inds[n][tt, S] for n in names}
+            logp = compute_log_prior(q, new_inds, self.branches)                   # red_blue.py:260-266
+            fix_logp_gibbs(logp, new_inds, names)                                  # red_blue.py:268
+            logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
+            u_acc = self._draw_accept_split(split, Ns)
+            prevL, prevP = st.L[tt, S], st.P[tt, S]
+            logP = base.tempered_log_posterior(logl, logp, st.betas)
+            prev = base.tempered_log_posterior(prevL, prevP, st.betas)
+            with np.errstate(invalid="ignore"):
+                lnpdiff = factors + logP - prev                                    # red_blue.py:292
+            with np.errstate(divide="ignore"):
+                keep = lnpdiff > np.log(u_acc)                                     # red_blue.py:294
+            new_logp = logp.copy()
+            new_logp[np.isinf(new_logp)] = 0.0                                     # move.py:523-526
+            st.L[tt, S] = logl * keep + prevL * (~keep)
+            st.P[tt, S] = new_logp * keep + prevP * (~keep)
+            for n in names:                                                        # move.py:659-682: every slot of an accepted walker
+                xs = st.x[n][tt, S].copy()
+                xs[keep] = q[n][keep]
+                st.x[n][tt, S] = xs
+            accepted[tt, S] = keep
+            if rec is not None:
+                rec.update({f"st_rint{split}": np.stack(rints), f"st_u_zz{split}": u_zz, f"st_u_acc{split}": u_acc,
+                            f"st_q{split}": {k: v.copy() for k, v in q.items()}, f"st_logp{split}": logp, f"st_logl{split}": logl,
+                            f"st_factors{split}": factors, f"st_lnpdiff{split}": lnpdiff, f"st_keep{split}": keep,
+                            f"st_S{split}": S, f"st_C{split}": C})
+                self._snapshot(rec, f"stupd{split}_")
+        self.mh_accepted += accepted
+        if rec is not None:
+            rec["mh_accepted"] = accepted
             self._snapshot(rec, "mhupd_")
         self._pt(True, rec)
         return accepted
@@ -411,9 +499,13 @@ class OracleRJSampler:
 
     def iteration(self):
         rec = {} if self.record else None
-        acc = self.mh_move(rec)
+        acc = self.mh_move(rec) if self.in_model == "gaussian" else self.stretch_move(rec)
         if rec is not None:
             self._snapshot(rec, "mh_")
+        if self.schedule == "none":
+            if rec is not None:
+                self.trace.append(rec)
+            return acc, -1, None
         bi, racc = self.rj_move(rec)
         if rec is not None:
             self._snapshot(rec, "rj_")

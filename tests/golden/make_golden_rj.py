@@ -23,7 +23,7 @@ sys.path.insert(0, "/root/reference/src")
 
 import numpy as np                                   # noqa: E402
 from eryn.ensemble import EnsembleSampler            # noqa: E402
-from eryn.moves import GaussianMove                  # noqa: E402
+from eryn.moves import GaussianMove, StretchMove     # noqa: E402
 from eryn.prior import uniform_dist                  # noqa: E402
 from eryn.state import State                         # noqa: E402
 
@@ -40,7 +40,10 @@ SINE_BOX = [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]
 
 
 def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=1e-4, n_init=(2, 1),
-            seed_data=42, seed_construct=135, seed_run=246, rj_moves="separate_branches"):
+            seed_data=42, seed_construct=135, seed_run=246, rj_moves="separate_branches", in_model="gaussian", init_spread=1e-4):
+    """in_model: "gaussian" - GaussianMove on the packed leaves; "stretch" - the red / blue StretchMove over EVERY branch and leaf
+    slot of a walker (stretch.py:160-231: one complement draw per branch, one zz per walker; red_blue.py:103-330).  rj_moves None:
+    no reversible jump (the leaf masks stay as they start)."""
     branch_names = ["gauss", "sine"]
     ndims = {"gauss": 3, "sine": 3}
     nleaves_max = dict(zip(branch_names, nl_max))
@@ -53,20 +56,24 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
     coords = {k: np.zeros((T, W, nleaves_max[k], 3)) for k in branch_names}
     inds = {k: np.zeros((T, W, nleaves_max[k]), dtype=bool) for k in branch_names}
     for nn in range(n_init[0]):
-        coords["gauss"][:, :, nn] = rs.multivariate_normal(gauss_inj[nn], np.diag(np.ones(3) * 1e-4), size=(T, W))
+        coords["gauss"][:, :, nn] = rs.multivariate_normal(gauss_inj[nn], np.diag(np.ones(3) * init_spread), size=(T, W))
         inds["gauss"][:, :, nn] = True
     for nn in range(n_init[1]):
-        coords["sine"][:, :, nn] = rs.multivariate_normal(sine_inj[nn], np.diag(np.ones(3) * 1e-4), size=(T, W))
+        coords["sine"][:, :, nn] = rs.multivariate_normal(sine_inj[nn], np.diag(np.ones(3) * init_spread), size=(T, W))
         inds["sine"][:, :, nn] = True
     priors = {"gauss": {i: uniform_dist(*GAUSS_BOX[i]) for i in range(3)},
               "sine": {i: uniform_dist(*SINE_BOX[i]) for i in range(3)}}
     cov = {k: np.diag(np.ones(3)) * cov_factor for k in branch_names}
 
     np.random.seed(seed_construct)          # R := snapshot of G at construction (ensemble.py:604,651-652)
-    s = EnsembleSampler(W, ndims, log_like_fn_gauss_and_sine, priors, args=[t, y, sigma],
-                        tempering_kwargs=dict(ntemps=T), nbranches=2, branch_names=branch_names,
-                        nleaves_max=nleaves_max, nleaves_min=nleaves_min, moves=GaussianMove(cov),
-                        rj_moves=rj_moves)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")     # (ensemble.py:509-514: the reference advises against the stretch move under RJ - and runs it)
+        s = EnsembleSampler(W, ndims, log_like_fn_gauss_and_sine, priors, args=[t, y, sigma],
+                            tempering_kwargs=dict(ntemps=T), nbranches=2, branch_names=branch_names,
+                            nleaves_max=nleaves_max, nleaves_min=nleaves_min,
+                            moves=GaussianMove(cov) if in_model == "gaussian" else StretchMove(),
+                            **({} if rj_moves is None else dict(rj_moves=rj_moves)))
     logp0 = s.compute_log_prior(coords, inds=inds)
     logl0 = s.compute_log_like(coords, inds=inds, logp=logp0)[0]
     state = State(coords, log_like=logl0, log_prior=logp0, inds=inds)
@@ -74,7 +81,7 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
     out = dict(T=T, W=W, ndata=ndata, sigma=float(sigma), nsteps=nsteps, t=t, y=y, nl_max=np.array(nl_max),
                nl_min=np.array(nl_min), cov_factor=float(cov_factor), seed_construct=seed_construct, seed_run=seed_run,
                gauss_box=np.array(GAUSS_BOX), sine_box=np.array(SINE_BOX), betas0=np.array(s.temperature_control.betas),
-               L0=logl0, P0=logp0, rj_moves=rj_moves)
+               L0=logl0, P0=logp0, rj_moves="none" if rj_moves is None else rj_moves, in_model=in_model)
     for k in branch_names:
         out[f"x0_{k}"], out[f"inds0_{k}"] = coords[k].copy(), inds[k].copy()
 
@@ -99,13 +106,13 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
         move.propose = propose
 
     wrap(s.moves[0], "mh")
-    for i, m in enumerate(s.rj_moves):
+    for i, m in enumerate(s.rj_moves if rj_moves is not None else []):
         wrap(m, f"rj{i}")
 
     np.random.seed(seed_run)                # G for the run
     it = 0
     for st in s.sample(state, iterations=nsteps, store=False):
-        assert [r["tag"][:2] for r in log] == ["mh", "rj"], [r["tag"] for r in log]
+        assert [r["tag"][:2] for r in log] == (["mh", "rj"] if rj_moves is not None else ["mh"]), [r["tag"] for r in log]
         for r in log:
             pre = f"it{it}_{r['tag'][:2]}_"
             for k, v in r.items():
@@ -116,13 +123,15 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
         log.clear()
         it += 1
     out["mh_accepted_total"] = np.array(s.moves[0].accepted)
-    out["rj_accepted_total"] = np.stack([np.array(m.accepted) for m in s.rj_moves])
-    out["rj_num_proposals"] = np.array([m.num_proposals for m in s.rj_moves])
-    path = os.path.join(HERE, name + ".npz")
+    if rj_moves is not None:
+        out["rj_accepted_total"] = np.stack([np.array(m.accepted) for m in s.rj_moves])
+        out["rj_num_proposals"] = np.array([m.num_proposals for m in s.rj_moves])
+    path = os.path.join(os.environ.get("GOLDEN_OUT", HERE), name + ".npz")
     np.savez_compressed(path, **out)
-    nl = [int(out[f"it{nsteps - 1}_rj_inds_{k}"].sum()) for k in branch_names]
+    last = "rj" if rj_moves is not None else "mh"
+    nl = [int(out[f"it{nsteps - 1}_{last}_inds_{k}"].sum()) for k in branch_names]
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB; in-model accept {out['mh_accepted_total'].mean() / nsteps:.2f}, "
-          f"rj accept {out['rj_accepted_total'].sum(0).mean() / nsteps:.2f}, leaves at the end {nl}")
+          + (f"rj accept {out['rj_accepted_total'].sum(0).mean() / nsteps:.2f}, " if rj_moves is not None else "") + f"leaves at the end {nl}")
 
 
 if __name__ == "__main__":
@@ -141,3 +150,14 @@ if __name__ == "__main__":
     # coins and leaf choices first, then the births branch by branch, the factors summed, one accept test (distgenrj.py:150-222)
     capture("rj5_together", T=3, W=8, nl_max=(4, 3), nl_min=(0, 0), nsteps=16, cov_factor=1e-3, seed_run=31,
             rj_moves="together")
+    # Round 5: the red / blue StretchMove over a state of several branches and leaves (stretch.py:160-231, red_blue.py:103-330;
+    # SURVEY 8 row a4's loop over branches): EVERY leaf slot of EVERY branch moves - one complement walker per branch, one zz per
+    # walker, factors (sum of nleaves_max * ndim - 1) log zz - and the leaf masks only decide what the prior and the likelihood see.
+    # Fixed masks (no reversible jump; two active leaves per branch: without reversible jump the reference hands a branch's ONLY
+    # leaf to the likelihood as a 1-D array, ensemble.py:1438-1441, which its own test model does not take) ...
+    capture("rjs1_stretch_fixed_leaves", T=3, W=32, nl_max=(3, 2), nl_min=(0, 0), nsteps=12, rj_moves=None, in_model="stretch",
+            seed_run=58, init_spread=4e-4, n_init=(2, 2))
+    # ... and as the in-model move beside birth / death (the reference warns, ensemble.py:509-514, and runs it): dead leaves keep
+    # moving with the stretch, births land on slots the stretch has been carrying along
+    capture("rjs2_stretch_with_rj", T=3, W=32, nl_max=(3, 2), nl_min=(0, 0), nsteps=12, in_model="stretch", seed_run=61,
+            init_spread=4e-4)

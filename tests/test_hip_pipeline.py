@@ -63,6 +63,25 @@ def test_pipeline_local_matches_single_context(tmp_path, nranks, T, W, D, iters)
     assert ref["swaps_total"].sum() > 0           # the boundary pairs really exchanged walkers
 
 
+@pytest.mark.parametrize("nranks,T,W,D,iters,model", [(4, 8, 256, 16, 16, "rosen_mix"), (4, 8, 256, 32, 12, "gauss"), (2, 8, 256, 64, 10, "gauss"),
+                                                       (2, 4, 256, 128, 8, "rosen_mix")])
+def test_pipeline_counts_that_arrive_late(tmp_path, nranks, T, W, D, iters, model):
+    """Round 5: only the adapting wave of a rank's first launch waits for the other ranks' swap counts - one look in front of the
+    first barrier, and if a rank's counts are still on their way it comes back for them later (behind its row gathers at D = 32 /
+    128, in place otherwise).  HENS_PIPE_FORCE_LATE=1 sends EVERY adaptation down that second path - on a one-GPU box the first look
+    often succeeds - and the chain must still be the unsharded one bit for bit, repeatedly (the first version of this path handed a
+    flag from lane 0 to the others through LDS without a barrier: half of the runs adapted from the wrong counts)."""
+    ref = _single(tmp_path, T, W, D, iters, model=model)
+    for rep in range(3):
+        out = tmp_path / f"late{rep}.npz"
+        env = _env(model=model)
+        env["HENS_PIPE_FORCE_LATE"] = "1"
+        r = subprocess.run([sys.executable, WORKER, "local", str(nranks), str(T), str(W), str(D), str(iters), str(out)], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        _compare(ref, np.load(out))
+
+
 @pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 128, 8, 7), (4, 8, 256, 32, 8)])
 def test_pipeline_delayed_adaptation_is_rank_count_invariant(tmp_path, nranks, T, W, D, iters):
     """adaptation_delay = 1 (the swap ratios of sweep s move the ladder before iteration s+2, so the ranks need

@@ -14,6 +14,8 @@ from oracle import eryn_oracle_rj as orj
 NAMES = ["rj1_two_branches", "rj2_min_leaves", "rj3_ten_leaves"]
 # rj_moves="iterate_branches": one RJ move walks through every branch; "together": one proposal changes every branch at once
 NAMES_ALL = NAMES + ["rj4_iterate_branches", "rj5_together"]
+# round 5: the red / blue StretchMove as the in-model move over every branch and leaf slot (no reversible jump / beside it)
+NAMES_STRETCH = ["rjs1_stretch_fixed_leaves", "rjs2_stretch_with_rj"]
 
 
 def load_rj(golden_dir, name):
@@ -30,16 +32,17 @@ def make_rj_oracle(fx, record=False):
     x0 = {b.name: fx[f"x0_{b.name}"] for b in branches}
     inds0 = {b.name: fx[f"inds0_{b.name}"] for b in branches}
     return orj.OracleRJSampler(branches, x0, inds0, fx["t"], fx["y"], float(fx["sigma"]), R, G, fx["betas0"],
-                               record=record, schedule=str(fx["rj_moves"]) if "rj_moves" in fx else "separate_branches")
+                               record=record, schedule=str(fx["rj_moves"]) if "rj_moves" in fx else "separate_branches",
+                               in_model=str(fx["in_model"]) if "in_model" in fx else "gaussian")
 
 
-@pytest.mark.parametrize("name", NAMES_ALL)
+@pytest.mark.parametrize("name", NAMES_ALL + NAMES_STRETCH)
 def test_rj_oracle_reproduces_the_reference(golden_dir, name):
     fx = load_rj(golden_dir, name)
     o = make_rj_oracle(fx)
     assert np.array_equal(o.st.P, fx["P0"]) and np.array_equal(o.st.L, fx["L0"])
     for it in range(int(fx["nsteps"])):
-        acc = o.mh_move()
+        acc = o.mh_move() if o.in_model == "gaussian" else o.stretch_move()
         pre = f"it{it}_mh_"
         assert np.array_equal(acc, fx[pre + "accepted"]), f"{pre}accepted"
         for b in o.branches:
@@ -47,6 +50,8 @@ def test_rj_oracle_reproduces_the_reference(golden_dir, name):
             assert np.array_equal(o.st.inds[b.name], fx[pre + f"inds_{b.name}"])
         assert np.array_equal(o.st.L, fx[pre + "L"]) and np.array_equal(o.st.P, fx[pre + "P"]), pre
         assert np.array_equal(o.st.betas, fx[pre + "betas"]) and np.array_equal(o.swaps_accepted, fx[pre + "swaps"])
+        if o.schedule == "none":
+            continue
         bi, racc = o.rj_move()
         pre = f"it{it}_rj_"
         assert bi == int(fx[pre + "branch"])
@@ -57,6 +62,9 @@ def test_rj_oracle_reproduces_the_reference(golden_dir, name):
         assert np.array_equal(o.st.L, fx[pre + "L"]) and np.array_equal(o.st.P, fx[pre + "P"]), pre
         assert np.array_equal(o.st.betas, fx[pre + "betas"]) and np.array_equal(o.swaps_accepted, fx[pre + "swaps"])
     assert np.array_equal(o.mh_accepted, fx["mh_accepted_total"])
+    if o.schedule == "none":
+        assert fx["mh_accepted_total"].sum() > 0 and not all(fx[f"inds0_{b.name}"].all() for b in o.branches), "some slots stay dead"
+        return
     nm = fx["rj_accepted_total"].shape[0]                     # one move object per branch, or ONE for "iterate_branches"
     assert np.array_equal(np.stack(o.rj_accepted)[:nm], fx["rj_accepted_total"])
     assert np.array_equal(np.array(o.rj_num_proposals)[:nm], fx["rj_num_proposals"])
