@@ -110,6 +110,7 @@ SIGNATURES = {
     "hens_rj_debug_draws": (C.c_int, [_P, C.c_int64] + [_P] * 11),
     "hens_rj_set_schedule": (C.c_int, [_P, C.c_int32]),
     "hens_rj_bd_all_step": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "hens_rj_stretch_split": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "hens_get_iteration": (C.c_int, [_P, _P]),
     "hens_set_iteration": (C.c_int, [_P, C.c_int64]),
     "hens_set_nsplits": (C.c_int, [_P, C.c_int32]),

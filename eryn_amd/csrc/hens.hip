@@ -182,10 +182,12 @@ struct hens_ctx_impl {
     double* rj_t = nullptr; double* rj_y = nullptr;        // [ndata] data of the template likelihood
     double* rj_step = nullptr; double* rj_u = nullptr; double* rj_birth = nullptr;   // parity staging
     int8_t* rj_change = nullptr; int32_t* rj_leaf = nullptr; uint8_t* rj_keep = nullptr;
+    int32_t* rj_st_own = nullptr; int32_t* rj_st_cw = nullptr; double* rj_uzz = nullptr;   // stretch half-step on leaf-packing records
     uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
     double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
     int64_t rj_tm_ndata = 0;
     bool rj_tm_valid = false;
+    int rj_st_ns = 0;                       // hens_rj_stretch_split: walkers of the half being moved
     unsigned* rj_ad_flag = nullptr;  // the folded adaptation's "ladder published" word (RjArgs::ad_flag), serial of the last folding launch
     uint32_t rj_ad_serial = 0;
     bool rj_defer_adapt = false;     // hens_rj_step: the adaptation behind a cascade rides in the next k_rj launch
@@ -1589,13 +1591,17 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
             flush_adapt(c);
         }
     }
-    const int64_t n = (int64_t)c->Tl * c->W;
+    if (mode == RJ_MODE_STRETCH) {                    // (a half-step: one wavefront per position of the moving half, c->rj_st_ns of them per rung)
+        a.st_own = c->rj_st_own; a.st_cw = c->rj_st_cw; a.st_uzz = c->rj_uzz; a.st_a = c->cfg.a; a.st_ns = c->rj_st_ns;
+    }
+    const int64_t n = (int64_t)c->Tl * (mode == RJ_MODE_STRETCH ? c->rj_st_ns : c->W);
     const dim3 grid((unsigned)((n + RJ_WAVES - 1) / RJ_WAVES)), block(RJ_WAVES * 64);
     const int tmm = a.tm ? a.tm_mode : -1;            // the instantiation: (mode, template scheme), see k_rj
 #define RJ_CASE(MODE_, TMM_) if (mode == MODE_ && tmm == TMM_) hipLaunchKernelGGL((k_rj<MODE_, TMM_>), grid, block, 0, c->stream, a); else
     RJ_CASE(RJ_MODE_EVAL, -1) RJ_CASE(RJ_MODE_EVAL, 0) RJ_CASE(RJ_MODE_EVAL, 2)
     RJ_CASE(RJ_MODE_MH, -1) RJ_CASE(RJ_MODE_MH, 0)
     RJ_CASE(RJ_MODE_BD, -1) RJ_CASE(RJ_MODE_BD, 1)
+    RJ_CASE(RJ_MODE_STRETCH, -1)
         return fail(c, HENS_ERR_INVALID, "k_rj: no instantiation for mode %d with template scheme %d", mode, tmm);
 #undef RJ_CASE
     const hipError_t e = hipGetLastError();
@@ -1603,12 +1609,12 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     return HENS_OK;
 }
 
-int rj_ready(hens_ctx_impl* c) {
+int rj_ready(hens_ctx_impl* c, bool between_halves = false) {
     int r = ready(c, true);
     if (r) return r;
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
     if (c->Tl != c->T) return fail(c, HENS_ERR_UNSUPPORTED, "the leaf-packing path runs on the whole ladder of one GPU");
-    if (c->expect_split != 0 || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
+    if ((c->expect_split != 0 && !between_halves) || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
     return HENS_OK;
 }
 
@@ -1622,6 +1628,9 @@ int rj_ensure_staging(hens_ctx_impl* c) {
     if ((r = dalloc(c, &c->rj_change, TW * RJ_MAX_BRANCH))) return r;
     if ((r = dalloc(c, &c->rj_leaf, TW * RJ_MAX_BRANCH))) return r;
     if ((r = dalloc(c, &c->rj_keep, TW))) return r;
+    if ((r = dalloc(c, &c->rj_st_own, TW))) return r;                              // (hens_rj_stretch_split)
+    if ((r = dalloc(c, &c->rj_st_cw, TW * RJ_MAX_BRANCH))) return r;
+    if ((r = dalloc(c, &c->rj_uzz, TW))) return r;
     return HENS_OK;
 }
 
@@ -2947,6 +2956,65 @@ int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint
     if ((r = check_flags(c, false))) return r;
     c->rj_num_mh += 1;
     if (!has_pt(c)) c->iter += 1;
+    return HENS_OK;
+}
+
+// One half of the red / blue StretchMove on leaf-packing records (round 5; SURVEY 8 row a4 over several branches and leaves):
+// RedBlueMove.propose's split (red_blue.py:103-197) + StretchMove.get_proposal's loop over the branches (stretch.py:160-231) +
+// priors / likelihood with inds, accept, update (red_blue.py:254-323), teacher-forced with the caller's draws.
+int hens_rj_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
+                          const double* u_acc, uint8_t* keep_out) {
+    hens_ctx_impl* c = enter(ctx);
+    int r = rj_ready(c, split == 1);
+    if (r) return r;
+    if (!labels || !rint || !u_zz || !u_acc) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (split < 0 || split > 1) return fail(c, HENS_ERR_INVALID, "split must be 0 or 1 (two sets)");
+    if (split != c->expect_split) return fail(c, HENS_ERR_STATE, "split calls must run 0, 1 in order (expected %d)", c->expect_split);
+    const int Tl = c->Tl, W = c->W, nb = c->rj.nb;
+    if (W < 2 * c->rj.ind_off)                                                      // red_blue.py:103-114 (every slot of every branch counts)
+        return fail(c, HENS_ERR_TOO_FEW_WALKERS, "It is unadvisable to use a red-blue move with fewer walkers than twice the number of dimensions.");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);
+    flush_adapt(c);
+    if ((r = rj_ensure_staging(c))) return r;
+    // ascending walker lists of the two sets (red_blue.py:150-154): set k has ceil((W - k) / 2) walkers (arange(W) % 2, shuffled)
+    const int n0 = (W + 1) / 2, Ns = split == 0 ? n0 : W - n0, Nc = W - Ns;
+    std::vector<int32_t> own((size_t)Tl * Ns), other((size_t)Tl * Nc), cw((size_t)nb * Tl * Ns);
+    for (int t = 0; t < Tl; ++t) {
+        int a = 0, b = 0;
+        for (int w = 0; w < W; ++w) {
+            const uint8_t l = labels[(size_t)t * W + w];
+            if (l > 1) return fail(c, HENS_ERR_INVALID, "labels must be 0 or 1");
+            if (l == split) { if (a >= Ns) return fail(c, HENS_ERR_INVALID, "labels must hold ceil((W - k) / 2) walkers of set k per rung"); own[(size_t)t * Ns + a++] = w; }
+            else { if (b >= Nc) return fail(c, HENS_ERR_INVALID, "labels must hold ceil((W - k) / 2) walkers of set k per rung"); other[(size_t)t * Nc + b++] = w; }
+        }
+    }
+    if (split == 0) c->labels_host.assign(labels, labels + (size_t)Tl * W);
+    else if (c->labels_host.size() != (size_t)Tl * W || memcmp(c->labels_host.data(), labels, (size_t)Tl * W) != 0)
+        return fail(c, HENS_ERR_INVALID, "labels differ between split 0 and split 1 of the same iteration");
+    for (int b = 0; b < nb; ++b)                                                    // rint[nbranches][Tl][Ns]: an index into the other set
+        for (int t = 0; t < Tl; ++t)
+            for (int k = 0; k < Ns; ++k) {
+                const int64_t ri = rint[((size_t)b * Tl + t) * Ns + k];
+                if (ri < 0 || ri >= Nc) return fail(c, HENS_ERR_INVALID, "rint out of range [0, %d)", Nc);
+                cw[((size_t)b * Tl + t) * Ns + k] = other[(size_t)t * Nc + ri];
+            }
+    const size_t n = (size_t)Tl * Ns;
+    HIPCHK(c, hipMemcpyAsync(c->rj_st_own, own.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_st_cw, cw.data(), (size_t)nb * n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_uzz, u_zz, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                                     // (the host vectors go out of scope)
+    c->rj_tm_valid = false;                   // (teacher-forced move: the reference's full evaluation, no resident templates)
+    c->rj_st_ns = Ns;
+    if ((r = rj_launch(c, RJ_MODE_STRETCH, 0, nullptr, nullptr, nullptr, nullptr, c->rj_u, c->rj_keep))) return r;
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, n, hipMemcpyDeviceToHost, c->stream));
+    if ((r = check_flags(c, false))) return r;
+    if (split == 1) {
+        c->rj_num_mh += 1;                    // (the in-model move's counter, whichever move it is)
+        if (!has_pt(c)) c->iter += 1;
+    }
+    c->expect_split = split ^ 1;
     return HENS_OK;
 }
 

@@ -25,7 +25,7 @@ namespace hens {
 
 constexpr int RJ_MAX_BRANCH = 4, RJ_ND = 3, RJ_MAX_RW = 128;
 enum { RJ_KIND_PULSE = 0, RJ_KIND_SINE = 1 };
-enum { RJ_MODE_EVAL = 0, RJ_MODE_MH = 1, RJ_MODE_BD = 2 };
+enum { RJ_MODE_EVAL = 0, RJ_MODE_MH = 1, RJ_MODE_BD = 2, RJ_MODE_STRETCH = 3 };
 enum : uint32_t { PURPOSE_RJ_NORMAL = 20, PURPOSE_RJ_ACC = 21, PURPOSE_RJ_BD = 22, PURPOSE_RJ_BIRTH = 23, PURPOSE_RJ_BRANCH = 24 };
 
 struct RjModel {
@@ -72,6 +72,14 @@ struct RjArgs {
     unsigned* ad_flag;
     uint32_t ad_serial;
     int32_t ad_fold;
+    // RJ_MODE_STRETCH (round 5): one half of the red / blue StretchMove over EVERY branch and leaf slot of a walker (stretch.py:
+    // 160-231 loops the branches: one complement walker per branch, one stretch factor per walker; red_blue.py:148-323).  One
+    // wavefront per POSITION of the moving half: walker st_own[tl][k]; u_acc / keep_out are indexed by position too.
+    const int32_t* st_own;              // [Tl][st_ns] the moving walkers (ascending per rung: red_blue.py:150-154)
+    const int32_t* st_cw;               // [nbranches][Tl][st_ns] every branch's complement walker (stretch.py:93-100, 205)
+    const double* st_uzz;               // [Tl][st_ns] the uniforms behind zz (stretch.py:129-132)
+    double st_a;                        // stretch scale
+    int32_t st_ns, st_pad_;
 };
 
 // k_adapt's arithmetic (tempering.py:563-596) in one wavefront, T <= 64: lane j owns rung j; same operations in the same order
@@ -236,10 +244,11 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     s_tab[threadIdx.x & 63] = RJ_EXP_TAB[threadIdx.x & 63];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t gw = (int64_t)blockIdx.x * RJ_WAVES + wv;
-    if (gw >= (int64_t)A.Tl * A.W) return;                  // whole wavefront (nothing below synchronises across waves)
+    const int64_t slot = (int64_t)blockIdx.x * RJ_WAVES + wv;     // one wavefront per walker - stretch half-step: per position of the half
+    if (slot >= (int64_t)A.Tl * (MODE == RJ_MODE_STRETCH ? A.st_ns : A.W)) return;   // whole wavefront (nothing below synchronises across waves)
     const RjModel& M = A.M;
-    const int tl = (int)(gw / A.W);
+    const int tl = (int)(slot / (MODE == RJ_MODE_STRETCH ? A.st_ns : A.W));
+    const int64_t gw = MODE == RJ_MODE_STRETCH ? (int64_t)tl * A.W + A.st_own[slot] : slot;
     const int RW = M.RW;
 #define RJ_TRACE(i) do { if (A.trace && gw < A.trace_n && lane == 0) A.trace[gw * 8 + (i)] = trace_stamp(); } while (0)
     RJ_TRACE(0);
@@ -288,6 +297,19 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 q[i] = cur[i] + st;
             }
         }
+    } else if (MODE == RJ_MODE_STRETCH) {
+        // every leaf slot of every branch moves, active or not (the masks only decide what prior and likelihood see): branch b's
+        // slots against branch b's complement walker, one stretch factor for the walker (stretch.py:128-145, 187-218); the Hastings
+        // factor counts every slot of every branch (stretch.py:222-223; without Gibbs sampling adjust_factors changes nothing)
+        const double zz = draw_zz(A.st_uzz[slot], A.st_a);                          // stretch.py:129-132
+        const size_t TN = (size_t)A.Tl * A.st_ns;
+        for (int i = lane; i < M.ind_off; i += 64) {
+            int b = 0;
+            while (b + 1 < M.nb && i >= M.off[b + 1]) ++b;
+            const double c = A.pool[(size_t)A.loc[(size_t)tl * A.W + A.st_cw[(size_t)b * TN + slot]] * RW + i];
+            q[i] = c - (c - cur[i]) * zz;                                           // stretch.py:141-145
+        }
+        factors = ((double)M.ind_off - 1.0) * log(zz);                              // stretch.py:223
     } else if (MODE == RJ_MODE_BD) {
       // one branch, or - branch < 0, the "together" schedule (ensemble.py:414-432, distgenrj.py:150-222) - every branch of the
       // walker in one proposal: the factors add up in branch order, then the edge factors (one sum over the branches, rj.py:236-270)
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     const double lnpdiff = factors + logP - prevP;                     // mh.py:155, rj.py:330
     double lu;
     if (A.u_acc) {
-        lu = log(A.u_acc[gw]);
+        lu = log(A.u_acc[MODE == RJ_MODE_STRETCH ? slot : gw]);
     } else {
         lu = log(rj_accept_uniform(A.seed, A.iter, wid, MODE, MODE == RJ_MODE_BD ? (A.branch >= 0 ? A.branch : M.nb) : 0));
     }
@@ -631,7 +653,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             if (A.accepted) A.accepted[gw] += 1u;     // ("iterate_branches": the move's mask is its LAST branch's, rj.py:385-386)
         }
     }
-    if (lane == 0 && A.keep_out) A.keep_out[gw] = keep ? 1 : 0;
+    if (lane == 0 && A.keep_out) A.keep_out[MODE == RJ_MODE_STRETCH ? slot : gw] = keep ? 1 : 0;
     RJ_TRACE(5);
 #undef RJ_TRACE
 #undef RJ_LDS_SYNC

@@ -75,11 +75,13 @@ class DeviceMove(Move):
     def _single_branch(state):
         names = list(state.branches.keys())
         if len(names) != 1:
-            raise NotImplementedError("the device path handles a single branch (SURVEY 8f-4: RJ is a later row)")
+            raise NotImplementedError("this move steps a single-branch state; states of several branches / leaves step on leaf-packing "
+                                      "records: eryn_amd.rj.RJEnsembleSampler with moves=StretchLeafMove() or GaussianLeafMove(cov)")
         br = state.branches[names[0]]
         T, W, nl, D = br.shape
         if nl != 1 or not np.all(br.inds):
-            raise NotImplementedError("the device path handles nleaves_max == 1 with all leaves active")
+            raise NotImplementedError("this move steps nleaves_max == 1 with all leaves active; several leaves step on leaf-packing "
+                                      "records (eryn_amd.rj.RJEnsembleSampler)")
         if state.blobs is not None or state.supplemental is not None:
             raise NotImplementedError("blobs / supplementals are outside the device hot path")
         return names[0], br, T, W, D

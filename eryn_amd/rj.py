@@ -48,7 +48,7 @@ class _TemplateLikelihood:
 
 class RJEngine:
     def __init__(self, ntemps, nwalkers, branches, t, y, sigma, seed=0, device_id=0, adaptive=True,
-                 adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1, fill_value=-1e300):
+                 adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1, fill_value=-1e300, a=2.0):
         self.branches = list(branches)
         if not 1 <= len(self.branches) <= 4:
             raise NotImplementedError("1 to 4 branches")
@@ -61,7 +61,7 @@ class RJEngine:
         self.eng = HipEnsemble(self.T, self.W, self.RW, _TemplateLikelihood(self.RW), -1.0, 1.0, tempered=True,
                                adaptive=adaptive, adaptation_lag=adaptation_lag, adaptation_time=adaptation_time,
                                stop_adaptation=stop_adaptation, live_dangerously=True, fill_value=fill_value, seed=seed,
-                               device_id=device_id)
+                               device_id=device_id, a=a)
         self.lib, self.ctx = self.eng.lib, self.eng.ctx
         self.schedule = "separate_branches"
         nb = len(self.branches)
@@ -157,6 +157,20 @@ class RJEngine:
         check(self.lib.hens_rj_bd_all_step(self.ctx, ptr(ch), ptr(lf), ptr(bt), ptr(u), ptr(keep)), self.ctx)
         return keep.astype(bool)
 
+    def stretch_split(self, split, labels, rint, u_zz, u_acc):
+        """One half of the red / blue StretchMove over every branch and leaf slot (stretch.py:160-231, red_blue.py:148-323):
+        labels[T, W] in {0, 1}, rint[nbranches, T, Ns] (one complement draw per branch), u_zz / u_acc[T, Ns]; returns the accept
+        mask [T, Ns] of the moving walkers in ascending order."""
+        lab = np.ascontiguousarray(labels, dtype=np.uint8)
+        ri = np.ascontiguousarray(rint, dtype=np.int64)
+        Ns = ri.shape[-1]
+        if lab.shape != (self.T, self.W) or ri.shape != (len(self.branches), self.T, Ns):
+            raise ValueError("labels must have shape (ntemps, nwalkers), rint (nbranches, ntemps, Ns)")
+        uz, ua = f64(u_zz, (self.T, Ns)), f64(u_acc, (self.T, Ns))
+        keep = np.empty((self.T, Ns), dtype=np.uint8)
+        check(self.lib.hens_rj_stretch_split(self.ctx, int(split), ptr(lab), ptr(ri), ptr(uz), ptr(ua), ptr(keep)), self.ctx)
+        return keep.astype(bool)
+
     def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
         return self.eng.pt_sweep(iperm, i1perm, u_swap, adapt=adapt)
 
@@ -235,6 +249,16 @@ class GaussianLeafMove:
         self.accepted, self.num_proposals = None, 0
 
 
+class StretchLeafMove:
+    """``StretchMove(a=2.0)`` of the reference as the in-model move on leaf-packing records (stretch.py:14-231 over
+    red_blue.py:103-330): every branch and every leaf slot of a walker moves - one complement walker per branch, one stretch
+    factor per walker.  (The reference advises against it beside reversible jump, ensemble.py:509-514, and runs it.)"""
+
+    def __init__(self, a=2.0):
+        self.a = float(a)
+        self.accepted, self.num_proposals = None, 0
+
+
 class RJEnsembleSampler:
     """``EnsembleSampler(nwalkers, ndims, log_like_fn, priors, tempering_kwargs=..., branch_names=..., nleaves_max=...,
     nleaves_min=..., moves=GaussianMove(cov), rj_moves="separate_branches")`` (ensemble.py:211-681) for the template model,
@@ -252,12 +276,16 @@ class RJEnsembleSampler:
         from .moves.tempering import TemperatureControl
         if not isinstance(log_like_fn, TemplateLikelihood):
             raise NotImplementedError("the device RJ path runs the template model: pass an eryn_amd.rj.TemplateLikelihood")
-        if rj_moves not in ("separate_branches", "iterate_branches", "together"):
+        if rj_moves not in ("separate_branches", "iterate_branches", "together", None, False):
             raise ValueError("When providing a str for rj_moves, must be 'together', 'iterate_branches', or "
                              f"'separate_branches'. Input is {rj_moves}")                # ensemble.py:473-476
-        self.rj_schedule = rj_moves
-        if not isinstance(moves, GaussianLeafMove):
-            raise NotImplementedError("the in-model move must be an eryn_amd.rj.GaussianLeafMove")
+        self.rj_schedule = rj_moves or None                  # None: no reversible jump - the leaf masks never change
+        if not isinstance(moves, (GaussianLeafMove, StretchLeafMove)):
+            raise NotImplementedError("the in-model move must be an eryn_amd.rj.GaussianLeafMove or StretchLeafMove")
+        if isinstance(moves, StretchLeafMove) and rng != "numpy":
+            raise NotImplementedError("the stretch move on leaf-packing records steps with rng='numpy' (the reference's draws)")
+        if self.rj_schedule is None and rng != "numpy":
+            raise NotImplementedError("rng='philox' steps the in-model move and the birth / death move together (hens_rj_step)")
         if rng not in ("numpy", "philox"):
             raise ValueError("rng must be 'numpy' or 'philox'")
         self.branch_names = list(branch_names if branch_names is not None else ndims.keys())
@@ -286,8 +314,10 @@ class RJEnsembleSampler:
             seed = int(np.random.randint(0, 2**31 - 1)) if rng == "philox" else 0
         self.engine = RJEngine(self.ntemps, self.nwalkers, self.branches, log_like_fn.t, log_like_fn.y, log_like_fn.sigma,
                                seed=seed, device_id=device_id, adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag,
-                               adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation)
-        self.engine.set_schedule(rj_moves)
+                               adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation,
+                               **({"a": moves.a} if isinstance(moves, StretchLeafMove) else {}))
+        if self.rj_schedule is not None:
+            self.engine.set_schedule(rj_moves)
         if rng == "philox":
             # the device draws axis-aligned steps (hens_rj_set_mh_scale: three standard deviations per branch): a covariance
             # with off-diagonal terms is another proposal - refused rather than silently reduced to its diagonal
@@ -297,7 +327,7 @@ class RJEnsembleSampler:
                                               "multivariate_normal draws with any covariance)")
             self.engine.set_mh_scale(np.stack([np.sqrt(np.diag(moves.cov[k])) for k in self.branch_names]))
         moves.accepted = np.zeros((self.ntemps, self.nwalkers))
-        nmoves = len(self.branch_names) if rj_moves == "separate_branches" else 1    # (rj move objects, ensemble.py:414-471)
+        nmoves = len(self.branch_names) if rj_moves == "separate_branches" else (1 if self.rj_schedule else 0)    # (rj move objects, ensemble.py:414-471)
         self.rj_accepted = [np.zeros((self.ntemps, self.nwalkers)) for _ in range(nmoves)]
         self.rj_num_proposals = [0 for _ in range(nmoves)]
         # rng="philox": the device counts the birth / death move over all branches together
@@ -324,17 +354,35 @@ class RJEnsembleSampler:
     def _iteration_numpy(self):
         eng, tc, R, T, W = self.engine, self.temperature_control, self._random, self.ntemps, self.nwalkers
         mv = self.moves[0]
-        x, inds, _, _, _ = eng.download()
-        # in-model move: move choice (ensemble.py:971), per branch one multivariate_normal over the packed leaves
-        # (gaussian.py:96-104, 265-268), the accept uniforms (mh.py:157)
-        R.choice(1, p=np.ones(1))
-        steps = {}
-        for b in self.branches:
-            n = int(inds[b.name].sum())
-            s = np.zeros(x[b.name].shape)
-            s[inds[b.name]] = 1.0 * R.multivariate_normal(np.zeros(3), mv.cov[b.name], size=n)
-            steps[b.name] = s
-        acc = eng.mh_step(steps, R.rand(T, W))
+        R.choice(1, p=np.ones(1))                                               # move choice (ensemble.py:971)
+        if isinstance(mv, StretchLeafMove):
+            # red / blue stretch over every branch and leaf slot: the split's shuffles from the GLOBAL stream (red_blue.py:119-124),
+            # per half and branch one randint of R, behind the first branch's the walkers' zz uniforms (stretch.py:205, 128-132),
+            # then the accept uniforms (red_blue.py:294)
+            labels = np.tile(np.arange(W), (T, 1)) % 2
+            for row in labels:
+                np.random.shuffle(row)
+            acc = np.zeros((T, W), dtype=bool)
+            for split in range(2):
+                Ns = int((labels[0] == split).sum())
+                rint, u_zz = [], None
+                for bi in range(len(self.branches)):
+                    rint.append(R.randint(W - Ns, size=(T, Ns)))
+                    if bi == 0:
+                        u_zz = R.rand(T, Ns)
+                keep = eng.stretch_split(split, labels, np.stack(rint), u_zz, R.rand(T, Ns))
+                for t in range(T):
+                    acc[t, np.flatnonzero(labels[t] == split)] = keep[t]
+        else:
+            x, inds, _, _, _ = eng.download()
+            # per branch one multivariate_normal over the packed leaves (gaussian.py:96-104, 265-268), the accept uniforms (mh.py:157)
+            steps = {}
+            for b in self.branches:
+                n = int(inds[b.name].sum())
+                s = np.zeros(x[b.name].shape)
+                s[inds[b.name]] = 1.0 * R.multivariate_normal(np.zeros(3), mv.cov[b.name], size=n)
+                steps[b.name] = s
+            acc = eng.mh_step(steps, R.rand(T, W))
         mv.accepted += acc
         mv.num_proposals += 1
         iperm, i1perm, u = tc.draw_swap_randoms()                               # mh.py:190-191
@@ -342,6 +390,8 @@ class RJEnsembleSampler:
         tc.swaps_accepted = swaps
         if tc.adaptive:
             tc.time += 1
+        if self.rj_schedule is None:
+            return acc, None
         # reversible jump (ensemble.py:988-990; distgenrj.py:35-222): on one branch chosen from R, or - "iterate_branches" - one
         # move (the choice among ONE move still draws) that takes the branches in turn, its accept mask the last branch's
         nb = len(self.branches)

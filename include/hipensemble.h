@@ -375,6 +375,16 @@ int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t i
  *   {-1, 0, +1} after the edge rule (distgenrj.py:69-73), leaf[Tl][W] the slot that is born or dies, birth[Tl][W][3] the
  *   prior draw of a born leaf, u_acc[Tl][W].  The library adds the proposal factors -/+ log q(leaf), the edge factors
  *   (rj.py:236-270) and the fix_logp_gibbs rule (move.py:368-402).  Follow it with hens_pt_sweep(adapt = 0) (rj.py:381-382).
+ * hens_rj_stretch_split: one half of the red / blue StretchMove on a state of several branches and leaves (round 5; SURVEY 8
+ *   row a4's loop over branches): RedBlueMove.propose (red_blue.py:103-330) + StretchMove.get_proposal / choose_c_vals /
+ *   get_new_points (stretch.py:74-231) without Gibbs sampling.  labels[Tl][W] in {0, 1} (arange(W) % 2 shuffled per rung,
+ *   red_blue.py:119-124; the same array for both splits), rint[nbranches][Tl][Ns] - EVERY branch its own complement draw,
+ *   an index into the other set in ascending walker order (stretch.py:93-100, 205) -, u_zz[Tl][Ns] the ONE stretch factor's
+ *   uniform per walker (stretch.py:128-132), u_acc[Tl][Ns], keep_out[Tl][Ns] by position of the moving set (ascending walker
+ *   order).  Every leaf slot of every branch moves, active or not; factors = (sum of nleaves_max * ndim - 1) log zz
+ *   (stretch.py:222-223); the leaf masks stay and decide what prior and likelihood see; rows are updated in place (complements
+ *   come from the other set).  Call split 0 then split 1, then hens_pt_sweep.  Fewer than twice as many walkers as leaf
+ *   coordinates -> HENS_ERR_TOO_FEW_WALKERS (red_blue.py:103-114).
  * hens_rj_set_mh_scale + hens_rj_step: production: n iterations of (in-model move, swaps + adaptation, birth / death on
  *   a uniformly chosen branch, swaps) with device-side Philox draws of the same distributions.  Every walker's model at the
  *   data points stays resident and birth / death evaluates `model +- one leaf`; the resident models AND the log-likelihoods
@@ -391,6 +401,8 @@ int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale);
 int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out);
 int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const int32_t* leaf, const double* birth,
                     const double* u_acc, uint8_t* keep_out);
+int hens_rj_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, const int64_t* rint, const double* u_zz,
+                          const double* u_acc, uint8_t* keep_out);
 int hens_rj_step(hens_ctx* ctx, int64_t n_iters);
 int hens_rj_get_counters(hens_ctx* ctx, double* accepted_bd, int64_t* num_mh, int64_t* num_bd);
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from tests import tolerance_log as tol
-from tests.test_oracle_golden_rj import NAMES, NAMES_ALL, load_rj, make_rj_oracle
+from tests.test_oracle_golden_rj import NAMES, NAMES_ALL, NAMES_STRETCH, load_rj, make_rj_oracle
 
 pytestmark = pytest.mark.gpu
 # the template likelihood sums 500 data points of FP64 exp / sin evaluated by the device's math library (each within an ulp or two
@@ -268,6 +268,101 @@ def test_rj_sampler_reproduces_the_reference_chain(golden_dir, name):
         assert np.array_equal(mid.branches[k].inds, fx[f"it{n // 2}_rj_inds_{k}"])
         assert np.isnan(mid.branches[k].coords[~mid.branches[k].inds]).all()
     s.engine.close()
+
+
+@pytest.mark.parametrize("name", NAMES_STRETCH)
+def test_stretch_move_over_branches_and_leaves_matches_the_oracle(golden_dir, name):
+    """Round 5 (SURVEY 8 row a4 over several branches and leaves): the red / blue StretchMove on leaf-packing records,
+    hens_rj_stretch_split, teacher-forced per half against the oracle (pinned bit for bit on the rjs* fixtures captured from the
+    reference): accept masks exact and no knife edge, every leaf slot - dead ones move too - and the log-prior exact, leaf masks
+    untouched, log-like 1e-12; then swaps + adaptation, and (rjs2) the birth / death move on the state the stretch left."""
+    fx = load_rj(golden_dir, name)
+    o = make_rj_oracle(fx, record=True)
+    eng = make_engine(fx, o)
+    n_acc = 0
+    for it in range(int(fx["nsteps"])):
+        o.iteration()
+        rec = o.trace[-1]
+        what = f"{name} it{it}"
+        x, inds, L, P = state_of(rec, "pre_", o)
+        eng.upload(x, inds, L, P, rec["betas_before"])
+        eng.set_adapt_time(rec["time_before"])
+        for split in range(2):
+            keep = eng.stretch_split(split, rec["st_labels"], rec[f"st_rint{split}"], rec[f"st_u_zz{split}"], rec[f"st_u_acc{split}"])
+            assert not knife(rec[f"st_lnpdiff{split}"], rec[f"st_u_acc{split}"]).any()
+            assert np.array_equal(keep, rec[f"st_keep{split}"]), f"{what}: accept mask of half {split}"
+            assert_state(eng, rec, f"stupd{split}_", o, what=what + f" after half {split}")
+            n_acc += int(keep.sum())
+        # swaps + adaptation on the oracle's exact log-likes (decisions depend on them to the last bit)
+        eng.upload(*state_of(rec, "mhupd_", o), rec["betas_before"])
+        eng.set_adapt_time(rec["time_before"])
+        sel, swaps = eng.pt_sweep(rec["iperm"], rec["i1perm"], rec["u_swap"], adapt=True)
+        assert np.array_equal(sel, rec["sel"]) and np.array_equal(swaps, rec["swaps"]), f"{what}: swaps"
+        betas = assert_state(eng, rec, "mh_", o, exact_L=True, what=what + " after the swaps")
+        np.testing.assert_allclose(betas, rec["betas_after"], rtol=1e-13, atol=0)
+        if o.schedule != "none":                                 # the birth / death move on what the stretch left behind
+            x, inds, L, P = state_of(rec, "rjpre_", o)
+            eng.upload(x, inds, L, P, rec["betas_after"])
+            birth = np.zeros((o.T, o.W, 3))
+            birth[rec["rj_change"] == +1] = rec["rj_birth"]
+            keep = eng.bd_step(rec["rj_branch"], rec["rj_change"], rec["rj_leaf"], birth, rec["rj_u_acc"])
+            assert np.array_equal(keep, rec["rj_accepted"]), f"{what}: birth/death accept mask"
+            assert_state(eng, rec, "rjupd_", o, what=what + " after birth/death")
+    assert n_acc > 0
+    eng.close()
+
+
+@pytest.mark.parametrize("name", NAMES_STRETCH)
+def test_rj_sampler_with_the_stretch_move_reproduces_the_reference_chain(golden_dir, name):
+    """RJEnsembleSampler(moves=StretchLeafMove(), rj_moves=None | "separate_branches") free-running from the reference's two seeds
+    lands on the reference's chain: every leaf slot and the log-prior exact, leaf masks exact, log-like 1e-12, ladder 1e-13."""
+    from eryn_amd.prior import uniform_dist
+    from eryn_amd.rj import RJEnsembleSampler, StretchLeafMove, TemplateLikelihood
+    from eryn_amd.state import State
+    fx = load_rj(golden_dir, name)
+    names = ["gauss", "sine"]
+    n = int(fx["nsteps"])
+    rj = None if str(fx["rj_moves"]) == "none" else str(fx["rj_moves"])
+    priors = {"gauss": {i: uniform_dist(*fx["gauss_box"][i]) for i in range(3)},
+              "sine": {i: uniform_dist(*fx["sine_box"][i]) for i in range(3)}}
+    np.random.seed(int(fx["seed_construct"]))          # R := snapshot of the global stream at construction
+    s = RJEnsembleSampler(int(fx["W"]), {k: 3 for k in names}, TemplateLikelihood({"gauss": "pulse", "sine": "sine"},
+                          fx["t"], fx["y"], float(fx["sigma"])), priors, tempering_kwargs=dict(ntemps=int(fx["T"])),
+                          nbranches=2, branch_names=names, nleaves_max=dict(zip(names, map(int, fx["nl_max"]))),
+                          nleaves_min=dict(zip(names, map(int, fx["nl_min"]))), moves=StretchLeafMove(), rj_moves=rj)
+    coords = {k: fx[f"x0_{k}"] for k in names}
+    inds = {k: fx[f"inds0_{k}"] for k in names}
+    np.random.seed(int(fx["seed_run"]))
+    last = s.run_mcmc(State(coords, log_like=fx["L0"], log_prior=fx["P0"], inds=inds), n, store=False)
+    pre = f"it{n - 1}_{'mh' if rj is None else 'rj'}_"
+    for k in names:
+        assert np.array_equal(last.branches[k].inds, fx[pre + f"inds_{k}"]), f"inds of {k}"
+        assert np.array_equal(last.branches[k].coords, fx[pre + f"x_{k}"]), f"coordinates of {k}"
+    assert np.array_equal(last.log_prior, fx[pre + "P"])
+    tol.check_logl(last.log_like, fx[pre + "L"], RTOL_L, 'template log-like')
+    np.testing.assert_allclose(last.betas, fx[pre + "betas"], rtol=1e-13, atol=0)
+    assert np.array_equal(s.moves[0].accepted, fx["mh_accepted_total"])
+    if rj is not None:
+        assert np.array_equal(np.stack(s.rj_accepted), fx["rj_accepted_total"])
+    s.engine.close()
+
+
+def test_stretch_move_on_records_refuses_too_few_walkers():
+    """red_blue.py:103-114 counts every leaf slot of every branch: nwalkers < 2 * sum(nleaves_max * ndim) raises RuntimeError."""
+    from eryn_amd.rj import RJEngine, TemplateBranch
+    t = np.linspace(-1, 1, 20)
+    brs = [TemplateBranch("gauss", "pulse", [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)], 3, 0),
+           TemplateBranch("sine", "sine", [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)], 2, 0)]
+    T, W = 2, 16                                                   # 15 leaf coordinates: 30 walkers needed
+    eng = RJEngine(T, W, brs, t, np.zeros(20), 1.0)
+    x = {"gauss": np.zeros((T, W, 3, 3)), "sine": np.zeros((T, W, 2, 3))}
+    inds = {"gauss": np.zeros((T, W, 3), dtype=bool), "sine": np.zeros((T, W, 2), dtype=bool)}
+    eng.upload(x, inds, betas=np.array([1.0, 0.5]))
+    eng.eval_state()
+    labels = np.tile(np.arange(W) % 2, (T, 1)).astype(np.uint8)
+    with pytest.raises(RuntimeError):
+        eng.stretch_split(0, labels, np.zeros((2, T, W // 2), dtype=np.int64), np.full((T, W // 2), 0.5), np.full((T, W // 2), 0.5))
+    eng.close()
 
 
 def test_rj_sampler_philox_mode():
