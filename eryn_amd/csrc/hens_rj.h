@@ -154,6 +154,9 @@ __device__ const double RJ_EXP_TAB[64] = {
     0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
     0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
 __device__ __forceinline__ double rj_exp_neg(double x, const double* tab) {
+#ifdef HENS_RJ_FAKE_EXP          // DEV PROBE, timing only (wrong values): what config 4 would cost if a pulse's exp were two FP64 operations
+    return fma(x, 1e-3, 1.0);
+#endif
     x = x < -800.0 ? -800.0 : x;
     const double kd = __builtin_rint(x * 0x1.71547652b82fep+6);           // 64 / ln 2
     const int k = (int)kd;
@@ -192,7 +195,6 @@ __device__ __forceinline__ double numpy_sum(const double* v, int n) {
     return res;
 }
 
-// index of the k-th set bit of m (k < popcount(m))
 __device__ __forceinline__ int nth_set_bit(uint32_t m, int k) {
     for (int j = 0; j < k; ++j) m &= m - 1u;
     return __builtin_ctz(m);
@@ -223,7 +225,10 @@ __device__ __forceinline__ double rj_accept_uniform(uint64_t seed, uint64_t it, 
     return u01(d.x, d.y);
 }
 
-constexpr int RJ_WAVES = 4;        // walkers per workgroup
+#ifndef HENS_RJ_WAVES
+#define HENS_RJ_WAVES 4
+#endif
+constexpr int RJ_WAVES = HENS_RJ_WAVES;        // walkers per workgroup
 
 // (four waves per SIMD: the kernel is bound by FP64 issue and hides its latencies with waves; with the sine rotation scheme the
 //  allocator would take 132 VGPRs - three waves - if it were not held to 128)
@@ -239,18 +244,26 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     __shared__ double s_cur[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_q[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_leafv[RJ_WAVES][32];
-    __shared__ double s_rot[RJ_WAVES][RJ_MAX_BRANCH][2][32];   // sine leaves: (sin, cos) of the rotation by 64 grid steps, per branch and leaf
+    __shared__ double s_par[RJ_WAVES][2][64];               // per leaf slot: pulse 1 / (2 c^2), exp(-h^2 / c^2); sine (sin, cos) of the rotation by one grid step
     __shared__ double s_tab[64];                            // rj_exp_neg's table (every wave writes the same 64 values, then reads)
     s_tab[threadIdx.x & 63] = RJ_EXP_TAB[threadIdx.x & 63];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef HENS_RJ_REVERSE
+    const int64_t slot = (int64_t)(gridDim.x - 1 - blockIdx.x) * RJ_WAVES + wv;
+#else
     const int64_t slot = (int64_t)blockIdx.x * RJ_WAVES + wv;     // one wavefront per walker - stretch half-step: per position of the half
+#endif
     if (slot >= (int64_t)A.Tl * (MODE == RJ_MODE_STRETCH ? A.st_ns : A.W)) return;   // whole wavefront (nothing below synchronises across waves)
     const RjModel& M = A.M;
     const int tl = (int)(slot / (MODE == RJ_MODE_STRETCH ? A.st_ns : A.W));
     const int64_t gw = MODE == RJ_MODE_STRETCH ? (int64_t)tl * A.W + A.st_own[slot] : slot;
     const int RW = M.RW;
+#ifdef HENS_RJ_TRACE_STRIDE        // DEV: every 64th walker instead of the first ones (all rounds of the launch)
+#define RJ_TRACE(i) do { if (A.trace && (gw & 63) == 0 && (gw >> 6) < A.trace_n && lane == 0) A.trace[(gw >> 6) * 8 + (i)] = trace_stamp(); } while (0)
+#else
 #define RJ_TRACE(i) do { if (A.trace && gw < A.trace_n && lane == 0) A.trace[gw * 8 + (i)] = trace_stamp(); } while (0)
+#endif
     RJ_TRACE(0);
     double* cur = s_cur[wv];
     double* q = s_q[wv];
@@ -264,11 +277,11 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 #define RJ_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     RJ_LDS_SYNC();
     uint32_t mask_old[RJ_MAX_BRANCH], mask[RJ_MAX_BRANCH];
-    for (int b = 0; b < M.nb; ++b) mask[b] = mask_old[b] = (uint32_t)cur[M.ind_off + b];
+    for (int b = 0; b < M.nb; ++b) mask[b] = mask_old[b] = __builtin_amdgcn_readfirstlane((uint32_t)cur[M.ind_off + b]);   // (wave-uniform: scalar registers)
     const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
 
     constexpr bool FOLD = HAVE_TM && MODE != RJ_MODE_EVAL;     // (production launches of hens_rj_step)
-    if (FOLD && A.ad_fold && gw == 0) {
+    if (FOLD && A.ad_fold && blockIdx.x == 0 && wv == 0) {
         __shared__ double s_ad[64];
         __shared__ unsigned s_adc[64];
         rj_adapt_wave(A.ad, lane, s_ad, s_adc);
@@ -413,26 +426,20 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     int sig_e = 0;
     const bool sig_pow2 = frexp(M.sigma, &sig_e) == 0.5 && sig_e > -1000 && sig_e < 1000;
     const double sig_inv = 1.0 / M.sigma;
-    // Sine leaves on a uniform grid (production path, resident templates): a lane's points lane, lane + 64, ... are 64 grid steps
-    // apart, so a * sin(w t + c) at the later points of a chunk is a rotation of (sin, cos) at its first by the leaf's angle w * 64 dt
-    // - one sincos per chunk of four points and 4 FMA-rate operations per further point instead of a sin each (the library's FP64
-    // sin is ~100 VALU operations: argument reduction in double-double + polynomial, five times an exp).  Against the direct
-    // formula the ARGUMENT differs by the rounding of w t_k (<= 130 eps ~ 1.5e-14, what the reference's own products carry) and each
-    // rotation adds ~1 eps: the log-likelihood moves by ~1e-15 relative (bar 1e-13; the replay tests run this path).  The parity API
-    // (tm == nullptr) keeps the reference's sin per point.
+    // Data points on a uniform grid (production path, resident templates; hens_rj_set_model: M.t_step64 = 64 grid steps): a lane
+    // owns RJ_PPL = 8 CONSECUTIVE points t0, t0 + h, ... and a leaf's values there follow from its first by recurrences (round 5):
+    //   pulse  e_k = exp(-(t0 + k h - b)^2 / (2 c^2)):  e_{k+1} = e_k r_k,  r_{k+1} = r_k g,  r_0 = exp(-(2 (t0 - b) h + h^2) / (2 c^2)),
+    //          g = exp(-h^2 / c^2) - two exps and two products per further point instead of an exp per point (14 FP64-rate operations each);
+    //   sine   a sin(w (t0 + k h) + c): the rotation of (sin, cos) at t0 by the leaf's angle w h - one sincos per lane and leaf.
+    // 1 / (2 c^2), g and the rotation are formed once per leaf SLOT, a lane per slot (one division, one exp, one sincos per wave).
+    // Against the direct formulas a pulse's value at the lane's last point carries <= ~1e-14 relative (7 roundings of e, 21 of r and
+    // g, the argument roundings of r_0), a sine's ~7 eps; the log-likelihood moves by ~1e-15 relative (bar 1e-12; the replay tests
+    // run this path).  A pulse narrower than the grid step (|c| < h: e_0 may underflow where a later point does not) takes an exp per
+    // point.  With |c| >= h the exponent of r_0 is below ndata in magnitude: no overflow.  The parity API (tm == nullptr) and
+    // non-uniform grids keep the reference's exp / sin per point, a lane's points 64 apart (below).
     const bool rot = HAVE_TM && M.t_step64 != 0.0;
-    constexpr int NPT = 4, MAXCH = 2;                        // (template points per lane and chunk; chunks a lane keeps: ndata <= 512)
-    auto sine_points = [&](const double a, const double w, const double c, const double sd, const double cd, const double (&ti)[NPT], double (&out)[NPT], const double sg) {
-        double sk, ck;
-        sincos(w * ti[0] + c, &sk, &ck);
-        out[0] += sg * (a * sk);
-#pragma unroll
-        for (int k = 1; k < NPT; ++k) {
-            const double sn = fma(sk, cd, ck * sd), cn = fma(ck, cd, -(sk * sd));
-            sk = sn; ck = cn;
-            out[k] += sg * (a * sk);
-        }
-    };
+    constexpr int NPT = 4, MAXCH = 2;                        // (strided form: template points per lane and chunk; chunks a lane keeps: ndata <= 512)
+    constexpr int RJ_PPL = NPT * MAXCH;                      // (uniform grid: consecutive points per lane)
     double* tmrow = HAVE_TM ? A.tm + (size_t)A.loc[gw] * M.ndata : nullptr;
     constexpr bool by_diff = TMM == 1 && MODE == RJ_MODE_BD;      // (resident templates exist for ndata <= 64 NPT MAXCH only: hens_rj_set_model)
     double tmk[MAXCH][NPT];                                  // the proposal's template at this lane's points (stored on acceptance)
@@ -440,19 +447,105 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     for (int ch = 0; ch < MAXCH; ++ch)
 #pragma unroll
         for (int k = 0; k < NPT; ++k) tmk[ch][k] = 0.0;
-    if (evaluated && by_diff) {
-        // template' = template + (born leaf) - (dead leaf) per branch under proposal: one leaf's values instead of every leaf's
-        double acc = 0.0;
-        if (rot) {                             // the changing sine leaf's rotation, once for both chunks
-            for (int b = 0; b < M.nb; ++b) {
-                if (ch_sign[b] == 0 || M.kind[b] == RJ_KIND_PULSE) continue;
-                const double* src = ch_sign[b] > 0 ? q : cur;
-                double sd, cd;
-                sincos((2 * M_PI * src[M.off[b] + ch_leaf[b] * RJ_ND + 1]) * M.t_step64, &sd, &cd);
-                if (lane == 0) { s_rot[wv][b][0][0] = sd; s_rot[wv][b][1][0] = cd; }
+    if (rot && (evaluated || (MODE == RJ_MODE_EVAL && total_leaves > 0))) {
+        const double h = M.t_step64 * (1.0 / 64.0);
+        {   // per leaf slot (a lane per slot, every branch at once; dead slots cost nothing and their values are never read)
+            const int s = lane < M.ind_off / RJ_ND ? lane : 0;
+            int b = 0;
+            while (b + 1 < M.nb && s * RJ_ND >= M.off[b + 1]) ++b;
+            const double p1 = q[s * RJ_ND + 1], p2 = q[s * RJ_ND + 2];
+            double v0, v1;
+            if (M.kind[b] == RJ_KIND_PULSE) {
+                v0 = 1.0 / (2 * (p2 * p2));
+                v1 = fabs(p2) >= h ? rj_exp_neg(-(h * h) * (2 * v0), s_tab) : -1.0;
+            } else {
+                sincos((2 * M_PI * p1) * h, &v0, &v1);
             }
+            s_par[wv][0][lane] = v0; s_par[wv][1][lane] = v1;
             RJ_LDS_SYNC();
         }
+        const int i0 = lane * RJ_PPL;
+        const double t0 = A.tdata[i0 < M.ndata ? i0 : 0];
+        // one leaf's values at the lane's points, added to out[] with sign sg (per point: out += sg * (a * value), as the strided form)
+        auto leaf_points = [&](const int b, const int n, double (&out)[RJ_PPL], const double sg) {
+            const double a = q[M.off[b] + n * RJ_ND], bb = q[M.off[b] + n * RJ_ND + 1], c = q[M.off[b] + n * RJ_ND + 2];
+            const int s = M.off[b] / RJ_ND + n;
+            const double v0 = s_par[wv][0][s], v1 = s_par[wv][1][s];
+            if (M.kind[b] == RJ_KIND_PULSE) {
+                const double dx = t0 - bb;
+                if (v1 >= 0.0) {
+                    double e = rj_exp_neg(-(dx * dx) * v0, s_tab);
+                    double r = rj_exp_neg(-((2 * dx) * h + h * h) * v0, s_tab);
+                    out[0] += sg * (a * e);
+#pragma unroll
+                    for (int k = 1; k < RJ_PPL; ++k) {
+                        e = e * r;
+                        r = r * v1;
+                        out[k] += sg * (a * e);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < RJ_PPL; ++k) {
+                        const double dk = dx + (double)k * h;
+                        out[k] += sg * (a * rj_exp_neg(-(dk * dk) * v0, s_tab));
+                    }
+                }
+            } else {
+                double sk, ck;
+                sincos((2 * M_PI * bb) * t0 + c, &sk, &ck);
+                out[0] += sg * (a * sk);
+#pragma unroll
+                for (int k = 1; k < RJ_PPL; ++k) {
+                    const double sn = fma(sk, v1, ck * v0), cn = fma(ck, v1, -(sk * v0));
+                    sk = sn; ck = cn;
+                    out[k] += sg * (a * sk);
+                }
+            }
+        };
+        double tm8[RJ_PPL];
+        if (by_diff) {                    // template' = template + (born leaf) - (dead leaf) per branch under proposal
+#pragma unroll
+            for (int k = 0; k < RJ_PPL; ++k) tm8[k] = i0 + k < M.ndata ? tmrow[i0 + k] : 0.0;
+            for (int b = 0; b < M.nb; ++b)
+                if (ch_sign[b] != 0) leaf_points(b, ch_leaf[b], tm8, ch_sign[b] > 0 ? 1.0 : -1.0);      // (a dead leaf's coordinates stay in the record)
+        } else {                          // every active leaf: branch by branch in ascending slot order, like the reference's sums
+#pragma unroll
+            for (int k = 0; k < RJ_PPL; ++k) tm8[k] = 0.0;
+            for (int b = 0; b < M.nb; ++b) {
+                double sub[RJ_PPL];
+#pragma unroll
+                for (int k = 0; k < RJ_PPL; ++k) sub[k] = 0.0;
+                uint32_t m = mask[b];
+                while (m) {
+                    const int n = __builtin_ctz(m);
+                    m &= m - 1u;
+                    leaf_points(b, n, sub, 1.0);
+                }
+#pragma unroll
+                for (int k = 0; k < RJ_PPL; ++k) tm8[k] += sub[k];
+            }
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < RJ_PPL; ++k) {
+            if (i0 + k < M.ndata) {
+                const double d0 = tm8[k] - A.ydata[i0 + k];
+                const double r = sig_pow2 ? d0 * sig_inv : d0 / M.sigma;
+                acc += r * r;
+            }
+            tmk[k / NPT][k % NPT] = tm8[k];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        logl = -0.5 * acc;
+        if (logl != logl) {
+            logl = -1e300;
+            atomicOr(A.flags, FLAG_NAN_LOGL);
+        }
+        if (!evaluated) logl = A.fill;
+    } else if (evaluated && by_diff) {
+        // the strided forms (no uniform grid; parity API): template' = template + (born leaf) - (dead leaf) per branch under proposal: one leaf's values instead of every leaf's
+        double acc = 0.0;
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
             const int i0 = ch * 64 * NPT;
@@ -479,12 +572,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                         }
                     } else {
                         const double w = 2 * M_PI * bb;
-                        if (rot) {
-                            sine_points(a, w, c, s_rot[wv][b][0][0], s_rot[wv][b][1][0], ti, tmk[ch], sg);
-                        } else {
 #pragma unroll
-                            for (int k = 0; k < NPT; ++k) tmk[ch][k] += sg * (a * sin(w * ti[k] + c));
-                        }
+                        for (int k = 0; k < NPT; ++k) tmk[ch][k] += sg * (a * sin(w * ti[k] + c));
                     }
                 }
 #pragma unroll
@@ -511,17 +600,6 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         // formed once per chunk instead of once per point (the FP64 division was a third of the work per template
         // point).  Per point the leaves are still summed branch by branch in ascending slot order, and the lane's points in
         // ascending order, like the reference's NumPy sums over the leaf and the data axes.
-        if (rot) {                             // every sine leaf's rotation by 64 grid steps, a lane per leaf, once for all chunks
-            for (int b = 0; b < M.nb; ++b) {
-                if (M.kind[b] == RJ_KIND_PULSE) continue;
-                if (lane < M.nl[b]) {
-                    double sd, cd;
-                    sincos((2 * M_PI * q[M.off[b] + lane * RJ_ND + 1]) * M.t_step64, &sd, &cd);
-                    s_rot[wv][b][0][lane] = sd; s_rot[wv][b][1][lane] = cd;
-                }
-            }
-            RJ_LDS_SYNC();
-        }
         for (int i0 = 0; i0 < M.ndata; i0 += 64 * NPT) {
             double ti[NPT], tm[NPT];
 #pragma unroll
@@ -549,12 +627,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                         }
                     } else {
                         const double w = 2 * M_PI * bb;
-                        if (rot) {
-                            sine_points(a, w, c, s_rot[wv][b][0][n], s_rot[wv][b][1][n], ti, sub, 1.0);
-                        } else {
 #pragma unroll
-                            for (int k = 0; k < NPT; ++k) sub[k] += a * sin(w * ti[k] + c);      // tests/test_eryn.py:67-69
-                        }
+                        for (int k = 0; k < NPT; ++k) sub[k] += a * sin(w * ti[k] + c);      // tests/test_eryn.py:67-69
                     }
                 }
 #pragma unroll
@@ -596,7 +670,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         for (int ch = 0; ch < MAXCH; ++ch)
 #pragma unroll
             for (int k = 0; k < NPT; ++k) {
-                const int i = ch * 64 * NPT + k * 64 + lane;
+                const int i = rot ? lane * RJ_PPL + ch * NPT + k : ch * 64 * NPT + k * 64 + lane;     // (the two forms' point of register [ch][k])
                 if (i < M.ndata) tmrow[i] = total_leaves > 0 ? tmk[ch][k] : 0.0;
             }
     };

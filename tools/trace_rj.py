@@ -31,3 +31,17 @@ tr = out.reshape(-1, 8)[:, :6].astype(np.int64); tr = tr[(tr[:, 0] > 0) & (tr[:,
 d = np.diff(tr, axis=1)
 print("waves traced", len(tr), "mode", mode, " phases: load, proposal, log-prior, likelihood, accept+update")
 print("mean", np.round(d.mean(0), 0), " median", np.median(d, axis=0), " lifetime mean", (tr[:, 5] - tr[:, 0]).mean())
+# (with a library built -DHENS_RJ_TRACE_STRIDE the traced waves are every 64th walker: quarters of the launch in dispatch order)
+q = len(tr) // 4
+for k in range(4):
+    dd = d[k * q:(k + 1) * q]
+    print(f"  quarter {k}: phases mean", np.round(dd.mean(0), 0), " lifetime mean", round(float((tr[k * q:(k + 1) * q, 5] - tr[k * q:(k + 1) * q, 0]).mean())), "p90", round(float(np.percentile(tr[k * q:(k + 1) * q, 5] - tr[k * q:(k + 1) * q, 0], 90))))
+if "raw" in sys.argv:
+    for k in (0, 1, 2, 63, 64, 65, 127, 128, 129, 130, 200, 255):
+        print(k, d[k], tr[k, 0] - tr[:, 0].min())
+if "rungs" in sys.argv:          # per rung: 32 traced waves each (stride build); start offsets are only comparable within an XCD
+    per = len(tr) // T
+    for r in range(T):
+        sl = slice(r * per, (r + 1) * per)
+        st = tr[sl, 0] - tr[:, 0].min()
+        print(f"  rung {r}: phases", np.round(d[sl].mean(0)), "lifetime", round(float((tr[sl, 5] - tr[sl, 0]).mean())), "start offset min/med/max", int(st.min()), int(np.median(st)), int(st.max()), "end max", int((tr[sl, 5] - tr[:, 0].min()).max()))
