@@ -183,6 +183,7 @@ struct hens_ctx_impl {
     double* rj_step = nullptr; double* rj_u = nullptr; double* rj_birth = nullptr;   // parity staging
     int8_t* rj_change = nullptr; int32_t* rj_leaf = nullptr; uint8_t* rj_keep = nullptr;
     int32_t* rj_st_own = nullptr; int32_t* rj_st_cw = nullptr; double* rj_uzz = nullptr;   // stretch half-step on leaf-packing records
+    double* rj_ctab = nullptr; int32_t* rj_cbn = nullptr;   // RjArgs::ctab / cbn: what a lane needs about its record coordinate (rj_push_ctab)
     uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
     double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
     int64_t rj_tm_ndata = 0;
@@ -1556,6 +1557,30 @@ bool iteration_is_mh(const hens_ctx_impl* c) {
 }
 
 // ---- reversible-jump leaf packing ---------------------------------------------------------------------------------------
+// RjArgs::ctab / cbn from the model (hens_rj_set_model, hens_rj_set_mh_scale): per record coordinate its box, step scale, the
+// branch's leaf log-density and (branch, leaf slot, dimension, leaf kind)
+int rj_push_ctab(hens_ctx_impl* c) {
+    const RjModel& M = c->rj;
+    std::vector<double> tab(4 * RJ_MAX_RW, 0.0);
+    std::vector<int32_t> bn(RJ_MAX_RW, 0);
+    for (int b = 0; b < M.nb; ++b)
+        for (int n = 0; n < M.nl[b]; ++n)
+            for (int d = 0; d < RJ_ND; ++d) {
+                const int i = M.off[b] + n * RJ_ND + d;
+                tab[RJ_CTAB_LO + i] = M.lo[b][d]; tab[RJ_CTAB_HI + i] = M.hi[b][d];
+                tab[RJ_CTAB_SCALE + i] = M.mh_scale[b][d]; tab[RJ_CTAB_LOGP + i] = M.leaf_logp[b];
+                bn[i] = b | (n << 4) | (d << 10) | (M.kind[b] << 12) | ((M.off[b] / RJ_ND + n) << 16);
+            }
+    int r;
+    if (!c->rj_ctab) {
+        if ((r = dalloc(c, &c->rj_ctab, tab.size()))) return r;
+        if ((r = dalloc(c, &c->rj_cbn, bn.size()))) return r;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->rj_ctab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_cbn, bn.data(), bn.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (the vectors go out of scope)
+    return HENS_OK;
+}
 // tm_mode: -1 no resident templates (parity API), else RjArgs::tm_mode
 int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const int8_t* change, const int32_t* leaf,
               const double* birth, const double* u_acc, uint8_t* keep, int tm_mode = -1) {
@@ -1571,6 +1596,7 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     if (mode == RJ_MODE_BD && c->rj_schedule == 1 && branch != c->rj.nb - 1) a.accepted = nullptr;
     a.keep_out = keep;
     a.tdata = c->rj_t; a.ydata = c->rj_y;
+    a.ctab = c->rj_ctab; a.cbn = c->rj_cbn;
     a.step = step; a.change = change; a.leaf = leaf; a.birth = birth; a.u_acc = u_acc;
     a.flags = c->flags;
     a.M = c->rj;
@@ -2906,6 +2932,7 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
     if (off + nbranches > c->D) return fail(c, HENS_ERR_INVALID, "record width ndim = %d cannot hold %d coordinates + %d masks", c->D, off, nbranches);
     c->rj = M;
     int r;
+    if ((r = rj_push_ctab(c))) return r;
     if (!c->rj_t) {
         if ((r = dalloc(c, &c->rj_t, (size_t)ndata))) return r;
         if ((r = dalloc(c, &c->rj_y, (size_t)ndata))) return r;
@@ -2935,7 +2962,8 @@ int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale) {
     for (int b = 0; b < c->rj.nb; ++b)
         for (int d = 0; d < RJ_ND; ++d) c->rj.mh_scale[b][d] = scale[b * RJ_ND + d];
     c->rj_have_scale = true;
-    return HENS_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    return rj_push_ctab(c);
 }
 
 int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out) {

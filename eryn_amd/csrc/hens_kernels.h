@@ -176,9 +176,7 @@ __device__ __forceinline__ PlaceDraw stretch_draws_at(uint64_t seed, uint64_t it
 
 // One Box-Muller pair of standard normals for coordinates (2 pr, 2 pr + 1) of walker `wid` (= rung * W + walker)
 // in iteration `it`: the draw of the Gaussian MH move (k_mh_draw and the inline MODE_MH path share it).
-__device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t wid, uint32_t pr) {
-    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_NORMAL | (pr << 8)};
-    const u4 d = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+__device__ __forceinline__ double2 mh_normal_from(const u4 d) {       // the Box-Muller pair out of one Philox result
     const double u1 = 1.0 - u01(d.x, d.y);                            // (0, 1]
     const double u2 = u01(d.z, d.w);
     // The transcendental part in single precision on the hardware units (v_log_f32, v_sin_f32 / v_cos_f32 take the angle in
@@ -189,6 +187,11 @@ __device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, ui
     const float r = __builtin_sqrtf(-2.0f * lf);
     const float ang = (float)u2;
     return double2{(double)(r * __builtin_amdgcn_cosf(ang)), (double)(r * __builtin_amdgcn_sinf(ang))};
+}
+__device__ __forceinline__ uint32_t mh_normal_key(uint32_t pr) { return PURPOSE_MH_NORMAL | (pr << 8); }
+__device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t wid, uint32_t pr) {
+    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, mh_normal_key(pr)};
+    return mh_normal_from(philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32)));
 }
 __device__ __forceinline__ double mh_uniform(uint64_t seed, uint64_t it, uint32_t wid) {         // mh.py:157
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_ACC};

@@ -24,6 +24,12 @@
 namespace hens {
 
 constexpr int RJ_MAX_BRANCH = 4, RJ_ND = 3, RJ_MAX_RW = 128;
+#define RJ_CBN_B(v) ((v) & 15)
+#define RJ_CBN_N(v) (((v) >> 4) & 63)
+#define RJ_CBN_D(v) (((v) >> 10) & 3)
+#define RJ_CBN_KIND(v) (((v) >> 12) & 3)
+#define RJ_CBN_SLOT(v) ((v) >> 16)
+constexpr int RJ_CTAB_LO = 0, RJ_CTAB_HI = RJ_MAX_RW, RJ_CTAB_SCALE = 2 * RJ_MAX_RW, RJ_CTAB_LOGP = 3 * RJ_MAX_RW;     // RjArgs::ctab
 enum { RJ_KIND_PULSE = 0, RJ_KIND_SINE = 1 };
 enum { RJ_MODE_EVAL = 0, RJ_MODE_MH = 1, RJ_MODE_BD = 2, RJ_MODE_STRETCH = 3 };
 enum : uint32_t { PURPOSE_RJ_NORMAL = 20, PURPOSE_RJ_ACC = 21, PURPOSE_RJ_BD = 22, PURPOSE_RJ_BIRTH = 23, PURPOSE_RJ_BRANCH = 24 };
@@ -49,6 +55,11 @@ struct RjArgs {
     const double* birth;                // [Tl][W][3] coordinates of the born leaf (generate_dist.rvs)
     const double* u_acc;                // [Tl][W] accept uniforms; nullptr: Philox
     unsigned* flags;
+    // per record coordinate i (hens_rj_set_model / hens_rj_set_mh_scale keep it current): ctab[0][i] lo, [1][i] hi, [2][i] in-model step scale,
+    // [3][i] the branch's leaf log-density; cbn[i] = branch | slot in the branch << 4 | dimension << 10 | leaf kind << 12 | slot in the record << 16 (RJ_CBN_*) - what a LANE needs about its coordinate in one
+    // coalesced load each, instead of scalar loads from the model struct one dependent index at a time (round 5: the log-prior phase
+    // was 5 000 of a wave's 28 000 cycles, a chain of ~20 s_load + s_waitcnt)
+    const double* ctab; const int32_t* cbn;
     RjModel M;
     double fill;
     uint64_t iter, seed;
@@ -202,33 +213,41 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, int k) {
 
 // ---- the Philox draws of the production path (hens_rj_step), one definition for k_rj and for hens_rj_debug_draws ------------
 // in-model step of record coordinate i (a unit normal; the caller scales it): gaussian.py:265-268
+__device__ __forceinline__ uint32_t rj_normal_key(int i) { return mh_normal_key((uint32_t)i | 0x10000u); }
 __device__ __forceinline__ double rj_unit_normal(uint64_t seed, uint64_t it, uint32_t wid, int i) {
     return mh_normal_pair(seed, it, wid, (uint32_t)i | 0x10000u).x;        // one Box-Muller pair per coordinate, first value used
 }
+// (k_rj evaluates the draws below that share (iteration, walker) in ONE Philox call, a lane per key - the counter's last word is all
+//  that differs: 40 quarter-rate multiplies per call, and a walker's draws were up to five calls on all 64 lanes each)
+__device__ __forceinline__ u4 rj_philox(uint64_t seed, uint64_t it, uint32_t wid, uint32_t key) {
+    return philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, key}, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ uint32_t rj_bd_key(int branch) { return PURPOSE_RJ_BD | ((uint32_t)branch << 16); }
+__device__ __forceinline__ uint32_t rj_birth_key(int branch, int d) { return PURPOSE_RJ_BIRTH | ((uint32_t)d << 8) | ((uint32_t)branch << 16); }
+__device__ __forceinline__ uint32_t rj_acc_key(int mode, int branch) { return PURPOSE_RJ_ACC | ((uint32_t)mode << 8) | ((uint32_t)branch << 16); }
 // birth / death: .x bit 0 = the +1 / -1 coin (distgenrj.py:63-66), .y = selector of the leaf among the candidates (:97-112)
 // (the branch is part of every birth / death key: "iterate_branches" runs the move on every branch within one iteration)
 __device__ __forceinline__ u4 rj_bd_raw(uint64_t seed, uint64_t it, uint32_t wid, int branch) {
-    return philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BD | ((uint32_t)branch << 16)}, (uint32_t)seed,
-                         (uint32_t)(seed >> 32));
+    return rj_philox(seed, it, wid, rj_bd_key(branch));
 }
 __device__ __forceinline__ int rj_pick(uint32_t sel, int cnt) { return (int)__umulhi(sel, (uint32_t)cnt); }   // uniform on [0, cnt)
 // coordinate d of a leaf born from the (uniform) prior: prior.py:60-66
 __device__ __forceinline__ double rj_birth_coord(uint64_t seed, uint64_t it, uint32_t wid, int branch, int d, double lo, double hi) {
-    const u4 e = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_BIRTH | ((uint32_t)d << 8) | ((uint32_t)branch << 16)},
-                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    const u4 e = rj_philox(seed, it, wid, rj_birth_key(branch, d));
     return u01(e.x, e.y) * (hi - lo) + lo;
 }
 // accept uniform of the in-model (mode 1) / birth-death (mode 2) move: mh.py:157, rj.py:332
 __device__ __forceinline__ double rj_accept_uniform(uint64_t seed, uint64_t it, uint32_t wid, int mode, int branch) {
-    const u4 d = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_RJ_ACC | ((uint32_t)mode << 8) | ((uint32_t)branch << 16)},
-                               (uint32_t)seed, (uint32_t)(seed >> 32));
+    const u4 d = rj_philox(seed, it, wid, rj_acc_key(mode, branch));
     return u01(d.x, d.y);
 }
 
 #ifndef HENS_RJ_WAVES
-#define HENS_RJ_WAVES 4
+#define HENS_RJ_WAVES 1
 #endif
-constexpr int RJ_WAVES = HENS_RJ_WAVES;        // walkers per workgroup
+// walkers per workgroup: nothing in k_rj synchronises across waves, and a one-wave workgroup gives its slot back the moment its walker is
+// done (walkers differ in leaf count: config 4, same box: 8 waves 155, 4 waves 148.0, 2 waves 146.8, 1 wave 145.0 us per iteration)
+constexpr int RJ_WAVES = HENS_RJ_WAVES;
 
 // (four waves per SIMD: the kernel is bound by FP64 issue and hides its latencies with waves; with the sine rotation scheme the
 //  allocator would take 132 VGPRs - three waves - if it were not held to 128)
@@ -243,7 +262,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     constexpr bool HAVE_TM = TMM >= 0;
     __shared__ double s_cur[RJ_WAVES][RJ_MAX_RW];
     __shared__ double s_q[RJ_WAVES][RJ_MAX_RW];
-    __shared__ double s_leafv[RJ_WAVES][32];
+    __shared__ double s_leafv[RJ_WAVES][64];
     __shared__ double s_par[RJ_WAVES][2][64];               // per leaf slot: pulse 1 / (2 c^2), exp(-h^2 / c^2); sine (sin, cos) of the rotation by one grid step
     __shared__ double s_tab[64];                            // rj_exp_neg's table (every wave writes the same 64 values, then reads)
     s_tab[threadIdx.x & 63] = RJ_EXP_TAB[threadIdx.x & 63];
@@ -265,6 +284,12 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 #define RJ_TRACE(i) do { if (A.trace && gw < A.trace_n && lane == 0) A.trace[gw * 8 + (i)] = trace_stamp(); } while (0)
 #endif
     RJ_TRACE(0);
+    // this lane's record coordinate (RjArgs::ctab / cbn), requested with the record: a global round trip is 1 000 - 2 500 cycles
+    // under this kernel's load, and asked for where they are used (log-prior phase) these loads made it longer than the chain of
+    // scalar loads they replace (config 4: 131.6 against 128.4 us per iteration)
+    const int c_bn = A.cbn[lane];
+    const double c_lo = A.ctab[RJ_CTAB_LO + lane], c_hi = A.ctab[RJ_CTAB_HI + lane], c_lp = A.ctab[RJ_CTAB_LOGP + lane];
+    const double c_sc = (MODE == RJ_MODE_MH && !A.step) ? A.ctab[RJ_CTAB_SCALE + lane] : 0.0;
     double* cur = s_cur[wv];
     double* q = s_q[wv];
     double* leafv = s_leafv[wv];
@@ -276,12 +301,19 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     }
 #define RJ_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     RJ_LDS_SYNC();
-    uint32_t mask_old[RJ_MAX_BRANCH], mask[RJ_MAX_BRANCH];
-    for (int b = 0; b < M.nb; ++b) mask[b] = mask_old[b] = __builtin_amdgcn_readfirstlane((uint32_t)cur[M.ind_off + b]);   // (wave-uniform: scalar registers)
+    // the leaf masks, wave-uniform, as four named scalars each (an ARRAY indexed by a run-time branch goes to scratch memory as soon as
+    // one access is not unrollable: seen in the ISA, round 5): selects on the branch index instead
+    uint32_t mk0 = 0u, mk1 = 0u, mk2 = 0u, mk3 = 0u;
+    // (masks ANDed with compare results, not a chain of selects: the compiler turns a select chain on a per-lane index into a table in
+    //  scratch memory)
+    auto mask_of = [&](const int b) { return (mk0 & (0u - (uint32_t)(b == 0))) | (mk1 & (0u - (uint32_t)(b == 1))) | (mk2 & (0u - (uint32_t)(b == 2))) | (mk3 & (0u - (uint32_t)(b == 3))); };
+    auto mask_set = [&](const int b, const uint32_t v) { mk0 = b == 0 ? v : mk0; mk1 = b == 1 ? v : mk1; mk2 = b == 2 ? v : mk2; mk3 = b == 3 ? v : mk3; };   // (selects of VALUES: conditional stores become a store through a selected pointer, and the four live in memory)
+    for (int b = 0; b < M.nb; ++b) mask_set(b, __builtin_amdgcn_readfirstlane((uint32_t)cur[M.ind_off + b]));
+    const uint32_t mo0 = mk0, mo1 = mk1, mo2 = mk2, mo3 = mk3;          // (the masks in front of the proposal)
+    auto mask_old_of = [&](const int b) { return (mo0 & (0u - (uint32_t)(b == 0))) | (mo1 & (0u - (uint32_t)(b == 1))) | (mo2 & (0u - (uint32_t)(b == 2))) | (mo3 & (0u - (uint32_t)(b == 3))); };
     const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
 
-    constexpr bool FOLD = HAVE_TM && MODE != RJ_MODE_EVAL;     // (production launches of hens_rj_step)
-    if (FOLD && A.ad_fold && blockIdx.x == 0 && wv == 0) {
+    if (HAVE_TM && MODE != RJ_MODE_EVAL && A.ad_fold && blockIdx.x == 0 && wv == 0) {     // (production launches of hens_rj_step)
         __shared__ double s_ad[64];
         __shared__ unsigned s_adc[64];
         rj_adapt_wave(A.ad, lane, s_ad, s_adc);
@@ -292,24 +324,32 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     RJ_TRACE(1);
     // ---- proposal -----------------------------------------------------------------------------------------------------
     double factors = 0.0;
+    bool u_have = false;
+    double u_drawn = 0.5;                                    // the accept uniform where a proposal's Philox call draws it along (in-model, birth / death)
     int ch_sign[RJ_MAX_BRANCH], ch_leaf[RJ_MAX_BRANCH];      // birth / death: what changes in every branch (+1 born, -1 dies, 0 nothing)
     for (int B = 0; B < RJ_MAX_BRANCH; ++B) { ch_sign[B] = 0; ch_leaf[B] = 0; }
     if (MODE == RJ_MODE_MH) {
         // every active leaf of every branch moves: q = x + step (gaussian.py:96-104, 265-268; factors = 0)
-        for (int i = lane; i < M.ind_off; i += 64) {
-            int b = 0;
-            while (b + 1 < M.nb && i >= M.off[b + 1]) ++b;
-            const int n = (i - M.off[b]) / RJ_ND, d = (i - M.off[b]) - n * RJ_ND;
-            if ((mask[b] >> n) & 1u) {
+        // (Philox mode: the accept uniform is drawn by the lane behind the last coordinate, in the same call as the coordinates' normals)
+        const bool draw_u = !A.u_acc;
+        for (int i = lane; i < M.ind_off + (draw_u ? 1 : 0); i += 64) {
+            const bool coord = i < M.ind_off;
+            const int bn = i < 64 ? c_bn : A.cbn[coord ? i : 0];          // (i >= 64: records of more than 64 coordinates)
+            const bool moves = coord && ((mask_of(RJ_CBN_B(bn)) >> RJ_CBN_N(bn)) & 1u);
+            u4 dr = u4{0u, 0u, 0u, 0u};
+            if (!A.step || !coord) dr = rj_philox(A.seed, A.iter, wid, coord ? rj_normal_key(i) : rj_acc_key(RJ_MODE_MH, 0));
+            if (!coord) u_drawn = u01(dr.x, dr.y);
+            if (moves) {
                 double st;
                 if (A.step) {
                     st = A.step[(size_t)gw * M.ind_off + i];
                 } else {
-                    st = M.mh_scale[b][d] * rj_unit_normal(A.seed, A.iter, wid, i);
+                    st = (i < 64 ? c_sc : A.ctab[RJ_CTAB_SCALE + i]) * mh_normal_from(dr).x;
                 }
                 q[i] = cur[i] + st;
             }
         }
+        if (draw_u) { u_drawn = __shfl(u_drawn, M.ind_off & 63); u_have = true; }
     } else if (MODE == RJ_MODE_STRETCH) {
         // every leaf slot of every branch moves, active or not (the masks only decide what prior and likelihood see): branch b's
         // slots against branch b's complement walker, one stretch factor for the walker (stretch.py:128-145, 187-218); the Hastings
@@ -317,8 +357,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         const double zz = draw_zz(A.st_uzz[slot], A.st_a);                          // stretch.py:129-132
         const size_t TN = (size_t)A.Tl * A.st_ns;
         for (int i = lane; i < M.ind_off; i += 64) {
-            int b = 0;
-            while (b + 1 < M.nb && i >= M.off[b + 1]) ++b;
+            const int b = RJ_CBN_B(A.cbn[i]);
             const double c = A.pool[(size_t)A.loc[(size_t)tl * A.W + A.st_cw[(size_t)b * TN + slot]] * RW + i];
             q[i] = c - (c - cur[i]) * zz;                                           // stretch.py:141-145
         }
@@ -332,25 +371,32 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
       for (int B = 0; B < RJ_MAX_BRANCH; ++B) { ch_sign[B] = 0; ch_leaf[B] = 0; }
       for (int B = b_lo; B < b_hi; ++B) {
         const size_t bo = A.branch >= 0 ? 0 : (size_t)B * TW;        // teacher-forced arrays: [nbranches][Tl][W] when all branches move
-        const int nold = __builtin_popcount(mask_old[B]);
+        const int nold = __builtin_popcount(mask_old_of(B));
         int c, lf;
+        u4 dr_bd = u4{0u, 0u, 0u, 0u};
         if (A.change) {
             c = A.change[bo + gw];
             lf = A.leaf[bo + gw];
         } else {
-            const u4 d = rj_bd_raw(A.seed, A.iter, wid, B);
-            c = (d.x & 1u) ? +1 : -1;                                 // distgenrj.py:63-66
+            // one Philox call for everything the walker draws for this branch: lane 0 the coin and the leaf selector, lanes 1 - 3 the
+            // born leaf's coordinates, lane 4 (first branch of the proposal) the accept uniform
+            const int accb = A.branch >= 0 ? A.branch : M.nb;
+            const uint32_t key = lane == 0 ? rj_bd_key(B) : (lane <= RJ_ND ? rj_birth_key(B, lane - 1) : rj_acc_key(RJ_MODE_BD, accb));
+            dr_bd = rj_philox(A.seed, A.iter, wid, key);
+            if (B == b_lo && !A.u_acc) { u_drawn = __shfl(u01(dr_bd.x, dr_bd.y), RJ_ND + 1); u_have = true; }
+            const uint32_t dx = __builtin_amdgcn_readfirstlane(dr_bd.x), dy = __builtin_amdgcn_readfirstlane(dr_bd.y);
+            c = (dx & 1u) ? +1 : -1;                                  // distgenrj.py:63-66
             if (M.nlmin[B] == M.nl[B]) c = 0;
             else if (nold == M.nlmin[B]) c = +1;                      // :69-73
             else if (nold == M.nl[B]) c = -1;
             const uint32_t full = M.nl[B] >= 32 ? 0xffffffffu : ((1u << M.nl[B]) - 1u);
-            const uint32_t pool_bits = c > 0 ? (~mask_old[B] & full) : mask_old[B];
+            const uint32_t pool_bits = c > 0 ? (~mask_old_of(B) & full) : mask_old_of(B);
             const int cnt = __builtin_popcount(pool_bits);
-            lf = cnt ? nth_set_bit(pool_bits, rj_pick(d.y, cnt)) : 0;                    // uniform over the candidates (:97-112)
+            lf = cnt ? nth_set_bit(pool_bits, rj_pick(dy, cnt)) : 0;                     // uniform over the candidates (:97-112)
         }
         ch_sign[B] = c; ch_leaf[B] = lf;
         if (c < 0) {                                                  // death: factor +log q(leaf) (:188-197)
-            mask[B] &= ~(1u << lf);
+            mask_set(B, mask_of(B) & ~(1u << lf));
             bool in = true;
             for (int d = 0; d < RJ_ND; ++d) {
                 const double v = cur[M.off[B] + lf * RJ_ND + d];
@@ -358,29 +404,36 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             }
             factors = factors + (in ? M.leaf_logp[B] : -INFINITY);
         } else if (c > 0) {                                           // birth from the prior: factor -log q(leaf) (:199-214)
-            mask[B] |= (1u << lf);
+            mask_set(B, mask_of(B) | (1u << lf));
             bool in = true;
-            for (int d = 0; d < RJ_ND; ++d) {
-                double v;
-                if (A.birth) {
-                    v = A.birth[(bo + (size_t)gw) * RJ_ND + d];
-                } else {
-                    v = rj_birth_coord(A.seed, A.iter, wid, B, d, M.lo[B][d], M.hi[B][d]);
+            if (A.birth) {
+                for (int d = 0; d < RJ_ND; ++d) {
+                    const double v = A.birth[(bo + (size_t)gw) * RJ_ND + d];
+                    in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
+                    if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
                 }
-                in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
-                if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
+            } else {                                                  // lane 1 + d holds coordinate d's draw (above): prior.py:60-66
+                const int d = lane >= 1 && lane <= RJ_ND ? lane - 1 : 0;
+                const int i = M.off[B] + d;                           // (a branch's box is the same for every leaf: leaf 0's coordinate d)
+                double lo, hi;
+                if (M.off[B] + RJ_ND <= 64) { lo = __shfl(c_lo, i); hi = __shfl(c_hi, i); }
+                else { lo = A.ctab[RJ_CTAB_LO + i]; hi = A.ctab[RJ_CTAB_HI + i]; }
+                const double v = u01(dr_bd.x, dr_bd.y) * (hi - lo) + lo;
+                const bool mine = lane >= 1 && lane <= RJ_ND;
+                in = __ballot(mine && !((v >= lo) && (v <= hi))) == 0ull;
+                if (mine) q[M.off[B] + lf * RJ_ND + d] = v;
             }
             factors = factors - (in ? M.leaf_logp[B] : -INFINITY);
         }
         if (!(M.nlmin[B] == M.nl[B] || M.nlmin[B] + 1 == M.nl[B])) {  // edge factors (rj.py:236-270)
-            const int nnew = __builtin_popcount(mask[B]);
+            const int nnew = __builtin_popcount(mask_of(B));
             const double lh = log(1 / 2.0);
             if (nold == M.nlmin[B]) edge += lh;
             if (nold == M.nl[B]) edge += lh;
             if (nnew == M.nlmin[B]) edge -= lh;
             if (nnew == M.nl[B]) edge -= lh;
         }
-        if (lane == 0) q[M.ind_off + B] = (double)mask[B];
+        if (lane == 0) q[M.ind_off + B] = (double)mask_of(B);
       }
       factors += edge;
     }
@@ -390,27 +443,48 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     // ---- log-prior over the leaf slots (ensemble.py:1189-1210): dead slots count 0.0, NumPy's sum order per branch ------
     double logp = 0.0;
     int total_leaves = 0;
-    for (int b = 0; b < M.nb; ++b) {
-        if (lane < M.nl[b]) {
-            double v = 0.0;
-            if ((mask[b] >> lane) & 1u) {
-                bool in = true;
-                for (int d = 0; d < RJ_ND; ++d) {
-                    const double x = q[M.off[b] + lane * RJ_ND + d];
-                    in = in && (x >= M.lo[b][d]) && (x <= M.hi[b][d]);
+    {
+        // a lane per COORDINATE tests its box (bounds out of RjArgs::ctab), a ballot collects the "outside" bits; a lane per leaf
+        // SLOT turns its three bits into the slot's term - 0.0 dead, the branch's constant log-density, -inf outside - and the
+        // terms are summed branch by branch out of LDS in NumPy's order
+        uint64_t outb[2];
+        int bn2[2];
+        double lp2[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = p * 64 + lane;
+            bool outside = false;
+            bn2[p] = 0; lp2[p] = 0.0;
+            if (i < M.ind_off) {                                           // (p = 1: records of more than 64 coordinates)
+                const int bn = p == 0 ? c_bn : A.cbn[i];
+                const double lo = p == 0 ? c_lo : A.ctab[RJ_CTAB_LO + i], hi = p == 0 ? c_hi : A.ctab[RJ_CTAB_HI + i];
+                bn2[p] = bn; lp2[p] = p == 0 ? c_lp : A.ctab[RJ_CTAB_LOGP + i];
+                if ((mask_of(RJ_CBN_B(bn)) >> RJ_CBN_N(bn)) & 1u) {
+                    const double x = q[i];
+                    outside = !((x >= lo) && (x <= hi));
                     if (!(fabs(x) < INFINITY)) atomicOr(A.flags, FLAG_NONFINITE_X);
                 }
-                v = in ? M.leaf_logp[b] : -INFINITY;
             }
-            leafv[lane] = v;
+            outb[p] = __ballot(outside);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = p * 64 + lane;
+            if (i < M.ind_off && RJ_CBN_D(bn2[p]) == 0) {                  // the lane of a slot's first coordinate: the slot's term
+                const uint64_t w0 = p == 0 ? outb[0] : outb[1], w1 = p == 0 ? outb[1] : 0ull;
+                const uint32_t o3 = (uint32_t)((w0 >> lane) | (lane > 61 ? w1 << (64 - lane) : 0ull)) & 7u;
+                const bool active = (mask_of(RJ_CBN_B(bn2[p])) >> RJ_CBN_N(bn2[p])) & 1u;
+                leafv[RJ_CBN_SLOT(bn2[p])] = active ? (o3 ? -INFINITY : lp2[p]) : 0.0;
+            }
         }
         RJ_LDS_SYNC();
-        logp = logp + numpy_sum(leafv, M.nl[b]);
-        RJ_LDS_SYNC();
-        total_leaves += __builtin_popcount(mask[b]);
+        for (int b = 0; b < M.nb; ++b) {
+            logp = logp + numpy_sum(leafv + M.off[b] / RJ_ND, M.nl[b]);
+            total_leaves += __builtin_popcount(mask_of(b));
+        }
     }
     {   // Move.fix_logp_gibbs (move.py:368-402): the branches under proposal are all of them (in-model) or one (RJ)
-        const int here = (MODE == RJ_MODE_BD && A.branch >= 0) ? __builtin_popcount(mask[A.branch]) : total_leaves;
+        const int here = (MODE == RJ_MODE_BD && A.branch >= 0) ? __builtin_popcount(mask_of(A.branch)) : total_leaves;
         if (MODE != RJ_MODE_EVAL) {
             if (total_leaves != 0 && here == 0) logp = -INFINITY;
             if (total_leaves == 0 && here == 0) logp = 0.0;
@@ -419,6 +493,18 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
 
     RJ_TRACE(3);
     // ---- template likelihood: lanes over the data points ------------------------------------------------------------------
+    // What the accept test reads is requested HERE, a likelihood ahead of its use (a global round trip is 1 000 - 2 500 cycles under
+    // this kernel's load): the walker's old log-likelihood and log-prior, the flag of the folded adaptation, and - once the flag has
+    // been seen raised, behind the per-slot parameters' LDS round trip - the rung's beta.  (Round 4 measured L and P requested at the
+    // HEAD of the kernel: four more spilled registers, +3 us; here they are live across the likelihood only.)
+    constexpr bool FOLD = HAVE_TM && MODE != RJ_MODE_EVAL;     // (production launches of hens_rj_step)
+    double Lold = 0.0, Pold = 0.0, beta_e = 0.0;
+    uint32_t flag_e = 0u;
+    bool have_beta = false;
+    if (MODE != RJ_MODE_EVAL) {
+        Lold = A.L[gw]; Pold = A.P[gw];
+        if (FOLD && A.ad_fold && A.tempered) flag_e = __hip_atomic_load(A.ad_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     double logl;
     const bool evaluated = total_leaves > 0 && !(fabs(logp) == INFINITY);   // ensemble.py:1278-1306, 1486-1513
     // (residual / sigma as the reference divides it, tests/test_eryn.py:52-54 - unless sigma is a power of two: then the product with
@@ -449,20 +535,27 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         for (int k = 0; k < NPT; ++k) tmk[ch][k] = 0.0;
     if (rot && (evaluated || (MODE == RJ_MODE_EVAL && total_leaves > 0))) {
         const double h = M.t_step64 * (1.0 / 64.0);
-        {   // per leaf slot (a lane per slot, every branch at once; dead slots cost nothing and their values are never read)
-            const int s = lane < M.ind_off / RJ_ND ? lane : 0;
-            int b = 0;
-            while (b + 1 < M.nb && s * RJ_ND >= M.off[b + 1]) ++b;
-            const double p1 = q[s * RJ_ND + 1], p2 = q[s * RJ_ND + 2];
+        // per leaf slot (the lane of the slot's first coordinate, every branch at once; dead slots' values are never read)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int i = p * 64 + lane;
+            if (i >= M.ind_off) continue;
+            const int bn = p == 0 ? c_bn : A.cbn[i];
+            if (RJ_CBN_D(bn) != 0) continue;
+            const double p1 = q[i + 1], p2 = q[i + 2];
             double v0, v1;
-            if (M.kind[b] == RJ_KIND_PULSE) {
+            if (RJ_CBN_KIND(bn) == RJ_KIND_PULSE) {
                 v0 = 1.0 / (2 * (p2 * p2));
                 v1 = fabs(p2) >= h ? rj_exp_neg(-(h * h) * (2 * v0), s_tab) : -1.0;
             } else {
                 sincos((2 * M_PI * p1) * h, &v0, &v1);
             }
-            s_par[wv][0][lane] = v0; s_par[wv][1][lane] = v1;
-            RJ_LDS_SYNC();
+            s_par[wv][0][RJ_CBN_SLOT(bn)] = v0; s_par[wv][1][RJ_CBN_SLOT(bn)] = v1;
+        }
+        RJ_LDS_SYNC();
+        if (FOLD && A.ad_fold && A.tempered && flag_e == A.ad_serial) {      // (the ladder is published: this rung's beta, a likelihood ahead)
+            beta_e = __hip_atomic_load(A.betas + (A.rung_begin + tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            have_beta = true;
         }
         const int i0 = lane * RJ_PPL;
         const double t0 = A.tdata[i0 < M.ndata ? i0 : 0];
@@ -515,7 +608,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 double sub[RJ_PPL];
 #pragma unroll
                 for (int k = 0; k < RJ_PPL; ++k) sub[k] = 0.0;
-                uint32_t m = mask[b];
+                uint32_t m = mask_of(b);
                 while (m) {
                     const int n = __builtin_ctz(m);
                     m &= m - 1u;
@@ -612,7 +705,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 double sub[NPT];
 #pragma unroll
                 for (int k = 0; k < NPT; ++k) sub[k] = 0.0;
-                uint32_t m = mask[b];
+                uint32_t m = mask_of(b);
                 const bool pulse = M.kind[b] == RJ_KIND_PULSE;
                 while (m) {
                     const int n = __builtin_ctz(m);
@@ -685,18 +778,19 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         }
         return;
     }
-    // (measured: requested at the head of the kernel, with the record, these two cost the in-model launch four more spilled
-    //  registers and config 4 3 us per iteration)
-    const double Lold = A.L[gw], Pold = A.P[gw];
     double logP, prevP;
     if (A.tempered) {                                                  // tempering.py:304-306,343-349
         double beta;
         if (FOLD && A.ad_fold) {                 // the ladder of this launch: published by wave 0 (long ago, as a rule)
             // (relaxed agent-scope loads - they read past the caches that are not coherent across XCDs; an ACQUIRE here invalidates
             //  the XCD's L2 once per wave: measured, the launch took twice as long)
-            while (__hip_atomic_load(A.ad_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.ad_serial) __builtin_amdgcn_s_sleep(4);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            beta = __hip_atomic_load(A.betas + (A.rung_begin + tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (have_beta) {
+                beta = beta_e;
+            } else {
+                while (__hip_atomic_load(A.ad_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.ad_serial) __builtin_amdgcn_s_sleep(4);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                beta = __hip_atomic_load(A.betas + (A.rung_begin + tl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             beta = A.betas[A.rung_begin + tl];
         }
@@ -715,7 +809,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     if (A.u_acc) {
         lu = log(A.u_acc[MODE == RJ_MODE_STRETCH ? slot : gw]);
     } else {
-        lu = log(rj_accept_uniform(A.seed, A.iter, wid, MODE, MODE == RJ_MODE_BD ? (A.branch >= 0 ? A.branch : M.nb) : 0));
+        // (in-model, birth / death: drawn along with the proposal - same key, same value)
+        lu = log(u_have ? u_drawn : rj_accept_uniform(A.seed, A.iter, wid, MODE, MODE == RJ_MODE_BD ? (A.branch >= 0 ? A.branch : M.nb) : 0));
     }
     const bool keep = lnpdiff > lu;                                    // mh.py:157, rj.py:332
     if (keep) {                                                        // Move.update (move.py:472-703)
