@@ -3254,6 +3254,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         // workgroup's columns meet there, slot order - BEFORE the wait for that neighbour's columns: its bottom boundary for
         // these very columns needs nothing else from this rank.  The rows themselves must be complete first (phase E, system
         // scope), so on a pipeline rank phase E does not hide in the walk's shadow.
+        // (Round 5, measured and dropped: only the hottest rung's rows in front of the hand-off, the others in the walk's shadow as on
+        //  one GPU - nothing at D = 32 / 64, +2 us at D = 128: profiles/r05c_pipe_overlap.txt)
         store_accepted();
         const PipeBox me = pipe_box(A.box, TG, W, D);
         if (has_top) {
@@ -3280,8 +3282,14 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             }
         }
         if (walking && lane < CB) {
+            // (straight-line walks for the shard heights of the BASELINE configs and their neighbours: Tl or Tl + 1 rungs.  Round 5: a
+            //  16-rung rank walked through the run-time loop - 4 400 cycles for this phase against 1 540 on one GPU)
             if (TE == 9) walk(std::integral_constant<int, 9>{});
             else if (TE == 8) walk(std::integral_constant<int, 8>{});
+            else if (TE == 16) walk(std::integral_constant<int, 16>{});
+            else if (TE == 17) walk(std::integral_constant<int, 17>{});
+            else if (TE == 4) walk(std::integral_constant<int, 4>{});
+            else if (TE == 5) walk(std::integral_constant<int, 5>{});
             else if (TE == 1) smask[lane * MW] = 0;
             else walk(std::integral_constant<int, 0>{});
         }
