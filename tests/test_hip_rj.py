@@ -550,6 +550,19 @@ def test_rj_production_step_together_replayed_through_the_oracle(T, W, nl_max, n
     _replay_rj(T, W, nl_max, nl_min, ndata=60, iters=iters, seed=17, start_leaves=(2, 2), calls=(3, iters - 3), schedule="together")
 
 
+@pytest.mark.parametrize("T,W,nl_max,nl_min,iters,ndata,schedule", [
+    (3, 12, (4, 3), (0, 0), 8, 130, "separate_branches"), (3, 8, (4, 3), (0, 1), 8, 130, "iterate_branches"),
+    (3, 8, (4, 3), (0, 0), 8, 130, "together"), (2, 16, (12, 12), (0, 0), 6, 60, "separate_branches"),
+    (2, 16, (12, 12), (0, 0), 6, 130, "separate_branches"), (2, 16, (12, 11), (0, 0), 6, 200, "together")])
+def test_rj_production_step_uniform_grid_and_wide_records(T, W, nl_max, nl_min, iters, ndata, schedule):
+    """Round 5: the production kernels' uniform-grid likelihood (more than 64 data points on a linspace: a lane owns 8 consecutive
+    points, pulses by recurrence, sines by rotation; pulses narrower than the grid step - c < 2 / (ndata - 1) is inside the prior -
+    take the exp per point) under every schedule, birth / death by difference with several branches changing at once
+    ("together"), and records of more than 64 coordinates (2 x 12 leaves x 3 = 72: the second pass of the per-coordinate
+    phases) - replayed through the oracle like the small shapes above."""
+    _replay_rj(T, W, nl_max, nl_min, ndata=ndata, iters=iters, seed=19, start_leaves=(2, 2), calls=(3, iters - 3), schedule=schedule)
+
+
 def test_rj_production_step_replayed_through_the_oracle_config4():
     """BASELINE config 4 at full size (8 x 2048 walkers, 2 branches x 10 leaves, 500 data points): three iterations of
     hens_rj_step replayed."""

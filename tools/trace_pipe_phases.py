@@ -23,9 +23,11 @@ for which, label in ((1, "first launch (k_stretch_fast)"), (3, "second launch (k
             out = np.zeros(n, dtype=np.uint64); nout = C.c_int64(0)
             _lib.check(e.lib.hens_debug_trace(e.ctx, 0, _lib.ptr(out), n, C.byref(nout)), e.ctx)
             tr = out.reshape(-1, 8).astype(np.int64)
+            wg0 = tr[0].copy()
             tr = tr[(tr[:, 0] > 0) & (tr[:, 7] > 0)]
             acc.append(np.diff(tr, axis=1).mean(0))
             span = tr[:, 7].max() - tr[:, 0].min()
         d = np.mean(acc, axis=0)
-        print(f"{label:32s} {kind:6s} workgroups {len(tr):5d}  phases", " ".join(f"{v:7.0f}" for v in d), f" lifetime {d.sum():7.0f}  span(last) {span}", flush=True)
+        life = tr[:, 7] - tr[:, 0]
+        print(f"{label:32s} {kind:6s} workgroups {len(tr):5d}  phases", " ".join(f"{v:7.0f}" for v in d), f" lifetime {d.sum():7.0f}  max {life.max()}  p99 {int(np.percentile(life, 99))}  workgroup (0,0): phases", " ".join(str(int(v)) for v in np.diff(wg0)), f"lifetime {wg0[7] - wg0[0]}", flush=True)
         e.close()
