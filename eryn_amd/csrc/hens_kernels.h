@@ -176,22 +176,34 @@ __device__ __forceinline__ PlaceDraw stretch_draws_at(uint64_t seed, uint64_t it
 
 // One Box-Muller pair of standard normals for coordinates (2 pr, 2 pr + 1) of walker `wid` (= rung * W + walker)
 // in iteration `it`: the draw of the Gaussian MH move (k_mh_draw and the inline MODE_MH path share it).
-__device__ __forceinline__ double2 mh_normal_from(const u4 d) {       // the Box-Muller pair out of one Philox result
-    const double u1 = 1.0 - u01(d.x, d.y);                            // (0, 1]
-    const double u2 = u01(d.z, d.w);
-    // The transcendental part in single precision on the hardware units (v_log_f32, v_sin_f32 / v_cos_f32 take the angle in
-    // revolutions): a proposal step needs the N(0, 1) shape, not 53 bits - the FP64 log / sqrt / sincospi made a launch
-    // that draws its normals in place ALU-bound (config 5: 33.5 M normals per launch).  The proposal stays symmetric
-    // (cos / sin of a uniform angle), which is all detailed balance asks of it.
-    const float lf = __builtin_amdgcn_logf((float)u1) * 0.69314718056f;       // ln u1 <= 0
+// A Box-Muller pair of standard normals out of TWO 32-bit words (round 5; rounds 3-4 spent a whole Philox result - two 53-bit
+// uniforms - on a pair whose transcendental part runs in single precision anyway).  The transcendental part on the hardware units
+// (v_log_f32, v_sin_f32 / v_cos_f32 take the angle in revolutions): a proposal step needs the N(0, 1) shape, not 53 bits - FP64
+// log / sqrt / sincospi made a launch that draws its normals in place ALU-bound.  The radius' uniform is (a + 1) / 2^32 in (0, 1]
+// (largest radius sqrt(64 ln 2) = 6.66); the proposal stays symmetric (cos / sin of a uniform angle), which is all detailed
+// balance asks of it.
+__device__ __forceinline__ double2 mh_normal_from32(const uint32_t a, const uint32_t b) {
+    const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;             // (0, 1]
+    const float ang = (float)b * 2.3283064365386963e-10f;                     // revolutions
+    const float lf = __builtin_amdgcn_logf(u1) * 0.69314718056f;              // ln u1 <= 0
     const float r = __builtin_sqrtf(-2.0f * lf);
-    const float ang = (float)u2;
     return double2{(double)(r * __builtin_amdgcn_cosf(ang)), (double)(r * __builtin_amdgcn_sinf(ang))};
 }
 __device__ __forceinline__ uint32_t mh_normal_key(uint32_t pr) { return PURPOSE_MH_NORMAL | (pr << 8); }
-__device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t wid, uint32_t pr) {
-    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, mh_normal_key(pr)};
-    return mh_normal_from(philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32)));
+// FOUR normals per Philox call: the pairs (2 pr, 2 pr + 1) of TWO walkers of a rung, g rows apart (w with bit g clear: words x, y;
+// bit g set: z, w) - the two rows one lane of the in-place MH launch owns in adjacent passes (g = its rows per pass, mh_pair_rows(D);
+// g = 0: every walker its own call, words x, y).  The launch was bound by the 40 quarter-rate multiplies of a call per pair
+// (config 5 on one GPU: 147 us for 268 MB of rows); k_mh_draw and hens_debug_draws evaluate the same function of (walker, pair).
+__device__ __forceinline__ u4 mh_normal_quad(uint64_t seed, uint64_t it, uint32_t rung, uint32_t W, uint32_t w_low, uint32_t pr) {
+    const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), rung * W + w_low, mh_normal_key(pr)};
+    return philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ double2 mh_normal_pair(uint64_t seed, uint64_t it, uint32_t rung, uint32_t W, uint32_t w, uint32_t pr, uint32_t g) {
+    const u4 d = mh_normal_quad(seed, it, rung, W, w & ~g, pr);
+    return (w & g) ? mh_normal_from32(d.z, d.w) : mh_normal_from32(d.x, d.y);
+}
+__host__ __device__ constexpr int mh_pair_rows(int D) {        // rows per pass of k_stretch_fast<D> (RPP) where a lane owns two rows or more
+    return D == 128 ? 8 : (D == 64 ? 16 : ((D == 32 || D == 16) ? 32 : 0));
 }
 __device__ __forceinline__ double mh_uniform(uint64_t seed, uint64_t it, uint32_t wid) {         // mh.py:157
     const u4 ctr{(uint32_t)it, (uint32_t)(it >> 32), wid, PURPOSE_MH_ACC};
@@ -1855,18 +1867,23 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     //  occupancy is not the explanation; the cause of the 0.9 us has not been isolated.  Rosenbrock was not measured with this
     //  change alone.)
     constexpr int HP = (DT >= 64 && !PIPE) ? NPASS / 2 : NPASS;
+    constexpr int MHG = NPASS >= 2 ? RPP : 0;             // (MH normals: rows of the tile that share a Philox call, mh_normal_quad)
+    static_assert(MHG == mh_pair_rows(DT) && (HP % 2 == 0 || NPASS == 1), "k_mh_draw pairs the rows this launch does");
+    u4 mh_d{0u, 0u, 0u, 0u};
 #define HENS_GATHER_PASS(p) \
         const int r = p * RPP + rsub;                                                                                                                          \
         rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;                                                                                             \
         sreg[p] = double2{0.0, 0.0};                                                                                                                           \
         creg[p] = double2{0.0, 0.0};                                                                                                                           \
+        if (MH && !A.mh_step && (!MHG || (p & 1) == 0))   /* the call of this row and (MHG) of the lane's next pass' row, MHG rows on */                       \
+            mh_d = mh_normal_quad(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl), (uint32_t)W, (uint32_t)(k0 + r), (uint32_t)jl);                         \
         if (rv[p]) {                                                                                                                                           \
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);                 \
             if (MH) {                                                                                                                                          \
                 if (A.mh_step) {                                                                                                                               \
                     creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);                                           \
-                } else { /* one Box-Muller pair per lane: exactly the two coordinates it owns */                                                               \
-                    const double2 z = mh_normal_pair(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl) * (uint32_t)W + (uint32_t)(k0 + r), (uint32_t)jl);    \
+                } else { /* a Box-Muller pair per lane and row - the two coordinates it owns; one Philox call per TWO rows (mh_normal_quad) */                 \
+                    const double2 z = (MHG && (p & 1)) ? mh_normal_from32(mh_d.z, mh_d.w) : mh_normal_from32(mh_d.x, mh_d.y);                                 \
                     const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];                                                                \
                     const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];                                                                       \
                     creg[p] = double2{s0 * z.x, s1 * z.y};                                                                                                     \
@@ -2287,7 +2304,7 @@ inline __global__ __launch_bounds__(256) void k_mh_draw(const MhDrawArgs A) {
     for (int i = threadIdx.x; i < 64 * npair; i += blockDim.x) {
         const int wl = i / npair, pr = i - wl * npair, w = w0 + wl;
         if (w >= W) continue;
-        const double2 n2 = mh_normal_pair(A.seed, A.iter, rung * (uint32_t)W + (uint32_t)w, (uint32_t)pr);
+        const double2 n2 = mh_normal_pair(A.seed, A.iter, rung, (uint32_t)W, (uint32_t)w, (uint32_t)pr, (uint32_t)mh_pair_rows(D));
         z[wl * ZS + 2 * pr] = n2.x;
         if (2 * pr + 1 < D) z[wl * ZS + 2 * pr + 1] = n2.y;
     }

@@ -215,7 +215,8 @@ __device__ __forceinline__ int nth_set_bit(uint32_t m, int k) {
 // in-model step of record coordinate i (a unit normal; the caller scales it): gaussian.py:265-268
 __device__ __forceinline__ uint32_t rj_normal_key(int i) { return mh_normal_key((uint32_t)i | 0x10000u); }
 __device__ __forceinline__ double rj_unit_normal(uint64_t seed, uint64_t it, uint32_t wid, int i) {
-    return mh_normal_pair(seed, it, wid, (uint32_t)i | 0x10000u).x;        // one Box-Muller pair per coordinate, first value used
+    const u4 d = philox4x32_10(u4{(uint32_t)it, (uint32_t)(it >> 32), wid, rj_normal_key(i)}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return mh_normal_from32(d.x, d.y).x;                                   // one Box-Muller pair per coordinate, first value used
 }
 // (k_rj evaluates the draws below that share (iteration, walker) in ONE Philox call, a lane per key - the counter's last word is all
 //  that differs: 40 quarter-rate multiplies per call, and a walker's draws were up to five calls on all 64 lanes each)
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 if (A.step) {
                     st = A.step[(size_t)gw * M.ind_off + i];
                 } else {
-                    st = (i < 64 ? c_sc : A.ctab[RJ_CTAB_SCALE + i]) * mh_normal_from(dr).x;
+                    st = (i < 64 ? c_sc : A.ctab[RJ_CTAB_SCALE + i]) * mh_normal_from32(dr.x, dr.y).x;
                 }
                 q[i] = cur[i] + st;
             }

@@ -543,7 +543,7 @@ def test_rj_production_step_iterate_branches_replayed_through_the_oracle(T, W, n
                schedule="iterate_branches")
 
 
-@pytest.mark.parametrize("T,W,nl_max,nl_min,iters", [(3, 8, (4, 3), (0, 0), 8), (2, 64, (2, 3), (0, 1), 6)])
+@pytest.mark.parametrize("T,W,nl_max,nl_min,iters", [(3, 8, (4, 3), (0, 0), 8), (2, 64, (2, 3), (0, 1), 14)])
 def test_rj_production_step_together_replayed_through_the_oracle(T, W, nl_max, nl_min, iters):
     """rj_moves="together" (hens_rj_set_schedule 2): one proposal changes a leaf in every branch of a walker - per-branch coins,
     leaf choices and births, the factors summed, one accept uniform."""
