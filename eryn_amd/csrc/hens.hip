@@ -2590,6 +2590,12 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 if (prof) { hipEvent_t e1 = new_event(c); evs.push_back(e1); (void)hipEventRecord(e1, c->stream); ev_kind.push_back(1); }
             } else if (pt) {
                 PtArgs p = pt_args(c, nullptr, false);
+                // Round 5: the stand-alone cascade of hens_step (MH iterations of a mix, the copying launches) accumulates its swap
+                // counts like the fused launch does, into a handful of rows the NEXT launch's folded adaptation sums - a row per
+                // workgroup (512 x 31 counts at config 5) could not be folded and cost a k_adapt launch of 11.5 us per MH iteration
+                static const bool acc_off = getenv("HENS_PT_NO_ACC") != nullptr;             // A/B knob
+                const bool use_acc = !acc_off && fast_path(c) && c->T <= 128;
+                if (use_acc) { p.swap_part = acc_take(c); p.acc_rows = 8 * acc_row_groups(c->T); acc_commit(c); }
                 if (prof) {
                     hipEvent_t e0 = new_event(c), e1 = new_event(c);
                     evs.push_back(e0);
@@ -2604,7 +2610,8 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                 c->cur ^= 1;
                 c->adapt_pending = true;
                 c->adapt_pending_adaptive = c->cfg.adaptive != 0;
-                c->adapt_src = nullptr;
+                c->adapt_src = use_acc ? p.swap_part : nullptr;
+                if (use_acc) c->adapt_nblocks = p.acc_rows;
             }
             c->iter += 1;
         }

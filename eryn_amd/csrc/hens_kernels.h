@@ -2628,6 +2628,7 @@ struct PtArgs {
     uint64_t seed;
     unsigned long long* trace;  // debug: per-workgroup phase timestamps, or nullptr
     int32_t T, W, Tl, rung_begin, idx_bits;
+    int32_t acc_rows;           // 0: swap_part is [nblocks][T-1], a row per workgroup; else a power of two: [acc_rows][T-1], accumulated (clean on entry)
 };
 
 constexpr int PT_COLS = 16;      // columns per workgroup: W/16 workgroups keep every CU busy at W = 4096
@@ -2771,7 +2772,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     for (int i = 1 + tid; i < T; i += PT_THREADS) {               // pair (i, i-1) -> swap_part index i-1
         unsigned n = 0;
         for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += bit(cc, i) ? 1u : 0u;
-        A.swap_part[(size_t)blockIdx.x * (T - 1) + (i - 1)] = n;
+        // (acc_rows: accumulated with atomics into a handful of rows that the next launch's folded adaptation sums - like the fused
+        //  launch's counts; else one row per workgroup, for the stand-alone adaptation)
+        if (A.acc_rows) { if (n) atomicAdd(&A.swap_part[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n); }
+        else A.swap_part[(size_t)blockIdx.x * (T - 1) + (i - 1)] = n;
     }
     PT_TRACE(6);
 #undef PT_TRACE
