@@ -1620,8 +1620,8 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     if (mode == RJ_MODE_STRETCH) {                    // (a half-step: one wavefront per position of the moving half, c->rj_st_ns of them per rung)
         a.st_own = c->rj_st_own; a.st_cw = c->rj_st_cw; a.st_uzz = c->rj_uzz; a.st_a = c->cfg.a; a.st_ns = c->rj_st_ns;
     }
-    const int64_t n = (int64_t)c->Tl * (mode == RJ_MODE_STRETCH ? c->rj_st_ns : c->W);
-    const dim3 grid((unsigned)((n + RJ_WAVES - 1) / RJ_WAVES)), block(RJ_WAVES * 64);
+    const int npr = mode == RJ_MODE_STRETCH ? c->rj_st_ns : c->W;     // waves per rung
+    const dim3 grid((unsigned)((npr + RJ_WAVES - 1) / RJ_WAVES), (unsigned)c->Tl), block(RJ_WAVES * 64);
     const int tmm = a.tm ? a.tm_mode : -1;            // the instantiation: (mode, template scheme), see k_rj
 #define RJ_CASE(MODE_, TMM_) if (mode == MODE_ && tmm == TMM_) hipLaunchKernelGGL((k_rj<MODE_, TMM_>), grid, block, 0, c->stream, a); else
     RJ_CASE(RJ_MODE_EVAL, -1) RJ_CASE(RJ_MODE_EVAL, 0) RJ_CASE(RJ_MODE_EVAL, 2)

@@ -269,14 +269,14 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     s_tab[threadIdx.x & 63] = RJ_EXP_TAB[threadIdx.x & 63];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef HENS_RJ_REVERSE
-    const int64_t slot = (int64_t)(gridDim.x - 1 - blockIdx.x) * RJ_WAVES + wv;
-#else
-    const int64_t slot = (int64_t)blockIdx.x * RJ_WAVES + wv;     // one wavefront per walker - stretch half-step: per position of the half
-#endif
-    if (slot >= (int64_t)A.Tl * (MODE == RJ_MODE_STRETCH ? A.st_ns : A.W)) return;   // whole wavefront (nothing below synchronises across waves)
+    // grid: x over the walkers (stretch half-step: the positions of the moving half) of a rung, y the rung - no 64-bit division of a
+    // linear index by the walkers per rung at the head of every wave (~150 scalar instructions)
+    const int NPR = MODE == RJ_MODE_STRETCH ? A.st_ns : A.W;
+    const int idx = (int)blockIdx.x * RJ_WAVES + wv;
+    if (idx >= NPR) return;                          // whole wavefront (nothing below synchronises across waves)
+    const int tl = (int)blockIdx.y;
+    const int64_t slot = (int64_t)tl * NPR + idx;    // one wavefront per walker - stretch half-step: per position of the half
     const RjModel& M = A.M;
-    const int tl = (int)(slot / (MODE == RJ_MODE_STRETCH ? A.st_ns : A.W));
     const int64_t gw = MODE == RJ_MODE_STRETCH ? (int64_t)tl * A.W + A.st_own[slot] : slot;
     const int RW = M.RW;
 #ifdef HENS_RJ_TRACE_STRIDE        // DEV: every 64th walker instead of the first ones (all rounds of the launch)
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     auto mask_old_of = [&](const int b) { return (mo0 & (0u - (uint32_t)(b == 0))) | (mo1 & (0u - (uint32_t)(b == 1))) | (mo2 & (0u - (uint32_t)(b == 2))) | (mo3 & (0u - (uint32_t)(b == 3))); };
     const uint32_t wid = (uint32_t)(A.rung_begin + tl) * (uint32_t)A.W + (uint32_t)(gw - (int64_t)tl * A.W);
 
-    if (HAVE_TM && MODE != RJ_MODE_EVAL && A.ad_fold && blockIdx.x == 0 && wv == 0) {     // (production launches of hens_rj_step)
+    if (HAVE_TM && MODE != RJ_MODE_EVAL && A.ad_fold && blockIdx.x == 0 && blockIdx.y == 0 && wv == 0) {     // (production launches of hens_rj_step)
         __shared__ double s_ad[64];
         __shared__ unsigned s_adc[64];
         rj_adapt_wave(A.ad, lane, s_ad, s_adc);
