@@ -254,7 +254,10 @@ constexpr int RJ_WAVES = HENS_RJ_WAVES;
 //  allocator would take 132 VGPRs - three waves - if it were not held to 128)
 // waves per SIMD the allocator is held to (measured at config 4: the in-model launch at three waves 165.8 us per iteration against
 // 157.0 at four; the birth / death launch by difference - 99 VGPRs - held to five 174.7)
-constexpr int RJ_WPE(int, int) { return 4; }
+#ifndef HENS_RJ_WPE_BD
+#define HENS_RJ_WPE_BD 4
+#endif
+constexpr int RJ_WPE(int mode, int tmm) { return (mode == RJ_MODE_BD && tmm == 1) ? HENS_RJ_WPE_BD : 4; }
 // MODE, TMM: RjArgs::mode and the resident-template scheme (-1: RjArgs::tm == nullptr, else RjArgs::tm_mode) as compile-time
 // parameters - one instantiation per launch kind (hens.hip: rj_launch), so that the birth / death launch by difference does not
 // carry the registers of the full evaluation's leaf loops, nor the in-model launch those of the birth / death proposal.
