@@ -1666,7 +1666,7 @@ void rj_cascade(hens_ctx_impl* c, uint64_t key, bool adapt) {
     flush_adapt(c);
     PtArgs p = pt_args(c, nullptr, false);
     p.iter = key;
-    hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(c->T), c->stream, p);
+    hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(pt_threads(c->T)), pt_lds_bytes(c->T), c->stream, p);
     c->cur ^= 1;
     c->adapt_pending = true;
     c->adapt_pending_adaptive = adapt && c->cfg.adaptive != 0;      // rj.py:381-382: swaps without adaptation after the RJ move
@@ -2438,7 +2438,7 @@ int hens_pt_sweep(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1perm, co
     PtArgs p = pt_args(c, colslot, false);
     p.colu = c->colu;
     p.selcol = c->selcol;
-    hipLaunchKernelGGL(k_pt_cascade<false>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
+    hipLaunchKernelGGL(k_pt_cascade<false>, dim3(pt_blocks(c)), dim3(pt_threads(c->T)), pt_lds_bytes(T), c->stream, p);
     c->adapt_pending = true;
     c->adapt_pending_adaptive = adapt && c->cfg.adaptive;
     flush_adapt(c);
@@ -2601,10 +2601,10 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
                     evs.push_back(e0);
                     evs.push_back(e1);
                     ev_kind.push_back(1);
-                    hipExtLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), (uint32_t)pt_lds_bytes(T),
+                    hipExtLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(pt_threads(c->T)), (uint32_t)pt_lds_bytes(T),
                                           c->stream, e0, e1, 0, p);
                 } else {
-                    hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T),
+                    hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(pt_threads(c->T)), pt_lds_bytes(T),
                                        c->stream, p);
                 }
                 c->cur ^= 1;
@@ -3359,11 +3359,11 @@ int hens_pt_plan_sharded(hens_ctx* ctx, const int64_t* iperm, const int64_t* i1p
         hipLaunchKernelGGL(k_pt_chain, dim3((W + 255) / 256), dim3(256), 0, c->stream, c->d_iperm, c->d_i1perm,
                            c->d_inv, c->d_uswap, colslot, c->colk, c->colu, T, W);
         p.colu = c->colu;
-        hipLaunchKernelGGL(k_pt_cascade<false>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
+        hipLaunchKernelGGL(k_pt_cascade<false>, dim3(pt_blocks(c)), dim3(pt_threads(c->T)), pt_lds_bytes(T), c->stream, p);
         hipLaunchKernelGGL(k_pt_sel_to_korder, dim3(grid_for(PW)), dim3(256), 0, c->stream, c->selcol, c->colk,
                            c->selk, T - 1, W);
     } else {
-        hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(PT_THREADS), pt_lds_bytes(T), c->stream, p);
+        hipLaunchKernelGGL(k_pt_cascade<true>, dim3(pt_blocks(c)), dim3(pt_threads(c->T)), pt_lds_bytes(T), c->stream, p);
     }
     c->adapt_pending = true;
     c->adapt_pending_adaptive = adapt && c->cfg.adaptive;

@@ -2633,6 +2633,7 @@ struct PtArgs {
 
 constexpr int PT_COLS = 16;      // columns per workgroup: W/16 workgroups keep every CU busy at W = 4096
 constexpr int PT_THREADS = 256;
+__host__ __device__ inline int pt_threads(int T) { const int ne = (T * 16 + 63) & ~63; return ne < 256 ? 256 : (ne > 1024 ? 1024 : ne); }   // k_pt_cascade: a thread per element
 
 // LDS per (rung, column) element: L f64, log-uniform f64, P f64, loc i32, slot i32; + betas[T] + swap bitmasks
 __host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_COLS * (8 + 8 + 8 + 4 + 4) + (size_t)T * 8 + (size_t)PT_COLS * ((T + 31) / 32) * 4; }
@@ -2643,7 +2644,7 @@ __host__ __device__ inline size_t pt_lds_layout(int T) { return (size_t)T * PT_C
 // and are reduced after the kernel boundary (a last-block ticket + release fence inside this
 // kernel cost more than the cascade itself).
 template <bool PHILOX>
-__global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
+__global__ __launch_bounds__(1024) void k_pt_cascade(const PtArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int T = A.T, W = A.W;
     const size_t NE = (size_t)T * PT_COLS;
@@ -2656,6 +2657,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     uint32_t* smask = reinterpret_cast<uint32_t*>(scol + NE);    // [PT_COLS][MW] swap bitmask per column (bit i = pair (i, i-1))
     const int MW = (T + 31) / 32;
     const int tid = threadIdx.x;
+    const int NTH = blockDim.x;                                  // pt_threads(T): a thread per element up to 1024 (round 5; 256 before)
     const int c0 = blockIdx.x * PT_COLS;
     const uint64_t it = A.iter;
 #define PT_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
@@ -2663,8 +2665,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
 
     // phase 1: column slots (Philox: computed in place from the rung's keys), then everything the
     // column needs - independent gathers, the log-uniform overlaps their latency
-    for (int t = tid; t < T; t += PT_THREADS) sbeta[t] = A.betas[t];
-    for (int e = tid; e < (int)NE; e += PT_THREADS) {
+    for (int t = tid; t < T; t += NTH) sbeta[t] = A.betas[t];
+    for (int e = tid; e < (int)NE; e += NTH) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
             const int slot = PHILOX ? pt_slot(A.seed, it, t, T, c, A.idx_bits, W) : A.colslot[(size_t)t * W + c];
@@ -2696,17 +2698,22 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     // phase 2: one lane per column walks hot -> cold.  Nothing is stored inside the loop (the swap
     // decisions go into a register bitmask), so the LDS reads of the next steps are issued ahead and
     // only the compare/select chain is serial.
-    if (tid < PT_COLS && c0 + tid < W) {
+    // (straight-line walks for the ladders of the BASELINE configs, as in k_split1_pt: round 5 - the run-time loop took 223 cycles
+    //  per pair at 32 rungs against ~100 straight-line)
+    auto walk = [&](auto tt) {
+        constexpr int TT = decltype(tt)::value;                      // 0: run-time ladder length
+        const int Tn = TT ? TT : T;
         const int cc = tid;
-        double cL = Lc[(size_t)(T - 1) * PT_COLS + cc];
+        double cL = Lc[(size_t)(Tn - 1) * PT_COLS + cc];
         uint32_t m = 0;
-        for (int i0 = T - 1; i0 >= 1; i0 -= 8) {                   // 8 steps per LDS round trip
+#pragma unroll
+        for (int i0 = Tn - 1; i0 >= 1; i0 -= 8) {                   // 8 steps per LDS round trip
             double Lb[8], lv[8], db[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int i = (i0 - q >= 1) ? i0 - q : 1;
                 Lb[q] = Lc[(size_t)(i - 1) * PT_COLS + cc];
-                lv[q] = lu[(size_t)(T - 1 - i) * PT_COLS + cc];
+                lv[q] = lu[(size_t)(Tn - 1 - i) * PT_COLS + cc];
                 db[q] = sbeta[i - 1] - sbeta[i];                                 // tempering.py:518-522
             }
 #pragma unroll
@@ -2724,6 +2731,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
                 }
             }
         }
+    };
+    if (tid < PT_COLS && c0 + tid < W) {
+        if (T == 8) walk(std::integral_constant<int, 8>{});
+        else if (T == 16) walk(std::integral_constant<int, 16>{});
+        else if (T == 32) walk(std::integral_constant<int, 32>{});
+        else walk(std::integral_constant<int, 0>{});
     }
     PT_TRACE(4);
     __syncthreads();
@@ -2734,7 +2747,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
     // carried walker settles there, and it started its fall at t + (number of consecutive swapped
     // pairs directly above).
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
-    for (int e = tid; e < (int)NE; e += PT_THREADS) {
+    for (int e = tid; e < (int)NE; e += NTH) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
         int st;
@@ -2769,7 +2782,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pt_cascade(const PtArgs A) {
         A.locnew[di] = locc[se];      // -1: row + log-prior arrive from another rank (hens_pt_finish_sharded)
         if (locc[se] >= 0) A.Pnew[di] = Pc[se];
     }
-    for (int i = 1 + tid; i < T; i += PT_THREADS) {               // pair (i, i-1) -> swap_part index i-1
+    for (int i = 1 + tid; i < T; i += NTH) {               // pair (i, i-1) -> swap_part index i-1
         unsigned n = 0;
         for (int cc = 0; cc < PT_COLS && c0 + cc < W; ++cc) n += bit(cc, i) ? 1u : 0u;
         // (acc_rows: accumulated with atomics into a handful of rows that the next launch's folded adaptation sums - like the fused
