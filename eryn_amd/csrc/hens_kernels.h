@@ -1870,30 +1870,47 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     constexpr int MHG = NPASS >= 2 ? RPP : 0;             // (MH normals: rows of the tile that share a Philox call, mh_normal_quad)
     static_assert(MHG == mh_pair_rows(DT) && (HP % 2 == 0 || NPASS == 1), "k_mh_draw pairs the rows this launch does");
     u4 mh_d{0u, 0u, 0u, 0u};
-#define HENS_GATHER_PASS(p) \
+    // the proposal's step scale of this lane's two coordinates, requested once in front of the passes
+    double mh_s0 = 0.0, mh_s1 = 0.0;
+    if (MH && !A.mh_step) {
+        mh_s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];
+        mh_s1 = A.mh_kind == MH_ISO ? mh_s0 : A.mh_scale[jl * 2 + 1];
+    }
+#define HENS_GATHER_PASS(p, DRAW) \
         const int r = p * RPP + rsub;                                                                                                                          \
         rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;                                                                                             \
         sreg[p] = double2{0.0, 0.0};                                                                                                                           \
         creg[p] = double2{0.0, 0.0};                                                                                                                           \
-        if (MH && !A.mh_step && (!MHG || (p & 1) == 0))   /* the call of this row and (MHG) of the lane's next pass' row, MHG rows on */                       \
+        if (MH && DRAW && (!MHG || (p & 1) == 0))         /* the call of this row and (MHG) of the lane's next pass' row, MHG rows on */                       \
             mh_d = mh_normal_quad(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl), (uint32_t)W, (uint32_t)(k0 + r), (uint32_t)jl);                         \
         if (rv[p]) {                                                                                                                                           \
             sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);                 \
             if (MH) {                                                                                                                                          \
-                if (A.mh_step) {                                                                                                                               \
+                if (!DRAW) {                                                                                                                                   \
                     creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);                                           \
                 } else { /* a Box-Muller pair per lane and row - the two coordinates it owns; one Philox call per TWO rows (mh_normal_quad) */                 \
                     const double2 z = (MHG && (p & 1)) ? mh_normal_from32(mh_d.z, mh_d.w) : mh_normal_from32(mh_d.x, mh_d.y);                                 \
-                    const double s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];                                                                \
-                    const double s1 = A.mh_kind == MH_ISO ? s0 : A.mh_scale[jl * 2 + 1];                                                                       \
-                    creg[p] = double2{s0 * z.x, s1 * z.y};                                                                                                     \
+                    creg[p] = double2{mh_s0 * z.x, mh_s1 * z.y};                                                                                               \
                 }                                                                                                                                              \
             }                                                                                                                                                  \
             else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2); \
         }                                                                                                                                                     
+    // (MH: the choice between the caller's steps and draws in place is made OUTSIDE the passes - as a branch inside a pass, both
+    //  sides writing the same registers, the compiler guarded the draw's products with a vmcnt(0) for the other side's load, which also
+    //  waits for the row load the pass has just issued: the passes' rows came one memory round trip after the other - phase B 19 600
+    //  cycles at 32 x 8192 x 128 against the stretch half-step's 11 100 for twice the rows; seen in the ISA, round 5.  The draws stay
+    //  BETWEEN the row requests: all requests first, then all draws, was slower - 124.9 against 121.2 us per iteration at config 5)
+    const bool mh_draw = MH && !A.mh_step;
+    if (mh_draw) {
 #pragma unroll
-    for (int p = 0; p < HP; ++p) {
-        HENS_GATHER_PASS(p)
+        for (int p = 0; p < HP; ++p) {
+            HENS_GATHER_PASS(p, 1)
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+            HENS_GATHER_PASS(p, 0)
+        }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
     const double2 hiv = *reinterpret_cast<const double2*>(A.hi + jl * 2);
@@ -1992,9 +2009,16 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         HENS_PROPOSE_PASS(p)
     }
     if constexpr (HP < NPASS) {
+        if (mh_draw) {
 #pragma unroll
-        for (int p = HP; p < NPASS; ++p) {
-            HENS_GATHER_PASS(p)
+            for (int p = HP; p < NPASS; ++p) {
+                HENS_GATHER_PASS(p, 1)
+            }
+        } else {
+#pragma unroll
+            for (int p = HP; p < NPASS; ++p) {
+                HENS_GATHER_PASS(p, 0)
+            }
         }
 #pragma unroll
         for (int p = HP; p < NPASS; ++p) {
