@@ -3155,6 +3155,10 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             if ((nonfin & gmask) != 0ull) atomicOr(A.flags, FLAG_NONFINITE_X);
         }
     }
+    // (the matrix operand of phase C - D = 64 / 128 dense: five / eighteen doubles per lane out of prec_sym - requested in front of the
+    //  barrier as in k_stretch_fast, in flight across it.  Rounds 4-5 requested it behind the barrier: phase C 5 600 cycles at
+    //  8 x 16384 x 64 against the first launch's 1 290, tools/trace_pipe_phases.py)
+    const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);
     FUSED_TRACE(3);
     lds_barrier();
 #ifdef HENS_DEV_BUILD
@@ -3164,8 +3168,6 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // ---- phase C: likelihood ------------------------------------------------------------------------------
     if (!nomove) {
         const bool inbox = (s_flag[lane] & 1) != 0;
-        // (the matrix operand is requested here, not in front of the barrier as in k_stretch_fast)
-        const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);
         like_partials<DT, LIKE, NW, CEN>(qtile, s_part, lane, wv, inbox, like_mf<DT, LIKE, NW>() ? s_mu : A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b, mfr);
     }
     FUSED_TRACE(4);
