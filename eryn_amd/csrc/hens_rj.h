@@ -56,8 +56,8 @@ struct RjArgs {
     const double* u_acc;                // [Tl][W] accept uniforms; nullptr: Philox
     unsigned* flags;
     // per record coordinate i (hens_rj_set_model / hens_rj_set_mh_scale keep it current): ctab[0][i] lo, [1][i] hi, [2][i] in-model step scale,
-    // [3][i] the branch's leaf log-density; cbn[i] = branch | slot in the branch << 4 | dimension << 10 | leaf kind << 12 | slot in the record << 16 (RJ_CBN_*) - what a LANE needs about its coordinate in one
-    // coalesced load each, instead of scalar loads from the model struct one dependent index at a time (round 5: the log-prior phase
+    // [3][i] the branch's leaf log-density; cbn[i] = branch | slot in the branch << 4 | dimension << 10 | leaf kind << 12 | slot in the
+    // record << 16 (RJ_CBN_*) - what a LANE needs about its coordinate in one coalesced load each, instead of scalar loads from the model struct one dependent index at a time (round 5: the log-prior phase
     // was 5 000 of a wave's 28 000 cycles, a chain of ~20 s_load + s_waitcnt)
     const double* ctab; const int32_t* cbn;
     RjModel M;
@@ -206,6 +206,7 @@ __device__ __forceinline__ double numpy_sum(const double* v, int n) {
     return res;
 }
 
+// index of the k-th set bit of m (k < popcount(m))
 __device__ __forceinline__ int nth_set_bit(uint32_t m, int k) {
     for (int j = 0; j < k; ++j) m &= m - 1u;
     return __builtin_ctz(m);
