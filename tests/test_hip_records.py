@@ -201,3 +201,21 @@ def test_every_kept_switch_reaches_the_default_paths_state(knob, T, W, D, tmp_pa
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(dict(np.load(out)))
     _assert_same(outs[0], outs[1], f"({T},{W},{D}) default vs {knob}=1")
+
+
+@pytest.mark.parametrize("T,W,D,like", [(8, 128, 64, "dense"), (32, 256, 128, "rosen")])
+def test_cascade_counts_accumulated_or_per_workgroup_same_chain(T, W, D, like, tmp_path):
+    """Round 5: the stand-alone cascade of a move mix's MH iterations accumulates its swap counts into a handful of rows that the
+    next launch's folded adaptation sums (PtArgs::acc_rows); HENS_PT_NO_ACC=1 keeps a row per workgroup and the k_adapt launch.
+    Same counts either way: the chain, the ladder and every counter agree bit for bit."""
+    outs = []
+    for env in ({}, {"HENS_PT_NO_ACC": "1"}):
+        out = str(tmp_path / f"{len(outs)}.npz")
+        e = dict(os.environ, **env)
+        if not env:
+            e.pop("HENS_PT_NO_ACC", None)
+        r = subprocess.run([sys.executable, "-c", _WORKER, ROOT, str(T), str(W), str(D), "1", like, out],
+                           env=e, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(dict(np.load(out)))
+    _assert_same(outs[0], outs[1], f"({T},{W},{D}) MH mix: accumulated counts vs HENS_PT_NO_ACC=1")
