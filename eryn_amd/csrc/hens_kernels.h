@@ -365,8 +365,12 @@ __device__ __forceinline__ bool pipe_arrive_collect(unsigned* ticket, unsigned n
 
 // loc >= 0: a row of the pool.  loc < 0: guest row ~loc of this rank's mailbox (a walker that arrived
 // through the ladder pipeline during the last PT sweep); `guest_delta` = (guest - pool) in doubles.
+// (branch-free, round 5: as `loc >= 0 ? ... : ...` every use compiled to a divergent branch with the reload of a spilled SGPR block
+//  - guest_delta's - inside it, and the wait for the LDS read of `loc` in front of it: a pipeline rank's gather passes issued their
+//  row requests 40 - 55 instructions apart where one GPU's go out back to back)
 __device__ __forceinline__ int64_t row_off(int32_t loc, int D, int64_t guest_delta) {
-    return loc >= 0 ? (int64_t)loc * D : guest_delta + (int64_t)(~loc) * D;
+    const int32_t sg = loc >> 31;                                    // 0 / -1
+    return (int64_t)(loc ^ sg) * D + ((int64_t)sg & guest_delta);    // loc ^ -1 = ~loc
 }
 
 // All rows of one swap-count accumulation buffer of k_split1_pt<PIPE> (nrows = 8 G rows of np pairs, G in {1, 2, 4, 8}, np <= 64 / G:
