@@ -1524,11 +1524,17 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             if (e1 < T) A.ad.betas_out[e1] = bnew1;
             if (e0 < T - 1 && !ad_x) {             // (ad_x: wave ADX, the only reader of the counts then, keeps these books)
                 A.ad.swaps_last[e0] = cnt0;
-                A.ad.swaps_total[e0] += cnt0;
+                // (a pipeline rank: an atomic without a return value - `+=` is a load this wave, in front of workgroup (0,0)'s first
+                //  barrier there, waits a memory round trip for: the rank's first launch 9.4 -> 8.8 us at 16 x 4096 x 32; the counts are
+                //  integers, the sum is the same double.  One GPU keeps `+=`: in the gathers' shadow it costs nothing, and the atomic made
+                //  config 2 0.1 us SLOWER - 17.40 -> 17.50, four alternations)
+                if constexpr (PIPE) atomicAdd(&A.ad.swaps_total[e0], cnt0);
+                else A.ad.swaps_total[e0] += cnt0;
             }
             if (e1 < T - 1) {
                 A.ad.swaps_last[e1] = cnt1;
-                A.ad.swaps_total[e1] += cnt1;
+                if constexpr (PIPE) atomicAdd(&A.ad.swaps_total[e1], cnt1);
+                else A.ad.swaps_total[e1] += cnt1;
             }
         }
     };
