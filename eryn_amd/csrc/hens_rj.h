@@ -623,11 +623,17 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 for (int k = 0; k < RJ_PPL; ++k) tm8[k] += sub[k];
             }
         }
+        // the data at the lane's points: all eight requested back to back behind the leaves (clamped indices, no divergence) - as a load
+        // inside `if (i0 + k < ndata)` each one was followed by its own s_waitcnt vmcnt(0): eight memory round trips in a row at the end
+        // of every likelihood (seen in the ISA, round 5)
+        double yv[RJ_PPL];
+#pragma unroll
+        for (int k = 0; k < RJ_PPL; ++k) yv[k] = A.ydata[i0 + k < M.ndata ? i0 + k : M.ndata - 1];
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < RJ_PPL; ++k) {
             if (i0 + k < M.ndata) {
-                const double d0 = tm8[k] - A.ydata[i0 + k];
+                const double d0 = tm8[k] - yv[k];
                 const double r = sig_pow2 ? d0 * sig_inv : d0 / M.sigma;
                 acc += r * r;
             }
