@@ -2901,6 +2901,17 @@ __host__ __device__ constexpr size_t fused_lds_base(int D, int NW, bool pipe = f
 }
 __host__ __device__ inline size_t fused_lds_bytes(int D, int NW, int like, bool pipe = false) { return fused_lds_base(D, NW, pipe) + mf_lds_extra(D, like); }
 
+// A kernel argument read where it is USED, not at the kernel's entry: the compiler hoists every by-value argument's scalar load to
+// the top (it is invariant and dereferenceable), and an argument that is first needed behind the likelihood lives in SGPRs across
+// it - k_split1_pt<32> spilled 53 of them into vector lanes (v_writelane / v_readlane, 176 such instructions in the kernel).  The
+// opaque offset keeps this load at its program point.
+template <class Tp>
+__device__ __forceinline__ Tp late_kernarg(size_t off) {
+    asm volatile("" : "+s"(off));
+    const __attribute__((address_space(4))) char* base = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const __attribute__((address_space(4))) Tp*>(base + off);
+}
+
 // SHORT: the ladder length does not divide 128 - cb T < 128 slots and cb T / 2 < 64 moving walkers per workgroup.  An
 // instantiation of its own: with run-time bounds the full-tile launch lost its compile-time-true row guards, 0.2 us at
 // config 2 (tools/ab3.sh: 22.4 / 22.6 / 22.5 us per iteration before / with run-time bounds / with this parameter).
@@ -3399,15 +3410,21 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const size_t di = (size_t)t * W + scol[e];
         if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
             A.ghome[(size_t)(A.par * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
-        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);  // (the slot's own counter and index: they do not move with a walker)
-        A.locnew[di] = locc[se];
+        WalkerRec* const wrecnew_l = PIPE ? A.wrecnew : late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew));
+        int32_t* const locnew_l = PIPE ? A.locnew : late_kernarg<int32_t*>(offsetof(FusedArgs, locnew));
+        wrecnew_l[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);  // (the slot's own counter and index: they do not move with a walker)
+        locnew_l[di] = locc[se];
     }
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
         unsigned n = 0;
         for (int cc = 0; cc < CB; ++cc) n += bit(cc, i) ? 1u : 0u;
         // (a pipeline rank too - round 3: one ticket per workgroup on ONE address, for a collector at the end of the launch, cost
         //  16 ns per workgroup, serialised: 17 us at 1024 workgroups; the next launch sums these rows and publishes the counts)
-        if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (TE - 1) + (i - 1)], n);
+        if (n) {
+            uint32_t* const acc_l = PIPE ? A.swap_acc : late_kernarg<uint32_t*>(offsetof(FusedArgs, swap_acc));
+            const int32_t rows_l = PIPE ? A.acc_rows : late_kernarg<int32_t>(offsetof(FusedArgs, acc_rows));
+            atomicAdd(&acc_l[(size_t)(blockIdx.x & (rows_l - 1)) * (TE - 1) + (i - 1)], n);
+        }
     }
     // ---- phase E, the walking wave's share ---------------------------------------------------------------------------
     if (!PIPE && walking) store_accepted();
