@@ -270,6 +270,17 @@ __device__ __forceinline__ unsigned long long trace_stamp() {
     return __builtin_amdgcn_s_memtime();
 #endif
 }
+// A kernel argument read where it is USED, not at the kernel's entry: the compiler hoists every by-value argument's scalar load to
+// the top (it is invariant and dereferenceable), and an argument that is first needed behind the likelihood lives in SGPRs across
+// it - k_split1_pt<32> spilled 53 of them into vector lanes (v_writelane / v_readlane, 176 such instructions in the kernel).  The
+// opaque offset keeps this load at its program point.
+template <class Tp>
+__device__ __forceinline__ Tp late_kernarg(size_t off) {
+    asm volatile("" : "+s"(off));
+    const __attribute__((address_space(4))) char* base = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const __attribute__((address_space(4))) Tp*>(base + off);
+}
+
 __device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -1520,21 +1531,27 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             }
         }
         if (blockIdx.x == 0 && blockIdx.y == 0) {
-            if (e0 < T) A.ad.betas_out[e0] = bnew0;
-            if (e1 < T) A.ad.betas_out[e1] = bnew1;
+            // (workgroup (0,0)'s books: the three pointers are read from the kernarg segment HERE on one GPU - as by-value arguments
+            //  they sit in SGPRs from the entry of every workgroup's every wave, late_kernarg)
+            constexpr size_t AD = offsetof(StretchArgs, ad);
+            double* const betas_out_l = PIPE ? A.ad.betas_out : late_kernarg<double*>(AD + offsetof(AdaptArgs, betas_out));
+            double* const swaps_last_l = PIPE ? A.ad.swaps_last : late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_last));
+            double* const swaps_total_l = PIPE ? A.ad.swaps_total : late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_total));
+            if (e0 < T) betas_out_l[e0] = bnew0;
+            if (e1 < T) betas_out_l[e1] = bnew1;
             if (e0 < T - 1 && !ad_x) {             // (ad_x: wave ADX, the only reader of the counts then, keeps these books)
-                A.ad.swaps_last[e0] = cnt0;
+                swaps_last_l[e0] = cnt0;
                 // (a pipeline rank: an atomic without a return value - `+=` is a load this wave, in front of workgroup (0,0)'s first
                 //  barrier there, waits a memory round trip for: the rank's first launch 9.4 -> 8.8 us at 16 x 4096 x 32; the counts are
                 //  integers, the sum is the same double.  One GPU keeps `+=`: in the gathers' shadow it costs nothing, and the atomic made
                 //  config 2 0.1 us SLOWER - 17.40 -> 17.50, four alternations)
-                if constexpr (PIPE) atomicAdd(&A.ad.swaps_total[e0], cnt0);
-                else A.ad.swaps_total[e0] += cnt0;
+                if constexpr (PIPE) atomicAdd(&swaps_total_l[e0], cnt0);
+                else swaps_total_l[e0] += cnt0;
             }
             if (e1 < T - 1) {
-                A.ad.swaps_last[e1] = cnt1;
-                if constexpr (PIPE) atomicAdd(&A.ad.swaps_total[e1], cnt1);
-                else A.ad.swaps_total[e1] += cnt1;
+                swaps_last_l[e1] = cnt1;
+                if constexpr (PIPE) atomicAdd(&swaps_total_l[e1], cnt1);
+                else swaps_total_l[e1] += cnt1;
             }
         }
     };
@@ -1583,8 +1600,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         // barrier, 4 150 cycles after the start against the complement wave's 3 000), so workgroup (0,0)'s books are kept here.
         if (blockIdx.x == 0 && blockIdx.y == 0) {
             if (g == 0 && p < T - 1) {
-                A.ad.swaps_last[p] = (double)s0;
-                A.ad.swaps_total[p] += (double)s0;
+                constexpr size_t AD = offsetof(StretchArgs, ad);
+                late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_last))[p] = (double)s0;
+                late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_total))[p] += (double)s0;
             }
             if (A.ad.zero_after) {
 #pragma unroll
@@ -2900,17 +2918,6 @@ __host__ __device__ constexpr size_t fused_lds_base(int D, int NW, bool pipe = f
            (2 * 2 * TILE + 5 * TILE + 64 + (pipe ? 3 * TILE : 0)) * 4;
 }
 __host__ __device__ inline size_t fused_lds_bytes(int D, int NW, int like, bool pipe = false) { return fused_lds_base(D, NW, pipe) + mf_lds_extra(D, like); }
-
-// A kernel argument read where it is USED, not at the kernel's entry: the compiler hoists every by-value argument's scalar load to
-// the top (it is invariant and dereferenceable), and an argument that is first needed behind the likelihood lives in SGPRs across
-// it - k_split1_pt<32> spilled 53 of them into vector lanes (v_writelane / v_readlane, 176 such instructions in the kernel).  The
-// opaque offset keeps this load at its program point.
-template <class Tp>
-__device__ __forceinline__ Tp late_kernarg(size_t off) {
-    asm volatile("" : "+s"(off));
-    const __attribute__((address_space(4))) char* base = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-    return *reinterpret_cast<const __attribute__((address_space(4))) Tp*>(base + off);
-}
 
 // SHORT: the ladder length does not divide 128 - cb T < 128 slots and cb T / 2 < 64 moving walkers per workgroup.  An
 // instantiation of its own: with run-time bounds the full-tile launch lost its compile-time-true row guards, 0.2 us at
