@@ -1292,7 +1292,11 @@ __device__ __forceinline__ void like_partials(const double* qtile, double* s_par
         double pa = 0.0, pb = 0.0;
         if (inbox) {
             typedef const __attribute__((address_space(4))) double* cptr_t;
-            const cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
+            // (opaque to the compiler: left alone it treats the pointer as free to re-read from the kernarg segment, lets the wide
+            //  coefficient loads in flight overwrite its registers, and puts a dependent scalar load - kernarg -> pointer -> coefficients -
+            //  in front of every batch: 16 of them in k_split1_pt<32>'s ISA, round 5)
+            cptr_t psym = (cptr_t)(uintptr_t)prec_sym_p;
+            asm volatile("" : "+s"(psym));
             const double* qrow = qtile + lane * (DT + 2);
             double qreg[DT];
 #pragma unroll
