@@ -1908,15 +1908,24 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         mh_s0 = A.mh_kind == MH_ISO ? A.mh_scale[0] : A.mh_scale[jl * 2];
         mh_s1 = A.mh_kind == MH_ISO ? mh_s0 : A.mh_scale[jl * 2 + 1];
     }
+    // the rows' indices of ALL passes out of LDS first (clamped row, no branch in between): read inside `if (rv[p])` every pass waited
+    // for its own LDS round trip before it could request its rows
+    int rs_i[NPASS], rc_i[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int rr = p * RPP + rsub < TILE ? p * RPP + rsub : 0;
+        rs_i[p] = s_rs[rr];
+        rc_i[p] = (MH || EVAL) ? 0 : s_rc[rr];
+    }
 #define HENS_GATHER_PASS(p, DRAW) \
         const int r = p * RPP + rsub;                                                                                                                          \
-        rv[p] = (r < TILE) && (s_flag[r < TILE ? r : 0] & 4) != 0;                                                                                             \
+        rv[p] = (r < TILE) && (k0 + r < Ns);   /* (= wave 0's `valid` of the row, s_flag bit 2, without the LDS read in front of every pass) */             \
         sreg[p] = double2{0.0, 0.0};                                                                                                                           \
         creg[p] = double2{0.0, 0.0};                                                                                                                           \
         if (MH && DRAW && (!MHG || (p & 1) == 0))         /* the call of this row and (MHG) of the lane's next pass' row, MHG rows on */                       \
             mh_d = mh_normal_quad(A.mh_seed, A.mh_iter, (uint32_t)(A.rung_begin + tl), (uint32_t)W, (uint32_t)(k0 + r), (uint32_t)jl);                         \
         if (rv[p]) {                                                                                                                                           \
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);                 \
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(rs_i[p], D, A.guest_delta) : (int64_t)rs_i[p] * D) + jl * 2);             \
             if (MH) {                                                                                                                                          \
                 if (!DRAW) {                                                                                                                                   \
                     creg[p] = *reinterpret_cast<const double2*>(A.mh_step + ((size_t)tl * W + k0 + r) * D + jl * 2);                                           \
@@ -1925,7 +1934,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                     creg[p] = double2{mh_s0 * z.x, mh_s1 * z.y};                                                                                               \
                 }                                                                                                                                              \
             }                                                                                                                                                  \
-            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2); \
+            else if (!EVAL) creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(rc_i[p], D, A.guest_delta) : (int64_t)rc_i[p] * D) + jl * 2); \
         }                                                                                                                                                     
     // (MH: the choice between the caller's steps and draws in place is made OUTSIDE the passes - as a branch inside a pass, both
     //  sides writing the same registers, the compiler guarded the draw's products with a vmcnt(0) for the other side's load, which also
@@ -3140,6 +3149,13 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     const double* __restrict__ pool_r = A.pool;
     double2 sreg[NPASS], creg[NPASS];
     bool rv[NPASS];
+    int rs_i[NPASS], rc_i[NPASS];                   // (the rows' indices of all passes out of LDS first: see k_stretch_fast)
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int rr = p * RPP + rsub < TILE ? p * RPP + rsub : 0;
+        rs_i[p] = s_rs[rr];
+        rc_i[p] = s_rc[rr];
+    }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const int r = p * RPP + rsub;
@@ -3147,8 +3163,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         sreg[p] = double2{0.0, 0.0};
         creg[p] = double2{0.0, 0.0};
         if (rv[p]) {
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rs[r], D, A.guest_delta) : (int64_t)s_rs[r] * D) + jl * 2);
-            creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(s_rc[r], D, A.guest_delta) : (int64_t)s_rc[r] * D) + jl * 2);
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(rs_i[p], D, A.guest_delta) : (int64_t)rs_i[p] * D) + jl * 2);
+            creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(rc_i[p], D, A.guest_delta) : (int64_t)rc_i[p] * D) + jl * 2);
         }
     }
     const double2 lov = *reinterpret_cast<const double2*>(A.lo + jl * 2);
@@ -3349,27 +3365,35 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         // (Round 5, measured and dropped: only the hottest rung's rows in front of the hand-off, the others in the walk's shadow as on
         //  one GPU - nothing at D = 32 / 64, +2 us at D = 128: profiles/r05c_pipe_overlap.txt)
         store_accepted();
-        const PipeBox me = pipe_box(A.box, TG, W, D);
+        // (a rank's hand-off arguments are read from the kernarg segment HERE, late_kernarg: as by-value arguments they lived in SGPRs
+        //  from the kernel's entry across the likelihood - the D = 32 instantiation spilled 250 of them into vector lanes, round 5)
+        char* const box_l = late_kernarg<char*>(offsetof(FusedArgs, box));
+        char* const box_hot_l = late_kernarg<char*>(offsetof(FusedArgs, box_hot));
+        const int32_t par_l = late_kernarg<int32_t>(offsetof(FusedArgs, par));
+        const uint32_t sweep_l = late_kernarg<uint32_t>(offsetof(FusedArgs, sweep));
+        const long long budget_l = late_kernarg<long long>(offsetof(FusedArgs, budget));
+        unsigned long long* const stats_l = late_kernarg<unsigned long long*>(offsetof(FusedArgs, stats));
+        const PipeBox me = pipe_box(box_l, TG, W, D);
         if (has_top) {
             if (tid >= ((T - 1) << CS) && tid < (T << CS)) {
-                const PipeBox hot = pipe_box(A.box_hot, TG, W, D);
+                const PipeBox hot = pipe_box(box_hot_l, TG, W, D);
                 // (column-ordered records: the hot neighbour's column c meets the walker at index c - no permutation on its side)
                 const int slot = COL ? c0 + (tid & (CB - 1)) : scol[tid];
-                sys_store(hot.lp_dn + (size_t)(A.par * 2) * W + slot, Lc[tid]);
-                sys_store(hot.lp_dn + (size_t)(A.par * 2 + 1) * W + slot, Pc[tid]);
-                __hip_atomic_store(hot.ldn_loc + (size_t)A.par * W + slot, locc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                sys_store(hot.lp_dn + (size_t)(par_l * 2) * W + slot, Lc[tid]);
+                sys_store(hot.lp_dn + (size_t)(par_l * 2 + 1) * W + slot, Pc[tid]);
+                __hip_atomic_store(hot.ldn_loc + (size_t)par_l * W + slot, locc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) pipe_raise(pipe_box(A.box_hot, TG, W, D).blk_ldn + blockIdx.x, A.sweep + 1);
+            if (tid == 0) pipe_raise(pipe_box(box_hot_l, TG, W, D).blk_ldn + blockIdx.x, sweep_l + 1);
             // what the hot neighbour's columns carry on leaving its rungs: the walk's top row
             if (walking) {
-                if (lane == 0) pipe_spin(me.blk_lup + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 4 : nullptr);
+                if (lane == 0) pipe_spin(me.blk_lup + blockIdx.x, sweep_l + 1, budget_l, A.flags, stats_l ? stats_l + 4 : nullptr);
                 if (lane < CB) {
                     const int c = c0 + lane, et = (T << CS) + lane;
-                    Lc[et] = sys_load(me.lp_up + (size_t)(A.par * 2) * W + c);
-                    Pc[et] = sys_load(me.lp_up + (size_t)(A.par * 2 + 1) * W + c);
-                    locc[et] = pipe_guest_loc(A.par, 0, W, c);
+                    Lc[et] = sys_load(me.lp_up + (size_t)(par_l * 2) * W + c);
+                    Pc[et] = sys_load(me.lp_up + (size_t)(par_l * 2 + 1) * W + c);
+                    locc[et] = pipe_guest_loc(par_l, 0, W, c);
                 }
             }
         }
@@ -3420,9 +3444,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         se_n = se;
         const size_t di = (size_t)t * W + scol[e];
         if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
-            A.ghome[(size_t)(A.par * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
-        WalkerRec* const wrecnew_l = PIPE ? A.wrecnew : late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew));
-        int32_t* const locnew_l = PIPE ? A.locnew : late_kernarg<int32_t*>(offsetof(FusedArgs, locnew));
+            A.ghome[(size_t)(late_kernarg<int32_t>(offsetof(FusedArgs, par)) * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
+        WalkerRec* const wrecnew_l = late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew));
+        int32_t* const locnew_l = late_kernarg<int32_t*>(offsetof(FusedArgs, locnew));
         wrecnew_l[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);  // (the slot's own counter and index: they do not move with a walker)
         locnew_l[di] = locc[se];
     }
@@ -3432,8 +3456,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         // (a pipeline rank too - round 3: one ticket per workgroup on ONE address, for a collector at the end of the launch, cost
         //  16 ns per workgroup, serialised: 17 us at 1024 workgroups; the next launch sums these rows and publishes the counts)
         if (n) {
-            uint32_t* const acc_l = PIPE ? A.swap_acc : late_kernarg<uint32_t*>(offsetof(FusedArgs, swap_acc));
-            const int32_t rows_l = PIPE ? A.acc_rows : late_kernarg<int32_t>(offsetof(FusedArgs, acc_rows));
+            uint32_t* const acc_l = late_kernarg<uint32_t*>(offsetof(FusedArgs, swap_acc));
+            const int32_t rows_l = late_kernarg<int32_t>(offsetof(FusedArgs, acc_rows));
             atomicAdd(&acc_l[(size_t)(blockIdx.x & (rows_l - 1)) * (TE - 1) + (i - 1)], n);
         }
     }
@@ -3441,21 +3465,28 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     if (!PIPE && walking) store_accepted();
 
     if constexpr (PIPE) {
-        const PipeBox me = pipe_box(A.box, TG, W, D);
+        char* const box_l = late_kernarg<char*>(offsetof(FusedArgs, box));
+        char* const box_cold_l = late_kernarg<char*>(offsetof(FusedArgs, box_cold));
+        const double* const pool_cold_l = late_kernarg<const double*>(offsetof(FusedArgs, pool_cold));
+        const int32_t par_l = late_kernarg<int32_t>(offsetof(FusedArgs, par));
+        const uint32_t sweep_l = late_kernarg<uint32_t>(offsetof(FusedArgs, sweep));
+        const long long budget_l = late_kernarg<long long>(offsetof(FusedArgs, budget));
+        unsigned long long* const stats_l = late_kernarg<unsigned long long*>(offsetof(FusedArgs, stats));
+        const PipeBox me = pipe_box(box_l, TG, W, D);
         // ---- my columns leave for the cold neighbour: its workgroup with the same index may start its walk -----------------
         if (has_bot) {
-            const PipeBox cold = pipe_box(A.box_cold, TG, W, D);
+            const PipeBox cold = pipe_box(box_cold_l, TG, W, D);
             if (tid < CB) {                                              // (slot threads of my coldest rung: t = 0, cc = tid)
-                sys_store(cold.lp_up + (size_t)(A.par * 2) * W + c0 + tid, Lc[se_n]);
-                sys_store(cold.lp_up + (size_t)(A.par * 2 + 1) * W + c0 + tid, Pc[se_n]);
+                sys_store(cold.lp_up + (size_t)(par_l * 2) * W + c0 + tid, Lc[se_n]);
+                sys_store(cold.lp_up + (size_t)(par_l * 2 + 1) * W + c0 + tid, Pc[se_n]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) pipe_raise(cold.blk_lup + blockIdx.x, A.sweep + 1);
+            if (tid == 0) pipe_raise(cold.blk_lup + blockIdx.x, sweep_l + 1);
             // ---- bottom boundary, hot side: pair (g, g-1) for the same columns (needs the cold neighbour's rung after ITS move,
             // not its walk); a walker may fall through all my rungs in one sweep, so the rows from above must have landed too
-            if (tid == 0) pipe_spin(me.blk_ldn + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 6 : nullptr);
-            if (tid == 64 && has_top) pipe_spin(me.blk_rows + blockIdx.x, A.sweep + 1, A.budget, A.flags, A.stats ? A.stats + 8 : nullptr);
+            if (tid == 0) pipe_spin(me.blk_ldn + blockIdx.x, sweep_l + 1, budget_l, A.flags, stats_l ? stats_l + 6 : nullptr);
+            if (tid == 64 && has_top) pipe_spin(me.blk_rows + blockIdx.x, sweep_l + 1, budget_l, A.flags, stats_l ? stats_l + 8 : nullptr);
             __syncthreads();
             if (tid < CB) {
                 const int cc = tid, c = c0 + cc, g = R0;
@@ -3467,28 +3498,28 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
                     slot_below = (int)prp((uint32_t)c, key, A.idx_bits, (uint32_t)W);
                 }
                 const double La = Lc[se_n];
-                const double Lb = sys_load(me.lp_dn + (size_t)(A.par * 2) * W + slot_below);
+                const double Lb = sys_load(me.lp_dn + (size_t)(par_l * 2) * W + slot_below);
                 const double db = A.betas[g - 1] - A.betas[g];                       // tempering.py:518-522
                 int32_t src = PIPE_NOSEL, yrow = 0;
                 if (db * (La - Lb) > log(pt_uniform(A.seed, A.iter, TG - 1 - g, W, c))) {   // tempering.py:535-541
                     src = locc[se_n];
-                    yrow = __hip_atomic_load(me.ldn_loc + (size_t)A.par * W + slot_below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    const double Pb = sys_load(me.lp_dn + (size_t)(A.par * 2 + 1) * W + slot_below);
-                    const int32_t gl = pipe_guest_loc(A.par, 1, W, c);
+                    yrow = __hip_atomic_load(me.ldn_loc + (size_t)par_l * W + slot_below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const double Pb = sys_load(me.lp_dn + (size_t)(par_l * 2 + 1) * W + slot_below);
+                    const int32_t gl = pipe_guest_loc(par_l, 1, W, c);
                     const size_t di = (size_t)scol[tid];                             // (rung 0 of the rank)
-                    A.wrecnew[di] = make_wrec(Lb, Pb, gl, wr_n.acc, wr_n.slot);
-                    A.locnew[di] = gl;
+                    late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew))[di] = make_wrec(Lb, Pb, gl, wr_n.acc, wr_n.slot);
+                    late_kernarg<int32_t*>(offsetof(FusedArgs, locnew))[di] = gl;
                     // its home: the row of the walker that goes down - or, if that one only just fell in from above (a guest
                     // itself), the row of the walker that went up across the top boundary
-                    A.ghome[(size_t)(A.par * 2 + 1) * W + c] = src >= 0 ? src : locc[((T - 1) << CS) + cc];
+                    A.ghome[(size_t)(par_l * 2 + 1) * W + c] = src >= 0 ? src : locc[((T - 1) << CS) + cc];
                 }
                 s_src[cc] = src;
                 s_yrow[cc] = yrow;
             }
             __syncthreads();
             {
-                double* dst = cold.guest + (size_t)(A.par * 2) * W * D;              // rows that move down: push
-                double* mine = me.guest + (size_t)(A.par * 2 + 1) * W * D;           // rows that move up: pull
+                double* dst = cold.guest + (size_t)(par_l * 2) * W * D;              // rows that move down: push
+                double* mine = me.guest + (size_t)(par_l * 2 + 1) * W * D;           // rows that move up: pull
                 // all of a thread's loads first - the pulls cross xGMI, their latencies must overlap - then the stores
                 for (int base = 0; base < CB * D; base += 4 * NT) {
                     double push[4], pull[4];
@@ -3503,7 +3534,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
                             if (src != PIPE_NOSEL) {
                                 on[q] = true;
                                 push[q] = sys_load(A.pool + row_off(src, D, A.guest_delta) + d);
-                                pull[q] = sys_load(A.pool_cold + (size_t)s_yrow[col] * D + d);
+                                pull[q] = sys_load(pool_cold_l + (size_t)s_yrow[col] * D + d);
                             }
                         }
                     }
@@ -3520,7 +3551,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) pipe_raise(cold.blk_rows + blockIdx.x, A.sweep + 1);
+            if (tid == 0) pipe_raise(cold.blk_rows + blockIdx.x, sweep_l + 1);
             // (that ALL rows from above have landed - what the cold neighbour's next iteration waits for - is said by this
             //  rank's NEXT launch: StretchArgs::rt_flag, k_pipe_epilogue; no grid-wide ticket here)
         }
