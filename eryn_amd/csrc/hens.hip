@@ -2110,6 +2110,19 @@ int hens_set_gaussian(hens_ctx* ctx, const double* mu, const double* prec) {
                     for (int i = 0; i < H; ++i)
                         for (int k = 0; k < H; ++k)
                             sym[(size_t)4 * BLK + (size_t)x * H * H + (size_t)i * H + k] = S(bi * H + i, bk * H + k);
+        } else if (D == 32 && MF32_ON) {
+            // the pair layout (generic-width paths) and, behind it, the matrix-pipe operands of like_tile_mf32: step c = (I, J >= I, s),
+            // mf[c][lane] = M_IJ[lane % 16][4 s + lane / 16]
+            static_assert(MF32_OFF >= 16 * 34 && MF32_END <= MF64_END, "prec_sym layout at D = 32");
+            sym.assign((size_t)MF32_END, 0.0);
+            pack_block(0, D, sym.data());
+            for (int cidx = 0; cidx < MF32_STEPS; ++cidx) {
+                const int I = mf32_I(cidx), J = mf32_J(cidx), st = mf32_S(cidx);
+                for (int l = 0; l < 64; ++l) {
+                    const int r = 16 * I + l % 16, k = 16 * J + 4 * st + l / 16;
+                    sym[(size_t)MF32_OFF + (size_t)cidx * 64 + l] = I == J ? prec[(size_t)r * D + k] : prec[(size_t)r * D + k] + prec[(size_t)k * D + r];
+                }
+            }
         } else {
             sym.assign((size_t)(D / 2) * (D + 2), 0.0);
             pack_block(0, D, sym.data());

@@ -57,7 +57,7 @@ struct IterArgs {
 };
 
 __host__ __device__ inline size_t iter_lds_bytes(int D, int NW) {
-    return ((size_t)3 * TILE * (D + 2) + (size_t)2 * NW * TILE + 3 * TILE + 3 * 2 * TILE + 128) * 8 +
+    return ((size_t)3 * TILE * (D + 2) + (size_t)2 * NW * TILE + 3 * TILE + 3 * 2 * TILE + 128 + 32) * 8 +
            ((size_t)2 * 2 * TILE + 3 * TILE + 2 * TILE + 3 * TILE + 2 * TILE + 64) * 4;
 }
 
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     double* Pc = Lc + NE;
     double* lupt = Pc + NE;                                              // [NE]
     double* sbeta = lupt + NE;                                           // [128]
-    int32_t* locc = reinterpret_cast<int32_t*>(sbeta + 128);             // [NE]
+    double* s_mu = sbeta + 128;                                          // [32] D = 32 dense: mu for the matrix-pipe likelihood (like_tile_mf32)
+    int32_t* locc = reinterpret_cast<int32_t*>(s_mu + 32);               // [NE]
     int32_t* scol = locc + NE;                                           // [NE]
     int32_t* s_rs = scol + NE;                                           // [3][TILE] own row: A, X, B
     int32_t* s_rc = s_rs + 3 * TILE;                                     // [2][TILE] complement row: A, X
@@ -172,6 +173,9 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     const int NEr = T << CS, NM = NEr >> 1;
 #define ITER_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
     ITER_TRACE(0);
+    const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);   // (D = 32 dense: the matrix operands of the three likelihood phases, requested first)
+    if constexpr (like_mf<DT, LIKE, NW>())
+        if (tid >= NT - DT / 2) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NT - DT / 2))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NT - DT / 2)));
 
     // ---- phase A: one wave per role ---------------------------------------------------------------------------
     //   waves 0 / 1 / 2 : lane m = the block's m-th first-half walker / the complement of its m-th second-half walker /
@@ -312,7 +316,10 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     lds_barrier();
 
     // ---- phase C1: likelihood of the first half-step proposals and of the replayed ones ---------------------------
-    {
+    if constexpr (like_mf<DT, LIKE, NW>()) {
+        like_tile_mf32<false>(tileA, s_part, lane, wv, s_mu, mfr);
+        like_tile_mf32<false>(tileX, s_part + NW * TILE, lane, wv, s_mu, mfr);
+    } else {
         const bool inA = (s_flag[lane] & 1) != 0, inX = (s_flag[TILE + lane] & 1) != 0;
         if (wv < LNW) {
             s_part[wv * TILE + lane] = like_partial<DT, LIKE, LNW, false>(tileA, lane, wv, inA, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         const bool inbox = (flagw & 1) != 0;
         double acc = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < LNW; ++w2) acc += part[w2 * TILE + lane];
+        for (int w2 = 0; w2 < like_nparts<DT, LIKE, LNW>(); ++w2) acc += part[w2 * TILE + lane];
         double logl = inbox ? -0.5 * acc : A.fill;                      // ensemble.py:1486-1513
         if (logl != logl) {                                             // red_blue.py:279-281
             logl = -1e300;
@@ -375,7 +382,9 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
     lds_barrier();
 
     // ---- phase C2 / D2 ------------------------------------------------------------------------------------------
-    {
+    if constexpr (like_mf<DT, LIKE, NW>()) {
+        like_tile_mf32<false>(tileB, s_part, lane, wv, s_mu, mfr);
+    } else {
         const bool inB = (s_flag[2 * TILE + lane] & 1) != 0;
         if (wv < LNW) s_part[wv * TILE + lane] = like_partial<DT, LIKE, LNW, false>(tileB, lane, wv, inB, A.mu, A.prec, A.prec_sym, A.rosen_a, A.rosen_b);
     }

@@ -1097,11 +1097,29 @@ constexpr int mf128_J(int c) { return mf128_I(c) + (c - mf128_base(mf128_I(c))) 
 constexpr int mf128_S(int c) { return (c - mf128_base(mf128_I(c))) % 4; }
 // mu in LDS, dense likelihood only (D = 128 on a pipeline rank: with it for every kind the diagonal likelihood's 127-VGPR launch would
 // lose its second workgroup per CU to 512 bytes of LDS)
-__host__ __device__ constexpr size_t mf_lds_extra(int D, int like) { return like != LIKE_DENSE ? 0 : (D == 64 ? 64 * 8 : (D == 128 ? 128 * 8 : 0)); }
+// D = 32 (round 5): two blocks of 16 coordinates, 3 block products = 12 steps (I, J >= I, s) behind the pair layout in prec_sym
+// (like_tile_mf32).  HENS_NO_MF32 builds the scalar-operand VALU form (sym_quad) instead.
+constexpr int MF32_OFF = 640;                                            // (17 x 34 = 578 doubles of pair layout in front, rounded up)
+constexpr int MF32_STEPS = 12;
+constexpr int MF32_END = MF32_OFF + MF32_STEPS * 64;
+constexpr int mf32_I(int c) { return c < 8 ? 0 : 1; }
+constexpr int mf32_J(int c) { return c < 4 ? 0 : 1; }
+constexpr int mf32_S(int c) { return c & 3; }
+#ifdef HENS_NO_MF32
+constexpr bool MF32_ON = false;
+#else
+constexpr bool MF32_ON = true;
+#endif
+__host__ __device__ constexpr size_t mf_lds_extra(int D, int like) {
+    return like != LIKE_DENSE ? 0 : (D == 64 ? 64 * 8 : (D == 128 ? 128 * 8 : (D == 32 && MF32_ON ? 32 * 8 : 0)));
+}
 typedef double d4_t __attribute__((ext_vector_type(4)));
-struct MfRegs { double m[5]; };
+struct MfRegs { double m[6]; };
 template <int DT, int LIKE, int NW>
-constexpr bool like_mf() { return LIKE == LIKE_DENSE && (DT == 64 || DT == 128) && NW == 8; }
+constexpr bool like_mf() { return LIKE == LIKE_DENSE && (DT == 64 || DT == 128 || (DT == 32 && MF32_ON)) && NW == 8; }
+// partial sums per walker phase C leaves in s_part[part][walker] (phase D adds them in order)
+template <int DT, int LIKE, int NW>
+constexpr int like_nparts() { return (LIKE == LIKE_DENSE && DT == 32 && MF32_ON && NW == 8) ? 2 : NW; }
 // step c = 0..39 in the order (I, J >= I, s)
 constexpr int mf64_I(int c) { return c < 16 ? 0 : (c < 28 ? 1 : (c < 36 ? 2 : 3)); }
 constexpr int mf64_base(int I) { return I == 0 ? 0 : (I == 1 ? 16 : (I == 2 ? 28 : 36)); }
@@ -1112,10 +1130,14 @@ template <int DT, int LIKE, int NW>
 __device__ __forceinline__ MfRegs like_prefetch(int lane, int wv, const double* prec_sym_p) {
     MfRegs r;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) r.m[t] = 0.0;
+    for (int t = 0; t < 6; ++t) r.m[t] = 0.0;
     if constexpr (like_mf<DT, LIKE, NW>() && DT == 64) {          // (D = 128: 18 operands per wave, requested where they are used)
 #pragma unroll
         for (int t = 0; t < 5; ++t) r.m[t] = prec_sym_p[MF64_OFF + (5 * wv + t) * 64 + lane];
+    }
+    if constexpr (like_mf<DT, LIKE, NW>() && DT == 32) {          // (waves 0-3: steps 0-5, waves 4-7: steps 6-11 - see like_tile_mf32)
+#pragma unroll
+        for (int t = 0; t < 6; ++t) r.m[t] = prec_sym_p[MF32_OFF + (6 * (wv >> 2) + t) * 64 + lane];
     }
     return r;
 }
@@ -1182,6 +1204,51 @@ __device__ __forceinline__ void like_tile_mf64(const double* qtile, double* srow
         default: break;
     }
     srow[wv * TILE + lane] = part;
+}
+
+// D = 32, the same scheme (round 5).  The scalar-operand form was bound by latency, not by issue: 136 coefficients per computing wave
+// through ~80 free SGPRs = eight batches of s_load_dwordx16 with a full wait each (SMEM returns out of order: there is no partial
+// wait), 2 070 cycles for phase C with both workgroups of a CU resident for the whole launch (tools/trace_fused2.py).  Here: 12 steps
+// (I, J >= I, s) x four 16-walker blocks = 48 MFMAs, six per wave - wave w takes walker block w & 3 and the steps' half w >> 2
+// ([0, 6): row block 0's products with column blocks 0 and half of 1; [6, 12): the rest of it and row block 1's own) - so a lane
+// reads 6 + 4 (+ 4) doubles of the tile where it read 32, and the six matrix operands come in one vector load each, requested in
+// front of the barrier.  TWO partial sums per walker (like_nparts): s_part[half][walker].
+template <int H, bool CEN>
+__device__ __forceinline__ double mf32_half(const double* qw, int g, const double* mu_s, const MfRegs& mf) {
+    constexpr int C0 = 6 * H;
+    d4_t accA = d4_t{0.0, 0.0, 0.0, 0.0}, accB = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int k = 16 * mf32_J(C0 + t) + 4 * mf32_S(C0 + t) + g;          // this lane's coordinate of the step
+        double bq = qw[k];
+        if (!CEN) bq -= mu_s[k];
+        if (mf32_I(C0 + t) == 0) accA = __builtin_amdgcn_mfma_f64_16x16x4f64(mf.m[t], bq, accA, 0, 0, 0);
+        else accB = __builtin_amdgcn_mfma_f64_16x16x4f64(mf.m[t], bq, accB, 0, 0, 0);
+    }
+    double p = 0.0;                                                           // rows g, g + 4, g + 8, g + 12 of the walker
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double x = qw[g + 4 * r];
+        if (!CEN) x -= mu_s[g + 4 * r];
+        p = r == 0 ? x * accA[0] : fma(x, accA[r], p);
+    }
+    if (H == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double x = qw[16 + g + 4 * r];
+            if (!CEN) x -= mu_s[16 + g + 4 * r];
+            p = fma(x, accB[r], p);
+        }
+    }
+    return sum_rows_f64(p);
+}
+// one 64-walker tile: the two partial sums of every walker into srow[half * TILE + walker]
+template <bool CEN>
+__device__ __forceinline__ void like_tile_mf32(const double* qtile, double* srow, int lane, int wv, const double* mu_s, const MfRegs& mf) {
+    const int j = lane & 15, g = lane >> 4, b = wv & 3;
+    const double* qw = qtile + (16 * b + j) * 34;
+    const double p = (wv < 4) ? mf32_half<0, CEN>(qw, g, mu_s, mf) : mf32_half<1, CEN>(qw, g, mu_s, mf);
+    if (g == 0) srow[(wv >> 2) * TILE + 16 * b + j] = p;
 }
 
 // D = 128, the same scheme: 36 block products = 144 steps, 18 per wave in the order (I, J >= I, s); a wave meets up to three row
@@ -1283,6 +1350,7 @@ __device__ __forceinline__ void like_partials(const double* qtile, double* s_par
                                               const double* prec_p, const double* prec_sym_p, double rosen_a, double rosen_b, const MfRegs& mf) {
     if constexpr (like_mf<DT, LIKE, NW>()) {          // (walkers outside the prior box ride along: a walker is a column of the product)
         if constexpr (DT == 64) like_tile_mf64<CEN>(qtile, s_part, lane, wv, mu_p, mf);
+        else if constexpr (DT == 32) like_tile_mf32<CEN>(qtile, s_part, lane, wv, mu_p, mf);
         else like_tile_mf128(qtile, s_part, lane, wv, mu_p, prec_sym_p);
         return;
     }
@@ -1371,6 +1439,9 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     if constexpr (like_mf<DT, LIKE, NW>()) {
         if (tid >= NW * 64 - DT / 2) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - DT / 2))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - DT / 2)));
     }
+    // (D = 32: the matrix operands of phase C are requested HERE - six doubles per lane.  In front of the barrier before phase C, as at
+    //  D = 64, they queue behind the workgroup's row gathers and phase C waits for them: 1 400 cycles where the MFMAs need 400)
+    MfRegs mfr = like_prefetch<DT == 32 ? DT : 0, LIKE, NW>(lane, wv, A.prec_sym);
     constexpr int ADW = 1;                      // the wave that runs the early ladder adaptation (a 9th, adaptation-only
                                                 // wave was measured: two 9-wave workgroups do not pack onto one CU)
     constexpr int PUSHW = 3;                    // pipeline rank, workgroup (0,0): the wave that publishes the last sweep's swap counts
@@ -2074,7 +2145,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         for (int q = 0; q < 8; ++q)
             if (adv[q]) atomicAdd(&s_cnt[(tid + q * NT) % Tm1], adv[q]);
     }
-    const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);   // (the matrix operand of phase C: in flight across the barrier)
+    if constexpr (DT != 32) mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);   // (the matrix operand of phase C: in flight across the barrier)
     HENS_TRACE(3);
     lds_barrier();
     HENS_TRACE(4);
@@ -2129,7 +2200,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         const bool inbox = (s_flag[lane] & 1) != 0;
         double acc = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + lane];
+        for (int w2 = 0; w2 < like_nparts<DT, LIKE, NW>(); ++w2) acc += s_part[w2 * TILE + lane];
         double logl = inbox ? -0.5 * acc : A.fill;             // ensemble.py:1486-1513
         if (logl != logl) {                                    // red_blue.py:279-281
             logl = -1e300;
@@ -2984,6 +3055,9 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     if constexpr (like_mf<DT, LIKE, NW>()) {
         if (tid >= NW * 64 - DT / 2) *reinterpret_cast<double2*>(s_mu + 2 * (tid - (NW * 64 - DT / 2))) = *reinterpret_cast<const double2*>(A.mu + 2 * (tid - (NW * 64 - DT / 2)));
     }
+    // (D = 32: the matrix operands of phase C are requested HERE - six doubles per lane.  In front of the barrier before phase C, as at
+    //  D = 64, they queue behind the workgroup's row gathers and phase C waits for them: 1 400 cycles where the MFMAs need 400)
+    MfRegs mfr = like_prefetch<DT == 32 ? DT : 0, LIKE, NW>(lane, wv, A.prec_sym);
     const int TG = A.T;                                                  // the whole ladder
     const int T = PIPE ? A.Tl : A.T;                                     // the rungs this workgroup holds
     const int W = A.W, CB = PIPE ? A.cbl : A.cb, CS = PIPE ? A.cbl_shift : A.cb_shift;
@@ -3206,7 +3280,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // (the matrix operand of phase C - D = 64 / 128 dense: five / eighteen doubles per lane out of prec_sym - requested in front of the
     //  barrier as in k_stretch_fast, in flight across it.  Rounds 4-5 requested it behind the barrier: phase C 5 600 cycles at
     //  8 x 16384 x 64 against the first launch's 1 290, tools/trace_pipe_phases.py)
-    const MfRegs mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);
+    if constexpr (DT != 32) mfr = like_prefetch<DT, LIKE, NW>(lane, wv, A.prec_sym);
     FUSED_TRACE(3);
     lds_barrier();
 #ifdef HENS_DEV_BUILD
@@ -3230,7 +3304,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
         const bool inbox = (s_flag[m] & 1) != 0;
         double acc = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) acc += s_part[w2 * TILE + m];
+        for (int w2 = 0; w2 < like_nparts<DT, LIKE, NW>(); ++w2) acc += s_part[w2 * TILE + m];
         double logl = inbox ? -0.5 * acc : A.fill;                      // ensemble.py:1486-1513
         if (logl != logl) {                                             // red_blue.py:279-281
             logl = -1e300;

@@ -1,0 +1,8 @@
+#!/bin/bash
+# config 2 A/B over any number of libraries: tools/r5_s24.sh name1 name2 ...  (ab_live/libhens_<name>.so; `ship` = the shipped one)
+R=$GRAFT_REPO_ROOT; cd $R; export PYTHONPATH=$R
+for rep in 1 2 3; do for l in "$@"; do
+  if [ $l = ship ]; then unset HENS_LIB; else export HENS_LIB=$R/ab_live/libhens_$l.so; fi
+  echo -n "$l K=20: "; python bench.py --steps 20 --warmup 5 --no-cpu --no-other 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step']*1e3,3), [round(k['avg_launch_us'],2) for k in d['roofline']['kernels']])"
+  echo -n "$l long: "; python bench.py --no-cpu --no-other 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step']*1e3,3))"
+done; done
