@@ -1374,7 +1374,9 @@ int pipe_fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs, bool mh
 //   32 x 2048 x 32  23.9 / 23.8   16 x 6144 x 32  33.5 / 34.5
 // Up to one workgroup per CU at D = 32 (two at D = 16, whose workgroups are half as heavy) the single launch wins
 // 15-19 %; with two D = 32 workgroups per CU its extra gathers and likelihoods cost what the second launch did, and the
-// profiled two-launch path stays.  The grid is W / cb workgroups (short tiles of ladders that do not divide 128 included:
+// profiled two-launch path stays.  (Round 5's last library, same columns: 4 x 4096 x 32 11.9 / 13.1, 8 x 4096 x 32 13.3 / 13.8,
+// 16 x 2048 x 32 14.0 / 14.6, 32 x 1024 x 32 15.7 / 16.5, 16 x 4096 x 16 15.2 / 15.6; 8 x 8192 x 32 19.3 / 16.4 - the rule stands, the margin
+// is 3-12 % now.)  The grid is W / cb workgroups (short tiles of ladders that do not divide 128 included:
 // 10 x 2048 x 32 15.2 / 18.5, 6 x 4096 x 32 15.0 / 18.1).
 bool iter_ok(const hens_ctx_impl* c) {
     static const bool off = getenv("HENS_NO_ITER") != nullptr;               // A/B knob: two launches per iteration

@@ -102,6 +102,31 @@ def test_eval_state_matches_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("D", [16, 32, 64, 128, 20])     # scalar-operand form / matrix pipe at three widths / rows padded to 32
+def test_eval_state_nonsymmetric_precision_and_walkers_outside_the_box(D):
+    """The device packs A_ik + A_ki (pair layout) or M_IJ = A_IJ + A_JI^T (matrix-pipe operands, hens_set_gaussian): a precision matrix
+    that is not symmetric gives the oracle's quadratic form (x - mu)^T A (x - mu) all the same.  Walkers outside the prior box - some of
+    them with huge coordinates - ride along in the tile (a walker is a column of the block products) and must not disturb their
+    neighbours: they get the fill value (ensemble.py:1486-1513), everybody else the oracle's value."""
+    T, W = 2, 320
+    R = np.random.RandomState(7)
+    mu, invcov = pu.gaussian_problem(D, True)
+    invcov = invcov + 0.05 * np.triu(R.randn(D, D), 1) * np.abs(invcov).mean()       # upper triangle only: not symmetric
+    x0 = R.uniform(-0.9, 0.9, size=(T, W, D))
+    out = R.rand(T, W) < 0.2
+    x0[out, R.randint(0, D, size=int(out.sum()))] = R.choice([1.5, -3.0, 1e300, -1e308], size=int(out.sum()))
+    o = orc.OracleSampler(x0, lambda x: orc.gaussian_log_like(x, mu, invcov), np.full(D, -1.0), np.full(D, 1.0),
+                          np.random.RandomState(1), np.random.RandomState(2), betas=orc.make_ladder(D, ntemps=T), record=False)
+    eng = pu.make_engine(o, mu, invcov)
+    eng.upload(o.x, betas=o.betas)
+    eng.eval_state()
+    _, L, P, _ = eng.download()
+    assert np.array_equal(P, o.P) and np.array_equal(np.isinf(P), out)
+    assert np.array_equal(L == -1e300, o.L == -1e300) and np.array_equal(L == -1e300, out)
+    tol.check_logl(L, o.L, what=f"hens_eval_state, non-symmetric precision, D = {D}")
+    eng.close()
+
+
 @pytest.mark.parametrize("T,W,D", [(2, 128, 5), (2, 256, 32), (3, 512, 128)])     # generic / fast / D = 128 fast kernels
 def test_diag_likelihood(T, W, D):
     o, mu, invcov = pu.make_oracle(T, W, D, box=5.0, dense=False)
