@@ -352,7 +352,12 @@ struct Queue {
         last_ka = ka + (implicit ? impl_off + std::min(sizeof(ImplicitArgs), (size_t)k.kernarg_size - impl_off) : args_size) - 1;
         p->reserved2 = 0;
         p->completion_signal.handle = signal ? done.handle : 0;
-        const uint16_t acq = (fresh && !(acq_agent_ok && own_only)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        uint16_t acq = (fresh && !(acq_agent_ok && own_only)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+#ifdef HENS_DEV_BUILD
+        // timing probe (NOT correct: another XCD's L2 may hold a stale copy of a row): no acquire fence between the launches of a call
+        static const bool acq_none = getenv("HENS_AQL_ACQ_NONE") != nullptr;
+        if (acq_none && !fresh) acq = HSA_FENCE_SCOPE_NONE;
+#endif
         const uint16_t rel = signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
         const uint16_t barrier = nobar_next ? 0u : 1u;
         nobar_next = false;
