@@ -1097,6 +1097,13 @@ int launch_fused_like(hens_ctx_impl* c, int like, const FusedArgs& f, hipEvent_t
 // the state as one record per walker (k_split1_pt, k_stretch_fast with StretchArgs::wrec) <-> by-field arrays (everything else)
 const uint32_t* iteration_keys(hens_ctx_impl* c);
 bool col_ok(const hens_ctx_impl* c);
+// The two stepping launches of one GPU on column-ordered records go out WITHOUT a release fence (hens_aql.h: norel_next): everything a
+// later launch reads they store write-through, and their waves end behind the stores' acknowledgements (hens_kernels.h: wt_store,
+// launch_end_wait).  HENS_AQL_RELEASE=1 keeps the fence (A/B knob).
+bool norel_ok(const hens_ctx_impl* c) {
+    static const bool keep = getenv("HENS_AQL_RELEASE") != nullptr;
+    return !keep && c->aql_now && c->colmode && !c->pipe.on;
+}
 bool pipe_col_ok(const hens_ctx_impl* c);
 void state_to_records(hens_ctx_impl* c) {
     if (c->packed) return;
@@ -1200,6 +1207,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
             if (c->aql_now && (nobar & 2) && c->aql.windex != c->aql.call_first) c->aql.nobar_next = true;
         }
 #endif
+        c->aql.norel_next = norel_ok(c);
         const int r = launch_stretch<MODE_STRETCH>(c, a, (c->N0 + TILE - 1) / TILE);
         c->ext_start = c->ext_stop = nullptr;
         if (r) return r;
@@ -1237,6 +1245,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         if (c->aql_now && (nobar & 1)) c->aql.nobar_next = true;
     }
 #endif
+    c->aql.norel_next = norel_ok(c);
     int r;
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like(c, LIKE_DENSE, f, e0, e1, false, c->colmode); break;

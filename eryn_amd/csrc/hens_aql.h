@@ -269,6 +269,8 @@ struct Queue {
     bool pending = false;            // packets submitted since the last drain
     bool own_only = false;           // since the last drain only this queue has touched the state (no HIP work, no host upload)
     bool fresh = true;               // the next packet is the first since the host (or the HIP stream) touched the state
+    bool norel_next = false;         // the next packet's kernel writes everything a later launch reads through to memory and waits for its
+                                     // stores (hens_kernels.h: wt_store, launch_end_wait): no release fence (not on a call's last packet)
     bool nobar_next = false;         // DEV PROBE (timing only, results wrong): the next packet goes out without the barrier bit
     std::string err;
 
@@ -358,7 +360,13 @@ struct Queue {
         static const bool acq_none = getenv("HENS_AQL_ACQ_NONE") != nullptr;
         if (acq_none && !fresh) acq = HSA_FENCE_SCOPE_NONE;
 #endif
-        const uint16_t rel = signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+        uint16_t rel = signal ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
+#ifdef HENS_DEV_BUILD
+        static const bool rel_none = getenv("HENS_AQL_REL_NONE") != nullptr;        // (timing probe, as HENS_AQL_ACQ_NONE below)
+        if (rel_none && !signal) rel = HSA_FENCE_SCOPE_NONE;
+#endif
+        if (norel_next && !signal) rel = HSA_FENCE_SCOPE_NONE;
+        norel_next = false;
         const uint16_t barrier = nobar_next ? 0u : 1u;
         nobar_next = false;
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (barrier << HSA_PACKET_HEADER_BARRIER) |

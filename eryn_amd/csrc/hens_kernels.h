@@ -284,6 +284,16 @@ __device__ __forceinline__ Tp late_kernarg(size_t off) {
 __device__ __forceinline__ void sys_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double sys_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// Write-through stores (agent scope, `sc1`): what the NEXT launch of a call reads - on whichever XCD - is written through to memory
+// by the two stepping launches of one GPU, so no line of it sits dirty in an XCD's L2 when the launch ends; every wave waits for its
+// stores' acknowledgements before it ends (launch_end_wait), and the launch's AQL packet carries NO release fence: the packet
+// processor's end-of-kernel L2 write-back cost 1.4 us per launch at config 2 with nothing to write back (round 5, LABNOTES 10.13).
+// The acquire fence at the head of the next launch stays (it drops the clean copies).
+__device__ __forceinline__ void wt_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wt_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wt_store(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void launch_end_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 
 // Flag discipline: everything a peer reads is stored with system-scope write-through stores (sys_store),
 // so raising a flag only needs those stores COMPLETE (s_waitcnt vmcnt(0)), not an L2 write-back: the
@@ -926,6 +936,12 @@ __device__ __forceinline__ void store_row16(double* p, double2 v) {
 #else
     *reinterpret_cast<double2*>(p) = v;
 #endif
+}
+// a walker record, written through: {L, P} and {loc, acc, slot, -} as two 16-byte stores
+__device__ __forceinline__ void wt_store_rec(WalkerRec* p, const WalkerRec& r) {
+    store_row16(&p->L, double2{r.L, r.P});
+    const double lo = __hiloint2double((int)r.acc, r.loc), hi = __hiloint2double(0, r.slot);
+    store_row16(reinterpret_cast<double*>(&p->loc), double2{lo, hi});
 }
 
 // Symmetric quadratic form, the share of wave WI.  psym holds, for every row pair p = 0..D/2-1,
@@ -1612,21 +1628,21 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             double* const betas_out_l = PIPE ? A.ad.betas_out : late_kernarg<double*>(AD + offsetof(AdaptArgs, betas_out));
             double* const swaps_last_l = PIPE ? A.ad.swaps_last : late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_last));
             double* const swaps_total_l = PIPE ? A.ad.swaps_total : late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_total));
-            if (e0 < T) betas_out_l[e0] = bnew0;
-            if (e1 < T) betas_out_l[e1] = bnew1;
+            if (e0 < T) wt_store(&betas_out_l[e0], bnew0);
+            if (e1 < T) wt_store(&betas_out_l[e1], bnew1);
             if (e0 < T - 1 && !ad_x) {             // (ad_x: wave ADX, the only reader of the counts then, keeps these books)
-                swaps_last_l[e0] = cnt0;
+                wt_store(&swaps_last_l[e0], cnt0);
                 // (a pipeline rank: an atomic without a return value - `+=` is a load this wave, in front of workgroup (0,0)'s first
                 //  barrier there, waits a memory round trip for: the rank's first launch 9.4 -> 8.8 us at 16 x 4096 x 32; the counts are
                 //  integers, the sum is the same double.  One GPU keeps `+=`: in the gathers' shadow it costs nothing, and the atomic made
                 //  config 2 0.1 us SLOWER - 17.40 -> 17.50, four alternations)
                 if constexpr (PIPE) atomicAdd(&swaps_total_l[e0], cnt0);
-                else swaps_total_l[e0] += cnt0;
+                else wt_store(&swaps_total_l[e0], swaps_total_l[e0] + cnt0);
             }
             if (e1 < T - 1) {
-                swaps_last_l[e1] = cnt1;
+                wt_store(&swaps_last_l[e1], cnt1);
                 if constexpr (PIPE) atomicAdd(&swaps_total_l[e1], cnt1);
-                else swaps_total_l[e1] += cnt1;
+                else wt_store(&swaps_total_l[e1], swaps_total_l[e1] + cnt1);
             }
         }
     };
@@ -1676,16 +1692,17 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
         if (blockIdx.x == 0 && blockIdx.y == 0) {
             if (g == 0 && p < T - 1) {
                 constexpr size_t AD = offsetof(StretchArgs, ad);
-                late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_last))[p] = (double)s0;
-                late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_total))[p] += (double)s0;
+                wt_store(&late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_last))[p], (double)s0);
+                double* const tot = late_kernarg<double*>(AD + offsetof(AdaptArgs, swaps_total));
+                wt_store(&tot[p], tot[p] + (double)s0);
             }
             if (A.ad.zero_after) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r)
-                    if (r * G + g < NR && p < T - 1 && u[r]) A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] = 0u;
+                    if (r * G + g < NR && p < T - 1 && u[r]) wt_store(&A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p], 0u);
             }
             if (A.ad.zero_rows)
-                for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
+                for (int e = lane; e < NR * (T - 1); e += 64) wt_store(&A.ad.zero_rows[e], 0u);
         }
     }
     auto adapt_early = [&]() {
@@ -1700,12 +1717,12 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
                 const int p = lane & (P2 - 1), g = lane / P2;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    if (r * G + g < NR && p < T - 1 && ad_u0[r]) A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p] = 0u;
-                    if (r < NR && lane + 64 < T - 1 && ad_u1[r]) A.ad.swap_part[(size_t)r * (T - 1) + lane + 64] = 0u;
+                    if (r * G + g < NR && p < T - 1 && ad_u0[r]) wt_store(&A.ad.swap_part[(size_t)(r * G + g) * (T - 1) + p], 0u);
+                    if (r < NR && lane + 64 < T - 1 && ad_u1[r]) wt_store(&A.ad.swap_part[(size_t)r * (T - 1) + lane + 64], 0u);
                 }
             }
             if (A.ad.zero_rows)                      // every workgroup reads the rows: clear the buffer of the NEXT sweep
-                for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
+                for (int e = lane; e < NR * (T - 1); e += 64) wt_store(&A.ad.zero_rows[e], 0u);
         }
         adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1, ad_x);
     };
@@ -2058,7 +2075,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int e = tid + q * NT;
-                if (e < total && adv[q]) A.ad.swap_part[e] = 0u;
+                if (e < total && adv[q]) wt_store(&A.ad.swap_part[e], 0u);
             }
         }
         if (cnt_push && A.cp_zero) {
@@ -2243,8 +2260,8 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;
             if (keep) {                                        // move.py:513-532
                 if (A.wrec) {
-                    *reinterpret_cast<double2*>(&A.wrec[gi].L) = double2{logl, newP};
-                    if (!MH) A.wrec[gi].acc = acc_old + 1u;
+                    store_row16(&A.wrec[gi].L, double2{logl, newP});             // (written through: wt_store)
+                    if (!MH) wt_store(&A.wrec[gi].acc, acc_old + 1u);
                 } else {
                     A.L[gi] = logl;
                     A.P[gi] = newP;
@@ -2324,6 +2341,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             __hip_atomic_store(A.pub_meta, (long long)A.home_off + (long long)tl * W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             pipe_raise(A.pub_flag, A.pub_value);
         }
+    if constexpr (!PIPE) launch_end_wait();        // (one GPU: this launch's packet carries no release fence - see wt_store)
     HENS_TRACE(7);
 #undef HENS_TRACE
 }
@@ -3521,8 +3539,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             A.ghome[(size_t)(late_kernarg<int32_t>(offsetof(FusedArgs, par)) * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
         WalkerRec* const wrecnew_l = late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew));
         int32_t* const locnew_l = late_kernarg<int32_t*>(offsetof(FusedArgs, locnew));
-        wrecnew_l[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);  // (the slot's own counter and index: they do not move with a walker)
-        locnew_l[di] = locc[se];
+        wt_store_rec(&wrecnew_l[di], make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot));  // (the slot's own counter and index: they do not move with a walker)
+        wt_store(&locnew_l[di], locc[se]);
     }
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
         unsigned n = 0;
@@ -3630,6 +3648,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             //  rank's NEXT launch: StretchArgs::rt_flag, k_pipe_epilogue; no grid-wide ticket here)
         }
     }
+    if constexpr (!PIPE) launch_end_wait();        // (one GPU: this launch's packet carries no release fence - see wt_store)
     FUSED_TRACE(7);
 #undef FUSED_TRACE
 }
