@@ -1097,12 +1097,12 @@ int launch_fused_like(hens_ctx_impl* c, int like, const FusedArgs& f, hipEvent_t
 // the state as one record per walker (k_split1_pt, k_stretch_fast with StretchArgs::wrec) <-> by-field arrays (everything else)
 const uint32_t* iteration_keys(hens_ctx_impl* c);
 bool col_ok(const hens_ctx_impl* c);
-// The two stepping launches of one GPU on column-ordered records go out WITHOUT a release fence (hens_aql.h: norel_next): everything a
+// The stepping launches of one GPU (k_stretch_fast + k_split1_pt in record mode, k_iter) go out WITHOUT a release fence (hens_aql.h: norel_next): everything a
 // later launch reads they store write-through, and their waves end behind the stores' acknowledgements (hens_kernels.h: wt_store,
 // launch_end_wait).  HENS_AQL_RELEASE=1 keeps the fence (A/B knob).
 bool norel_ok(const hens_ctx_impl* c) {
     static const bool keep = getenv("HENS_AQL_RELEASE") != nullptr;
-    return !keep && c->aql_now && c->colmode && !c->pipe.on;
+    return !keep && c->aql_now && !c->pipe.on;
 }
 bool pipe_col_ok(const hens_ctx_impl* c);
 void state_to_records(hens_ctx_impl* c) {
@@ -1415,6 +1415,7 @@ bool col_ok(const hens_ctx_impl* c) {
 int launch_iter_like(hens_ctx_impl* c, int like, const IterArgs& f, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(c->W / c->label_cb);
     constexpr int NW = 8;
+    c->aql.norel_next = norel_ok(c);
     return launch_by_ptr(c, ktab_iter(like, c->D, f.period != nullptr), "k_iter", grid, NW * 64, iter_lds_bytes(c->D, NW), c->aql_last, e0, e1, f);
 }
 

@@ -117,15 +117,15 @@ struct LadderFold {
         if (e0 < T) s_beta[e0] = bnew0;
         if (e1 < T) s_beta[e1] = bnew1;
         if (lead) {
-            if (e0 < T) ad.betas_out[e0] = bnew0;
-            if (e1 < T) ad.betas_out[e1] = bnew1;
+            if (e0 < T) wt_store(&ad.betas_out[e0], bnew0);        // (written through: see wt_store, hens_kernels.h)
+            if (e1 < T) wt_store(&ad.betas_out[e1], bnew1);
             if (e0 < T - 1) {
-                ad.swaps_last[e0] = c0;
-                ad.swaps_total[e0] += c0;
+                wt_store(&ad.swaps_last[e0], c0);
+                wt_store(&ad.swaps_total[e0], ad.swaps_total[e0] + c0);
             }
             if (e1 < T - 1) {
-                ad.swaps_last[e1] = c1;
-                ad.swaps_total[e1] += c1;
+                wt_store(&ad.swaps_last[e1], c1);
+                wt_store(&ad.swaps_total[e1], ad.swaps_total[e1] + c1);
             }
         }
     }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
             for (int r = 0; r < 8; ++r) { s0 += u0[r]; s1 += u1[r]; }
             for (int m = P2; m < 64; m <<= 1) s0 += __shfl_xor(s0, m);
             if (lead && A.ad.zero_rows)              // the buffer nobody reads or writes during this launch
-                for (int e = lane; e < NR * (T - 1); e += 64) A.ad.zero_rows[e] = 0u;
+                for (int e = lane; e < NR * (T - 1); e += 64) wt_store(&A.ad.zero_rows[e], 0u);
             fold.part1(A.ad, lane, (double)s0, (double)s1, b0, b1);
         } else {
             if (lane < T) sbeta[lane] = A.betas[lane];
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         }
         const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
-        A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]);
-        A.locnew[di] = locc[se];
+        wt_store_rec(&A.wrecnew[di], make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]));
+        wt_store(&A.locnew[di], locc[se]);
     }
     for (int i = 1 + tid; i < T; i += NT) {
         unsigned n = 0;
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n);
     }
     if (walking) store_accepted();
+    launch_end_wait();                       // (this launch's packet carries no release fence - see wt_store)
     ITER_TRACE(7);
 #undef ITER_TRACE
 }
