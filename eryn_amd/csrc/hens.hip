@@ -1208,6 +1208,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         }
 #endif
         c->aql.norel_next = norel_ok(c);
+        a.norel = c->aql.norel_next ? 1 : 0;
         const int r = launch_stretch<MODE_STRETCH>(c, a, (c->N0 + TILE - 1) / TILE);
         c->ext_start = c->ext_stop = nullptr;
         if (r) return r;
@@ -1246,6 +1247,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     }
 #endif
     c->aql.norel_next = norel_ok(c);
+    f.norel = c->aql.norel_next ? 1 : 0;
     int r;
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like(c, LIKE_DENSE, f, e0, e1, false, c->colmode); break;
@@ -1416,7 +1418,9 @@ int launch_iter_like(hens_ctx_impl* c, int like, const IterArgs& f, hipEvent_t e
     const dim3 grid(c->W / c->label_cb);
     constexpr int NW = 8;
     c->aql.norel_next = norel_ok(c);
-    return launch_by_ptr(c, ktab_iter(like, c->D, f.period != nullptr), "k_iter", grid, NW * 64, iter_lds_bytes(c->D, NW), c->aql_last, e0, e1, f);
+    IterArgs g = f;
+    g.norel = c->aql.norel_next ? 1 : 0;
+    return launch_by_ptr(c, ktab_iter(like, c->D, g.period != nullptr), "k_iter", grid, NW * 64, iter_lds_bytes(c->D, NW), c->aql_last, e0, e1, g);
 }
 
 int iter_iteration(hens_ctx_impl* c, int which, int ib, std::vector<hipEvent_t>* evs) {

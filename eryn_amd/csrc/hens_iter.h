@@ -51,6 +51,7 @@ struct IterArgs {
     uint64_t iter, seed;
     int32_t T, W, idx_bits, cb, cb_shift;
     int32_t acc_rows;                                         // rows of swap_acc (FusedArgs::acc_rows)
+    int32_t norel;                                            // see StretchArgs::norel
     int32_t half_rows;                                        // T * W: rows r and r ^ half belong to the same walker
     int32_t ad_on;                                            // the previous cascade's ladder adaptation rides in this launch
     AdaptArgs ad;                                             //   (every workgroup recomputes it from the accumulated counts)
@@ -475,8 +476,13 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         }
         const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
-        wt_store_rec(&A.wrecnew[di], make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]));
-        wt_store(&A.locnew[di], locc[se]);
+        if (A.norel) {                       // (see k_split1_pt's phase G)
+            wt_store_rec(&A.wrecnew[di], make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]));
+            wt_store(&A.locnew[di], locc[se]);
+        } else {
+            A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]);
+            A.locnew[di] = locc[se];
+        }
     }
     for (int i = 1 + tid; i < T; i += NT) {
         unsigned n = 0;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         if (n) atomicAdd(&A.swap_acc[(size_t)(blockIdx.x & (A.acc_rows - 1)) * (T - 1) + (i - 1)], n);
     }
     if (walking) store_accepted();
-    launch_end_wait();                       // (this launch's packet carries no release fence - see wt_store)
+    if (A.norel) launch_end_wait();          // (this launch's packet carries no release fence - see wt_store)
     ITER_TRACE(7);
 #undef ITER_TRACE
 }

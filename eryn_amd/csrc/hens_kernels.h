@@ -635,6 +635,8 @@ struct StretchArgs {
     // rule from N0 / split); `split` is then 0 for the first set, 1 for the last (every complement already sits in its home
     // row) and 2 for the ones between
     int32_t ns_x, soff_x;
+    int32_t norel;             // this launch's packet carries no release fence (hens_aql.h: norel_next): the records are written through and
+                               // every wave ends behind its stores (wt_store, launch_end_wait); 0: plain stores, the fence writes them back
     int32_t xcd_shift;         // > 0: log2(tiles per rung) + 1 - workgroups are renumbered so that an XCD (linear id mod 8) works on whole rungs
     AdaptArgs ad;
 };
@@ -2260,8 +2262,13 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;
             if (keep) {                                        // move.py:513-532
                 if (A.wrec) {
-                    store_row16(&A.wrec[gi].L, double2{logl, newP});             // (written through: wt_store)
-                    if (!MH) wt_store(&A.wrec[gi].acc, acc_old + 1u);
+                    if (PIPE || late_kernarg<int32_t>(offsetof(StretchArgs, norel))) {       // (written through: wt_store; a rank: see k_split1_pt's phase G)
+                        store_row16(&A.wrec[gi].L, double2{logl, newP});
+                        if (!MH) wt_store(&A.wrec[gi].acc, acc_old + 1u);
+                    } else {
+                        *reinterpret_cast<double2*>(&A.wrec[gi].L) = double2{logl, newP};
+                        if (!MH) A.wrec[gi].acc = acc_old + 1u;
+                    }
                 } else {
                     A.L[gi] = logl;
                     A.P[gi] = newP;
@@ -2341,7 +2348,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
             __hip_atomic_store(A.pub_meta, (long long)A.home_off + (long long)tl * W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             pipe_raise(A.pub_flag, A.pub_value);
         }
-    if constexpr (!PIPE) launch_end_wait();        // (one GPU: this launch's packet carries no release fence - see wt_store)
+    if constexpr (!PIPE) if (late_kernarg<int32_t>(offsetof(StretchArgs, norel))) launch_end_wait();        // (no release fence on this launch's packet - see wt_store)
     HENS_TRACE(7);
 #undef HENS_TRACE
 }
@@ -2999,6 +3006,7 @@ struct FusedArgs {
     uint64_t iter, seed;
     int32_t T, W, idx_bits, cb, cb_shift, ndim_active;
     int32_t acc_rows;                                         // rows of swap_acc (a power of two): workgroup b adds to row b % acc_rows
+    int32_t norel;                                            // see StretchArgs::norel
     // ---- PIPE instantiation: a rank of the ladder pipeline (T, keys, betas stay GLOBAL; the state arrays are the rank's) ----
     int32_t Tl, rung_begin;                                   // resident rungs [rung_begin, rung_begin + Tl)
     int32_t cbl, cbl_shift;                                   // columns per workgroup: 128 / Tl (a multiple of cb)
@@ -3539,8 +3547,17 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             A.ghome[(size_t)(late_kernarg<int32_t>(offsetof(FusedArgs, par)) * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
         WalkerRec* const wrecnew_l = late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew));
         int32_t* const locnew_l = late_kernarg<int32_t*>(offsetof(FusedArgs, locnew));
-        wt_store_rec(&wrecnew_l[di], make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot));  // (the slot's own counter and index: they do not move with a walker)
-        wt_store(&locnew_l[di], locc[se]);
+        // (the slot's own counter and index: they do not move with a walker.  Written through where the launch goes out without a
+        //  release fence and on a pipeline rank (HIP stream, fences kept - cheaper with nothing dirty: 8 x 16384 x 64 as a rank 52.3 ->
+        //  50.9 us, 16 x 4096 x 32 18.9 -> 18.4); plain in the MH mix's stretch iterations (HIP stream): the two halves of a record and
+        //  its neighbours merge in L2, written through they cost config 5's second launch 5 us, 60.6 -> 66.0)
+        if (PIPE || late_kernarg<int32_t>(offsetof(FusedArgs, norel))) {
+            wt_store_rec(&wrecnew_l[di], make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot));
+            wt_store(&locnew_l[di], locc[se]);
+        } else {
+            wrecnew_l[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);
+            locnew_l[di] = locc[se];
+        }
     }
     for (int i = 1 + tid; i < TE; i += NT) {                             // pair (i, i-1) -> index i-1
         unsigned n = 0;
@@ -3648,7 +3665,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             //  rank's NEXT launch: StretchArgs::rt_flag, k_pipe_epilogue; no grid-wide ticket here)
         }
     }
-    if constexpr (!PIPE) launch_end_wait();        // (one GPU: this launch's packet carries no release fence - see wt_store)
+    if constexpr (!PIPE) if (late_kernarg<int32_t>(offsetof(FusedArgs, norel))) launch_end_wait();        // (no release fence on this launch's packet - see wt_store)
     FUSED_TRACE(7);
 #undef FUSED_TRACE
 }
