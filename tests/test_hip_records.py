@@ -182,14 +182,18 @@ def test_config2_keeps_the_two_launch_path():
 @pytest.mark.parametrize("knob,T,W,D", [("HENS_NO_COL", 16, 4096, 32), ("HENS_NO_COL", 8, 2048, 64), ("HENS_NO_XCD", 16, 4096, 32),
                                         ("HENS_NO_XCD", 8, 2048, 64), ("HENS_NO_AQL", 16, 4096, 32), ("HENS_NO_AQL", 8, 4096, 32),
                                         ("HENS_NO_AQL", 10, 512, 64), ("HENS_NO_FOLD", 16, 4096, 32), ("HENS_NO_FOLD", 8, 2048, 64),
-                                        ("HENS_AQL_FLUSH", 16, 4096, 32)])
+                                        ("HENS_AQL_FLUSH", 16, 4096, 32), ("HENS_AQL_RELEASE", 16, 4096, 32), ("HENS_AQL_RELEASE", 8, 4096, 32),
+                                        ("HENS_AQL_RELEASE", 10, 2048, 32), ("HENS_AQL_RELEASE", 8, 2048, 64)])
 def test_every_kept_switch_reaches_the_default_paths_state(knob, T, W, D, tmp_path):
     """The A/B switches the library still reads select another ORDER of the same arithmetic - walker records by slot instead of by
     cascade column, plain instead of XCD-affine workgroup numbering, the HIP stream instead of the context's AQL queue - so the
     chain must be the default path's bit for bit (round 4: every kept switch is in the suite, the others are gone).
     HENS_NO_FOLD on a two-launch shape with the AQL queue on (round 5): the stand-alone adaptation is a HIP-stream kernel between two
     batches of AQL packets - the queue must drain in front of it (fused_iteration), or the ladder is adapted from half-written counts.
-    HENS_AQL_FLUSH (any value: "1" = flush register written, never read back) changes how kernel arguments are flushed, nothing else."""
+    HENS_AQL_FLUSH (any value: "1" = flush register written, never read back) changes how kernel arguments are flushed, nothing else.
+    HENS_AQL_RELEASE (round 5): the stepping launches' packets keep their release fence and the records go out as plain stores - the
+    default path (no fence: records, row tables and the adaptation's books written through, waves end behind their stores) must
+    reach the same state on the two-launch path in column and in slot order and on the one-launch path (see also tools/aql_check.py)."""
     outs = []
     for env in ({}, {knob: "1"}):
         out = str(tmp_path / f"{len(outs)}.npz")
