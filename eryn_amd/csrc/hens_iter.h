@@ -461,8 +461,9 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
 
     // ---- phase G: permuted records of the 128 slots, swap counts ------------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
-    if (tid < NEr) {
-        const int e = tid, t = e >> CS, cc = e & (CB - 1);
+    const bool paired = A.norel != 0;            // (two lanes per record, one 32-byte sector: see k_split1_pt's phase G)
+    if (paired ? tid < 2 * NEr : tid < NEr) {
+        const int e = paired ? tid >> 1 : tid, t = e >> CS, cc = e & (CB - 1);
         int st;
         if (MW == 1) {
             const uint32_t mw = smask[cc];
@@ -476,9 +477,11 @@ __global__ __launch_bounds__(NW * 64) void k_iter(const IterArgs A) {
         }
         const int se = (st << CS) + cc;
         const size_t di = (size_t)t * W + scol[e];
-        if (A.norel) {                       // (see k_split1_pt's phase G)
-            wt_store_rec(&A.wrecnew[di], make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]));
-            wt_store(&A.locnew[di], locc[se]);
+        if (paired) {
+            const int h = tid & 1;
+            const double2 v = h == 0 ? double2{Lc[se], Pc[se]} : double2{__hiloint2double(s_el[e], locc[se]), 0.0};
+            store_row16(reinterpret_cast<double*>(&A.wrecnew[di]) + 2 * h, v);
+            if (h == 1) wt_store(&A.locnew[di], locc[se]);
         } else {
             A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], (uint32_t)s_el[e]);
             A.locnew[di] = locc[se];

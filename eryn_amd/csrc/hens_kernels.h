@@ -3059,6 +3059,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     double* s_lu = s_fac + TILE;
     double* s_Lold = s_lu + TILE;
     double* s_Pold = s_Lold + TILE;
+    int2* s_own = reinterpret_cast<int2*>(s_Lold);                       // [NE] {accept counter, slot index} of slot e, phase D -> G (s_Lold / s_Pold: 2 x TILE doubles, otherwise unused)
     double* Lc = s_Pold + TILE;                                          // [NEX] cascade tables, element e = t * cb + cc
     double* Pc = Lc + NEX;
     double* lupt = Pc + NEX;                                             // [NE] log-uniform of pair T-1-t on column cc
@@ -3366,6 +3367,7 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             s_flag[m] |= 2;
         }
     }
+    if (tid < NEr) s_own[tid] = int2{(int)wr_n.acc, wr_n.slot};            // (phase G's paired record stores read them from here)
     FUSED_TRACE(5);
     lds_barrier();
 #ifdef HENS_DEV_BUILD
@@ -3527,8 +3529,8 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // ---- phase G: permuted L / P / loc of the 128 slots, swap counts ----------------------------------------------
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < TE) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
     int se_n = 0;                                                        // the element that settles in this thread's slot
-    if (tid < NEr) {
-        const int e = tid, t = e >> CS, cc = e & (CB - 1);
+    auto settles = [&](const int e) -> int {                             // element that ends up in slot e: (rung it comes from, column)
+        const int t = e >> CS, cc = e & (CB - 1);
         int st;
         if (MW == 1) {                                            // T <= 32: the whole column mask in one register
             const uint32_t mw = smask[cc];
@@ -3540,20 +3542,33 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
             st = t;
             while (bit(cc, st + 1)) ++st;
         }
-        const int se = (st << CS) + cc;
-        se_n = se;
+        return (st << CS) + cc;
+    };
+    // Written through where the launch goes out without a release fence, and on a pipeline rank (HIP stream, fences kept - cheaper
+    // with nothing dirty: 8 x 16384 x 64 as a rank 52.3 -> 50.9 us, 16 x 4096 x 32 18.9 -> 18.4): TWO lanes per record - lane 2e writes
+    // {L, P}, lane 2e + 1 {row, accept counter, slot index, -} - so that a record leaves the wave as ONE 32-byte sector (16-byte halves
+    // from one lane in two instructions are two partial-sector writes, each a read-modify-write at the memory side, and the wait for
+    // their acknowledgements is the launch's tail: 3 940 -> 1 870 cycles, config 2 16.5 -> 15.9 us per iteration; LABNOTES 10.13).  The
+    // slot's own counter and index - they do not move with a walker - come from s_own (phase D).  Plain stores in the MH mix's
+    // stretch iterations (HIP stream): there the records' halves and neighbours merge in L2.
+    const bool paired = PIPE || late_kernarg<int32_t>(offsetof(FusedArgs, norel)) != 0;
+    if (PIPE && tid < NEr) {
+        se_n = settles(tid);
+        if (has_top && (se_n >> CS) == T)                                // the hot neighbour's walker settles here, in a guest row:
+            A.ghome[(size_t)(late_kernarg<int32_t>(offsetof(FusedArgs, par)) * 2) * W + c0 + (tid & (CB - 1))] = locc[((T - 1) << CS) + (tid & (CB - 1))];   // its home = the row of the walker that went up
+    }
+    if (paired ? tid < 2 * NEr : tid < NEr) {
+        const int e = paired ? tid >> 1 : tid, t = e >> CS;
+        const int se = settles(e);
         const size_t di = (size_t)t * W + scol[e];
-        if (PIPE && has_top && st == T)                                  // the hot neighbour's walker settles here, in a guest row:
-            A.ghome[(size_t)(late_kernarg<int32_t>(offsetof(FusedArgs, par)) * 2) * W + c0 + cc] = locc[((T - 1) << CS) + cc];   // its home = the row of the walker that went up
         WalkerRec* const wrecnew_l = late_kernarg<WalkerRec*>(offsetof(FusedArgs, wrecnew));
         int32_t* const locnew_l = late_kernarg<int32_t*>(offsetof(FusedArgs, locnew));
-        // (the slot's own counter and index: they do not move with a walker.  Written through where the launch goes out without a
-        //  release fence and on a pipeline rank (HIP stream, fences kept - cheaper with nothing dirty: 8 x 16384 x 64 as a rank 52.3 ->
-        //  50.9 us, 16 x 4096 x 32 18.9 -> 18.4); plain in the MH mix's stretch iterations (HIP stream): the two halves of a record and
-        //  its neighbours merge in L2, written through they cost config 5's second launch 5 us, 60.6 -> 66.0)
-        if (PIPE || late_kernarg<int32_t>(offsetof(FusedArgs, norel))) {
-            wt_store_rec(&wrecnew_l[di], make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot));
-            wt_store(&locnew_l[di], locc[se]);
+        if (paired) {
+            const int h = tid & 1;
+            const int2 own = s_own[e];
+            const double2 v = h == 0 ? double2{Lc[se], Pc[se]} : double2{__hiloint2double(own.x, locc[se]), __hiloint2double(0, own.y)};
+            store_row16(reinterpret_cast<double*>(&wrecnew_l[di]) + 2 * h, v);
+            if (h == 1) wt_store(&locnew_l[di], locc[se]);
         } else {
             wrecnew_l[di] = make_wrec(Lc[se], Pc[se], locc[se], wr_n.acc, wr_n.slot);
             locnew_l[di] = locc[se];
