@@ -2827,7 +2827,12 @@ __global__ __launch_bounds__(1024) void k_pt_cascade(const PtArgs A) {
     // phase 1: column slots (Philox: computed in place from the rung's keys), then everything the
     // column needs - independent gathers, the log-uniform overlaps their latency
     for (int t = tid; t < T; t += NTH) sbeta[t] = A.betas[t];
-    for (int e = tid; e < (int)NE; e += NTH) {
+    // (record mode: the slot this thread reads in phase 1 is the slot it writes in phase 3 - same element e, destination = the
+    //  element's own slot - so the slot's accept counter, which stays with the slot, is kept in a register from the record load
+    //  instead of being read again in front of the store: one dependent memory round trip less at the launch's tail, round 5)
+    constexpr int PT_KEEP = 2;                                   // elements per thread covered (T <= 128: NE <= 2 x 1024)
+    uint32_t acc_keep[PT_KEEP] = {0u, 0u};
+    for (int e = tid, k = 0; e < (int)NE; e += NTH, ++k) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c < W) {
             const int slot = PHILOX ? pt_slot(A.seed, it, t, T, c, A.idx_bits, W) : A.colslot[(size_t)t * W + c];
@@ -2836,6 +2841,8 @@ __global__ __launch_bounds__(1024) void k_pt_cascade(const PtArgs A) {
             if (A.wrec) {
                 const WalkerRec wr = A.wrec[(size_t)t * W + slot];
                 Lc[e] = wr.L; Pc[e] = wr.P; locc[e] = wr.loc;
+                if (k == 0) acc_keep[0] = wr.acc;
+                if (k == 1) acc_keep[1] = wr.acc;
             } else {
                 Lc[e] = A.Lfull[(size_t)t * W + slot];
                 if (tl >= 0 && tl < A.Tl) {
@@ -2908,7 +2915,7 @@ __global__ __launch_bounds__(1024) void k_pt_cascade(const PtArgs A) {
     // carried walker settles there, and it started its fall at t + (number of consecutive swapped
     // pairs directly above).
     auto bit = [&](int cc, int i) -> bool { return (i >= 1 && i < T) && ((smask[cc * MW + (i >> 5)] >> (i & 31)) & 1u); };
-    for (int e = tid; e < (int)NE; e += NTH) {
+    for (int e = tid, k = 0; e < (int)NE; e += NTH, ++k) {
         const int t = e / PT_COLS, cc = e - t * PT_COLS, c = c0 + cc;
         if (c >= W) continue;
         int st;
@@ -2935,7 +2942,9 @@ __global__ __launch_bounds__(1024) void k_pt_cascade(const PtArgs A) {
         if (tl < 0 || tl >= A.Tl) continue;
         const size_t di = (size_t)tl * W + dslot;
         if (A.wrecnew) {
-            A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], A.wrec[di].acc);   // (the slot keeps its accept counter)
+            // (the slot keeps its accept counter; record mode holds the whole ladder: tl = t, di = this element's own record)
+            const uint32_t acc_own = (k < PT_KEEP && A.rung_begin == 0) ? (k == 0 ? acc_keep[0] : acc_keep[1]) : A.wrec[di].acc;
+            A.wrecnew[di] = make_wrec(Lc[se], Pc[se], locc[se], acc_own);
             A.locnew[di] = locc[se];
             continue;
         }
