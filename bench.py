@@ -128,7 +128,8 @@ def moved_bytes(kind, tw, D, acc):
 
 
 def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25):
-    """Per-kernel durations (HIP events on the engine's own stream, one pair per launch) -> fractions of the HBM peak.
+    """Per-kernel durations (profiled_pass: the launches' own dispatch timestamps, or HIP event pairs where the workload steps on
+    the HIP stream) -> fractions of the HBM peak.
 
     Three byte counts per launch, each divided by the same measured duration:
       frac         SURVEY 8d's algorithmic bytes, the reference's data movement: B_stretch per proposal (a written row counted
@@ -181,11 +182,83 @@ def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25):
             "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this shape, tools/profile_bench.sh; "
                               "not measured in this run)" if dom["traffic"] is not None else None,
             "bytes": "achieved / frac: SURVEY 8d's algorithmic bytes per launch (B_stretch per proposal with the written row counted "
-                     "unconditionally, B_pt per walker-step with moved rows per swap) over the launch duration measured live with "
-                     "HIP events; achieved_moved / frac_moved: the bytes this design moves (accepted rows only; a swap permutes a "
+                     "unconditionally, B_pt per walker-step with moved rows per swap) over the launch duration measured live "
+                     "(launch_clock); achieved_moved / frac_moved: the bytes this design moves (accepted rows only; a swap permutes a "
                      "36-byte record, not a row); frac_traffic: HBM bytes from the rocprofv3 counters",
             "algorithmic_bytes_per_launch": dom["bytes_8d"], "moved_bytes_per_launch": dom["bytes_moved"],
-            "avg_launch_us": dom["avg_launch_us"], "kernels": ks, "warnings": warn}
+            "avg_launch_us": dom["avg_launch_us"], "kernels": ks, "warnings": warn,
+            "launch_clock": CLOCKS.get(int(tm.get("clock", 0))), "span_us_per_iteration": tm.get("span_us_per_iteration")}
+
+
+CLOCKS = {0: None, 1: "HIP event pair per launch on the HIP stream (the queue this workload steps on in the timed blocks too)",
+          2: "dispatch timestamps of the AQL packets (hsa_amd_profiling_get_dispatch_time; same queue, packets, fences and kernel "
+             "arguments as the timed blocks)"}
+
+
+def profiled_pass(eng, steps, calls=10):
+    """Per-launch durations on the path the timed blocks ran: `calls` further calls of `steps` steps with hens_set_profiling(2) -
+    on one GPU every packet of the context's AQL queue carries a completion signal that the packet processor stamps with the
+    launch's begin and end (the figures rocprofv3's kernel trace reads); calls that step on the HIP stream anyway (MH mix, ranks)
+    get a HIP event pair per launch.  Returns the summed hens_timing fields + which clock + begin-to-end span per iteration."""
+    eng.set_profiling(2)
+    acc = None
+    span = 0.0
+    try:
+        for _ in range(max(int(calls), 1)):
+            eng.step(steps)
+            eng.synchronize()
+            tm = eng.timing()
+            span += tm["total_ms"]
+            if acc is None:
+                acc = dict(tm)
+            else:
+                for k, v in tm.items():
+                    if k != "clock":
+                        acc[k] += v
+    finally:
+        eng.set_profiling(0)
+    acc["span_us_per_iteration"] = span * 1e3 / max(acc["n_iters"], 1)
+    return acc
+
+
+def consistency(roof, ms_per_step):
+    """The per-launch durations must fit inside the driver-timed iteration they are quoted beside."""
+    tot = sum(k["avg_launch_us"] * k["launches_per_iteration"] for k in roof["kernels"])
+    roof["sum_kernel_us_per_iteration"] = tot
+    roof["timed_us_per_iteration"] = ms_per_step * 1e3
+    roof["kernels_fit_in_timed_iteration"] = bool(tot <= ms_per_step * 1e3 * 1.005)
+    if not roof["kernels_fit_in_timed_iteration"]:
+        roof.setdefault("warnings", []).append(f"per-launch durations sum to {tot:.2f} us > the timed {ms_per_step * 1e3:.2f} us per iteration: "
+                                               f"the profiled pass did not run the timed path")
+
+
+def flag_accounting(roof):
+    """SURVEY 8d charges a swapped slot with 16 D + 32 moved bytes (the reference copies rows); this design permutes a 36-byte
+    record, so at wide rows the 8d byte count exceeds what any memory system could move in the measured time.  Where that
+    happens - any kernel's or the whole path's 8d fraction above 1 - the entry's headline fractions are the counter / moved-byte
+    ones and the 8d figures stay under `accounting_exceeds_traffic`."""
+    over = [k for k in roof["kernels"] if k["frac"] > 1.0] or roof.get("whole_path_frac", 0.0) > 1.0
+    if not over:
+        roof["accounting_exceeds_traffic"] = False
+        return
+    kept = {"whole_path_frac_8d": roof.get("whole_path_frac"), "whole_path_GBps_8d": roof.get("whole_path_GBps"), "frac_8d": roof["frac"], "achieved_8d": roof["achieved"],
+            "kernels_frac_8d": {k["kernel"].split(" ")[0]: k["frac"] for k in roof["kernels"]},
+            "why": "SURVEY 8d's B_pt counts moved ROWS per swap (the reference's np.copy of every pair); this design permutes 36-byte records - "
+                   "above D = 64 the 8d bytes exceed what can move in the measured time, so the 8d fraction is not a roofline fraction here"}
+    roof["accounting_exceeds_traffic"] = True
+    roof["accounting_8d"] = kept
+    for k in roof["kernels"]:
+        k["frac_8d_flagged"] = k.pop("frac")
+        k["frac"] = k["frac_traffic"] if k.get("frac_traffic") is not None else k["frac_moved"]
+        k["frac_kind"] = "counter" if k.get("frac_traffic") is not None else "moved"
+    roof["frac"] = roof["frac_traffic"] if roof.get("frac_traffic") is not None else roof["frac_moved"]
+    roof["achieved"] = roof["frac"] * HBM_PEAK_GBS
+    roof["frac_kind"] = "counter" if roof.get("frac_traffic") is not None else "moved"
+    if "whole_path_frac" in roof:
+        roof["whole_path_frac"] = roof["whole_path_frac_moved"]
+        roof["whole_path_GBps"] = roof["whole_path_moved_GBps"]
+        roof["whole_path_frac_kind"] = "moved"
+    roof["warnings"] = [w for w in roof.get("warnings", []) if "frac = " not in w and "whole-path fraction above 1" not in w]
 
 
 def whole_path(roof, T, W, D, f_sw, acc, value):
@@ -294,21 +367,31 @@ def time_other_shape(T, W, D, steps, warmup, rosen_mix=False):
     nit = max(steps * BLOCKS, 1)
     f_sw = float(np.mean(c["swaps_total"] / W / nit))
     acc = float(c["accepted"].mean() / max(c["num_proposals"], 1))
-    eng.set_profiling(True)
-    eng.step(steps)
-    eng.synchronize()
-    tm = eng.timing()
-    eng.set_profiling(False)
+    tm = profiled_pass(eng, steps)
     eng.close()
     value = T * W * steps / dt
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
     whole_path(roof, T, W, D, f_sw, acc, value)
+    consistency(roof, dt / steps * 1e3)
+    flag_accounting(roof)
     return {"shape": f"ntemps={T}, nwalkers={W}, ndim={D}, " + ("Rosenbrock, StretchMove + GaussianMove 50/50" if rosen_mix else "dense Gaussian, StretchMove") + " + adaptive PT",
             "ms_per_step": dt / steps * 1e3, "value": value, "block_ms": [t * 1e3 for t in times],
             "cold_blocks": cold_blocks(times, steps, T * W), "stretch_acceptance": acc,
-            "swap_fraction": f_sw, "whole_path_frac": roof["whole_path_frac"], "whole_path_frac_moved": roof["whole_path_frac_moved"],
-            "kernels": [{k: v for k, v in kk.items() if k in ("kernel", "launches_per_iteration", "avg_launch_us", "frac", "frac_moved", "frac_traffic")}
-                        for kk in roof["kernels"]]}
+            "swap_fraction": f_sw, **other_roofline(roof)}
+
+
+OTHER_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_kind", "traffic", "whole_path_frac", "whole_path_frac_kind", "whole_path_frac_moved",
+              "launch_clock", "sum_kernel_us_per_iteration", "timed_us_per_iteration", "kernels_fit_in_timed_iteration",
+              "accounting_exceeds_traffic", "accounting_8d", "warnings")
+KERNEL_KEYS = ("kernel", "launches_per_iteration", "avg_launch_us", "frac", "frac_kind", "frac_8d_flagged", "frac_moved", "frac_traffic")
+
+
+def other_roofline(roof):
+    """What an `other_shapes` entry keeps of a roofline block."""
+    out = {k: roof[k] for k in OTHER_KEYS if k in roof and roof[k] not in (None, [])}
+    if "kernels" in roof:
+        out["kernels"] = [{k: v for k, v in kk.items() if k in KERNEL_KEYS} for kk in roof["kernels"]]
+    return out
 
 
 def run_single(args):
@@ -331,16 +414,14 @@ def run_single(args):
     f_sw = float(np.mean(c["swaps_total"] / W / nit)) if T > 1 else 0.0
     acc = float(c["accepted"].mean() / max(c["num_proposals"], 1))
 
-    # per-launch durations: a further pass of K steps with a HIP event pair around every launch, on the engine's stream
-    eng.set_profiling(True)
-    eng.step(args.steps)
-    eng.synchronize()
-    tm = eng.timing()
-    eng.set_profiling(False)
+    # per-launch durations: further calls of K steps on the SAME queue with a completion signal per packet (dispatch timestamps)
+    tm = profiled_pass(eng, args.steps)
     eng.close()
     value = T * W * args.steps / dt
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
     whole_path(roof, T, W, D, f_sw, acc, value)
+    consistency(roof, dt / args.steps * 1e3)
+    flag_accounting(roof)
     if not args.no_cpu:                      # (the secondary figures of the default run; --no-cpu = the bare line)
         bw = measured_copy_bandwidth()
         roof["measured_copy_GBps"] = bw       # this box's device-to-device copy rate, beside the 8 TB/s spec peak
@@ -369,9 +450,7 @@ def run_single(args):
                 out["other_shapes"][name] = {"shape": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "value": r["value"],
                                              "cold_blocks": cold_blocks([t_ / 1e3 for t_ in r["block_ms"]], args.steps, r["config"]["ntemps"] * r["config"]["nwalkers"]),
                                              "config": {k: v for k, v in r["config"].items() if k != "workload"},
-                                             "roofline": {k: v for k, v in r["roofline"].items() if k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_path_frac", "whole_path_frac_moved", "kernel")} |
-                                                         ({"kernels": [{k: v for k, v in kk.items() if k in ("kernel", "launches_per_iteration", "avg_launch_us", "frac", "frac_moved", "frac_traffic")}
-                                                                        for kk in r["roofline"]["kernels"]]} if "kernels" in r["roofline"] else {})}
+                                             "roofline": other_roofline(r["roofline"])}
             except Exception as exc:                  # noqa: BLE001  (a secondary figure must not cost the headline line)
                 out["other_shapes"][name] = {"error": f"{type(exc).__name__}: {exc}"}
         for v in out["other_shapes"].values():        # (the line is long enough: the other shapes keep their first five blocks only)
@@ -405,15 +484,14 @@ def run_cfg5(args):
     dt = float(np.median(times))
     c, m = eng.counters(), eng.mh_counters()
     f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps * BLOCKS, 1)))
-    eng.set_profiling(True)
-    eng.step(args.steps)
-    eng.synchronize()
-    tm = eng.timing()
+    tm = profiled_pass(eng, args.steps, calls=3)
     eng.close()
     value = T * W * args.steps / dt
     acc5 = float(c["accepted"].mean() / max(c["num_proposals"], 1))
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc5)
     whole_path(roof, T, W, D, f_sw, acc5, value)
+    consistency(roof, dt / args.steps * 1e3)
+    flag_accounting(roof)
     return {
         "metric": "walker-steps/sec (ntemps x nwalkers x iters/s), Rosenbrock logL, move mix", "value": value,
         "unit": "walker-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -703,14 +781,14 @@ def run_sharded(args):
     f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps * BLOCKS, 1)))
     tm = None
     if mode == "pipeline" and result is not None:     # per-launch durations of this rank's kernels
-        eng.set_profiling(True)
+        eng.set_profiling(2)                            # (a rank steps on the HIP stream: an event pair per launch)
         try:
             eng.step(args.steps)
             eng.synchronize()
             tm = eng.timing()
         except RuntimeError:
             tm = None
-        eng.set_profiling(False)
+        eng.set_profiling(0)
     dist.barrier()
     value = T * W * args.steps / dt
     out = None

@@ -34,7 +34,7 @@ class HensTiming(C.Structure):
     _fields_ = [
         ("total_ms", C.c_double), ("stretch_ms", C.c_double), ("pt_ms", C.c_double), ("plan_ms", C.c_double),
         ("n_stretch", C.c_int64), ("n_pt", C.c_int64), ("n_plan", C.c_int64), ("n_iters", C.c_int64),
-        ("fused_ms", C.c_double), ("n_fused", C.c_int64),
+        ("fused_ms", C.c_double), ("n_fused", C.c_int64), ("clock", C.c_int64),
     ]
 
 

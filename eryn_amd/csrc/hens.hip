@@ -206,7 +206,8 @@ struct hens_ctx_impl {
     int64_t trace_words = 0;
     bool tracing = false, trace_pt = false, trace_fused = false;
     int trace_rj = -1;               // k_rj launches of this mode stamp their phases (hens_debug_trace 4: in-model move, 5: birth / death)
-    bool per_kernel_events = false;
+    int per_kernel_events = 0;       // hens_set_profiling: 0 off, 1 HIP event pairs, 2 dispatch timestamps on the queue the call uses
+    bool aql_prof_total = false;     // timing.total_ms of the last call came from dispatch timestamps
     hens_timing timing{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool step_events = false;        // the last hens_step call recorded ev0 / ev1 (hens_timing::total_ms)
@@ -1208,6 +1209,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         }
 #endif
         c->aql.norel_next = norel_ok(c);
+        c->aql.prof_kind = 0;
         a.norel = c->aql.norel_next ? 1 : 0;
         const int r = launch_stretch<MODE_STRETCH>(c, a, (c->N0 + TILE - 1) / TILE);
         c->ext_start = c->ext_stop = nullptr;
@@ -1247,6 +1249,7 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     }
 #endif
     c->aql.norel_next = norel_ok(c);
+    c->aql.prof_kind = 2;
     f.norel = c->aql.norel_next ? 1 : 0;
     int r;
     switch (c->cfg.likelihood_kind) {
@@ -1420,6 +1423,7 @@ int launch_iter_like(hens_ctx_impl* c, int like, const IterArgs& f, hipEvent_t e
     c->aql.norel_next = norel_ok(c);
     IterArgs g = f;
     g.norel = c->aql.norel_next ? 1 : 0;
+    c->aql.prof_kind = 3;
     return launch_by_ptr(c, ktab_iter(like, c->D, g.period != nullptr), "k_iter", grid, NW * 64, iter_lds_bytes(c->D, NW), c->aql_last, e0, e1, g);
 }
 
@@ -2525,9 +2529,17 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     c->N0 = (W + 1) / 2;
     c->win_count = 0;
     const bool pt = has_pt(c);
-    const bool prof = c->per_kernel_events;
     const bool fused = fused_ok(c);
     const bool iter1 = iter_ok(c);
+    static const bool ev_env = getenv("HENS_STEP_EVENTS") != nullptr;
+    // Which queue: the two-launch iteration of one GPU goes to the context's AQL queue (hens_aql.h) unless something in this call
+    // needs the HIP stream between its launches (per-kernel events, traces, the MH move of a mix).
+    const bool aql_able = c->aql_on && fused && !piped && !c->tracing && c->mh_kind < 0 && n_iters > 0;
+    // per-launch durations: mode 1 = HIP event pairs (forces the HIP stream); mode 2 = the launches' own dispatch timestamps on
+    // the queue the call would use anyway - the AQL queue's packets (hens_aql.h: set_prof), HIP events where the call steps on
+    // the HIP stream whatever the mode (pipeline ranks, the MH mix)
+    const bool aprof = c->per_kernel_events == 2 && aql_able && !ev_env && n_iters <= 8192;
+    const bool prof = c->per_kernel_events == 1 || (c->per_kernel_events == 2 && !aprof);
     if (piped && !c->pipe.fused_decided) {         // (every rank reaches the same verdict: pipe_fused_possible)
         c->pipe.fused = pipe_fused_possible(c);
         c->pipe.fused_decided = true;
@@ -2544,11 +2556,10 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     // (an event pair around the call - total_ms of hens_get_timing - only when timing is asked for: per-kernel profiling or
     //  HENS_STEP_EVENTS=1.  A record is a barrier packet in front of the first launch and one more behind the last: a short
     //  call - the driver times blocks of 20 iterations - pays for both.)
-    static const bool ev_env = getenv("HENS_STEP_EVENTS") != nullptr;
     c->step_events = prof || ev_env;
-    // Which queue: the two-launch iteration of one GPU goes to the context's AQL queue (hens_aql.h) unless something in this call
-    // needs the HIP stream between its launches (per-kernel events, traces, the MH move of a mix).
-    const bool use_aql = c->aql_on && fused && !piped && !c->step_events && !c->tracing && c->mh_kind < 0 && n_iters > 0;
+    const bool use_aql = aql_able && !c->step_events;
+    if (c->aql_on && c->aql.prof != aprof && !c->aql.set_prof(aprof)) return fail(c, HENS_ERR_HIP, "AQL dispatch timestamps: %s", c->aql.err.c_str());
+    if (aprof) (void)c->aql.set_prof(true);       // (clears the last call's records)
     if (use_aql) {
         c->aql.own_only = !c->hip_dirty;
         if (c->hip_dirty) {                      // the HIP stream may still be working on the state (upload, evaluation, ...)
@@ -2658,7 +2669,30 @@ int hens_step(hens_ctx* ctx, int64_t n_iters) {
     HIPCHK(c, hipGetLastError());
     if (c->step_events) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timing.n_iters = n_iters;
+    if (aprof) {
+        // the call's packets have their own completion signals: wait for the queue, read the stamps
+        const bool dirty = c->hip_dirty;
+        if ((r = aql_settle(c))) return r;
+        c->hip_dirty = dirty;
+        std::vector<int> kinds;
+        if (!c->aql.collect_prof(c->launch_us, kinds)) return fail(c, HENS_ERR_HIP, "AQL dispatch timestamps: %s", c->aql.err.c_str());
+        std::vector<double> keep;
+        for (size_t k = 0; k < kinds.size(); ++k) {
+            const double ms = (c->launch_us[2 * k + 1] - c->launch_us[2 * k]) * 1e-3;
+            if (kinds[k] < 0) continue;              // (round-key window plans: not a stepping launch)
+            keep.push_back(c->launch_us[2 * k]);
+            keep.push_back(c->launch_us[2 * k + 1]);
+            if (kinds[k] == 0) { c->timing.stretch_ms += ms; c->timing.n_stretch += 1; }
+            else if (kinds[k] == 1) { c->timing.pt_ms += ms; c->timing.n_pt += 1; }
+            else { c->timing.fused_ms += ms; c->timing.n_fused += 1; }
+        }
+        if (!c->launch_us.empty()) c->timing.total_ms = (c->launch_us.back() - c->launch_us.front()) * 1e-3;
+        c->launch_us.swap(keep);
+        c->aql_prof_total = true;
+        c->timing.clock = 2;
+    } else c->aql_prof_total = false;
     if (prof) {
+        c->timing.clock = 1;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms = 0;
         c->launch_us.clear();
@@ -2781,7 +2815,8 @@ int hens_set_iteration(hens_ctx* ctx, int64_t iter) {
 int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events) {
     hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
-    c->per_kernel_events = per_kernel_events != 0;
+    if (per_kernel_events < 0 || per_kernel_events > 2) return fail(c, HENS_ERR_INVALID, "hens_set_profiling: mode 0, 1 or 2");
+    c->per_kernel_events = per_kernel_events;
     return HENS_OK;
 }
 
@@ -2792,7 +2827,7 @@ int hens_get_timing(hens_ctx* ctx, hens_timing* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0;
     if (c->timing.n_iters > 0 && c->step_events) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->timing.total_ms = ms;
+    if (!c->aql_prof_total) c->timing.total_ms = ms;      // (dispatch-timestamp mode: first begin to last end, set by hens_step)
     *out = c->timing;
     return HENS_OK;
 }

@@ -272,6 +272,14 @@ struct Queue {
     bool norel_next = false;         // the next packet's kernel writes everything a later launch reads through to memory and waits for its
                                      // stores (hens_kernels.h: wt_store, launch_end_wait): no release fence (not on a call's last packet)
     bool nobar_next = false;         // DEV PROBE (timing only, results wrong): the next packet goes out without the barrier bit
+    // Dispatch timestamps (hens_set_profiling(ctx, 2), round 6): every packet of a profiled call carries a completion signal of its
+    // own and the packet processor stamps the launch's begin and end into it (hsa_amd_profiling_*: what rocprofv3's kernel trace
+    // reads) - per-launch durations of the SAME packets, fences and queue the timed calls use, not of a HIP-stream stand-in.
+    bool prof = false;
+    int prof_kind = -1;              // tag of the next packet (hens_step: 0 first launch, 2 second launch, 3 one-launch iteration; -1 other)
+    std::vector<hsa_signal_t> prof_pool;
+    size_t prof_used = 0;
+    std::vector<int> prof_kinds;
     std::string err;
 
     bool create(Device& d) {
@@ -313,8 +321,37 @@ struct Queue {
         rung = windex;
         return true;
     }
+    bool set_prof(bool on) {
+        if (!q) return false;
+        if (on == prof) { if (on) { prof_used = 0; prof_kinds.clear(); } return true; }
+        if (!drain(30.0)) return false;
+        if (hsa_amd_profiling_set_profiler_enabled(q, on ? 1 : 0) != HSA_STATUS_SUCCESS) { err = "hsa_amd_profiling_set_profiler_enabled failed"; return false; }
+        prof = on;
+        prof_used = 0;
+        prof_kinds.clear();
+        return true;
+    }
+    // begin / end of every profiled packet since set_prof(true), in us after the first one's begin (call after drain)
+    bool collect_prof(std::vector<double>& begin_end_us, std::vector<int>& kinds) {
+        begin_end_us.clear();
+        kinds.clear();
+        uint64_t freq = 0;
+        if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &freq) != HSA_STATUS_SUCCESS || freq == 0) { err = "no HSA timestamp frequency"; return false; }
+        uint64_t t0 = 0;
+        for (size_t i = 0; i < prof_used; ++i) {
+            hsa_amd_profiling_dispatch_time_t t{};
+            if (hsa_amd_profiling_get_dispatch_time(dev->agent, prof_pool[i], &t) != HSA_STATUS_SUCCESS || t.end < t.start) { err = "hsa_amd_profiling_get_dispatch_time failed"; return false; }
+            if (i == 0) t0 = t.start;
+            begin_end_us.push_back((double)(int64_t)(t.start - t0) * 1e6 / (double)freq);
+            begin_end_us.push_back((double)(int64_t)(t.end - t0) * 1e6 / (double)freq);
+            kinds.push_back(prof_kinds[i]);
+        }
+        return true;
+    }
     void destroy() {
         if (q) { (void)drain(5.0); (void)hsa_queue_destroy(q); q = nullptr; }
+        for (hsa_signal_t s : prof_pool) (void)hsa_signal_destroy(s);
+        prof_pool.clear();
         if (done.handle) { (void)hsa_signal_destroy(done); done.handle = 0; }
         if (kernarg) { (void)hsa_amd_memory_pool_free(kernarg); kernarg = nullptr; }
     }
@@ -353,7 +390,18 @@ struct Queue {
         p->kernarg_address = ka;
         last_ka = ka + (implicit ? impl_off + std::min(sizeof(ImplicitArgs), (size_t)k.kernarg_size - impl_off) : args_size) - 1;
         p->reserved2 = 0;
-        p->completion_signal.handle = signal ? done.handle : 0;
+        if (prof) {                  // (the call's completion signal then rides on a barrier packet behind its last launch: drain())
+            if (prof_used == prof_pool.size()) {
+                hsa_signal_t s{};
+                if (hsa_signal_create(1, 0, nullptr, &s) != HSA_STATUS_SUCCESS) { err = "hsa_signal_create failed (profiling)"; return false; }
+                prof_pool.push_back(s);
+            }
+            hsa_signal_store_relaxed(prof_pool[prof_used], 1);
+            p->completion_signal = prof_pool[prof_used++];
+            prof_kinds.push_back(prof_kind);
+            prof_kind = -1;
+        } else
+            p->completion_signal.handle = signal ? done.handle : 0;
         uint16_t acq = (fresh && !(acq_agent_ok && own_only)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
 #ifdef HENS_DEV_BUILD
         // timing probe (NOT correct: another XCD's L2 may hold a stale copy of a row): no acquire fence between the launches of a call
@@ -372,8 +420,8 @@ struct Queue {
         const uint16_t header = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (barrier << HSA_PACKET_HEADER_BARRIER) |
                                            (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
         const uint16_t setup = (uint16_t)(3u << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
-        if (signal) hsa_signal_add_relaxed(done, 1);                  // (the packet's completion takes the 1 back off)
-        unsignalled = !signal;
+        if (signal && !prof) hsa_signal_add_relaxed(done, 1);         // (the packet's completion takes the 1 back off)
+        unsignalled = !signal || prof;
         __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
         windex += 1;
         packets += 1;

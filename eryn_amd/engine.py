@@ -269,7 +269,9 @@ class HipEnsemble:
         return out
 
     def set_profiling(self, on):
-        check(self.lib.hens_set_profiling(self.ctx, int(bool(on))), self.ctx)
+        """0 / False off; 1 / True a HIP event pair per launch (HIP stream); 2 the launches' own dispatch timestamps on the queue
+        the call uses anyway (include/hipensemble.h: hens_set_profiling)."""
+        check(self.lib.hens_set_profiling(self.ctx, int(on)), self.ctx)
 
     def timing(self):
         t = HensTiming()

@@ -191,7 +191,12 @@ int hens_get_counters(hens_ctx* ctx, double* accepted, int64_t* num_proposals,
 int hens_reset_counters(hens_ctx* ctx);
 int hens_set_adapt_time(hens_ctx* ctx, int64_t t);
 
-/* Timing of the most recent hens_step call, from hipEvents on the context's stream.
+/* Timing of the most recent hens_step call.  hens_set_profiling(ctx, mode): 0 off; 1 a HIP event pair around every launch
+ * (forces the call onto the HIP stream); 2 (round 6) the launches' own dispatch timestamps on the queue the call uses anyway -
+ * on one GPU the context's AQL queue, same packets, fences and kernel arguments as an untimed call, each packet with a
+ * completion signal the packet processor stamps (hsa_amd_profiling_get_dispatch_time: what rocprofv3's kernel trace reads);
+ * calls that step on the HIP stream whatever the mode (pipeline ranks, the Gaussian move of a mix) fall back to event pairs.
+ * hens_timing::clock says which one the figures came from.
  *   total_ms      wall time of the whole call on the device (0 unless per-kernel profiling is on or HENS_STEP_EVENTS=1: the
  *                 event pair costs a short call two barrier packets)
  *   stretch_ms    summed duration of the stretch kernels, n_stretch = their count
@@ -209,6 +214,7 @@ typedef struct hens_timing {
     int64_t n_iters;
     double fused_ms;          /* launches that run the second half-step and the cascade together (k_split1_pt) */
     int64_t n_fused;
+    int64_t clock;            /* 0 none, 1 HIP event pairs on the HIP stream, 2 dispatch timestamps of the AQL packets */
 } hens_timing;
 int hens_set_profiling(hens_ctx* ctx, int32_t per_kernel_events);
 int hens_get_timing(hens_ctx* ctx, hens_timing* out);

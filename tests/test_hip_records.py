@@ -223,3 +223,91 @@ def test_cascade_counts_accumulated_or_per_workgroup_same_chain(T, W, D, like, t
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(dict(np.load(out)))
     _assert_same(outs[0], outs[1], f"({T},{W},{D}) MH mix: accumulated counts vs HENS_PT_NO_ACC=1")
+
+
+# ---- round 6: the fence-free stepping launches' guard inside -m gpu -------------------------------------------
+_LONG_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.test_hip_records import _engine, _snapshot
+T, W, D, use_mh, like, n = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
+eng, *_ = _engine(T, W, D, like_kind=like)
+if use_mh:
+    # a call with a Gaussian move in the mix steps on the HIP stream as a whole (hens_step: use_aql): AQL queue -> HIP stream ->
+    # AQL queue -> HIP stream -> AQL queue, the walker records handed over in record mode every time
+    mh = ("iso", 0.05 if like == "rosen" else 0.3, 0.5)
+    eng.step(2); eng.step(n // 4)
+    eng.set_mh_proposal(*mh); eng.step(n // 4)
+    eng.set_mh_proposal(None, None, 0.0); eng.step(n // 4)
+    eng.set_mh_proposal(*mh); eng.step(7)
+    eng.set_mh_proposal(None, None, 0.0); eng.step(n - 3 * (n // 4))
+else:
+    eng.step(2); eng.step(n // 2); eng.step(n - n // 2)
+np.savez(sys.argv[8], **_snapshot(eng, bool(use_mh)))
+"""
+# D = 128 dense; Rosenbrock 4 x 8192 x 128 (one GPU's share of config 5); a short-tile ladder (10 rungs: slot order); a shape that
+# steps in ONE launch per iteration (k_iter); calls with and without a Gaussian move in the mix in turn (AQL queue <-> HIP stream)
+_LONG_SHAPES = [(8, 1024, 128, 0, "dense"), (4, 8192, 128, 0, "rosen"), (10, 2048, 32, 0, "dense"), (8, 4096, 32, 0, "dense"),
+                (16, 1024, 32, 1, "dense"), (4, 2048, 128, 1, "rosen")]
+_LONG_ITERS = 2000
+_long_default = {}
+
+
+def _long_run(shape, env, tmp_path, tag):
+    T, W, D, use_mh, like = shape
+    out = str(tmp_path / f"{tag}.npz")
+    e = dict(os.environ, **env)
+    for k in ("HENS_AQL_RELEASE", "HENS_NO_AQL"):
+        if k not in env:
+            e.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _LONG_WORKER, ROOT, str(T), str(W), str(D), str(use_mh), like, str(_LONG_ITERS), out],
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize("knob", ["HENS_AQL_RELEASE", "HENS_NO_AQL"])
+@pytest.mark.parametrize("shape", _LONG_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_fence_free_launches_reach_the_fenced_paths_state_over_2000_iterations(knob, shape, tmp_path):
+    """The stepping launches of one GPU carry no release fence (hens_aql.h: norel_next): every store a later launch reads is
+    written through and every wave ends behind its stores' acknowledgements - an invariant of the kernels' code that nothing
+    enforces statically.  This is its guard: 2 000 iterations on each shape class the default path serves, against the same
+    chain with the fence kept (HENS_AQL_RELEASE=1: plain record stores, release at the end of every packet) and against the HIP
+    stream (HENS_NO_AQL=1: the runtime's own fences), final positions, log-probabilities, ladder and counters bit for bit.  One
+    stale line read on another XCD anywhere in 2 000 iterations and the chains part."""
+    if shape not in _long_default:
+        _long_default[shape] = _long_run(shape, {}, tmp_path, "default")
+    other = _long_run(shape, {knob: "1"}, tmp_path, knob)
+    _assert_same(_long_default[shape], other, f"{shape} default vs {knob}=1 after {_LONG_ITERS} iterations")
+
+
+@pytest.mark.parametrize("T,W,D,one", [(16, 4096, 32, False), (8, 2048, 64, False), (8, 4096, 32, True)])
+def test_dispatch_timestamps_time_the_same_chain_on_the_same_queue(T, W, D, one):
+    """hens_set_profiling(ctx, 2) (round 6): per-launch durations from the AQL packets' own dispatch timestamps.  The profiled
+    call must (a) stay on the AQL queue (clock == 2), (b) count one first and one second launch per iteration (or one k_iter
+    launch), (c) report durations that fit inside the call's begin-to-end span, and (d) leave the chain untouched: the state
+    after profiled + plain calls equals the state after plain calls only."""
+    a, *_ = _engine(T, W, D)
+    b, *_ = _engine(T, W, D)
+    a.step(7)
+    a.set_profiling(2)
+    a.step(20)
+    tm = a.timing()
+    lt = a.launch_times()
+    a.set_profiling(0)
+    a.step(5)
+    b.step(7); b.step(20); b.step(5)
+    _assert_same(_snapshot(a), _snapshot(b), f"({T},{W},{D}) profiled call vs plain call")
+    assert tm["clock"] == 2, "the profiled call left the AQL queue"
+    assert tm["n_iters"] == 20
+    if one:
+        assert tm["n_stretch"] == 0 and tm["n_fused"] == 20
+    else:
+        assert tm["n_stretch"] == 20 and tm["n_fused"] == 20
+    n = tm["n_stretch"] + tm["n_fused"]
+    assert lt.shape == (n, 2)
+    assert np.all(lt[:, 1] > lt[:, 0]) and np.all(lt[1:, 0] >= lt[:-1, 1] - 1e-3), "launches of one queue with barrier bits do not overlap"
+    busy = (tm["stretch_ms"] + tm["fused_ms"]) * 1e3
+    assert 0 < busy <= tm["total_ms"] * 1e3 * 1.0001
+    assert 1.0 < busy / 20 < 200.0, f"implausible per-iteration kernel time {busy / 20:.2f} us"
+    a.close(); b.close()
