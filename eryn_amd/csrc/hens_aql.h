@@ -276,6 +276,9 @@ struct Queue {
     // own and the packet processor stamps the launch's begin and end into it (hsa_amd_profiling_*: what rocprofv3's kernel trace
     // reads) - per-launch durations of the SAME packets, fences and queue the timed calls use, not of a HIP-stream stand-in.
     bool prof = false;
+    bool prof_enabled = false;       // the queue stamps packets that carry a completion signal: switched on when the queue is created (as
+                                     // HIP's runtime does for its own queues) - switched on later, between two calls, the packet processor
+                                     // went on with the queue descriptor it had and the first profiled call read zeros (round 6, session 1)
     int prof_kind = -1;              // tag of the next packet (hens_step: 0 first launch, 2 second launch, 3 one-launch iteration; -1 other)
     std::vector<hsa_signal_t> prof_pool;
     size_t prof_used = 0;
@@ -319,13 +322,17 @@ struct Queue {
         __builtin_ia32_sfence();
         windex = hsa_queue_load_write_index_relaxed(q);
         rung = windex;
+        if (!getenv("HENS_AQL_PROF_LATE") && hsa_amd_profiling_set_profiler_enabled(q, 1) == HSA_STATUS_SUCCESS) prof_enabled = true;
         return true;
     }
     bool set_prof(bool on) {
         if (!q) return false;
         if (on == prof) { if (on) { prof_used = 0; prof_kinds.clear(); } return true; }
         if (!drain(30.0)) return false;
-        if (hsa_amd_profiling_set_profiler_enabled(q, on ? 1 : 0) != HSA_STATUS_SUCCESS) { err = "hsa_amd_profiling_set_profiler_enabled failed"; return false; }
+        if (on && !prof_enabled) {
+            if (hsa_amd_profiling_set_profiler_enabled(q, 1) != HSA_STATUS_SUCCESS) { err = "hsa_amd_profiling_set_profiler_enabled failed"; return false; }
+            prof_enabled = true;
+        }
         prof = on;
         prof_used = 0;
         prof_kinds.clear();
@@ -340,7 +347,7 @@ struct Queue {
         uint64_t t0 = 0;
         for (size_t i = 0; i < prof_used; ++i) {
             hsa_amd_profiling_dispatch_time_t t{};
-            if (hsa_amd_profiling_get_dispatch_time(dev->agent, prof_pool[i], &t) != HSA_STATUS_SUCCESS || t.end < t.start) { err = "hsa_amd_profiling_get_dispatch_time failed"; return false; }
+            if (hsa_amd_profiling_get_dispatch_time(dev->agent, prof_pool[i], &t) != HSA_STATUS_SUCCESS || t.end <= t.start) { err = "hsa_amd_profiling_get_dispatch_time: no timestamps in a profiled packet's signal"; return false; }
             if (i == 0) t0 = t.start;
             begin_end_us.push_back((double)(int64_t)(t.start - t0) * 1e6 / (double)freq);
             begin_end_us.push_back((double)(int64_t)(t.end - t0) * 1e6 / (double)freq);
