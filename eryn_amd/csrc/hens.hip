@@ -188,6 +188,7 @@ struct hens_ctx_impl {
     double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
     int64_t rj_tm_ndata = 0;
     bool rj_tm_valid = false;
+    bool rj_tm_drift = false;        // hens_rj_step has updated the resident templates by +- a leaf since their last full evaluation
     int rj_st_ns = 0;                       // hens_rj_stretch_split: walkers of the half being moved
     unsigned* rj_ad_flag = nullptr;  // the folded adaptation's "ladder published" word (RjArgs::ad_flag), serial of the last folding launch
     uint32_t rj_ad_serial = 0;
@@ -1104,7 +1105,7 @@ bool col_ok(const hens_ctx_impl* c);
 // launch_end_wait).  HENS_AQL_RELEASE=1 keeps the fence (A/B knob).
 bool norel_ok(const hens_ctx_impl* c) {
     static const bool keep = getenv("HENS_AQL_RELEASE") != nullptr;
-    return !keep && c->aql_now && !c->pipe.on;
+    return ROWSTORE_WRITE_THROUGH && !keep && c->aql_now && !c->pipe.on;      // (rows must leave write-through: hens_kernels.h)
 }
 bool pipe_col_ok(const hens_ctx_impl* c);
 void state_to_records(hens_ctx_impl* c) {
@@ -1830,7 +1831,8 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
     if (cfg->ntemps > 4096) return fail(nullptr, HENS_ERR_UNSUPPORTED, "ntemps > 4096 not supported");
     if (cfg->ndim_active < 0 || cfg->ndim_active > cfg->ndim)
         return fail(nullptr, HENS_ERR_INVALID, "ndim_active must be 0 (= ndim) or in [1, ndim]");
-    if (!cfg->live_dangerously && cfg->nwalkers < 2 * (cfg->ndim_active ? cfg->ndim_active : cfg->ndim))   // red_blue.py:108-114
+    // (leaf-packing records: a record is wider than the walker's coordinates - its red / blue move checks for itself, hens_rj_stretch_split)
+    if (!cfg->live_dangerously && cfg->likelihood_kind != HENS_LIKE_TEMPLATE && cfg->nwalkers < 2 * (cfg->ndim_active ? cfg->ndim_active : cfg->ndim))   // red_blue.py:108-114
         return fail(nullptr, HENS_ERR_TOO_FEW_WALKERS,
                     "It is unadvisable to use a red-blue move with fewer walkers than twice the number of "
                     "dimensions. If you would like to do this, please set live_dangerously to True.");
@@ -2223,6 +2225,18 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     state_to_fields(c);                       // (hens_step leaves the state in record mode)
     flush_adapt(c);
     const size_t TW = (size_t)c->Tl * c->W;
+    // Leaf-packing contexts with resident templates (round 6): what the caller is about to hold is what a resumed chain
+    // would start from - exact templates and log-likelihoods, a function of the coordinates.  If hens_rj_step has updated the
+    // templates by +- one leaf since their last full evaluation, that evaluation runs HERE, in front of the copy: the State the
+    // caller stores carries the very log-likelihoods the device goes on with, and the next hens_rj_step call finds its templates
+    // valid (round 5 invalidated them behind the copy: the stored log_like was the +- value the device then replaced, and every
+    // stored step paid the evaluation at the head of the next call instead).
+    if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE && (x || logl) && c->rj_tm && c->rj_tm_valid && c->rj_tm_drift) {
+        int r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        if (r) return r;
+        c->rj_tm_drift = false;
+        if ((r = check_flags(c, true))) return r;
+    }
     if (x) {
         hipLaunchKernelGGL(k_gather_rows, dim3(grid_for((int64_t)TW * c->D)), dim3(256), 0, c->stream, c->pool,
                            c->loc[c->cur], c->xtmp, (int64_t)TW, c->D, guest_delta(c));
@@ -2232,9 +2246,6 @@ int hens_download_state(hens_ctx* ctx, double* x, double* logl, double* logp, do
     if (logp) HIPCHK(c, hipMemcpyAsync(logp, c->P[c->cur], TW * 8, hipMemcpyDeviceToHost, c->stream));
     if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas[c->bcur], (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // leaf-packing contexts: what the caller now holds is what a resumed chain would start from - the next hens_rj_step call
-    // re-evaluates the resident templates and log-likelihoods from the coordinates, as it does after an upload (see hens_rj_step)
-    if (c->cfg.likelihood_kind == HENS_LIKE_TEMPLATE && (x || logl)) c->rj_tm_valid = false;
     return HENS_OK;
 }
 
@@ -2248,6 +2259,7 @@ int hens_eval_state(hens_ctx* ctx) {
         r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         if (r) return r;
         c->rj_tm_valid = c->rj_tm != nullptr;
+        c->rj_tm_drift = false;
         r = check_flags(c, true);
         if (r) return r;
         c->have_logs = true;
@@ -3089,8 +3101,9 @@ int hens_rj_stretch_split(hens_ctx* ctx, int32_t split, const uint8_t* labels, c
     if (split < 0 || split > 1) return fail(c, HENS_ERR_INVALID, "split must be 0 or 1 (two sets)");
     if (split != c->expect_split) return fail(c, HENS_ERR_STATE, "split calls must run 0, 1 in order (expected %d)", c->expect_split);
     const int Tl = c->Tl, W = c->W, nb = c->rj.nb;
-    if (W < 2 * c->rj.ind_off)                                                      // red_blue.py:103-114 (every slot of every branch counts)
-        return fail(c, HENS_ERR_TOO_FEW_WALKERS, "It is unadvisable to use a red-blue move with fewer walkers than twice the number of dimensions.");
+    if (!c->cfg.live_dangerously && W < 2 * c->rj.ind_off)                          // red_blue.py:103-114 (every slot of every branch counts)
+        return fail(c, HENS_ERR_TOO_FEW_WALKERS, "It is unadvisable to use a red-blue move with fewer walkers than twice the number of dimensions. "
+                                                 "If you would like to do this, please set live_dangerously to True.");
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
     state_to_fields(c);
     flush_adapt(c);
@@ -3224,6 +3237,7 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     if (c->rj_tm && !c->rj_tm_valid && n_iters > 0) {
         if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0))) return r;
         c->rj_tm_valid = true;
+        c->rj_tm_drift = false;
         fresh = true;
     }
     static const bool fold_off = getenv("HENS_NO_FOLD") != nullptr;           // A/B knob: k_adapt behind every cascade
@@ -3237,9 +3251,10 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     } defer{c};
     c->rj_defer_adapt = !fold_off && c->rj_tm != nullptr;
     for (int64_t i = 0; i < n_iters; ++i) {
-        if (c->rj_tm && c->iter % RJ_REFRESH == RJ_REFRESH - 1 && !fresh)
+        if (c->rj_tm && c->iter % RJ_REFRESH == RJ_REFRESH - 1 && !fresh && c->rj_tm_drift)
             if ((r = rj_launch(c, RJ_MODE_EVAL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0))) return r;
         fresh = false;
+        c->rj_tm_drift = c->rj_tm != nullptr;
         // in-model Gaussian move on the packed leaves, then swaps + adaptation (mh.py:190-191)
         if ((r = rj_launch(c, RJ_MODE_MH, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tmode))) return r;
         c->rj_num_mh += 1;

@@ -406,9 +406,9 @@ struct Queue {
             hsa_signal_store_relaxed(prof_pool[prof_used], 1);
             p->completion_signal = prof_pool[prof_used++];
             prof_kinds.push_back(prof_kind);
-            prof_kind = -1;
         } else
             p->completion_signal.handle = signal ? done.handle : 0;
+        prof_kind = -1;              // (a tag holds for ONE packet, profiled or not)
         uint16_t acq = (fresh && !(acq_agent_ok && own_only)) ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_AGENT;
 #ifdef HENS_DEV_BUILD
         // timing probe (NOT correct: another XCD's L2 may hold a stale copy of a row): no acquire fence between the launches of a call

@@ -938,6 +938,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef HENS_ROWSTORE
 #define HENS_ROWSTORE 1
 #endif
+// The stepping launches of one GPU carry no release fence (hens_aql.h: norel_next; hens.hip: norel_ok) BECAUSE a row leaves as a
+// write-through store: with HENS_ROWSTORE 0 or 2 (A/B libraries) rows would sit dirty in one XCD's L2 and the next launch would
+// read stale data on another - norel_ok() asks this constant and keeps the fence then.
+constexpr bool ROWSTORE_WRITE_THROUGH = HENS_ROWSTORE == 1;
 typedef double dvec2 __attribute__((ext_vector_type(2)));
 // system scope (sc0 sc1): written through to memory - for rows a peer GPU reads (an agent-scope store may sit
 // dirty in this GPU's L2, which a read arriving over xGMI does not probe)

@@ -573,7 +573,13 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
                 const double dx = t0 - bb;
                 if (v1 >= 0.0) {
                     double e = rj_exp_neg(-(dx * dx) * v0, s_tab);
-                    double r = rj_exp_neg(-((2 * dx) * h + h * h) * v0, s_tab);
+                    // (r_0's exponent is positive while the points approach the centre; a centre far outside the data grid with |c|
+                    //  close to h takes it past 709 - r_0 = inf while e_0 has underflowed to 0, 0 x inf = NaN.  Whenever e_0 > 0 the
+                    //  exponent is below 700 (e_0 > 0: |dx| < 38.6 c; exponent > 700: |dx| > 700 c^2 / h >= 700 c), so the clamp
+                    //  changes no value: it keeps r_0 finite where every product is 0 anyway.  ADVICE r5.)
+                    double xr = -((2 * dx) * h + h * h) * v0;
+                    xr = xr > 700.0 ? 700.0 : xr;
+                    double r = rj_exp_neg(xr, s_tab);
                     out[0] += sg * (a * e);
 #pragma unroll
                     for (int k = 1; k < RJ_PPL; ++k) {

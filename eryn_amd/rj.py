@@ -48,7 +48,7 @@ class _TemplateLikelihood:
 
 class RJEngine:
     def __init__(self, ntemps, nwalkers, branches, t, y, sigma, seed=0, device_id=0, adaptive=True,
-                 adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1, fill_value=-1e300, a=2.0):
+                 adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1, fill_value=-1e300, a=2.0, live_dangerously=False):
         self.branches = list(branches)
         if not 1 <= len(self.branches) <= 4:
             raise NotImplementedError("1 to 4 branches")
@@ -60,7 +60,7 @@ class RJEngine:
         # the engine's prior box is unused on records; HipEnsemble wants one
         self.eng = HipEnsemble(self.T, self.W, self.RW, _TemplateLikelihood(self.RW), -1.0, 1.0, tempered=True,
                                adaptive=adaptive, adaptation_lag=adaptation_lag, adaptation_time=adaptation_time,
-                               stop_adaptation=stop_adaptation, live_dangerously=True, fill_value=fill_value, seed=seed,
+                               stop_adaptation=stop_adaptation, live_dangerously=live_dangerously, fill_value=fill_value, seed=seed,
                                device_id=device_id, a=a)
         self.lib, self.ctx = self.eng.lib, self.eng.ctx
         self.schedule = "separate_branches"
@@ -254,8 +254,9 @@ class StretchLeafMove:
     red_blue.py:103-330): every branch and every leaf slot of a walker moves - one complement walker per branch, one stretch
     factor per walker.  (The reference advises against it beside reversible jump, ensemble.py:509-514, and runs it.)"""
 
-    def __init__(self, a=2.0):
+    def __init__(self, a=2.0, live_dangerously=False):
         self.a = float(a)
+        self.live_dangerously = bool(live_dangerously)         # red_blue.py:41-47,108: fewer walkers than 2 x (all leaf slots' coordinates)
         self.accepted, self.num_proposals = None, 0
 
 
@@ -268,7 +269,13 @@ class RJEnsembleSampler:
     rng="numpy":  the reference's streams (the sampler-owned RandomState cloned from the global ``np.random`` at
                   construction + the global stream) are drawn on the host IN THE REFERENCE'S ORDER and handed to the device:
                   same seeds => the reference's chain (tests/test_hip_rj.py against the rj* fixtures).
-    rng="philox": device-side draws, ``thin_by`` iterations per host call (``hens_rj_step``)."""
+    rng="philox": device-side draws, ``thin_by`` iterations per host call (``hens_rj_step``).  The device keeps every walker's
+                  model resident and updates it by +- one leaf per accepted birth / death; the models and log-likelihoods are
+                  re-evaluated from the coordinates every 64 iterations and whenever the state is downloaded (the evaluation
+                  runs in front of the copy, so a stored ``State.log_like`` is exactly what the device continues with and a chain
+                  resumed from it is the uninterrupted chain bit for bit).  Consequence: WHERE the re-evaluations fall depends
+                  on ``store`` / ``thin_by``, so two runs that differ only in those agree to rounding (log-likelihoods to ~1e-13
+                  relative), not bit for bit - as two reference runs with a different likelihood summation order would."""
 
     def __init__(self, nwalkers, ndims, log_like_fn, priors, tempering_kwargs=None, nbranches=None, branch_names=None,
                  nleaves_max=None, nleaves_min=None, moves=None, rj_moves="separate_branches", rng="numpy", seed=None,
@@ -282,12 +289,12 @@ class RJEnsembleSampler:
         self.rj_schedule = rj_moves or None                  # None: no reversible jump - the leaf masks never change
         if not isinstance(moves, (GaussianLeafMove, StretchLeafMove)):
             raise NotImplementedError("the in-model move must be an eryn_amd.rj.GaussianLeafMove or StretchLeafMove")
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
         if isinstance(moves, StretchLeafMove) and rng != "numpy":
             raise NotImplementedError("the stretch move on leaf-packing records steps with rng='numpy' (the reference's draws)")
         if self.rj_schedule is None and rng != "numpy":
             raise NotImplementedError("rng='philox' steps the in-model move and the birth / death move together (hens_rj_step)")
-        if rng not in ("numpy", "philox"):
-            raise ValueError("rng must be 'numpy' or 'philox'")
         self.branch_names = list(branch_names if branch_names is not None else ndims.keys())
         if nbranches is not None and nbranches != len(self.branch_names):
             raise ValueError("nbranches does not match branch_names")
@@ -315,7 +322,7 @@ class RJEnsembleSampler:
         self.engine = RJEngine(self.ntemps, self.nwalkers, self.branches, log_like_fn.t, log_like_fn.y, log_like_fn.sigma,
                                seed=seed, device_id=device_id, adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag,
                                adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation,
-                               **({"a": moves.a} if isinstance(moves, StretchLeafMove) else {}))
+                               **({"a": moves.a, "live_dangerously": moves.live_dangerously} if isinstance(moves, StretchLeafMove) else {}))
         if self.rj_schedule is not None:
             self.engine.set_schedule(rj_moves)
         if rng == "philox":

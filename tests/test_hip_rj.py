@@ -363,6 +363,13 @@ def test_stretch_move_on_records_refuses_too_few_walkers():
     with pytest.raises(RuntimeError):
         eng.stretch_split(0, labels, np.zeros((2, T, W // 2), dtype=np.int64), np.full((T, W // 2), 0.5), np.full((T, W // 2), 0.5))
     eng.close()
+    # ... unless the move lives dangerously (red_blue.py:108: the guard is skipped), as StretchMove(live_dangerously=True) does upstream
+    eng = RJEngine(T, W, brs, t, np.zeros(20), 1.0, live_dangerously=True)
+    eng.upload(x, inds, betas=np.array([1.0, 0.5]))
+    eng.eval_state()
+    keep = eng.stretch_split(0, labels, np.zeros((2, T, W // 2), dtype=np.int64), np.full((T, W // 2), 0.5), np.full((T, W // 2), 0.5))
+    assert keep.shape == (T, W // 2)
+    eng.close()
 
 
 def test_rj_sampler_philox_mode():
@@ -619,3 +626,40 @@ def test_rj_adaptation_folded_into_the_next_launch_changes_nothing(tmp_path):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), f"folded adaptation vs k_adapt: `{k}` differs"
     assert outs[0]["acc_mh"].sum() > 0 and outs[0]["acc_bd"].sum() > 0 and outs[0]["swaps_total"].sum() > 0
     assert not np.array_equal(outs[0]["betas"], __import__("eryn_amd.moves.tempering", fromlist=["make_ladder"]).make_ladder(6, ntemps=6)), "the ladder must have moved"
+
+
+def test_pulse_centre_far_outside_the_data_grid_is_not_a_nan():
+    """the production likelihood's pulse recurrence e_{k+1} = e_k r_k formed r_0 = exp(-((2 dx) h + h^2) / (2 c^2)) without a
+    bound - a centre 1 000 grid steps past the data with c close to the grid step makes the exponent +790: r_0 = inf while e_0 has
+    underflowed to 0, 0 x inf = NaN, and hens_rj_step aborted with "likelihood is returning Nan".  The prior box below lets centres
+    sit up to 3 units (750 steps) outside; the chain must run and its log-likelihoods must be the direct formula's."""
+    from eryn_amd.rj import RJEngine, TemplateBranch
+    from oracle import eryn_oracle_rj as orj
+    T, W, N = 2, 64, 500
+    t = np.linspace(-1, 1, N)                                              # h = 0.004
+    rs = np.random.RandomState(5)
+    y = 1.0 * np.sin(2 * np.pi * 3.0 * t + 0.5) + 0.5 * rs.randn(N)
+    boxes = {"gauss": [(2.5, 3.5), (-1.0, 4.0), (0.0041, 0.0060)], "sine": [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]}
+    brs = [TemplateBranch("gauss", "pulse", boxes["gauss"], 3, 0), TemplateBranch("sine", "sine", boxes["sine"], 2, 0)]
+    eng = RJEngine(T, W, brs, t, y, 0.5, seed=3)
+    x = {"gauss": np.zeros((T, W, 3, 3)), "sine": np.zeros((T, W, 2, 3))}
+    inds = {"gauss": np.zeros((T, W, 3), dtype=bool), "sine": np.zeros((T, W, 2), dtype=bool)}
+    x["gauss"][:, :, 0] = [3.0, 3.0, 0.0045]                                # dx h / c^2 = 4 x 0.004 / 2.0e-5 = 790 at the first point
+    x["gauss"][:, :, 1] = [3.0, 1.9, 0.0042]
+    x["gauss"][:, :, :2, 1] += 0.05 * rs.rand(T, W, 2)
+    x["sine"][:, :, 0] = [1.0, 3.0, 0.5]
+    inds["gauss"][:, :, :2] = True
+    inds["sine"][:, :, 0] = True
+    eng.upload(x, inds, betas=np.array([1.0, 0.5]))
+    eng.eval_state()
+    eng.set_mh_scale(np.array([[1e-2, 1e-2, 1e-5], [1e-2, 1e-2, 1e-2]]))
+    eng.step(6)                                                             # (raised RuntimeError before the clamp)
+    eng.synchronize()
+    x1, inds1, L1, P1, _ = eng.download()
+    okind = {"pulse": orj.KIND_PULSE, "sine": orj.KIND_SINE}
+    obr = [orj.Branch("gauss", okind["pulse"], boxes["gauss"], 3, 0), orj.Branch("sine", okind["sine"], boxes["sine"], 2, 0)]
+    ref = orj.template_log_like(x1, inds1, obr, t, y, 0.5)
+    assert np.isfinite(L1).all()
+    assert (x1["gauss"][:, :, :, 1][inds1["gauss"]] > 1.5).any(), "the far-out centres must still be there"
+    tol.check_logl(L1, ref, RTOL_L, "template log-like with pulse centres far outside the grid")
+    eng.close()

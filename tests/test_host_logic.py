@@ -30,7 +30,7 @@ def test_struct_layout_matches_header():
     import ctypes as C
     # hens_config: 12 x i32, i64, 4 x f64, u64
     assert C.sizeof(_lib.HensConfig) == 12 * 4 + 8 + 4 * 8 + 8
-    assert C.sizeof(_lib.HensTiming) == 4 * 8 + 4 * 8 + 8 + 8          # + fused_ms, n_fused
+    assert C.sizeof(_lib.HensTiming) == 4 * 8 + 4 * 8 + 8 + 8 + 8      # + fused_ms, n_fused, clock
 
 
 def test_no_gpu_fails_loudly():
