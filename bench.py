@@ -810,7 +810,9 @@ def run_sharded(args):
             "block_ms": [t * 1e3 for t in times], "timing": f"median of {BLOCKS} blocks of {args.steps} steps, max over ranks",
             "config": {"workload": f"{cfgname}: ladder sharded over {world} GPU(s), ntemps={T} ({Tl} rungs/GPU), nwalkers={W}, "
                                    f"ndim={D} {model}+adaptive PT on the reference's "
-                                   f"adaptation schedule, Philox RNG", "ntemps": T, "nwalkers": W, "ndim": D,
+                                   f"adaptation schedule, Philox RNG.  WEAK scaling: the ladder grows with N (one fixed-size shard per GPU), so "
+                                   f"this line is NOT the N = 1 headline's workload (config 2) - the N = 1 point of this series is `weak_base` "
+                                   f"(one such shard alone on one GPU, timed in this run) and `efficiency` = weak_base.ms_per_step / ms_per_step", "ntemps": T, "nwalkers": W, "ndim": D,
                        "parallelism": f"ladder-shard x{world}", "transport": transport, "dist_backend": backend,
                        "world_size_seen_by_backend": dist.get_world_size(), "swap_fraction": f_sw},
             "roofline": roof,
