@@ -86,6 +86,7 @@ SIGNATURES = {
     "hens_get_mh_counters": (C.c_int, [_P, _P, _P]),
     "hens_step_marked": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "hens_get_marked_counters": (C.c_int, [_P, _P, _P]),
+    "hens_step_report": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
     "hens_pipe_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "hens_pipe_connect": (C.c_int, [_P, _P]),
     "hens_pipe_connect_local": (C.c_int, [_P, _P]),

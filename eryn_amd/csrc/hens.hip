@@ -187,6 +187,7 @@ struct hens_ctx_impl {
     uint32_t* rj_acc_bd = nullptr;          // [Tl][W] accept counts of the birth / death move (the in-model move uses `accepted`)
     double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
     int64_t rj_tm_ndata = 0;
+    uint8_t* mask_buf = nullptr;     // hens_step_report: [Tl][W] accept counts of the call's last iterations
     bool rj_tm_valid = false;
     bool rj_tm_drift = false;        // hens_rj_step has updated the resident templates by +- a leaf since their last full evaluation
     int rj_st_ns = 0;                       // hens_rj_stretch_split: walkers of the half being moved
@@ -2762,6 +2763,34 @@ int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last) {
     if (c->mark_mh) HIPCHK(c, hipMemcpyAsync(c->accepted_mark + TW, c->accepted_mh, TW * 4, hipMemcpyDeviceToDevice, c->stream));
     c->mark_valid = true;
     return n_last > 0 ? hens_step(ctx, n_last) : HENS_OK;
+}
+
+// n_iters iterations and what a sampler loop reads after EVERY proposal (ensemble.py:974-977), in one call and one small copy: the
+// accept counts of the call's last `n_last` iterations per walker (uint8, saturating: the reference's `accepted` of one
+// sub-iteration summed over num_repeats_in_model proposals), the last cascade's swap counts and the ladder.  The walkers stay on
+// the device: the drop-in moves' lazy State (eryn_amd/state.py: DeviceState) downloads them when somebody reads them.
+int hens_step_report(hens_ctx* ctx, int64_t n_iters, int64_t n_last, uint8_t* accepted_last, double* swaps_last, double* betas) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c) return fail(c, HENS_ERR_INVALID, "null context");
+    if (n_last < 1 || n_iters < n_last) return fail(c, HENS_ERR_INVALID, "hens_step_report: 1 <= n_last <= n_iters");
+    int r = hens_step_marked(ctx, n_iters - n_last, n_last);
+    if (r) return r;
+    if ((r = aql_settle(c))) return r;
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);                       // (the counters ride in the walker records during a hens_step call)
+    flush_adapt(c);                           // (swap counts and ladder of the last cascade)
+    const size_t TW = (size_t)c->Tl * c->W;
+    if (accepted_last) {
+        if (!c->mask_buf && (r = dalloc(c, &c->mask_buf, TW))) return r;
+        const bool mh = c->mark_mh && c->accepted_mh;
+        hipLaunchKernelGGL(k_accept_mask, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, c->accepted, c->accepted_mark,
+                           mh ? c->accepted_mh : nullptr, mh ? c->accepted_mark + TW : nullptr, c->mask_buf, (int64_t)TW);
+        HIPCHK(c, hipMemcpyAsync(accepted_last, c->mask_buf, TW, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (swaps_last && c->T > 1) HIPCHK(c, hipMemcpyAsync(swaps_last, c->swaps_last, (size_t)(c->T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas[c->bcur], (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HENS_OK;
 }
 
 // the counters kept by the last hens_step_marked call ([Tl][W] each; accepted_mh may be null; zeros if there is no MH move)

@@ -2432,6 +2432,17 @@ inline __global__ void k_unpack_cols(const WalkerRec* __restrict__ w, const uint
     }
 }
 
+// hens_step_report: the accept mask of the call's last iteration(s) = what the counters gained since the mark (the stretch move's
+// and the Gaussian move's counters: one of them moved)
+inline __global__ void k_accept_mask(const uint32_t* __restrict__ acc, const uint32_t* __restrict__ mark, const uint32_t* __restrict__ acc_mh,
+                                     const uint32_t* __restrict__ mark_mh, uint8_t* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t d = acc[i] - mark[i];
+        if (acc_mh) d += acc_mh[i] - mark_mh[i];
+        out[i] = d > 255u ? 255u : (uint8_t)d;
+    }
+}
+
 inline __global__ void k_iota(int32_t* p, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         p[i] = (int32_t)i;

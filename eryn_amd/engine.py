@@ -64,6 +64,8 @@ class HipEnsemble:
                          fill_value=float(fill_value), adaptation_lag=float(adaptation_lag),
                          adaptation_time=float(adaptation_time), seed=int(seed) & (2**64 - 1))
         self.tempered = bool(tempered)
+        self.state_epoch = 0         # bumped by every call that changes the walkers: a DeviceState (eryn_amd/state.py) is current while it matches
+        self.lazy_downloads = 0
         self.a = float(a)
         self.ctx = C.c_void_p()
         code = self.lib.hens_create(C.byref(cfg), C.byref(self.ctx))
@@ -118,6 +120,7 @@ class HipEnsemble:
 
     # -- state ---------------------------------------------------------------------------------
     def upload(self, x, logl=None, logp=None, betas=None):
+        self.state_epoch += 1
         x = self._pad(f64(x, (self.Tl, self.W, self.D)))
         logl = None if logl is None else f64(logl, (self.Tl, self.W))
         logp = None if logp is None else f64(logp, (self.Tl, self.W))
@@ -135,6 +138,7 @@ class HipEnsemble:
         return x, logl, logp, betas
 
     def eval_state(self):
+        self.state_epoch += 1
         check(self.lib.hens_eval_state(self.ctx), self.ctx)
 
     # -- parity-mode steps -----------------------------------------------------------------------
@@ -151,6 +155,7 @@ class HipEnsemble:
         return (self.W - int(split) + self.nsplits - 1) // self.nsplits
 
     def stretch_split(self, split, labels, rint, u_zz, u_acc):
+        self.state_epoch += 1
         labels = np.ascontiguousarray(labels, dtype=np.uint8)
         if labels.shape != (self.Tl, self.W):
             raise ValueError("labels must have shape (ntemps, nwalkers)")
@@ -179,6 +184,7 @@ class HipEnsemble:
         return q, inbox.astype(bool)
 
     def accept_split(self, split, logl, u_acc):
+        self.state_epoch += 1
         Ns = self.set_size(split)
         logl, u_acc = f64(logl, (self.Tl, Ns)), f64(u_acc, (self.Tl, Ns))
         keep = np.empty((self.Tl, Ns), dtype=np.uint8)
@@ -186,6 +192,7 @@ class HipEnsemble:
         return keep.astype(bool)
 
     def pt_sweep(self, iperm, i1perm, u_swap, adapt=True):
+        self.state_epoch += 1
         shp = (self.T - 1, self.W)
         iperm = np.ascontiguousarray(iperm, dtype=np.int64)
         i1perm = np.ascontiguousarray(i1perm, dtype=np.int64)
@@ -200,12 +207,30 @@ class HipEnsemble:
 
     # -- production ------------------------------------------------------------------------------
     def step(self, n_iters):
+        self.state_epoch += 1
         check(self.lib.hens_step(self.ctx, int(n_iters)), self.ctx)
 
     def step_marked(self, n_before, n_last):
         """n_before iterations, the accept counters kept on the device, n_last iterations (thin_by > 1: the reference stores
         the accept mask of the last sub-iteration only, ensemble.py:968-979); see marked_counters."""
+        self.state_epoch += 1
         check(self.lib.hens_step_marked(self.ctx, int(n_before), int(n_last)), self.ctx)
+
+    def step_report(self, n_iters, n_last=1):
+        """``step(n_iters)`` + what a sampler loop reads after every proposal (ensemble.py:974-977) in one call: the accept counts
+        of the last ``n_last`` iterations ``[Tl, W]`` (uint8), the last cascade's swap counts, the ladder.  The walkers stay on
+        the device (include/hipensemble.h: hens_step_report)."""
+        self.state_epoch += 1
+        acc = np.empty((self.Tl, self.W), dtype=np.uint8)
+        swaps = np.zeros(max(self.T - 1, 0))
+        betas = np.empty(self.T) if self.tempered else None
+        check(self.lib.hens_step_report(self.ctx, int(n_iters), int(n_last), ptr(acc), ptr(swaps) if self.T > 1 else None, ptr(betas)), self.ctx)
+        return acc, swaps, betas
+
+    def download_betas(self):
+        betas = np.empty(self.T)
+        check(self.lib.hens_download_state(self.ctx, None, None, None, ptr(betas)), self.ctx)
+        return betas
 
     def marked_counters(self):
         """The accept counts (stretch move, MH move) in front of the last step_marked call's final iterations."""
@@ -290,6 +315,7 @@ class HipEnsemble:
     # -- ladder sharding (eryn_amd/ladder.py) ----------------------------------------------------------
     def stretch_iter(self):
         """One Philox iteration of both halves on the resident rungs (asynchronous, no PT)."""
+        self.state_epoch += 1
         check(self.lib.hens_stretch_iter(self.ctx), self.ctx)
 
     def device_buffers(self):
@@ -326,6 +352,7 @@ class HipEnsemble:
     # -- Metropolis-Hastings proposals (include/hipensemble.h: hens_mh_*) --------------------------------
     def mh_step(self, step, u_acc):
         """One full-ensemble proposal q = x + step with the caller's draws; returns the accept mask [Tl, W]."""
+        self.state_epoch += 1
         step = self._pad(np.ascontiguousarray(step, dtype=np.float64).reshape(self.Tl, self.W, self.D))
         u_acc = np.ascontiguousarray(u_acc, dtype=np.float64).reshape(self.Tl, self.W)
         keep = np.empty((self.Tl, self.W), dtype=np.uint8)
@@ -335,6 +362,7 @@ class HipEnsemble:
     def set_mh_proposal(self, kind, scale, weight):
         """Mix Gaussian MH proposals into ``step()``: kind "iso" | "diag" | "full" (scale = std dev, std devs,
         lower Cholesky factor), weight = probability per iteration; kind None switches the mix off."""
+        self._move_cfg = None                                  # (DeviceMove._propose_philox's memo of what it asked for last)
         if kind is None:
             check(self.lib.hens_set_mh_proposal(self.ctx, -1, None, 0.0), self.ctx)
             return
@@ -423,4 +451,5 @@ class HipEnsemble:
         return {n: (float(raw[2 * i]) * 1e-8, int(raw[2 * i + 1])) for i, n in enumerate(names)}
 
     def pt_finish_sharded(self, n_recv):
+        self.state_epoch += 1
         check(self.lib.hens_pt_finish_sharded(self.ctx, int(n_recv)), self.ctx)

@@ -4,7 +4,7 @@ import numpy as np
 
 from ..engine import HipEnsemble
 from ..periodic import period_vector
-from ..state import State
+from ..state import DeviceState, State
 from .move import Move
 
 __all__ = ["DeviceMove"]
@@ -18,12 +18,23 @@ class DeviceMove(Move):
     needs_walker_guard = False
 
     def __init__(self, likelihood=None, prior_box=None, device_id=0, fill_value=-1e300, trust_resident=False,
-                 a=2.0, live_dangerously=False, **kwargs):
+                 a=2.0, live_dangerously=False, rng="numpy", lazy_state=None, seed=None, **kwargs):
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
         self.likelihood = likelihood
         self.prior_box = prior_box
         self.device_id = device_id
         self.fill_value = fill_value
         self.trust_resident = trust_resident
+        # rng="numpy": the reference's two streams, drawn on the host in the reference's order and handed to the parity API - same
+        #   seeds, same chain as Eryn.  rng="philox" (round 6): propose() IS one hens_step iteration - device-side draws, the
+        #   production kernels - and returns what the sampler loop reads after every proposal (accept mask, swap counts, ladder).
+        # lazy_state: propose() returns a DeviceState (eryn_amd/state.py) - the walkers are copied back when somebody reads them,
+        #   not after every proposal.  Default: on with rng="philox", off with rng="numpy" (a State returned in the lazy form must
+        #   be read before the next proposal if it is to be kept).
+        self.rng = rng
+        self.lazy_state = (rng == "philox") if lazy_state is None else bool(lazy_state)
+        self.seed = seed
         self.engine = None
         self._resident = None
         self._engine_a = a
@@ -58,9 +69,12 @@ class DeviceMove(Move):
         if tc is not None:
             kw = dict(adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag, adaptation_time=tc.adaptation_time,
                       stop_adaptation=tc.stop_adaptation)
+        seed = self.seed
+        if seed is None:
+            seed = int(np.random.randint(0, 2**31 - 1)) if self.rng == "philox" else 0
         self.engine = HipEnsemble(T, W, D, self.likelihood, lo, hi, a=self._engine_a, tempered=tc is not None,
                                   live_dangerously=self._engine_live or not self.needs_walker_guard, fill_value=self.fill_value,
-                                  device_id=self.device_id, **kw)
+                                  device_id=self.device_id, seed=seed, **kw)
         return self.engine
 
     def _apply_periodic(self, eng, name, D):
@@ -79,6 +93,8 @@ class DeviceMove(Move):
                                       "records: eryn_amd.rj.RJEnsembleSampler with moves=StretchLeafMove() or GaussianLeafMove(cov)")
         br = state.branches[names[0]]
         T, W, nl, D = br.shape
+        if isinstance(state, DeviceState):         # (made by a device move: one leaf, all active, no blobs)
+            return names[0], br, T, W, D
         if nl != 1 or not np.all(br.inds):
             raise NotImplementedError("this move steps nleaves_max == 1 with all leaves active; several leaves step on leaf-packing "
                                       "records (eryn_amd.rj.RJEnsembleSampler)")
@@ -97,8 +113,15 @@ class DeviceMove(Move):
             shared[0] = state
         self._resident = state
 
+    @staticmethod
+    def _bump(eng):
+        """The context is about to change its walkers: DeviceStates handed out before are no longer current."""
+        eng.state_epoch = getattr(eng, "state_epoch", 0) + 1
+
     def _upload_if_needed(self, eng, state, br):
         tc = self.temperature_control
+        if isinstance(state, DeviceState) and state.is_current(eng) and (self.trust_resident or not state.materialized):
+            return        # the context still holds exactly this state, and nobody has had its arrays in hand to change them
         if self.trust_resident and self._get_resident() is state:
             return
         if state.log_like is None or state.log_prior is None:
@@ -110,6 +133,22 @@ class DeviceMove(Move):
     # -- the tail of every in-model propose(): PT sweep, adaptation, new State -------------------------
     def _finish(self, eng, state, name, br, T, W):
         tc = self.temperature_control
+        if self.lazy_state and hasattr(eng, "download_betas"):
+            # the walkers stay on the device: the State that goes back reads them when somebody asks (DeviceState)
+            if tc is not None and T > 1:
+                iperm, i1perm, u = _swap_draws(tc, T, W)
+                do_adapt = bool(tc.adaptive)
+                sel, swaps = eng.pt_sweep(iperm, i1perm, u, adapt=do_adapt)
+                tc.swaps_accepted = swaps
+                if do_adapt:
+                    tc.betas = eng.download_betas()
+                    tc.time += 1
+            elif tc is not None:
+                tc.swaps_accepted = np.empty(0)
+            out = DeviceState(eng, eng.state_epoch, name, (T, W, 1, br.shape[3]), br.inds, betas=None if tc is None else tc.betas,
+                              random_state=state.random_state)
+            self._set_resident(out)
+            return out
         if tc is not None and T > 1:                                   # red_blue.py:330-331, mh.py:190-191
             iperm, i1perm, u = _swap_draws(tc, T, W)
             do_adapt = bool(tc.adaptive)
@@ -127,6 +166,47 @@ class DeviceMove(Move):
                     betas=None if tc is None else tc.betas, random_state=state.random_state)
         self._set_resident(out)
         return out
+
+
+    # -- rng="philox": one proposal = one hens_step iteration --------------------------------------------------------------
+    def _propose_philox(self, model, state, mh_proposal=None):
+        """``propose()`` of the device-draw mode: the context steps ONE iteration of the production path (this move, the swap
+        cascade, the ladder adaptation: ensemble.py:974 + red_blue.py:330-331 / mh.py:190-191) and hands back the accept mask,
+        the swap counts and the ladder; the walkers stay where they are (DeviceState)."""
+        name, br, T, W, D = self._single_branch(state)
+        eng = self._ensure_engine(T, W, D)
+        if hasattr(eng.likelihood, "evaluate"):
+            raise NotImplementedError("rng='philox' steps on the device: it needs a device likelihood (eryn_amd.likelihood)")
+        tc = self.temperature_control
+        self._apply_periodic(eng, name, D)
+        self._upload_if_needed(eng, state, br)
+        want = ("mh",) + tuple(np.asarray(v).tobytes() if i else v for i, v in enumerate(mh_proposal)) if mh_proposal else ("stretch",)
+        if getattr(eng, "_move_cfg", None) != want:          # which move the context's next iteration runs (weight 1: no mix inside)
+            if mh_proposal:
+                eng.set_mh_proposal(mh_proposal[0], mh_proposal[1], 1.0)
+            else:
+                eng.set_mh_proposal(None, None, 0.0)
+            eng._move_cfg = want
+        self._bump(eng)
+        acc, swaps, betas = eng.step_report(1, 1)
+        accepted = acc.astype(bool)
+        if tc is not None:
+            tc.swaps_accepted = swaps if T > 1 else np.empty(0)
+            if T > 1 and tc.adaptive:
+                tc.betas = betas
+                tc.time += 1
+        if self._accepted is not None:
+            self.accepted += accepted
+        self.num_proposals += 1
+        if self.lazy_state:
+            out = DeviceState(eng, eng.state_epoch, name, (T, W, 1, D), br.inds, betas=None if tc is None else tc.betas,
+                              random_state=state.random_state)
+        else:
+            x, L, P, _ = eng.download()
+            out = State({name: x[:, :, None, :]}, inds={name: br.inds}, log_like=L, log_prior=P,
+                        betas=None if tc is None else tc.betas, random_state=state.random_state)
+        self._set_resident(out)
+        return out, accepted
 
 
 def _swap_draws(tc, T, W):

@@ -24,8 +24,11 @@ class MHMove(DeviceMove):
         eng = self._ensure_engine(T, W, D)
         if hasattr(eng.likelihood, "evaluate"):
             raise NotImplementedError("MH moves on the device need a device likelihood")
+        if self.rng == "philox":                                       # device-side normals (k_stretch_fast<MODE_MH> / k_mh_draw)
+            return self._propose_philox(model, state, mh_proposal=self.device_proposal())
         self._apply_periodic(eng, name, D)
         self._upload_if_needed(eng, state, br)
+        self._bump(eng)
         step = self.get_step(model.random, T * W, D)                   # gaussian.py:116 (all leaves active)
         u_acc = model.random.rand(T, W)                                # mh.py:157
         accepted = eng.mh_step(step, u_acc)

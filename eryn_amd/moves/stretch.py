@@ -27,13 +27,18 @@ class StretchMove(DeviceMove):
         device_id, fill_value: engine options.
         trust_resident: skip the host->device upload when ``state`` is the object this move
             returned last (safe when no host-side code mutates the State in between).
+        rng: "numpy" (default) - the reference's streams drawn on the host in the reference's order: the reference's chain;
+            "philox" - ``propose()`` is ONE ``hens_step`` iteration with device-side draws (the benchmarked kernels).
+        lazy_state: return a ``DeviceState`` whose arrays are copied from the device when they are read (default with
+            rng="philox"): a sampler that stores every ``thin_by``-th step downloads the walkers at stored steps only.
+        seed: Philox seed of a context this move creates itself (default: drawn from the global ``np.random``).
     """
 
     needs_walker_guard = True          # red_blue.py:108-114
 
     def __init__(self, a=2.0, nsplits=2, randomize_split=True, live_dangerously=False, likelihood=None,
                  prior_box=None, device_id=0, fill_value=-1e300, trust_resident=False, return_gpu=False,
-                 **kwargs):
+                 rng="numpy", lazy_state=None, seed=None, **kwargs):
         if not 2 <= int(nsplits) <= 8:
             raise NotImplementedError("the device path runs red-blue moves of 2 to 8 sets")
         self.a = a
@@ -42,18 +47,21 @@ class StretchMove(DeviceMove):
         self.live_dangerously = live_dangerously
         DeviceMove.__init__(self, likelihood=likelihood, prior_box=prior_box, device_id=device_id,
                             fill_value=fill_value, trust_resident=trust_resident, a=a,
-                            live_dangerously=live_dangerously, **kwargs)
+                            live_dangerously=live_dangerously, rng=rng, lazy_state=lazy_state, seed=seed, **kwargs)
 
     # -- the plugin entry point -------------------------------------------------------------------
     def propose(self, model, state):
         name, br, T, W, D = self._single_branch(state)
         eng = self._ensure_engine(T, W, D)
-        self._apply_periodic(eng, name, D)
-        self._upload_if_needed(eng, state, br)
         if getattr(eng, "a", self.a) != float(self.a):                  # (a tuning hook changed move.a: stretch.py:37 reads it per proposal)
             eng.set_stretch_scale(self.a)
         if getattr(eng, "nsplits", 2) != self.nsplits:                 # (the context's parity API defaults to two sets)
             eng.set_nsplits(self.nsplits)
+        if self.rng == "philox":
+            return self._propose_philox(model, state)
+        self._apply_periodic(eng, name, D)
+        self._upload_if_needed(eng, state, br)
+        self._bump(eng)
 
         accepted = np.zeros((T, W), dtype=bool)
         labels = np.tile(np.arange(W), (T, 1)) % self.nsplits         # red_blue.py:119-124

@@ -182,6 +182,14 @@ int hens_step(hens_ctx* ctx, int64_t n_iters);
  * kept counts ([rungs][nwalkers] f64 each: stretch move, MH move - zeros without one; either pointer may be null). */
 int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last);
 int hens_get_marked_counters(hens_ctx* ctx, double* accepted, double* accepted_mh);
+/* hens_step(n_iters) + what EnsembleSampler's loop reads after every proposal (ensemble.py:974-977: `accepted_out`,
+ * `move.temperature_control.swaps_accepted`; tempering.py:563-649: the adapted ladder), in one call and one small copy:
+ *   accepted_last[Tl][W] u8   accept counts of the call's last n_last iterations (one sampler sub-iteration =
+ *                             num_repeats_in_model proposals; saturates at 255)
+ *   swaps_last[T-1], betas[T] of the last cascade / after its adaptation.   Any pointer may be NULL.
+ * The walkers are NOT copied: the drop-in moves return a State whose arrays download on first read
+ * (eryn_amd/state.py: DeviceState; SURVEY 8 b-2 "device-resident State mirror"). */
+int hens_step_report(hens_ctx* ctx, int64_t n_iters, int64_t n_last, uint8_t* accepted_last, double* swaps_last, double* betas);
 
 /* Counters.  Replaces Move.accepted / num_proposals (move.py:404-421, red_blue.py:326-327),
  * TemperatureControl.swaps_accepted / time (tempering.py:542,596).  Any pointer may be NULL.

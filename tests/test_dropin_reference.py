@@ -80,7 +80,35 @@ class OracleEngine:
         return sel, sw
 
     def download(self, want_x=True):
+        self.calls.append("download")
         return self.x.copy(), self.L.copy(), self.P.copy(), None if self.betas is None else self.betas.copy()
+
+    # -- what the lazy State and the device-draw mode use (round 6) -----------------------------------------------------
+    tempered = True
+
+    def download_betas(self):
+        return self.betas.copy()
+
+    def set_mh_proposal(self, kind, scale, weight):
+        self.calls.append(("mh_proposal", kind, weight))
+
+    def step_report(self, n_iters, n_last=1):
+        """Stand-in for hens_step_report: n_iters whole iterations of the pinned oracle on draws of its own (the device draws
+        with Philox; what is under test here is the protocol, not the stream)."""
+        from oracle import eryn_oracle as orc
+        if getattr(self, "_o", None) is None or self._o_src is not self.x:
+            self._o = orc.OracleSampler(self.x, self.loglike, self.lo, self.hi, np.random.RandomState(77), np.random.RandomState(78),
+                                        betas=self.betas, a=self.a)
+            self._o.time = self.time
+        o, acc = self._o, np.zeros((self.T, self.W))
+        for i in range(n_iters):
+            m = o.iteration()
+            if i >= n_iters - n_last:
+                acc += m
+        self.x, self.L, self.P, self.betas, self.time = o.x, o.L, o.P, o.betas, o.time
+        self._o_src = self.x
+        self.calls.append("step")
+        return acc.astype(np.uint8), np.array(o.swaps_accepted, dtype=float), self.betas.copy()
 
 
 def _fixture(golden_dir, name):
@@ -200,3 +228,79 @@ def test_invalid_periodic_injection_fails_loudly(eryn, golden_dir):
     with pytest.raises(ValueError):
         move.periodic = 3.0                    # neither a container nor a dict (ensemble.py:340-345)
     move.periodic = None                       # the no-op assignment stays legal
+
+
+# ---- round 6: the device-resident State mirror (VERDICT r5 missing #3) -------------------------------------------
+def test_lazy_state_under_the_real_sampler_downloads_at_stored_steps_only(eryn, golden_dir):
+    """``StretchMove(lazy_state=True)`` hands the unmodified reference sampler a DeviceState: with num_repeats_in_model = 3 and
+    thin_by = 2 the reference's loop (ensemble.py:965-1041) proposes 36 times and stores 6 steps - the walkers must cross the
+    boundary 6 times (``Backend.save_step`` reads them, backends/backend.py:1049-1090), not 36, and the chain must still be the
+    r1 fixture's, captured from the reference's own StretchMove with the same seeds.  A state somebody has read is uploaded
+    again before the next proposal (its arrays may have been changed); one nobody has read is not."""
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import StretchMove
+    from eryn_amd.state import DeviceState
+    fx = _fixture(golden_dir, "r1_repeats3_thin2")
+    T, W, D, box, n = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"]), int(fx["nsteps"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    move = StretchMove(likelihood=GaussianLikelihood(mu, invcov), prior_box=(-box, box), lazy_state=True)
+    eng = OracleEngine(T, W, D, lambda x: _loglike(x, mu, invcov), -box, box)
+    move.attach_engine(eng)
+    fx = dict(fx, a=2.0)
+    s = _reference_sampler(eryn, fx, move, num_repeats_in_model=int(fx["repeats"]))
+    np.random.seed(int(fx["seed_run"]))
+    it = 0
+    for state in s.sample(fx["x0"], iterations=n, thin_by=int(fx["thin_by"]), store=True):
+        assert isinstance(state, DeviceState) and state.materialized          # (save_step has read it)
+        pre = f"it{it}_"
+        assert np.array_equal(state.branches["model_0"].coords[:, :, 0, :], fx[pre + "x"])
+        assert np.array_equal(state.log_like, fx[pre + "L"]) and np.array_equal(state.log_prior, fx[pre + "P"])
+        assert np.array_equal(state.betas, fx[pre + "betas"])
+        assert np.array_equal(s.backend.accepted, fx[pre + "backend_accepted"])
+        it += 1
+    assert np.array_equal(s.get_chain()["model_0"][:, :, :, 0, :], fx["chain"])
+    assert np.array_equal(move.accepted, fx["move_accepted"]) and move.num_proposals == int(fx["num_proposals"]) == 36
+    assert eng.calls.count("download") == n, f"{eng.calls.count('download')} downloads for {n} stored steps"
+    assert eng.calls.count("upload") == n, "one upload at the start + one behind every stored step but the last"
+
+
+def test_device_draw_move_under_the_real_sampler_thin_by_10(eryn, golden_dir):
+    """``StretchMove(rng="philox")``: propose() is ONE device iteration (hens_step_report) and returns the accept mask, the swap
+    counts and the ladder - everything the reference's loop reads after a proposal (ensemble.py:974-977) - while the walkers
+    stay on the device.  Under the unmodified reference sampler with thin_by = 10, store = True: 40 proposals, 4 stored steps,
+    4 downloads, 4 uploads; the backend holds what the device held at the stored steps."""
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import GaussianMove, StretchMove
+    fx = _fixture(golden_dir, "f2_pt")
+    T, W, D, box = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    like = GaussianLikelihood(mu, invcov)
+    move = StretchMove(likelihood=like, prior_box=(-box, box), rng="philox", seed=11)
+    assert move.lazy_state
+    eng = OracleEngine(T, W, D, lambda x: _loglike(x, mu, invcov), -box, box)
+    move.attach_engine(eng)
+    s = _reference_sampler(eryn, fx, move)
+    seen = []
+    for state in s.sample(fx["x0"], iterations=4, thin_by=10, store=True):
+        seen.append((eng.x.copy(), eng.L.copy(), eng.betas.copy()))
+    assert eng.calls.count("step") == 40 and eng.calls.count("download") == 4 and eng.calls.count("upload") == 4
+    chain = s.get_chain()["model_0"]
+    assert chain.shape == (4, T, W, 1, D)
+    for i, (x, L, b) in enumerate(seen):
+        assert np.array_equal(chain[i][:, :, 0, :], x) and np.array_equal(s.get_log_like()[i], L)
+        assert np.array_equal(s.get_betas()[i], b)
+    assert move.num_proposals == 40 and move.accepted.sum() > 0 and move.accepted.max() <= 40
+    assert np.array_equal(s.temperature_control.betas, eng.betas) and s.temperature_control.swaps_accepted.shape == (T - 1,)
+    # a state nobody read is stale once the context has stepped on: reading it then fails loudly
+    gen = s.sample(state, iterations=2, thin_by=1, store=False)
+    first = next(gen)
+    next(gen)
+    with pytest.raises(RuntimeError):
+        first.log_like
+    # the Gaussian move of a mix asks the context for its own move before it steps
+    g = GaussianMove({"model_0": 0.01}, likelihood=like, prior_box=(-box, box), rng="philox")
+    g.attach_engine(eng)
+    g.temperature_control = s.temperature_control
+    g.accepted = np.zeros((T, W))
+    st, acc = g.propose(s.get_model(), state)
+    assert ("mh_proposal", "iso", 1.0) in eng.calls and acc.shape == (T, W)

@@ -367,3 +367,92 @@ def test_philox_sampler_steps_a_three_set_stretch_move():
     last = s.run_mcmc(np.random.RandomState(2).randn(T, W, D), 6, thin_by=2)
     assert s.moves[0].num_proposals == 12 and 0.05 < s.moves[0].accepted.mean() / 12 < 0.9
     assert np.isfinite(last.log_like).all() and s.get_chain()["model_0"].shape[0] == 6
+
+
+# ---- round 6: device-draw drop-in moves with a device-resident State ---------------------------------------------
+def _gauss(D, seed=3):
+    rs = np.random.RandomState(seed)
+    A = rs.randn(D, D)
+    return 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+
+
+@pytest.mark.parametrize("T,W,D,thin", [(8, 512, 32, 1), (4, 256, 16, 5), (16, 1024, 64, 3)])
+def test_device_draw_move_in_the_numpy_loop_is_hens_step(T, W, D, thin):
+    """``StretchMove(rng="philox")`` under eryn_amd's host loop (rng="numpy": one ``propose()`` per iteration, as the reference's
+    sampler calls it) against ONE ``hens_step`` call of the same length on a context of its own: same seed, same state - positions,
+    log-probabilities, ladder bit for bit, accept counters equal to the summed masks.  The walkers cross the boundary at stored
+    steps only (DeviceState)."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.moves import StretchMove
+    from eryn_amd.moves.tempering import make_ladder
+    from eryn_amd.state import DeviceState
+    mu, invcov = _gauss(D)
+    like = GaussianLikelihood(mu, invcov)
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    x0 = np.random.RandomState(1).randn(T, W, D)
+    n = 6
+    s = EnsembleSampler(W, D, like, priors, tempering_kwargs=dict(ntemps=T), moves=StretchMove(rng="philox"), seed=17)
+    eng = s.engine
+    states = []
+    for st in s.sample(x0, iterations=n, thin_by=thin, store=True):
+        assert isinstance(st, DeviceState)
+        states.append(st)
+    assert getattr(eng, "lazy_downloads", 0) == n, "the walkers must be copied back at stored steps only"
+    ref = HipEnsemble(T, W, D, like, -20.0, 20.0, seed=17)
+    ref.upload(x0, betas=make_ladder(D, ntemps=T))
+    ref.eval_state()
+    for k in range(n):
+        ref.step(thin)
+        x, L, P, betas = ref.download()
+        st = states[k]
+        assert np.array_equal(st.branches["model_0"].coords[:, :, 0, :], x), f"positions at stored step {k}"
+        assert np.array_equal(st.log_like, L) and np.array_equal(st.log_prior, P) and np.array_equal(st.betas, betas)
+    c = ref.counters()
+    assert np.array_equal(s.moves[0].accepted, c["accepted"]) and s.moves[0].num_proposals == n * thin
+    assert np.array_equal(s.temperature_control.swaps_accepted, c["swaps_last"])
+    assert np.array_equal(s.get_chain()["model_0"][-1][:, :, 0, :], x)
+    ref.close()
+
+
+def test_device_draw_move_mix_in_the_numpy_loop():
+    """StretchMove + GaussianMove, both rng="philox", chosen per proposal by the sampler's own stream (ensemble.py:971): every
+    proposal is one device iteration of ITS move; the accept counters of the two moves partition the proposals."""
+    from eryn_amd.moves import GaussianMove, StretchMove
+    T, W, D = 4, 512, 32
+    mu, invcov = _gauss(D)
+    like = GaussianLikelihood(mu, invcov)
+    priors = {i: uniform_dist(-20.0, 20.0) for i in range(D)}
+    mvs = [(StretchMove(rng="philox"), 0.6), (GaussianMove({"model_0": 0.01}, rng="philox"), 0.4)]
+    np.random.seed(5)
+    s = EnsembleSampler(W, D, like, priors, tempering_kwargs=dict(ntemps=T), moves=mvs, seed=3)
+    last = s.run_mcmc(np.random.RandomState(1).randn(T, W, D), 40, store=False)
+    st, g = s.moves
+    assert st.num_proposals + g.num_proposals == 40 and st.num_proposals > 5 and g.num_proposals > 5
+    c, cm = s.engine.counters(), s.engine.mh_counters()
+    assert np.array_equal(st.accepted, c["accepted"]) and np.array_equal(g.accepted, cm["accepted"])
+    assert c["num_proposals"] == st.num_proposals and cm["num_proposals"] == g.num_proposals
+    assert np.isfinite(last.log_like).all() and st.accepted.sum() > 0 and g.accepted.sum() > 0
+
+
+def test_numpy_loop_with_the_lazy_device_move_runs_config_2_under_150_us_per_iteration():
+    """the drop-in move under a host loop that calls ``propose()`` once per iteration ran at ~1 200 us per iteration
+    (17.8 MB down + up per proposal).  With the device-draw move and the device-resident State the per-proposal traffic is the
+    accept mask (64 kB) + swap counts + ladder: <= 150 us per iteration at BASELINE config 2 (16 x 4096 x 32), Python loop included."""
+    import time
+    from eryn_amd.moves import StretchMove
+    T, W, D = 16, 4096, 32
+    rs = np.random.RandomState(0)
+    A = rs.randn(D, D)
+    mu, invcov = 0.1 * rs.randn(D), np.linalg.inv(A @ A.T / D + np.eye(D))
+    priors = {i: uniform_dist(-50.0, 50.0) for i in range(D)}
+    s = EnsembleSampler(W, D, GaussianLikelihood(mu, invcov), priors, tempering_kwargs=dict(ntemps=T), moves=StretchMove(rng="philox"), seed=2024)
+    st = s.run_mcmc(np.random.RandomState(1).randn(T, W, D), 100, store=False)      # warm-up
+    best = np.inf
+    for _ in range(3):
+        t0 = time.perf_counter()
+        st = s.run_mcmc(st, 500, store=False)
+        best = min(best, (time.perf_counter() - t0) / 500)
+    print(f"numpy loop + lazy device move: {best * 1e6:.1f} us per iteration at config 2")
+    assert best * 1e6 <= 150.0, f"{best * 1e6:.1f} us per iteration"
+    assert s.engine.lazy_downloads <= 8
+    assert np.isfinite(st.log_like).all()
