@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.environ.get("HENS_LIB") or os.path.join(LIB_DIR, "libhipensemble.so")
-OBJ_DIR = os.path.join(os.path.dirname(HERE), "build", "hens_obj")
+OBJ_DIR = os.environ.get("HENS_OBJ_DIR") or os.path.join(os.path.dirname(HERE), "build", "hens_obj")      # (A/B libraries: objects of their own)
 # hens.hip: the C ABI, the host logic and the small kernels; hens_k_<likelihood>.hip (x 2 parts): the stepping kernels' instantiations
 # (csrc/hens_ktable.h) - one translation unit per (likelihood, part), compiled side by side, then linked.
 UNITS = [("hens", "hens.hip", [])] + [(f"hens_k_{k}_{part}", f"hens_k_{k}.hip", [f"-DHENS_KT_PART={part}"])

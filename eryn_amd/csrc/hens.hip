@@ -188,6 +188,9 @@ struct hens_ctx_impl {
     double* rj_tm = nullptr;                // [2 Tl W][ndata] every pool row's template, resident (RjArgs::tm), or nullptr (ndata > 512)
     int64_t rj_tm_ndata = 0;
     uint8_t* mask_buf = nullptr;     // hens_step_report: [Tl][W] accept counts of the call's last iterations
+    uint32_t* report_prev = nullptr; // ... [2][Tl][W] the stretch / MH accept counters as the last report left them
+    bool report_valid = false;
+    uint64_t report_iter = 0, report_books = 0;
     bool rj_tm_valid = false;
     bool rj_tm_drift = false;        // hens_rj_step has updated the resident templates by +- a leaf since their last full evaluation
     int rj_st_ns = 0;                       // hens_rj_stretch_split: walkers of the half being moved
@@ -418,7 +421,7 @@ size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)6 * c->W + 16; }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
-int fast_nw(int D) { return (D == 32 || D == 64 || D == 128) ? 8 : 4; }
+int fast_nw(int D) { return D == 64 ? HENS_NW64 : ((D == 32 || D == 128) ? 8 : 4); }
 // row widths with a compile-time-width kernel (k_stretch_fast)
 bool fast_path(const hens_ctx_impl* c) {
     const int D = c->D;
@@ -450,7 +453,7 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
         // (periodic parameters: an instantiation of their own - on a pipeline rank too - but not for the evaluation launch, which
         //  proposes nothing)
         const bool pipe = c->pipe.on, per = mode != MODE_EVAL && c->period;
-        const int NW = fast_nw(c->D);
+        const int NW = (mode == MODE_MH && c->D == 64) ? 8 : fast_nw(c->D);       // (the MH launch pairs rows per 8-wave pass: k_mh_draw)
         return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW, like), false,
                              c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
     }
@@ -2770,26 +2773,49 @@ int hens_step_marked(hens_ctx* ctx, int64_t n_before, int64_t n_last) {
 // sub-iteration summed over num_repeats_in_model proposals), the last cascade's swap counts and the ladder.  The walkers stay on
 // the device: the drop-in moves' lazy State (eryn_amd/state.py: DeviceState) downloads them when somebody reads them.
 int hens_step_report(hens_ctx* ctx, int64_t n_iters, int64_t n_last, uint8_t* accepted_last, double* swaps_last, double* betas) {
-    hens_ctx_impl* c = enter(ctx);
+    hens_ctx_impl* c = CTX(ctx);
     if (!c) return fail(c, HENS_ERR_INVALID, "null context");
     if (n_last < 1 || n_iters < n_last) return fail(c, HENS_ERR_INVALID, "hens_step_report: 1 <= n_last <= n_iters");
-    int r = hens_step_marked(ctx, n_iters - n_last, n_last);
-    if (r) return r;
+    int r;
+    const size_t TW = (size_t)c->Tl * c->W;
+    // The accept counts of the last n_last iterations = the counters now minus the counters in front of those iterations.  The
+    // "before" copy is kept from report to report (report_prev: updated by the kernel that forms the difference), so the usual
+    // caller - one report per iteration - pays no snapshot, and nothing here leaves record mode: the counters are read where
+    // they ride (k_report_mask).  Anything else that moved the counters in between (hens_step, a reset, another iteration
+    // counter) is noticed by the books below and costs one snapshot launch.
+    auto books = [&] { return (uint64_t)c->num_proposals + (uint64_t)c->num_proposals_mh; };
+    const bool have_prev = c->report_prev && c->report_valid && c->report_iter == c->iter && c->report_books == books() && n_iters == n_last;
+    if (n_iters > n_last && (r = hens_step(ctx, n_iters - n_last))) return r;
+    auto launch_mask = [&](uint8_t* out) {
+        const bool mh = c->accepted_mh != nullptr;
+        hipLaunchKernelGGL(k_report_mask, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, c->packed ? c->wrec[c->cur] : nullptr, c->colmode ? 1 : 0,
+                           c->accepted, mh ? c->accepted_mh : nullptr, c->report_prev, c->report_prev + TW, out, c->Tl, c->W);
+    };
+    if (!have_prev) {
+        if ((r = aql_settle(c))) return r;
+        HIPCHK(c, hipSetDevice(c->cfg.device_id));
+        if (!c->report_prev) {
+            if ((r = dalloc(c, &c->report_prev, 2 * TW))) return r;
+            HIPCHK(c, hipMemsetAsync(c->report_prev, 0, 2 * TW * 4, c->stream));
+        }
+        if (!c->mask_buf && (r = dalloc(c, &c->mask_buf, TW))) return r;
+        launch_mask(nullptr);
+        HIPCHK(c, hipGetLastError());
+    }
+    if ((r = hens_step(ctx, n_last))) { c->report_valid = false; return r; }
     if ((r = aql_settle(c))) return r;
     HIPCHK(c, hipSetDevice(c->cfg.device_id));
-    state_to_fields(c);                       // (the counters ride in the walker records during a hens_step call)
     flush_adapt(c);                           // (swap counts and ladder of the last cascade)
-    const size_t TW = (size_t)c->Tl * c->W;
-    if (accepted_last) {
-        if (!c->mask_buf && (r = dalloc(c, &c->mask_buf, TW))) return r;
-        const bool mh = c->mark_mh && c->accepted_mh;
-        hipLaunchKernelGGL(k_accept_mask, dim3(grid_for((int64_t)TW)), dim3(256), 0, c->stream, c->accepted, c->accepted_mark,
-                           mh ? c->accepted_mh : nullptr, mh ? c->accepted_mark + TW : nullptr, c->mask_buf, (int64_t)TW);
-        HIPCHK(c, hipMemcpyAsync(accepted_last, c->mask_buf, TW, hipMemcpyDeviceToHost, c->stream));
-    }
+    launch_mask(c->mask_buf);
+    HIPCHK(c, hipGetLastError());
+    if (accepted_last) HIPCHK(c, hipMemcpyAsync(accepted_last, c->mask_buf, TW, hipMemcpyDeviceToHost, c->stream));
     if (swaps_last && c->T > 1) HIPCHK(c, hipMemcpyAsync(swaps_last, c->swaps_last, (size_t)(c->T - 1) * 8, hipMemcpyDeviceToHost, c->stream));
     if (betas) HIPCHK(c, hipMemcpyAsync(betas, c->betas[c->bcur], (size_t)c->T * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hip_dirty = false;
+    c->report_valid = true;
+    c->report_iter = c->iter;
+    c->report_books = books();
     return HENS_OK;
 }
 
@@ -2845,6 +2871,7 @@ int hens_reset_counters(hens_ctx* ctx) {
     c->num_proposals = 0;
     c->num_proposals_mh = 0;
     c->rj_num_mh = c->rj_num_bd = 0;
+    c->report_valid = false;
     return HENS_OK;
 }
 

@@ -938,6 +938,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef HENS_ROWSTORE
 #define HENS_ROWSTORE 1
 #endif
+// wavefronts per workgroup of the D = 64 stepping kernels (A/B libraries: -DHENS_NW64=4, round 6's one-round probe)
+#ifndef HENS_NW64
+#define HENS_NW64 8
+#endif
 // The stepping launches of one GPU carry no release fence (hens_aql.h: norel_next; hens.hip: norel_ok) BECAUSE a row leaves as a
 // write-through store: with HENS_ROWSTORE 0 or 2 (A/B libraries) rows would sit dirty in one XCD's L2 and the next launch would
 // read stale data on another - norel_ok() asks this constant and keeps the fence then.
@@ -2012,7 +2016,7 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     //  change alone.)
     constexpr int HP = (DT >= 64 && !PIPE) ? NPASS / 2 : NPASS;
     constexpr int MHG = NPASS >= 2 ? RPP : 0;             // (MH normals: rows of the tile that share a Philox call, mh_normal_quad)
-    static_assert(MHG == mh_pair_rows(DT) && (HP % 2 == 0 || NPASS == 1), "k_mh_draw pairs the rows this launch does");
+    static_assert(!MH || (MHG == mh_pair_rows(DT) && (HP % 2 == 0 || NPASS == 1)), "k_mh_draw pairs the rows this launch does");
     u4 mh_d{0u, 0u, 0u, 0u};
     // the proposal's step scale of this lane's two coordinates, requested once in front of the passes
     double mh_s0 = 0.0, mh_s1 = 0.0;
@@ -2440,6 +2444,31 @@ inline __global__ void k_accept_mask(const uint32_t* __restrict__ acc, const uin
         uint32_t d = acc[i] - mark[i];
         if (acc_mh) d += acc_mh[i] - mark_mh[i];
         out[i] = d > 255u ? 255u : (uint8_t)d;
+    }
+}
+
+// ... the same without leaving record mode (hens_step_report's fast form): a slot's accept counter rides in its walker record
+// (column order: record.slot names the slot; slot order: the record's index does), the Gaussian move's counters are an array by
+// slot.  prev / prev_mh: the counters as the last report left them - updated here; out (may be null: snapshot only) by slot.
+inline __global__ void k_report_mask(const WalkerRec* __restrict__ w, int colmode, const uint32_t* __restrict__ acc_fields,
+                                     const uint32_t* __restrict__ acc_mh, uint32_t* __restrict__ prev, uint32_t* __restrict__ prev_mh,
+                                     uint8_t* __restrict__ out, int T, int W) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)T * W; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t a;
+        int64_t s = i;
+        if (w) {
+            const int4 la = *reinterpret_cast<const int4*>(&w[i].loc);      // {loc, acc, slot, -}: the record's second 16 bytes
+            a = (uint32_t)la.y;
+            if (colmode) s = (i / W) * W + la.z;
+        } else a = acc_fields[i];
+        uint32_t d = a - prev[s];
+        prev[s] = a;
+        if (acc_mh) {
+            const uint32_t m = acc_mh[s];
+            d += m - prev_mh[s];
+            prev_mh[s] = m;
+        }
+        if (out) out[s] = d > 255u ? 255u : (uint8_t)d;
     }
 }
 

@@ -241,16 +241,23 @@ class EnsembleSampler:
             return
 
         for _ in range(iterations):
-            for _ in range(thin_by):
-                accepted = np.zeros((self.ntemps, self.nwalkers))
+            for sub in range(thin_by):
+                # the reference re-zeroes `accepted` at every sub-iteration (ensemble.py:968): what reaches the backend is the LAST
+                # sub-iteration's sum over its repeats - only that one is formed here; and `state.random_state` (ensemble.py:981,
+                # a copy of R's 2.5 kB state: ~50 us) is attached where somebody can see the state: the tune hook, the yield
+                last = sub == thin_by - 1
+                if last:
+                    accepted = np.zeros((self.ntemps, self.nwalkers))
                 for _repeat in range(self.num_repeats_in_model):                # ensemble.py:969-984
                     move = self._random.choice(self.moves, p=self.weights)      # ensemble.py:971
                     state, accepted_out = move.propose(model, state)
-                    accepted += accepted_out
-                    swaps = tc.swaps_accepted if self.ntemps > 1 else None
-                    state.random_state = self.random_state
+                    if last:
+                        accepted += accepted_out
                     if tune:
+                        state.random_state = self.random_state
                         move.tune(state, accepted_out)
+            swaps = tc.swaps_accepted if self.ntemps > 1 else None
+            state.random_state = self.random_state
             if store:
                 self.backend.save_step(state, accepted, swaps_accepted=swaps)
             self._previous_state = state
@@ -384,8 +391,9 @@ class EnsembleSampler:
         if nsteps == 0:                                    # ensemble.py:1095-1096
             return initial_state
         results = None
-        if self.rng == "philox" and kwargs.get("store", True) is False:
-            # nothing is stored: one device-resident call for all iterations, one download at the end
+        if kwargs.get("store", True) is False:
+            # nothing is stored: ONE yield (rng="philox": one device-resident call for all iterations, one download at the end;
+            # rng="numpy": the same proposals in the same order, the state is looked at once, at the end)
             kw = dict(kwargs)
             thin = int(kw.pop("thin_by", 1))
             for results in self.sample(initial_state, iterations=1, thin_by=thin * nsteps, **kw):

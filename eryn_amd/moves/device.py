@@ -41,6 +41,26 @@ class DeviceMove(Move):
         self._engine_live = live_dangerously
         Move.__init__(self, **kwargs)
 
+    # -- accept counts of the device-draw mode: folded into the sampler's array on demand ----------------------
+    _pend, _npend = None, 0
+
+    def _fold(self):
+        if self._pend is not None and self._npend:
+            self._accepted += self._pend
+            self._pend[...] = 0
+            self._npend = 0
+
+    @property
+    def accepted(self):
+        self._fold()
+        return Move.accepted.fget(self)
+
+    @accepted.setter
+    def accepted(self, accepted):
+        if self._npend:                       # (a sampler replaces the array: what is pending belongs to the old one)
+            self._fold()
+        Move.accepted.fset(self, accepted)
+
     # -- engine -----------------------------------------------------------------------------------
     def _box(self):
         pb = self.prior_box
@@ -189,14 +209,23 @@ class DeviceMove(Move):
             eng._move_cfg = want
         self._bump(eng)
         acc, swaps, betas = eng.step_report(1, 1)
-        accepted = acc.astype(bool)
+        accepted = acc.view(np.bool_)                                  # (one iteration: the counts are 0 / 1)
         if tc is not None:
             tc.swaps_accepted = swaps if T > 1 else np.empty(0)
             if T > 1 and tc.adaptive:
                 tc.betas = betas
                 tc.time += 1
         if self._accepted is not None:
-            self.accepted += accepted
+            # move.accepted (move.py:404-421) is a float array the sampler owns; adding a mask to it costs more host time than the
+            # device iteration it describes, so the masks pile up in a byte array and are folded in when somebody looks (the
+            # `accepted` property below) or after 200 proposals
+            if self._pend is None or self._pend.shape != acc.shape:
+                self._fold()
+                self._pend, self._npend = np.zeros_like(acc), 0
+            np.add(self._pend, acc, out=self._pend)
+            self._npend += 1
+            if self._npend >= 200:
+                self._fold()
         self.num_proposals += 1
         if self.lazy_state:
             out = DeviceState(eng, eng.state_epoch, name, (T, W, 1, D), br.inds, betas=None if tc is None else tc.betas,

@@ -31,7 +31,7 @@ def run(st):
         x0 = np.clip(1.0 + 0.05 * np.random.RandomState(1).randn(T, W, D), -4.9, 4.9)
     else:
         mu, invcov = bench.gaussian_problem(D)
-        eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024)
+        eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, np.diag(invcov).copy() if like == "diag" else invcov), -50.0, 50.0, seed=2024)
         x0 = np.random.RandomState(1).randn(T, W, D)
     eng.upload(x0, betas=make_ladder(D, ntemps=T))
     eng.eval_state()
