@@ -38,6 +38,15 @@ class HensTiming(C.Structure):
     ]
 
 
+RJ_MOVE_MH, RJ_MOVE_BD, RJ_MOVE_BD_ALL, RJ_MOVE_STRETCH = 0, 1, 2, 3      # include/hipensemble.h: HENS_RJ_MOVE_*
+
+
+class HensRjDraws(C.Structure):
+    """struct hens_rj_draws (include/hipensemble.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("step", "change", "leaf", "birth", "labels", "rint", "u_zz", "u_acc")] + \
+               [("branch", C.c_int32), ("split", C.c_int32)]
+
+
 class HensPipeRegions(C.Structure):
     """struct hens_pipe_region_table (include/hipensemble.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("ldn_out", "ldn_rows_out", "ldn_in", "ldn_rows_in", "lup_out", "lup_in",
@@ -111,6 +120,8 @@ SIGNATURES = {
     "hens_rj_debug_draws": (C.c_int, [_P, C.c_int64] + [_P] * 11),
     "hens_rj_set_schedule": (C.c_int, [_P, C.c_int32]),
     "hens_rj_bd_all_step": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "hens_rj_propose": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    "hens_rj_accept": (C.c_int, [_P, _P, _P]),
     "hens_rj_stretch_split": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "hens_get_iteration": (C.c_int, [_P, _P]),
     "hens_set_iteration": (C.c_int, [_P, C.c_int64]),

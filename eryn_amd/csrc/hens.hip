@@ -192,6 +192,11 @@ struct hens_ctx_impl {
     bool report_valid = false;
     uint64_t report_iter = 0, report_books = 0;
     bool rj_tm_valid = false;
+    // host-callable likelihood on leaf-packing records (hens_rj_propose / hens_rj_accept)
+    double *rj_hq = nullptr, *rj_hlogp = nullptr, *rj_hfac = nullptr, *rj_hlu = nullptr, *rj_hlogl = nullptr;
+    uint8_t* rj_hmoved = nullptr;
+    uint32_t* rj_h_accepted = nullptr;
+    bool rj_hostlike = false, rj_accept_pending = false;
     bool rj_tm_drift = false;        // hens_rj_step has updated the resident templates by +- a leaf since their last full evaluation
     int rj_st_ns = 0;                       // hens_rj_stretch_split: walkers of the half being moved
     unsigned* rj_ad_flag = nullptr;  // the folded adaptation's "ladder published" word (RjArgs::ad_flag), serial of the last folding launch
@@ -1662,12 +1667,20 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     }
     const int npr = mode == RJ_MODE_STRETCH ? c->rj_st_ns : c->W;     // waves per rung
     const dim3 grid((unsigned)((npr + RJ_WAVES - 1) / RJ_WAVES), (unsigned)c->Tl), block(RJ_WAVES * 64);
-    const int tmm = a.tm ? a.tm_mode : -1;            // the instantiation: (mode, template scheme), see k_rj
+    int tmm = a.tm ? a.tm_mode : -1;                  // the instantiation: (mode, template scheme), see k_rj
+    if (c->rj_hostlike) {                             // hens_rj_propose: the proposal only (k_rj<MODE, -2>), k_rj_accept finishes
+        if (a.tm || !u_acc || mode == RJ_MODE_EVAL) return fail(c, HENS_ERR_STATE, "hens_rj_propose: a teacher-forced move with its accept uniforms");
+        tmm = -2;
+        a.hq = c->rj_hq; a.hlogp = c->rj_hlogp; a.hfac = c->rj_hfac; a.hlu = c->rj_hlu; a.hmoved = c->rj_hmoved;
+        a.keep_out = nullptr;
+        c->rj_h_accepted = a.accepted;
+    }
 #define RJ_CASE(MODE_, TMM_) if (mode == MODE_ && tmm == TMM_) hipLaunchKernelGGL((k_rj<MODE_, TMM_>), grid, block, 0, c->stream, a); else
     RJ_CASE(RJ_MODE_EVAL, -1) RJ_CASE(RJ_MODE_EVAL, 0) RJ_CASE(RJ_MODE_EVAL, 2)
     RJ_CASE(RJ_MODE_MH, -1) RJ_CASE(RJ_MODE_MH, 0)
     RJ_CASE(RJ_MODE_BD, -1) RJ_CASE(RJ_MODE_BD, 1)
     RJ_CASE(RJ_MODE_STRETCH, -1)
+    RJ_CASE(RJ_MODE_MH, -2) RJ_CASE(RJ_MODE_BD, -2) RJ_CASE(RJ_MODE_STRETCH, -2)
         return fail(c, HENS_ERR_INVALID, "k_rj: no instantiation for mode %d with template scheme %d", mode, tmm);
 #undef RJ_CASE
     const hipError_t e = hipGetLastError();
@@ -1681,6 +1694,7 @@ int rj_ready(hens_ctx_impl* c, bool between_halves = false) {
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
     if (c->Tl != c->T) return fail(c, HENS_ERR_UNSUPPORTED, "the leaf-packing path runs on the whole ladder of one GPU");
     if ((c->expect_split != 0 && !between_halves) || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
+    if (c->rj_accept_pending) return fail(c, HENS_ERR_STATE, "hens_rj_accept must follow hens_rj_propose");
     return HENS_OK;
 }
 
@@ -3340,6 +3354,70 @@ int hens_rj_step(hens_ctx* ctx, int64_t n_iters) {
     // the reference raises "The likelihood function is returning Nan." / on an infinite coordinate at once (ensemble.py:1258-
     // 1262, 1542); here once per call: the template likelihood's flags are read back with the call's last launch
     return check_flags(c, true);
+}
+
+// ---- leaf-packing moves with a HOST-CALLABLE likelihood (round 6; ensemble.py:1306-1334,1340-1545, rj.py:145-388) ---------------
+// hens_rj_propose runs the proposal half of one teacher-forced move on the records - in-model Gaussian move on every active leaf,
+// birth / death on one branch or on all of them, a red / blue stretch half-step - up to and including the log-prior, and hands the
+// proposed records back; the caller packs the active leaves the way compute_log_like does (groups_from_inds order) and calls the
+// user's function; hens_rj_accept finishes the move with those log-likelihoods.  The leaf-packing twin of hens_propose_split /
+// hens_accept_split.
+int hens_rj_propose(hens_ctx* ctx, int32_t move, const hens_rj_draws* d, double* q_out, double* logp_out, uint8_t* moved_out) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c || !d || !q_out || !logp_out || !moved_out) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_* needs a context created with HENS_LIKE_TEMPLATE");
+    if (c->rj_accept_pending) return fail(c, HENS_ERR_STATE, "hens_rj_accept must follow hens_rj_propose");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W, RW = (size_t)c->rj.RW;
+    int r;
+    if (!c->rj_hq) {
+        if ((r = dalloc(c, &c->rj_hq, TW * RW))) return r;
+        if ((r = dalloc(c, &c->rj_hlogp, TW))) return r;
+        if ((r = dalloc(c, &c->rj_hfac, TW))) return r;
+        if ((r = dalloc(c, &c->rj_hlu, TW))) return r;
+        if ((r = dalloc(c, &c->rj_hlogl, TW))) return r;
+        if ((r = dalloc(c, &c->rj_hmoved, TW))) return r;
+    }
+    HIPCHK(c, hipMemsetAsync(c->rj_hmoved, 0, TW, c->stream));
+    c->rj_hostlike = true;
+    switch (move) {
+        case HENS_RJ_MOVE_MH: r = hens_rj_mh_step(ctx, d->step, d->u_acc, nullptr); break;
+        case HENS_RJ_MOVE_BD: r = hens_rj_bd_step(ctx, d->branch, d->change, d->leaf, d->birth, d->u_acc, nullptr); break;
+        case HENS_RJ_MOVE_BD_ALL: r = hens_rj_bd_all_step(ctx, d->change, d->leaf, d->birth, d->u_acc, nullptr); break;
+        case HENS_RJ_MOVE_STRETCH: r = hens_rj_stretch_split(ctx, d->split, d->labels, d->rint, d->u_zz, d->u_acc, nullptr); break;
+        default: r = fail(c, HENS_ERR_INVALID, "hens_rj_propose: move must be HENS_RJ_MOVE_MH, _BD, _BD_ALL or _STRETCH");
+    }
+    c->rj_hostlike = false;
+    if (r) return r;
+    HIPCHK(c, hipMemcpyAsync(q_out, c->rj_hq, TW * RW * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(logp_out, c->rj_hlogp, TW * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(moved_out, c->rj_hmoved, TW, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rj_accept_pending = true;
+    return HENS_OK;
+}
+
+int hens_rj_accept(hens_ctx* ctx, const double* logl, uint8_t* keep_out) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c || !logl) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (!c->rj_accept_pending) return fail(c, HENS_ERR_STATE, "hens_rj_accept must follow hens_rj_propose");
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    const size_t TW = (size_t)c->Tl * c->W;
+    for (size_t i = 0; i < TW; ++i)
+        if (logl[i] != logl[i]) return fail(c, HENS_ERR_NONFINITE, "The likelihood function is returning Nan.");       // ensemble.py:1542
+    HIPCHK(c, hipMemcpyAsync(c->rj_hlogl, logl, TW * 8, hipMemcpyHostToDevice, c->stream));
+    RjAcceptArgs a{};
+    a.pool = c->pool; a.loc = c->loc[c->cur]; a.L = c->L[c->cur]; a.P = c->P[c->cur];
+    a.betas = c->cfg.tempered ? c->betas[c->bcur] : nullptr;
+    a.accepted = c->rj_h_accepted; a.keep_out = c->rj_keep;
+    a.hq = c->rj_hq; a.hlogp = c->rj_hlogp; a.hfac = c->rj_hfac; a.hlu = c->rj_hlu; a.hmoved = c->rj_hmoved; a.logl = c->rj_hlogl;
+    a.Tl = c->Tl; a.W = c->W; a.RW = c->rj.RW; a.rung_begin = c->cfg.rung_begin; a.tempered = c->cfg.tempered;
+    hipLaunchKernelGGL(k_rj_accept, dim3((unsigned)((TW + 3) / 4)), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    if (keep_out) HIPCHK(c, hipMemcpyAsync(keep_out, c->rj_keep, TW, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rj_accept_pending = false;
+    return HENS_OK;
 }
 
 int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule) {

@@ -46,6 +46,82 @@ class _TemplateLikelihood:
         pass
 
 
+class CallableLikelihood:
+    """A user ``log_like_fn`` for a state of several branches / leaves, called the way ``EnsembleSampler.compute_log_like`` calls
+    it (ensemble.py:1219-1545): walkers with an infinite log-prior or without any active leaf are not evaluated; the active leaves
+    of the others are packed per branch (``coords[inds]``: walker-major, slot order) with their group ids (utils/utility.py:8-40,
+    renumbered 0..ngroups-1, ensemble.py:1306-1324); ``vectorize=True`` hands the function every group at once -
+    ``fn([leaves_b0, leaves_b1, ...], [groups_b0, ...] if provide_groups, *args, **kwargs)`` - else it is called per group with
+    ``[leaves_b or None for every branch]`` (:1420-1470).  Not evaluated -> ``fill_zero_leaves_val`` (:1486-1513); NaN raises.
+    The proposal, prior, accept test and update around it run on the device (hens_rj_propose / hens_rj_accept)."""
+
+    def __init__(self, fn, args=None, kwargs=None, vectorize=False, provide_groups=False, fill_zero_leaves_val=-1e300):
+        self.fn, self.args, self.kwargs = fn, list(args or []), dict(kwargs or {})
+        self.vectorize, self.provide_groups, self.fill = bool(vectorize), bool(provide_groups), float(fill_zero_leaves_val)
+        self.ncalls = 0
+
+    def __call__(self, x, inds, logp, names, only=None, has_reversible_jump=True):
+        """x / inds: {name: [T, W, nl, ndim] / [T, W, nl]}, logp [T, W]; ``only`` [T, W] bool: the walkers a move touched (the
+        others keep their log-likelihood: their entry here is never read)."""
+        first = names[0]
+        T, W = inds[first].shape[:2]
+        for name in names:                                                  # ensemble.py:1258-1262
+            xa = x[name][inds[name]]
+            if np.any(np.isinf(xa)):
+                raise ValueError("At least one parameter value was infinite")
+            if np.any(np.isnan(xa)):
+                raise ValueError("At least one parameter value was NaN")
+        only = None if only is None else np.asarray(only, dtype=bool)
+        if np.all(np.isinf(logp if only is None else logp[only])):          # :1272-1276
+            import warnings
+            warnings.warn("All points input for the Likelihood have a log prior of -inf.")
+            return np.full_like(logp, -1e300)
+        bad = np.isinf(logp) if only is None else (np.isinf(logp) | ~only)
+        inds_copy = {k: np.array(inds[k], dtype=bool, copy=True) for k in names}
+        for k in names:
+            inds_copy[k][bad] = False
+        gid = np.arange(T * W).reshape(T, W)
+        groups = {k: np.repeat(gid[:, :, None], inds_copy[k].shape[2], axis=-1)[inds_copy[k]] for k in names}
+        unique_groups = np.unique(np.concatenate([groups[k] for k in names]))
+        groups_map = np.arange(len(unique_groups))
+        ll_groups = []
+        for k in names:
+            tu, inverse = np.unique(groups[k], return_inverse=True)
+            ll_groups.append(groups_map[np.isin(unique_groups, tu)][inverse])
+        params_in = [x[k][inds_copy[k]] for k in names]
+        ll = np.full(T * W, -1e300)
+        if len(unique_groups):
+            if self.vectorize:
+                a = [params_in[0] if len(params_in) == 1 else params_in]
+                if self.provide_groups:
+                    a.append(ll_groups[0] if len(ll_groups) == 1 else ll_groups)
+                results = self.fn(*a, *self.args, **self.kwargs)
+                self.ncalls += 1
+            else:
+                results = []
+                for g in groups_map:
+                    arg = [None] * len(names)
+                    for bi in range(len(names)):
+                        keep = np.where(ll_groups[bi] == g)[0]
+                        if keep.shape[0] > 0:
+                            p = params_in[bi][keep]
+                            if not has_reversible_jump and p.shape[0] == 1:
+                                p = p[0]
+                            arg[bi] = p
+                    results.append(self.fn(arg[0] if len(names) == 1 else arg, *self.args, **self.kwargs))
+                    self.ncalls += 1
+            results = np.asarray(results)
+            if results.ndim == 2 and results.shape[1] == 1:
+                results = np.squeeze(results, axis=1)
+            if results.ndim != 1:
+                raise NotImplementedError("blobs are outside the device hot path: the likelihood must return one value per group")
+            ll[unique_groups] = results
+        ll[np.delete(np.arange(T * W), unique_groups)] = self.fill
+        if np.any(np.isnan(ll)):
+            raise ValueError("The likelihood function is returning Nan.")
+        return ll.reshape(T, W)
+
+
 class RJEngine:
     def __init__(self, ntemps, nwalkers, branches, t, y, sigma, seed=0, device_id=0, adaptive=True,
                  adaptation_lag=10000, adaptation_time=100, stop_adaptation=-1, fill_value=-1e300, a=2.0, live_dangerously=False):
@@ -64,6 +140,7 @@ class RJEngine:
                                device_id=device_id, a=a)
         self.lib, self.ctx = self.eng.lib, self.eng.ctx
         self.schedule = "separate_branches"
+        self.host_like = None        # a CallableLikelihood: every parity move = propose on the device, evaluate here, accept on the device
         nb = len(self.branches)
         kinds = np.array([b.kind for b in self.branches], dtype=np.int32)
         nlmax = np.array([b.nleaves_max for b in self.branches], dtype=np.int32)
@@ -121,15 +198,45 @@ class RJEngine:
         return x, inds, L, P, betas
 
     def eval_state(self):
-        self.eng.eval_state()
+        self.eng.eval_state()                                    # (log-prior on the device; log-like: the template model's)
+        if self.host_like is not None:                           # ... or the host callable's
+            rec, _, P, betas = self.eng.download()
+            x, inds = self.unpack(rec)
+            L = self.host_like(x, inds, P, [b.name for b in self.branches])
+            self.eng.upload(rec, L, P, betas)
 
     def set_adapt_time(self, t):
         self.eng.set_adapt_time(t)
+
+    # -- moves with a host-callable likelihood: hens_rj_propose -> the user's function -> hens_rj_accept -------------
+    def _host_move(self, move, **d):
+        """One teacher-forced move whose likelihood is ``self.host_like``: the device proposes and computes the log-prior, the
+        host packs the active leaves and calls the user's function (CallableLikelihood), the device tests and updates."""
+        self.eng.state_epoch += 1
+        keepalive = {k: v for k, v in d.items() if isinstance(v, np.ndarray)}
+        dr = _lib.HensRjDraws(**{k: (v.ctypes.data if isinstance(v, np.ndarray) else v) for k, v in d.items()})
+        q = np.empty((self.T, self.W, self.RW))
+        logp = np.empty((self.T, self.W))
+        moved = np.empty((self.T, self.W), dtype=np.uint8)
+        check(self.lib.hens_rj_propose(self.ctx, int(move), C.byref(dr), ptr(q), ptr(logp), ptr(moved)), self.ctx)
+        del keepalive
+        x, inds = self.unpack(q)
+        try:
+            logl = f64(self.host_like(x, inds, logp, [b.name for b in self.branches], only=moved.astype(bool)))
+        except Exception:
+            # the move must not stay half done: reject everything (log-like -inf fails every accept test), then re-raise
+            check(self.lib.hens_rj_accept(self.ctx, ptr(np.full((self.T, self.W), -np.inf)), None), self.ctx)
+            raise
+        keep = np.empty((self.T, self.W), dtype=np.uint8)
+        check(self.lib.hens_rj_accept(self.ctx, ptr(logl), ptr(keep)), self.ctx)
+        return keep.astype(bool)
 
     # -- parity-mode moves -----------------------------------------------------------------------------------------
     def mh_step(self, steps, u_acc):
         st = f64(self.steps_to_records(steps))
         u = f64(u_acc, (self.T, self.W))
+        if self.host_like is not None:
+            return self._host_move(_lib.RJ_MOVE_MH, step=st, u_acc=u)
         keep = np.empty((self.T, self.W), dtype=np.uint8)
         check(self.lib.hens_rj_mh_step(self.ctx, ptr(st), ptr(u), ptr(keep)), self.ctx)
         return keep.astype(bool)
@@ -140,6 +247,8 @@ class RJEngine:
         lf = np.ascontiguousarray(np.where(np.asarray(change) == 0, 0, leaf), dtype=np.int32)
         bt = f64(birth, (self.T, self.W, 3))
         u = f64(u_acc, (self.T, self.W))
+        if self.host_like is not None:
+            return self._host_move(_lib.RJ_MOVE_BD, branch=int(branch), change=ch, leaf=lf, birth=bt, u_acc=u)
         keep = np.empty((self.T, self.W), dtype=np.uint8)
         check(self.lib.hens_rj_bd_step(self.ctx, int(branch), ptr(ch), ptr(lf), ptr(bt), ptr(u), ptr(keep)), self.ctx)
         return keep.astype(bool)
@@ -153,6 +262,8 @@ class RJEngine:
         u = f64(u_acc, (self.T, self.W))
         if ch.shape != (nb, self.T, self.W) or lf.shape != ch.shape:
             raise ValueError("change / leaf must have shape (nbranches, ntemps, nwalkers)")
+        if self.host_like is not None:
+            return self._host_move(_lib.RJ_MOVE_BD_ALL, change=ch, leaf=lf, birth=bt, u_acc=u)
         keep = np.empty((self.T, self.W), dtype=np.uint8)
         check(self.lib.hens_rj_bd_all_step(self.ctx, ptr(ch), ptr(lf), ptr(bt), ptr(u), ptr(keep)), self.ctx)
         return keep.astype(bool)
@@ -167,6 +278,9 @@ class RJEngine:
         if lab.shape != (self.T, self.W) or ri.shape != (len(self.branches), self.T, Ns):
             raise ValueError("labels must have shape (ntemps, nwalkers), rint (nbranches, ntemps, Ns)")
         uz, ua = f64(u_zz, (self.T, Ns)), f64(u_acc, (self.T, Ns))
+        if self.host_like is not None:
+            kw = self._host_move(_lib.RJ_MOVE_STRETCH, split=int(split), labels=lab, rint=ri, u_zz=uz, u_acc=ua)     # by walker
+            return np.stack([kw[t][lab[t] == split] for t in range(self.T)])
         keep = np.empty((self.T, Ns), dtype=np.uint8)
         check(self.lib.hens_rj_stretch_split(self.ctx, int(split), ptr(lab), ptr(ri), ptr(uz), ptr(ua), ptr(keep)), self.ctx)
         return keep.astype(bool)
@@ -279,10 +393,22 @@ class RJEnsembleSampler:
 
     def __init__(self, nwalkers, ndims, log_like_fn, priors, tempering_kwargs=None, nbranches=None, branch_names=None,
                  nleaves_max=None, nleaves_min=None, moves=None, rj_moves="separate_branches", rng="numpy", seed=None,
-                 device_id=0, **unused):
+                 device_id=0, args=None, kwargs=None, vectorize=False, provide_groups=False, fill_zero_leaves_val=-1e300, **unused):
         from .moves.tempering import TemperatureControl
+        # log_like_fn: a TemplateLikelihood (the model lives in the kernel) or - round 6 - any Python function of the packed active
+        # leaves with the reference's own ``args`` / ``kwargs`` / ``vectorize`` / ``provide_groups`` (ensemble.py:211-330): the
+        # device proposes, computes the prior, tests and updates, the host evaluates (CallableLikelihood)
+        self.host_like = None
+        if callable(log_like_fn) and not isinstance(log_like_fn, (TemplateLikelihood, CallableLikelihood)):
+            log_like_fn = CallableLikelihood(log_like_fn, args, kwargs, vectorize, provide_groups, fill_zero_leaves_val)
+        if isinstance(log_like_fn, CallableLikelihood):
+            if rng != "numpy":
+                raise NotImplementedError("a host-callable likelihood steps with rng='numpy' (rng='philox' needs the likelihood on the device)")
+            self.host_like = log_like_fn
+            names_ = list(branch_names if branch_names is not None else ndims.keys())
+            log_like_fn = TemplateLikelihood({k: "pulse" for k in names_}, np.zeros(2), np.zeros(2), 1.0)     # (never evaluated)
         if not isinstance(log_like_fn, TemplateLikelihood):
-            raise NotImplementedError("the device RJ path runs the template model: pass an eryn_amd.rj.TemplateLikelihood")
+            raise NotImplementedError("log_like_fn: an eryn_amd.rj.TemplateLikelihood, a CallableLikelihood or a Python function")
         if rj_moves not in ("separate_branches", "iterate_branches", "together", None, False):
             raise ValueError("When providing a str for rj_moves, must be 'together', 'iterate_branches', or "
                              f"'separate_branches'. Input is {rj_moves}")                # ensemble.py:473-476
@@ -323,6 +449,7 @@ class RJEnsembleSampler:
                                seed=seed, device_id=device_id, adaptive=tc.adaptive, adaptation_lag=tc.adaptation_lag,
                                adaptation_time=tc.adaptation_time, stop_adaptation=tc.stop_adaptation,
                                **({"a": moves.a, "live_dangerously": moves.live_dangerously} if isinstance(moves, StretchLeafMove) else {}))
+        self.engine.host_like = self.host_like
         if self.rj_schedule is not None:
             self.engine.set_schedule(rj_moves)
         if rng == "philox":
@@ -347,7 +474,7 @@ class RJEnsembleSampler:
     # -- the reference's evaluation entry points, with inds (ensemble.py:1127-1217, 1219-1545) -----------------------
     def _eval(self, coords, inds):
         self.engine.upload(coords, inds, betas=self.temperature_control.betas)
-        self.engine.eval_state()
+        self.engine.eval_state()                 # (a host-callable likelihood is called from there)
         _, _, L, P, _ = self.engine.download()
         return L, P
 

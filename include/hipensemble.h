@@ -451,6 +451,31 @@ int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule);
 int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf, const double* birth, const double* u_acc,
                         uint8_t* keep_out);
 
+/* Leaf-packing moves with a HOST-CALLABLE likelihood (round 6).  Replaces, for states of several branches / leaves whose
+ * log_like_fn is an arbitrary Python function, the proposal + prior half and the accept + update half of MHMove.propose
+ * (mh.py:56-193), ReversibleJumpMove.propose (rj.py:145-388) and RedBlueMove.propose (red_blue.py:103-330); between the two
+ * the caller does what EnsembleSampler.compute_log_like does on the host (ensemble.py:1306-1334, 1340-1545; utils/utility.py:
+ * 8-40 groups_from_inds): packs the active leaves per branch, calls the user's function, fills -1e300 / fill_zero_leaves_val.
+ * The leaf-packing twin of hens_propose_split / hens_accept_split.
+ *   move   HENS_RJ_MOVE_MH       in-model Gaussian move on every active leaf: draws->step [Tl][W][ncoord], u_acc [Tl][W]
+ *          HENS_RJ_MOVE_BD       birth / death on draws->branch: change, leaf [Tl][W], birth [Tl][W][3], u_acc [Tl][W]
+ *          HENS_RJ_MOVE_BD_ALL   ... on every branch in one proposal: [nbranches][...] arrays as hens_rj_bd_all_step
+ *          HENS_RJ_MOVE_STRETCH  one half of the red / blue stretch move: split, labels, rint, u_zz, u_acc as
+ *                                hens_rj_stretch_split
+ *   q_out[Tl][W][RW]   the proposed records (every slot's coordinates + the leaf masks, hens_upload_state's layout)
+ *   logp_out[Tl][W]    their log-prior, Move.fix_logp_gibbs applied (move.py:368-402): -inf = do not evaluate
+ *   moved_out[Tl][W]   1 for the walkers this proposal moves (all of them; a stretch half-step: the moving set)
+ * hens_rj_accept(logl[Tl][W]) - the caller's log-likelihoods of the moved walkers (entries of the others are ignored; NaN ->
+ * HENS_ERR_NONFINITE, ensemble.py:1542) - runs the tempered accept test and Move.update; keep_out[Tl][W] by WALKER. */
+enum { HENS_RJ_MOVE_MH = 0, HENS_RJ_MOVE_BD = 1, HENS_RJ_MOVE_BD_ALL = 2, HENS_RJ_MOVE_STRETCH = 3 };
+typedef struct hens_rj_draws {
+    const double* step; const int8_t* change; const int32_t* leaf; const double* birth;
+    const uint8_t* labels; const int64_t* rint; const double* u_zz; const double* u_acc;
+    int32_t branch, split;
+} hens_rj_draws;
+int hens_rj_propose(hens_ctx* ctx, int32_t move, const hens_rj_draws* draws, double* q_out, double* logp_out, uint8_t* moved_out);
+int hens_rj_accept(hens_ctx* ctx, const double* logl, uint8_t* keep_out);
+
 /* The Philox iteration counter: the index of the NEXT iteration hens_step will run (iterations completed on this
  * context so far, by hens_step or by the parity API). */
 int hens_get_iteration(hens_ctx* ctx, int64_t* iter_out);

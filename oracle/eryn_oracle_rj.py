@@ -99,9 +99,44 @@ def template_log_like(x, inds, branches, t, y, sigma):
     return -0.5 * np.sum(((tmpl - y) / sigma) ** 2, axis=-1)
 
 
-def compute_log_like(x, inds, logp, branches, t, y, sigma, fill=-1e300):
+def lorentz_chirp_log_like(x_list, t, y, sigma):
+    """A user likelihood that is NOT the kernel's template model (round 6: reversible jump with a host-callable likelihood), in the
+    reference's calling convention for several branches without vectorisation (ensemble.py:1420-1470): ``x_list[b]`` holds the
+    active leaves of branch b of ONE walker, ``[nleaves, 3]``, or None.  Branch 0: Lorentzian lines a / (1 + ((t - b) / c)^2);
+    branch 1: chirps a sin(2 pi b t + c t^2).  Gaussian noise of width sigma."""
+    lines, chirps = x_list
+    tm = np.zeros_like(t)
+    if lines is not None:
+        for a, b, c in np.atleast_2d(lines):
+            tm = tm + a / (1.0 + ((t - b) / c) ** 2)
+    if chirps is not None:
+        for a, b, c in np.atleast_2d(chirps):
+            tm = tm + a * np.sin(2 * np.pi * b * t + c * t ** 2)
+    return -0.5 * np.sum(((tm - y) / sigma) ** 2)
+
+
+def callable_log_like(like_fn, x, inds, evaluated, args):
+    """What ensemble.py:1306-1334, 1420-1480 hands a non-vectorised user function: per evaluated walker (group) the list over the
+    branches of that walker's active leaves ``coords[inds]`` - in slot order - or None for a branch without one."""
+    first = next(iter(x))
+    T, W = x[first].shape[:2]
+    out = np.zeros((T, W))
+    for tt in range(T):
+        for w in range(W):
+            if not evaluated[tt, w]:
+                continue
+            arg = []
+            for name in x:
+                m = inds[name][tt, w]
+                arg.append(x[name][tt, w][m] if m.any() else None)
+            out[tt, w] = like_fn(arg, *args)
+    return out
+
+
+def compute_log_like(x, inds, logp, branches, t, y, sigma, fill=-1e300, like_fn=None):
     """ensemble.py:1219-1545 with ``inds``: walkers with an infinite prior are not evaluated, walkers without any active
-    leaf get ``fill_zero_leaves_val``; everything that is not evaluated is -1e300."""
+    leaf get ``fill_zero_leaves_val``; everything that is not evaluated is -1e300.  ``like_fn``: a user function in the
+    reference's per-walker calling convention (args = [t, y, sigma]) instead of the template model."""
     for br in branches:
         xa = x[br.name][inds[br.name]]
         if np.any(np.isinf(xa)):
@@ -116,7 +151,10 @@ def compute_log_like(x, inds, logp, branches, t, y, sigma, fill=-1e300):
         any_leaf |= inds[br.name].any(axis=-1)
     evaluated = any_leaf & ~bad                                                    # groups_from_inds on inds_copy (:1278-1306)
     ll = np.full(logp.shape, -1e300)
-    vals = template_log_like(x, inds, branches, t, y, sigma)
+    if like_fn is not None:
+        vals = callable_log_like(like_fn, {br.name: x[br.name] for br in branches}, inds, evaluated, [t, y, sigma])
+    else:
+        vals = template_log_like(x, inds, branches, t, y, sigma)
     ll[evaluated] = vals[evaluated]
     ll[~evaluated] = fill                                                          # :1513
     if np.any(np.isnan(ll)):
@@ -163,7 +201,7 @@ class OracleRJSampler:
 
     def __init__(self, branches, x0, inds0, t, y, sigma, R, G, betas, adaptive=True, adaptation_lag=10000,
                  adaptation_time=100, stop_adaptation=-1, fill=-1e300, record=False, schedule="separate_branches",
-                 in_model="gaussian", a=2.0):
+                 in_model="gaussian", a=2.0, like_fn=None):
         # schedule: the sampler's ``rj_moves`` string (ensemble.py:434-480) - "separate_branches": one DistributionGenerateRJ per
         # branch, one of them chosen per iteration; "iterate_branches": ONE move that walks through every branch in turn;
         # "together": ONE move that proposes a birth or death in every branch of a walker at once (ensemble.py:414-432)
@@ -176,8 +214,9 @@ class OracleRJSampler:
         self.branches = list(branches)
         self.t, self.y, self.sigma = np.asarray(t, dtype=np.float64), np.asarray(y, dtype=np.float64), float(sigma)
         self.R, self.G = R, G
+        self.like_fn = like_fn
         P = compute_log_prior(x0, inds0, self.branches)
-        L = compute_log_like(x0, inds0, P, self.branches, self.t, self.y, self.sigma, fill)
+        L = compute_log_like(x0, inds0, P, self.branches, self.t, self.y, self.sigma, fill, like_fn=like_fn)
         self.st = RJState(x0, inds0, L, P, betas)
         first = self.branches[0].name
         self.T, self.W = self.st.x[first].shape[:2]
@@ -289,7 +328,7 @@ class OracleRJSampler:
             steps[b.name] = step
         logp = compute_log_prior(q, st.inds, self.branches)                        # mh.py:120
         fix_logp_gibbs(logp, st.inds, [b.name for b in self.branches])             # mh.py:122-124 (every branch runs)
-        logl = compute_log_like(q, st.inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
+        logl = compute_log_like(q, st.inds, logp, self.branches, self.t, self.y, self.sigma, self.fill, like_fn=self.like_fn)
         u_acc = self._draw_accept("mh")
         accepted, lnpdiff = self._accept(np.zeros((self.T, self.W)), logl, logp, u_acc)
         if rec is not None:
@@ -343,7 +382,7 @@ class OracleRJSampler:
             new_inds = {n: st.inds[n][tt, S] for n in names}
             logp = compute_log_prior(q, new_inds, self.branches)                   # red_blue.py:260-266
             fix_logp_gibbs(logp, new_inds, names)                                  # red_blue.py:268
-            logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
+            logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill, like_fn=self.like_fn)
             u_acc = self._draw_accept_split(split, Ns)
             prevL, prevP = st.L[tt, S], st.P[tt, S]
             logP = base.tempered_log_posterior(logl, logp, st.betas)
@@ -477,7 +516,7 @@ class OracleRJSampler:
         factors += edge
         logp = compute_log_prior(q, new_inds, self.branches)                       # rj.py:300
         fix_logp_gibbs(logp, new_inds, [self.branches[bi].name for bi in bis])     # rj.py:302 (the branches under proposal)
-        logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill)
+        logl = compute_log_like(q, new_inds, logp, self.branches, self.t, self.y, self.sigma, self.fill, like_fn=self.like_fn)
         self._bi = bis[0] if len(bis) == 1 else len(self.branches)
         u_acc = self._draw_accept("rj")
         accepted, lnpdiff = self._accept(factors, logl, logp, u_acc)

@@ -40,7 +40,8 @@ SINE_BOX = [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]
 
 
 def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=1e-4, n_init=(2, 1),
-            seed_data=42, seed_construct=135, seed_run=246, rj_moves="separate_branches", in_model="gaussian", init_spread=1e-4):
+            seed_data=42, seed_construct=135, seed_run=246, rj_moves="separate_branches", in_model="gaussian", init_spread=1e-4,
+            model="template"):
     """in_model: "gaussian" - GaussianMove on the packed leaves; "stretch" - the red / blue StretchMove over EVERY branch and leaf
     slot of a walker (stretch.py:160-231: one complement draw per branch, one zz per walker; red_blue.py:103-330).  rj_moves None:
     no reversible jump (the leaf masks stay as they start)."""
@@ -69,7 +70,13 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")     # (ensemble.py:509-514: the reference advises against the stretch move under RJ - and runs it)
-        s = EnsembleSampler(W, ndims, log_like_fn_gauss_and_sine, priors, args=[t, y, sigma],
+        # model "lorentz_chirp" (round 6): a likelihood the device library has no kernel for - oracle/eryn_oracle_rj.py's
+        # lorentz_chirp_log_like, the function the -m gpu test hands to RJEnsembleSampler as the user's callable
+        like = log_like_fn_gauss_and_sine
+        if model == "lorentz_chirp":
+            sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)) if os.path.isdir(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle")) else "/root/repo")
+            from oracle.eryn_oracle_rj import lorentz_chirp_log_like as like
+        s = EnsembleSampler(W, ndims, like, priors, args=[t, y, sigma],
                             tempering_kwargs=dict(ntemps=T), nbranches=2, branch_names=branch_names,
                             nleaves_max=nleaves_max, nleaves_min=nleaves_min,
                             moves=GaussianMove(cov) if in_model == "gaussian" else StretchMove(),
@@ -82,6 +89,8 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
                nl_min=np.array(nl_min), cov_factor=float(cov_factor), seed_construct=seed_construct, seed_run=seed_run,
                gauss_box=np.array(GAUSS_BOX), sine_box=np.array(SINE_BOX), betas0=np.array(s.temperature_control.betas),
                L0=logl0, P0=logp0, rj_moves="none" if rj_moves is None else rj_moves, in_model=in_model)
+    if model != "template":
+        out["model"] = model
     for k in branch_names:
         out[f"x0_{k}"], out[f"inds0_{k}"] = coords[k].copy(), inds[k].copy()
 
@@ -161,3 +170,11 @@ if __name__ == "__main__":
     # moving with the stretch, births land on slots the stretch has been carrying along
     capture("rjs2_stretch_with_rj", T=3, W=32, nl_max=(3, 2), nl_min=(0, 0), nsteps=12, in_model="stretch", seed_run=61,
             init_spread=4e-4)
+    # Round 6: reversible jump with a likelihood that is a plain Python function of the packed active leaves (ensemble.py:1306-1334,
+    # 1420-1480) - Lorentzian lines + chirps, nothing the device library has a kernel for: the device proposes / tests / updates,
+    # the host evaluates (hens_rj_propose / hens_rj_accept)
+    capture("rjh1_callable", T=3, W=8, nl_max=(4, 3), nl_min=(0, 0), nsteps=16, model="lorentz_chirp", cov_factor=1e-3, seed_run=412)
+    capture("rjh2_callable_together", T=3, W=8, nl_max=(3, 3), nl_min=(1, 0), nsteps=12, model="lorentz_chirp", cov_factor=1e-3,
+            seed_run=413, rj_moves="together")
+    capture("rjh3_callable_stretch", T=2, W=32, nl_max=(3, 2), nl_min=(0, 0), nsteps=8, model="lorentz_chirp", in_model="stretch",
+            seed_run=414, init_spread=4e-4)

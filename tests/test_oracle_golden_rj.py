@@ -16,6 +16,9 @@ NAMES = ["rj1_two_branches", "rj2_min_leaves", "rj3_ten_leaves"]
 NAMES_ALL = NAMES + ["rj4_iterate_branches", "rj5_together"]
 # round 5: the red / blue StretchMove as the in-model move over every branch and leaf slot (no reversible jump / beside it)
 NAMES_STRETCH = ["rjs1_stretch_fixed_leaves", "rjs2_stretch_with_rj"]
+# round 6: the likelihood is a plain Python function of the packed active leaves (oracle/eryn_oracle_rj.py: lorentz_chirp_log_like),
+# not the template model - separate_branches, "together" with a leaf floor, and the stretch move as the in-model move
+NAMES_CALLABLE = ["rjh1_callable", "rjh2_callable_together", "rjh3_callable_stretch"]
 
 
 def load_rj(golden_dir, name):
@@ -33,10 +36,11 @@ def make_rj_oracle(fx, record=False):
     inds0 = {b.name: fx[f"inds0_{b.name}"] for b in branches}
     return orj.OracleRJSampler(branches, x0, inds0, fx["t"], fx["y"], float(fx["sigma"]), R, G, fx["betas0"],
                                record=record, schedule=str(fx["rj_moves"]) if "rj_moves" in fx else "separate_branches",
-                               in_model=str(fx["in_model"]) if "in_model" in fx else "gaussian")
+                               in_model=str(fx["in_model"]) if "in_model" in fx else "gaussian",
+                               like_fn=orj.lorentz_chirp_log_like if "model" in fx and str(fx["model"]) == "lorentz_chirp" else None)
 
 
-@pytest.mark.parametrize("name", NAMES_ALL + NAMES_STRETCH)
+@pytest.mark.parametrize("name", NAMES_ALL + NAMES_STRETCH + NAMES_CALLABLE)
 def test_rj_oracle_reproduces_the_reference(golden_dir, name):
     fx = load_rj(golden_dir, name)
     o = make_rj_oracle(fx)
