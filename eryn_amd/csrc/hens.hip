@@ -231,7 +231,6 @@ struct hens_ctx_impl {
     bool hip_dirty = true;           // the HIP stream may hold work the AQL queue has not been ordered behind
     bool aql_failed = false;         // a dispatch inside a void helper failed (checked by fused_iteration)
     int aql_ring_every = 8;
-    int stagger[4] = {0, 3, 512, 0};  // stagger_for: units, launch mask, slots, force (read from the environment when the context is created)
     // kernels launched by host function pointer (launch_by_ptr): dynamic-LDS attribute set on this context's device, AQL handle
     struct KernelSlot { bool attr_done = false; const hens_aql::Kernel* ak = nullptr; };
     std::unordered_map<const void*, KernelSlot> kslots;
@@ -426,7 +425,7 @@ size_t plan_lds_bytes(const hens_ctx_impl* c) { return (size_t)6 * c->W + 16; }
 
 // ---- stretch dispatch ----------------------------------------------------------------------------
 constexpr int FAST_NW_32 = 8;
-int fast_nw(int D) { return D == 64 ? HENS_NW64 : ((D == 32 || D == 128) ? 8 : 4); }
+int fast_nw(int D) { return (D == 32 || D == 64 || D == 128) ? 8 : 4; }
 // row widths with a compile-time-width kernel (k_stretch_fast)
 bool fast_path(const hens_ctx_impl* c) {
     const int D = c->D;
@@ -458,7 +457,7 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
         // (periodic parameters: an instantiation of their own - on a pipeline rank too - but not for the evaluation launch, which
         //  proposes nothing)
         const bool pipe = c->pipe.on, per = mode != MODE_EVAL && c->period;
-        const int NW = (mode == MODE_MH && c->D == 64) ? 8 : fast_nw(c->D);       // (the MH launch pairs rows per 8-wave pass: k_mh_draw)
+        const int NW = fast_nw(c->D);
         return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW, like), false,
                              c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
     }
@@ -1178,18 +1177,6 @@ const uint32_t* iteration_keys(hens_ctx_impl* c) {
     return c->ikeys + (size_t)(c->iter - c->ikeys_iter0) * c->T * 8;
 }
 
-// stagger_start's arguments for a launch of `nwg` workgroups (launch 1 = first half-step, 2 = second half-step + cascade): only
-// launches of more than one round of workgroups are staggered.  HENS_STAGGER = units of 64 shader cycles (bit 30: by dispatch
-// order instead of the CU's thread-group slot), HENS_STAGGER_LAUNCH = bit mask of the launches (default both),
-// HENS_STAGGER_SLOTS = resident workgroup slots of the chip (default 512: two 8-wave workgroups on each of 256 CUs).
-void stagger_for(const hens_ctx_impl* c, long nwg, int launch, int32_t* units, int32_t* slots) {
-    const int st = c->stagger[0], which = c->stagger[1], ns = c->stagger[2], force = c->stagger[3];
-    *units = 0; *slots = ns;
-    if (st == 0 || !(which & launch) || c->D < 32) return;
-    if (nwg <= ns && !force) return;
-    *units = st;
-}
-
 int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     const int T = c->T, W = c->W;
     if (!c->packed) {                        // (the pack kernel - first call after another entry point - runs on the HIP stream)
@@ -1234,7 +1221,6 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
         c->aql.norel_next = norel_ok(c);
         c->aql.prof_kind = 0;
         a.norel = c->aql.norel_next ? 1 : 0;
-        stagger_for(c, (long)((c->N0 + TILE - 1) / TILE) * c->Tl, 1, &a.stagger, &a.stagger_slots);
         const int r = launch_stretch<MODE_STRETCH>(c, a, (c->N0 + TILE - 1) / TILE);
         c->ext_start = c->ext_stop = nullptr;
         if (r) return r;
@@ -1275,7 +1261,6 @@ int fused_iteration(hens_ctx_impl* c, std::vector<hipEvent_t>* evs) {
     c->aql.norel_next = norel_ok(c);
     c->aql.prof_kind = 2;
     f.norel = c->aql.norel_next ? 1 : 0;
-    stagger_for(c, (long)(c->W / c->label_cb), 2, &f.stagger, &f.stagger_slots);
     int r;
     switch (c->cfg.likelihood_kind) {
         case HENS_LIKE_GAUSS_DENSE: r = launch_fused_like(c, LIKE_DENSE, f, e0, e1, false, c->colmode); break;
@@ -1880,10 +1865,6 @@ int hens_create(const hens_config* cfg, hens_ctx** out) {
         TRYHIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi));
     }
     c->own_stream = true;
-    {
-        static const char* names[4] = {"HENS_STAGGER", "HENS_STAGGER_LAUNCH", "HENS_STAGGER_SLOTS", "HENS_STAGGER_FORCE"};
-        for (int i = 0; i < 4; ++i) if (const char* v = getenv(names[i])) c->stagger[i] = atoi(v);
-    }
     {   // the context's AQL queue for the stepping launches (hens_aql.h); HENS_NO_AQL=1: everything on the HIP stream
         static const bool aql_off = getenv("HENS_NO_AQL") != nullptr;
         if (!aql_off) {

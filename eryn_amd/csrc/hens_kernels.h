@@ -293,22 +293,6 @@ __device__ __forceinline__ void wt_store(double* p, double v) { __hip_atomic_sto
 __device__ __forceinline__ void wt_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wt_store(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void launch_end_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// Round 6: launches of more than one round of workgroups (the config-3 shard: 1 024 workgroups on 512 slots) ran
-// their rounds in lockstep - the two resident workgroups of a CU walk A -> E together, the fabric idles while both compute.
-// `stagger` > 0: in the FIRST round (linear dispatch index below `slots`) the workgroup in the CU's odd thread-group slot (HW_ID
-// TG_ID bit 0; bit 30 of `stagger`: odd half of the dispatch order instead) starts stagger x 64 shader cycles late, so that its
-// gathers fall into its neighbour's likelihood / accept phases - and stay there: later rounds start as slots free up.
-// Timing only: no result depends on when a workgroup runs.
-__device__ __forceinline__ void stagger_start(int32_t stagger, uint32_t lin, uint32_t slots) {
-    if (stagger == 0 || lin >= slots) return;
-    const uint32_t units = (uint32_t)stagger & 0xFFFFu;
-    bool late;
-    if (stagger & (1 << 30)) late = ((lin >> 3) / (slots >> 4)) & 1u;          // per XCD: the second half of its first round
-    else late = (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1u) != 0u;   // hwreg(HW_REG_HW_ID, 16, 4): TG_ID
-    if (!late) return;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)units * 64ull) __builtin_amdgcn_s_sleep(8);
-}
 
 
 // Flag discipline: everything a peer reads is stored with system-scope write-through stores (sys_store),
@@ -654,7 +638,6 @@ struct StretchArgs {
     int32_t norel;             // this launch's packet carries no release fence (hens_aql.h: norel_next): the records are written through and
                                // every wave ends behind its stores (wt_store, launch_end_wait); 0: plain stores, the fence writes them back
     int32_t xcd_shift;         // > 0: log2(tiles per rung) + 1 - workgroups are renumbered so that an XCD (linear id mod 8) works on whole rungs
-    int32_t stagger, stagger_slots;   // see stagger_start (0: off)
     AdaptArgs ad;
 };
 
@@ -937,10 +920,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //   HENS_ROWSTORE 0 plain (write-back L2), 1 sc1 write-through (asm), 2 nontemporal
 #ifndef HENS_ROWSTORE
 #define HENS_ROWSTORE 1
-#endif
-// wavefronts per workgroup of the D = 64 stepping kernels (A/B libraries: -DHENS_NW64=4, round 6's one-round probe)
-#ifndef HENS_NW64
-#define HENS_NW64 8
 #endif
 // The stepping launches of one GPU carry no release fence (hens_aql.h: norel_next; hens.hip: norel_ok) BECAUSE a row leaves as a
 // write-through store: with HENS_ROWSTORE 0 or 2 (A/B libraries) rows would sit dirty in one XCD's L2 and the next launch would
@@ -1502,7 +1481,6 @@ __global__ __launch_bounds__(NW * 64) void k_stretch_fast(const StretchArgs A) {
     const bool ad_lead = ad_on && A.ad_on == 2;
     const bool ad_here = ad_on && (!ad_lead || (blockIdx.x == 0 && blockIdx.y == 0));
 #define HENS_TRACE(i) do { if (A.trace && tid == 0) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = trace_stamp(); } while (0)
-    if constexpr (!EVAL && DT >= 32) stagger_start(A.stagger, blockIdx.x + blockIdx.y * gridDim.x, (uint32_t)A.stagger_slots);
     HENS_TRACE(0);
 #ifdef HENS_DEV_BUILD
     if (HENS_CUT_S == 9 && !EVAL && !PIPE && A.inplace) return;
@@ -3091,7 +3069,6 @@ struct FusedArgs {
     int32_t par, nranks, rank;
     int32_t sys_rows;                                         // rows are stored at system scope (a peer pulls rows out of this pool)
     int32_t no_move;                                          // PIPE: the cascade alone (the iteration's move was a full-ensemble MH launch)
-    int32_t stagger, stagger_slots;                           // see stagger_start (0: off)
 };
 
 // (pipe: the cascade tables hold one more rung - what the hot neighbour's columns carry - and the bottom boundary's lists)
@@ -3169,7 +3146,6 @@ __global__ __launch_bounds__(NW * 64) void k_split1_pt(const FusedArgs A) {
     // NEr = cb T <= 128 slots and NM = NEr / 2 <= 64 moving walkers; the lanes / rows beyond them idle
     const int NEr = SHORT ? (T << CS) : 2 * TILE, NM = SHORT ? (NEr >> 1) : TILE;
 #define FUSED_TRACE(i) do { if (A.trace && tid == 0) A.trace[(size_t)blockIdx.x * 8 + (i)] = trace_stamp(); } while (0)
-    if constexpr (DT >= 32) stagger_start(A.stagger, blockIdx.x, (uint32_t)A.stagger_slots);
     FUSED_TRACE(0);
 #ifdef HENS_DEV_BUILD
     if (HENS_CUT_F == 9) return;
