@@ -195,7 +195,7 @@ CLOCKS = {0: None, 1: "HIP event pair per launch on the HIP stream (the queue th
              "arguments as the timed blocks)"}
 
 
-def profiled_pass(eng, steps, calls=10):
+def profiled_pass(eng, steps, calls=10, expect_us=0.0):
     """Per-launch durations on the path the timed blocks ran: `calls` further calls of `steps` steps with hens_set_profiling(2) -
     on one GPU every packet of the context's AQL queue carries a completion signal that the packet processor stamps with the
     launch's begin and end (the figures rocprofv3's kernel trace reads); calls that step on the HIP stream anyway (MH mix, ranks)
@@ -223,6 +223,13 @@ def profiled_pass(eng, steps, calls=10):
             acc = None
         finally:
             eng.set_profiling(0)
+        if acc is not None and mode == 2:
+            # sanity: the launches of a queue with barrier bits tile the call - under a profiler that intercepts the queue
+            # (rocprofv3) the signals carry somebody else's stamps (seen: 1.2 us "launches" in a 16 us iteration)
+            busy = (acc["stretch_ms"] + acc["fused_ms"] + acc["pt_ms"]) * 1e3 / max(acc["n_iters"], 1)
+            if not (0.5 * span * 1e3 / max(acc["n_iters"], 1) <= busy and busy >= 0.5 * expect_us):
+                print(f"[bench] dispatch timestamps implausible ({busy:.2f} us of kernels per iteration): falling back to HIP events", file=sys.stderr, flush=True)
+                acc = None
         if acc is not None:
             break
     if acc is None:
@@ -377,7 +384,7 @@ def time_other_shape(T, W, D, steps, warmup, rosen_mix=False):
     nit = max(steps * BLOCKS, 1)
     f_sw = float(np.mean(c["swaps_total"] / W / nit))
     acc = float(c["accepted"].mean() / max(c["num_proposals"], 1))
-    tm = profiled_pass(eng, steps)
+    tm = profiled_pass(eng, steps, expect_us=dt / steps * 1e6)
     eng.close()
     value = T * W * steps / dt
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
@@ -425,7 +432,7 @@ def run_single(args):
     acc = float(c["accepted"].mean() / max(c["num_proposals"], 1))
 
     # per-launch durations: further calls of K steps on the SAME queue with a completion signal per packet (dispatch timestamps)
-    tm = profiled_pass(eng, args.steps)
+    tm = profiled_pass(eng, args.steps, expect_us=dt / args.steps * 1e6)
     eng.close()
     value = T * W * args.steps / dt
     roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
@@ -494,7 +501,7 @@ def run_cfg5(args):
     dt = float(np.median(times))
     c, m = eng.counters(), eng.mh_counters()
     f_sw = float(np.mean(c["swaps_total"] / W / max(args.steps * BLOCKS, 1)))
-    tm = profiled_pass(eng, args.steps, calls=3)
+    tm = profiled_pass(eng, args.steps, calls=3, expect_us=dt / args.steps * 1e6)
     eng.close()
     value = T * W * args.steps / dt
     acc5 = float(c["accepted"].mean() / max(c["num_proposals"], 1))
@@ -541,6 +548,24 @@ def rj_roofline(value, evals, alg):
             out["warning"] = "VALU fraction above 1: the static profile does not match this run"
     else:
         out.update(achieved=None, frac=None)
+    per = (st or {}).get("per_instantiation")
+    if per:
+        # round 6: the same launches in the path's own arithmetic - FP64 flops (add + mul + 2 fma + transcendental, x 64 lanes, from
+        # the SQ_INSTS_VALU_*_F64 counters) against the 78.6 TFLOP/s FP64 vector peak, and what a walker's wavefront issues by class
+        def mix(v):
+            pw = v["per_wave"]
+            g = lambda n: float(pw.get("SQ_INSTS_" + n, 0.0))
+            f64 = g("VALU_ADD_F64") + g("VALU_MUL_F64") + g("VALU_FMA_F64") + g("VALU_TRANS_F64")
+            return {"avg_us": v["avg_us"], "fp64_TFLOPs": v["fp64_TFLOPs"], "frac_of_fp64_vector_peak": v["frac_of_fp64_vector_peak_78.6TF"],
+                    "valu_issue_frac": v["valu_issue_frac"],
+                    "per_walker": {"valu": g("VALU"), "fp64_add": g("VALU_ADD_F64"), "fp64_mul": g("VALU_MUL_F64"), "fp64_fma": g("VALU_FMA_F64"),
+                                   "fp64_trans": g("VALU_TRANS_F64"), "int32": g("VALU_INT32"), "int64": g("VALU_INT64"), "cvt": g("VALU_CVT"),
+                                   "valu_other (moves, selects, compares, lane exchanges)": g("VALU") - f64 - g("VALU_INT32") - g("VALU_INT64") - g("VALU_CVT"),
+                                   "salu": g("SALU"), "smem": g("SMEM"), "lds": g("LDS"), "vmem_rd": g("VMEM_RD"), "vmem_wr": g("VMEM_WR")}}
+        names = {"k_rj<1, 0>": "in-model move (full evaluation)", "k_rj<2, 1>": "birth / death (model +- one leaf)"}
+        out["fp64_roofline"] = {"peak_TFLOPs": 78.6, "source": "profiles/rj_valu.json (static: rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 ... passes of "
+                                                                 "this command, tools/profile_rj.sh; durations from the same profile's kernel trace)",
+                                "launches": {names[k]: mix(v) for k, v in per.items() if k in names}}
     return out
 
 
