@@ -339,6 +339,9 @@ __device__ __forceinline__ void pipe_spin(const unsigned* f, uint32_t target, lo
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         return;
     }
+    // (a wait of this context has timed out before: the run has failed - every later wait of its queued launches would spend the
+    //  whole budget again, 8 ranks x iterations x 2 launches of them one after the other; slow path only)
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FLAG_PIPE_TIMEOUT) return;
     const long long w0 = stats ? wall_clock64() : 0;      // (debug statistics only: ~1.5 us per reading)
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < target ||

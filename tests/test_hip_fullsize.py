@@ -74,3 +74,29 @@ def test_config5_full_size_rosenbrock_move_mix():
 def test_config5_shard_replayed_through_the_oracle():
     kinds = rp._run_case(4, 8192, 128, like_kind="rosen", box=5.0, calls=(4,), x_scale=0.3, mh=("iso", 2e-3, 0.5))
     assert "mh" in kinds and "stretch" in kinds
+
+
+def test_eight_ranks_sharing_one_gpu_at_w_2048_run_or_fail_cleanly(tmp_path):
+    """VERDICT r5 #4.  Eight ranks of config 3's ladder at nwalkers = 2048 on ONE GPU: 8 x 2 launches of 256 workgroups whose flag
+    waits need their producers resident - more than the chip holds at once, so this deadlocks two runs out of three (on a node every
+    rank has a GPU of its own).  What is asserted is that it NEVER hangs the GPU: the flag waits are bounded on the shader clock
+    (HENS_PIPE_TIMEOUT_S), the run either finishes - then bit-identical to the whole ladder on one context - or every rank's call
+    fails with a RuntimeError within the budget and the process exits; never a kill by the harness's timeout."""
+    import time
+    T, W, D, iters = 64, 2048, 64, 4
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", HENS_PIPE_TIMEOUT_S="5", PIPE_TEST_DELAY="0", PIPE_TEST_MODEL="gauss")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, WORKER, "local", "8", str(T), str(W), str(D), str(iters), str(tmp_path / "local.npz")],
+                       env=env, capture_output=True, text=True, timeout=300)       # (far above 5 s of flag budget + start-up: a hang fails here)
+    took = time.time() - t0
+    if r.returncode == 0:
+        _worker(["single", T, W, D, iters, tmp_path / "single.npz"])
+        with np.load(tmp_path / "single.npz") as a, np.load(tmp_path / "local.npz") as b:
+            for k in KEYS:
+                assert np.array_equal(a[k], b[k]), f"{k}: whole ladder vs 8 shards at W = 2048"
+    else:
+        msg = r.stdout[-3000:] + r.stderr[-3000:]
+        assert "RuntimeError" in msg and ("flag" in msg or "timed out" in msg or "pipeline" in msg), f"an unclean failure:\n{msg}"
+        assert took < 200, f"the bounded waits took {took:.0f} s"
+    # the GPU is still usable afterwards
+    _worker(["single", 4, 256, 16, 2, tmp_path / "after.npz"])
