@@ -178,3 +178,5 @@ if __name__ == "__main__":
             seed_run=413, rj_moves="together")
     capture("rjh3_callable_stretch", T=2, W=32, nl_max=(3, 2), nl_min=(0, 0), nsteps=8, model="lorentz_chirp", in_model="stretch",
             seed_run=414, init_spread=4e-4)
+    capture("rjh4_callable_iterate", T=3, W=8, nl_max=(4, 3), nl_min=(0, 1), nsteps=12, model="lorentz_chirp", cov_factor=1e-3,
+            seed_run=415, rj_moves="iterate_branches")

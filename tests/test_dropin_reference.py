@@ -304,3 +304,31 @@ def test_device_draw_move_under_the_real_sampler_thin_by_10(eryn, golden_dir):
     g.accepted = np.zeros((T, W))
     st, acc = g.propose(s.get_model(), state)
     assert ("mh_proposal", "iso", 1.0) in eng.calls and acc.shape == (T, W)
+
+
+def test_device_draw_move_mix_under_the_real_sampler_keeps_one_resident_state(eryn, golden_dir):
+    """Stretch + Gaussian, both rng="philox", under the unmodified reference sampler: the sampler's own stream picks the move per
+    proposal (ensemble.py:971); the two moves share one context and one resident state - a DeviceState made by one move is current
+    for the other (no upload in between), and every proposal tells the context which move to run."""
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves import GaussianMove, StretchMove
+    from eryn_amd.state import DeviceState
+    fx = _fixture(golden_dir, "m6_mix")
+    T, W, D, box = int(fx["T"]), int(fx["W"]), int(fx["D"]), float(fx["box"])
+    mu, invcov = fx["mu"], fx["invcov"]
+    like = GaussianLikelihood(mu, invcov)
+    eng = OracleEngine(T, W, D, lambda x: _loglike(x, mu, invcov), -box, box)
+    shared = [None]
+    mvs = [(StretchMove(likelihood=like, prior_box=(-box, box), rng="philox"), 0.5),
+           (GaussianMove({"model_0": 0.01}, likelihood=like, prior_box=(-box, box), rng="philox"), 0.5)]
+    for m, _ in mvs:
+        m.attach_engine(eng, shared)
+    s = _reference_sampler(eryn, fx, mvs)
+    state = s.run_mcmc(fx["x0"], 30, store=False)
+    assert isinstance(state, DeviceState)
+    st, g = mvs[0][0], mvs[1][0]
+    assert st.num_proposals + g.num_proposals == 30 and st.num_proposals > 3 and g.num_proposals > 3
+    assert eng.calls.count("upload") == 1 and eng.calls.count("download") == 0, "one upload at the start, nothing read until the end"
+    kinds = [c[1] for c in eng.calls if isinstance(c, tuple) and c[0] == "mh_proposal"]
+    assert "iso" in kinds and None in kinds, "the context was told to run the Gaussian move and the stretch move in turn"
+    assert np.array_equal(state.log_like, eng.L) and eng.calls.count("download") == 1

@@ -17,8 +17,8 @@ NAMES_ALL = NAMES + ["rj4_iterate_branches", "rj5_together"]
 # round 5: the red / blue StretchMove as the in-model move over every branch and leaf slot (no reversible jump / beside it)
 NAMES_STRETCH = ["rjs1_stretch_fixed_leaves", "rjs2_stretch_with_rj"]
 # round 6: the likelihood is a plain Python function of the packed active leaves (oracle/eryn_oracle_rj.py: lorentz_chirp_log_like),
-# not the template model - separate_branches, "together" with a leaf floor, and the stretch move as the in-model move
-NAMES_CALLABLE = ["rjh1_callable", "rjh2_callable_together", "rjh3_callable_stretch"]
+# not the template model - separate_branches, "together" with a leaf floor, the stretch move as the in-model move, "iterate_branches"
+NAMES_CALLABLE = ["rjh1_callable", "rjh2_callable_together", "rjh3_callable_stretch", "rjh4_callable_iterate"]
 
 
 def load_rj(golden_dir, name):

@@ -146,6 +146,45 @@ def test_rj_sampler_with_a_python_likelihood_reproduces_the_reference_chain(gold
 
 
 @pytest.mark.gpu
+def test_vectorised_python_likelihood_lands_on_the_same_chain(golden_dir):
+    """``vectorize=True, provide_groups=True`` (ensemble.py:1376-1409): ONE call per proposal with every group's packed leaves and
+    the group ids - the chain is the per-group one's (and so the reference's, rjh1), with 1 / (evaluated walkers) of the calls."""
+    from eryn_amd.prior import uniform_dist
+    from eryn_amd.rj import GaussianLeafMove, RJEnsembleSampler
+    from eryn_amd.state import State
+    fx = load_rj(golden_dir, "rjh1_callable")
+    names = ["gauss", "sine"]
+    n = int(fx["nsteps"])
+    priors = {"gauss": {i: uniform_dist(*fx["gauss_box"][i]) for i in range(3)},
+              "sine": {i: uniform_dist(*fx["sine_box"][i]) for i in range(3)}}
+    calls = []
+
+    def vec_fn(params, groups, t, y, sigma):
+        calls.append(len(params[0]) + len(params[1]))
+        ng = int(max(g.max() if len(g) else -1 for g in groups)) + 1
+        out = np.zeros(ng)
+        for g in range(ng):
+            arg = [p[gr == g] if np.any(gr == g) else None for p, gr in zip(params, groups)]
+            out[g] = orj.lorentz_chirp_log_like(arg, t, y, sigma)
+        return out
+
+    np.random.seed(int(fx["seed_construct"]))
+    s = RJEnsembleSampler(int(fx["W"]), {k: 3 for k in names}, vec_fn, priors, args=[fx["t"], fx["y"], float(fx["sigma"])],
+                          vectorize=True, provide_groups=True, tempering_kwargs=dict(ntemps=int(fx["T"])), branch_names=names,
+                          nleaves_max=dict(zip(names, map(int, fx["nl_max"]))), nleaves_min=dict(zip(names, map(int, fx["nl_min"]))),
+                          moves=GaussianLeafMove({k: np.eye(3) * float(fx["cov_factor"]) for k in names}))
+    np.random.seed(int(fx["seed_run"]))
+    last = s.run_mcmc(State({k: fx[f"x0_{k}"] for k in names}, log_like=fx["L0"], log_prior=fx["P0"],
+                            inds={k: fx[f"inds0_{k}"] for k in names}), n, store=False)
+    pre = f"it{n - 1}_rj_"
+    for k in names:
+        assert np.array_equal(last.branches[k].inds, fx[pre + f"inds_{k}"]) and np.array_equal(last.branches[k].coords, fx[pre + f"x_{k}"])
+    assert np.array_equal(last.log_like, fx[pre + "L"]) and np.array_equal(last.log_prior, fx[pre + "P"])
+    assert len(calls) == 2 * n, "one call per proposal (in-model move + birth / death per iteration)"
+    s.engine.close()
+
+
+@pytest.mark.gpu
 def test_initial_log_like_of_a_python_likelihood_and_error_paths(golden_dir):
     """run_mcmc without log_like / log_prior evaluates them - the prior on the device, the likelihood through the user's function;
     a likelihood that raises leaves the context usable (the pending move is rejected as a whole); NaN raises ValueError."""
