@@ -13,7 +13,7 @@ OBJ_DIR = os.environ.get("HENS_OBJ_DIR") or os.path.join(os.path.dirname(HERE), 
 UNITS = [("hens", "hens.hip", [])] + [(f"hens_k_{k}_{part}", f"hens_k_{k}.hip", [f"-DHENS_KT_PART={part}"])
                                       for k in ("dense", "diag", "rosen") for part in (0, 1)]
 SOURCES = sorted({os.path.join(SRC_DIR, u[1]) for u in UNITS})
-DEPS = SOURCES + [os.path.join(SRC_DIR, h) for h in ("hens_kernels.h", "hens_rj.h", "hens_iter.h", "hens_aql.h", "hens_ktable.h", "hens_ktable.inc")] + [
+DEPS = SOURCES + [os.path.join(SRC_DIR, h) for h in ("hens_kernels.h", "hens_rj.h", "hens_iter.h", "hens_tile2.h", "hens_aql.h", "hens_ktable.h", "hens_ktable.inc")] + [
     os.path.join(os.path.dirname(HERE), "include", "hipensemble.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-cuda-compat"] + os.environ.get("HENS_BUILD_DEFS", "").split()   # (inline __global__: see hens_kernels.h)
 
@@ -54,7 +54,7 @@ def build(force=False, verbose=False):
         # an object is kept if it is newer than everything its unit includes (the kernel units see neither hens.hip nor the RJ / AQL
         # headers) and was made by the same command
         deps = [os.path.join(SRC_DIR, src), os.path.join(os.path.dirname(HERE), "include", "hipensemble.h"), os.path.abspath(__file__)] + [
-            os.path.join(SRC_DIR, h) for h in (("hens_kernels.h", "hens_iter.h", "hens_ktable.h") +
+            os.path.join(SRC_DIR, h) for h in (("hens_kernels.h", "hens_iter.h", "hens_tile2.h", "hens_ktable.h") +
                                                (("hens_rj.h", "hens_aql.h") if name == "hens" else ("hens_ktable.inc",)))]
         stamp = obj + ".cmd"
         fresh = (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd) and

@@ -4,6 +4,7 @@
 #include "hens_kernels.h"
 #include "hens_rj.h"
 #include "hens_iter.h"
+#include "hens_tile2.h"
 #include "hens_aql.h"
 #include "hens_ktable.h"
 #include <unordered_map>
@@ -355,6 +356,16 @@ const void* ktab_stretch_fast(int like, int mode, int D, bool pipe, bool per) {
     }
     return nullptr;
 }
+const void* ktab_stretch2(int like, int D) {
+    switch (like) {
+        case LIKE_DENSE: return ktab_stretch2_dense(D);
+#ifndef HENS_DEV_BUILD
+        case LIKE_DIAG: return ktab_stretch2_diag(D);
+        case LIKE_ROSEN: return ktab_stretch2_rosen(D);
+#endif
+    }
+    return nullptr;
+}
 const void* ktab_stretch(int like, int mode) {
     switch (like) {
         case LIKE_DENSE: return ktab_stretch_dense(mode);
@@ -458,6 +469,27 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
         //  proposes nothing)
         const bool pipe = c->pipe.on, per = mode != MODE_EVAL && c->period;
         const int NW = fast_nw(c->D);
+        {
+            // Round 6: launches of more than one round of workgroups (two 8-wave workgroups on each of 256 CUs) go to the persistent,
+            // software-pipelined kernel (hens_tile2.h) - hens_step's in-place first launch on column-ordered records, the adaptation
+            // folded the way its lambdas are ported (counts in accumulation rows, ladders of up to 128 rungs).  HENS_NO_TILE2=1: the
+            // rounds of k_stretch_fast; HENS_TILE2_FORCE=n: n tiles per workgroup on any grid that divides (tests).
+            static const bool off = getenv("HENS_NO_TILE2") != nullptr;
+            static const int force = getenv("HENS_TILE2_FORCE") ? atoi(getenv("HENS_TILE2_FORCE")) : 0;
+            const void* k2 = (!off && mode == MODE_STRETCH && !pipe && !per && a.inplace && a.col && a.wrec && a.ikeys && a.ns_x == 0 && !a.trace &&
+                              (a.ad_on == 0 || (a.ad_on == 1 && a.ad.nblocks <= 8 * a.ad.row_groups))) ? ktab_stretch2(like, c->D) : nullptr;
+            int tp = 0;                  // (the kernel walks TWO tiles per workgroup; grids beyond 1 024 tiles run as rounds of pairs)
+            if (k2 && ntiles % 2 == 0 && (force > 0 || (long)ntiles * c->Tl > 512)) tp = 2;
+            if (tp > 1 && tile2_lds_bytes(c->D, like) <= 80 * 1024) {
+                const int gx = ntiles / tp;
+                a.tiles_per_wg = tp;
+                a.xcd_shift = 0;
+                static const bool xcd = getenv("HENS_NO_XCD") == nullptr;
+                if (xcd && (gx & (gx - 1)) == 0 && ((long)gx * c->Tl) % 8 == 0) { int sh = 0; while ((1 << sh) < gx) ++sh; a.xcd_shift = sh + 1; }
+                return launch_by_ptr(c, k2, "k_stretch2", dim3(gx, c->Tl), NW * 64, tile2_lds_bytes(c->D, like), false,
+                                     c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
+            }
+        }
         return launch_by_ptr(c, ktab_stretch_fast(like, mode, c->D, pipe, per), "k_stretch_fast", grid, NW * 64, fast_lds_bytes(c->D, NW, like), false,
                              c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
     }

@@ -641,6 +641,7 @@ struct StretchArgs {
     int32_t norel;             // this launch's packet carries no release fence (hens_aql.h: norel_next): the records are written through and
                                // every wave ends behind its stores (wt_store, launch_end_wait); 0: plain stores, the fence writes them back
     int32_t xcd_shift;         // > 0: log2(tiles per rung) + 1 - workgroups are renumbered so that an XCD (linear id mod 8) works on whole rungs
+    int32_t tiles_per_wg;      // k_stretch2 (hens_tile2.h): tiles a persistent workgroup walks (grid.x = tiles per rung / tiles_per_wg)
     AdaptArgs ad;
 };
 

@@ -311,3 +311,50 @@ def test_dispatch_timestamps_time_the_same_chain_on_the_same_queue(T, W, D, one)
     assert 0 < busy <= tm["total_ms"] * 1e3 * 1.0001
     assert 1.0 < busy / 20 < 200.0, f"implausible per-iteration kernel time {busy / 20:.2f} us"
     a.close(); b.close()
+
+
+# ---- round 6: the persistent, software-pipelined first launch (hens_tile2.h) ------------------------------------------------------
+_TILE2_WORKER = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests import parity_utils as pu
+from oracle import eryn_oracle as orc
+from eryn_amd.engine import HipEnsemble
+from eryn_amd.likelihood import GaussianLikelihood, RosenbrockLikelihood
+T, W, D, like, n, stop = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
+mu, invcov = pu.gaussian_problem(D)
+lk = RosenbrockLikelihood(D) if like == "rosen" else GaussianLikelihood(mu, np.diag(invcov).copy() if like == "diag" else invcov)
+box = 5.0 if like == "rosen" else 50.0
+eng = HipEnsemble(T, W, D, lk, -box, box, seed=5, adaptation_lag=50, adaptation_time=10, stop_adaptation=stop)
+eng.upload(np.clip(np.random.RandomState(11).randn(T, W, D), -0.9 * box, 0.9 * box), betas=orc.make_ladder(D, ntemps=T))
+eng.eval_state()
+eng.step(2); eng.step(n // 2); eng.step(n - n // 2)
+x, L, P, betas = eng.download()
+c = eng.counters()
+eng.set_profiling(2); eng.step(4); tm = eng.timing(); eng.set_profiling(0)
+np.savez(sys.argv[8], x=x, L=L, P=P, betas=betas, accepted=c["accepted"], swaps_total=c["swaps_total"])
+"""
+
+
+@pytest.mark.parametrize("T,W,D,like,iters,stop", [(8, 16384, 64, "dense", 60, -1), (4, 512, 64, "dense", 300, -1), (8, 2048, 64, "diag", 300, -1),
+                                                    (8, 2048, 64, "rosen", 300, 40), (8, 1168, 64, "dense", 200, 30), (16, 512, 64, "dense", 200, -1),
+                                                    (2, 512, 64, "diag", 200, -1)])
+def test_persistent_pipelined_first_launch_equals_the_rounds_of_workgroups(T, W, D, like, iters, stop, tmp_path):
+    """k_stretch2 (hens_tile2.h; round 6): launches of more than one round of workgroups at D = 64 run the first half-step in
+    persistent workgroups that walk two tiles, tile n + 1's phase A and part of its gathers under tile n's likelihood / accept
+    phases.  Same arithmetic, same draws: the chain must be k_stretch_fast's (HENS_NO_TILE2=1) bit for bit - at the config-3
+    shard (selected by default) and, forced (HENS_TILE2_FORCE=1), on small grids: three likelihoods, a ragged last tile
+    (N0 = 584), ladders of 2, 4, 8, 16 rungs, the adaptation moving and stopped half-way (stop_adaptation)."""
+    outs = []
+    for env in ({"HENS_TILE2_FORCE": "1"}, {"HENS_NO_TILE2": "1"}):
+        out = str(tmp_path / f"{len(outs)}.npz")
+        e = dict(os.environ, **env)
+        for k in ("HENS_TILE2_FORCE", "HENS_NO_TILE2"):
+            if k not in env:
+                e.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", _TILE2_WORKER, ROOT, str(T), str(W), str(D), like, str(iters), str(stop), out],
+                           env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(dict(np.load(out)))
+    _assert_same(outs[0], outs[1], f"({T},{W},{D},{like}) persistent pipelined first launch vs rounds of workgroups")
+    assert outs[0]["accepted"].sum() > 0 and outs[0]["swaps_total"].sum() > 0
