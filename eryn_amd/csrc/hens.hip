@@ -356,12 +356,12 @@ const void* ktab_stretch_fast(int like, int mode, int D, bool pipe, bool per) {
     }
     return nullptr;
 }
-const void* ktab_stretch2(int like, int D) {
+const void* ktab_stretch2(int like, int D, bool pipe) {
     switch (like) {
-        case LIKE_DENSE: return ktab_stretch2_dense(D);
+        case LIKE_DENSE: return ktab_stretch2_dense(D, pipe);
 #ifndef HENS_DEV_BUILD
-        case LIKE_DIAG: return ktab_stretch2_diag(D);
-        case LIKE_ROSEN: return ktab_stretch2_rosen(D);
+        case LIKE_DIAG: return ktab_stretch2_diag(D, pipe);
+        case LIKE_ROSEN: return ktab_stretch2_rosen(D, pipe);
 #endif
     }
     return nullptr;
@@ -476,16 +476,29 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
             // rounds of k_stretch_fast; HENS_TILE2_FORCE=n: n tiles per workgroup on any grid that divides (tests).
             static const bool off = getenv("HENS_NO_TILE2") != nullptr;
             static const int force = getenv("HENS_TILE2_FORCE") ? atoi(getenv("HENS_TILE2_FORCE")) : 0;
-            const void* k2 = (!off && mode == MODE_STRETCH && !pipe && !per && a.inplace && a.col && a.wrec && a.ikeys && a.ns_x == 0 && !a.trace &&
-                              (a.ad_on == 0 || (a.ad_on == 1 && a.ad.nblocks <= 8 * a.ad.row_groups))) ? ktab_stretch2(like, c->D) : nullptr;
+            // A rank of the ladder pipeline stepping with the two in-place launches (pipe_fused_iteration) has the kernel's PIPE
+            // instantiation, for what that ports of k_stretch_fast<PIPE>: the lead workgroup's adaptation (ad_on == 2, the counts in
+            // the mailbox's one row), counts pushed by the publishing wave (cnt_push != 1), no (L, P) publishing, no injection hook.
+            static const bool off_pipe = getenv("HENS_NO_TILE2_PIPE") != nullptr;
+            const bool ad_ok = pipe ? (a.ad_on == 0 || (a.ad_on == 2 && a.ad.nblocks <= 8 * a.ad.row_groups && a.ad.row_groups == 1))
+                                    : (a.ad_on == 0 || (a.ad_on == 1 && a.ad.nblocks <= 8 * a.ad.row_groups));
+            // (cnt_push == 1 - the delayed schedule's push through k_stretch_fast's count-reduction machinery: here the publishing wave's,
+            //  cnt_push = 3, same rows, same mailbox words and flag)
+            const bool push_ok = a.cnt_push != 1 || (a.cp_zero && a.cp_rows != c->swap_part);
+            const bool pipe_ok = !pipe || (!off_pipe && c->pipe.fused && a.ghome && !a.pub_lp && push_ok && a.inject_c64 <= 0);
+            const void* k2 = (!off && mode == MODE_STRETCH && pipe_ok && !per && a.inplace && a.col && a.wrec && a.ikeys && a.ns_x == 0 && !a.trace &&
+                              ad_ok) ? ktab_stretch2(like, c->D, pipe) : nullptr;
             int tp = 0;                  // (the kernel walks TWO tiles per workgroup; grids beyond 1 024 tiles run as rounds of pairs)
             if (k2 && ntiles % 2 == 0 && (force > 0 || (long)ntiles * c->Tl > 512)) tp = 2;
             if (tp > 1 && tile2_lds_bytes(c->D, like) <= 80 * 1024) {
                 const int gx = ntiles / tp;
                 a.tiles_per_wg = tp;
+                if (pipe && a.cnt_push == 1) a.cnt_push = 3;
                 a.xcd_shift = 0;
                 static const bool xcd = getenv("HENS_NO_XCD") == nullptr;
                 if (xcd && (gx & (gx - 1)) == 0 && ((long)gx * c->Tl) % 8 == 0) { int sh = 0; while ((1 << sh) < gx) ++sh; a.xcd_shift = sh + 1; }
+                static const bool say = getenv("HENS_TILE2_LOG") != nullptr;      // (tests: which kernel a context's first launches went to)
+                if (say && c->iter < 3) fprintf(stderr, "hens: k_stretch2<pipe=%d> grid %d x %d, ad_on %d, cnt_push %d\n", pipe ? 1 : 0, gx, c->Tl, a.ad_on, a.cnt_push);
                 return launch_by_ptr(c, k2, "k_stretch2", dim3(gx, c->Tl), NW * 64, tile2_lds_bytes(c->D, like), false,
                                      c->aql_now ? nullptr : c->ext_start, c->ext_stop, a);
             }

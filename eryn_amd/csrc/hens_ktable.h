@@ -11,7 +11,7 @@ namespace hens {
 #define HENS_KTABLE_DECL(KIND)                                                                                                \
     const void* ktab_stretch_fast_##KIND(int mode, int D, bool pipe, bool per);                                               \
     const void* ktab_stretch_##KIND(int mode);                                                                                \
-    const void* ktab_stretch2_##KIND(int D);                                                                                  \
+    const void* ktab_stretch2_##KIND(int D, bool pipe);                                                                                  \
     const void* ktab_split1_pt_##KIND(int D, bool per, bool shrt, bool pipe, bool col);                                       \
     const void* ktab_iter_##KIND(int D, bool per);
 HENS_KTABLE_DECL(dense)

@@ -29,18 +29,32 @@
 #ifndef HENS_T2_PREC
 #define HENS_T2_PREC 1
 #endif
+// a pipeline rank's lead workgroup: its adaptation chain behind the first barrier, in the shadow of tile 0's gathers (1), or in front
+// of it as in k_stretch_fast<64> (0)
+#ifndef HENS_T2_PIPE_SHADOW
+#define HENS_T2_PIPE_SHADOW 0
+#endif
 namespace hens {
 
 __host__ __device__ constexpr size_t tile2_lds_bytes(int D, int like) {
     return ((size_t)2 * TILE * (D + 2) + 8 * TILE + 128 + 2 * TILE) * 8 + (size_t)2 * 4 * TILE * 4 + mf_lds_extra(D, like);
 }
 
-template <int DT, int LIKE>
+// PIPE: the context is a rank of the ladder pipeline stepping with the two in-place launches (pipe_fused_iteration) - k_stretch_fast's
+// hooks for it, ported: the head of the launch (rows-complete flag to the cold neighbour, the last sweep's swap counts to every rank's
+// mailbox, the wait for the hot neighbour's rows), the lead workgroup's adaptation chain and the ring the others read their rung's
+// beta from, guest rows (a walker that arrived through the pipeline sits in the mailbox and goes home here, accepted or not),
+// system-scope stores of rows a peer may pull.  The host keeps k_stretch_fast<PIPE> for what is not ported: the separate-launch
+// pipeline's publishing of (L, P) (pub_lp), counts pushed through the reduction machinery (cnt_push == 1: adaptation_delay > 0),
+// every-workgroup adaptation (ad_on == 1), the latency-injection hook.  cnt_push == 3 (this kernel only; the host's translation of
+// cnt_push == 1 on the delayed schedule): the publishing wave pushes the last sweep's counts as with 2, but the adapting wave takes
+// every pair - its own rank's too - from the mailbox (the ladder lags a sweep: adaptation_delay = 1).
+template <int DT, int LIKE, bool PIPE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_stretch2(const StretchArgs A) {
     static_assert(DT == 64 || DT == 128, "row widths whose tile does not stay centred (phase E reads the proposal from the tile)");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = 8, D = DT, RS = DT + 2, NT = NW * 64, LPR = DT / 2, RPP = NT / LPR, NPASS = (TILE + RPP - 1) / RPP, HP = NPASS / 2;
-    constexpr bool PIPE = false, CEN = false;
+    constexpr bool CEN = false;
     static_assert(!like_centred(LIKE, DT) && HP >= 1, "");
     double* const qt = reinterpret_cast<double*>(smem_raw);              // [2][TILE][RS]
     double* const s_part = qt + 2 * TILE * RS;                           // [NW][TILE]
@@ -77,10 +91,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int Ns = A.split == 0 ? A.N0 : W - A.N0;
     const int s_off = A.split == 0 ? 0 : A.N0;
     const bool ad_on = A.ad_on != 0;
-    const bool ad_lead = false;
-    const bool ad_here = ad_on;
+    // (one GPU: every workgroup adapts for itself, ad_on == 1; a pipeline rank: workgroup (0,0) adapts and publishes the ring,
+    //  ad_on == 2 - the host launches this kernel with nothing else)
+    const bool ad_lead = PIPE && ad_on;
+    const bool ad_here = ad_on && (!ad_lead || (blockIdx.x == 0 && blockIdx.y == 0));
     const bool ad_early = ad_here && A.ad.nblocks <= 8 * A.ad.row_groups;      // (the host launches this kernel only then)
-    const bool ad_defer = ad_early;
+    const bool ad_defer = ad_early && !PIPE;
+    constexpr int PUSHW = 3;                    // pipeline rank, workgroup (0,0): the wave that publishes the last sweep's swap counts
+    if (PIPE && blockIdx.x == 0 && blockIdx.y == 0) {          // (k_stretch_fast's head of a rank's launch)
+        if (A.rt_flag && tid == 0) pipe_raise(A.rt_flag, A.rt_value);
+        if (A.cnt_push >= 2 && wv == PUSHW) pipe_push_counts(A.cp_rows, A.cp_nblocks, A.cp_np, A.cp_boxes, A.cp_nranks, A.cp_rank, A.cp_T,
+                                                             A.rung_begin, W, DT, A.cp_sweep, lane, false);
+    }
+    const bool cnt_wait = PIPE && ad_here && ad_lead && (A.wmask >> PF_CNT0) != 0ull;
+    // the hot neighbour's rows of the previous sweep: wave 0 (tile 0's accept wave) waits, the others meet it at the first barrier -
+    // nothing in front of that barrier touches a row
+    if (PIPE && A.wmask) {
+        if (wv == 0 && ((A.wmask >> lane) & 1ull) && lane < PF_CNT0)
+            pipe_spin(A.wflags + lane, A.wtarget, A.wbudget, A.flags, A.wstats ? A.wstats : nullptr);
+    }
     const bool ad_x = ad_defer && NW >= 4 && A.ad.T <= 64 && A.ad.moving;
     double ad_c0 = 0.0, ad_c1 = 0.0, ad_dT0 = 0.0, ad_dT1 = 0.0, ad_b0n = 1.0, ad_b1n = 1.0, ad_bb0 = 1.0, ad_bb1 = 1.0, ad_inv0 = 1.0;
     auto adapt_part1 = [&](const double cnt0, const double cnt1, const double ad_b, const double ad_b1, const bool exp_elsewhere = false) {
@@ -256,6 +285,69 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         }
         adapt_part1((double)s0, (double)s1, ad_bi0, ad_bi1, ad_x);
     };
+    // A pipeline rank's adapting wave (workgroup (0,0)), k_stretch_fast's in two pieces: in front of the first barrier only the LOADS
+    // (ladder, one look at the other ranks' count flags, its own rank's counts summed out of the accumulation rows, the mailbox's
+    // row) - one round trip in the shadow of phase A; the ~4 000-cycle chain behind the barrier, in the shadow of tile 0's first
+    // gathers (pipe_chain below).  A persistent workgroup that starts its first tile 2 us late ends 2 us late, and the launch with
+    // it: measured with the whole chain in front of the barrier (k_stretch_fast's D = 64 place), a lone rank's first launch at
+    // 8 x 16384 x 64 22.8 us against 19.9 for the same shape as a ladder of its own.  What crosses the barrier waits in LDS
+    // (s_part: nobody touches it before tile 0's likelihood phase).
+    unsigned* const s_late = reinterpret_cast<unsigned*>(s_part);      // [l] late, [64 + l] own sums, [128 + l] / [192 + l] counts of rungs l / l + 64
+    double* const s_lateb = s_part + 128;                              // [l] / [64 + l] the ladder
+    auto pipe_chain = [&]() {
+        const int T = A.ad.T, rb = A.rung_begin, np = A.cp_np;
+        const bool own_acc = A.cnt_push == 2;
+        unsigned m0 = s_late[128 + lane], m1 = s_late[192 + lane];
+        const unsigned own_sum = s_late[64 + lane];
+        const double b0 = s_lateb[lane], b1 = s_lateb[64 + lane];
+        if (s_late[lane] != 0u) {
+            // a rank's counts were not there at the first look: wait for them now
+            if (lane >= PF_CNT0 && lane != PF_CNT0 + A.cp_rank && ((A.wmask >> lane) & 1ull))
+                pipe_spin(A.wflags + lane, A.wtarget_cnt, A.wbudget, A.flags, A.wstats ? A.wstats + 2 : nullptr);
+            if (!(own_acc && A.cp_nranks == 1)) {
+                if (lane < T - 1) m0 = A.ad.swap_part[lane];
+                if (lane + 64 < T - 1) m1 = A.ad.swap_part[lane + 64];
+            }
+        }
+        if (own_acc) {                           // my pairs out of my own sums: global pair e = rung_begin + local pair
+            const int j0 = lane - rb, j1 = lane + 64 - rb;
+            const unsigned o0 = (unsigned)__shfl((int)own_sum, (j0 >= 0 && j0 < np) ? j0 : 0);
+            const unsigned o1 = (unsigned)__shfl((int)own_sum, (j1 >= 0 && j1 < np) ? j1 : 0);
+            if (j0 >= 0 && j0 < np) m0 = o0;
+            if (j1 >= 0 && j1 < np) m1 = o1;
+        }
+        adapt_part1((double)m0, (double)m1, b0, b1);
+        adapt_part2();
+    };
+    if constexpr (PIPE) {
+        if (ad_early && ad_lead && wv == ADW) {
+            const int T = A.ad.T;
+            const double b0 = (lane < T) ? A.ad.betas_in[lane] : 1.0, b1 = (lane + 64 < T) ? A.ad.betas_in[lane + 64] : 1.0;
+            uint32_t fl = 0xFFFFFFFFu;
+            if (cnt_wait && lane >= PF_CNT0 && lane != PF_CNT0 + A.cp_rank && ((A.wmask >> lane) & 1ull))
+                fl = __hip_atomic_load(A.wflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unsigned own_sum = 0;                    // lane p: this rank's count of local pair p (cnt_push == 2)
+            if (A.cnt_push == 2) own_sum = acc_rows_sum(A.cp_rows, A.cp_nblocks, A.cp_np, lane);
+            bool late = false;
+            if (cnt_wait) {
+                const bool here = fl >= A.wtarget_cnt;
+                late = __ballot(!here) != 0ull;
+                if (A.inject_c64 < 0) late = true;       // (HENS_PIPE_FORCE_LATE=1, tests: every adaptation takes the late path)
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);          // (acquire side: see pipe_spin)
+            }
+            unsigned m0 = 0, m1 = 0;                 // (row_groups = 1: the mailbox's reduced counts, one row)
+            if (!late && !(A.cnt_push == 2 && A.cp_nranks == 1)) {
+                if (lane < T - 1) m0 = A.ad.swap_part[lane];
+                if (lane + 64 < T - 1) m1 = A.ad.swap_part[lane + 64];
+            }
+            s_late[lane] = late ? 1u : 0u;           // (every lane its own word: see k_stretch_fast)
+            s_late[64 + lane] = own_sum; s_late[128 + lane] = m0; s_late[192 + lane] = m1;
+            s_lateb[lane] = b0; s_lateb[64 + lane] = b1;
+#if !HENS_T2_PIPE_SHADOW
+            pipe_chain();
+#endif
+        }
+    }
     if (ad_early && wv == ADW && !(PIPE && ad_lead)) {
         const int T = A.ad.T, NR = A.ad.nblocks;
         // (row_groups G > 1 - ladders of at most 64 / G pairs: lane = (group g, pair p), group g sums rows g, g + G, ...)
@@ -283,6 +375,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     uint32_t acc_old = 0;
     bool valid = false;
     int32_t rs_mine = 0, rc_mine = 0;
+    int32_t ghome_row = 0;                   // pipeline rank: the home row of a walker that sits in a guest row (rs_mine < 0)
     if (A.tempered && !ad_on) beta_pre = A.betas[A.rung_begin + tl];
 
     // phase A of tile j, first part: requests and draws (accept wave: the walker's record, one Philox call -> zz, log u, the Hastings
@@ -305,6 +398,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                 factors = ((double)A.ndim_active - 1.0) * log(zz_mine);           // stretch.py:223
                 rs_mine = la.x;
                 acc_old = (uint32_t)la.y;
+                if (PIPE && A.ghome) ghome_row = A.ghome[la.x < 0 ? ~la.x : 0];   // (tile 0: consumed in phase D - no wait in front of the barrier)
                 Lold = lp.x; Pold = lp.y;
             }
         } else if (wv == cw) {
@@ -323,8 +417,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         if (wv == aw) {
             s_zz2[b * TILE + lane] = zz_mine;
             S_RS(b)[lane] = rs_mine;
-            S_DST(b)[lane] = rs_mine;                            // (in place: an accepted proposal overwrites the walker's row)
-            S_FLAG(b)[lane] = valid ? 4 : 0;
+            // (in place: an accepted proposal overwrites the walker's row.  A guest of a pipeline rank goes home, accepted or not:
+            //  tiles behind the first have had its home row for a whole tile - flag 16, the proposal phase stores the old row there
+            //  and phase E only accepted rows as everywhere; tile 0 learns it in phase D as in k_stretch_fast - flag 8, phase E)
+            const bool guest_known = PIPE && j > 0 && A.ghome && rs_mine < 0 && valid;
+            S_DST(b)[lane] = guest_known ? ghome_row : rs_mine;
+            S_FLAG(b)[lane] = (valid ? 4 : 0) | (guest_known ? 16 : 0);
         } else if (wv == cw) {
             S_RC(b)[lane] = rc_mine;
         }
@@ -333,12 +431,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     phaseA_request(0);
     phaseA_publish(0);
     lds_barrier();
+    // (the accumulation rows the publishing and the adapting wave have read: cleared behind the first barrier)
+    if (PIPE && A.cnt_push >= 2 && A.cp_zero && wv == PUSHW && blockIdx.x == 0 && blockIdx.y == 0)
+        acc_rows_clear(const_cast<uint32_t*>(A.cp_rows), A.cp_nblocks, A.cp_np, lane);
 
     // ---- the tile loop -------------------------------------------------------------------------------------------------------------
     const int jl = tid & (LPR - 1);
     const int rsub = tid / LPR;
     const double* __restrict__ pool_r = A.pool;
     double* __restrict__ pool_w = A.pool;
+    const bool sysw = PIPE && (tl == A.sys_rung || A.sys_all);           // (rows a peer may pull: a property of the launch / the rung)
     double2 sreg[NPASS], creg[NPASS];
     bool rv[NPASS];
 #define T2_GATHER(p, b, k0)                                                                                                     \
@@ -348,14 +450,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         sreg[p] = double2{0.0, 0.0};                                                                                            \
         creg[p] = double2{0.0, 0.0};                                                                                            \
         if (rv[p]) {                                                                                                            \
-            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)rs_i[p] * D + jl * 2);                                \
-            creg[p] = *reinterpret_cast<const double2*>(pool_r + (int64_t)rc_i[p] * D + jl * 2);                                \
+            sreg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(rs_i[p], D, A.guest_delta) : (int64_t)rs_i[p] * D) + jl * 2); \
+            creg[p] = *reinterpret_cast<const double2*>(pool_r + (PIPE ? row_off(rc_i[p], D, A.guest_delta) : (int64_t)rc_i[p] * D) + jl * 2); \
         }                                                                                                                       \
     }
 #define T2_PROPOSE(p, b)                                                                                                        \
     {                                                                                                                           \
         const int r = p * RPP + rsub;                                                                                           \
         bool ok = true, finite = true;                                                                                          \
+        if (PIPE && b > 0 && rv[p] && rs_i[p] < 0 && A.ghome) { /* a guest whose home row is known (flag 16): the old row goes home now */ \
+            double* const hd = pool_w + (size_t)S_DST(b)[r] * D + jl * 2;                                                       \
+            if (sysw) { sys_store(hd, sreg[p].x); sys_store(hd + 1, sreg[p].y); }                                               \
+            else { wt_store(hd, sreg[p].x); wt_store(hd + 1, sreg[p].y); }                                                      \
+        }                                                                                                                       \
         if (rv[p]) {                                                                                                            \
             const double zz = s_zz2[b * TILE + r];                                                                              \
             double2 qv;                                                                                                         \
@@ -377,13 +484,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     // phase E of tile j: accepted rows only, in place, out of the tile (k_stretch_fast's phase E)
     auto phaseE = [&](const int j) {
         const int b = j & 1, k0 = (bx + j * GX) * TILE;
+        if constexpr (PIPE) {
+            // A pipeline rank: rows a peer may pull are written at system scope; a guest of tile 0 (flag 8, set in phase D) goes home
+            // accepted or not - its old row is read again (the registers it was gathered into carry the next tile's rows by now;
+            // this phase runs in the shadow of that tile's gathers).  Values and addresses of all passes first, then the stores back
+            // to back (see k_stretch_fast's phase E).
+            double2 val[NPASS];
+            double* dstp[NPASS];
+            bool on[NPASS];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
-            const int r = p * RPP + rsub;
-            if (!((r < TILE) && (k0 + r < Ns))) continue;
-            if ((S_FLAG(b)[r] & 2) == 0) continue;
-            const double2 qv = *reinterpret_cast<const double2*>(qt + (size_t)b * TILE * RS + r * RS + jl * 2);
-            store_row16(pool_w + (size_t)S_DST(b)[r] * D + jl * 2, qv);
+            for (int p = 0; p < NPASS; ++p) {
+                const int r = p * RPP + rsub;
+                on[p] = false;
+                val[p] = double2{0.0, 0.0};
+                dstp[p] = pool_w;
+                if (!((r < TILE) && (k0 + r < Ns))) continue;
+                const int fl = S_FLAG(b)[r];
+                val[p] = *reinterpret_cast<const double2*>(qt + (size_t)b * TILE * RS + r * RS + jl * 2);
+                if ((fl & (2 | 8)) == 8) val[p] = *reinterpret_cast<const double2*>(pool_r + row_off(S_RS(b)[r], D, A.guest_delta) + jl * 2);
+                on[p] = (fl & (2 | 8)) != 0;
+                dstp[p] = pool_w + (size_t)S_DST(b)[r] * D + jl * 2;
+            }
+            if (sysw) {
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) if (on[p]) store_row16_sys(dstp[p], val[p]);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NPASS; ++p) if (on[p]) store_row16(dstp[p], val[p]);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const int r = p * RPP + rsub;
+                if (!((r < TILE) && (k0 + r < Ns))) continue;
+                if ((S_FLAG(b)[r] & 2) == 0) continue;
+                const double2 qv = *reinterpret_cast<const double2*>(qt + (size_t)b * TILE * RS + r * RS + jl * 2);
+                store_row16(pool_w + (size_t)S_DST(b)[r] * D + jl * 2, qv);
+            }
         }
     };
 
@@ -402,6 +539,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
             if (ad_x && lane + 2 < A.ad.T) ad_dT0 *= s_exp[lane];
             adapt_part2();
         }
+#if HENS_T2_PIPE_SHADOW
+        if constexpr (PIPE) {
+            if (ad_early && ad_lead && wv == ADW) pipe_chain();
+        }
+#endif
     }
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -431,6 +573,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         lds_barrier();
         // (tile j - 1's phase E has read the other buffer's flags / destinations in front of this barrier: they are free now)
         if (more) phaseA_publish(j + 1);
+        // a pipeline rank: the rung's new beta out of the lead workgroup's ring, requested now and consumed behind the likelihood
+        double beta_ring = -1.0;
+        const double* ring_slot = nullptr;
+        const bool ring_me = PIPE && ad_lead && !ad_here;
+        if (ring_me && wv == b * 4) {
+            ring_slot = A.ad_ring + (size_t)(A.ad_serial & 3u) * A.ad.T + (A.rung_begin + tl);
+            beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #if HENS_T2_PREC > 0
         if (more) {
             lds_barrier();
@@ -483,7 +633,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
             const size_t gi = (size_t)tl * W + own;
             double logP, prevP;
             if (A.tempered) {                                      // tempering.py:304-306,343-349
-                const double beta = ad_on ? s_beta[A.rung_begin + tl] : beta_pre;
+                double beta = beta_pre;
+                if (ring_me) {                                 // workgroup (0,0) may still be adapting: wait for the value
+                    if (beta_ring < 0.0) {                     // (the budget runs on the shader clock: see spin_expired)
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        while (beta_ring < 0.0) {
+                            __builtin_amdgcn_s_sleep(1);
+                            beta_ring = __hip_atomic_load(ring_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (spin_expired(t0, 200000000LL)) { atomicOr(A.flags, FLAG_PIPE_TIMEOUT); break; }
+                        }
+                    }
+                    beta = beta_ring;
+                } else if (ad_on) {
+                    beta = s_beta[A.rung_begin + tl];
+                }
                 double lt = logl * beta;
                 if (lt != lt) lt = -INFINITY;
                 logP = lt + logp;
@@ -498,7 +661,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
             const bool keep = lnpdiff > lu;                        // red_blue.py:294
             const double newP = (fabs(logp) == INFINITY) ? 0.0 : logp;
             if (keep) {                                            // move.py:513-532
-                if (late_kernarg<int32_t>(offsetof(StretchArgs, norel))) {
+                if (PIPE || late_kernarg<int32_t>(offsetof(StretchArgs, norel))) {
                     store_row16(&A.wrec[gi].L, double2{logl, newP});
                     wt_store(&A.wrec[gi].acc, acc_old + 1u);
                 } else {
@@ -507,12 +670,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
                 }
                 atomicOr(&S_FLAG(b)[lane], 2);
             }
+            if (PIPE && A.ghome && rs_mine < 0) {              // a guest: its row - new or old - goes to its home row
+                A.wrec[gi].loc = ghome_row;
+                A.loc[gi] = ghome_row;
+                if (j == 0) {                                  // (tile 0: phase E moves the row; later tiles' old rows are home already)
+                    S_DST(b)[lane] = ghome_row;
+                    atomicOr(&S_FLAG(b)[lane], 8);
+                }
+            }
             if (A.keep_out) A.keep_out[(size_t)tl * Ns + k0 + lane] = keep ? 1 : 0;
         }
         lds_barrier();
     }
     phaseE(TP - 1);
-    if (late_kernarg<int32_t>(offsetof(StretchArgs, norel))) launch_end_wait();
+    if constexpr (!PIPE) if (late_kernarg<int32_t>(offsetof(StretchArgs, norel))) launch_end_wait();
 #undef T2_GATHER
 #undef T2_PROPOSE
 }

@@ -82,6 +82,100 @@ def test_pipeline_counts_that_arrive_late(tmp_path, nranks, T, W, D, iters, mode
         _compare(ref, np.load(out))
 
 
+def _tile2_env(model="gauss", late=False, delay=0):
+    env = _env(model=model, delay=delay)
+    env["HENS_TILE2_FORCE"] = "1"
+    env["HENS_TILE2_LOG"] = "1"
+    env.pop("HENS_NO_TILE2", None)
+    env.pop("HENS_NO_TILE2_PIPE", None)
+    if late:
+        env["HENS_PIPE_FORCE_LATE"] = "1"
+    return env
+
+
+@pytest.mark.parametrize("nranks,T,W,D,iters,model,late", [(2, 8, 512, 64, 12, "gauss", False), (4, 8, 1024, 64, 10, "gauss", True),
+                                                            (2, 16, 1168, 64, 10, "gauss", False), (1, 4, 512, 64, 8, "gauss", False),
+                                                            (2, 8, 2048, 64, 12, "gauss", True), (4, 16, 512, 64, 10, "gauss", False),
+                                                            (8, 16, 512, 64, 10, "gauss", True)])
+def test_pipeline_ranks_with_the_persistent_pipelined_first_launch(tmp_path, nranks, T, W, D, iters, model, late):
+    """Round 6: k_stretch2<PIPE> (hens_tile2.h) - a rank's first launch in persistent workgroups of two tiles: the head of the
+    launch, the lead workgroup's adaptation chain + ring, guests going home (tile 0: in phase E, read again; tile 1: the old row
+    in the proposal phase), system-scope rows.  Forced onto small grids (HENS_TILE2_FORCE=1), the sharded run must be the unsharded
+    chain of k_stretch_fast (HENS_NO_TILE2=1) bit for bit: 1, 2, 4 and 8 ranks, two rungs per rank, a ragged last tile, counts that
+    arrive late.  (A context with the MH mix keeps its records by slot - pipe_col_ok - and with them k_stretch_fast.)"""
+    env0 = _env(model=model)
+    env0["HENS_NO_TILE2"] = "1"
+    ref_out = tmp_path / "single.npz"
+    r = subprocess.run([sys.executable, WORKER, "single", str(T), str(W), str(D), str(iters), str(ref_out)], env=env0, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "k_stretch2" not in r.stderr
+    ref = dict(np.load(ref_out))
+    for rep in range(2):
+        out = tmp_path / f"local{rep}.npz"
+        r = subprocess.run([sys.executable, WORKER, "local", str(nranks), str(T), str(W), str(D), str(iters), str(out)],
+                           env=_tile2_env(model, late), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "k_stretch2<pipe=1>" in r.stderr, "the ranks' first launches did not go to k_stretch2<PIPE>:\n" + r.stderr[-2000:]
+        _compare(ref, np.load(out))
+    assert ref["swaps_total"].sum() > 0 and ref["accepted"].sum() > 0
+
+
+@pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 8, 512, 64, 12), (4, 8, 1024, 64, 10)])
+def test_pipeline_ranks_with_the_persistent_pipelined_first_launch_delayed_schedule(tmp_path, nranks, T, W, D, iters):
+    """... and on the delayed schedule (adaptation_delay = 1): the last sweep's counts go out on the publishing wave (cnt_push = 3 in
+    place of k_stretch_fast's count-reduction machinery), the adapting wave takes every pair from the mailbox.  N ranks == one rank
+    of the same pipeline stepping with k_stretch_fast, bit for bit."""
+    env0 = _env(delay=1)
+    env0["HENS_NO_TILE2"] = "1"
+    ref_out = tmp_path / "single.npz"
+    r = subprocess.run([sys.executable, WORKER, "single", str(T), str(W), str(D), str(iters), str(ref_out)], env=env0, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = dict(np.load(ref_out))
+    out = tmp_path / "local.npz"
+    r = subprocess.run([sys.executable, WORKER, "local", str(nranks), str(T), str(W), str(D), str(iters), str(out)],
+                       env=_tile2_env(delay=1), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "k_stretch2<pipe=1>" in r.stderr and "cnt_push 3" in r.stderr, r.stderr[-2000:]
+    _compare(ref, np.load(out))
+    assert ref["swaps_total"].sum() > 0 and ref["accepted"].sum() > 0
+
+
+def test_pipeline_ipc_processes_with_the_persistent_pipelined_first_launch(tmp_path):
+    """... and one rank per PROCESS (mailboxes through HIP IPC, as on a multi-GPU node), k_stretch2<PIPE> forced."""
+    world, T, W, D, iters = 2, 4, 512, 64, 8
+    env0 = _env()
+    env0["HENS_NO_TILE2"] = "1"
+    ref_out = tmp_path / "single.npz"
+    r = subprocess.run([sys.executable, WORKER, "single", str(T), str(W), str(D), str(iters), str(ref_out)], env=env0, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = dict(np.load(ref_out))
+    env = _tile2_env()
+    env["MASTER_PORT"] = str(29500 + (os.getpid() % 2000))
+    procs = [subprocess.Popen([sys.executable, WORKER, "ipc", str(rk), str(world), str(T), str(W), str(D), str(iters), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for rk in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert all("k_stretch2<pipe=1>" in o for o in outs), "\n".join(outs)
+    snaps = [np.load(tmp_path / f"rank{rk}.npz") for rk in range(world)]
+    got = {k: np.concatenate([s_[k] for s_ in snaps], axis=0) for k in ("x", "L", "P", "accepted")}
+    for k in ("betas", "swaps_total", "swaps_last"):
+        for s_ in snaps[1:]:
+            assert np.array_equal(s_[k], snaps[0][k])
+        got[k] = snaps[0][k]
+    _compare(ref, got)
+
+
 @pytest.mark.parametrize("nranks,T,W,D,iters", [(2, 4, 128, 8, 7), (4, 8, 256, 32, 8)])
 def test_pipeline_delayed_adaptation_is_rank_count_invariant(tmp_path, nranks, T, W, D, iters):
     """adaptation_delay = 1 (the swap ratios of sweep s move the ladder before iteration s+2, so the ranks need
