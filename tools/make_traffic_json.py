@@ -41,7 +41,7 @@ for name, pat in (("k_stretch_fast", rf"k_stretch_fast<{D}, {like}, 0,"), ("k_st
                   ("k_split1_pt", rf"k_split1_pt<{D}, {like},"), ("k_iter", rf"k_iter<{D}, {like},"), ("PT", r"k_pt_cascade<true>")):
     f, w = mean_of(F, pat), mean_of(Wf, pat)
     if (f is None or w is None) and name == "k_stretch_fast":          # launches of more than one round: the persistent kernel (hens_tile2.h)
-        f, w = mean_of(F, rf"k_stretch2<{D}, {like}>"), mean_of(Wf, rf"k_stretch2<{D}, {like}>")
+        f, w = mean_of(F, rf"k_stretch2<{D}, {like}[,>]"), mean_of(Wf, rf"k_stretch2<{D}, {like}[,>]")
     if f is None or w is None:
         continue
     entry[name] = (2.0 * f + w) * 1024

@@ -3,7 +3,7 @@
 # config 2, one config-3 shard, ALL of config 5 on one GPU and one config-5 shard, the SQ pass, the RJ profile with the instruction
 # classes, config 4 / 5 lines, the pipeline rank (lead workgroup without a tile / beside its tile), the 2-rank dry run.
 #     bash tools/r6_final_profiles.sh <tag>
-tag=${1:-r06m}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out
+tag=${1:-r06z}; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out
 export PYTHONPATH=$R
 cd $R
 python bench.py --steps 20 --warmup 5 > $out/bench_steps20.json 2> $out/bench.err
