@@ -26,6 +26,27 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.hens_version()
 
 
+def test_fence_free_kernels_store_census_is_the_reviewed_one():
+    """The stepping launches of one GPU carry no release fence on their AQL packet (hens_kernels.h: wt_store, launch_end_wait): every
+    store a later launch reads must be write-through, and one plain store added to k_stretch_fast / k_stretch2 / k_split1_pt / k_iter
+    would be a silent stale read on another XCD.  The ISA cannot say which stores a later launch reads, but it can say that their
+    number has not changed since somebody looked: per fence-free kernel, the counts of global stores, of plain ones (no sc0 / sc1 / nt)
+    and of atomics in the built library against the reviewed census (tools/store_census.py --write after the review)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import store_census
+    _build.build()
+    got = store_census.census()
+    want = json.load(open(store_census.GOLDEN))["kernels"]
+    assert sorted(got) == sorted(want), ("fence-free instantiations changed: " +
+                                         ", ".join(sorted(set(got) ^ set(want))[:6]) + " - review and run tools/store_census.py --write")
+    moved = {k: (want[k], got[k]) for k in got if got[k] != want[k]}
+    assert not moved, (f"{len(moved)} fence-free kernels changed their store counts, e.g. {list(moved.items())[:3]}: is every store a later "
+                       f"launch reads still write-through?  Then python tools/store_census.py --write")
+    assert len(got) >= 100 and all(v["stores"] > v["plain"] for v in got.values())
+
+
 def test_struct_layout_matches_header():
     import ctypes as C
     # hens_config: 12 x i32, i64, 4 x f64, u64
