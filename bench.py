@@ -71,6 +71,80 @@ def static_json(name):
         return None
 
 
+def live_traffic(T, W, D, steps=100, warmup=20, timeout=180):
+    """HBM bytes per launch from the PMC counters, collected by THIS run: two rocprofv3 passes (`--kernel-trace --pmc FETCH_SIZE`,
+    then `WRITE_SIZE`: separate passes, MI355X_MICROARCH.md's recipe) over a child process that steps the same shape on the same
+    path (`bench.py --traffic-child`), bytes = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 reports KB; the factor 2 is the guide's gfx950
+    correction for wide coalesced reads, calibrated in the same pass on the child's evaluation launch, which streams every row of
+    the state exactly once).  Returns ({kernel key: bytes per launch}, source string) or (None, why not): the static figures of
+    profiles/traffic.json (tools/profile_bench.sh, the same recipe on the builder's box) stand in then."""
+    import glob
+    import re
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH", "ROCPROF_OUTPUT_PATH")):
+        return None, "this run is itself under a profiler"
+    means = {}
+    try:
+        for C in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                cmd = [prof, "--kernel-trace", "--pmc", C, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                       os.path.abspath(__file__), "--traffic-child", "--ntemps", str(T), "--nwalkers", str(W), "--ndim", str(D),
+                       "--steps", str(steps), "--warmup", str(warmup)]
+                r = subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+                files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+                if r.returncode != 0 or not files:
+                    return None, f"rocprofv3 --pmc {C} pass failed (rc {r.returncode})"
+                import csv
+                agg = {}
+                for row in csv.DictReader(open(files[0])):
+                    if row["Counter_Name"] == C:
+                        agg.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+                means[C] = {k: sum(v) / len(v) for k, v in agg.items()}
+    except Exception as exc:                              # noqa: BLE001  (a secondary figure: the static file stands in)
+        return None, f"{type(exc).__name__}: {exc}"
+
+    def mean_of(C, pat):
+        for k, v in means[C].items():
+            if re.search(pat, k):
+                return v
+        return None
+    out = {}
+    for name, pats in (("k_stretch_fast", (rf"k_stretch_fast<{D}, 0, 0,", rf"k_stretch2<{D}, 0[,>]")), ("k_split1_pt", (rf"k_split1_pt<{D}, 0,",)),
+                       ("k_iter", (rf"k_iter<{D}, 0,",)), ("PT", (r"k_pt_cascade<true>",))):
+        for pat in pats:
+            f, w = mean_of("FETCH_SIZE", pat), mean_of("WRITE_SIZE", pat)
+            if f is not None and w is not None:
+                out[name] = (2.0 * f + w) * 1024
+                break
+    cal = mean_of("FETCH_SIZE", rf"k_stretch_fast<{D}, 0, 1,")
+    ratio = None if cal is None else cal * 1024 / (T * W * D * 8)
+    if not out:
+        return None, "no stepping kernel in the counter output"
+    return out, (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two passes run by this bench.py over a child process stepping the same "
+                 f"shape on the same path ({steps} iterations); bytes = 2 x FETCH + WRITE, the evaluation launch of the same pass reports "
+                 f"{'n/a' if ratio is None else f'{ratio:.3f}'} of the bytes it is known to read (the guide's gfx950 correction: 0.5)")
+
+
+def traffic_child(args):
+    """The process live_traffic profiles: the timed path of run_single, nothing else."""
+    from eryn_amd.engine import HipEnsemble
+    from eryn_amd.likelihood import GaussianLikelihood
+    from eryn_amd.moves.tempering import make_ladder
+    T, W, D = args.ntemps, args.nwalkers, args.ndim
+    mu, invcov = gaussian_problem(D)
+    eng = HipEnsemble(T, W, D, GaussianLikelihood(mu, invcov), -50.0, 50.0, seed=2024, device_id=0)
+    eng.upload(np.random.RandomState(1).randn(T, W, D), betas=make_ladder(D, ntemps=T) if T > 1 else None)
+    eng.eval_state()
+    eng.step(args.warmup)
+    eng.step(args.steps)
+    eng.synchronize()
+    eng.close()
+
+
 def cpu_baseline(T, W, D, seconds=12.0, max_iters=200):
     """Eryn-faithful NumPy restatement (oracle/, pinned bit-exact to the reference) timed on the host cores on a
     bounded sample of the same workload."""
@@ -127,7 +201,7 @@ def moved_bytes(kind, tw, D, acc):
     return tw * (32 + 36)        # cascade-only launch
 
 
-def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25):
+def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25, traffic_live=None, traffic_live_source=None):
     """Per-kernel durations (profiled_pass: the launches' own dispatch timestamps, or HIP event pairs where the workload steps on
     the HIP stream) -> fractions of the HBM peak.
 
@@ -158,7 +232,7 @@ def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25):
         us = tm["pt_ms"] / tm["n_pt"] * 1e3
         ks.append({"kernel": "PT cascade launch(es)", "launches_per_iteration": tm["n_pt"] / tm["n_iters"],
                    "avg_launch_us": us, "bytes_8d": b_pt(T, D, f_sw) * tw, "bytes_moved": moved_bytes("pt", tw, D, acc)})
-    traffic = (static_json("traffic.json") or {}).get("shapes", {}).get(f"{T_local}x{W}x{D}", {})
+    traffic = traffic_live if traffic_live else (static_json("traffic.json") or {}).get("shapes", {}).get(f"{T_local}x{W}x{D}", {})
     warn = []
     for k in ks:
         sec = k["avg_launch_us"] * 1e-6
@@ -179,8 +253,9 @@ def kernel_roofline(tm, T_local, T, W, D, f_sw, acc=0.25):
     return {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["frac"], "achieved_moved": dom["achieved_moved_GBps"], "frac_moved": dom["frac_moved"],
             "frac_traffic": dom["frac_traffic"], "traffic": dom["traffic"],
-            "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this shape, tools/profile_bench.sh; "
-                              "not measured in this run)" if dom["traffic"] is not None else None,
+            "traffic_source": (traffic_live_source if traffic_live else
+                               "profiles/traffic.json (static: rocprofv3 --pmc passes of this shape, tools/profile_bench.sh; "
+                               "not measured in this run)") if dom["traffic"] is not None else None,
             "bytes": "achieved / frac: SURVEY 8d's algorithmic bytes per launch (B_stretch per proposal with the written row counted "
                      "unconditionally, B_pt per walker-step with moved rows per swap) over the launch duration measured live "
                      "(launch_clock); achieved_moved / frac_moved: the bytes this design moves (accepted rows only; a swap permutes a "
@@ -456,7 +531,10 @@ def run_single(args):
     tm = profiled_pass(eng, args.steps, expect_us=dt / args.steps * 1e6)
     eng.close()
     value = T * W * args.steps / dt
-    roof = kernel_roofline(tm, T, T, W, D, f_sw, acc)
+    live, live_src = (None, "skipped (--no-cpu: the bare line)") if (args.no_cpu or args.no_live_traffic) else live_traffic(T, W, D)
+    roof = kernel_roofline(tm, T, T, W, D, f_sw, acc, traffic_live=live, traffic_live_source=live_src)
+    if live is None and not args.no_cpu:
+        roof["traffic_live_unavailable"] = live_src
     whole_path(roof, T, W, D, f_sw, acc, value)
     consistency(roof, dt / args.steps * 1e3)
     flag_accounting(roof)
@@ -938,7 +1016,12 @@ def main():
     ap.add_argument("--no-staged", action="store_true", help="N > 1: skip the RCCL neighbour-exchange pass")
     ap.add_argument("--no-waits", action="store_true", help="N > 1: skip the per-rank wait breakdown pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc passes of this run")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.traffic_child:
+        traffic_child(args)
+        return
     global BLOCKS
     world = int(os.environ.get("WORLD_SIZE", "0"))
     n = max(args.gpus, world, 1)

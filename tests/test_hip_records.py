@@ -248,7 +248,8 @@ np.savez(sys.argv[8], **_snapshot(eng, bool(use_mh)))
 # D = 128 dense; Rosenbrock 4 x 8192 x 128 (one GPU's share of config 5); a short-tile ladder (10 rungs: slot order); a shape that
 # steps in ONE launch per iteration (k_iter); calls with and without a Gaussian move in the mix in turn (AQL queue <-> HIP stream)
 _LONG_SHAPES = [(8, 1024, 128, 0, "dense"), (4, 8192, 128, 0, "rosen"), (10, 2048, 32, 0, "dense"), (8, 4096, 32, 0, "dense"),
-                (16, 1024, 32, 1, "dense"), (4, 2048, 128, 1, "rosen")]
+                (16, 1024, 32, 1, "dense"), (4, 2048, 128, 1, "rosen"),
+                (8, 16384, 64, 0, "dense")]          # (the config-3 shard: k_stretch2, the persistent first launch, is fence-free too)
 _LONG_ITERS = 2000
 _long_default = {}
 
@@ -270,8 +271,8 @@ def _long_run(shape, env, tmp_path, tag):
 @pytest.mark.parametrize("shape", _LONG_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_fence_free_launches_reach_the_fenced_paths_state_over_2000_iterations(knob, shape, tmp_path):
     """The stepping launches of one GPU carry no release fence (hens_aql.h: norel_next): every store a later launch reads is
-    written through and every wave ends behind its stores' acknowledgements - an invariant of the kernels' code that nothing
-    enforces statically.  This is its guard: 2 000 iterations on each shape class the default path serves, against the same
+    written through and every wave ends behind its stores' acknowledgements - an invariant of the kernels' code (its static
+    tripwire: tools/store_census.py).  This is its dynamic guard: 2 000 iterations on each shape class the default path serves, against the same
     chain with the fence kept (HENS_AQL_RELEASE=1: plain record stores, release at the end of every packet) and against the HIP
     stream (HENS_NO_AQL=1: the runtime's own fences), final positions, log-probabilities, ladder and counters bit for bit.  One
     stale line read on another XCD anywhere in 2 000 iterations and the chains part."""
