@@ -112,6 +112,7 @@ SIGNATURES = {
     "hens_comm_selfsend": (C.c_int, [_P, C.c_int64, _P, _P]),
     "hens_debug_permutation": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int64, _P]),
     "hens_rj_set_model": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_double]),
+    "hens_rj_set_model_general": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "hens_rj_set_mh_scale": (C.c_int, [_P, _P]),
     "hens_rj_mh_step": (C.c_int, [_P, _P, _P, _P]),
     "hens_rj_bd_step": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),

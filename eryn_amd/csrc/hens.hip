@@ -198,6 +198,7 @@ struct hens_ctx_impl {
     uint8_t* rj_hmoved = nullptr;
     uint32_t* rj_h_accepted = nullptr;
     bool rj_hostlike = false, rj_accept_pending = false;
+    bool rj_general = false;                 // hens_rj_set_model_general: leaf widths other than 3 / no template likelihood - hens_rj_propose / _accept only
     bool rj_tm_drift = false;        // hens_rj_step has updated the resident templates by +- a leaf since their last full evaluation
     int rj_st_ns = 0;                       // hens_rj_stretch_split: walkers of the half being moved
     unsigned* rj_ad_flag = nullptr;  // the folded adaptation's "ladder published" word (RjArgs::ad_flag), serial of the last folding launch
@@ -1640,11 +1641,11 @@ int rj_push_ctab(hens_ctx_impl* c) {
     std::vector<int32_t> bn(RJ_MAX_RW, 0);
     for (int b = 0; b < M.nb; ++b)
         for (int n = 0; n < M.nl[b]; ++n)
-            for (int d = 0; d < RJ_ND; ++d) {
-                const int i = M.off[b] + n * RJ_ND + d;
+            for (int d = 0; d < M.nd[b]; ++d) {
+                const int i = M.off[b] + n * M.nd[b] + d;
                 tab[RJ_CTAB_LO + i] = M.lo[b][d]; tab[RJ_CTAB_HI + i] = M.hi[b][d];
                 tab[RJ_CTAB_SCALE + i] = M.mh_scale[b][d]; tab[RJ_CTAB_LOGP + i] = M.leaf_logp[b];
-                bn[i] = b | (n << 4) | (d << 10) | (M.kind[b] << 12) | ((M.off[b] / RJ_ND + n) << 16);
+                bn[i] = b | (n << 4) | (d << 10) | (M.kind[b] << 12) | ((M.slot0[b] + n) << 16);
             }
     int r;
     if (!c->rj_ctab) {
@@ -1698,6 +1699,8 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     const int npr = mode == RJ_MODE_STRETCH ? c->rj_st_ns : c->W;     // waves per rung
     const dim3 grid((unsigned)((npr + RJ_WAVES - 1) / RJ_WAVES), (unsigned)c->Tl), block(RJ_WAVES * 64);
     int tmm = a.tm ? a.tm_mode : -1;                  // the instantiation: (mode, template scheme), see k_rj
+    if (c->rj_general && mode == RJ_MODE_EVAL && !c->rj_hostlike) tmm = -2;      // (no device likelihood: the log-prior alone)
+    else if (c->rj_general && !c->rj_hostlike) return fail(c, HENS_ERR_STATE, "a model without a device likelihood steps with hens_rj_propose / hens_rj_accept");
     if (c->rj_hostlike) {                             // hens_rj_propose: the proposal only (k_rj<MODE, -2>), k_rj_accept finishes
         if (a.tm || !u_acc || mode == RJ_MODE_EVAL) return fail(c, HENS_ERR_STATE, "hens_rj_propose: a teacher-forced move with its accept uniforms");
         tmm = -2;
@@ -1710,7 +1713,7 @@ int rj_launch(hens_ctx_impl* c, int mode, int branch, const double* step, const 
     RJ_CASE(RJ_MODE_MH, -1) RJ_CASE(RJ_MODE_MH, 0)
     RJ_CASE(RJ_MODE_BD, -1) RJ_CASE(RJ_MODE_BD, 1)
     RJ_CASE(RJ_MODE_STRETCH, -1)
-    RJ_CASE(RJ_MODE_MH, -2) RJ_CASE(RJ_MODE_BD, -2) RJ_CASE(RJ_MODE_STRETCH, -2)
+    RJ_CASE(RJ_MODE_MH, -2) RJ_CASE(RJ_MODE_BD, -2) RJ_CASE(RJ_MODE_STRETCH, -2) RJ_CASE(RJ_MODE_EVAL, -2)
         return fail(c, HENS_ERR_INVALID, "k_rj: no instantiation for mode %d with template scheme %d", mode, tmm);
 #undef RJ_CASE
     const hipError_t e = hipGetLastError();
@@ -1725,6 +1728,8 @@ int rj_ready(hens_ctx_impl* c, bool between_halves = false) {
     if (c->Tl != c->T) return fail(c, HENS_ERR_UNSUPPORTED, "the leaf-packing path runs on the whole ladder of one GPU");
     if ((c->expect_split != 0 && !between_halves) || c->propose_pending) return fail(c, HENS_ERR_STATE, "a half-step is pending");
     if (c->rj_accept_pending) return fail(c, HENS_ERR_STATE, "hens_rj_accept must follow hens_rj_propose");
+    if (c->rj_general && !c->rj_hostlike)
+        return fail(c, HENS_ERR_STATE, "this context's model has no device likelihood (hens_rj_set_model_general): step it with hens_rj_propose / hens_rj_accept");
     return HENS_OK;
 }
 
@@ -1734,7 +1739,7 @@ int rj_ensure_staging(hens_ctx_impl* c) {
     int r;
     if ((r = dalloc(c, &c->rj_step, TW * c->D))) return r;
     if ((r = dalloc(c, &c->rj_u, TW))) return r;
-    if ((r = dalloc(c, &c->rj_birth, TW * RJ_ND * RJ_MAX_BRANCH))) return r;      // ([nbranches][Tl][W]: hens_rj_bd_all_step)
+    if ((r = dalloc(c, &c->rj_birth, TW * RJ_MAX_ND * RJ_MAX_BRANCH))) return r;      // ([nbranches][Tl][W]: hens_rj_bd_all_step)
     if ((r = dalloc(c, &c->rj_change, TW * RJ_MAX_BRANCH))) return r;
     if ((r = dalloc(c, &c->rj_leaf, TW * RJ_MAX_BRANCH))) return r;
     if ((r = dalloc(c, &c->rj_keep, TW))) return r;
@@ -3112,6 +3117,7 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
         if (nleaves_max[b] < 1 || nleaves_max[b] > 32 || nleaves_min[b] < 0 || nleaves_min[b] > nleaves_max[b])
             return fail(c, HENS_ERR_INVALID, "branch %d: need 0 <= nleaves_min <= nleaves_max <= 32", b);
         M.kind[b] = kinds[b]; M.nl[b] = nleaves_max[b]; M.nlmin[b] = nleaves_min[b]; M.off[b] = off;
+        M.nd[b] = RJ_ND; M.slot0[b] = off / RJ_ND; M.ndmax = RJ_ND;
         off += nleaves_max[b] * RJ_ND;
         for (int d = 0; d < RJ_ND; ++d) {
             M.lo[b][d] = lo[b * RJ_ND + d]; M.hi[b][d] = hi[b * RJ_ND + d];
@@ -3129,6 +3135,7 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
     M.RW = c->D;
     if (off + nbranches > c->D) return fail(c, HENS_ERR_INVALID, "record width ndim = %d cannot hold %d coordinates + %d masks", c->D, off, nbranches);
     c->rj = M;
+    c->rj_general = false;
     int r;
     if ((r = rj_push_ctab(c))) return r;
     if (!c->rj_t) {
@@ -3153,10 +3160,60 @@ int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, co
     return HENS_OK;
 }
 
+// A leaf-packing model WITHOUT a device likelihood: branches of 1 .. RJ_MAX_ND box-prior parameters per leaf (ensemble.py:325-329:
+// `ndims` per branch), stepped with hens_rj_propose / hens_rj_accept around the caller's log-likelihood (ensemble.py:1306-1334,
+// 1340-1545).  lo / hi: the branches' boxes one after the other (ndims[0] values, then ndims[1], ...); leaf_logp: the branches'
+// constant leaf log-densities, accumulated by the caller in the reference's order (prior.py:364-383).
+int hens_rj_set_model_general(hens_ctx* ctx, int32_t nbranches, const int32_t* ndims, const int32_t* nleaves_max,
+                              const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp) {
+    hens_ctx_impl* c = enter(ctx);
+    if (!c || !ndims || !nleaves_max || !nleaves_min || !lo || !hi || !leaf_logp) return fail(c, HENS_ERR_INVALID, "null argument");
+    if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE) return fail(c, HENS_ERR_STATE, "hens_rj_set_model_general needs HENS_LIKE_TEMPLATE");
+    if (nbranches < 1 || nbranches > RJ_MAX_BRANCH) return fail(c, HENS_ERR_INVALID, "1..%d branches", RJ_MAX_BRANCH);
+    HIPCHK(c, hipSetDevice(c->cfg.device_id));
+    state_to_fields(c);
+    RjModel M{};
+    M.nb = nbranches; M.ndata = 0; M.sigma = 1.0; M.t_step64 = 0.0;
+    int off = 0, slot = 0, k = 0;
+    for (int b = 0; b < nbranches; ++b) {
+        if (ndims[b] < 1 || ndims[b] > RJ_MAX_ND) return fail(c, HENS_ERR_UNSUPPORTED, "branch %d: 1..%d parameters per leaf", b, RJ_MAX_ND);
+        if (nleaves_max[b] < 1 || nleaves_max[b] > 32 || nleaves_min[b] < 0 || nleaves_min[b] > nleaves_max[b])
+            return fail(c, HENS_ERR_INVALID, "branch %d: need 0 <= nleaves_min <= nleaves_max <= 32", b);
+        M.kind[b] = 0; M.nl[b] = nleaves_max[b]; M.nlmin[b] = nleaves_min[b]; M.off[b] = off;
+        M.nd[b] = ndims[b]; M.slot0[b] = slot; M.ndmax = std::max(M.ndmax, ndims[b]);
+        off += nleaves_max[b] * ndims[b];
+        slot += nleaves_max[b];
+        for (int d = 0; d < ndims[b]; ++d, ++k) {
+            M.lo[b][d] = lo[k]; M.hi[b][d] = hi[k];
+            if (!(M.hi[b][d] > M.lo[b][d])) return fail(c, HENS_ERR_INVALID, "branch %d: empty prior box", b);
+        }
+        M.leaf_logp[b] = leaf_logp[b];
+    }
+    if (slot > 64) return fail(c, HENS_ERR_UNSUPPORTED, "%d leaf slots: at most 64 over all branches", slot);
+    M.ind_off = off;
+    M.RW = c->D;
+    if (off + nbranches > c->D || c->D > RJ_MAX_RW)
+        return fail(c, HENS_ERR_INVALID, "record width ndim = %d cannot hold %d coordinates + %d masks (at most %d)", c->D, off, nbranches, RJ_MAX_RW);
+    c->rj = M;
+    c->rj_general = true;
+    int r;
+    if ((r = rj_push_ctab(c))) return r;
+    if (!c->rj_acc_bd) {
+        if ((r = dalloc(c, &c->rj_acc_bd, (size_t)c->Tl * c->W))) return r;
+        HIPCHK(c, hipMemsetAsync(c->rj_acc_bd, 0, (size_t)c->Tl * c->W * 4, c->stream));
+    }
+    c->rj_tm_valid = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_like = true;
+    c->have_prior = true;
+    return HENS_OK;
+}
+
 int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale) {
     hens_ctx_impl* c = enter(ctx);
     if (!c || !scale) return fail(c, HENS_ERR_INVALID, "null argument");
     if (c->cfg.likelihood_kind != HENS_LIKE_TEMPLATE || !c->have_like) return fail(c, HENS_ERR_STATE, "hens_rj_set_model first");
+    if (c->rj_general) return fail(c, HENS_ERR_STATE, "the Philox in-model move belongs to hens_rj_step: template models only");
     for (int b = 0; b < c->rj.nb; ++b)
         for (int d = 0; d < RJ_ND; ++d) c->rj.mh_scale[b][d] = scale[b * RJ_ND + d];
     c->rj_have_scale = true;
@@ -3263,7 +3320,7 @@ int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const i
     if ((r = rj_ensure_staging(c))) return r;
     HIPCHK(c, hipMemcpyAsync(c->rj_change, change, TW, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_leaf, leaf, TW * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, TW * RJ_ND * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, TW * (size_t)c->rj.ndmax * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
     c->rj_tm_valid = false;                   // (teacher-forced move: the reference's full evaluation, no resident templates)
     if ((r = rj_launch(c, RJ_MODE_BD, branch, nullptr, c->rj_change, c->rj_leaf, c->rj_birth, c->rj_u, c->rj_keep))) return r;
@@ -3293,7 +3350,7 @@ int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf
     if ((r = rj_ensure_staging(c))) return r;
     HIPCHK(c, hipMemcpyAsync(c->rj_change, change, NB * TW, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_leaf, leaf, NB * TW * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, NB * TW * RJ_ND * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->rj_birth, birth, NB * TW * (size_t)c->rj.ndmax * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->rj_u, u_acc, TW * 8, hipMemcpyHostToDevice, c->stream));
     c->rj_tm_valid = false;                   // (teacher-forced move: the reference's full evaluation, no resident templates)
     if ((r = rj_launch(c, RJ_MODE_BD, -1, nullptr, c->rj_change, c->rj_leaf, c->rj_birth, c->rj_u, c->rj_keep))) return r;

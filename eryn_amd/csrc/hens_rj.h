@@ -24,6 +24,9 @@
 namespace hens {
 
 constexpr int RJ_MAX_BRANCH = 4, RJ_ND = 3, RJ_MAX_RW = 128;
+// leaf parameters per branch: RJ_ND = 3 for the built-in template models (pulse / sine) and everything that runs their likelihood on the
+// device; 1 .. RJ_MAX_ND per branch for models whose likelihood the host evaluates (hens_rj_set_model_general, k_rj<MODE, -2>)
+constexpr int RJ_MAX_ND = 4;
 #define RJ_CBN_B(v) ((v) & 15)
 #define RJ_CBN_N(v) (((v) >> 4) & 63)
 #define RJ_CBN_D(v) (((v) >> 10) & 3)
@@ -37,11 +40,14 @@ enum : uint32_t { PURPOSE_RJ_NORMAL = 20, PURPOSE_RJ_ACC = 21, PURPOSE_RJ_BD = 2
 struct RjModel {
     int32_t nb, RW, ndata, ind_off;                 // branches, record width (doubles), data points, offset of the first mask
     int32_t kind[RJ_MAX_BRANCH], nl[RJ_MAX_BRANCH], nlmin[RJ_MAX_BRANCH], off[RJ_MAX_BRANCH];
-    double lo[RJ_MAX_BRANCH][RJ_ND], hi[RJ_MAX_BRANCH][RJ_ND];
+    double lo[RJ_MAX_BRANCH][RJ_MAX_ND], hi[RJ_MAX_BRANCH][RJ_MAX_ND];
     double leaf_logp[RJ_MAX_BRANCH];                // sum_d log(1 / (hi_d - lo_d)) accumulated by the host in the reference's order
-    double mh_scale[RJ_MAX_BRANCH][RJ_ND];          // Philox mode: standard deviations of the in-model Gaussian step
+    double mh_scale[RJ_MAX_BRANCH][RJ_MAX_ND];      // Philox mode: standard deviations of the in-model Gaussian step
     double sigma;
     double t_step64;                                // the data points lie on a uniform grid: 64 grid steps (else 0), see k_rj
+    // leaf parameters per branch, first leaf-slot number per branch, the widest branch (= the stride of the birth arrays): 3,
+    // off / 3, 3 for the template models; read by the host-likelihood instantiations only (k_rj<MODE, -2>)
+    int32_t nd[RJ_MAX_BRANCH], slot0[RJ_MAX_BRANCH], ndmax, pad_;
 };
 
 struct RjArgs {
@@ -287,6 +293,11 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     const int tl = (int)blockIdx.y;
     const int64_t slot = (int64_t)tl * NPR + idx;    // one wavefront per walker - stretch half-step: per position of the half
     const RjModel& M = A.M;
+    // (leaf width, first slot, birth-array stride of a branch: compile-time 3 wherever the device evaluates the template likelihood)
+    constexpr bool GEN = TMM == -2;
+    auto ndb = [&](const int b) { return GEN ? M.nd[b] : RJ_ND; };
+    auto slot0 = [&](const int b) { return GEN ? M.slot0[b] : M.off[b] / RJ_ND; };
+    const int bstride = GEN ? M.ndmax : RJ_ND;
     const int64_t gw = MODE == RJ_MODE_STRETCH ? (int64_t)tl * A.W + A.st_own[slot] : slot;
     const int RW = M.RW;
 #ifdef HENS_RJ_TRACE_STRIDE        // DEV: every 64th walker instead of the first ones (all rounds of the launch)
@@ -392,9 +403,9 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             // one Philox call for everything the walker draws for this branch: lane 0 the coin and the leaf selector, lanes 1 - 3 the
             // born leaf's coordinates, lane 4 (first branch of the proposal) the accept uniform
             const int accb = A.branch >= 0 ? A.branch : M.nb;
-            const uint32_t key = lane == 0 ? rj_bd_key(B) : (lane <= RJ_ND ? rj_birth_key(B, lane - 1) : rj_acc_key(RJ_MODE_BD, accb));
+            const uint32_t key = lane == 0 ? rj_bd_key(B) : (lane <= ndb(B) ? rj_birth_key(B, lane - 1) : rj_acc_key(RJ_MODE_BD, accb));
             dr_bd = rj_philox(A.seed, A.iter, wid, key);
-            if (B == b_lo && !A.u_acc) { u_drawn = __shfl(u01(dr_bd.x, dr_bd.y), RJ_ND + 1); u_have = true; }
+            if (B == b_lo && !A.u_acc) { u_drawn = __shfl(u01(dr_bd.x, dr_bd.y), ndb(B) + 1); u_have = true; }
             const uint32_t dx = __builtin_amdgcn_readfirstlane(dr_bd.x), dy = __builtin_amdgcn_readfirstlane(dr_bd.y);
             c = (dx & 1u) ? +1 : -1;                                  // distgenrj.py:63-66
             if (M.nlmin[B] == M.nl[B]) c = 0;
@@ -409,8 +420,8 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
         if (c < 0) {                                                  // death: factor +log q(leaf) (:188-197)
             mask_set(B, mask_of(B) & ~(1u << lf));
             bool in = true;
-            for (int d = 0; d < RJ_ND; ++d) {
-                const double v = cur[M.off[B] + lf * RJ_ND + d];
+            for (int d = 0; d < ndb(B); ++d) {
+                const double v = cur[M.off[B] + lf * ndb(B) + d];
                 in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
             }
             factors = factors + (in ? M.leaf_logp[B] : -INFINITY);
@@ -418,21 +429,21 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             mask_set(B, mask_of(B) | (1u << lf));
             bool in = true;
             if (A.birth) {
-                for (int d = 0; d < RJ_ND; ++d) {
-                    const double v = A.birth[(bo + (size_t)gw) * RJ_ND + d];
+                for (int d = 0; d < ndb(B); ++d) {
+                    const double v = A.birth[(bo + (size_t)gw) * bstride + d];
                     in = in && (v >= M.lo[B][d]) && (v <= M.hi[B][d]);
-                    if (lane == 0) q[M.off[B] + lf * RJ_ND + d] = v;
+                    if (lane == 0) q[M.off[B] + lf * ndb(B) + d] = v;
                 }
             } else {                                                  // lane 1 + d holds coordinate d's draw (above): prior.py:60-66
-                const int d = lane >= 1 && lane <= RJ_ND ? lane - 1 : 0;
+                const int d = lane >= 1 && lane <= ndb(B) ? lane - 1 : 0;
                 const int i = M.off[B] + d;                           // (a branch's box is the same for every leaf: leaf 0's coordinate d)
                 double lo, hi;
-                if (M.off[B] + RJ_ND <= 64) { lo = __shfl(c_lo, i); hi = __shfl(c_hi, i); }
+                if (M.off[B] + ndb(B) <= 64) { lo = __shfl(c_lo, i); hi = __shfl(c_hi, i); }
                 else { lo = A.ctab[RJ_CTAB_LO + i]; hi = A.ctab[RJ_CTAB_HI + i]; }
                 const double v = u01(dr_bd.x, dr_bd.y) * (hi - lo) + lo;
-                const bool mine = lane >= 1 && lane <= RJ_ND;
+                const bool mine = lane >= 1 && lane <= ndb(B);
                 in = __ballot(mine && !((v >= lo) && (v <= hi))) == 0ull;
-                if (mine) q[M.off[B] + lf * RJ_ND + d] = v;
+                if (mine) q[M.off[B] + lf * ndb(B) + d] = v;
             }
             factors = factors - (in ? M.leaf_logp[B] : -INFINITY);
         }
@@ -483,14 +494,15 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
             const int i = p * 64 + lane;
             if (i < M.ind_off && RJ_CBN_D(bn2[p]) == 0) {                  // the lane of a slot's first coordinate: the slot's term
                 const uint64_t w0 = p == 0 ? outb[0] : outb[1], w1 = p == 0 ? outb[1] : 0ull;
-                const uint32_t o3 = (uint32_t)((w0 >> lane) | (lane > 61 ? w1 << (64 - lane) : 0ull)) & 7u;
+                const uint32_t wbits = GEN ? (1u << M.nd[RJ_CBN_B(bn2[p])]) - 1u : 7u;     // (the slot's coordinates: nd consecutive lanes)
+                const uint32_t o3 = (uint32_t)((w0 >> lane) | (lane > (GEN ? 60 : 61) ? w1 << (64 - lane) : 0ull)) & wbits;
                 const bool active = (mask_of(RJ_CBN_B(bn2[p])) >> RJ_CBN_N(bn2[p])) & 1u;
                 leafv[RJ_CBN_SLOT(bn2[p])] = active ? (o3 ? -INFINITY : lp2[p]) : 0.0;
             }
         }
         RJ_LDS_SYNC();
         for (int b = 0; b < M.nb; ++b) {
-            logp = logp + numpy_sum(leafv + M.off[b] / RJ_ND, M.nl[b]);
+            logp = logp + numpy_sum(leafv + slot0(b), M.nl[b]);
             total_leaves += __builtin_popcount(mask_of(b));
         }
     }
@@ -503,6 +515,10 @@ __global__ __launch_bounds__(RJ_WAVES * 64) __attribute__((amdgpu_waves_per_eu(R
     }
 
     if constexpr (TMM == -2) {               // host-callable likelihood: the proposal goes out, k_rj_accept takes over (RjArgs::hq)
+        if (MODE == RJ_MODE_EVAL) {          // (hens_eval_state on a model without a device likelihood: the log-prior; the caller's L follows)
+            if (lane == 0) { A.P[gw] = logp; A.L[gw] = A.fill; }
+            return;
+        }
         for (int i = lane; i < RW; i += 64) A.hq[(size_t)gw * RW + i] = q[i];
         if (lane == 0) {
             A.hlogp[gw] = logp;

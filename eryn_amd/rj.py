@@ -36,6 +36,26 @@ class TemplateBranch:
         self.leaf_logp = float(acc[0])
 
 
+class LeafBranch:
+    """One model type WITHOUT a device likelihood (round 6): a uniform box per leaf parameter - 1 to 4 of them, the reference's
+    ``ndims[name]`` (ensemble.py:325-329) - and a leaf budget.  For chains whose likelihood is the caller's Python function
+    (CallableLikelihood, hens_rj_set_model_general)."""
+    kind = 0
+
+    def __init__(self, name, box, nleaves_max, nleaves_min=0):
+        self.name = str(name)
+        self.lo = f64([b[0] for b in box])
+        self.hi = f64([b[1] for b in box])
+        self.ndim = int(self.lo.shape[0])
+        if not 1 <= self.ndim <= 4:
+            raise NotImplementedError("a leaf has 1 to 4 parameters")
+        self.nleaves_max, self.nleaves_min = int(nleaves_max), int(nleaves_min)
+        acc = np.zeros(1)                      # prior.py:364-383: sequential ``prior_vals += temp`` from 0.0
+        for d in range(self.ndim):
+            acc += np.log(1 / (self.hi[d] - self.lo[d]))
+        self.leaf_logp = float(acc[0])
+
+
 class _TemplateLikelihood:
     kind = _lib.LIKE_TEMPLATE
 
@@ -128,10 +148,15 @@ class RJEngine:
         self.branches = list(branches)
         if not 1 <= len(self.branches) <= 4:
             raise NotImplementedError("1 to 4 branches")
-        self.ncoord = sum(b.nleaves_max * 3 for b in self.branches)
+        self.ncoord = sum(b.nleaves_max * b.ndim for b in self.branches)
+        self.ndmax = max(b.ndim for b in self.branches)          # (the stride of the birth arrays: 3 for the template models)
+        # a model without a device likelihood: any LeafBranch, or no data (hens_rj_set_model_general; host_like steps it)
+        self.general = t is None or any(not isinstance(b, TemplateBranch) for b in self.branches)
         rw = self.ncoord + len(self.branches)
         self.RW = rw + (rw & 1)                                  # even record width: 16-byte row alignment
-        self.off = np.cumsum([0] + [b.nleaves_max * 3 for b in self.branches])[:-1]
+        if self.RW > 128:
+            raise NotImplementedError(f"{self.ncoord} leaf coordinates + {len(self.branches)} masks: a record holds 128 doubles")
+        self.off = np.cumsum([0] + [b.nleaves_max * b.ndim for b in self.branches])[:-1]
         self.T, self.W = int(ntemps), int(nwalkers)
         # the engine's prior box is unused on records; HipEnsemble wants one
         self.eng = HipEnsemble(self.T, self.W, self.RW, _TemplateLikelihood(self.RW), -1.0, 1.0, tempered=True,
@@ -145,9 +170,14 @@ class RJEngine:
         kinds = np.array([b.kind for b in self.branches], dtype=np.int32)
         nlmax = np.array([b.nleaves_max for b in self.branches], dtype=np.int32)
         nlmin = np.array([b.nleaves_min for b in self.branches], dtype=np.int32)
+        lp = f64([b.leaf_logp for b in self.branches])
+        if self.general:
+            nds = np.array([b.ndim for b in self.branches], dtype=np.int32)
+            lo, hi = f64(np.concatenate([b.lo for b in self.branches])), f64(np.concatenate([b.hi for b in self.branches]))
+            check(self.lib.hens_rj_set_model_general(self.ctx, nb, ptr(nds), ptr(nlmax), ptr(nlmin), ptr(lo), ptr(hi), ptr(lp)), self.ctx)
+            return
         lo = f64(np.stack([b.lo for b in self.branches]))
         hi = f64(np.stack([b.hi for b in self.branches]))
-        lp = f64([b.leaf_logp for b in self.branches])
         t, y = f64(t), f64(y)
         if t.shape != y.shape or t.ndim != 1:
             raise ValueError("t and y must be 1-D arrays of the same length")
@@ -159,14 +189,14 @@ class RJEngine:
 
     # -- records <-> branches --------------------------------------------------------------------------------
     def pack(self, x, inds):
-        """{name: coords[T, W, nl, 3]}, {name: inds[T, W, nl]} -> records[T, W, RW]."""
+        """{name: coords[T, W, nl, ndim]}, {name: inds[T, W, nl]} -> records[T, W, RW]."""
         rec = np.zeros((self.T, self.W, self.RW))
         for bi, b in enumerate(self.branches):
             c = np.asarray(x[b.name], dtype=np.float64)
-            if c.shape != (self.T, self.W, b.nleaves_max, 3):
-                raise ValueError(f"coords of branch {b.name} must have shape {(self.T, self.W, b.nleaves_max, 3)}")
+            if c.shape != (self.T, self.W, b.nleaves_max, b.ndim):
+                raise ValueError(f"coords of branch {b.name} must have shape {(self.T, self.W, b.nleaves_max, b.ndim)}")
             c = np.where(np.isnan(c), 0.0, c)                    # a stored chain marks unused leaves with NaN
-            rec[:, :, self.off[bi]:self.off[bi] + b.nleaves_max * 3] = c.reshape(self.T, self.W, -1)
+            rec[:, :, self.off[bi]:self.off[bi] + b.nleaves_max * b.ndim] = c.reshape(self.T, self.W, -1)
             m = np.asarray(inds[b.name], dtype=bool)
             rec[:, :, self.ncoord + bi] = (m * (1 << np.arange(b.nleaves_max))).sum(axis=-1)
         return rec
@@ -174,7 +204,7 @@ class RJEngine:
     def unpack(self, rec, nan_fill=False):
         x, inds = {}, {}
         for bi, b in enumerate(self.branches):
-            x[b.name] = rec[:, :, self.off[bi]:self.off[bi] + b.nleaves_max * 3].reshape(self.T, self.W, b.nleaves_max, 3).copy()
+            x[b.name] = rec[:, :, self.off[bi]:self.off[bi] + b.nleaves_max * b.ndim].reshape(self.T, self.W, b.nleaves_max, b.ndim).copy()
             m = rec[:, :, self.ncoord + bi].astype(np.int64)
             inds[b.name] = ((m[:, :, None] >> np.arange(b.nleaves_max)) & 1).astype(bool)
             if nan_fill:                                         # backend.py:1049-1059
@@ -182,10 +212,10 @@ class RJEngine:
         return x, inds
 
     def steps_to_records(self, steps):
-        """{name: step[T, W, nl, 3]} (zero on unused slots) -> [T, W, ncoord] in record layout."""
+        """{name: step[T, W, nl, ndim]} (zero on unused slots) -> [T, W, ncoord] in record layout."""
         out = np.zeros((self.T, self.W, self.ncoord))
         for bi, b in enumerate(self.branches):
-            out[:, :, self.off[bi]:self.off[bi] + b.nleaves_max * 3] = np.asarray(steps[b.name]).reshape(self.T, self.W, -1)
+            out[:, :, self.off[bi]:self.off[bi] + b.nleaves_max * b.ndim] = np.asarray(steps[b.name]).reshape(self.T, self.W, -1)
         return out
 
     # -- state ---------------------------------------------------------------------------------------------------
@@ -242,10 +272,10 @@ class RJEngine:
         return keep.astype(bool)
 
     def bd_step(self, branch, change, leaf, birth, u_acc):
-        """change[T, W] in {-1, 0, +1}, leaf[T, W] slot, birth[T, W, 3] (rows of walkers that give birth), u_acc[T, W]."""
+        """change[T, W] in {-1, 0, +1}, leaf[T, W] slot, birth[T, W, ndim of the branch] (rows of walkers that give birth), u_acc[T, W]."""
         ch = np.ascontiguousarray(change, dtype=np.int8)
         lf = np.ascontiguousarray(np.where(np.asarray(change) == 0, 0, leaf), dtype=np.int32)
-        bt = f64(birth, (self.T, self.W, 3))
+        bt = self._birth_rows(birth, self.branches[int(branch)].ndim)
         u = f64(u_acc, (self.T, self.W))
         if self.host_like is not None:
             return self._host_move(_lib.RJ_MOVE_BD, branch=int(branch), change=ch, leaf=lf, birth=bt, u_acc=u)
@@ -254,11 +284,12 @@ class RJEngine:
         return keep.astype(bool)
 
     def bd_all_step(self, change, leaf, birth, u_acc):
-        """"together": one proposal over every branch - change / leaf [nbranches, T, W], birth [nbranches, T, W, 3], u_acc [T, W]."""
+        """"together": one proposal over every branch - change / leaf [nbranches, T, W], birth [nbranches][T, W, ndim of the branch]
+        (one array when every branch has the same width), u_acc [T, W]."""
         nb = len(self.branches)
         ch = np.ascontiguousarray(change, dtype=np.int8)
         lf = np.ascontiguousarray(np.where(np.asarray(change) == 0, 0, leaf), dtype=np.int32)
-        bt = f64(birth, (nb, self.T, self.W, 3))
+        bt = np.ascontiguousarray(np.stack([self._birth_rows(birth[bi], b.ndim) for bi, b in enumerate(self.branches)]))
         u = f64(u_acc, (self.T, self.W))
         if ch.shape != (nb, self.T, self.W) or lf.shape != ch.shape:
             raise ValueError("change / leaf must have shape (nbranches, ntemps, nwalkers)")
@@ -267,6 +298,15 @@ class RJEngine:
         keep = np.empty((self.T, self.W), dtype=np.uint8)
         check(self.lib.hens_rj_bd_all_step(self.ctx, ptr(ch), ptr(lf), ptr(bt), ptr(u), ptr(keep)), self.ctx)
         return keep.astype(bool)
+
+    def _birth_rows(self, birth, nd):
+        """[T, W, nd] -> [T, W, ndmax] (the library's stride: the model's widest branch)."""
+        b = f64(birth, (self.T, self.W, nd))
+        if nd == self.ndmax:
+            return b
+        out = np.zeros((self.T, self.W, self.ndmax))
+        out[:, :, :nd] = b
+        return out
 
     def stretch_split(self, split, labels, rint, u_zz, u_acc):
         """One half of the red / blue StretchMove over every branch and leaf slot (stretch.py:160-231, red_blue.py:148-323):
@@ -290,7 +330,7 @@ class RJEngine:
 
     # -- production -------------------------------------------------------------------------------------------------
     def set_mh_scale(self, scale):
-        """Standard deviations of the in-model Gaussian step per branch and leaf parameter: [nbranches, 3]."""
+        """Standard deviations of the in-model Gaussian step per branch and leaf parameter: [nbranches, 3] (template models)."""
         s = f64(scale, (len(self.branches), 3))
         check(self.lib.hens_rj_set_mh_scale(self.ctx, ptr(s)), self.ctx)
 
@@ -348,7 +388,7 @@ class TemplateLikelihood:
 
     def __init__(self, kinds, t, y, sigma):
         self.kinds = {k: _KINDS[v] for k, v in kinds.items()}
-        self.t, self.y, self.sigma = f64(t), f64(y), float(sigma)
+        self.t, self.y, self.sigma = (None if t is None else f64(t)), (None if y is None else f64(y)), float(sigma)
 
 
 class GaussianLeafMove:
@@ -358,8 +398,8 @@ class GaussianLeafMove:
     def __init__(self, cov_all):
         self.cov = {k: np.atleast_2d(np.asarray(v, dtype=np.float64)) for k, v in cov_all.items()}
         for k, c in self.cov.items():
-            if c.shape != (3, 3):
-                raise NotImplementedError("a leaf's proposal covariance must be a 3 x 3 matrix")
+            if c.ndim != 2 or c.shape[0] != c.shape[1] or not 1 <= c.shape[0] <= 4:
+                raise NotImplementedError("a leaf's proposal covariance must be an ndim x ndim matrix (ndim = 1 .. 4)")
         self.accepted, self.num_proposals = None, 0
 
 
@@ -406,7 +446,7 @@ class RJEnsembleSampler:
                 raise NotImplementedError("a host-callable likelihood steps with rng='numpy' (rng='philox' needs the likelihood on the device)")
             self.host_like = log_like_fn
             names_ = list(branch_names if branch_names is not None else ndims.keys())
-            log_like_fn = TemplateLikelihood({k: "pulse" for k in names_}, np.zeros(2), np.zeros(2), 1.0)     # (never evaluated)
+            log_like_fn = TemplateLikelihood({k: "pulse" for k in names_}, None, None, 1.0)     # (never evaluated: no device likelihood)
         if not isinstance(log_like_fn, TemplateLikelihood):
             raise NotImplementedError("log_like_fn: an eryn_amd.rj.TemplateLikelihood, a CallableLikelihood or a Python function")
         if rj_moves not in ("separate_branches", "iterate_branches", "together", None, False):
@@ -429,13 +469,21 @@ class RJEnsembleSampler:
         self.nleaves_max, self.nleaves_min = dict(nleaves_max), dict(nleaves_min)
         self.branches = []
         for k in self.branch_names:
-            if self.ndims[k] != 3:
+            nd = int(self.ndims[k])
+            if self.host_like is None and nd != 3:
                 raise NotImplementedError("a leaf of the template model has three parameters")
+            if isinstance(moves, GaussianLeafMove) and moves.cov[k].shape != (nd, nd):
+                raise ValueError(f"branch {k}: the proposal covariance must be {nd} x {nd}")
             pr = priors[k]
             box = pr.box_bounds() if hasattr(pr, "box_bounds") else \
-                ([pr[i].min_val for i in range(3)], [pr[i].max_val for i in range(3)])
-            self.branches.append(TemplateBranch(k, log_like_fn.kinds[k], list(zip(box[0], box[1])), self.nleaves_max[k],
-                                                self.nleaves_min[k]))
+                ([pr[i].min_val for i in range(nd)], [pr[i].max_val for i in range(nd)])
+            if len(box[0]) != nd:
+                raise ValueError(f"branch {k}: {len(box[0])} prior boxes for ndims = {nd}")
+            if self.host_like is not None:     # (no device likelihood: 1 .. 4 parameters per leaf, hens_rj_set_model_general)
+                self.branches.append(LeafBranch(k, list(zip(box[0], box[1])), self.nleaves_max[k], self.nleaves_min[k]))
+            else:
+                self.branches.append(TemplateBranch(k, log_like_fn.kinds[k], list(zip(box[0], box[1])), self.nleaves_max[k],
+                                                    self.nleaves_min[k]))
         total_ndim = sum(self.nleaves_max[k] * self.ndims[k] for k in self.branch_names)     # ensemble.py:325-329
         tk = dict(tempering_kwargs or {})
         if not tk:
@@ -514,7 +562,7 @@ class RJEnsembleSampler:
             for b in self.branches:
                 n = int(inds[b.name].sum())
                 s = np.zeros(x[b.name].shape)
-                s[inds[b.name]] = 1.0 * R.multivariate_normal(np.zeros(3), mv.cov[b.name], size=n)
+                s[inds[b.name]] = 1.0 * R.multivariate_normal(np.zeros(b.ndim), mv.cov[b.name], size=n)
                 steps[b.name] = s
             acc = eng.mh_step(steps, R.rand(T, W))
         mv.accepted += acc
@@ -556,7 +604,8 @@ class RJEnsembleSampler:
         _, inds, _, _, betas = eng.download()
         tc.betas = betas
         nb = len(self.branches)
-        change, leaf, birth = np.zeros((nb, T, W), dtype=np.int64), np.zeros((nb, T, W), dtype=np.int64), np.zeros((nb, T, W, 3))
+        change, leaf = np.zeros((nb, T, W), dtype=np.int64), np.zeros((nb, T, W), dtype=np.int64)
+        birth = [np.zeros((T, W, b.ndim)) for b in self.branches]
         for bi, b in enumerate(self.branches):
             if b.nleaves_min != b.nleaves_max:
                 change[bi], leaf[bi] = self._draw_change_leaf(b, inds[b.name])
@@ -582,8 +631,8 @@ class RJEnsembleSampler:
 
     @staticmethod
     def _draw_births(b, nbirth):
-        draws = np.zeros((nbirth, 3))
-        for d in range(3):                                                      # ProbDistContainer.rvs: GLOBAL stream, per parameter
+        draws = np.zeros((nbirth, b.ndim))
+        for d in range(b.ndim):                                                 # ProbDistContainer.rvs: GLOBAL stream, per parameter
             draws[:, d] = np.random.rand(nbirth) * (b.hi[d] - b.lo[d]) + b.lo[d]          # prior.py:60-66, 432-497
         return draws
 
@@ -593,7 +642,7 @@ class RJEnsembleSampler:
         _, inds, _, _, betas = eng.download()
         tc.betas = betas
         b = self.branches[bi]
-        change, leaf, birth = np.zeros((T, W), dtype=np.int64), np.zeros((T, W), dtype=np.int64), np.zeros((T, W, 3))
+        change, leaf, birth = np.zeros((T, W), dtype=np.int64), np.zeros((T, W), dtype=np.int64), np.zeros((T, W, b.ndim))
         if b.nleaves_min != b.nleaves_max:
             change, leaf = self._draw_change_leaf(b, inds[b.name])
             birth[change == +1] = self._draw_births(b, int((change == +1).sum()))
@@ -616,7 +665,7 @@ class RJEnsembleSampler:
         st = State(initial_state, copy=True)
         coords, inds = st.branches_coords, st.branches_inds
         for b in self.branches:
-            if coords[b.name].shape != (self.ntemps, self.nwalkers, b.nleaves_max, 3):
+            if coords[b.name].shape != (self.ntemps, self.nwalkers, b.nleaves_max, b.ndim):
                 raise ValueError("incompatible input dimensions")
         if st.betas is not None:
             tc.betas = np.array(st.betas, dtype=np.float64)

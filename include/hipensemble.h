@@ -411,6 +411,15 @@ int hens_debug_permutation(hens_ctx* ctx, int32_t which, int32_t rung, int64_t i
 int hens_rj_set_model(hens_ctx* ctx, int32_t nbranches, const int32_t* kinds, const int32_t* nleaves_max,
                       const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp,
                       int32_t ndata, const double* t, const double* y, double sigma);
+/* A leaf-packing model WITHOUT a device likelihood (round 6): the reference's `ndims` per branch (ensemble.py:325-329) - 1 .. 4
+ * box-prior parameters per leaf, up to 4 branches, up to 64 leaf slots and 128 record doubles in all - for chains whose likelihood is
+ * the caller's function of the packed active leaves (ensemble.py:1306-1334, 1340-1545): such a context is stepped with
+ * hens_rj_propose / hens_rj_accept only (hens_rj_step and the parity moves with the built-in template likelihood refuse it), and
+ * hens_eval_state leaves the log-prior and the fill value as log-likelihood (the caller uploads its own).  Record layout as
+ * hens_rj_set_model's with ndims[b] doubles per leaf slot; lo / hi: the branches' boxes one after the other; the `birth` arrays of
+ * hens_rj_draws have a stride of max(ndims) doubles per walker. */
+int hens_rj_set_model_general(hens_ctx* ctx, int32_t nbranches, const int32_t* ndims, const int32_t* nleaves_max,
+                              const int32_t* nleaves_min, const double* lo, const double* hi, const double* leaf_logp);
 int hens_rj_set_mh_scale(hens_ctx* ctx, const double* scale);
 int hens_rj_mh_step(hens_ctx* ctx, const double* step, const double* u_acc, uint8_t* keep_out);
 int hens_rj_bd_step(hens_ctx* ctx, int32_t branch, const int8_t* change, const int32_t* leaf, const double* birth,

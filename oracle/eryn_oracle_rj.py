@@ -115,6 +115,30 @@ def lorentz_chirp_log_like(x_list, t, y, sigma):
     return -0.5 * np.sum(((tm - y) / sigma) ** 2)
 
 
+def ramp_burst_log_like(x_list, t, y, sigma):
+    """A user likelihood over branches of DIFFERENT leaf widths (round 6: hens_rj_set_model_general), same calling convention as
+    lorentz_chirp_log_like.  Branch 0, two parameters per leaf: ramps a + b t; branch 1, four: bursts
+    a exp(-((t - t0) / w)^2) cos(2 pi f (t - t0)).  Gaussian noise of width sigma."""
+    ramps, bursts = x_list
+    tm = np.zeros_like(t)
+    if ramps is not None:
+        for a, b in np.atleast_2d(ramps):
+            tm = tm + (a + b * t)
+    if bursts is not None:
+        for a, t0, w, f in np.atleast_2d(bursts):
+            tm = tm + a * np.exp(-(((t - t0) / w) ** 2)) * np.cos(2 * np.pi * f * (t - t0))
+    return -0.5 * np.sum(((tm - y) / sigma) ** 2)
+
+
+def offset_log_like(offs, t, y, sigma):
+    """... and ONE branch of one-parameter leaves: constant offsets (a leaf is a number).  With one model type the reference hands the
+    function that branch's leaves directly, not a list over the branches (ensemble.py:1466-1467)."""
+    tm = np.zeros_like(t)
+    for (a,) in np.asarray(offs).reshape(-1, 1):
+        tm = tm + a
+    return -0.5 * np.sum(((tm - y) / sigma) ** 2)
+
+
 def callable_log_like(like_fn, x, inds, evaluated, args):
     """What ensemble.py:1306-1334, 1420-1480 hands a non-vectorised user function: per evaluated walker (group) the list over the
     branches of that walker's active leaves ``coords[inds]`` - in slot order - or None for a branch without one."""
@@ -129,7 +153,7 @@ def callable_log_like(like_fn, x, inds, evaluated, args):
             for name in x:
                 m = inds[name][tt, w]
                 arg.append(x[name][tt, w][m] if m.any() else None)
-            out[tt, w] = like_fn(arg, *args)
+            out[tt, w] = like_fn(arg[0] if len(arg) == 1 else arg, *args)        # (one model type: taken out of the list, :1466-1467)
     return out
 
 

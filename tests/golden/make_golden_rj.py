@@ -39,12 +39,29 @@ GAUSS_BOX = [(2.5, 3.5), (-1.0, 1.0), (0.01, 0.21)]               # tests/test_e
 SINE_BOX = [(0.5, 1.5), (1.0, 20.0), (0.0, 2 * np.pi)]
 
 
+# Round 6: models whose branches have OTHER leaf widths than three (the reference's `ndims` per branch, ensemble.py:325-329) and a
+# likelihood that is a plain Python function (oracle/eryn_oracle_rj.py) - the device library's hens_rj_set_model_general.
+# name -> (branch names, boxes, starting leaves per branch, the likelihood's name in oracle/eryn_oracle_rj.py, the data's signal)
+GENERAL_MODELS = {
+    "ramp_burst": (["ramp", "burst"],
+                   [[(-1.0, 1.0), (-2.0, 2.0)], [(0.5, 3.0), (-1.0, 1.0), (0.05, 0.5), (1.0, 8.0)]],
+                   [np.array([[0.3, -0.8], [-0.2, 0.5], [0.1, 0.2]]),
+                    np.array([[2.0, -0.3, 0.2, 3.0], [1.2, 0.4, 0.1, 6.0], [0.9, 0.0, 0.3, 2.0]])],
+                   "ramp_burst_log_like",
+                   lambda t: 0.3 - 0.8 * t + 2.0 * np.exp(-(((t + 0.3) / 0.2) ** 2)) * np.cos(2 * np.pi * 3.0 * (t + 0.3))),
+    "offset": (["offset"], [[(-3.0, 3.0)]], [np.array([[0.7], [-0.4], [0.2], [1.1]])], "offset_log_like", lambda t: 0.3 + 0.0 * t),
+}
+
+
 def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=1e-4, n_init=(2, 1),
             seed_data=42, seed_construct=135, seed_run=246, rj_moves="separate_branches", in_model="gaussian", init_spread=1e-4,
             model="template"):
     """in_model: "gaussian" - GaussianMove on the packed leaves; "stretch" - the red / blue StretchMove over EVERY branch and leaf
     slot of a walker (stretch.py:160-231: one complement draw per branch, one zz per walker; red_blue.py:103-330).  rj_moves None:
     no reversible jump (the leaf masks stay as they start)."""
+    if model in GENERAL_MODELS:
+        return capture_general(name, T, W, nl_max, nl_min, nsteps, ndata, sigma, cov_factor, n_init, seed_data, seed_construct, seed_run,
+                               rj_moves, in_model, init_spread, model)
     branch_names = ["gauss", "sine"]
     ndims = {"gauss": 3, "sine": 3}
     nleaves_max = dict(zip(branch_names, nl_max))
@@ -65,6 +82,38 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
     priors = {"gauss": {i: uniform_dist(*GAUSS_BOX[i]) for i in range(3)},
               "sine": {i: uniform_dist(*SINE_BOX[i]) for i in range(3)}}
     cov = {k: np.diag(np.ones(3)) * cov_factor for k in branch_names}
+    boxes = None
+    return run_capture(name, T, W, nl_max, nl_min, nsteps, ndata, sigma, cov_factor, seed_construct, seed_run, rj_moves, in_model, model,
+                       branch_names, ndims, nleaves_max, nleaves_min, t, y, coords, inds, priors, cov, boxes)
+
+
+def capture_general(name, T, W, nl_max, nl_min, nsteps, ndata, sigma, cov_factor, n_init, seed_data, seed_construct, seed_run, rj_moves,
+                    in_model, init_spread, model):
+    """The same capture for a GENERAL_MODELS entry: branches of 1 .. 4 parameters per leaf, the likelihood a Python function."""
+    branch_names, boxes, inj, like_name, signal = GENERAL_MODELS[model]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import oracle.eryn_oracle_rj as orj_
+    like = getattr(orj_, like_name)
+    ndims = {k: len(bx) for k, bx in zip(branch_names, boxes)}
+    nleaves_max = dict(zip(branch_names, nl_max))
+    nleaves_min = dict(zip(branch_names, nl_min))
+    t = np.linspace(-1, 1, ndata)
+    rs = np.random.RandomState(seed_data)
+    y = signal(t) + sigma * rs.randn(ndata)
+    coords = {k: np.zeros((T, W, nleaves_max[k], ndims[k])) for k in branch_names}
+    inds = {k: np.zeros((T, W, nleaves_max[k]), dtype=bool) for k in branch_names}
+    for bi, k in enumerate(branch_names):
+        for nn in range(n_init[bi]):
+            coords[k][:, :, nn] = rs.multivariate_normal(inj[bi][nn], np.diag(np.ones(ndims[k]) * init_spread), size=(T, W))
+            inds[k][:, :, nn] = True
+    priors = {k: {i: uniform_dist(*boxes[bi][i]) for i in range(ndims[k])} for bi, k in enumerate(branch_names)}
+    cov = {k: np.diag(np.ones(ndims[k])) * cov_factor for k in branch_names}
+    return run_capture(name, T, W, nl_max, nl_min, nsteps, ndata, sigma, cov_factor, seed_construct, seed_run, rj_moves, in_model, model,
+                       branch_names, ndims, nleaves_max, nleaves_min, t, y, coords, inds, priors, cov, boxes, like=like)
+
+
+def run_capture(name, T, W, nl_max, nl_min, nsteps, ndata, sigma, cov_factor, seed_construct, seed_run, rj_moves, in_model, model,
+                branch_names, ndims, nleaves_max, nleaves_min, t, y, coords, inds, priors, cov, boxes, like=None):
 
     np.random.seed(seed_construct)          # R := snapshot of G at construction (ensemble.py:604,651-652)
     import warnings
@@ -72,12 +121,12 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
         warnings.simplefilter("ignore")     # (ensemble.py:509-514: the reference advises against the stretch move under RJ - and runs it)
         # model "lorentz_chirp" (round 6): a likelihood the device library has no kernel for - oracle/eryn_oracle_rj.py's
         # lorentz_chirp_log_like, the function the -m gpu test hands to RJEnsembleSampler as the user's callable
-        like = log_like_fn_gauss_and_sine
+        like = log_like_fn_gauss_and_sine if like is None else like
         if model == "lorentz_chirp":
             sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)) if os.path.isdir(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle")) else "/root/repo")
             from oracle.eryn_oracle_rj import lorentz_chirp_log_like as like
         s = EnsembleSampler(W, ndims, like, priors, args=[t, y, sigma],
-                            tempering_kwargs=dict(ntemps=T), nbranches=2, branch_names=branch_names,
+                            tempering_kwargs=dict(ntemps=T), nbranches=len(branch_names), branch_names=branch_names,
                             nleaves_max=nleaves_max, nleaves_min=nleaves_min,
                             moves=GaussianMove(cov) if in_model == "gaussian" else StretchMove(),
                             **({} if rj_moves is None else dict(rj_moves=rj_moves)))
@@ -87,8 +136,14 @@ def capture(name, T, W, nl_max, nl_min, nsteps, ndata=40, sigma=2.0, cov_factor=
 
     out = dict(T=T, W=W, ndata=ndata, sigma=float(sigma), nsteps=nsteps, t=t, y=y, nl_max=np.array(nl_max),
                nl_min=np.array(nl_min), cov_factor=float(cov_factor), seed_construct=seed_construct, seed_run=seed_run,
-               gauss_box=np.array(GAUSS_BOX), sine_box=np.array(SINE_BOX), betas0=np.array(s.temperature_control.betas),
+               betas0=np.array(s.temperature_control.betas),
                L0=logl0, P0=logp0, rj_moves="none" if rj_moves is None else rj_moves, in_model=in_model)
+    if boxes is None:
+        out.update(gauss_box=np.array(GAUSS_BOX), sine_box=np.array(SINE_BOX))
+    else:
+        out["branch_names"] = np.array(branch_names)
+        for k, bx in zip(branch_names, boxes):
+            out[f"{k}_box"] = np.array(bx)
     if model != "template":
         out["model"] = model
     for k in branch_names:
@@ -180,3 +235,13 @@ if __name__ == "__main__":
             seed_run=414, init_spread=4e-4)
     capture("rjh4_callable_iterate", T=3, W=8, nl_max=(4, 3), nl_min=(0, 1), nsteps=12, model="lorentz_chirp", cov_factor=1e-3,
             seed_run=415, rj_moves="iterate_branches")
+    # ... and branches of OTHER leaf widths than three (ndims = {ramp: 2, burst: 4}; one branch of one-parameter leaves):
+    # separate_branches, "together" with a leaf floor, the stretch move over slots of different widths, "iterate_branches"
+    capture("rjn1_widths_2_4", T=3, W=8, nl_max=(3, 3), nl_min=(0, 0), nsteps=16, model="ramp_burst", cov_factor=1e-3, seed_run=511,
+            sigma=0.5, n_init=(1, 2))
+    capture("rjn2_widths_together", T=3, W=8, nl_max=(2, 4), nl_min=(1, 0), nsteps=16, model="ramp_burst", cov_factor=1e-3, seed_run=512,
+            sigma=3.0, n_init=(1, 1), rj_moves="together")
+    capture("rjn3_widths_stretch", T=2, W=48, nl_max=(3, 3), nl_min=(0, 0), nsteps=8, model="ramp_burst", in_model="stretch", seed_run=513,
+            sigma=0.5, n_init=(1, 2), init_spread=1e-4)
+    capture("rjn4_width_1_iterate", T=3, W=8, nl_max=(6,), nl_min=(1,), nsteps=14, model="offset", cov_factor=4e-3, seed_run=514,
+            sigma=0.5, n_init=(2,), rj_moves="iterate_branches")

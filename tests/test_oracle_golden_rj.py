@@ -19,6 +19,10 @@ NAMES_STRETCH = ["rjs1_stretch_fixed_leaves", "rjs2_stretch_with_rj"]
 # round 6: the likelihood is a plain Python function of the packed active leaves (oracle/eryn_oracle_rj.py: lorentz_chirp_log_like),
 # not the template model - separate_branches, "together" with a leaf floor, the stretch move as the in-model move, "iterate_branches"
 NAMES_CALLABLE = ["rjh1_callable", "rjh2_callable_together", "rjh3_callable_stretch", "rjh4_callable_iterate"]
+# ... over branches of OTHER leaf widths than three (ndims = {ramp: 2, burst: 4}; one branch of one-parameter leaves, where the reference
+# hands the function the leaves themselves instead of a list over the branches)
+NAMES_WIDTHS = ["rjn1_widths_2_4", "rjn2_widths_together", "rjn3_widths_stretch", "rjn4_width_1_iterate"]
+LIKES = {"lorentz_chirp": "lorentz_chirp_log_like", "ramp_burst": "ramp_burst_log_like", "offset": "offset_log_like"}
 
 
 def load_rj(golden_dir, name):
@@ -27,9 +31,13 @@ def load_rj(golden_dir, name):
 
 
 def make_rj_oracle(fx, record=False):
-    cov = np.diag(np.ones(3)) * float(fx["cov_factor"])
-    branches = [orj.Branch("gauss", orj.KIND_PULSE, fx["gauss_box"], int(fx["nl_max"][0]), int(fx["nl_min"][0]), cov),
-                orj.Branch("sine", orj.KIND_SINE, fx["sine_box"], int(fx["nl_max"][1]), int(fx["nl_min"][1]), cov)]
+    if "branch_names" in fx:                                   # (a model of general leaf widths: the boxes say how wide)
+        branches = [orj.Branch(str(k), orj.KIND_PULSE, fx[f"{k}_box"], int(fx["nl_max"][i]), int(fx["nl_min"][i]),
+                               np.diag(np.ones(len(fx[f"{k}_box"]))) * float(fx["cov_factor"])) for i, k in enumerate(fx["branch_names"])]
+    else:
+        cov = np.diag(np.ones(3)) * float(fx["cov_factor"])
+        branches = [orj.Branch("gauss", orj.KIND_PULSE, fx["gauss_box"], int(fx["nl_max"][0]), int(fx["nl_min"][0]), cov),
+                    orj.Branch("sine", orj.KIND_SINE, fx["sine_box"], int(fx["nl_max"][1]), int(fx["nl_min"][1]), cov)]
     R = np.random.RandomState(int(fx["seed_construct"]))      # R := snapshot of the global stream at construction
     G = np.random.RandomState(int(fx["seed_run"]))
     x0 = {b.name: fx[f"x0_{b.name}"] for b in branches}
@@ -37,10 +45,10 @@ def make_rj_oracle(fx, record=False):
     return orj.OracleRJSampler(branches, x0, inds0, fx["t"], fx["y"], float(fx["sigma"]), R, G, fx["betas0"],
                                record=record, schedule=str(fx["rj_moves"]) if "rj_moves" in fx else "separate_branches",
                                in_model=str(fx["in_model"]) if "in_model" in fx else "gaussian",
-                               like_fn=orj.lorentz_chirp_log_like if "model" in fx and str(fx["model"]) == "lorentz_chirp" else None)
+                               like_fn=getattr(orj, LIKES[str(fx["model"])]) if "model" in fx else None)
 
 
-@pytest.mark.parametrize("name", NAMES_ALL + NAMES_STRETCH + NAMES_CALLABLE)
+@pytest.mark.parametrize("name", NAMES_ALL + NAMES_STRETCH + NAMES_CALLABLE + NAMES_WIDTHS)
 def test_rj_oracle_reproduces_the_reference(golden_dir, name):
     fx = load_rj(golden_dir, name)
     o = make_rj_oracle(fx)

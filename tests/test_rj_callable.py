@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from oracle import eryn_oracle_rj as orj
-from tests.test_oracle_golden_rj import NAMES_CALLABLE, load_rj
+from tests.test_oracle_golden_rj import LIKES, NAMES_CALLABLE, NAMES_WIDTHS, load_rj
 
 REF = "/root/reference/src"
 
@@ -143,6 +143,89 @@ def test_rj_sampler_with_a_python_likelihood_reproduces_the_reference_chain(gold
     for k in names:
         assert np.array_equal(mid.branches[k].inds, fx[f"it{n // 2}_{'mh' if rj is None else 'rj'}_inds_{k}"])
     s.engine.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES_WIDTHS)
+def test_rj_sampler_over_branches_of_other_leaf_widths_reproduces_the_reference_chain(golden_dir, name):
+    """The reference's ``ndims`` per branch (ensemble.py:325-329): leaves of two and four parameters side by side, and one branch of
+    one-parameter leaves (hens_rj_set_model_general: 1 .. 4 box-prior parameters per leaf, the likelihood the caller's function) -
+    separate_branches, "together" with a leaf floor, the stretch move over slots of different widths, "iterate_branches".  From the
+    reference's two seeds the chain is the reference's: masks, every slot's coordinates, log-prior and log-likelihood bit for bit."""
+    from eryn_amd.prior import uniform_dist
+    from eryn_amd.rj import GaussianLeafMove, RJEnsembleSampler, StretchLeafMove
+    from eryn_amd.state import State
+    fx = load_rj(golden_dir, name)
+    names = [str(k) for k in fx["branch_names"]]
+    ndims = {k: len(fx[f"{k}_box"]) for k in names}
+    n = int(fx["nsteps"])
+    rj = None if str(fx["rj_moves"]) == "none" else str(fx["rj_moves"])
+    priors = {k: {i: uniform_dist(*fx[f"{k}_box"][i]) for i in range(ndims[k])} for k in names}
+    move = StretchLeafMove() if str(fx["in_model"]) == "stretch" else GaussianLeafMove({k: np.eye(ndims[k]) * float(fx["cov_factor"]) for k in names})
+    like = getattr(orj, LIKES[str(fx["model"])])
+    calls = []
+
+    def user_fn(x, t, y, sigma):
+        calls.append(1)
+        return like(x, t, y, sigma)
+
+    np.random.seed(int(fx["seed_construct"]))
+    s = RJEnsembleSampler(int(fx["W"]), ndims, user_fn, priors, args=[fx["t"], fx["y"], float(fx["sigma"])],
+                          tempering_kwargs=dict(ntemps=int(fx["T"])), nbranches=len(names), branch_names=names,
+                          nleaves_max=dict(zip(names, map(int, fx["nl_max"]))), nleaves_min=dict(zip(names, map(int, fx["nl_min"]))),
+                          moves=move, rj_moves=rj)
+    assert s.engine.general and s.engine.ndmax == max(ndims.values())
+    coords = {k: fx[f"x0_{k}"] for k in names}
+    inds = {k: fx[f"inds0_{k}"] for k in names}
+    L0, P0 = s._eval(coords, inds)                     # (hens_eval_state on a model without a device likelihood + the user's function)
+    assert np.array_equal(P0, fx["P0"]) and np.array_equal(L0, fx["L0"])
+    np.random.seed(int(fx["seed_run"]))
+    last = s.run_mcmc(State(coords, log_like=fx["L0"], log_prior=fx["P0"], inds=inds), n, store=True)
+    assert len(calls) > 0
+    pre = f"it{n - 1}_{'mh' if rj is None else 'rj'}_"
+    for k in names:
+        assert np.array_equal(last.branches[k].inds, fx[pre + f"inds_{k}"]), f"inds of {k}"
+        assert np.array_equal(last.branches[k].coords, fx[pre + f"x_{k}"]), f"coordinates of {k}"
+    assert np.array_equal(last.log_prior, fx[pre + "P"])
+    assert np.array_equal(last.log_like, fx[pre + "L"])
+    np.testing.assert_allclose(last.betas, fx[pre + "betas"], rtol=1e-13, atol=0)
+    assert np.array_equal(s.moves[0].accepted, fx["mh_accepted_total"])
+    if rj is not None:
+        assert np.array_equal(np.stack(s.rj_accepted), fx["rj_accepted_total"])
+        assert fx["rj_accepted_total"].sum() > 0
+    for it in range(n):                                # every stored step, not only the last
+        st = s.chain[it]
+        for k in names:
+            assert np.array_equal(st.branches[k].inds, fx[f"it{it}_{'mh' if rj is None else 'rj'}_inds_{k}"]), (it, k)
+    # the device paths that need a likelihood on the device refuse this model
+    with pytest.raises(RuntimeError):
+        s.engine.step(1)
+    s.engine.close()
+
+
+@pytest.mark.gpu
+def test_general_leaf_widths_are_validated():
+    from eryn_amd.rj import LeafBranch, RJEngine
+    with pytest.raises(NotImplementedError):
+        LeafBranch("five", [(0, 1)] * 5, 2)
+    with pytest.raises(NotImplementedError):                # 33 x 4 coordinates + 1 mask > 128 record doubles
+        RJEngine(2, 16, [LeafBranch("wide", [(0, 1)] * 4, 32), LeafBranch("more", [(0, 1)] * 1, 2)], None, None, 1.0)
+    e = RJEngine(2, 32, [LeafBranch("a", [(0, 1), (0, 2)], 3), LeafBranch("b", [(-1, 1)], 5, 1)], None, None, 1.0)
+    assert e.general and e.ncoord == 11 and e.RW == 14 and e.ndmax == 2
+    x = {"a": np.random.RandomState(0).rand(2, 32, 3, 2), "b": np.random.RandomState(1).rand(2, 32, 5, 1) * 2 - 1}
+    inds = {"a": np.random.RandomState(2).rand(2, 32, 3) < 0.5, "b": np.random.RandomState(3).rand(2, 32, 5) < 0.5}
+    x["a"][1, 4, 0, 1] = 2.5                                # outside its box
+    inds["a"][1, 4, 0] = True
+    e.upload(x, inds, betas=np.array([1.0, 0.5]))
+    e.eng.eval_state()
+    xd, id_, L, P, _ = e.download()
+    assert all(np.array_equal(xd[k], x[k]) and np.array_equal(id_[k], inds[k]) for k in x)
+    want = inds["a"].sum(-1) * np.log(1 / 1.0 / 2.0) + inds["b"].sum(-1) * np.log(1 / 2.0)
+    assert np.isneginf(P[1, 4])
+    m = np.ones_like(P, dtype=bool)
+    m[1, 4] = False
+    np.testing.assert_allclose(P[m], want[m], rtol=1e-15, atol=1e-15)
+    e.close()
 
 
 @pytest.mark.gpu
