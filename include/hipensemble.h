@@ -456,7 +456,7 @@ int hens_rj_debug_draws(hens_ctx* ctx, int64_t iter, double* step, double* u_mh,
 int hens_rj_set_schedule(hens_ctx* ctx, int32_t schedule);
 
 /* Parity-mode birth / death over ALL branches in one proposal ("together"): change / leaf [nbranches][Tl][W],
- * birth [nbranches][Tl][W][3], ONE u_acc [Tl][W] (rj.py:145-388 with gibbs_sampling_setup = None). */
+ * birth [nbranches][Tl][W][3 - max(ndims) on a hens_rj_set_model_general context], ONE u_acc [Tl][W] (rj.py:145-388 with gibbs_sampling_setup = None). */
 int hens_rj_bd_all_step(hens_ctx* ctx, const int8_t* change, const int32_t* leaf, const double* birth, const double* u_acc,
                         uint8_t* keep_out);
 
