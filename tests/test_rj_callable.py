@@ -5,7 +5,8 @@ CPU: ``eryn_amd.rj.CallableLikelihood`` packs the active leaves and calls the us
 per group and vectorised with group ids - and against the pinned oracle everywhere.
 GPU (-m gpu): ``RJEnsembleSampler(log_like_fn=<python function>)`` - the device proposes, computes the prior, tests and updates
 (hens_rj_propose / hens_rj_accept), the host evaluates - lands on the chains the reference produced with the same function and
-seeds (fixtures rjh1 / rjh2 / rjh3: separate_branches, "together" with a leaf floor, the stretch move as the in-model move)."""
+seeds (fixtures rjh1 - rjh4: separate_branches, "together" with a leaf floor, the stretch move as the in-model move, "iterate_branches";
+rjn1 - rjn4: the same over branches of 1, 2 and 4 parameters per leaf, hens_rj_set_model_general)."""
 import os
 import sys
 import types
