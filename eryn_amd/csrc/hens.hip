@@ -486,7 +486,15 @@ int launch_stretch_like(hens_ctx_impl* c, int like, int mode, StretchArgs a, int
             // (cnt_push == 1 - the delayed schedule's push through k_stretch_fast's count-reduction machinery: here the publishing wave's,
             //  cnt_push = 3, same rows, same mailbox words and flag)
             const bool push_ok = a.cnt_push != 1 || (a.cp_zero && a.cp_rows != c->swap_part);
-            const bool pipe_ok = !pipe || (!off_pipe && c->pipe.fused && a.ghome && !a.pub_lp && push_ok && a.inject_c64 <= 0);
+            // Not where the launch waits for OTHER ranks' swap counts (the reference's adaptation schedule on more than one rank): a
+            // persistent workgroup that starts its first tile late ends late by as much, and the lead workgroup waits for those counts in
+            // front of its first tile - the whole lateness of the slowest rank's counts would land on the launch's end, where
+            // k_stretch_fast's rounds of workgroups absorb 6.5 us of it (the last workgroups go to whichever slot frees first;
+            // DESIGN 6.1, profiles/r05_pipe_slack_*).  A lone rank, the delayed schedule (the counts it needs arrived a sweep ago) and
+            // launches without a pending adaptation have no such wait.  HENS_TILE2_PIPE_WAITS=1 (tests): everywhere.
+            static const bool with_waits = getenv("HENS_TILE2_PIPE_WAITS") != nullptr;
+            const bool wait_ok = with_waits || (a.wmask >> PF_CNT0) == 0ull || a.wtarget_cnt < c->pipe.sweep;      // (counts of an EARLIER sweep: there)
+            const bool pipe_ok = !pipe || (!off_pipe && c->pipe.fused && a.ghome && !a.pub_lp && push_ok && a.inject_c64 <= 0 && wait_ok);
             const void* k2 = (!off && mode == MODE_STRETCH && pipe_ok && !per && a.inplace && a.col && a.wrec && a.ikeys && a.ns_x == 0 && !a.trace &&
                               ad_ok) ? ktab_stretch2(like, c->D, pipe) : nullptr;
             int tp = 0;                  // (the kernel walks TWO tiles per workgroup; grids beyond 1 024 tiles run as rounds of pairs)

@@ -86,6 +86,7 @@ def _tile2_env(model="gauss", late=False, delay=0):
     env = _env(model=model, delay=delay)
     env["HENS_TILE2_FORCE"] = "1"
     env["HENS_TILE2_LOG"] = "1"
+    env["HENS_TILE2_PIPE_WAITS"] = "1"      # (also where the launch waits for other ranks' counts: by default those keep k_stretch_fast<PIPE>)
     env.pop("HENS_NO_TILE2", None)
     env.pop("HENS_NO_TILE2_PIPE", None)
     if late:
@@ -140,6 +141,24 @@ def test_pipeline_ranks_with_the_persistent_pipelined_first_launch_delayed_sched
     assert "k_stretch2<pipe=1>" in r.stderr and "cnt_push 3" in r.stderr, r.stderr[-2000:]
     _compare(ref, np.load(out))
     assert ref["swaps_total"].sum() > 0 and ref["accepted"].sum() > 0
+
+
+@pytest.mark.parametrize("delay,expect", [(0, False), (1, True)])
+def test_ranks_that_wait_for_other_ranks_counts_keep_the_rounds_of_workgroups(tmp_path, delay, expect):
+    """Which kernel a rank's first launch goes to when nothing forces it (only the grid: HENS_TILE2_FORCE): on the reference's
+    adaptation schedule with more than one rank the launch waits for the OTHER ranks' swap counts, and a persistent workgroup that
+    starts late ends late - those launches keep k_stretch_fast<PIPE>, whose rounds of workgroups absorb 6.5 us of lateness; on the
+    delayed schedule (the counts it needs arrived a sweep ago) the ranks take k_stretch2<PIPE>."""
+    env = _tile2_env(delay=delay)
+    env.pop("HENS_TILE2_PIPE_WAITS")
+    out = tmp_path / "local.npz"
+    r = subprocess.run([sys.executable, WORKER, "local", "2", "8", "512", "64", "8", str(out)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stderr.splitlines() if "k_stretch2<pipe=1>" in ln]
+    if expect:
+        assert any("ad_on 2" in ln for ln in lines), r.stderr[-2000:]
+    else:        # (the first launches of a run carry no adaptation yet: those may go to k_stretch2; none with the lead's chain does)
+        assert not any("ad_on 2" in ln for ln in lines), "\n".join(lines)
 
 
 def test_pipeline_ipc_processes_with_the_persistent_pipelined_first_launch(tmp_path):
